@@ -1,0 +1,193 @@
+"""ctypes front-ends for the CHECKERS under oracle/ -- test infrastructure, not product code.
+
+* ``BpOracle``  -> oracle/libbp_oracle.so  (C restatement of bp.hpp:192-325, oracle/bp_oracle.c)
+* ``RefBp``     -> oracle/_ref/libref_bp.so (the real reference headers behind oracle/ref_harness.cpp;
+  exists only where /root/reference was present at build time, or where the prebuilt .so travelled)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this module.
+Nothing under ``ldpc_amd/`` does (tests/test_layout.py enforces it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libbp_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libref_bp.so")
+REFERENCE_ROOT = "/root/reference"
+
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(ref: bool | None = None) -> None:
+    """(Re)build the checker libraries with oracle/Makefile; ``ref`` defaults to 'if the reference is here'."""
+    targets = ["all"]
+    if ref is None:
+        ref = os.path.isdir(os.path.join(REFERENCE_ROOT, "src_cpp"))
+    if ref:
+        targets.append("ref")
+    subprocess.run(["make", "-C", _HERE, *targets], check=True, capture_output=True)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def csr_arrays(h):
+    """(m, n, row_ptr int32, col_idx int32) of a binary matrix, columns sorted in each row."""
+    h = sp.csr_matrix(h)
+    h = h.copy()
+    h.eliminate_zeros()
+    h.sum_duplicates()
+    h.sort_indices()
+    m, n = h.shape
+    return m, n, np.ascontiguousarray(h.indptr, np.int32), np.ascontiguousarray(h.indices, np.int32)
+
+
+def _method_id(bp_method) -> int:
+    s = str(bp_method).lower()
+    if s in ("product_sum", "ps", "0", "prod_sum"):
+        return 0
+    if s in ("minimum_sum", "ms", "1", "min_sum"):
+        return 1
+    raise ValueError(bp_method)
+
+
+def _probs(n, error_rate=None, error_channel=None):
+    if error_channel is not None:
+        p = np.ascontiguousarray(error_channel, np.float64)
+        assert p.shape == (n,)
+        return p
+    return np.full(n, float(error_rate), np.float64)
+
+
+class _OracleLib:
+    _lib = None
+
+    @classmethod
+    def get(cls):
+        if cls._lib is None:
+            if not os.path.exists(ORACLE_SO):
+                build(ref=False)
+            lib = C.CDLL(ORACLE_SO)
+            lib.bp_oracle_new.restype = C.c_void_p
+            lib.bp_oracle_new.argtypes = [C.c_int, C.c_int, _i32p, _i32p]
+            lib.bp_oracle_free.argtypes = [C.c_void_p]
+            lib.bp_oracle_decode_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, _u8p, C.c_int64, _u8p,
+                C.c_void_p, _i32p, _u8p]
+            lib.oracle_gen_bsc_syndromes.argtypes = [
+                C.c_int, C.c_int, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
+                _u8p, C.c_void_p]
+            lib.oracle_sm64.restype = C.c_uint64
+            lib.oracle_sm64.argtypes = [C.c_uint64, C.c_uint64]
+            cls._lib = lib
+        return cls._lib
+
+
+class BpOracle:
+    """CPU restatement of the reference's parallel-schedule BP (one syndrome at a time)."""
+
+    def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum",
+                 ms_scaling_factor=1.0):
+        self.lib = _OracleLib.get()
+        self.m, self.n, self.row_ptr, self.col_idx = csr_arrays(h)
+        self.channel_probs = _probs(self.n, error_rate, error_channel)
+        self.max_iter = int(max_iter) if max_iter else self.n  # _bp_decoder.pyx:357
+        self.method = _method_id(bp_method)
+        self.alpha = float(ms_scaling_factor)
+        self._h = self.lib.bp_oracle_new(self.m, self.n, self.row_ptr, self.col_idx)
+        if not self._h:
+            raise ValueError("bad CSR input")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.bp_oracle_free(self._h)
+            self._h = None
+
+    def decode_batch(self, syndromes, want_llr=True):
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        if s.ndim == 1:
+            s = s[None, :]
+        assert s.shape[1] == self.m
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.bp_oracle_decode_batch(
+            self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b, dec,
+            llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def gen_bsc_syndromes(self, seed, p, shot0, shots, want_errors=False):
+        from ldpc_amd.prng import bernoulli_threshold
+        synd = np.zeros((shots, self.m), np.uint8)
+        err = np.zeros((shots, self.n), np.uint8) if want_errors else None
+        self.lib.oracle_gen_bsc_syndromes(
+            self.m, self.n, self.row_ptr, self.col_idx, seed, bernoulli_threshold(p), shot0, shots,
+            synd, err.ctypes.data if want_errors else None)
+        return (synd, err) if want_errors else synd
+
+
+class RefBp:
+    """The real reference ``ldpc::bp::BpDecoder`` (bp.hpp:51-666) behind oracle/ref_harness.cpp."""
+
+    SCHEDULE = {"serial": 0, "parallel": 1, "serial_relative": 2}  # bp.hpp:28-32
+    INPUT = {"syndrome": 0, "received_vector": 1, "auto": 2}  # bp.hpp:34-38
+
+    def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum",
+                 ms_scaling_factor=1.0, schedule="parallel", input_vector_type="syndrome"):
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
+        lib = C.CDLL(REF_SO)
+        lib.ref_bp_new.restype = C.c_void_p
+        lib.ref_bp_new.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int,
+                                   C.c_int, C.c_double, C.c_int]
+        lib.ref_bp_free.argtypes = [C.c_void_p]
+        lib.ref_bp_set_channel.argtypes = [C.c_void_p, _f64p]
+        lib.ref_bp_decode_batch.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int64, _u8p, C.c_void_p,
+                                            _i32p, _u8p]
+        lib.ref_bp_mulvec.argtypes = [C.c_void_p, _u8p, _u8p]
+        self.lib = lib
+        self.m, self.n, row_ptr, col_idx = csr_arrays(h)
+        rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32)
+        self.channel_probs = _probs(self.n, error_rate, error_channel)
+        self.max_iter = int(max_iter) if max_iter else self.n
+        self._h = lib.ref_bp_new(self.m, self.n, len(col_idx), np.ascontiguousarray(rows), col_idx,
+                                 self.channel_probs, self.max_iter, _method_id(bp_method),
+                                 self.SCHEDULE[schedule], float(ms_scaling_factor),
+                                 self.INPUT[input_vector_type])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.ref_bp_free(self._h)
+            self._h = None
+
+    def set_channel(self, probs):
+        self.channel_probs = np.ascontiguousarray(probs, np.float64)
+        self.lib.ref_bp_set_channel(self._h, self.channel_probs)
+
+    def decode_batch(self, inputs, want_llr=True):
+        s = np.ascontiguousarray(inputs, np.uint8)
+        if s.ndim == 1:
+            s = s[None, :]
+        b, ln = s.shape
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.ref_bp_decode_batch(self._h, s, ln, b, dec, llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def mulvec(self, v):
+        out = np.zeros(self.m, np.uint8)
+        self.lib.ref_bp_mulvec(self._h, np.ascontiguousarray(v, np.uint8), out)
+        return out

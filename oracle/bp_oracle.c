@@ -1,0 +1,223 @@
+/*
+ * oracle/bp_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's flooding-schedule belief propagation
+ * (ldpc::bp::BpDecoder::bp_decode_parallel, /root/reference/src_cpp/bp.hpp:192-325) on flat
+ * CSR/CSC arrays instead of the reference's doubly-linked-list matrix.  It performs the SAME
+ * floating-point operations in the SAME order as the reference (rows walked in ascending column
+ * order, columns in ascending row order -- sparse_matrix_base.hpp:423-482 keeps both sorted), so on
+ * one host/libm it must agree with the reference bit for bit, log-probability ratios included.
+ * tests/test_oracle_vs_ref.py checks exactly that against oracle/_ref (the real reference headers
+ * compiled here); tests/golden/ holds reference outputs the oracle is pinned to everywhere else.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
+ * The product path (ldpc_amd/csrc) never links or calls it.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -std=c11 -ffp-contract=off: the reference is built without
+ * FMA contraction -- setup.py:66-67 passes only -std=c++2a -O3).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BP_PRODUCT_SUM 0 /* bp.hpp:23-26 */
+#define BP_MINIMUM_SUM 1
+
+/* ---- SplitMix64 counter PRNG (twin of ldpc_amd/prng.py) -------------------------------------- */
+static inline uint64_t sm64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1u) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+uint64_t oracle_sm64(uint64_t seed, uint64_t idx) { return sm64(seed, idx); }
+
+/*
+ * Synthetic BSC batch: error bit (shot, j) = ((sm64(seed, shot*n + j) >> 11) < threshold), and
+ * syndrome = H e mod 2 (gf2sparse.hpp:177-214 mulvec; noise model of noise_models/bsc.py:4-23 with
+ * a counter-based stream).  errors may be NULL.
+ */
+void oracle_gen_bsc_syndromes(int m, int n, const int32_t *row_ptr, const int32_t *col_idx,
+                              uint64_t seed, uint64_t threshold, int64_t shot0, int64_t shots,
+                              uint8_t *syndromes, uint8_t *errors) {
+    for (int64_t b = 0; b < shots; b++) {
+        uint64_t base = (uint64_t)(shot0 + b) * (uint64_t)n;
+        for (int i = 0; i < m; i++) {
+            uint8_t s = 0;
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++)
+                s ^= (uint8_t)((sm64(seed, base + (uint64_t)col_idx[e]) >> 11) < threshold);
+            syndromes[b * m + i] = s;
+        }
+        if (errors)
+            for (int j = 0; j < n; j++)
+                errors[b * n + j] = (uint8_t)((sm64(seed, base + (uint64_t)j) >> 11) < threshold);
+    }
+}
+
+/* ---- decoder state --------------------------------------------------------------------------- */
+typedef struct {
+    int m, n, nnz;
+    int32_t *row_ptr, *col_idx; /* CSR, columns ascending inside a row  */
+    int32_t *col_ptr, *csc_edge, *csc_row; /* CSC: CSR edge id + row of each entry, rows ascending */
+    double *b2c, *c2b;          /* per CSR edge: BpEntry::bit_to_check_msg / check_to_bit_msg (bp.hpp:42-48) */
+    double *llr0;               /* initial_log_prob_ratios (bp.hpp:66) */
+    uint8_t *cand;              /* candidate_syndrome (bp.hpp:63) */
+} bp_oracle;
+
+void bp_oracle_free(bp_oracle *o) {
+    if (!o) return;
+    free(o->row_ptr); free(o->col_idx); free(o->col_ptr); free(o->csc_edge); free(o->csc_row);
+    free(o->b2c); free(o->c2b); free(o->llr0); free(o->cand); free(o);
+}
+
+/* CSR must have sorted, duplicate-free column indices in every row. Returns NULL on bad input. */
+bp_oracle *bp_oracle_new(int m, int n, const int32_t *row_ptr, const int32_t *col_idx) {
+    if (m < 0 || n < 0 || row_ptr[0] != 0) return NULL;
+    int nnz = row_ptr[m];
+    for (int i = 0; i < m; i++)
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+            if (col_idx[e] < 0 || col_idx[e] >= n) return NULL;
+            if (e > row_ptr[i] && col_idx[e] <= col_idx[e - 1]) return NULL;
+        }
+    bp_oracle *o = (bp_oracle *)calloc(1, sizeof *o);
+    o->m = m; o->n = n; o->nnz = nnz;
+    o->row_ptr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    o->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    o->col_ptr = (int32_t *)calloc((size_t)(n + 1), sizeof(int32_t));
+    o->csc_edge = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    o->csc_row = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    o->b2c = (double *)calloc((size_t)(nnz ? nnz : 1), sizeof(double));
+    o->c2b = (double *)calloc((size_t)(nnz ? nnz : 1), sizeof(double));
+    o->llr0 = (double *)calloc((size_t)(n ? n : 1), sizeof(double));
+    o->cand = (uint8_t *)calloc((size_t)(m ? m : 1), 1);
+    memcpy(o->row_ptr, row_ptr, sizeof(int32_t) * (size_t)(m + 1));
+    memcpy(o->col_idx, col_idx, sizeof(int32_t) * (size_t)nnz);
+    for (int e = 0; e < nnz; e++) o->col_ptr[col_idx[e] + 1]++;
+    for (int j = 0; j < n; j++) o->col_ptr[j + 1] += o->col_ptr[j];
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    memcpy(fill, o->col_ptr, sizeof(int32_t) * (size_t)n);
+    for (int i = 0; i < m; i++) /* ascending i => rows ascending inside each column */
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+            int p = fill[col_idx[e]]++;
+            o->csc_edge[p] = e;
+            o->csc_row[p] = i;
+        }
+    free(fill);
+    return o;
+}
+
+/*
+ * One decode of one syndrome: bp.hpp:192-325 (PARALLEL schedule), with initialise_log_domain_bp
+ * (bp.hpp:147-157) inlined.  Outputs mirror the members the Cython layer reads afterwards:
+ * decoding (bp.hpp:62), log_prob_ratios (bp.hpp:65), iterations (bp.hpp:69), converge (bp.hpp:71).
+ * If max_iter <= 0 the loop body never runs and the outputs are left untouched, as in the reference.
+ */
+void bp_oracle_decode(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                      double ms_scaling_factor, const uint8_t *syndrome, uint8_t *decoding,
+                      double *log_prob_ratios, int32_t *iterations, uint8_t *converge) {
+    const int m = o->m, n = o->n;
+    *converge = 0;
+
+    for (int j = 0; j < n; j++) { /* bp.hpp:149-156 */
+        o->llr0[j] = log((1 - channel_probs[j]) / channel_probs[j]);
+        for (int p = o->col_ptr[j]; p < o->col_ptr[j + 1]; p++) o->b2c[o->csc_edge[p]] = o->llr0[j];
+    }
+
+    for (int it = 1; it <= max_iter; it++) {
+        if (bp_method == BP_PRODUCT_SUM) { /* bp.hpp:201-219 */
+            for (int i = 0; i < m; i++) {
+                const int lo = o->row_ptr[i], hi = o->row_ptr[i + 1];
+                o->cand[i] = 0;
+                double temp = 1.0;
+                for (int e = lo; e < hi; e++) {
+                    o->c2b[e] = temp;
+                    temp *= tanh(o->b2c[e] / 2);
+                }
+                temp = 1;
+                for (int e = hi - 1; e >= lo; e--) {
+                    o->c2b[e] *= temp;
+                    int message_sign = syndrome[i] != 0u ? -1 : 1;
+                    o->c2b[e] = message_sign * log((1 + o->c2b[e]) / (1 - o->c2b[e]));
+                    temp *= tanh(o->b2c[e] / 2);
+                }
+            }
+        } else { /* bp.hpp:220-273 */
+            double alpha;
+            if (ms_scaling_factor == 0.0) alpha = 1.0 - pow(2.0, -1.0 * it);
+            else alpha = ms_scaling_factor;
+            for (int i = 0; i < m; i++) {
+                const int lo = o->row_ptr[i], hi = o->row_ptr[i + 1];
+                o->cand[i] = 0;
+                int total_sgn = syndrome[i];
+                double temp = DBL_MAX;
+                for (int e = lo; e < hi; e++) {
+                    if (o->b2c[e] <= 0) total_sgn += 1;
+                    o->c2b[e] = temp;
+                    double a = fabs(o->b2c[e]);
+                    if (a < temp) temp = a;
+                }
+                temp = DBL_MAX;
+                for (int e = hi - 1; e >= lo; e--) {
+                    int sgn = total_sgn;
+                    if (o->b2c[e] <= 0) sgn += 1;
+                    if (temp < o->c2b[e]) o->c2b[e] = temp;
+                    int message_sign = (sgn % 2 == 0) ? 1 : -1;
+                    o->c2b[e] *= message_sign * alpha;
+                    double a = fabs(o->b2c[e]);
+                    if (a < temp) temp = a;
+                }
+            }
+        }
+
+        for (int j = 0; j < n; j++) { /* bp.hpp:276-298 */
+            double temp = o->llr0[j];
+            for (int p = o->col_ptr[j]; p < o->col_ptr[j + 1]; p++) {
+                const int e = o->csc_edge[p];
+                o->b2c[e] = temp;
+                temp += o->c2b[e];
+            }
+            log_prob_ratios[j] = temp;
+            if (temp <= 0) {
+                decoding[j] = 1;
+                for (int p = o->col_ptr[j]; p < o->col_ptr[j + 1]; p++) o->cand[o->csc_row[p]] ^= 1;
+            } else {
+                decoding[j] = 0;
+            }
+        }
+
+        if (memcmp(o->cand, syndrome, (size_t)m) == 0) *converge = 1; /* bp.hpp:300-302 */
+        *iterations = it;
+        if (*converge) return;
+
+        for (int j = 0; j < n; j++) { /* bp.hpp:311-318 */
+            double temp = 0;
+            for (int p = o->col_ptr[j + 1] - 1; p >= o->col_ptr[j]; p--) {
+                const int e = o->csc_edge[p];
+                o->b2c[e] += temp;
+                temp += o->c2b[e];
+            }
+        }
+    }
+}
+
+/*
+ * Batch wrapper: rows of `syndromes` (shots x m) decoded one after another by the function above
+ * (what every caller of the reference does: `for shot: decoder.decode(shot)`).
+ * llr may be NULL.
+ */
+void bp_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                            double ms_scaling_factor, const uint8_t *syndromes, int64_t shots,
+                            uint8_t *decodings, double *llr, int32_t *iterations,
+                            uint8_t *converge) {
+    double *tmp = llr ? NULL : (double *)malloc(sizeof(double) * (size_t)(o->n ? o->n : 1));
+    for (int64_t b = 0; b < shots; b++) {
+        iterations[b] = 0;
+        bp_oracle_decode(o, channel_probs, max_iter, bp_method, ms_scaling_factor,
+                         syndromes + b * o->m, decodings + b * o->n,
+                         llr ? llr + b * o->n : tmp, iterations + b, converge + b);
+    }
+    free(tmp);
+}

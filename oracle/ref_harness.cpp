@@ -1,0 +1,81 @@
+/*
+ * oracle/ref_harness.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A thin extern "C" shim around the REAL reference decoder: it #includes the reference's own
+ * header-only sources from where they lie under /root/reference/src_cpp (nothing is copied into
+ * this repository) and exposes ldpc::bp::BpDecoder::decode through plain pointers so Python can
+ * call it with ctypes.  Built only in the build container by oracle/Makefile into
+ * oracle/_ref/libref_bp.so (git-ignored; the GPU box only ever sees the prebuilt .so).
+ *
+ * Used to (i) prove oracle/bp_oracle.c bit-exact and (ii) generate tests/golden/*.npz
+ * (tests/golden/make_golden.py).  `cstdint` must precede bp.hpp.
+ */
+#include <cstdint>
+#include <vector>
+#include <cstring>
+#include "bp.hpp"
+
+using ldpc::bp::BpDecoder;
+using ldpc::bp::BpSparse;
+
+struct ref_bp {
+    BpSparse *pcm;
+    BpDecoder *dec;
+};
+
+extern "C" {
+
+/* rows/cols: coordinates of the nnz ones of H, any order (insert_entry keeps lists sorted). */
+ref_bp *ref_bp_new(int m, int n, int nnz, const int32_t *rows, const int32_t *cols,
+                   const double *channel_probs, int max_iter, int bp_method, int schedule,
+                   double ms_scaling_factor, int input_type) {
+    auto *r = new ref_bp;
+    r->pcm = new BpSparse(m, n, nnz);
+    for (int k = 0; k < nnz; k++) r->pcm->insert_entry(rows[k], cols[k]);
+    std::vector<double> probs(channel_probs, channel_probs + n);
+    r->dec = new BpDecoder(*r->pcm, probs, max_iter, static_cast<ldpc::bp::BpMethod>(bp_method),
+                           static_cast<ldpc::bp::BpSchedule>(schedule), ms_scaling_factor, 1,
+                           ldpc::bp::NULL_INT_VECTOR, 0, false,
+                           static_cast<ldpc::bp::BpInputType>(input_type));
+    return r;
+}
+
+void ref_bp_free(ref_bp *r) {
+    if (!r) return;
+    delete r->dec;
+    delete r->pcm;
+    delete r;
+}
+
+void ref_bp_set_channel(ref_bp *r, const double *channel_probs) {
+    for (int j = 0; j < r->dec->bit_count; j++) r->dec->channel_probabilities[j] = channel_probs[j];
+}
+
+/* One BpDecoder::decode call (bp.hpp:159-190); `len` is m (syndrome) or n (received vector). */
+void ref_bp_decode(ref_bp *r, const uint8_t *input, int len, uint8_t *decoding, double *llr,
+                   int32_t *iterations, uint8_t *converge) {
+    std::vector<uint8_t> in(input, input + len);
+    r->dec->decode(in);
+    const int n = r->dec->bit_count;
+    std::memcpy(decoding, r->dec->decoding.data(), (size_t)n);
+    if (llr) std::memcpy(llr, r->dec->log_prob_ratios.data(), sizeof(double) * (size_t)n);
+    *iterations = r->dec->iterations;
+    *converge = r->dec->converge ? 1 : 0;
+}
+
+void ref_bp_decode_batch(ref_bp *r, const uint8_t *inputs, int len, int64_t shots,
+                         uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    const int n = r->dec->bit_count;
+    for (int64_t b = 0; b < shots; b++)
+        ref_bp_decode(r, inputs + b * len, len, decodings + b * n, llr ? llr + b * n : nullptr,
+                      iterations + b, converge + b);
+}
+
+/* GF2Sparse::mulvec (gf2sparse.hpp:177-214) */
+void ref_bp_mulvec(ref_bp *r, const uint8_t *in, uint8_t *out) {
+    std::vector<uint8_t> v(in, in + r->pcm->n);
+    auto s = r->pcm->mulvec(v);
+    std::memcpy(out, s.data(), (size_t)r->pcm->m);
+}
+
+} /* extern "C" */
