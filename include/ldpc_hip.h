@@ -1,0 +1,140 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip.so: batched flooding-schedule belief propagation on MI355X.
+ *
+ * This is the drop-in boundary for the one hot path of quantumgizmos/ldpc that this library
+ * replaces: ldpc.BpDecoder.decode (src_python/ldpc/bp_decoder/_bp_decoder.pyx:642-695) ->
+ * ldpc::bp::BpDecoder::decode (src_cpp/bp.hpp:159-190) -> bp_decode_parallel (bp.hpp:192-325),
+ * applied to a BATCH of independent syndromes.  The reference has no FFI for this path today (its
+ * Cython layer includes bp.hpp directly, _bp_decoder.pxd:9-83); these entry points are what a
+ * binding for a device decoder would bind, one per reference member it stands in for.
+ * INTEGRATION.md shows the Cython/ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (LDPC_HIP_OK) or a negative ldpc_hip_status;
+ *     ldpc_hip_last_error() returns a thread-local message for the last failure.  No exceptions
+ *     and no aborts cross this boundary (the reference's decode() is not `except +`,
+ *     _bp_decoder.pxd:78).
+ *   - the caller owns every buffer it passes; the library owns device memory, streams and events
+ *     inside the handle.  Data pointers may be host or device pointers (detected per call).
+ *   - a handle is single-consumer, like the reference object (its messages live inside H,
+ *     bp.hpp:42-48); distinct handles are independent.  One handle lives on one GPU.
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LDPC_HIP_OK = 0,
+    LDPC_HIP_ERR_INVALID = -1,  /* bad argument (shape, range, NULL) */
+    LDPC_HIP_ERR_DEVICE = -2,   /* HIP runtime error (message has hipGetErrorString) */
+    LDPC_HIP_ERR_NOMEM = -3,    /* workspace does not fit */
+    LDPC_HIP_ERR_UNSUPPORTED = -4
+} ldpc_hip_status;
+
+/* ldpc::bp::BpMethod, bp.hpp:23-26 */
+#define LDPC_HIP_PRODUCT_SUM 0
+#define LDPC_HIP_MINIMUM_SUM 1
+
+/*
+ * Decoder description = the arguments of ldpc::bp::BpDecoder::BpDecoder (bp.hpp:77-88) that
+ * the parallel schedule uses, with the parity-check matrix as CSR instead of a BpSparse&
+ * (Py2BpSparse, _bp_decoder.pyx:9-49, builds that from the same coordinates).
+ */
+typedef struct {
+    int32_t m;                    /* check_count  (bp.hpp:56) */
+    int32_t n;                    /* bit_count    (bp.hpp:57) */
+    int32_t nnz;                  /* = csr_row_ptr[m] */
+    const int32_t *csr_row_ptr;   /* [m+1], host */
+    const int32_t *csr_col_idx;   /* [nnz], host, strictly ascending inside each row */
+    const double *channel_probs;  /* [n], host: channel_probabilities (bp.hpp:55) */
+    int32_t max_iter;             /* maximum_iterations (bp.hpp:58), >= 1 */
+    int32_t bp_method;            /* LDPC_HIP_PRODUCT_SUM | LDPC_HIP_MINIMUM_SUM (bp.hpp:59) */
+    double ms_scaling_factor;     /* bp.hpp:61; 0.0 selects alpha = 1 - 2^-it (bp.hpp:222-228) */
+    int32_t device;               /* HIP device ordinal; -1 = current device */
+} ldpc_hip_bp_desc;
+
+typedef struct ldpc_hip_bp ldpc_hip_bp; /* opaque handle */
+
+/* replaces: BpDecoderBase.__cinit__ -> new BpDecoderCpp(...)  (_bp_decoder.pyx:118-132) */
+int ldpc_hip_bp_create(const ldpc_hip_bp_desc *desc, ldpc_hip_bp **out);
+
+/* replaces: BpDecoderBase.__dealloc__ (_bp_decoder.pyx:162-165) */
+void ldpc_hip_bp_destroy(ldpc_hip_bp *h);
+
+/* replaces: writes to bpd.channel_probabilities by the error_rate / error_channel setters and
+ * update_channel_probs (_bp_decoder.pyx:180-223).  Priors log((1-p)/p) (bp.hpp:150-151) are
+ * evaluated on the host in double precision and uploaded. */
+int ldpc_hip_bp_set_channel(ldpc_hip_bp *h, const double *channel_probs, int32_t n);
+
+/* replaces: the max_iter / bp_method / ms_scaling_factor setters (_bp_decoder.pyx:342-394,487-499) */
+int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method,
+                           double ms_scaling_factor);
+
+/* Launch stream (a hipStream_t) for decode calls; NULL selects the handle's own stream. */
+int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *hip_stream);
+
+/*
+ * replaces: BpDecoder.decode for `batch` syndromes at once (_bp_decoder.pyx:676-695 marshalling +
+ * bp.hpp:192-325).  Row b of every array belongs to syndrome b.
+ *
+ *   syndromes  [batch x m] uint8, C-contiguous       in   (bytes as the reference sees them: any
+ *                                                          non-zero byte flips the product-sum sign,
+ *                                                          min-sum uses the byte's parity, a byte > 1
+ *                                                          can never converge: bp.hpp:213,236,300)
+ *   decoding   [batch x n] uint8                      out  bpd.decoding          (bp.hpp:62)
+ *   llr        [batch x n] float64, or NULL           out  bpd.log_prob_ratios   (bp.hpp:65)
+ *   iterations [batch]     int32,  or NULL            out  bpd.iterations        (bp.hpp:69)
+ *   converge   [batch]     uint8,  or NULL            out  bpd.converge          (bp.hpp:71)
+ *
+ * Per-syndrome early exit is preserved: the outputs of row b are those of the first iteration whose
+ * hard decision reproduces syndrome b (bp.hpp:300-308), or of iteration max_iter.
+ * Synchronous with respect to the host: returns after the results are in the output buffers.
+ */
+int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                             uint8_t *decoding, double *llr, int32_t *iterations,
+                             uint8_t *converge);
+
+/* Same, but only enqueues on the launch stream; all pointers must be device pointers. */
+int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                                   uint8_t *decoding, double *llr, int32_t *iterations,
+                                   uint8_t *converge);
+
+/*
+ * replaces: GF2Sparse::mulvec (gf2sparse.hpp:177-214) over a batch:
+ * out[b][i] = XOR_{j in row i} in[b][j].  Used by received-vector mode (bp.hpp:162-180).
+ */
+int ldpc_hip_gf2_mulvec_batch(ldpc_hip_bp *h, const uint8_t *vectors, int64_t batch,
+                              uint8_t *out_syndromes);
+
+/*
+ * Synthetic input generator for benchmarks: independent BSC errors
+ * e[b][j] = ((splitmix64(seed, (shot0+b)*n + j) >> 11) < threshold)  (noise model of
+ * noise_models/bsc.py:4-23 with a counter-based stream) and syndromes = H e mod 2
+ * (mcs.py:124-126).  `errors` may be NULL.  Device or host output pointers.
+ */
+int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold, int64_t shot0,
+                               int64_t batch, uint8_t *syndromes, uint8_t *errors);
+
+/* Duration in milliseconds of the BP kernel launch of the last decode call on this handle,
+ * measured with HIP events on the launch stream (0 if none yet). */
+int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms);
+
+/* Bytes of device workspace a decode of `batch` syndromes needs (message arrays dominate:
+ * 2 * 8 * nnz bytes per syndrome). */
+int64_t ldpc_hip_bp_workspace_bytes(const ldpc_hip_bp *h, int64_t batch);
+
+/* Tuning knobs (0 = library default): waves per workgroup of the BP kernel. */
+int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t reserved);
+
+const char *ldpc_hip_last_error(void);
+const char *ldpc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */

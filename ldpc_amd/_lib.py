@@ -1,0 +1,77 @@
+"""ctypes binding of libldpc_hip.so (C ABI: include/ldpc_hip.h).
+
+There is exactly one compute path: the HIP library.  If it is missing or does not load, importing
+the decoder raises -- there is no CPU fallback (the CPU restatement under oracle/ is a test checker
+and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libldpc_hip.so")
+
+# every symbol include/ldpc_hip.h declares (tests/test_cabi_symbols.py checks header <-> library)
+SYMBOLS = (
+    "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
+    "ldpc_hip_bp_set_stream", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async",
+    "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
+    "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_last_error", "ldpc_hip_version",
+)
+
+
+class BpDesc(C.Structure):
+    """``ldpc_hip_bp_desc`` (include/ldpc_hip.h)."""
+    _fields_ = [
+        ("m", C.c_int32), ("n", C.c_int32), ("nnz", C.c_int32),
+        ("csr_row_ptr", C.POINTER(C.c_int32)), ("csr_col_idx", C.POINTER(C.c_int32)),
+        ("channel_probs", C.POINTER(C.c_double)),
+        ("max_iter", C.c_int32), ("bp_method", C.c_int32),
+        ("ms_scaling_factor", C.c_double), ("device", C.c_int32),
+    ]
+
+
+class LdpcHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libldpc_hip.so once; raise loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'  or  make -C ldpc_amd/csrc). "
+            "ldpc_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+    lib.ldpc_hip_bp_create.argtypes = [C.POINTER(BpDesc), C.POINTER(vp)]
+    lib.ldpc_hip_bp_destroy.argtypes = [vp]
+    lib.ldpc_hip_bp_destroy.restype = None
+    lib.ldpc_hip_bp_set_channel.argtypes = [vp, C.POINTER(dbl), i32]
+    lib.ldpc_hip_bp_set_params.argtypes = [vp, i32, i32, dbl]
+    lib.ldpc_hip_bp_set_stream.argtypes = [vp, vp]
+    lib.ldpc_hip_bp_decode_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    lib.ldpc_hip_bp_decode_batch_async.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    lib.ldpc_hip_gf2_mulvec_batch.argtypes = [vp, vp, i64, vp]
+    lib.ldpc_hip_gen_bsc_syndromes.argtypes = [vp, u64, u64, i64, i64, vp, vp]
+    lib.ldpc_hip_bp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ldpc_hip_bp_workspace_bytes.argtypes = [vp, i64]
+    lib.ldpc_hip_bp_workspace_bytes.restype = i64
+    lib.ldpc_hip_bp_set_tuning.argtypes = [vp, i32, i32]
+    lib.ldpc_hip_last_error.restype = C.c_char_p
+    lib.ldpc_hip_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().ldpc_hip_last_error().decode("utf-8", "replace")
+        raise LdpcHipError(f"libldpc_hip error {rc}: {msg}")

@@ -1,0 +1,478 @@
+"""Host-side mirror of the reference's ``BpDecoder`` (src_python/ldpc/bp_decoder/_bp_decoder.pyx).
+
+Same constructor keywords, property names, alias strings, exception types and messages as the
+reference, so code written against ``ldpc.BpDecoder`` runs unchanged; the arithmetic happens in
+libldpc_hip.so (HIP kernels for gfx950) behind ``ldpc_amd.engine.HipBpEngine``.  There is no CPU
+fallback: ``decode`` raises if the HIP library or a GPU is missing.
+
+Additions over the reference (it has no batch API): ``decode_batch`` and the
+``*_batch`` result views.
+
+Reference behaviours deliberately reproduced (each cited where implemented):
+  * effective defaults come from the base initialiser's ``kwargs.get`` (pyx:90-100), not from the
+    subclass signature: ``bp_method`` defaults to product_sum, ``max_iter=0`` means ``n``;
+  * an all-zero input returns zeros with ``converge=True`` WITHOUT running BP, leaving
+    ``log_prob_ratios`` / ``iter`` / ``decoding`` from the previous call (pyx:679-681, 688-690);
+  * the output array has the input's dtype (pyx:673, 693-695).
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional, Union
+
+import numpy as np
+import scipy.sparse
+
+from ldpc_amd.helpers.scipy_helpers import convert_to_binary_sparse
+
+# ldpc::bp enums (bp.hpp:23-38)
+PRODUCT_SUM, MINIMUM_SUM = 0, 1
+SERIAL, PARALLEL, SERIAL_RELATIVE = 0, 1, 2
+SYNDROME, RECEIVED_VECTOR, AUTO = 0, 1, 2
+
+_PS_ALIASES = ("prod_sum", "product_sum", "ps", "0", "prod sum")  # pyx:386
+_MS_ALIASES = ("min_sum", "minimum_sum", "ms", "1", "minimum sum", "min sum")  # pyx:388
+_UNSET = object()  # "keyword not passed by the caller"
+
+
+def _check_pcm_type(pcm):
+    if not isinstance(pcm, (np.ndarray, scipy.sparse.spmatrix)):  # pyx:17-21, 113-117
+        raise TypeError(f"The input matrix is of an invalid type. Please input\
+        a np.ndarray or scipy.sparse.spmatrix object, not {type(pcm)}")
+
+
+def _ingest(pcm) -> scipy.sparse.csr_matrix:
+    """Py2BpSparse (pyx:9-49): validate and return canonical CSR (sorted columns, ones only)."""
+    _check_pcm_type(pcm)
+    h = scipy.sparse.csr_matrix(convert_to_binary_sparse(pcm))
+    h.sum_duplicates()  # insert_entry returns the existing entry for a repeated coordinate
+    h.data[:] = 1       # (sparse_matrix_base.hpp:437-440), so duplicates collapse to a single one
+    h.sort_indices()
+    return h
+
+
+def io_test(pcm):
+    """Round-trip a matrix through the ingest path (reference ``io_test``, pyx:74-78)."""
+    return scipy.sparse.csr_matrix(_ingest(pcm), dtype=np.uint8)
+
+
+def _typed(name, value, types, type_name):
+    # the reference's Cython signature rejects wrongly typed arguments with TypeError before any
+    # setter runs (e.g. python_test/test_bp_decoder.py:143-168)
+    if value is not None and not isinstance(value, types):
+        raise TypeError(f"Argument '{name}' has incorrect type (expected {type_name}, got {type(value).__name__})")
+
+
+class BpDecoderBase:
+    """Parameter/validation surface shared by the BP decoder family (``cdef class BpDecoderBase``, pyx:82-579)."""
+
+    def __init__(self, pcm, **kwargs):
+        error_rate = kwargs.get("error_rate", None)  # pyx:90-100
+        error_channel = kwargs.get("error_channel", None)
+        max_iter = kwargs.get("max_iter", 0)
+        bp_method = kwargs.get("bp_method", 0)
+        ms_scaling_factor = kwargs.get("ms_scaling_factor", 1.0)
+        schedule = kwargs.get("schedule", 0)
+        omp_thread_count = kwargs.get("omp_thread_count", 1)
+        random_serial_schedule = kwargs.get("random_serial_schedule", False)
+        random_schedule_seed = kwargs.get("random_schedule_seed", 0)
+        serial_schedule_order = kwargs.get("serial_schedule_order", None)
+        channel_probs = kwargs.get("channel_probs", [None])
+
+        self._engine = None
+        self._engine_key = None
+        self._device = kwargs.get("_device", -1)
+
+        self._h = _ingest(pcm)
+        self.m, self.n = int(pcm.shape[0]), int(pcm.shape[1])
+
+        # state of the C++ object (`new BpDecoderCpp(...)`, pyx:132 / bp.hpp:77-132)
+        self._channel_probs = np.zeros(self.n, np.float64)
+        self._channel_dirty = True
+        self._max_iter = 0
+        self._bp_method = PRODUCT_SUM
+        self._schedule = PARALLEL
+        self._ms_scaling_factor = 1.0
+        self._omp_thread_count = 1
+        self._serial_schedule_order = np.arange(self.n, dtype=np.int64)  # bp.hpp:120-124
+        self._random_schedule_seed = 0
+        self._random_serial_schedule = False
+        self._bp_input_type = SYNDROME
+        self._decoding = np.zeros(self.n, np.uint8)
+        self._log_prob_ratios = np.zeros(self.n, np.float64)
+        self._iterations = 0
+        self._converge = False
+        # batch views (additive API)
+        self.converge_batch = None
+        self.iter_batch = None
+        self.log_prob_ratios_batch = None
+
+        self.bp_method = bp_method  # pyx:135-142
+        self.max_iter = max_iter
+        self.ms_scaling_factor = ms_scaling_factor
+        self.schedule = schedule
+        self.serial_schedule_order = serial_schedule_order
+        self.random_schedule_seed = random_schedule_seed
+        self.omp_thread_count = omp_thread_count
+        self.random_serial_schedule = random_serial_schedule
+
+        if isinstance(channel_probs, (list, np.ndarray)):  # ldpc_v1 compatibility, pyx:145-147
+            if len(channel_probs) > 0 and channel_probs[0] is not None:
+                error_channel = channel_probs
+
+        if error_channel is not None:
+            self.error_channel = error_channel
+        elif error_rate is not None:
+            self.error_rate = error_rate
+        else:  # pyx:153-155 (the reference forgets the f-prefix; the literal braces are its message)
+            raise ValueError("Please specify the error channel. Either: 1) error_rate: float or 2) error_channel:\
+            list of floats of length equal to the block length of the code {self.n}.")
+
+    # ---- channel (pyx:167-233) ------------------------------------------------------------------
+    @property
+    def error_rate(self) -> np.ndarray:
+        return self._channel_probs.astype(float).copy()
+
+    @error_rate.setter
+    def error_rate(self, value: Optional[float]) -> None:
+        if value is not None:
+            if not isinstance(value, float):
+                raise ValueError("The `error_rate` parameter must be specified as a single float value.")
+            self._channel_probs[:] = value
+            self._channel_dirty = True
+
+    @property
+    def error_channel(self) -> np.ndarray:
+        return self._channel_probs.astype(float).copy()
+
+    @error_channel.setter
+    def error_channel(self, value) -> None:
+        if value is not None:
+            if len(value) != self.n:
+                raise ValueError(f"The error channel vector must have length {self.n}, not {len(value)}.")
+            self._channel_probs[:] = np.asarray([value[i] for i in range(self.n)], dtype=np.float64)
+            self._channel_dirty = True
+
+    def update_channel_probs(self, value) -> None:
+        self.error_channel = value
+
+    @property
+    def channel_probs(self) -> np.ndarray:
+        return self._channel_probs.astype(float).copy()
+
+    # ---- input vector type (pyx:236-276) --------------------------------------------------------
+    @property
+    def input_vector_type(self) -> str:
+        return {SYNDROME: "syndrome", RECEIVED_VECTOR: "received_vector", AUTO: "auto"}[self._bp_input_type]
+
+    @input_vector_type.setter
+    def input_vector_type(self, input_type: str):
+        key = input_type.lower()
+        if key in ("auto", "a", "2"):
+            if self.m == self.n:
+                raise ValueError("Please specify the input vector type. Either: 1) input_vector_type: 'syndrome' or 2) input_vector_type:\
+                'received_vector'.")
+            self._bp_input_type = AUTO
+        elif key in ("syndrome", "s", "0"):
+            self._bp_input_type = SYNDROME
+        elif key in ("received_vector", "r", "1"):
+            self._bp_input_type = RECEIVED_VECTOR
+        else:
+            raise ValueError(f"The input vector type '{input_type}' is invalid. \
+                    Please choose from the following methods: \
+                    'input_vector_type=syndrome', 'input_vector_type=received_vector'")
+
+    # ---- results (pyx:279-329) ------------------------------------------------------------------
+    @property
+    def log_prob_ratios(self) -> np.ndarray:
+        return np.array(self._log_prob_ratios, dtype=np.float64)
+
+    @property
+    def converge(self) -> bool:
+        return bool(self._converge)
+
+    @property
+    def iter(self) -> int:
+        return int(self._iterations)
+
+    @property
+    def check_count(self) -> int:
+        return self.m
+
+    @property
+    def bit_count(self) -> int:
+        return self.n
+
+    # ---- algorithm parameters (pyx:332-579) -----------------------------------------------------
+    @property
+    def max_iter(self) -> int:
+        return self._max_iter
+
+    @max_iter.setter
+    def max_iter(self, value: int) -> None:
+        if not isinstance(value, int):
+            raise ValueError("max_iter input parameter is invalid. This must be specified as a positive int.")
+        if value < 0:
+            raise ValueError(f"max_iter input parameter must be a positive int. Not {value}.")
+        self._max_iter = value if value != 0 else self.n  # pyx:357
+
+    @property
+    def bp_method(self) -> str:
+        return "product_sum" if self._bp_method == PRODUCT_SUM else "minimum_sum"
+
+    @bp_method.setter
+    def bp_method(self, value: Union[str, int]) -> None:
+        key = str(value).lower()
+        if key in _PS_ALIASES:
+            self._bp_method = PRODUCT_SUM
+        elif key in _MS_ALIASES:
+            self._bp_method = MINIMUM_SUM
+        else:
+            raise ValueError(f"BP method '{value}' is invalid. \
+                    Please choose from the following methods: \
+                    'product_sum', 'minimum_sum'")
+
+    @property
+    def schedule(self) -> str:
+        return {PARALLEL: "parallel", SERIAL: "serial", SERIAL_RELATIVE: "serial_relative"}[self._schedule]
+
+    @schedule.setter
+    def schedule(self, value: Union[str, int]) -> None:
+        key = str(value).lower()
+        if key in ("parallel", "p", "0"):
+            self._schedule = PARALLEL
+        elif key in ("serial", "s", "1"):
+            self._schedule = SERIAL
+        elif key in ("serial_relative", "sr", "2"):
+            self._schedule = SERIAL_RELATIVE
+        else:
+            raise ValueError(f"The BP schedule method '{value}' is invalid. \
+                    Please choose from the following methods: \
+                    'schedule=parallel', 'schedule=serial', 'schedule=serial_relative'")
+
+    @property
+    def serial_schedule_order(self):
+        if self._serial_schedule_order is None or len(self._serial_schedule_order) == 0:
+            return None
+        return np.array(self._serial_schedule_order, dtype=int)
+
+    @serial_schedule_order.setter
+    def serial_schedule_order(self, value) -> None:
+        if value is None:
+            return
+        if not len(value) == self.n:
+            raise Exception("Input error. The `serial_schedule_order` input parameter must have length equal to the length of the code.")
+        for i in range(self.n):
+            if not isinstance(value[i], (int, np.int64, np.int32)) or value[i] < 0 or value[i] >= self.n:
+                raise ValueError(f"serial_schedule_order[{i}] is invalid. It must be a non-negative integer less than {self.n}.")
+        self._serial_schedule_order = np.asarray(value, dtype=np.int64).copy()
+        self.random_serial_schedule = False
+
+    @property
+    def ms_scaling_factor(self) -> float:
+        return self._ms_scaling_factor
+
+    @ms_scaling_factor.setter
+    def ms_scaling_factor(self, value: float) -> None:
+        if not isinstance(value, (float, int)):
+            raise TypeError("The ms_scaling factor must be specified as a float")
+        self._ms_scaling_factor = float(value)
+
+    @property
+    def omp_thread_count(self) -> int:
+        if self._omp_thread_count != 1:
+            warnings.warn("The OpenMP functionality is not yet implemented")
+        return self._omp_thread_count
+
+    @omp_thread_count.setter
+    def omp_thread_count(self, value: int) -> None:
+        if not isinstance(value, int) or value < 1:
+            raise TypeError("The omp_thread_count must be specified as a\
+            positive integer.")
+        self._omp_thread_count = value
+        if self._omp_thread_count != 1:
+            warnings.warn("The OpenMP functionality is not yet implemented")
+
+    @property
+    def random_schedule_seed(self) -> int:
+        return self._random_schedule_seed
+
+    @random_schedule_seed.setter
+    def random_schedule_seed(self, value: int) -> None:
+        if not isinstance(value, int) or value < -2:
+            raise ValueError("The value of random_schedule_seed must\
+            be a positive integer. Set as -1 to disable to the random\
+            schedule. Set as 0 to use the system clock.")
+        self._random_serial_schedule = True  # pyx:551 (the constructor resets it right after, pyx:142)
+        self._random_schedule_seed = value
+
+    @property
+    def random_serial_schedule(self) -> bool:
+        return self._random_serial_schedule
+
+    @random_serial_schedule.setter
+    def random_serial_schedule(self, value: bool) -> None:
+        self._random_serial_schedule = value
+
+    # ---- device engine --------------------------------------------------------------------------
+    def _get_engine(self):
+        """Create / refresh the HIP handle lazily so that construction and validation need no GPU."""
+        from ldpc_amd.engine import HipBpEngine
+        if self._engine is None:
+            self._engine = HipBpEngine(self._h.indptr, self._h.indices, self.n, self._channel_probs,
+                                       self._max_iter, self._bp_method, self._ms_scaling_factor,
+                                       device=self._device)
+            self._channel_dirty = False
+            self._engine_key = (self._max_iter, self._bp_method, self._ms_scaling_factor)
+        if self._channel_dirty:  # the reference re-reads channel_probabilities on every decode (bp.hpp:149-151)
+            self._engine.set_channel(self._channel_probs)
+            self._channel_dirty = False
+        key = (self._max_iter, self._bp_method, self._ms_scaling_factor)
+        if key != self._engine_key:
+            self._engine.set_params(*key)
+            self._engine_key = key
+        return self._engine
+
+    def _require_parallel(self):
+        if self._schedule != PARALLEL:
+            raise NotImplementedError(
+                f"schedule='{self.schedule}' is not available on the MI355X path yet: only the flooding "
+                "('parallel') schedule (bp.hpp:192-325) is implemented in HIP; there is no CPU fallback.")
+
+
+class BpDecoder(BpDecoderBase):
+    """Belief-propagation decoder for binary linear codes (drop-in for ``ldpc.BpDecoder``, pyx:581-709)."""
+
+    def __init__(self, pcm, *, error_rate=_UNSET, error_channel=_UNSET, max_iter=_UNSET, bp_method=_UNSET,
+                 ms_scaling_factor=_UNSET, schedule=_UNSET, omp_thread_count=_UNSET, random_schedule_seed=_UNSET,
+                 serial_schedule_order=_UNSET, input_vector_type: str = "auto", random_serial_schedule=_UNSET,
+                 **kwargs):
+        """Keywords as in the reference (pyx:620-623): ``error_rate: float``, ``error_channel``,
+        ``max_iter: int = 0`` (0 -> n), ``bp_method: str`` ('product_sum' | 'minimum_sum' and aliases),
+        ``ms_scaling_factor = 1.0``, ``schedule = 'parallel'``, ``omp_thread_count = 1``,
+        ``random_schedule_seed = 0``, ``serial_schedule_order = None``, ``input_vector_type = 'auto'``,
+        ``random_serial_schedule = False``, ``channel_probs`` (ldpc_v1 alias of ``error_channel``).
+
+        Only keywords the caller actually passes reach the base initialiser -- in the reference Cython
+        forwards the call's own kwargs to ``BpDecoderBase.__cinit__``, whose ``kwargs.get`` defaults
+        (pyx:90-100) therefore win over the signature's: an omitted ``bp_method`` means product_sum
+        (pinned by python_test/test_bp_decoder.py:121-136).
+        """
+        for key in kwargs.keys():  # pyx:625-627
+            if key not in ["channel_probs", "_device"]:
+                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
+        _check_pcm_type(pcm)
+        given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
+                     ms_scaling_factor=ms_scaling_factor, schedule=schedule, omp_thread_count=omp_thread_count,
+                     random_schedule_seed=random_schedule_seed, serial_schedule_order=serial_schedule_order,
+                     random_serial_schedule=random_serial_schedule)
+        passed = dict(kwargs)
+        passed.update({k: v for k, v in given.items() if v is not _UNSET})
+        _typed("error_rate", passed.get("error_rate"), float, "float")
+        _typed("max_iter", passed.get("max_iter"), int, "int")
+        _typed("bp_method", passed.get("bp_method"), str, "str")
+        _typed("schedule", passed.get("schedule"), str, "str")
+        _typed("omp_thread_count", passed.get("omp_thread_count"), int, "int")
+        _typed("random_schedule_seed", passed.get("random_schedule_seed"), int, "int")
+        _typed("input_vector_type", input_vector_type, str, "str")
+        super().__init__(pcm, **passed)
+        self.input_vector_type = input_vector_type  # pyx:629
+
+    # ---- single input, reference signature (pyx:642-695) ----------------------------------------
+    def decode(self, input_vector: np.ndarray) -> np.ndarray:
+        ln = len(input_vector)
+        if self._bp_input_type == SYNDROME and not ln == self.m:
+            raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding). Not length {ln}.")
+        elif self._bp_input_type == RECEIVED_VECTOR and not ln == self.n:
+            raise ValueError(f"The input_vector must have length {self.n} (for received vector decoding). Not length {ln}.")
+        elif self._bp_input_type == AUTO and not (ln == self.m or ln == self.n):
+            raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding) or length {self.n} (for received vector decoding). Not length {ln}.")
+        dtype = input_vector.dtype
+        vec = np.asarray(input_vector).astype(np.uint8)  # element-wise uint8 narrowing, pyx:676-678
+        if not vec.any():  # pyx:679-681 / 688-690
+            self._converge = True
+            return np.zeros(self.n, dtype=dtype)
+        self._require_parallel()
+        as_syndrome = self._bp_input_type == SYNDROME or (self._bp_input_type == AUTO and ln == self.m)
+        eng = self._get_engine()
+        if as_syndrome:
+            dec, llr, it, cv = eng.decode_batch(vec[None, :])
+            out = dec[0]
+        else:  # bp.hpp:162-180: decode H r, then XOR the received vector back in
+            synd = eng.mulvec_batch(vec[None, :])
+            dec, llr, it, cv = eng.decode_batch(synd)
+            out = dec[0] ^ vec
+        self._decoding = out.astype(np.uint8)
+        self._log_prob_ratios = llr[0]
+        self._iterations = int(it[0])
+        self._converge = bool(cv[0])
+        return out.astype(dtype)
+
+    # ---- batch (additive) -----------------------------------------------------------------------
+    def decode_batch(self, input_vectors, want_log_prob_ratios: bool = True):
+        """Decode every row of a 2-D array in one launch.
+
+        ``input_vectors``: ``(B, m)`` syndromes or ``(B, n)`` received vectors (same rule as
+        ``decode``), NumPy array (any integer dtype; result has the same dtype) or a torch CUDA uint8
+        tensor (results stay in HBM as torch tensors).  Row ``b`` of the result equals
+        ``decode(input_vectors[b])`` of the reference, including the all-zero shortcut.  Afterwards
+        ``converge_batch`` (B,) bool, ``iter_batch`` (B,) int32 (0 for shortcut rows) and
+        ``log_prob_ratios_batch`` (B, n) float64 (zeros for shortcut rows) describe every row and
+        the scalar properties describe the last row that actually ran BP.
+        """
+        from ldpc_amd.engine import _is_torch
+        if input_vectors.ndim != 2:
+            raise ValueError("decode_batch expects a 2-D array of shape (batch, m) or (batch, n).")
+        ln = int(input_vectors.shape[1])
+        if self._bp_input_type == SYNDROME and not ln == self.m:
+            raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding). Not length {ln}.")
+        elif self._bp_input_type == RECEIVED_VECTOR and not ln == self.n:
+            raise ValueError(f"The input_vector must have length {self.n} (for received vector decoding). Not length {ln}.")
+        elif self._bp_input_type == AUTO and not (ln == self.m or ln == self.n):
+            raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding) or length {self.n} (for received vector decoding). Not length {ln}.")
+        self._require_parallel()
+        as_syndrome = self._bp_input_type == SYNDROME or (self._bp_input_type == AUTO and ln == self.m)
+        eng = self._get_engine()
+        if _is_torch(input_vectors):
+            import torch
+            vec = input_vectors
+            synd = vec if as_syndrome else eng.mulvec_batch(vec)
+            dec, llr, it, cv = eng.decode_batch(synd, want_llr=want_log_prob_ratios)
+            if not as_syndrome:
+                dec ^= vec
+            zero = ~vec.any(dim=1)  # all-zero shortcut rows (pyx:679-681)
+            if bool(zero.any()):
+                dec[zero] = 0
+                cv[zero] = 1
+                it[zero] = 0
+                if llr is not None:
+                    llr[zero] = 0
+            self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv.bool(), it, llr
+            return dec
+        dtype = input_vectors.dtype
+        vec = np.ascontiguousarray(np.asarray(input_vectors).astype(np.uint8))
+        synd = vec if as_syndrome else eng.mulvec_batch(vec)
+        dec, llr, it, cv = eng.decode_batch(synd, want_llr=want_log_prob_ratios)
+        if not as_syndrome:
+            dec ^= vec
+        zero = ~vec.any(axis=1)
+        dec[zero] = 0
+        cv[zero] = True
+        it[zero] = 0
+        if llr is not None:
+            llr[zero] = 0.0
+        self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv, it, llr
+        ran = np.flatnonzero(~zero)
+        if len(ran):
+            last = int(ran[-1])
+            self._decoding = dec[last].astype(np.uint8)
+            if llr is not None:
+                self._log_prob_ratios = llr[last]
+            self._iterations = int(it[last])
+        if len(vec):
+            self._converge = bool(cv[-1])
+        return dec.astype(dtype)
+
+    @property
+    def decoding(self) -> np.ndarray:
+        return np.array(self._decoding).astype(int)  # pyx:698-709

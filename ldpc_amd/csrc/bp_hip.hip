@@ -1,0 +1,858 @@
+// bp_hip.hip -- libldpc_hip.so: batched flooding belief propagation for gfx950 (MI355X, CDNA4).
+//
+// What it replaces (reference = quantumgizmos/ldpc @ /root/reference):
+//   ldpc::bp::BpDecoder::bp_decode_parallel          src_cpp/bp.hpp:192-325
+//   ldpc::bp::BpDecoder::initialise_log_domain_bp    src_cpp/bp.hpp:147-157
+//   ldpc::gf2sparse::GF2Sparse::mulvec               src_cpp/gf2sparse.hpp:177-214
+// for a BATCH of independent syndromes.  This is not a translation of that code: the reference walks
+// a doubly linked list per syndrome on one CPU thread; here
+//
+//   * the unit of data parallelism is the syndrome.  64 syndromes form a TILE; lane l of every
+//     wavefront owns syndrome l of its tile, so each per-edge message access of a wavefront is one
+//     fully coalesced 512-byte row  msg[tile][edge][0..63]  (batch-minor layout),
+//   * one workgroup owns one tile for the WHOLE decode (all iterations): its wavefronts stride over
+//     the checks (check pass) and then over the bits (bit pass) of that tile, separated by
+//     workgroup barriers only -- tiles never talk to each other, so there is no grid-wide sync,
+//     no atomics and one kernel launch per decode,
+//   * every lane walks its node's <= DR (row) / <= DC (column) edges SEQUENTIALLY in ascending
+//     column / row order, i.e. in the reference's linked-list order (sparse_matrix_base.hpp:423-482
+//     keeps both lists sorted), so every floating-point operation is performed in the reference's
+//     association order -- min-sum is bit-identical, product-sum differs only by libm vs ocml ulps,
+//   * hard decisions are kept bit-packed per (tile, bit) as the wavefront's ballot; the syndrome
+//     test of bp.hpp:300-302 is an XOR-gather of those 64-bit words per check,
+//   * a syndrome that converges freezes its outputs (bp.hpp:300-308 early return); a tile whose 64
+//     syndromes are all done retires its workgroup.
+//
+// No MFMA: the path is a sparse gather/scatter bound by HBM bandwidth (4 * nnz * 8 bytes per
+// syndrome-iteration) and by FP64 transcendentals.
+//
+// Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+
+#define LDPC_WAVE 64  // gfx950 wavefront; also the tile width (syndromes per workgroup)
+
+// ------------------------------------------------------------------------------------------------
+// device side
+// ------------------------------------------------------------------------------------------------
+
+struct BpArgs {
+    int32_t m, n, nnz, max_iter;
+    double ms_scaling_factor;
+    int64_t batch;       // syndromes in this launch (last tile may be partial)
+    const int32_t *row_ptr, *col_idx;   // CSR
+    const int32_t *col_ptr, *csc_edge;  // CSC: CSR edge id of each column entry, rows ascending
+    const double *llr0;                 // initial_log_prob_ratios (bp.hpp:66), host-computed
+    double *A;                          // bit_to_check_msg  [tiles][nnz][64]  (bp.hpp:44)
+    double *C;                          // check_to_bit_msg  [tiles][nnz][64]  (bp.hpp:45)
+    const uint64_t *par;                // [tiles][m]  bit l = syndrome byte & 1 of lane l
+    const uint64_t *nzm;                // [tiles][m]  bit l = syndrome byte != 0 of lane l
+    const uint64_t *invalid;            // [tiles]     bit l = some syndrome byte > 1 (never converges)
+    uint64_t *dec;                      // [tiles][n]  ballot of hard decisions (zero-initialised)
+    double *llr_t;                      // [tiles][n][64] or nullptr
+    int32_t *iters;                     // [batch] or nullptr
+    uint8_t *conv;                      // [batch] or nullptr
+};
+
+__device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin of ldpc_amd/prng.py
+    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // wave-uniform value -> SGPR pair
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_or(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo |= __shfl_xor(lo, off, LDPC_WAVE);
+        hi |= __shfl_xor(hi, off, LDPC_WAVE);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// check -> bit, product-sum, one lane, edge values already turned into x = prefix * suffix
+// (bp.hpp:211-216): message_sign * log((1 + x) / (1 - x))
+__device__ __forceinline__ double ps_message(double x, bool negate) {
+    double c = log((1.0 + x) / (1.0 - x));
+    return negate ? -c : c;
+}
+
+template <int METHOD, int DR, int DC>
+__global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
+    const int lane = threadIdx.x & (LDPC_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+
+    const int32_t *__restrict__ row_ptr = a.row_ptr;
+    const int32_t *__restrict__ col_idx = a.col_idx;
+    const int32_t *__restrict__ col_ptr = a.col_ptr;
+    const int32_t *__restrict__ csc_edge = a.csc_edge;
+    const double *__restrict__ llr0 = a.llr0;
+    const uint64_t *__restrict__ par = a.par + tile * m;
+    const uint64_t *__restrict__ nzm = a.nzm + tile * m;
+
+    double *At = a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE + lane;
+    double *Ct = a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE + lane;
+    uint64_t *dec = a.dec + tile * n;
+    double *llr_t = a.llr_t ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE + lane : nullptr;
+
+    __shared__ uint64_t red[16];
+
+    // lanes beyond the batch (partial last tile) are born "done"
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    const uint64_t never = a.invalid[tile];
+    int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
+
+    // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
+    for (int e = wave; e < nnz; e += nwaves) At[(size_t)e * LDPC_WAVE] = llr0[col_idx[e]];
+    __syncthreads();
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        // ---------------- check pass (bp.hpp:201-273) ----------------
+        double alpha = 0.0;
+        if (METHOD == LDPC_HIP_MINIMUM_SUM)
+            alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+
+        for (int i = wave; i < m; i += nwaves) {
+            const int rs = row_ptr[i];
+            const int d = row_ptr[i + 1] - rs;
+            const double *Ae = At + (size_t)rs * LDPC_WAVE;
+            double *Ce = Ct + (size_t)rs * LDPC_WAVE;
+            if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+                const bool neg = (nzm[i] >> lane) & 1ull;  // syndrome[i] != 0 (bp.hpp:213)
+                if (d <= DR) {
+                    double t[DR], pre[DR];
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) t[k] = tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                    double temp = 1.0;
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) { pre[k] = temp; temp *= t[k]; }
+                    temp = 1.0;
+#pragma unroll
+                    for (int k = DR - 1; k >= 0; --k)
+                        if (k < d) {
+                            Ce[(size_t)k * LDPC_WAVE] = ps_message(pre[k] * temp, neg);
+                            temp *= t[k];
+                        }
+                } else {  // heavy row: stream it twice, exactly as the reference's two sweeps
+                    double temp = 1.0;
+                    for (int k = 0; k < d; ++k) {
+                        Ce[(size_t)k * LDPC_WAVE] = temp;
+                        temp *= tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                    }
+                    temp = 1.0;
+                    for (int k = d - 1; k >= 0; --k) {
+                        Ce[(size_t)k * LDPC_WAVE] = ps_message(Ce[(size_t)k * LDPC_WAVE] * temp, neg);
+                        temp *= tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                    }
+                }
+            } else {
+                // total_sgn = syndrome[i] + #{b2c <= 0}; only its parity is used (bp.hpp:236-262)
+                int parity = (int)((par[i] >> lane) & 1ull);
+                if (d <= DR) {
+                    double b[DR], pre[DR];
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) b[k] = Ae[(size_t)k * LDPC_WAVE];
+                    double temp = DBL_MAX;
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) {
+                            if (b[k] <= 0) parity ^= 1;
+                            pre[k] = temp;
+                            const double ab = fabs(b[k]);
+                            if (ab < temp) temp = ab;
+                        }
+                    temp = DBL_MAX;
+#pragma unroll
+                    for (int k = DR - 1; k >= 0; --k)
+                        if (k < d) {
+                            const int sgn = parity ^ (b[k] <= 0 ? 1 : 0);
+                            double mag = pre[k];
+                            if (temp < mag) mag = temp;
+                            const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
+                            Ce[(size_t)k * LDPC_WAVE] = mag * signed_alpha;
+                            const double ab = fabs(b[k]);
+                            if (ab < temp) temp = ab;
+                        }
+                } else {
+                    double temp = DBL_MAX;
+                    for (int k = 0; k < d; ++k) {
+                        const double bk = Ae[(size_t)k * LDPC_WAVE];
+                        if (bk <= 0) parity ^= 1;
+                        Ce[(size_t)k * LDPC_WAVE] = temp;
+                        const double ab = fabs(bk);
+                        if (ab < temp) temp = ab;
+                    }
+                    temp = DBL_MAX;
+                    for (int k = d - 1; k >= 0; --k) {
+                        const double bk = Ae[(size_t)k * LDPC_WAVE];
+                        const int sgn = parity ^ (bk <= 0 ? 1 : 0);
+                        double mag = Ce[(size_t)k * LDPC_WAVE];
+                        if (temp < mag) mag = temp;
+                        const double signed_alpha = sgn ? -alpha : alpha;
+                        Ce[(size_t)k * LDPC_WAVE] = mag * signed_alpha;
+                        const double ab = fabs(bk);
+                        if (ab < temp) temp = ab;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- bit pass (bp.hpp:276-298 and 311-318, fused) ----------------
+        const bool last = (it == a.max_iter);
+        const bool lane_live = !((done >> lane) & 1ull);
+        for (int j = wave; j < n; j += nwaves) {
+            const int cs = col_ptr[j];
+            const int d = col_ptr[j + 1] - cs;
+            const double prior = llr0[j];
+            double llr;
+            if (d <= DC) {
+                int e[DC];
+                double c[DC], pre[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k)
+                    if (k < d) { e[k] = csc_edge[cs + k]; c[k] = Ct[(size_t)e[k] * LDPC_WAVE]; }
+                double temp = prior;
+#pragma unroll
+                for (int k = 0; k < DC; ++k)
+                    if (k < d) { pre[k] = temp; temp += c[k]; }
+                llr = temp;
+                double s = 0.0;
+#pragma unroll
+                for (int k = DC - 1; k >= 0; --k)
+                    if (k < d) { At[(size_t)e[k] * LDPC_WAVE] = pre[k] + s; s += c[k]; }
+            } else {
+                double temp = prior;
+                for (int k = 0; k < d; ++k) {
+                    const size_t e = (size_t)csc_edge[cs + k] * LDPC_WAVE;
+                    At[e] = temp;
+                    temp += Ct[e];
+                }
+                llr = temp;
+                double s = 0.0;
+                for (int k = d - 1; k >= 0; --k) {
+                    const size_t e = (size_t)csc_edge[cs + k] * LDPC_WAVE;
+                    At[e] = At[e] + s;
+                    s += Ct[e];
+                }
+            }
+            const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+            if (lane == 0) dec[j] = (dec[j] & done) | (hard & ~done);
+            if (last && llr_t && lane_live) llr_t[(size_t)j * LDPC_WAVE] = llr;
+        }
+        __syncthreads();
+
+        // ---------------- syndrome test (bp.hpp:292-294, 300-308) ----------------
+        uint64_t unsat = 0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            uint64_t cand = 0;
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) cand ^= dec[col_idx[e]];
+            unsat |= cand ^ par[i];
+        }
+        unsat = wave_or(unsat);
+        if (lane == 0) red[wave] = unsat;
+        __syncthreads();
+        unsat = never;
+        for (int w = 0; w < nwaves; ++w) unsat |= red[w];
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            if (!last && llr_t) {
+                // these syndromes stop here: their posteriors are those of THIS iteration (the
+                // check->bit messages of this iteration are still intact in C)
+                const bool mine = (newly >> lane) & 1ull;
+                for (int j = wave; j < n; j += nwaves) {
+                    double temp = llr0[j];
+                    for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p)
+                        temp += Ct[(size_t)csc_edge[p] * LDPC_WAVE];
+                    if (mine) llr_t[(size_t)j * LDPC_WAVE] = temp;
+                }
+            }
+            done |= newly;
+        }
+        if (done == ~0ull) break;
+        __syncthreads();  // red[] is reused next iteration
+    }
+
+    if (wave == 0) {
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (b < a.batch) {
+            const bool cv = ((done >> lane) & 1ull) != 0;
+            if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;  // bp.hpp:304
+            if (a.conv) a.conv[b] = cv ? 1 : 0;
+        }
+    }
+}
+
+// syndromes [batch][m] u8  ->  par / nzm [tiles][m] u64, invalid [tiles] u64 (pre-zeroed)
+__global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch, int m,
+                                      uint64_t *par, uint64_t *nzm, uint64_t *invalid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = blockIdx.y;
+    if (i >= m) return;
+    uint64_t p = 0, z = 0, inv = 0;
+    const int64_t b0 = tile * LDPC_WAVE;
+    for (int l = 0; l < LDPC_WAVE; ++l) {
+        const int64_t b = b0 + l;
+        if (b < batch) {
+            const uint8_t v = synd[b * m + i];
+            p |= (uint64_t)(v & 1u) << l;
+            z |= (uint64_t)(v != 0u) << l;
+            inv |= (uint64_t)(v > 1u) << l;
+        }
+    }
+    par[tile * m + i] = p;
+    nzm[tile * m + i] = z;
+    if (inv) atomicOr((unsigned long long *)&invalid[tile], (unsigned long long)inv);
+}
+
+// dec [tiles][n] u64 -> decoding [batch][n] u8
+__global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch, int n,
+                                       uint8_t *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = blockIdx.y;
+    if (j >= n) return;
+    const uint64_t v = dec[tile * n + j];
+    const int64_t b0 = tile * LDPC_WAVE;
+    for (int l = 0; l < LDPC_WAVE; ++l) {
+        const int64_t b = b0 + l;
+        if (b < batch) out[b * n + j] = (uint8_t)((v >> l) & 1ull);
+    }
+}
+
+// llr_t [tiles][n][64] f64 -> llr [batch][n] f64, 64x64 tiles through LDS
+__global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__restrict__ llr_t,
+                                                            int64_t batch, int n, double *out) {
+    __shared__ double tilebuf[LDPC_WAVE][LDPC_WAVE + 1];
+    const int j0 = blockIdx.x * LDPC_WAVE;
+    const int64_t tile = blockIdx.y;
+    const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+    for (int r = 0; r < 16; ++r) {
+        const int jj = r * 4 + hi;
+        if (j0 + jj < n) tilebuf[jj][lo] = llr_t[((size_t)tile * n + j0 + jj) * LDPC_WAVE + lo];
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+        const int l = r * 4 + hi;
+        const int64_t b = tile * LDPC_WAVE + l;
+        if (b < batch && j0 + lo < n) out[(size_t)b * n + j0 + lo] = tilebuf[lo][l];
+    }
+}
+
+// GF2Sparse::mulvec over a batch (gf2sparse.hpp:177-214): one thread per (vector, check)
+__global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
+                                  const int32_t *__restrict__ col_idx, int m, int n,
+                                  const uint8_t *__restrict__ in, int64_t batch, uint8_t *out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * m) return;
+    const int64_t b = t / m;
+    const int i = (int)(t - b * m);
+    uint8_t s = 0;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) s ^= in[b * n + col_idx[e]];
+    out[t] = s;
+}
+
+// synthetic BSC shots: syndrome[b][i] = XOR_{j in row i} bernoulli(seed, (shot0+b)*n + j)
+__global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
+                                         const int32_t *__restrict__ col_idx, int m, int n,
+                                         uint64_t seed, uint64_t threshold, int64_t shot0,
+                                         int64_t batch, uint8_t *synd) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * m) return;
+    const int64_t b = t / m;
+    const int i = (int)(t - b * m);
+    const uint64_t base = (uint64_t)(shot0 + b) * (uint64_t)n;
+    uint8_t s = 0;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+        s ^= (uint8_t)((sm64(seed, base + (uint64_t)col_idx[e]) >> 11) < threshold);
+    synd[t] = s;
+}
+
+__global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, int64_t shot0,
+                                      int64_t batch, uint8_t *err) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * n) return;
+    const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
+    err[t] = (uint8_t)((sm64(seed, idx) >> 11) < threshold);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(_e == hipErrorOutOfMemory ? LDPC_HIP_ERR_NOMEM : LDPC_HIP_ERR_DEVICE, \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,      \
+                        __LINE__);                                                            \
+    } while (0)
+
+struct DeviceBuf {  // grow-only device allocation
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(LDPC_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes,
+                        hipGetErrorString(e));
+        }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ldpc_hip_bp {
+    int device = 0;
+    int32_t m = 0, n = 0, nnz = 0;
+    int32_t max_iter = 1, bp_method = 0;
+    double ms_scaling_factor = 1.0;
+    int32_t max_row_deg = 0, max_col_deg = 0;
+    int32_t waves_per_wg = 0;  // 0 = auto
+    std::vector<double> channel_probs;
+
+    int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
+    double *d_llr0 = nullptr;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    float accumulated_ms = 0.f;
+
+    DeviceBuf msgA, msgC, par, nzm, invalid, dec, llr_t;             // workspace
+    DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
+    int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
+};
+
+static int upload_priors(ldpc_hip_bp *h) {
+    // bp.hpp:150-151, evaluated by the host libm so that priors are bit-identical to the reference's
+    std::vector<double> llr0((size_t)h->n);
+    for (int j = 0; j < h->n; ++j)
+        llr0[(size_t)j] = std::log((1 - h->channel_probs[(size_t)j]) / h->channel_probs[(size_t)j]);
+    HIPCHK(hipMemcpy(h->d_llr0, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static bool is_device_ptr(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory reports an error: clear it
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+extern "C" {
+
+const char *ldpc_hip_last_error(void) { return g_last_error.c_str(); }
+const char *ldpc_hip_version(void) { return "ldpc_hip 0.1 (gfx950)"; }
+
+int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
+    if (!d || !out) return fail(LDPC_HIP_ERR_INVALID, "null descriptor or output");
+    *out = nullptr;
+    if (d->m < 0 || d->n < 0 || !d->csr_row_ptr || (d->nnz > 0 && !d->csr_col_idx) || !d->channel_probs)
+        return fail(LDPC_HIP_ERR_INVALID, "bad matrix description");
+    if (d->csr_row_ptr[0] != 0 || d->csr_row_ptr[d->m] != d->nnz)
+        return fail(LDPC_HIP_ERR_INVALID, "csr_row_ptr[0] must be 0 and csr_row_ptr[m] == nnz");
+    if (d->max_iter < 1) return fail(LDPC_HIP_ERR_INVALID, "max_iter must be >= 1");
+    if (d->bp_method != LDPC_HIP_PRODUCT_SUM && d->bp_method != LDPC_HIP_MINIMUM_SUM)
+        return fail(LDPC_HIP_ERR_INVALID, "bp_method must be 0 (product_sum) or 1 (minimum_sum)");
+    int32_t max_row = 0;
+    for (int i = 0; i < d->m; ++i) {
+        const int lo = d->csr_row_ptr[i], hi = d->csr_row_ptr[i + 1];
+        if (hi < lo) return fail(LDPC_HIP_ERR_INVALID, "csr_row_ptr not monotone at row %d", i);
+        if (hi - lo > max_row) max_row = hi - lo;
+        for (int e = lo; e < hi; ++e) {
+            if (d->csr_col_idx[e] < 0 || d->csr_col_idx[e] >= d->n)
+                return fail(LDPC_HIP_ERR_INVALID, "column index out of range in row %d", i);
+            if (e > lo && d->csr_col_idx[e] <= d->csr_col_idx[e - 1])
+                return fail(LDPC_HIP_ERR_INVALID, "row %d: column indices must be strictly ascending", i);
+        }
+    }
+    int device = d->device;
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    HIPCHK(hipSetDevice(device));
+
+    auto *h = new ldpc_hip_bp;
+    h->device = device;
+    h->m = d->m; h->n = d->n; h->nnz = d->nnz;
+    h->max_iter = d->max_iter; h->bp_method = d->bp_method;
+    h->ms_scaling_factor = d->ms_scaling_factor;
+    h->max_row_deg = max_row;
+    h->channel_probs.assign(d->channel_probs, d->channel_probs + d->n);
+
+    // CSC view: csc_edge[p] = CSR edge id; filling by ascending row keeps rows ascending per column
+    std::vector<int32_t> col_ptr((size_t)d->n + 1, 0), csc_edge((size_t)(d->nnz ? d->nnz : 1));
+    for (int e = 0; e < d->nnz; ++e) col_ptr[(size_t)d->csr_col_idx[e] + 1]++;
+    for (int j = 0; j < d->n; ++j) {
+        if (col_ptr[(size_t)j + 1] > h->max_col_deg) h->max_col_deg = col_ptr[(size_t)j + 1];
+        col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
+    }
+    {
+        std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int i = 0; i < d->m; ++i)
+            for (int e = d->csr_row_ptr[i]; e < d->csr_row_ptr[i + 1]; ++e)
+                csc_edge[(size_t)fill[(size_t)d->csr_col_idx[e]]++] = e;
+    }
+#define ALLOC_COPY(dst, src, count, T)                                                          \
+    do {                                                                                        \
+        hipError_t _e = hipMalloc((void **)&(dst), sizeof(T) * (size_t)((count) ? (count) : 1)); \
+        if (_e == hipSuccess && (count))                                                        \
+            _e = hipMemcpy((dst), (src), sizeof(T) * (size_t)(count), hipMemcpyHostToDevice);   \
+        if (_e != hipSuccess) {                                                                 \
+            ldpc_hip_bp_destroy(h);                                                             \
+            return fail(LDPC_HIP_ERR_DEVICE, "device upload failed: %s", hipGetErrorString(_e)); \
+        }                                                                                       \
+    } while (0)
+    ALLOC_COPY(h->d_row_ptr, d->csr_row_ptr, d->m + 1, int32_t);
+    ALLOC_COPY(h->d_col_idx, d->csr_col_idx, d->nnz, int32_t);
+    ALLOC_COPY(h->d_col_ptr, col_ptr.data(), d->n + 1, int32_t);
+    ALLOC_COPY(h->d_csc_edge, csc_edge.data(), d->nnz, int32_t);
+    ALLOC_COPY(h->d_llr0, d->channel_probs, d->n, double);  // overwritten by upload_priors
+#undef ALLOC_COPY
+    int rc = upload_priors(h);
+    if (rc) { ldpc_hip_bp_destroy(h); return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        ldpc_hip_bp_destroy(h);
+        return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return LDPC_HIP_OK;
+}
+
+void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->llr_t,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc})
+        b->release();
+    if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
+    if (h->d_col_idx) (void)hipFree(h->d_col_idx);
+    if (h->d_col_ptr) (void)hipFree(h->d_col_ptr);
+    if (h->d_csc_edge) (void)hipFree(h->d_csc_edge);
+    if (h->d_llr0) (void)hipFree(h->d_llr0);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int ldpc_hip_bp_set_channel(ldpc_hip_bp *h, const double *p, int32_t n) {
+    if (!h || !p) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    if (n != h->n)  // bp.hpp:103-106
+        return fail(LDPC_HIP_ERR_INVALID,
+                    "Channel probabilities vector must have length equal to the number of bits");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->channel_probs.assign(p, p + n);
+    return upload_priors(h);
+}
+
+int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method, double alpha) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (max_iter < 1) return fail(LDPC_HIP_ERR_INVALID, "max_iter must be >= 1");
+    if (bp_method != LDPC_HIP_PRODUCT_SUM && bp_method != LDPC_HIP_MINIMUM_SUM)
+        return fail(LDPC_HIP_ERR_INVALID, "bp_method must be 0 (product_sum) or 1 (minimum_sum)");
+    h->max_iter = max_iter;
+    h->bp_method = bp_method;
+    h->ms_scaling_factor = alpha;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *s) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_wg, int32_t max_chunk_tiles) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (waves_per_wg < 0 || waves_per_wg > 16)
+        return fail(LDPC_HIP_ERR_INVALID, "waves_per_workgroup must be in [0, 16]");
+    h->waves_per_wg = waves_per_wg;
+    h->max_chunk_tiles = max_chunk_tiles > 0 ? max_chunk_tiles : 0;
+    return LDPC_HIP_OK;
+}
+
+int64_t ldpc_hip_bp_workspace_bytes(const ldpc_hip_bp *h, int64_t batch) {
+    if (!h || batch < 0) return -1;
+    const int64_t tiles = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    return tiles * (2ll * 8 * h->nnz * LDPC_WAVE + 2ll * 8 * h->m + 8 + 8ll * h->n +
+                    8ll * h->n * LDPC_WAVE);
+}
+
+int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
+    if (!h || !ms) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    *ms = 0.f;
+    if (!h->timed) return LDPC_HIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float last = 0.f;
+    HIPCHK(hipEventElapsedTime(&last, h->ev0, h->ev1));
+    *ms = h->accumulated_ms + last;
+    return LDPC_HIP_OK;
+}
+
+}  // extern "C"
+
+typedef void (*bp_kernel_t)(const BpArgs);
+
+template <int METHOD>
+static bp_kernel_t pick_kernel(int max_row, int max_col) {
+    const bool r8 = max_row <= 8, c4 = max_col <= 4, c8 = max_col <= 8;
+    if (r8 && c4) return bp_decode_kernel<METHOD, 8, 4>;
+    if (r8 && c8) return bp_decode_kernel<METHOD, 8, 8>;
+    if (c8) return bp_decode_kernel<METHOD, 16, 8>;
+    return bp_decode_kernel<METHOD, 16, 16>;  // heavier nodes take the streaming path inside
+}
+
+// Everything below runs on h->stream with device pointers only.
+static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                         double *llr, int32_t *iters, uint8_t *conv) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    if (tiles_total == 0) return LDPC_HIP_OK;
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
+
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;  // grid.y of the pack/unpack launches stays below 65536
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = 2 * per_tile_msg + per_tile_llr + 16 * (size_t)(h->m + h->n + 1);
+        int64_t fit = (int64_t)(budget / (per_tile ? per_tile : 1));
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+
+    bp_kernel_t kern = h->bp_method == LDPC_HIP_PRODUCT_SUM
+                           ? pick_kernel<LDPC_HIP_PRODUCT_SUM>(h->max_row_deg, h->max_col_deg)
+                           : pick_kernel<LDPC_HIP_MINIMUM_SUM>(h->max_row_deg, h->max_col_deg);
+    h->accumulated_ms = 0.f;
+    h->timed = false;
+    hipStream_t st = h->stream;
+
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        BpArgs a;
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
+        a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
+        a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
+        a.invalid = (const uint64_t *)h->invalid.p;
+        a.dec = (uint64_t *)h->dec.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+
+        int waves = h->waves_per_wg;
+        if (waves <= 0) waves = tiles >= 512 ? 8 : 16;
+        if (h->timed) {  // fold the previous chunk's time before the events are re-recorded
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), 0, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st,
+                               (const uint64_t *)h->dec.p, nb, h->n, decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st,
+                                   (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LDPC_HIP_OK;
+}
+
+extern "C" {
+
+int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
+                                   uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
+    if (batch > (1ll << 40)) return fail(LDPC_HIP_ERR_INVALID, "batch too large");
+    HIPCHK(hipSetDevice(h->device));
+    return decode_device(h, synd, batch, decoding, llr, iters, conv);
+}
+
+int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                             double *llr, int32_t *iters, uint8_t *conv) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = (size_t)batch, m = (size_t)h->m, n = (size_t)h->n;
+    const uint8_t *d_synd = synd;
+    uint8_t *d_dec = decoding;
+    double *d_llr = llr;
+    int32_t *d_it = iters;
+    uint8_t *d_cv = conv;
+    int rc;
+    const bool h_synd = !is_device_ptr(synd), h_dec = !is_device_ptr(decoding);
+    const bool h_llr = llr && !is_device_ptr(llr), h_it = iters && !is_device_ptr(iters);
+    const bool h_cv = conv && !is_device_ptr(conv);
+    if (h_synd) {
+        if ((rc = h->st_synd.ensure(B * m ? B * m : 1))) return rc;
+        HIPCHK(hipMemcpyAsync(h->st_synd.p, synd, B * m, hipMemcpyHostToDevice, h->stream));
+        d_synd = (const uint8_t *)h->st_synd.p;
+    }
+    if (h_dec) { if ((rc = h->st_dec.ensure(B * n ? B * n : 1))) return rc; d_dec = (uint8_t *)h->st_dec.p; }
+    if (h_llr) { if ((rc = h->st_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; d_llr = (double *)h->st_llr.p; }
+    if (h_it) { if ((rc = h->st_iters.ensure(B * 4))) return rc; d_it = (int32_t *)h->st_iters.p; }
+    if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
+
+    if ((rc = decode_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv))) return rc;
+
+    if (h_dec) HIPCHK(hipMemcpyAsync(decoding, d_dec, B * n, hipMemcpyDeviceToHost, h->stream));
+    if (h_llr) HIPCHK(hipMemcpyAsync(llr, d_llr, B * n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (h_it) HIPCHK(hipMemcpyAsync(iters, d_it, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (h_cv) HIPCHK(hipMemcpyAsync(conv, d_cv, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_gf2_mulvec_batch(ldpc_hip_bp *h, const uint8_t *vectors, int64_t batch, uint8_t *out) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0 || h->m == 0) return LDPC_HIP_OK;
+    if (!vectors || !out) return fail(LDPC_HIP_ERR_INVALID, "null buffer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = (size_t)batch, m = (size_t)h->m, n = (size_t)h->n;
+    const uint8_t *d_in = vectors;
+    uint8_t *d_out = out;
+    int rc;
+    const bool h_in = !is_device_ptr(vectors), h_out = !is_device_ptr(out);
+    if (h_in) {
+        if ((rc = h->st_misc.ensure(B * n ? B * n : 1))) return rc;
+        HIPCHK(hipMemcpyAsync(h->st_misc.p, vectors, B * n, hipMemcpyHostToDevice, h->stream));
+        d_in = (const uint8_t *)h->st_misc.p;
+    }
+    if (h_out) { if ((rc = h->st_synd.ensure(B * m))) return rc; d_out = (uint8_t *)h->st_synd.p; }
+    const int64_t total = batch * h->m;
+    hipLaunchKernelGGL(gf2_mulvec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                       h->d_row_ptr, h->d_col_idx, h->m, h->n, d_in, batch, d_out);
+    HIPCHK(hipGetLastError());
+    if (h_out) HIPCHK(hipMemcpyAsync(out, d_out, B * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold, int64_t shot0,
+                               int64_t batch, uint8_t *syndromes, uint8_t *errors) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0 || shot0 < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch or shot0");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!syndromes) return fail(LDPC_HIP_ERR_INVALID, "null syndromes buffer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = (size_t)batch, m = (size_t)h->m, n = (size_t)h->n;
+    uint8_t *d_s = syndromes, *d_e = errors;
+    int rc;
+    const bool h_s = !is_device_ptr(syndromes), h_e = errors && !is_device_ptr(errors);
+    if (h_s) { if ((rc = h->st_synd.ensure(B * m ? B * m : 1))) return rc; d_s = (uint8_t *)h->st_synd.p; }
+    if (h_e) { if ((rc = h->st_misc.ensure(B * n ? B * n : 1))) return rc; d_e = (uint8_t *)h->st_misc.p; }
+    if (h->m > 0) {
+        const int64_t total = batch * h->m;
+        hipLaunchKernelGGL(gen_bsc_syndromes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, h->d_row_ptr, h->d_col_idx, h->m, h->n, seed, threshold, shot0,
+                           batch, d_s);
+    }
+    if (errors && h->n > 0) {
+        const int64_t total = batch * h->n;
+        hipLaunchKernelGGL(gen_bsc_errors_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           h->stream, h->n, seed, threshold, shot0, batch, d_e);
+    }
+    HIPCHK(hipGetLastError());
+    if (h_s) HIPCHK(hipMemcpyAsync(syndromes, d_s, B * m, hipMemcpyDeviceToHost, h->stream));
+    if (h_e) HIPCHK(hipMemcpyAsync(errors, d_e, B * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+"""``HipBpEngine``: Python owner of one ``ldpc_hip_bp`` handle (include/ldpc_hip.h).
+
+It plays the role ``BpDecoderCpp *bpd`` plays inside the reference's Cython class
+(_bp_decoder.pxd:85-93): the object the user-facing ``BpDecoder`` forwards to.  Arrays cross the
+boundary as raw pointers: NumPy arrays as host pointers (the library stages them through HBM),
+torch CUDA tensors as device pointers (no copy; outputs stay resident in HBM).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ldpc_amd import _lib
+
+PRODUCT_SUM = 0  # ldpc::bp::BpMethod, bp.hpp:23-26
+MINIMUM_SUM = 1
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class HipBpEngine:
+    def __init__(self, row_ptr, col_idx, n, channel_probs, max_iter, bp_method, ms_scaling_factor,
+                 device: int = -1):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        probs = np.ascontiguousarray(channel_probs, np.float64)
+        self.m = int(len(row_ptr) - 1)
+        self.n = int(n)
+        self.nnz = int(len(col_idx))
+        if probs.shape != (self.n,):
+            raise ValueError("Channel probabilities vector must have length equal to the number of bits")
+        desc = _lib.BpDesc(
+            m=self.m, n=self.n, nnz=self.nnz,
+            csr_row_ptr=row_ptr.ctypes.data_as(C.POINTER(C.c_int32)),
+            csr_col_idx=col_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+            channel_probs=probs.ctypes.data_as(C.POINTER(C.c_double)),
+            max_iter=int(max_iter), bp_method=int(bp_method),
+            ms_scaling_factor=float(ms_scaling_factor), device=int(device))
+        _lib.check(self._lib.ldpc_hip_bp_create(C.byref(desc), C.byref(self._h)))
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ldpc_hip_bp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters -------------------------------------------------------------------------------
+    def set_channel(self, channel_probs):
+        p = np.ascontiguousarray(channel_probs, np.float64)
+        _lib.check(self._lib.ldpc_hip_bp_set_channel(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), len(p)))
+
+    def set_params(self, max_iter, bp_method, ms_scaling_factor):
+        _lib.check(self._lib.ldpc_hip_bp_set_params(self._h, int(max_iter), int(bp_method), float(ms_scaling_factor)))
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self._lib.ldpc_hip_bp_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def set_tuning(self, waves_per_workgroup=0, max_chunk_tiles=0):
+        _lib.check(self._lib.ldpc_hip_bp_set_tuning(self._h, int(waves_per_workgroup), int(max_chunk_tiles)))
+
+    def workspace_bytes(self, batch):
+        return int(self._lib.ldpc_hip_bp_workspace_bytes(self._h, int(batch)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0.0)
+        _lib.check(self._lib.ldpc_hip_bp_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- data path --------------------------------------------------------------------------------
+    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False):
+        """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
+
+        NumPy in -> NumPy out (host pointers); torch CUDA tensor in -> torch CUDA tensors out.
+        ``out`` may carry preallocated torch outputs ``(decoding, llr, iterations, converge)``.
+        """
+        if _is_torch(syndromes):
+            import torch
+            s = syndromes
+            if s.dtype != torch.uint8 or s.dim() != 2 or s.shape[1] != self.m or not s.is_cuda:
+                raise ValueError(f"syndromes must be a CUDA uint8 tensor of shape (B, {self.m})")
+            s = s.contiguous()
+            b = int(s.shape[0])
+            # launch on torch's current stream so the call is ordered after whatever produced `s`
+            self.set_stream(torch.cuda.current_stream(s.device).cuda_stream)
+            if out is not None:
+                dec, llr, it, cv = out
+            else:
+                dec = torch.empty((b, self.n), dtype=torch.uint8, device=s.device)
+                llr = torch.empty((b, self.n), dtype=torch.float64, device=s.device) if want_llr else None
+                it = torch.empty((b,), dtype=torch.int32, device=s.device)
+                cv = torch.empty((b,), dtype=torch.uint8, device=s.device)
+            fn = self._lib.ldpc_hip_bp_decode_batch_async if asynchronous else self._lib.ldpc_hip_bp_decode_batch
+            _lib.check(fn(self._h, s.data_ptr(), b, dec.data_ptr(), llr.data_ptr() if llr is not None else None,
+                          it.data_ptr(), cv.data_ptr()))
+            return dec, llr, it, cv
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape (B, {self.m})")
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        cv = np.zeros(b, np.uint8)
+        _lib.check(self._lib.ldpc_hip_bp_decode_batch(
+            self._h, s.ctypes.data, b, dec.ctypes.data, llr.ctypes.data if want_llr else None,
+            it.ctypes.data, cv.ctypes.data))
+        return dec, llr, it, cv.astype(bool)
+
+    def mulvec_batch(self, vectors):
+        """``GF2Sparse::mulvec`` (gf2sparse.hpp:177-214) for every row of ``vectors`` (B, n)."""
+        if _is_torch(vectors):
+            import torch
+            v = vectors.contiguous()
+            self.set_stream(torch.cuda.current_stream(v.device).cuda_stream)
+            out = torch.empty((v.shape[0], self.m), dtype=torch.uint8, device=v.device)
+            _lib.check(self._lib.ldpc_hip_gf2_mulvec_batch(self._h, v.data_ptr(), int(v.shape[0]), out.data_ptr()))
+            return out
+        v = np.ascontiguousarray(vectors, np.uint8)
+        out = np.zeros((v.shape[0], self.m), np.uint8)
+        _lib.check(self._lib.ldpc_hip_gf2_mulvec_batch(self._h, v.ctypes.data, v.shape[0], out.ctypes.data))
+        return out
+
+    def gen_bsc_syndromes(self, seed, error_rate, shot0, shots, device=None, want_errors=False):
+        """Synthetic BSC shots generated on the GPU (twin of ``noise_models.generate_bsc_batch`` + H e)."""
+        from ldpc_amd.prng import bernoulli_threshold
+        thr = bernoulli_threshold(error_rate)
+        if device is not None:
+            import torch
+            self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+            synd = torch.empty((shots, self.m), dtype=torch.uint8, device=device)
+            err = torch.empty((shots, self.n), dtype=torch.uint8, device=device) if want_errors else None
+            _lib.check(self._lib.ldpc_hip_gen_bsc_syndromes(
+                self._h, seed, thr, shot0, shots, synd.data_ptr(), err.data_ptr() if want_errors else None))
+        else:
+            synd = np.zeros((shots, self.m), np.uint8)
+            err = np.zeros((shots, self.n), np.uint8) if want_errors else None
+            _lib.check(self._lib.ldpc_hip_gen_bsc_syndromes(
+                self._h, seed, thr, shot0, shots, synd.ctypes.data, err.ctypes.data if want_errors else None))
+        return (synd, err) if want_errors else synd

@@ -1,0 +1,85 @@
+"""Loader for tests/golden/*.npz (reference outputs captured by tests/golden/make_golden.py)."""
+from __future__ import annotations
+
+import glob
+import os
+import zlib
+
+import numpy as np
+import scipy.sparse as sp
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names(prefix: str = ""):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def _h_from_recipe(recipe: str):
+    from ldpc_amd import codes
+    allowed = {"regular_ldpc_code": codes.regular_ldpc_code}
+    fn, args = recipe.split("(", 1)
+    args = args.rstrip(")")
+    pos, kw = [], {}
+    for a in args.split(","):
+        if "=" in a:
+            k, v = a.split("=")
+            kw[k.strip()] = int(v)
+        else:
+            pos.append(int(a))
+    return allowed[fn](*pos, **kw)
+
+
+_H_CACHE: dict = {}
+
+
+def load_case(name: str) -> dict:
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    m, n = int(z["m"]), int(z["n"])
+    recipe = str(z["recipe"])
+    if recipe:
+        if recipe not in _H_CACHE:
+            _H_CACHE[recipe] = _h_from_recipe(recipe)
+        h = _H_CACHE[recipe]
+    else:
+        rp, ci = z["row_ptr"], z["col_idx"]
+        h = sp.csr_matrix((np.ones(len(ci), np.uint8), ci, rp), shape=(m, n), dtype=np.uint8)
+    h = sp.csr_matrix(h)
+    h.sort_indices()
+    rp = np.ascontiguousarray(h.indptr, np.int32)
+    ci = np.ascontiguousarray(h.indices, np.int32)
+    crc = zlib.crc32(ci.tobytes(), zlib.crc32(rp.tobytes(), zlib.crc32(np.array([m, n], np.int64).tobytes())))
+    assert np.uint32(crc) == z["h_crc"], f"{name}: parity-check matrix does not match the fixture's checksum"
+    synd = z["syndromes"]
+    if bool(z["syndromes_packed"]):
+        synd = np.unpackbits(synd, axis=1, count=m)
+    dec = np.unpackbits(z["decoding"], axis=1, count=n)
+    return dict(
+        name=name, h=h, m=m, n=n, channel_probs=z["channel_probs"], max_iter=int(z["max_iter"]),
+        bp_method=("product_sum", "minimum_sum")[int(z["bp_method"])],
+        ms_scaling_factor=float(z["ms_scaling_factor"]), syndromes=np.ascontiguousarray(synd, np.uint8),
+        decoding=dec, converge=z["converge"].astype(bool), iterations=z["iterations"].astype(np.int32),
+        llr=z["llr"], llr_rowsum=z["llr_rowsum"], note=str(z["note"]),
+    )
+
+
+def llr_close(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5) -> bool:
+    """north_star tolerance: posterior log-probability ratios within 1e-5 RELATIVE of the reference.
+
+    Non-finite entries must match exactly in kind (NaN with NaN, +inf with +inf, -inf with -inf).
+    """
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    fin = np.isfinite(want)
+    if not np.array_equal(fin, np.isfinite(got)):
+        return False
+    if not np.array_equal(np.isnan(want), np.isnan(got)):
+        return False
+    inf = np.isinf(want)
+    if not np.array_equal(np.sign(want[inf]), np.sign(got[inf])):
+        return False
+    return bool(np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin])))
+
+
+def rowsum(llr: np.ndarray) -> np.ndarray:
+    return np.sum(np.where(np.abs(llr) < 1e100, llr, 0.0), axis=1)
