@@ -158,7 +158,8 @@ def main() -> None:
             ok = bool(np.array_equal(gd, cd) and np.array_equal(iters[:sample], ci) and np.array_equal(conv[:sample], cc))
             if llr is not None:
                 gl = llr[:sample].cpu().numpy()
-                ok = ok and bool(np.all(np.abs(gl - cl) <= 1e-5 * np.abs(cl)))
+                from oracle import llr_close
+                ok = ok and llr_close(gl, cl, rtol=1e-5)
             cpu["parity_vs_gpu"] = {"syndromes": int(sample), "hard_decisions_iters_converge_exact_llr_1e-5": ok}
             res["cpu_baseline"] = cpu
             if not ok:

@@ -49,6 +49,14 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'  or  make -C ldpc_amd/csrc). "
             "ldpc_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64/libhsa-runtime64 (SONAME libamdhip64.so.7).  If this library
+    # pulled in /opt/rocm's copy first, a later `import torch` would load a SECOND HIP runtime and find
+    # no GPUs; importing torch first makes both share torch's runtime.  (A plain C consumer of the ABI
+    # links /opt/rocm's runtime and never meets torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     lib.ldpc_hip_bp_create.argtypes = [C.POINTER(BpDesc), C.POINTER(vp)]

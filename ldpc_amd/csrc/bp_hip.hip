@@ -40,6 +40,13 @@
 #include <vector>
 
 #include "../../include/ldpc_hip.h"
+#include "bp_math.h"
+
+// LDPC_MATH: 0 = ocml tanh/log, 1 = fast ~1-ulp routines, 2 = bit-identical twins of the host glibc
+// the reference runs on (default: product-sum LLRs then match the reference bit for bit)
+#ifndef LDPC_MATH
+#define LDPC_MATH 2
+#endif
 
 #define LDPC_WAVE 64  // gfx950 wavefront; also the tile width (syndromes per workgroup)
 
@@ -88,15 +95,69 @@ __device__ __forceinline__ uint64_t wave_or(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// check -> bit, product-sum, one lane, edge values already turned into x = prefix * suffix
-// (bp.hpp:211-216): message_sign * log((1 + x) / (1 - x))
+// Message arrays are reached through buffer descriptors: "SGPR descriptor + SGPR edge offset + VGPR
+// lane offset", so an access costs no per-lane 64-bit address arithmetic and no address VGPR pairs
+// (flat global_load needs a VGPR pair per distinct address; with ~30 addresses live that alone cost
+// an occupancy step).  One descriptor covers one tile's [nnz][64] doubles: nnz * 512 bytes < 4 GiB.
+typedef unsigned int ldpc_v2u __attribute__((ext_vector_type(2)));
+struct MsgBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ double ld(int lane8, int edge) const {  // edge is wave-uniform
+        ldpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (int)((unsigned)edge << 9), 0);
+        return __builtin_bit_cast(double, v);
+    }
+    __device__ __forceinline__ void st(int lane8, int edge, double x) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ldpc_v2u, x), rsrc, lane8,
+                                              (int)((unsigned)edge << 9), 0);
+    }
+};
+__device__ __forceinline__ MsgBuf make_msgbuf(double *base, unsigned rows) {
+    MsgBuf b;
+    b.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows << 9), 0x00020000);
+    return b;
+}
+
+// check -> bit, product-sum, one lane: message_sign * log((1 + x) / (1 - x))  (bp.hpp:211-216),
+// x = (exclusive prefix product) * (exclusive suffix product) of the tanh values of the row
 __device__ __forceinline__ double ps_message(double x, bool negate) {
+#if LDPC_MATH == 0
     double c = log((1.0 + x) / (1.0 - x));
+#elif LDPC_MATH == 1
+    double c = ldpc_math::ps_log_ratio(x);
+#else
+    double c = ldpc_math::ps_log_ratio_libm(x);
+#endif
     return negate ? -c : c;
+}
+
+// tanh(b / 2) of bp.hpp:208,217 (b / 2 == b * 0.5 exactly)
+__device__ __forceinline__ double ps_tanh_half(double b) {
+#if LDPC_MATH == 0
+    return tanh(b * 0.5);
+#elif LDPC_MATH == 1
+    return ldpc_math::tanh_half(b);
+#else
+    return ldpc_math::tanh_half_libm(b);
+#endif
+}
+
+// Keeps the scheduler from interleaving the (independent) per-edge transcendental chains: each chain
+// needs ~20 VGPRs of temporaries and interleaving 6-8 of them costs occupancy for no gain -- latency is
+// hidden by the other wavefronts of the SIMD, not by ILP inside one.
+#define LDPC_EDGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// What array A holds per edge: product-sum stores tanh(b2c / 2) (the only form the check update
+// reads; evaluating it in the BIT pass puts half of the transcendental work next to each of the two
+// memory passes), min-sum stores b2c itself.  Same value either way: one tanh per edge per iteration
+// of the same argument the reference uses (it evaluates it twice, bp.hpp:208 and :217).
+template <int METHOD>
+__device__ __forceinline__ double edge_form(double b2c) {
+    return METHOD == LDPC_HIP_PRODUCT_SUM ? ps_tanh_half(b2c) : b2c;
 }
 
 template <int METHOD, int DR, int DC>
 __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
+    constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront in the bit pass
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)(blockDim.x >> 6);
@@ -111,12 +172,14 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     const uint64_t *__restrict__ par = a.par + tile * m;
     const uint64_t *__restrict__ nzm = a.nzm + tile * m;
 
-    double *At = a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE + lane;
-    double *Ct = a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE + lane;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     uint64_t *dec = a.dec + tile * n;
-    double *llr_t = a.llr_t ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE + lane : nullptr;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
 
-    __shared__ uint64_t red[16];
+    __shared__ uint64_t red[2][16];
 
     // lanes beyond the batch (partial last tile) are born "done"
     const int64_t valid = a.batch - tile * LDPC_WAVE;
@@ -125,7 +188,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
 
     // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
-    for (int e = wave; e < nnz; e += nwaves) At[(size_t)e * LDPC_WAVE] = llr0[col_idx[e]];
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD>(llr0[col_idx[e]]));
     __syncthreads();
 
     for (int it = 1; it <= a.max_iter; ++it) {
@@ -134,136 +197,180 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
         if (METHOD == LDPC_HIP_MINIMUM_SUM)
             alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
 
+        // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
+        // works on row i its loads for row i + nwaves are already in flight.
+        double cur[DR];
+        int rs = 0, d = 0;
+        if (wave < m) {
+            rs = row_ptr[wave];
+            d = row_ptr[wave + 1] - rs;
+            if (d <= DR) {
+#pragma unroll
+                for (int k = 0; k < DR; ++k)
+                    if (k < d) cur[k] = At.ld(l8, rs + k);
+            }
+        }
         for (int i = wave; i < m; i += nwaves) {
-            const int rs = row_ptr[i];
-            const int d = row_ptr[i + 1] - rs;
-            const double *Ae = At + (size_t)rs * LDPC_WAVE;
-            double *Ce = Ct + (size_t)rs * LDPC_WAVE;
+            const int inext = i + nwaves;
+            double nxt[DR];
+            int rs_n = 0, d_n = 0;
+            if (inext < m) {
+                rs_n = row_ptr[inext];
+                d_n = row_ptr[inext + 1] - rs_n;
+                if (d_n <= DR) {
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d_n) nxt[k] = At.ld(l8, rs_n + k);
+                }
+            }
             if (METHOD == LDPC_HIP_PRODUCT_SUM) {
                 const bool neg = (nzm[i] >> lane) & 1ull;  // syndrome[i] != 0 (bp.hpp:213)
                 if (d <= DR) {
-                    double t[DR], pre[DR];
-#pragma unroll
-                    for (int k = 0; k < DR; ++k)
-                        if (k < d) t[k] = tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                    double pre[DR];
                     double temp = 1.0;
 #pragma unroll
                     for (int k = 0; k < DR; ++k)
-                        if (k < d) { pre[k] = temp; temp *= t[k]; }
+                        if (k < d) { pre[k] = temp; temp *= cur[k]; }
                     temp = 1.0;
 #pragma unroll
                     for (int k = DR - 1; k >= 0; --k)
                         if (k < d) {
-                            Ce[(size_t)k * LDPC_WAVE] = ps_message(pre[k] * temp, neg);
-                            temp *= t[k];
+                            Ct.st(l8, rs + k, ps_message(pre[k] * temp, neg));
+                            temp *= cur[k];
+                            LDPC_EDGE_FENCE();
                         }
                 } else {  // heavy row: stream it twice, exactly as the reference's two sweeps
                     double temp = 1.0;
                     for (int k = 0; k < d; ++k) {
-                        Ce[(size_t)k * LDPC_WAVE] = temp;
-                        temp *= tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                        Ct.st(l8, rs + k, temp);
+                        temp *= At.ld(l8, rs + k);
                     }
                     temp = 1.0;
                     for (int k = d - 1; k >= 0; --k) {
-                        Ce[(size_t)k * LDPC_WAVE] = ps_message(Ce[(size_t)k * LDPC_WAVE] * temp, neg);
-                        temp *= tanh(Ae[(size_t)k * LDPC_WAVE] * 0.5);
+                        Ct.st(l8, rs + k, ps_message(Ct.ld(l8, rs + k) * temp, neg));
+                        temp *= At.ld(l8, rs + k);
                     }
                 }
             } else {
                 // total_sgn = syndrome[i] + #{b2c <= 0}; only its parity is used (bp.hpp:236-262)
                 int parity = (int)((par[i] >> lane) & 1ull);
                 if (d <= DR) {
-                    double b[DR], pre[DR];
-#pragma unroll
-                    for (int k = 0; k < DR; ++k)
-                        if (k < d) b[k] = Ae[(size_t)k * LDPC_WAVE];
+                    double pre[DR];
                     double temp = DBL_MAX;
 #pragma unroll
                     for (int k = 0; k < DR; ++k)
                         if (k < d) {
-                            if (b[k] <= 0) parity ^= 1;
+                            if (cur[k] <= 0) parity ^= 1;
                             pre[k] = temp;
-                            const double ab = fabs(b[k]);
+                            const double ab = fabs(cur[k]);
                             if (ab < temp) temp = ab;
                         }
                     temp = DBL_MAX;
 #pragma unroll
                     for (int k = DR - 1; k >= 0; --k)
                         if (k < d) {
-                            const int sgn = parity ^ (b[k] <= 0 ? 1 : 0);
+                            const int sgn = parity ^ (cur[k] <= 0 ? 1 : 0);
                             double mag = pre[k];
                             if (temp < mag) mag = temp;
                             const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
-                            Ce[(size_t)k * LDPC_WAVE] = mag * signed_alpha;
-                            const double ab = fabs(b[k]);
+                            Ct.st(l8, rs + k, mag * signed_alpha);
+                            const double ab = fabs(cur[k]);
                             if (ab < temp) temp = ab;
                         }
                 } else {
                     double temp = DBL_MAX;
                     for (int k = 0; k < d; ++k) {
-                        const double bk = Ae[(size_t)k * LDPC_WAVE];
+                        const double bk = At.ld(l8, rs + k);
                         if (bk <= 0) parity ^= 1;
-                        Ce[(size_t)k * LDPC_WAVE] = temp;
+                        Ct.st(l8, rs + k, temp);
                         const double ab = fabs(bk);
                         if (ab < temp) temp = ab;
                     }
                     temp = DBL_MAX;
                     for (int k = d - 1; k >= 0; --k) {
-                        const double bk = Ae[(size_t)k * LDPC_WAVE];
+                        const double bk = At.ld(l8, rs + k);
                         const int sgn = parity ^ (bk <= 0 ? 1 : 0);
-                        double mag = Ce[(size_t)k * LDPC_WAVE];
+                        double mag = Ct.ld(l8, rs + k);
                         if (temp < mag) mag = temp;
                         const double signed_alpha = sgn ? -alpha : alpha;
-                        Ce[(size_t)k * LDPC_WAVE] = mag * signed_alpha;
+                        Ct.st(l8, rs + k, mag * signed_alpha);
                         const double ab = fabs(bk);
                         if (ab < temp) temp = ab;
                     }
                 }
             }
+            rs = rs_n;
+            d = d_n;
+#pragma unroll
+            for (int k = 0; k < DR; ++k) cur[k] = nxt[k];
         }
         __syncthreads();
 
         // ---------------- bit pass (bp.hpp:276-298 and 311-318, fused) ----------------
+        // UB columns per wavefront step: all their message loads are issued before the first is used.
         const bool last = (it == a.max_iter);
         const bool lane_live = !((done >> lane) & 1ull);
-        for (int j = wave; j < n; j += nwaves) {
-            const int cs = col_ptr[j];
-            const int d = col_ptr[j + 1] - cs;
-            const double prior = llr0[j];
-            double llr;
-            if (d <= DC) {
-                int e[DC];
-                double c[DC], pre[DC];
+        for (int j0 = wave * UB; j0 < n; j0 += nwaves * UB) {
+            int cs[UB], dg[UB], e[UB][DC];
+            double c[UB][DC];
 #pragma unroll
-                for (int k = 0; k < DC; ++k)
-                    if (k < d) { e[k] = csc_edge[cs + k]; c[k] = Ct[(size_t)e[k] * LDPC_WAVE]; }
-                double temp = prior;
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + u;
+                cs[u] = 0;
+                dg[u] = -1;  // -1: no such column
+                if (j < n) {
+                    cs[u] = col_ptr[j];
+                    dg[u] = col_ptr[j + 1] - cs[u];
+                    if (dg[u] <= DC) {
 #pragma unroll
-                for (int k = 0; k < DC; ++k)
-                    if (k < d) { pre[k] = temp; temp += c[k]; }
-                llr = temp;
-                double s = 0.0;
-#pragma unroll
-                for (int k = DC - 1; k >= 0; --k)
-                    if (k < d) { At[(size_t)e[k] * LDPC_WAVE] = pre[k] + s; s += c[k]; }
-            } else {
-                double temp = prior;
-                for (int k = 0; k < d; ++k) {
-                    const size_t e = (size_t)csc_edge[cs + k] * LDPC_WAVE;
-                    At[e] = temp;
-                    temp += Ct[e];
-                }
-                llr = temp;
-                double s = 0.0;
-                for (int k = d - 1; k >= 0; --k) {
-                    const size_t e = (size_t)csc_edge[cs + k] * LDPC_WAVE;
-                    At[e] = At[e] + s;
-                    s += Ct[e];
+                        for (int k = 0; k < DC; ++k)
+                            if (k < dg[u]) {
+                                e[u][k] = csc_edge[cs[u] + k];
+                                c[u][k] = Ct.ld(l8, e[u][k]);
+                            }
+                    }
                 }
             }
-            const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
-            if (lane == 0) dec[j] = (dec[j] & done) | (hard & ~done);
-            if (last && llr_t && lane_live) llr_t[(size_t)j * LDPC_WAVE] = llr;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int j = j0 + u;
+                if (dg[u] < 0) continue;
+                const double prior = llr0[j];
+                double llr;
+                if (dg[u] <= DC) {
+                    double pre[DC];
+                    double temp = prior;
+#pragma unroll
+                    for (int k = 0; k < DC; ++k)
+                        if (k < dg[u]) { pre[k] = temp; temp += c[u][k]; }
+                    llr = temp;
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = DC - 1; k >= 0; --k)
+                        if (k < dg[u]) {
+                            At.st(l8, e[u][k], edge_form<METHOD>(pre[k] + s));
+                            s += c[u][k];
+                            if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+                        }
+                } else {  // heavy column: two streaming sweeps like the reference's
+                    double temp = prior;
+                    for (int k = 0; k < dg[u]; ++k) {
+                        const int ee = csc_edge[cs[u] + k];
+                        At.st(l8, ee, temp);
+                        temp += Ct.ld(l8, ee);
+                    }
+                    llr = temp;
+                    double s = 0.0;
+                    for (int k = dg[u] - 1; k >= 0; --k) {
+                        const int ee = csc_edge[cs[u] + k];
+                        At.st(l8, ee, edge_form<METHOD>(At.ld(l8, ee) + s));
+                        s += Ct.ld(l8, ee);
+                    }
+                }
+                const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                if (lane == 0) dec[j] = done ? ((dec[j] & done) | (hard & ~done)) : hard;
+                if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+            }
         }
         __syncthreads();
 
@@ -275,28 +382,29 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
             unsat |= cand ^ par[i];
         }
         unsat = wave_or(unsat);
-        if (lane == 0) red[wave] = unsat;
+        uint64_t *slot = red[it & 1];  // double-buffered: no barrier needed before the next reuse
+        if (lane == 0) slot[wave] = unsat;
         __syncthreads();
         unsat = never;
-        for (int w = 0; w < nwaves; ++w) unsat |= red[w];
+        for (int w = 0; w < nwaves; ++w) unsat |= slot[w];
         const uint64_t newly = uniform64(~unsat & ~done);
         if (newly) {
             if ((newly >> lane) & 1ull) my_iter = it;
-            if (!last && llr_t) {
+            if (!last && want_llr) {
                 // these syndromes stop here: their posteriors are those of THIS iteration (the
                 // check->bit messages of this iteration are still intact in C)
                 const bool mine = (newly >> lane) & 1ull;
                 for (int j = wave; j < n; j += nwaves) {
                     double temp = llr0[j];
                     for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p)
-                        temp += Ct[(size_t)csc_edge[p] * LDPC_WAVE];
-                    if (mine) llr_t[(size_t)j * LDPC_WAVE] = temp;
+                        temp += Ct.ld(l8, csc_edge[p]);
+                    if (mine) Lt.st(l8, j, temp);
                 }
+                __syncthreads();  // C is overwritten by the next check pass
             }
             done |= newly;
         }
         if (done == ~0ull) break;
-        __syncthreads();  // red[] is reused next iteration
     }
 
     if (wave == 0) {
@@ -648,10 +756,13 @@ typedef void (*bp_kernel_t)(const BpArgs);
 
 template <int METHOD>
 static bp_kernel_t pick_kernel(int max_row, int max_col) {
-    const bool r8 = max_row <= 8, c4 = max_col <= 4, c8 = max_col <= 8;
-    if (r8 && c4) return bp_decode_kernel<METHOD, 8, 4>;
-    if (r8 && c8) return bp_decode_kernel<METHOD, 8, 8>;
-    if (c8) return bp_decode_kernel<METHOD, 16, 8>;
+    // register arrays are sized by the template bounds, so the common regular codes get exact fits:
+    // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3, surface-code rows of 4 and columns of 2
+    if (max_row <= 4 && max_col <= 3) return bp_decode_kernel<METHOD, 4, 3>;
+    if (max_row <= 6 && max_col <= 3) return bp_decode_kernel<METHOD, 6, 3>;
+    if (max_row <= 8 && max_col <= 4) return bp_decode_kernel<METHOD, 8, 4>;
+    if (max_row <= 8 && max_col <= 8) return bp_decode_kernel<METHOD, 8, 8>;
+    if (max_col <= 8) return bp_decode_kernel<METHOD, 16, 8>;
     return bp_decode_kernel<METHOD, 16, 16>;  // heavier nodes take the streaming path inside
 }
 

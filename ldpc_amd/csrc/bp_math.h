@@ -1,0 +1,262 @@
+// bp_math.h -- FP64 elementary functions for the product-sum check update on gfx950.
+//
+// The reference evaluates, per edge and per iteration (src_cpp/bp.hpp:205-218),
+//     t = std::tanh(b / 2)          and          c = std::log((1 + x) / (1 - x))
+// with the host libm.  ocml's double-double tanh/log are several hundred instructions each; the two
+// routines below are ~40 FP64 instructions each and are written so that they ROUND like a good libm
+// does, which matters more here than raw ulp counts:
+//
+//   * tanh_half(b) follows the classical expm1 formulation libms use (|x| >= 1: 1 - 2/(expm1(2|x|)+2),
+//     |x| < 1: -e/(e+2) with e = expm1(-2|x|)), because the reference's results depend on how
+//     tanh rounds just below 1.0: x = prod tanh(...) feeds log((1+x)/(1-x)), so one ulp of t near 1
+//     moves a message by ~1e-4.  "1 - q" with an accurately computed small q rounds the way the
+//     exact tanh does; "(1-E)/(1+E)" does not.
+//   * log_pos(q) is the classical s = f/(2+f), log(1+f) = 2 atanh(s) evaluation with the degree-7
+//     minimax polynomial in s^2 (coefficients Lg1..Lg7 from Sun's freely redistributable fdlibm
+//     e_log.c, the published algorithm most libms derive from), error < 1 ulp.
+//
+// Everything is branch-free straight-line code (no per-lane divergence) and is host-compilable so
+// tests/test_device_math.py can measure it against the host libm on the CPU.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#include "bp_libm_tables.h"
+
+#if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
+#define LDPC_HD __host__ __device__ __forceinline__
+#else
+#define LDPC_HD static inline
+#endif
+
+namespace ldpc_math {
+
+LDPC_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// 2^k as a double for k in [-1022, 1023] by exponent construction (no libm call)
+LDPC_HD double pow2i(int k) {
+    const uint64_t bits = (uint64_t)(int64_t)(k + 1023) << 52;
+    double r;
+    memcpy(&r, &bits, sizeof r);
+    return r;
+}
+
+// z = k*ln2 + r, |r| <= ln2/2 (Cody-Waite, ln2 split so that k*ln2_hi is exact); returns expm1(r)
+// (Taylor through r^13: truncation < 2^-56 relative on the reduced interval) and k.
+LDPC_HD double expm1_reduced(double z, int &k) {
+    const double inv_ln2 = 1.44269504088896338700e+00;
+    const double ln2_hi = 6.93147180369123816490e-01;  // 0x3fe62e42fee00000
+    const double ln2_lo = 1.90821492927058770002e-10;  // 0x3dea39ef35793c76
+    const double kf = __builtin_rint(z * inv_ln2);
+    k = (int)kf;
+    double r = fma_(-kf, ln2_hi, z);
+    r = fma_(-kf, ln2_lo, r);
+    double p = 1.0 / 6227020800.0;            // 1/13!
+    p = fma_(p, r, 1.0 / 479001600.0);        // 1/12!
+    p = fma_(p, r, 1.0 / 39916800.0);
+    p = fma_(p, r, 1.0 / 3628800.0);
+    p = fma_(p, r, 1.0 / 362880.0);
+    p = fma_(p, r, 1.0 / 40320.0);
+    p = fma_(p, r, 1.0 / 5040.0);
+    p = fma_(p, r, 1.0 / 720.0);
+    p = fma_(p, r, 1.0 / 120.0);
+    p = fma_(p, r, 1.0 / 24.0);
+    p = fma_(p, r, 1.0 / 6.0);
+    p = fma_(p, r, 0.5);
+    return fma_(p * r, r, r);  // r + r^2 * P(r)
+}
+
+// tanh(b / 2), sign-symmetric, NaN -> NaN, +-inf -> +-1, |b| > ~38.2 -> +-1 exactly.
+LDPC_HD double tanh_half(double b) {
+    double a = __builtin_fabs(b);
+    a = a > 40.0 ? 40.0 : a;       // tanh(20) == 1.0 already; keeps exp in range; NaN stays NaN
+    const bool big = a >= 2.0;     // |b/2| >= 1
+    int k;
+    const double p = expm1_reduced(big ? a : -a, k);
+    const double twok = pow2i(k);  // k in [-3, 58]
+    // big:   e^a + 1        = 2^k p + (2^k + 1)         (one rounding)
+    // small: expm1(-a)      = 2^k p + (2^k - 1)         (one rounding)
+    const double em = fma_(twok, p, twok + (big ? 1.0 : -1.0));
+    const double den = big ? em : em + 2.0;
+    const double num = big ? 2.0 : -em;
+    const double quo = num / den;
+    const double t = big ? 1.0 - quo : quo;
+    return __builtin_copysign(t, b);
+}
+
+// log(q) for q in [0, +inf] (the ratio (1+x)/(1-x) is never negative): 0 -> -inf, +inf -> +inf,
+// NaN -> NaN.  q is never subnormal on this path (q >= 2^-54 when non-zero).
+LDPC_HD double log_pos(double q) {
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits;
+    memcpy(&bits, &q, sizeof bits);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    uint64_t mb = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;  // mantissa in [1, 2)
+    double mant;
+    memcpy(&mant, &mb, sizeof mant);
+    const bool up = mant > 1.41421356237309504880;
+    mant = up ? mant * 0.5 : mant;  // [sqrt(1/2), sqrt(2)]
+    e += up ? 1 : 0;
+    const double f = mant - 1.0;    // exact
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma_(w, fma_(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_(w, fma_(w, fma_(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    r = q == 0.0 ? -INFINITY : r;
+    r = q == INFINITY ? INFINITY : r;
+    r = q != q ? q : r;
+    return r;
+}
+
+// check -> bit product-sum message body (bp.hpp:211-216): log((1 + x) / (1 - x))
+LDPC_HD double ps_log_ratio(double x) { return log_pos((1.0 + x) / (1.0 - x)); }
+
+// =================================================================================================
+// Bit-identical twins of the host libm the reference runs on (x86-64 glibc >= 2.28, FMA-capable CPU).
+//
+// std::tanh there is fdlibm's algorithm on top of fdlibm's expm1 (glibc sysdeps/ieee754/dbl-64/
+// s_tanh.c, s_expm1.c: plain IEEE double operations, no FMA -- there is no multiarch variant), and
+// std::log is the table-driven routine of ARM's optimized-routines (e_log.c, the FMA multiarch build
+// contracts every mul+add).  Both are deterministic sequences of IEEE operations, so repeating the
+// same operations in the same order -- with fma() exactly where the host build fuses -- yields the
+// same bits on a GPU.  tests/test_device_math.py verifies bit-identity against the host libm on
+// tens of millions of arguments; with these two routines the product-sum kernel reproduces the
+// reference's log-probability ratios BIT FOR BIT, which also settles every knife-edge case (a
+// posterior that is exactly 0.0 in the reference stays exactly 0.0 here).
+// Everything is restricted to the arguments the BP update can produce (see each routine).
+// =================================================================================================
+
+LDPC_HD uint64_t as_u64(double x) { uint64_t u; memcpy(&u, &x, sizeof u); return u; }
+LDPC_HD double as_f64(uint64_t u) { double x; memcpy(&x, &u, sizeof x); return x; }
+LDPC_HD double add_exponent(double y, int k) { return as_f64(as_u64(y) + ((uint64_t)(int64_t)k << 52)); }
+
+// fdlibm expm1 for 2^-54 <= |w| < 44 (what tanh hands it): same reduction, polynomial grouping,
+// division and exponent surgery as glibc's __expm1.
+LDPC_HD double expm1_libm(double w) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
+                 Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
+                 Q5 = -2.01099218183624371326e-07;
+    const uint32_t hx = (uint32_t)(as_u64(w) >> 32) & 0x7fffffffu;
+    const bool neg = w < 0.0;
+    int k = 0;
+    if (hx > 0x3fd62e42u) {                       // |w| > 0.5 ln2
+        if (hx < 0x3ff0a2b2u) k = neg ? -1 : 1;   // and |w| < 1.5 ln2
+        else k = (int)(invln2 * w + (neg ? -0.5 : 0.5));
+    }
+    const double t_k = (double)k;
+    const double hi = w - t_k * ln2_hi;  // k = 0: hi = w, lo = 0, c = 0 (identical to the unreduced path)
+    const double lo = t_k * ln2_lo;
+    const double x = hi - lo;
+    const double c = (hi - x) - lo;
+    const double hfx = 0.5 * x;
+    const double hxs = x * hfx;
+    const double R1 = 1.0 + hxs * Q1, h2 = hxs * hxs;
+    const double R2 = Q2 + hxs * Q3, h4 = h2 * h2;
+    const double R3 = Q4 + hxs * Q5;
+    const double r1 = R1 + h2 * R2 + h4 * R3;
+    const double t = 3.0 - r1 * hfx;
+    double e = hxs * ((r1 - t) / (6.0 - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5 * (x - e) - 0.5;
+    if (k == 1) return x < -0.25 ? -2.0 * (e - (x + 0.5)) : 1.0 + 2.0 * (x - e);
+    if (k <= -2 || k > 56) {
+        const double y = add_exponent(1.0 - (e - x), k);
+        return y - 1.0;
+    }
+    if (k < 20) {
+        const double tt = as_f64((uint64_t)(0x3ff00000u - (0x200000u >> k)) << 32);  // 1 - 2^-k
+        return add_exponent(tt - (e - x), k);
+    }
+    const double tt = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);         // 2^-k
+    return add_exponent((x - (e + tt)) + 1.0, k);
+}
+
+// std::tanh(b / 2) exactly as glibc evaluates it (s_tanh.c), any double b.
+LDPC_HD double tanh_half_libm(double b) {
+    const double x = b * 0.5;  // == b / 2
+    const double ax = __builtin_fabs(x);
+    double z;
+    if (!(ax < 22.0)) {
+        z = (x != x) ? x + x : 1.0;                // NaN -> NaN; |x| >= 22 and +-inf -> 1
+    } else if (ax < 0x1p-55) {
+        return x * (1.0 + x);                      // tiny (also +-0)
+    } else if (ax >= 1.0) {
+        const double t = expm1_libm(2.0 * ax);
+        z = 1.0 - 2.0 / (t + 2.0);
+    } else {
+        const double t = expm1_libm(-2.0 * ax);
+        z = -t / (t + 2.0);
+    }
+    return __builtin_signbit(x) ? -z : z;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double k_log_tab[256] = LDPC_LOG_TAB;
+#elif !defined(__HIPCC__)
+static const double k_log_tab[256] = LDPC_LOG_TAB;
+#endif
+
+// std::log(q) exactly as glibc's FMA build evaluates it, for q in [0, +inf] or NaN, q not subnormal.
+LDPC_HD double log_libm(double q) {
+#if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
+    return q;  // host pass of hipcc: never called
+#else
+    const double A[5] = LDPC_LOG_POLY;
+    const double B[11] = LDPC_LOG_POLY1;
+    const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    const uint64_t ix = as_u64(q);
+    const uint64_t LO = 0x3fee000000000000ull;  // asuint64(1.0 - 0x1p-4)
+    const uint64_t HI = 0x3ff1090000000000ull;  // asuint64(1.0 + 0x1.09p-4)
+    if (ix - LO < HI - LO) {
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        const double r = q - 1.0, r2 = r * r, r3 = r * r2;
+        const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_(r, B[8], B[7])));
+        const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_(r, B[5], B[4])));
+        const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_(r, B[2], B[1])));
+        double w = r * 0x1p27;
+        const double rhi = r + w - w;
+        const double rlo = r - rhi;
+        w = rhi * rhi * B[0];  // B[0] == -0.5
+        const double hi = r + w;
+        double lo = r - hi + w;
+        lo = fma_(B[0] * rlo, rhi + r, lo);
+        return fma_(r3, p1, lo) + hi;
+    }
+    if (q == 0.0) return -INFINITY;
+    if (!(q < INFINITY)) return q;  // +inf -> +inf, NaN -> NaN
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)((tmp >> (52 - LDPC_LOG_TABLE_BITS)) & 127);
+    const int64_t k = (int64_t)tmp >> 52;
+    const double z = as_f64(ix - (tmp & (0xfffull << 52)));
+    const double invc = k_log_tab[2 * i], logc = k_log_tab[2 * i + 1];
+    const double r = fma_(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = fma_(kd, Ln2hi, logc);
+    const double hi = w + r;
+    const double lo = fma_(kd, Ln2lo, w - hi + r);
+    const double r2 = r * r;
+    const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
+    return fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
+#endif
+}
+
+// std::log((1 + x) / (1 - x)) with the host libm's bits (correctly rounded IEEE division)
+LDPC_HD double ps_log_ratio_libm(double x) { return log_libm((1.0 + x) / (1.0 - x)); }
+
+}  // namespace ldpc_math

@@ -191,3 +191,17 @@ class RefBp:
         out = np.zeros(self.m, np.uint8)
         self.lib.ref_bp_mulvec(self._h, np.ascontiguousarray(v, np.uint8), out)
         return out
+
+
+def llr_close(got, want, rtol=1e-5) -> bool:
+    """north_star tolerance: LLRs within ``rtol`` RELATIVE of the reference; non-finite entries must
+    match in kind (NaN with NaN, +inf with +inf, -inf with -inf)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    fin = np.isfinite(want)
+    if not np.array_equal(fin, np.isfinite(got)) or not np.array_equal(np.isnan(want), np.isnan(got)):
+        return False
+    inf = np.isinf(want)
+    if not np.array_equal(np.sign(want[inf]), np.sign(got[inf])):
+        return False
+    return bool(np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin])))

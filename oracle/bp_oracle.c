@@ -65,7 +65,17 @@ typedef struct {
     double *b2c, *c2b;          /* per CSR edge: BpEntry::bit_to_check_msg / check_to_bit_msg (bp.hpp:42-48) */
     double *llr0;               /* initial_log_prob_ratios (bp.hpp:66) */
     uint8_t *cand;              /* candidate_syndrome (bp.hpp:63) */
+    /* Optional substitutes for tanh(b/2) and log((1+x)/(1-x)): tests plug the DEVICE math routines
+     * (ldpc_amd/csrc/bp_math.h, compiled for the host) in here to predict on the CPU what the HIP
+     * kernel computes.  NULL (the default) = the reference's libm expressions, untouched. */
+    double (*tanh_half)(double);
+    double (*log_ratio)(double);
 } bp_oracle;
+
+void bp_oracle_set_math(bp_oracle *o, double (*tanh_half)(double), double (*log_ratio)(double)) {
+    o->tanh_half = tanh_half;
+    o->log_ratio = log_ratio;
+}
 
 void bp_oracle_free(bp_oracle *o) {
     if (!o) return;
@@ -134,14 +144,15 @@ void bp_oracle_decode(bp_oracle *o, const double *channel_probs, int max_iter, i
                 double temp = 1.0;
                 for (int e = lo; e < hi; e++) {
                     o->c2b[e] = temp;
-                    temp *= tanh(o->b2c[e] / 2);
+                    temp *= o->tanh_half ? o->tanh_half(o->b2c[e]) : tanh(o->b2c[e] / 2);
                 }
                 temp = 1;
                 for (int e = hi - 1; e >= lo; e--) {
                     o->c2b[e] *= temp;
                     int message_sign = syndrome[i] != 0u ? -1 : 1;
-                    o->c2b[e] = message_sign * log((1 + o->c2b[e]) / (1 - o->c2b[e]));
-                    temp *= tanh(o->b2c[e] / 2);
+                    o->c2b[e] = message_sign * (o->log_ratio ? o->log_ratio(o->c2b[e])
+                                                             : log((1 + o->c2b[e]) / (1 - o->c2b[e])));
+                    temp *= o->tanh_half ? o->tanh_half(o->b2c[e]) : tanh(o->b2c[e] / 2);
                 }
             }
         } else { /* bp.hpp:220-273 */

@@ -63,22 +63,7 @@ def load_case(name: str) -> dict:
     )
 
 
-def llr_close(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5) -> bool:
-    """north_star tolerance: posterior log-probability ratios within 1e-5 RELATIVE of the reference.
-
-    Non-finite entries must match exactly in kind (NaN with NaN, +inf with +inf, -inf with -inf).
-    """
-    got = np.asarray(got, np.float64)
-    want = np.asarray(want, np.float64)
-    fin = np.isfinite(want)
-    if not np.array_equal(fin, np.isfinite(got)):
-        return False
-    if not np.array_equal(np.isnan(want), np.isnan(got)):
-        return False
-    inf = np.isinf(want)
-    if not np.array_equal(np.sign(want[inf]), np.sign(got[inf])):
-        return False
-    return bool(np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin])))
+from oracle import llr_close  # noqa: E402,F401  (single definition of the tolerance rule)
 
 
 def rowsum(llr: np.ndarray) -> np.ndarray:
