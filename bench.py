@@ -45,6 +45,7 @@ def main() -> None:
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="syndromes for the CPU baseline (-1 = 3 per host thread, 0 = skip)")
+    ap.add_argument("--math", default="libm_exact", choices=["libm_exact", "fast"], help="device tanh/log (include/ldpc_hip.h)")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     args = ap.parse_args()
 
@@ -77,6 +78,7 @@ def main() -> None:
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), args.max_iter, 0, 1.0, device=local_rank)
     if args.waves:
         eng.set_tuning(waves_per_workgroup=args.waves)
+    eng.set_math(args.math)
 
     # inputs resident in HBM before the timed region; this rank's shard of the global shot stream
     synd = eng.gen_bsc_syndromes(7, args.p, shot0=rank * B, shots=B, device=dev)
@@ -134,7 +136,7 @@ def main() -> None:
                 "batch_per_gpu": B, "global_batch": total, "p": args.p, "max_iter": args.max_iter,
                 "outputs": "decoding u8, log_prob_ratios f64, iterations i32, converge u8" if llr is not None else "no LLR",
                 "parallelism": f"batch-sharded x{world}, one gather of decoded rows" if world > 1 else "single GPU",
-                "mean_iterations": float(iters.mean()), "converged_fraction": float(conv.mean()),
+                "device_math": args.math, "mean_iterations": float(iters.mean()), "converged_fraction": float(conv.mean()),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

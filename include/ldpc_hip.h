@@ -128,8 +128,21 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms);
  * 2 * 8 * nnz bytes per syndrome). */
 int64_t ldpc_hip_bp_workspace_bytes(const ldpc_hip_bp *h, int64_t batch);
 
-/* Tuning knobs (0 = library default): waves per workgroup of the BP kernel. */
-int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t reserved);
+/* Tuning knobs (0 = library default): wavefronts per workgroup of the BP kernel (1..16) and the
+ * largest number of 64-syndrome tiles decoded per launch (bounds the workspace). */
+int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t max_chunk_tiles);
+
+/*
+ * How the product-sum update evaluates std::tanh / std::log of bp.hpp:208-217 on the device:
+ *   LDPC_HIP_MATH_LIBM_EXACT (default): re-implementations of the host glibc's tanh (fdlibm expm1
+ *       based) and log (table driven, FMA build) that are bit-identical to them, so log_prob_ratios
+ *       equal the reference's to the last bit (as min-sum's always do);
+ *   LDPC_HIP_MATH_FAST: ~1-ulp routines, ~40 % fewer FP64 operations; hard decisions identical
+ *       except on exact ties of the reference's posterior, LLRs within the 1e-5 relative tolerance.
+ */
+#define LDPC_HIP_MATH_LIBM_EXACT 0
+#define LDPC_HIP_MATH_FAST 1
+int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);
 
 const char *ldpc_hip_last_error(void);
 const char *ldpc_hip_version(void);

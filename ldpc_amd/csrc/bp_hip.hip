@@ -42,11 +42,8 @@
 #include "../../include/ldpc_hip.h"
 #include "bp_math.h"
 
-// LDPC_MATH: 0 = ocml tanh/log, 1 = fast ~1-ulp routines, 2 = bit-identical twins of the host glibc
-// the reference runs on (default: product-sum LLRs then match the reference bit for bit)
-#ifndef LDPC_MATH
-#define LDPC_MATH 2
-#endif
+// math modes of the product-sum kernel (ldpc_hip_bp_set_math): 0 = bit-identical twins of the host
+// glibc the reference runs on (default), 1 = fast ~1-ulp routines (bp_math.h)
 
 #define LDPC_WAVE 64  // gfx950 wavefront; also the tile width (syndromes per workgroup)
 
@@ -119,26 +116,16 @@ __device__ __forceinline__ MsgBuf make_msgbuf(double *base, unsigned rows) {
 
 // check -> bit, product-sum, one lane: message_sign * log((1 + x) / (1 - x))  (bp.hpp:211-216),
 // x = (exclusive prefix product) * (exclusive suffix product) of the tanh values of the row
+template <int MATH>
 __device__ __forceinline__ double ps_message(double x, bool negate) {
-#if LDPC_MATH == 0
-    double c = log((1.0 + x) / (1.0 - x));
-#elif LDPC_MATH == 1
-    double c = ldpc_math::ps_log_ratio(x);
-#else
-    double c = ldpc_math::ps_log_ratio_libm(x);
-#endif
+    const double c = MATH == 0 ? ldpc_math::ps_log_ratio_libm(x) : ldpc_math::ps_log_ratio(x);
     return negate ? -c : c;
 }
 
-// tanh(b / 2) of bp.hpp:208,217 (b / 2 == b * 0.5 exactly)
+// tanh(b / 2) of bp.hpp:208,217
+template <int MATH>
 __device__ __forceinline__ double ps_tanh_half(double b) {
-#if LDPC_MATH == 0
-    return tanh(b * 0.5);
-#elif LDPC_MATH == 1
-    return ldpc_math::tanh_half(b);
-#else
-    return ldpc_math::tanh_half_libm(b);
-#endif
+    return MATH == 0 ? ldpc_math::tanh_half_libm(b) : ldpc_math::tanh_half(b);
 }
 
 // Keeps the scheduler from interleaving the (independent) per-edge transcendental chains: each chain
@@ -150,12 +137,12 @@ __device__ __forceinline__ double ps_tanh_half(double b) {
 // reads; evaluating it in the BIT pass puts half of the transcendental work next to each of the two
 // memory passes), min-sum stores b2c itself.  Same value either way: one tanh per edge per iteration
 // of the same argument the reference uses (it evaluates it twice, bp.hpp:208 and :217).
-template <int METHOD>
+template <int METHOD, int MATH>
 __device__ __forceinline__ double edge_form(double b2c) {
-    return METHOD == LDPC_HIP_PRODUCT_SUM ? ps_tanh_half(b2c) : b2c;
+    return METHOD == LDPC_HIP_PRODUCT_SUM ? ps_tanh_half<MATH>(b2c) : b2c;
 }
 
-template <int METHOD, int DR, int DC>
+template <int METHOD, int MATH, int DR, int DC>
 __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront in the bit pass
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
@@ -188,7 +175,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
 
     // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
-    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD>(llr0[col_idx[e]]));
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(llr0[col_idx[e]]));
     __syncthreads();
 
     for (int it = 1; it <= a.max_iter; ++it) {
@@ -235,7 +222,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 #pragma unroll
                     for (int k = DR - 1; k >= 0; --k)
                         if (k < d) {
-                            Ct.st(l8, rs + k, ps_message(pre[k] * temp, neg));
+                            Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg));
                             temp *= cur[k];
                             LDPC_EDGE_FENCE();
                         }
@@ -247,7 +234,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     }
                     temp = 1.0;
                     for (int k = d - 1; k >= 0; --k) {
-                        Ct.st(l8, rs + k, ps_message(Ct.ld(l8, rs + k) * temp, neg));
+                        Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg));
                         temp *= At.ld(l8, rs + k);
                     }
                 }
@@ -348,7 +335,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 #pragma unroll
                     for (int k = DC - 1; k >= 0; --k)
                         if (k < dg[u]) {
-                            At.st(l8, e[u][k], edge_form<METHOD>(pre[k] + s));
+                            At.st(l8, e[u][k], edge_form<METHOD, MATH>(pre[k] + s));
                             s += c[u][k];
                             if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
                         }
@@ -363,7 +350,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     double s = 0.0;
                     for (int k = dg[u] - 1; k >= 0; --k) {
                         const int ee = csc_edge[cs[u] + k];
-                        At.st(l8, ee, edge_form<METHOD>(At.ld(l8, ee) + s));
+                        At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + s));
                         s += Ct.ld(l8, ee);
                     }
                 }
@@ -559,6 +546,7 @@ struct ldpc_hip_bp {
     double ms_scaling_factor = 1.0;
     int32_t max_row_deg = 0, max_col_deg = 0;
     int32_t waves_per_wg = 0;  // 0 = auto
+    int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
     std::vector<double> channel_probs;
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
@@ -609,6 +597,8 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (d->max_iter < 1) return fail(LDPC_HIP_ERR_INVALID, "max_iter must be >= 1");
     if (d->bp_method != LDPC_HIP_PRODUCT_SUM && d->bp_method != LDPC_HIP_MINIMUM_SUM)
         return fail(LDPC_HIP_ERR_INVALID, "bp_method must be 0 (product_sum) or 1 (minimum_sum)");
+    if (d->nnz >= (1 << 23) || d->n >= (1 << 23))  // one buffer descriptor spans a tile: rows * 512 B < 4 GiB
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "matrices with nnz or n >= 2^23 are not supported");
     int32_t max_row = 0;
     for (int i = 0; i < d->m; ++i) {
         const int lo = d->csr_row_ptr[i], hi = d->csr_row_ptr[i + 1];
@@ -731,6 +721,14 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_wg, int32_t max_chu
     return LDPC_HIP_OK;
 }
 
+int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (math_mode != LDPC_HIP_MATH_LIBM_EXACT && math_mode != LDPC_HIP_MATH_FAST)
+        return fail(LDPC_HIP_ERR_INVALID, "math_mode must be 0 (libm-exact) or 1 (fast)");
+    h->math_mode = math_mode;
+    return LDPC_HIP_OK;
+}
+
 int64_t ldpc_hip_bp_workspace_bytes(const ldpc_hip_bp *h, int64_t batch) {
     if (!h || batch < 0) return -1;
     const int64_t tiles = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
@@ -754,16 +752,16 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
 
 typedef void (*bp_kernel_t)(const BpArgs);
 
-template <int METHOD>
+template <int METHOD, int MATH>
 static bp_kernel_t pick_kernel(int max_row, int max_col) {
     // register arrays are sized by the template bounds, so the common regular codes get exact fits:
     // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3, surface-code rows of 4 and columns of 2
-    if (max_row <= 4 && max_col <= 3) return bp_decode_kernel<METHOD, 4, 3>;
-    if (max_row <= 6 && max_col <= 3) return bp_decode_kernel<METHOD, 6, 3>;
-    if (max_row <= 8 && max_col <= 4) return bp_decode_kernel<METHOD, 8, 4>;
-    if (max_row <= 8 && max_col <= 8) return bp_decode_kernel<METHOD, 8, 8>;
-    if (max_col <= 8) return bp_decode_kernel<METHOD, 16, 8>;
-    return bp_decode_kernel<METHOD, 16, 16>;  // heavier nodes take the streaming path inside
+    if (max_row <= 4 && max_col <= 3) return bp_decode_kernel<METHOD, MATH, 4, 3>;
+    if (max_row <= 6 && max_col <= 3) return bp_decode_kernel<METHOD, MATH, 6, 3>;
+    if (max_row <= 8 && max_col <= 4) return bp_decode_kernel<METHOD, MATH, 8, 4>;
+    if (max_row <= 8 && max_col <= 8) return bp_decode_kernel<METHOD, MATH, 8, 8>;
+    if (max_col <= 8) return bp_decode_kernel<METHOD, MATH, 16, 8>;
+    return bp_decode_kernel<METHOD, MATH, 16, 16>;  // heavier nodes take the streaming path inside
 }
 
 // Everything below runs on h->stream with device pointers only.
@@ -796,9 +794,10 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
 
-    bp_kernel_t kern = h->bp_method == LDPC_HIP_PRODUCT_SUM
-                           ? pick_kernel<LDPC_HIP_PRODUCT_SUM>(h->max_row_deg, h->max_col_deg)
-                           : pick_kernel<LDPC_HIP_MINIMUM_SUM>(h->max_row_deg, h->max_col_deg);
+    bp_kernel_t kern;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
+    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
     h->accumulated_ms = 0.f;
     h->timed = false;
     hipStream_t st = h->stream;

@@ -15,7 +15,7 @@
 //     minimax polynomial in s^2 (coefficients Lg1..Lg7 from Sun's freely redistributable fdlibm
 //     e_log.c, the published algorithm most libms derive from), error < 1 ulp.
 //
-// Everything is branch-free straight-line code (no per-lane divergence) and is host-compilable so
+// Everything is (nearly) straight-line code (no per-lane divergence) and is host-compilable so
 // tests/test_device_math.py can measure it against the host libm on the CPU.
 #pragma once
 
@@ -142,8 +142,11 @@ LDPC_HD uint64_t as_u64(double x) { uint64_t u; memcpy(&u, &x, sizeof u); return
 LDPC_HD double as_f64(uint64_t u) { double x; memcpy(&x, &u, sizeof x); return x; }
 LDPC_HD double add_exponent(double y, int k) { return as_f64(as_u64(y) + ((uint64_t)(int64_t)k << 52)); }
 
-// fdlibm expm1 for 2^-54 <= |w| < 44 (what tanh hands it): same reduction, polynomial grouping,
-// division and exponent surgery as glibc's __expm1.
+// fdlibm expm1 (glibc __expm1) restricted to what tanh hands it: w in [2, 44] or w in (-2, -2^-54].
+// Straight-line: every k-dependent tail of the original is evaluated and the right one selected, so a
+// wavefront whose lanes fall into different ranges does not serialise (each tail is 3-5 operations,
+// a divergent branch costs more).  Per lane the selected value is computed by exactly the original's
+// operations.  (k == 1 cannot occur on this domain and is not provided.)
 LDPC_HD double expm1_libm(double w) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
@@ -152,11 +155,9 @@ LDPC_HD double expm1_libm(double w) {
                  Q5 = -2.01099218183624371326e-07;
     const uint32_t hx = (uint32_t)(as_u64(w) >> 32) & 0x7fffffffu;
     const bool neg = w < 0.0;
-    int k = 0;
-    if (hx > 0x3fd62e42u) {                       // |w| > 0.5 ln2
-        if (hx < 0x3ff0a2b2u) k = neg ? -1 : 1;   // and |w| < 1.5 ln2
-        else k = (int)(invln2 * w + (neg ? -0.5 : 0.5));
-    }
+    int k = (int)(invln2 * w + (neg ? -0.5 : 0.5));
+    k = hx < 0x3ff0a2b2u ? (neg ? -1 : 1) : k;  // 0.5 ln2 < |w| < 1.5 ln2
+    k = hx > 0x3fd62e42u ? k : 0;               // |w| <= 0.5 ln2: no reduction
     const double t_k = (double)k;
     const double hi = w - t_k * ln2_hi;  // k = 0: hi = w, lo = 0, c = 0 (identical to the unreduced path)
     const double lo = t_k * ln2_lo;
@@ -169,41 +170,40 @@ LDPC_HD double expm1_libm(double w) {
     const double R3 = Q4 + hxs * Q5;
     const double r1 = R1 + h2 * R2 + h4 * R3;
     const double t = 3.0 - r1 * hfx;
-    double e = hxs * ((r1 - t) / (6.0 - x * t));
-    if (k == 0) return x - (x * e - hxs);
-    e = (x * (e - c) - c);
+    const double e0 = hxs * ((r1 - t) / (6.0 - x * t));
+    const double res_k0 = x - (x * e0 - hxs);
+    double e = (x * (e0 - c) - c);
     e -= hxs;
-    if (k == -1) return 0.5 * (x - e) - 0.5;
-    if (k == 1) return x < -0.25 ? -2.0 * (e - (x + 0.5)) : 1.0 + 2.0 * (x - e);
-    if (k <= -2 || k > 56) {
-        const double y = add_exponent(1.0 - (e - x), k);
-        return y - 1.0;
-    }
-    if (k < 20) {
-        const double tt = as_f64((uint64_t)(0x3ff00000u - (0x200000u >> k)) << 32);  // 1 - 2^-k
-        return add_exponent(tt - (e - x), k);
-    }
-    const double tt = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);         // 2^-k
-    return add_exponent((x - (e + tt)) + 1.0, k);
+    const double res_m1 = 0.5 * (x - e) - 0.5;
+    const double emx = e - x;
+    const double res_far = add_exponent(1.0 - emx, k) - 1.0;                           // k <= -2 or k > 56
+    const int ks = k < 0 ? 0 : (k > 31 ? 31 : k);                                      // shift guard only
+    const double one_m = as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ks)) << 32);    // 1 - 2^-k
+    const double res_lt20 = add_exponent(one_m - emx, k);                              // 2 <= k < 20
+    const double two_mk = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);       // 2^-k
+    const double res_ge20 = add_exponent((x - (e + two_mk)) + 1.0, k);                 // 20 <= k <= 56
+    double r = res_far;
+    r = (k >= 2 && k < 20) ? res_lt20 : r;
+    r = (k >= 20 && k <= 56) ? res_ge20 : r;
+    r = k == -1 ? res_m1 : r;
+    r = k == 0 ? res_k0 : r;
+    return r;
 }
 
-// std::tanh(b / 2) exactly as glibc evaluates it (s_tanh.c), any double b.
+// std::tanh(b / 2) exactly as glibc evaluates it (s_tanh.c), any double b; straight-line.
 LDPC_HD double tanh_half_libm(double b) {
     const double x = b * 0.5;  // == b / 2
     const double ax = __builtin_fabs(x);
-    double z;
-    if (!(ax < 22.0)) {
-        z = (x != x) ? x + x : 1.0;                // NaN -> NaN; |x| >= 22 and +-inf -> 1
-    } else if (ax < 0x1p-55) {
-        return x * (1.0 + x);                      // tiny (also +-0)
-    } else if (ax >= 1.0) {
-        const double t = expm1_libm(2.0 * ax);
-        z = 1.0 - 2.0 / (t + 2.0);
-    } else {
-        const double t = expm1_libm(-2.0 * ax);
-        z = -t / (t + 2.0);
-    }
-    return __builtin_signbit(x) ? -z : z;
+    const double axc = ax < 22.0 ? ax : 22.0;      // keeps the speculative main path in range (NaN -> 22)
+    const bool big = axc >= 1.0;
+    const double t = expm1_libm(big ? 2.0 * axc : -2.0 * axc);
+    const double quo = (big ? 2.0 : -t) / (t + 2.0);
+    double z = big ? 1.0 - quo : quo;              // 1 - 2/(t+2)   |   -t/(t+2)
+    z = ax < 22.0 ? z : 1.0;                        // |x| >= 22, +-inf
+    z = __builtin_signbit(x) ? -z : z;
+    z = ax < 0x1p-55 ? x * (1.0 + x) : z;           // tiny and +-0 (carries its own sign)
+    z = x != x ? x + x : z;                         // NaN
+    return z;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -223,8 +223,8 @@ LDPC_HD double log_libm(double q) {
     const uint64_t ix = as_u64(q);
     const uint64_t LO = 0x3fee000000000000ull;  // asuint64(1.0 - 0x1p-4)
     const uint64_t HI = 0x3ff1090000000000ull;  // asuint64(1.0 + 0x1.09p-4)
+    double y;
     if (ix - LO < HI - LO) {
-        if (ix == 0x3ff0000000000000ull) return 0.0;
         const double r = q - 1.0, r2 = r * r, r3 = r * r2;
         const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_(r, B[8], B[7])));
         const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_(r, B[5], B[4])));
@@ -236,23 +236,26 @@ LDPC_HD double log_libm(double q) {
         const double hi = r + w;
         double lo = r - hi + w;
         lo = fma_(B[0] * rlo, rhi + r, lo);
-        return fma_(r3, p1, lo) + hi;
+        y = fma_(r3, p1, lo) + hi;
+        y = ix == 0x3ff0000000000000ull ? 0.0 : y;  // log(1) = +0 exactly
+    } else {
+        const uint64_t tmp = ix - 0x3fe6000000000000ull;
+        const int i = (int)((tmp >> (52 - LDPC_LOG_TABLE_BITS)) & 127);
+        const int64_t k = (int64_t)tmp >> 52;
+        const double z = as_f64(ix - (tmp & (0xfffull << 52)));
+        const double invc = k_log_tab[2 * i], logc = k_log_tab[2 * i + 1];
+        const double r = fma_(z, invc, -1.0);
+        const double kd = (double)k;
+        const double w = fma_(kd, Ln2hi, logc);
+        const double hi = w + r;
+        const double lo = fma_(kd, Ln2lo, w - hi + r);
+        const double r2 = r * r;
+        const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
+        y = fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
+        y = q == 0.0 ? -INFINITY : y;
+        y = q < INFINITY ? y : q;  // +inf -> +inf, NaN -> NaN
     }
-    if (q == 0.0) return -INFINITY;
-    if (!(q < INFINITY)) return q;  // +inf -> +inf, NaN -> NaN
-    const uint64_t tmp = ix - 0x3fe6000000000000ull;
-    const int i = (int)((tmp >> (52 - LDPC_LOG_TABLE_BITS)) & 127);
-    const int64_t k = (int64_t)tmp >> 52;
-    const double z = as_f64(ix - (tmp & (0xfffull << 52)));
-    const double invc = k_log_tab[2 * i], logc = k_log_tab[2 * i + 1];
-    const double r = fma_(z, invc, -1.0);
-    const double kd = (double)k;
-    const double w = fma_(kd, Ln2hi, logc);
-    const double hi = w + r;
-    const double lo = fma_(kd, Ln2lo, w - hi + r);
-    const double r2 = r * r;
-    const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
-    return fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
+    return y;
 #endif
 }
 

@@ -69,6 +69,11 @@ class HipBpEngine:
     def set_tuning(self, waves_per_workgroup=0, max_chunk_tiles=0):
         _lib.check(self._lib.ldpc_hip_bp_set_tuning(self._h, int(waves_per_workgroup), int(max_chunk_tiles)))
 
+    def set_math(self, mode):
+        """'libm_exact' (default, bit-identical LLRs) or 'fast' (~1 ulp); see include/ldpc_hip.h."""
+        code = {"libm_exact": 0, "exact": 0, 0: 0, "fast": 1, 1: 1}[mode]
+        _lib.check(self._lib.ldpc_hip_bp_set_math(self._h, code))
+
     def workspace_bytes(self, batch):
         return int(self._lib.ldpc_hip_bp_workspace_bytes(self._h, int(batch)))
 

@@ -205,3 +205,14 @@ def llr_close(got, want, rtol=1e-5) -> bool:
     if not np.array_equal(np.sign(want[inf]), np.sign(got[inf])):
         return False
     return bool(np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin])))
+
+
+def bits_equal(a, b) -> bool:
+    """Bit-identical float64 arrays, except that any NaN matches any NaN (the sign/payload of a NaN
+    is not a result: it depends on operand order inside inf - inf)."""
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    if a.shape != b.shape:
+        return False
+    same = a.view(np.uint64) == b.view(np.uint64)
+    return bool(np.all(same | (np.isnan(a) & np.isnan(b))))

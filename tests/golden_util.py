@@ -63,7 +63,7 @@ def load_case(name: str) -> dict:
     )
 
 
-from oracle import llr_close  # noqa: E402,F401  (single definition of the tolerance rule)
+from oracle import bits_equal, llr_close  # noqa: E402,F401  (single definition of the comparison rules)
 
 
 def rowsum(llr: np.ndarray) -> np.ndarray:

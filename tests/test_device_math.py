@@ -91,11 +91,7 @@ def test_special_values(dm):
     assert lr(np.nextafter(1.0, 0.0)) == np.log(2.0 / 2.0 ** -53 - 1.0) or abs(lr(np.nextafter(1.0, 0.0)) - 37.42994775023705) < 1e-13
 
 
-def _bits_equal(a, b):
-    """Bit-identical, except that any NaN matches any NaN (payload/sign of a NaN is not a result)."""
-    a, b = np.asarray(a), np.asarray(b)
-    same = a.view(np.uint64) == b.view(np.uint64)
-    return bool(np.all(same | (np.isnan(a) & np.isnan(b))))
+from golden_util import bits_equal as _bits_equal  # noqa: E402
 
 
 def test_libm_twins_are_bit_identical_to_the_host_libm(dm):

@@ -1,13 +1,19 @@
 """GPU parity: the HIP path (through the C ABI) against the reference's captured outputs and the oracle.
 
 Bar (BASELINE.json north_star): hard decisions, converge flags and iteration counts bit-exact;
-posterior log-probability ratios within 1e-5 RELATIVE (min-sum: bit-exact, it has no transcendental).
+posterior log-probability ratios within 1e-5 RELATIVE.  The kernels do better than the bar: min-sum
+has no transcendental and the default product-sum math is a bit-identical twin of the host glibc
+the reference runs on (ldpc_amd/csrc/bp_math.h), so against the GOLDEN vectors (captured from the
+real reference in the build container) LLRs are asserted BIT-EXACT for both methods.  Against the
+oracle, which calls the libm of whatever host runs the test, product-sum LLRs are asserted bit-exact
+when that libm is the same glibc and within 1e-5 otherwise.  The optional fast math mode is held
+to the north_star tolerance.
 Nothing here reads /root/reference; oracle/ is used only as the checker.
 """
 import numpy as np
 import pytest
 
-from golden_util import case_names, load_case, llr_close, rowsum
+from golden_util import bits_equal, case_names, load_case, llr_close, rowsum
 
 pytestmark = pytest.mark.gpu
 
@@ -20,6 +26,11 @@ def _engine(c, **over):
     return HipBpEngine(h.indptr, h.indices, c["n"], over.get("channel_probs", c["channel_probs"]),
                        over.get("max_iter", c["max_iter"]), 0 if c["bp_method"] == "product_sum" else 1,
                        c["ms_scaling_factor"])
+
+
+def _host_libm_is_glibc():
+    import platform
+    return platform.machine() == "x86_64" and platform.libc_ver()[0] == "glibc"
 
 
 def _synd(h, p, seed, shots, shot0=0):
@@ -38,11 +49,25 @@ def test_golden_fixture(name):
     assert np.array_equal(cv, c["converge"]), "converge flags differ from the reference"
     assert np.array_equal(it, c["iterations"]), "iteration counts differ from the reference"
     k = len(c["llr"])
-    if c["bp_method"] == "minimum_sum":
-        assert np.array_equal(llr[:k].view(np.uint64), c["llr"].view(np.uint64)), "min-sum LLRs must be bit-exact"
-    else:
-        assert llr_close(llr[:k], c["llr"], rtol=LLR_RTOL)
-    assert np.allclose(rowsum(llr), c["llr_rowsum"], rtol=1e-6, atol=1e-6)
+    assert llr_close(llr[:k], c["llr"], rtol=LLR_RTOL)          # the north_star bar
+    assert bits_equal(llr[:k], c["llr"]), "LLRs are expected to match the reference bit for bit"
+    assert np.allclose(rowsum(llr), c["llr_rowsum"], rtol=1e-12, atol=1e-12)
+
+
+KNIFE_EDGE = {"edge_degree1_empty_ps"}  # reference posterior exactly 0.0: only the libm-exact mode reproduces it
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if n not in KNIFE_EDGE])
+def test_golden_fixture_fast_math(name):
+    """Optional fast math (ldpc_hip_bp_set_math(1)): exact decisions/flags/iterations, LLRs within 1e-5."""
+    c = load_case(name)
+    eng = _engine(c)
+    eng.set_math("fast")
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+    assert np.array_equal(dec, c["decoding"])
+    assert np.array_equal(cv, c["converge"])
+    assert np.array_equal(it, c["iterations"])
+    assert llr_close(llr[: len(c["llr"])], c["llr"], rtol=LLR_RTOL)
 
 
 def test_golden_through_device_pointers():
@@ -96,10 +121,9 @@ def test_against_oracle_on_seeded_batches(code, p, max_iter, method, alpha, shot
     assert np.array_equal(dec, wd)
     assert np.array_equal(cv, wc)
     assert np.array_equal(it, wi)
-    if method == "minimum_sum":
-        assert np.array_equal(llr.view(np.uint64), wl.view(np.uint64))
-    else:
-        assert llr_close(llr, wl, rtol=LLR_RTOL)
+    assert llr_close(llr, wl, rtol=LLR_RTOL)
+    if method == "minimum_sum" or _host_libm_is_glibc():
+        assert bits_equal(llr, wl)
     # property: a converged row reproduces its syndrome (bp.hpp:300-302)
     chk = (dec.astype(np.int64) @ h.T.toarray().astype(np.int64)) % 2
     assert np.array_equal(chk[cv], synd[cv])
@@ -130,7 +154,7 @@ def test_chunked_batches_match_single_launch(oracle_built):
     eng.set_tuning(max_chunk_tiles=3)
     d1, l1, i1, c1 = eng.decode_batch(synd)
     assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1)
-    assert np.array_equal(l0.view(np.uint64), l1.view(np.uint64))
+    assert bits_equal(l0, l1)
 
 
 def test_batch_independence_and_determinism():
@@ -144,10 +168,10 @@ def test_batch_independence_and_determinism():
     perm = np.random.default_rng(0).permutation(500)
     d1, l1, i1, c1 = eng.decode_batch(synd[perm])
     assert np.array_equal(d0[perm], d1) and np.array_equal(i0[perm], i1) and np.array_equal(c0[perm], c1)
-    assert np.array_equal(l0[perm].view(np.uint64), l1.view(np.uint64))
+    assert bits_equal(l0[perm], l1)
     d2, l2, i2, c2 = eng.decode_batch(np.repeat(synd[:7], 40, axis=0))
     assert np.array_equal(d2, np.repeat(d0[:7], 40, axis=0))
-    assert np.array_equal(l2.view(np.uint64), np.repeat(l0[:7], 40, axis=0).view(np.uint64))
+    assert bits_equal(l2, np.repeat(l0[:7], 40, axis=0))
 
 
 def test_empty_and_single_row_batches():
@@ -175,7 +199,7 @@ def test_channel_and_parameter_updates(oracle_built):
                                            ms_scaling_factor=0.8).decode_batch(synd)
     dec, llr, it, cv = eng.decode_batch(synd)
     assert np.array_equal(dec, wd) and np.array_equal(it, wi) and np.array_equal(cv, wc)
-    assert np.array_equal(llr.view(np.uint64), wl.view(np.uint64))
+    assert bits_equal(llr, wl)
 
 
 def test_device_generator_and_mulvec_match_host_twins(oracle_built):

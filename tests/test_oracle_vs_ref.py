@@ -35,7 +35,7 @@ def test_bit_exact(name, mk, p, max_iter, method, alpha, shots, oracle_built):
     d1, l1, i1, c1 = o.decode_batch(synd)
     d2, l2, i2, c2 = r.decode_batch(synd)
     assert np.array_equal(d1, d2) and np.array_equal(i1, i2) and np.array_equal(c1, c2)
-    assert np.array_equal(l1.view(np.uint64), l2.view(np.uint64)), "log_prob_ratios differ in some bit"
+    assert oracle.bits_equal(l1, l2), "log_prob_ratios differ in some bit"
 
 
 def test_mulvec_and_generator_twins(oracle_built):
