@@ -46,6 +46,8 @@ def main() -> None:
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="syndromes for the CPU baseline (-1 = 3 per host thread, 0 = skip)")
     ap.add_argument("--math", default="libm_exact", choices=["libm_exact", "fast"], help="device tanh/log (include/ldpc_hip.h)")
+    ap.add_argument("--bp-method", default="product_sum", choices=["product_sum", "minimum_sum"],
+                    help="product_sum is the BASELINE workload; minimum_sum (alpha 0.625) is a diagnostic memory-only run")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     args = ap.parse_args()
 
@@ -75,7 +77,9 @@ def main() -> None:
     m, nnz = h.shape[0], h.nnz
     B = args.batch_per_gpu
     total = B * world
-    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), args.max_iter, 0, 1.0, device=local_rank)
+    method_id = 0 if args.bp_method == "product_sum" else 1
+    alpha = 1.0 if method_id == 0 else 0.625
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), args.max_iter, method_id, alpha, device=local_rank)
     if args.waves:
         eng.set_tuning(waves_per_workgroup=args.waves)
     eng.set_math(args.math)
@@ -123,7 +127,7 @@ def main() -> None:
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
         res = {
-            "metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k",
+            "metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k" if method_id == 0 else "syndromes_per_sec_DIAGNOSTIC_min_sum",
             "value": total * args.steps / elapsed,
             "unit": "syndromes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -131,7 +135,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: (3,6)-regular LDPC n={n} (m={m}, E={nnz}), product_sum flooding BP, "
+                "workload": f"configs[1]: (3,6)-regular LDPC n={n} (m={m}, E={nnz}), {args.bp_method} flooding BP, "
                             f"max_iter={args.max_iter}, batch={B} syndromes per GPU, BSC p={args.p}, code seed 1, error seed 7",
                 "batch_per_gpu": B, "global_batch": total, "p": args.p, "max_iter": args.max_iter,
                 "outputs": "decoding u8, log_prob_ratios f64, iterations i32, converge u8" if llr is not None else "no LLR",
@@ -155,7 +159,7 @@ def main() -> None:
             err = generate_bsc_batch(n, args.p, 7, 0, sample)
             s_host = np.asarray((h.astype(np.int32) @ err.T.astype(np.int32)).T % 2, dtype=np.uint8)
             assert np.array_equal(s_host, synd[:sample].cpu().numpy()), "device shot generator differs from its host twin"
-            cpu, (cd, cl, ci, cc) = cpu_bench.run(h, args.p, args.max_iter, "product_sum", 1.0, s_host, cores=cores)
+            cpu, (cd, cl, ci, cc) = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, s_host, cores=cores)
             gd = dec[:sample].cpu().numpy()
             ok = bool(np.array_equal(gd, cd) and np.array_equal(iters[:sample], ci) and np.array_equal(conv[:sample], cc))
             if llr is not None:

@@ -117,8 +117,8 @@ __device__ __forceinline__ MsgBuf make_msgbuf(double *base, unsigned rows) {
 // check -> bit, product-sum, one lane: message_sign * log((1 + x) / (1 - x))  (bp.hpp:211-216),
 // x = (exclusive prefix product) * (exclusive suffix product) of the tanh values of the row
 template <int MATH>
-__device__ __forceinline__ double ps_message(double x, bool negate) {
-    const double c = MATH == 0 ? ldpc_math::ps_log_ratio_libm(x) : ldpc_math::ps_log_ratio(x);
+__device__ __forceinline__ double ps_message(double x, bool negate, const double *log_tab) {
+    const double c = MATH == 0 ? ldpc_math::ps_log_ratio_libm(x, log_tab) : ldpc_math::ps_log_ratio(x);
     return negate ? -c : c;
 }
 
@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     const int l8 = lane * 8;
 
     __shared__ uint64_t red[2][16];
+    __shared__ __attribute__((aligned(16))) double log_tab[256];  // glibc log's {1/c, log c} table, LDS-resident
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
 
     // lanes beyond the batch (partial last tile) are born "done"
     const int64_t valid = a.batch - tile * LDPC_WAVE;
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 #pragma unroll
                     for (int k = DR - 1; k >= 0; --k)
                         if (k < d) {
-                            Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg));
+                            Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg, log_tab));
                             temp *= cur[k];
                             LDPC_EDGE_FENCE();
                         }
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     }
                     temp = 1.0;
                     for (int k = d - 1; k >= 0; --k) {
-                        Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg));
+                        Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg, log_tab));
                         temp *= At.ld(l8, rs + k);
                     }
                 }
@@ -829,8 +832,9 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.iters = iters ? iters + b0 : nullptr;
         a.conv = conv ? conv + b0 : nullptr;
 
+        // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
         int waves = h->waves_per_wg;
-        if (waves <= 0) waves = tiles >= 512 ? 8 : 16;
+        if (waves <= 0) waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
         if (h->timed) {  // fold the previous chunk's time before the events are re-recorded
             float prev = 0.f;
             HIPCHK(hipEventSynchronize(h->ev1));

@@ -138,6 +138,24 @@ LDPC_HD double ps_log_ratio(double x) { return log_pos((1.0 + x) / (1.0 - x)); }
 // Everything is restricted to the arguments the BP update can produce (see each routine).
 // =================================================================================================
 
+// IEEE-754 correctly rounded n / d for finite, non-zero, normal d and results far from the overflow /
+// underflow thresholds -- every division of the product-sum update qualifies once d == 0 is handled by
+// the caller (|operands| in [2^-54, 2^65]).  On the device this is the Newton-Raphson + final-residual
+// sequence the compiler itself emits for `/` (v_rcp_f64, four FMAs, q = n*r, rem = n - d*q,
+// q + rem*r), minus the v_div_scale / v_div_fmas / v_div_fixup range handling that is a no-op for such
+// operands: same bits, three instructions fewer per division.  On the host it is just `/`.
+LDPC_HD double div_cr(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma_(fma_(-d, r, 1.0), r, r);
+    r = fma_(fma_(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return fma_(fma_(-d, q, n), r, q);
+#else
+    return n / d;
+#endif
+}
+
 LDPC_HD uint64_t as_u64(double x) { uint64_t u; memcpy(&u, &x, sizeof u); return u; }
 LDPC_HD double as_f64(uint64_t u) { double x; memcpy(&x, &u, sizeof x); return x; }
 LDPC_HD double add_exponent(double y, int k) { return as_f64(as_u64(y) + ((uint64_t)(int64_t)k << 52)); }
@@ -170,7 +188,7 @@ LDPC_HD double expm1_libm(double w) {
     const double R3 = Q4 + hxs * Q5;
     const double r1 = R1 + h2 * R2 + h4 * R3;
     const double t = 3.0 - r1 * hfx;
-    const double e0 = hxs * ((r1 - t) / (6.0 - x * t));
+    const double e0 = hxs * div_cr(r1 - t, 6.0 - x * t);  // denominator in [5.6, 6.4]
     const double res_k0 = x - (x * e0 - hxs);
     double e = (x * (e0 - c) - c);
     e -= hxs;
@@ -197,7 +215,7 @@ LDPC_HD double tanh_half_libm(double b) {
     const double axc = ax < 22.0 ? ax : 22.0;      // keeps the speculative main path in range (NaN -> 22)
     const bool big = axc >= 1.0;
     const double t = expm1_libm(big ? 2.0 * axc : -2.0 * axc);
-    const double quo = (big ? 2.0 : -t) / (t + 2.0);
+    const double quo = div_cr(big ? 2.0 : -t, t + 2.0);  // denominator in [1.1, 2^64]
     double z = big ? 1.0 - quo : quo;              // 1 - 2/(t+2)   |   -t/(t+2)
     z = ax < 22.0 ? z : 1.0;                        // |x| >= 22, +-inf
     z = __builtin_signbit(x) ? -z : z;
@@ -206,14 +224,18 @@ LDPC_HD double tanh_half_libm(double b) {
     return z;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// {1/c, log(c)} pairs of glibc's log (bp_libm_tables.h).  Device code never indexes this array from
+// the hot loop: a per-lane global load in the middle of the arithmetic would queue behind the streaming
+// message traffic (gfx9 completes vector-memory operations in issue order), so the kernel stages the
+// 2 KiB table into LDS once per workgroup and hands log_libm the LDS pointer.
+#if defined(__HIPCC__)
 __device__ const double k_log_tab[256] = LDPC_LOG_TAB;
-#elif !defined(__HIPCC__)
+#else
 static const double k_log_tab[256] = LDPC_LOG_TAB;
 #endif
 
 // std::log(q) exactly as glibc's FMA build evaluates it, for q in [0, +inf] or NaN, q not subnormal.
-LDPC_HD double log_libm(double q) {
+LDPC_HD double log_libm(double q, const double *tab) {
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
     return q;  // host pass of hipcc: never called
 #else
@@ -243,7 +265,7 @@ LDPC_HD double log_libm(double q) {
         const int i = (int)((tmp >> (52 - LDPC_LOG_TABLE_BITS)) & 127);
         const int64_t k = (int64_t)tmp >> 52;
         const double z = as_f64(ix - (tmp & (0xfffull << 52)));
-        const double invc = k_log_tab[2 * i], logc = k_log_tab[2 * i + 1];
+        const double invc = tab[2 * i], logc = tab[2 * i + 1];
         const double r = fma_(z, invc, -1.0);
         const double kd = (double)k;
         const double w = fma_(kd, Ln2hi, logc);
@@ -259,7 +281,13 @@ LDPC_HD double log_libm(double q) {
 #endif
 }
 
-// std::log((1 + x) / (1 - x)) with the host libm's bits (correctly rounded IEEE division)
-LDPC_HD double ps_log_ratio_libm(double x) { return log_libm((1.0 + x) / (1.0 - x)); }
+// std::log((1 + x) / (1 - x)) with the host libm's bits; |x| <= 1 or NaN.  1 - x == 0 (x == 1) gives
+// 2 / 0 = +inf exactly as IEEE division does.
+LDPC_HD double ps_log_ratio_libm(double x, const double *tab) {
+    const double den = 1.0 - x;
+    double q = div_cr(1.0 + x, den == 0.0 ? 1.0 : den);
+    q = den == 0.0 ? INFINITY : q;
+    return log_libm(q, tab);
+}
 
 }  // namespace ldpc_math

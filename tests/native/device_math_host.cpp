@@ -14,10 +14,10 @@ void dm_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i 
 void ref_tanh_half_v(long n, const double *in, long double *out) { for (long i = 0; i < n; i++) out[i] = tanhl((long double)in[i] / 2); }
 void ref_log_v(long n, const double *in, long double *out) { for (long i = 0; i < n; i++) out[i] = logl((long double)in[i]); }
 double dx_tanh_half(double b) { return ldpc_math::tanh_half_libm(b); }
-double dx_log_ratio(double x) { return ldpc_math::ps_log_ratio_libm(x); }
+double dx_log_ratio(double x) { return ldpc_math::ps_log_ratio_libm(x, ldpc_math::k_log_tab); }
 void dx_tanh_half_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::tanh_half_libm(in[i]); }
-void dx_log_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::log_libm(in[i]); }
-void dx_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::ps_log_ratio_libm(in[i]); }
+void dx_log_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::log_libm(in[i], ldpc_math::k_log_tab); }
+void dx_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::ps_log_ratio_libm(in[i], ldpc_math::k_log_tab); }
 void libm_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = std::log((1 + in[i]) / (1 - in[i])); }
 void *dx_tanh_half_ptr() { return (void *)&dx_tanh_half; }
 void *dx_log_ratio_ptr() { return (void *)&dx_log_ratio; }
