@@ -140,6 +140,12 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t 
  *   LDPC_HIP_MATH_FAST: ~1-ulp routines, ~40 % fewer FP64 operations; hard decisions identical
  *       except on exact ties of the reference's posterior, LLRs within the 1e-5 relative tolerance.
  */
+/* For matrices whose rows all have one weight and whose columns all have one weight the BP kernel
+ * streams messages through a per-wavefront LDS ring filled by asynchronous global->LDS loads
+ * (default on).  0 forces the register-prefetch variant used for irregular matrices; results are
+ * identical either way. */
+int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable);
+
 #define LDPC_HIP_MATH_LIBM_EXACT 0
 #define LDPC_HIP_MATH_FAST 1
 int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);

@@ -63,7 +63,8 @@ struct BpArgs {
     const uint64_t *par;                // [tiles][m]  bit l = syndrome byte & 1 of lane l
     const uint64_t *nzm;                // [tiles][m]  bit l = syndrome byte != 0 of lane l
     const uint64_t *invalid;            // [tiles]     bit l = some syndrome byte > 1 (never converges)
-    uint64_t *dec;                      // [tiles][n]  ballot of hard decisions (zero-initialised)
+    uint64_t *dec;                      // [tiles][n]  frozen hard decisions, bit l = lane l (zero-initialised)
+    uint64_t *dcur;                     // [tiles][n]  hard decisions of the running iteration
     double *llr_t;                      // [tiles][n][64] or nullptr
     int32_t *iters;                     // [batch] or nullptr
     uint8_t *conv;                      // [batch] or nullptr
@@ -142,9 +143,139 @@ __device__ __forceinline__ double edge_form(double b2c) {
     return METHOD == LDPC_HIP_PRODUCT_SUM ? ps_tanh_half<MATH>(b2c) : b2c;
 }
 
-template <int METHOD, int MATH, int DR, int DC>
+// ---- per-node arithmetic, shared by the register-prefetch and the LDS-ring variants ----------------
+
+// One check row held in registers: cur[0..d) are the row's A values in ascending column order.
+// Computes the d check->bit messages (bp.hpp:201-219 / 220-273) and stores them to C[rs + k].
+template <int METHOD, int MATH, int DR>
+__device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs, bool neg, int parity0,
+                                          double alpha, const MsgBuf &Ct, int l8, const double *log_tab) {
+    double pre[DR];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+        double temp = 1.0;
+#pragma unroll
+        for (int k = 0; k < DR; ++k)
+            if (k < d) { pre[k] = temp; temp *= cur[k]; }
+        temp = 1.0;
+#pragma unroll
+        for (int k = DR - 1; k >= 0; --k)
+            if (k < d) {
+                Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg, log_tab));
+                temp *= cur[k];
+                LDPC_EDGE_FENCE();
+            }
+    } else {
+        // total_sgn = syndrome[i] + #{b2c <= 0}; only its parity is used (bp.hpp:236-262)
+        int parity = parity0;
+        double temp = DBL_MAX;
+#pragma unroll
+        for (int k = 0; k < DR; ++k)
+            if (k < d) {
+                if (cur[k] <= 0) parity ^= 1;
+                pre[k] = temp;
+                const double ab = fabs(cur[k]);
+                if (ab < temp) temp = ab;
+            }
+        temp = DBL_MAX;
+#pragma unroll
+        for (int k = DR - 1; k >= 0; --k)
+            if (k < d) {
+                const int sgn = parity ^ (cur[k] <= 0 ? 1 : 0);
+                double mag = pre[k];
+                if (temp < mag) mag = temp;
+                const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
+                Ct.st(l8, rs + k, mag * signed_alpha);
+                const double ab = fabs(cur[k]);
+                if (ab < temp) temp = ab;
+            }
+    }
+}
+
+// A row heavier than the register bound: two streaming sweeps, exactly the reference's loops.
+template <int METHOD, int MATH>
+__device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int parity, double alpha,
+                                                   const MsgBuf &At, const MsgBuf &Ct, int l8,
+                                                   const double *log_tab) {
+    if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+        double temp = 1.0;
+        for (int k = 0; k < d; ++k) {
+            Ct.st(l8, rs + k, temp);
+            temp *= At.ld(l8, rs + k);
+        }
+        temp = 1.0;
+        for (int k = d - 1; k >= 0; --k) {
+            Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg, log_tab));
+            temp *= At.ld(l8, rs + k);
+        }
+    } else {
+        double temp = DBL_MAX;
+        for (int k = 0; k < d; ++k) {
+            const double bk = At.ld(l8, rs + k);
+            if (bk <= 0) parity ^= 1;
+            Ct.st(l8, rs + k, temp);
+            const double ab = fabs(bk);
+            if (ab < temp) temp = ab;
+        }
+        temp = DBL_MAX;
+        for (int k = d - 1; k >= 0; --k) {
+            const double bk = At.ld(l8, rs + k);
+            const int sgn = parity ^ (bk <= 0 ? 1 : 0);
+            double mag = Ct.ld(l8, rs + k);
+            if (temp < mag) mag = temp;
+            const double signed_alpha = sgn ? -alpha : alpha;
+            Ct.st(l8, rs + k, mag * signed_alpha);
+            const double ab = fabs(bk);
+            if (ab < temp) temp = ab;
+        }
+    }
+}
+
+// One bit column held in registers: c[0..d) are its check->bit messages in ascending row order, e[] the
+// CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored.
+template <int METHOD, int MATH, int DC>
+__device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&e)[DC], int d, double prior,
+                                             const MsgBuf &At, int l8) {
+    double pre[DC];
+    double temp = prior;
+#pragma unroll
+    for (int k = 0; k < DC; ++k)
+        if (k < d) { pre[k] = temp; temp += c[k]; }
+    const double llr = temp;
+    double s = 0.0;
+#pragma unroll
+    for (int k = DC - 1; k >= 0; --k)
+        if (k < d) {
+            At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + s));
+            s += c[k];
+            if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+        }
+    return llr;
+}
+
+// ---- LDS-DMA ring ------------------------------------------------------------------------------------
+// A wavefront keeps RING_DEPTH rows (check pass) or bit pairs (bit pass) of message data in flight into
+// its private LDS ring with `buffer_load_dwordx4 ... lds`: 64 lanes x 16 B = two whole 512-byte edge
+// segments per instruction, no VGPRs held while the data is in flight.  hipcc does not count these loads,
+// so the waits are explicit: vector-memory operations complete in issue order, hence "at most N
+// operations outstanding", with N = the number of operations issued AFTER the wanted load, proves it has
+// landed.  N must be a lower bound of that number (a smaller N only waits longer); the steady-state
+// constants below assume exactly-regular node degrees, which is why the ring variant is only selected
+// for such matrices (host side: rows all of weight DR, columns all of weight DC).
+#define LDPC_RING_DEPTH 3
+extern __shared__ __attribute__((aligned(16))) unsigned char ldpc_dyn_lds[];
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;  // M0 carries the LDS destination; it is compiler-reserved, so save/restore it in the same statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N < 63 ? N : 63) : "memory"); }
+__device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int METHOD, int MATH, int DR, int DC, int RING>
 __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
-    constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront in the bit pass
+    constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)(blockDim.x >> 6);
@@ -161,7 +292,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 
     const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dec = a.dec + tile * n;    // frozen decisions of converged syndromes (zero-initialised)
+    uint64_t *dcur = a.dcur + tile * n;  // this iteration's hard decisions, all lanes
     const bool want_llr = a.llr_t != nullptr;
     const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
     const int l8 = lane * 8;
@@ -170,6 +302,15 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     __shared__ __attribute__((aligned(16))) double log_tab[256];  // glibc log's {1/c, log c} table, LDS-resident
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+
+    // ring geometry (RING variant): one slot holds a check row (DR segments) or a pair of bit columns (2*DC)
+    constexpr int ROW_DMAS = (DR + 1) / 2;                       // 1 KiB DMA instructions per row
+    constexpr int SLOT_BYTES = (ROW_DMAS > DC ? ROW_DMAS : DC) * 1024;
+    constexpr int N_CHECK = LDPC_RING_DEPTH * DR + (LDPC_RING_DEPTH - 1) * ROW_DMAS;
+    constexpr int N_BIT = LDPC_RING_DEPTH * (2 * DC + 2) + (LDPC_RING_DEPTH - 1) * DC;
+    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (LDPC_RING_DEPTH * SLOT_BYTES);
+    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (LDPC_RING_DEPTH * SLOT_BYTES));
+    const unsigned l16 = (unsigned)lane * 16u;
 
     // lanes beyond the batch (partial last tile) are born "done"
     const int64_t valid = a.batch - tile * LDPC_WAVE;
@@ -187,179 +328,169 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
         if (METHOD == LDPC_HIP_MINIMUM_SUM)
             alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
 
-        // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
-        // works on row i its loads for row i + nwaves are already in flight.
-        double cur[DR];
-        int rs = 0, d = 0;
-        if (wave < m) {
-            rs = row_ptr[wave];
-            d = row_ptr[wave + 1] - rs;
-            if (d <= DR) {
+        if (RING) {
+            // every row has exactly DR entries: row i starts at edge i * DR
+            const int nsteps = wave < m ? (m - wave + nwaves - 1) / nwaves : 0;
+            auto issue_row = [&](int i, int slot) {
 #pragma unroll
-                for (int k = 0; k < DR; ++k)
-                    if (k < d) cur[k] = At.ld(l8, rs + k);
-            }
-        }
-        for (int i = wave; i < m; i += nwaves) {
-            const int inext = i + nwaves;
-            double nxt[DR];
-            int rs_n = 0, d_n = 0;
-            if (inext < m) {
-                rs_n = row_ptr[inext];
-                d_n = row_ptr[inext + 1] - rs_n;
-                if (d_n <= DR) {
+                for (int c = 0; c < ROW_DMAS; ++c)
+                    lds_dma16(At.rsrc, l16, (unsigned)(i * DR + 2 * c) << 9, ring_addr + slot * SLOT_BYTES + c * 1024);
+            };
+            for (int p = 0; p < LDPC_RING_DEPTH; ++p)
+                if (p < nsteps) issue_row(wave + p * nwaves, p);
+            int slot = 0;
+            for (int idx = 0; idx < nsteps; ++idx) {
+                const int i = wave + idx * nwaves;
+                if (idx >= LDPC_RING_DEPTH && idx + LDPC_RING_DEPTH - 1 < nsteps) wait_vmcnt<N_CHECK>();
+                else wait_vmcnt<0>();
+                double cur[DR];
 #pragma unroll
-                    for (int k = 0; k < DR; ++k)
-                        if (k < d_n) nxt[k] = At.ld(l8, rs_n + k);
-                }
+                for (int k = 0; k < DR; ++k) cur[k] = ringp[slot * (SLOT_BYTES / 8) + k * LDPC_WAVE + lane];
+                wait_lds_reads();  // the slot is free once its values sit in registers
+                if (idx + LDPC_RING_DEPTH < nsteps) issue_row(i + LDPC_RING_DEPTH * nwaves, slot);
+                const bool neg = (nzm[i] >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
+                const int parity = (int)((par[i] >> lane) & 1ull);
+                check_row<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab);
+                slot = slot + 1 == LDPC_RING_DEPTH ? 0 : slot + 1;
             }
-            if (METHOD == LDPC_HIP_PRODUCT_SUM) {
-                const bool neg = (nzm[i] >> lane) & 1ull;  // syndrome[i] != 0 (bp.hpp:213)
+        } else {
+            // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
+            // works on row i its loads for row i + nwaves are already in flight.
+            double cur[DR];
+            int rs = 0, d = 0;
+            if (wave < m) {
+                rs = row_ptr[wave];
+                d = row_ptr[wave + 1] - rs;
                 if (d <= DR) {
-                    double pre[DR];
-                    double temp = 1.0;
 #pragma unroll
                     for (int k = 0; k < DR; ++k)
-                        if (k < d) { pre[k] = temp; temp *= cur[k]; }
-                    temp = 1.0;
-#pragma unroll
-                    for (int k = DR - 1; k >= 0; --k)
-                        if (k < d) {
-                            Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg, log_tab));
-                            temp *= cur[k];
-                            LDPC_EDGE_FENCE();
-                        }
-                } else {  // heavy row: stream it twice, exactly as the reference's two sweeps
-                    double temp = 1.0;
-                    for (int k = 0; k < d; ++k) {
-                        Ct.st(l8, rs + k, temp);
-                        temp *= At.ld(l8, rs + k);
-                    }
-                    temp = 1.0;
-                    for (int k = d - 1; k >= 0; --k) {
-                        Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg, log_tab));
-                        temp *= At.ld(l8, rs + k);
-                    }
-                }
-            } else {
-                // total_sgn = syndrome[i] + #{b2c <= 0}; only its parity is used (bp.hpp:236-262)
-                int parity = (int)((par[i] >> lane) & 1ull);
-                if (d <= DR) {
-                    double pre[DR];
-                    double temp = DBL_MAX;
-#pragma unroll
-                    for (int k = 0; k < DR; ++k)
-                        if (k < d) {
-                            if (cur[k] <= 0) parity ^= 1;
-                            pre[k] = temp;
-                            const double ab = fabs(cur[k]);
-                            if (ab < temp) temp = ab;
-                        }
-                    temp = DBL_MAX;
-#pragma unroll
-                    for (int k = DR - 1; k >= 0; --k)
-                        if (k < d) {
-                            const int sgn = parity ^ (cur[k] <= 0 ? 1 : 0);
-                            double mag = pre[k];
-                            if (temp < mag) mag = temp;
-                            const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
-                            Ct.st(l8, rs + k, mag * signed_alpha);
-                            const double ab = fabs(cur[k]);
-                            if (ab < temp) temp = ab;
-                        }
-                } else {
-                    double temp = DBL_MAX;
-                    for (int k = 0; k < d; ++k) {
-                        const double bk = At.ld(l8, rs + k);
-                        if (bk <= 0) parity ^= 1;
-                        Ct.st(l8, rs + k, temp);
-                        const double ab = fabs(bk);
-                        if (ab < temp) temp = ab;
-                    }
-                    temp = DBL_MAX;
-                    for (int k = d - 1; k >= 0; --k) {
-                        const double bk = At.ld(l8, rs + k);
-                        const int sgn = parity ^ (bk <= 0 ? 1 : 0);
-                        double mag = Ct.ld(l8, rs + k);
-                        if (temp < mag) mag = temp;
-                        const double signed_alpha = sgn ? -alpha : alpha;
-                        Ct.st(l8, rs + k, mag * signed_alpha);
-                        const double ab = fabs(bk);
-                        if (ab < temp) temp = ab;
-                    }
+                        if (k < d) cur[k] = At.ld(l8, rs + k);
                 }
             }
-            rs = rs_n;
-            d = d_n;
+            for (int i = wave; i < m; i += nwaves) {
+                const int inext = i + nwaves;
+                double nxt[DR];
+                int rs_n = 0, d_n = 0;
+                if (inext < m) {
+                    rs_n = row_ptr[inext];
+                    d_n = row_ptr[inext + 1] - rs_n;
+                    if (d_n <= DR) {
 #pragma unroll
-            for (int k = 0; k < DR; ++k) cur[k] = nxt[k];
+                        for (int k = 0; k < DR; ++k)
+                            if (k < d_n) nxt[k] = At.ld(l8, rs_n + k);
+                    }
+                }
+                const bool neg = (nzm[i] >> lane) & 1ull;
+                const int parity = (int)((par[i] >> lane) & 1ull);
+                if (d <= DR) check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+                else check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+                rs = rs_n;
+                d = d_n;
+#pragma unroll
+                for (int k = 0; k < DR; ++k) cur[k] = nxt[k];
+            }
         }
         __syncthreads();
 
         // ---------------- bit pass (bp.hpp:276-298 and 311-318, fused) ----------------
-        // UB columns per wavefront step: all their message loads are issued before the first is used.
         const bool last = (it == a.max_iter);
         const bool lane_live = !((done >> lane) & 1ull);
-        for (int j0 = wave * UB; j0 < n; j0 += nwaves * UB) {
-            int cs[UB], dg[UB], e[UB][DC];
-            double c[UB][DC];
+        if (RING) {
+            // every column has exactly DC entries; a step handles the column pair (2g, 2g + 1), whose
+            // 2*DC gathered segments arrive as DC DMA instructions (lanes 0-31 one segment, 32-63 the next)
+            const int ngroups = (n + 1) / 2;
+            const int nsteps = wave < ngroups ? (ngroups - wave + nwaves - 1) / nwaves : 0;
+            auto issue_pair = [&](int g, int slot) {
+                const int base = 2 * g * DC;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int j = j0 + u;
-                cs[u] = 0;
-                dg[u] = -1;  // -1: no such column
-                if (j < n) {
-                    cs[u] = col_ptr[j];
-                    dg[u] = col_ptr[j + 1] - cs[u];
-                    if (dg[u] <= DC) {
-#pragma unroll
-                        for (int k = 0; k < DC; ++k)
-                            if (k < dg[u]) {
-                                e[u][k] = csc_edge[cs[u] + k];
-                                c[u][k] = Ct.ld(l8, e[u][k]);
-                            }
-                    }
+                for (int c = 0; c < DC; ++c) {
+                    const int q0 = base + 2 * c, q1 = base + 2 * c + 1;
+                    const unsigned ea = (unsigned)csc_edge[q0 < nnz ? q0 : 0];
+                    const unsigned eb = (unsigned)csc_edge[q1 < nnz ? q1 : 0];
+                    const unsigned voff = ((lane < 32 ? ea : eb) << 9) + (unsigned)(lane & 31) * 16u;
+                    lds_dma16(Ct.rsrc, voff, 0u, ring_addr + slot * SLOT_BYTES + c * 1024);
                 }
-            }
+            };
+            for (int p = 0; p < LDPC_RING_DEPTH; ++p)
+                if (p < nsteps) issue_pair(wave + p * nwaves, p);
+            int slot = 0;
+            for (int idx = 0; idx < nsteps; ++idx) {
+                const int g = wave + idx * nwaves;
+                if (idx >= LDPC_RING_DEPTH && idx + LDPC_RING_DEPTH - 1 < nsteps) wait_vmcnt<N_BIT>();
+                else wait_vmcnt<0>();
+                double c[2][DC];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int j = j0 + u;
-                if (dg[u] < 0) continue;
-                const double prior = llr0[j];
-                double llr;
-                if (dg[u] <= DC) {
-                    double pre[DC];
-                    double temp = prior;
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int k = 0; k < DC; ++k)
-                        if (k < dg[u]) { pre[k] = temp; temp += c[u][k]; }
-                    llr = temp;
-                    double s = 0.0;
+                        c[u][k] = ringp[slot * (SLOT_BYTES / 8) + (u * DC + k) * LDPC_WAVE + lane];
+                wait_lds_reads();
+                if (idx + LDPC_RING_DEPTH < nsteps) issue_pair(g + LDPC_RING_DEPTH * nwaves, slot);
 #pragma unroll
-                    for (int k = DC - 1; k >= 0; --k)
-                        if (k < dg[u]) {
-                            At.st(l8, e[u][k], edge_form<METHOD, MATH>(pre[k] + s));
-                            s += c[u][k];
-                            if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
-                        }
-                } else {  // heavy column: two streaming sweeps like the reference's
-                    double temp = prior;
-                    for (int k = 0; k < dg[u]; ++k) {
-                        const int ee = csc_edge[cs[u] + k];
-                        At.st(l8, ee, temp);
-                        temp += Ct.ld(l8, ee);
-                    }
-                    llr = temp;
-                    double s = 0.0;
-                    for (int k = dg[u] - 1; k >= 0; --k) {
-                        const int ee = csc_edge[cs[u] + k];
-                        At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + s));
-                        s += Ct.ld(l8, ee);
+                for (int u = 0; u < 2; ++u) {
+                    const int j = 2 * g + u;
+                    if (j < n) {
+                        int e[DC];
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) e[k] = csc_edge[j * DC + k];
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, llr0[j], At, l8);
+                        const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                        if (lane == 0) dcur[j] = hard;
+                        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
                     }
                 }
-                const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
-                if (lane == 0) dec[j] = done ? ((dec[j] & done) | (hard & ~done)) : hard;
-                if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                slot = slot + 1 == LDPC_RING_DEPTH ? 0 : slot + 1;
+            }
+        } else {
+            // UB columns per wavefront step: all their message loads are issued before the first is used.
+            for (int j0 = wave * UB; j0 < n; j0 += nwaves * UB) {
+                int cs[UB], dg[UB], e[UB][DC];
+                double c[UB][DC];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = j0 + u;
+                    cs[u] = 0;
+                    dg[u] = -1;  // -1: no such column
+                    if (j < n) {
+                        cs[u] = col_ptr[j];
+                        dg[u] = col_ptr[j + 1] - cs[u];
+                        if (dg[u] <= DC) {
+#pragma unroll
+                            for (int k = 0; k < DC; ++k)
+                                if (k < dg[u]) {
+                                    e[u][k] = csc_edge[cs[u] + k];
+                                    c[u][k] = Ct.ld(l8, e[u][k]);
+                                }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = j0 + u;
+                    if (dg[u] < 0) continue;
+                    const double prior = llr0[j];
+                    double llr;
+                    if (dg[u] <= DC) {
+                        llr = bit_column<METHOD, MATH, DC>(c[u], e[u], dg[u], prior, At, l8);
+                    } else {  // heavy column: two streaming sweeps like the reference's
+                        double temp = prior;
+                        for (int k = 0; k < dg[u]; ++k) {
+                            const int ee = csc_edge[cs[u] + k];
+                            At.st(l8, ee, temp);
+                            temp += Ct.ld(l8, ee);
+                        }
+                        llr = temp;
+                        double s = 0.0;
+                        for (int k = dg[u] - 1; k >= 0; --k) {
+                            const int ee = csc_edge[cs[u] + k];
+                            At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + s));
+                            s += Ct.ld(l8, ee);
+                        }
+                    }
+                    const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                    if (lane == 0) dcur[j] = hard;
+                    if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                }
             }
         }
         __syncthreads();
@@ -368,34 +499,38 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
         uint64_t unsat = 0;
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             uint64_t cand = 0;
-            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) cand ^= dec[col_idx[e]];
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) cand ^= dcur[col_idx[e]];
             unsat |= cand ^ par[i];
         }
         unsat = wave_or(unsat);
-        uint64_t *slot = red[it & 1];  // double-buffered: no barrier needed before the next reuse
-        if (lane == 0) slot[wave] = unsat;
+        uint64_t *slot_red = red[it & 1];  // double-buffered: no barrier needed before the next reuse
+        if (lane == 0) slot_red[wave] = unsat;
         __syncthreads();
         unsat = never;
-        for (int w = 0; w < nwaves; ++w) unsat |= slot[w];
+        for (int w = 0; w < nwaves; ++w) unsat |= slot_red[w];
         const uint64_t newly = uniform64(~unsat & ~done);
         if (newly) {
+            // these syndromes stop here (bp.hpp:300-308): freeze their decisions, and their posteriors are
+            // those of THIS iteration (its check->bit messages are still intact in C)
             if ((newly >> lane) & 1ull) my_iter = it;
-            if (!last && want_llr) {
-                // these syndromes stop here: their posteriors are those of THIS iteration (the
-                // check->bit messages of this iteration are still intact in C)
-                const bool mine = (newly >> lane) & 1ull;
-                for (int j = wave; j < n; j += nwaves) {
+            const bool mine = (newly >> lane) & 1ull;
+            for (int j = wave; j < n; j += nwaves) {
+                if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+                if (!last && want_llr) {
                     double temp = llr0[j];
-                    for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p)
-                        temp += Ct.ld(l8, csc_edge[p]);
+                    for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p) temp += Ct.ld(l8, csc_edge[p]);
                     if (mine) Lt.st(l8, j, temp);
                 }
-                __syncthreads();  // C is overwritten by the next check pass
             }
             done |= newly;
+            __syncthreads();  // C is overwritten by the next check pass
         }
         if (done == ~0ull) break;
     }
+
+    // syndromes that never converged report the last iteration's decisions (bp.hpp:320-322)
+    if (done != ~0ull)
+        for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
 
     if (wave == 0) {
         const int64_t b = tile * LDPC_WAVE + lane;
@@ -550,6 +685,8 @@ struct ldpc_hip_bp {
     int32_t max_row_deg = 0, max_col_deg = 0;
     int32_t waves_per_wg = 0;  // 0 = auto
     int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
+    bool regular = false;   // every row has the same weight and every column has the same weight
+    bool use_ring = true;   // LDS-DMA ring variant allowed (tuning knob)
     std::vector<double> channel_probs;
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
@@ -560,7 +697,7 @@ struct ldpc_hip_bp {
     bool timed = false;
     float accumulated_ms = 0.f;
 
-    DeviceBuf msgA, msgC, par, nzm, invalid, dec, llr_t;             // workspace
+    DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
 };
@@ -624,15 +761,21 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     h->max_iter = d->max_iter; h->bp_method = d->bp_method;
     h->ms_scaling_factor = d->ms_scaling_factor;
     h->max_row_deg = max_row;
+    int32_t min_row = d->m ? max_row : 0;
+    for (int i = 0; i < d->m; ++i)
+        if (d->csr_row_ptr[i + 1] - d->csr_row_ptr[i] < min_row) min_row = d->csr_row_ptr[i + 1] - d->csr_row_ptr[i];
     h->channel_probs.assign(d->channel_probs, d->channel_probs + d->n);
 
     // CSC view: csc_edge[p] = CSR edge id; filling by ascending row keeps rows ascending per column
     std::vector<int32_t> col_ptr((size_t)d->n + 1, 0), csc_edge((size_t)(d->nnz ? d->nnz : 1));
     for (int e = 0; e < d->nnz; ++e) col_ptr[(size_t)d->csr_col_idx[e] + 1]++;
+    int32_t min_col = d->n ? INT32_MAX : 0;
     for (int j = 0; j < d->n; ++j) {
         if (col_ptr[(size_t)j + 1] > h->max_col_deg) h->max_col_deg = col_ptr[(size_t)j + 1];
+        if (col_ptr[(size_t)j + 1] < min_col) min_col = col_ptr[(size_t)j + 1];
         col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
     }
+    h->regular = d->m > 0 && d->n > 0 && min_row == max_row && min_col == h->max_col_deg;
     {
         std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
         for (int i = 0; i < d->m; ++i)
@@ -673,7 +816,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->llr_t,
+    for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
                          &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
@@ -724,6 +867,12 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_wg, int32_t max_chu
     return LDPC_HIP_OK;
 }
 
+int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    h->use_ring = enable != 0;
+    return LDPC_HIP_OK;
+}
+
 int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (math_mode != LDPC_HIP_MATH_LIBM_EXACT && math_mode != LDPC_HIP_MATH_FAST)
@@ -755,16 +904,23 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
 
 typedef void (*bp_kernel_t)(const BpArgs);
 
+struct KernelChoice {
+    bp_kernel_t fn;
+    int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
+};
+
 template <int METHOD, int MATH>
-static bp_kernel_t pick_kernel(int max_row, int max_col) {
-    // register arrays are sized by the template bounds, so the common regular codes get exact fits:
-    // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3, surface-code rows of 4 and columns of 2
-    if (max_row <= 4 && max_col <= 3) return bp_decode_kernel<METHOD, MATH, 4, 3>;
-    if (max_row <= 6 && max_col <= 3) return bp_decode_kernel<METHOD, MATH, 6, 3>;
-    if (max_row <= 8 && max_col <= 4) return bp_decode_kernel<METHOD, MATH, 8, 4>;
-    if (max_row <= 8 && max_col <= 8) return bp_decode_kernel<METHOD, MATH, 8, 8>;
-    if (max_col <= 8) return bp_decode_kernel<METHOD, MATH, 16, 8>;
-    return bp_decode_kernel<METHOD, MATH, 16, 16>;  // heavier nodes take the streaming path inside
+static KernelChoice pick_kernel(int max_row, int max_col, bool regular) {
+    // Register arrays are sized by the template bounds, so the common regular codes get exact fits:
+    // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
+    if (regular && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 1>, 3 * 1024};
+    if (regular && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 1>, 4 * 1024};
+    if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0};
+    if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0};
+    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0};
+    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0};
+    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0};
+    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0};  // heavier nodes take the streaming path inside
 }
 
 // Everything below runs on h->stream with device pointers only.
@@ -795,12 +951,14 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
     if ((rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk))) return rc;
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
 
-    bp_kernel_t kern;
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
-    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    const bool regular = h->regular && h->use_ring;
+    KernelChoice kern;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, regular);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, regular);
+    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, regular);
     h->accumulated_ms = 0.f;
     h->timed = false;
     hipStream_t st = h->stream;
@@ -828,6 +986,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
         a.invalid = (const uint64_t *)h->invalid.p;
         a.dec = (uint64_t *)h->dec.p;
+        a.dcur = (uint64_t *)h->dcur.p;
         a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
         a.iters = iters ? iters + b0 : nullptr;
         a.conv = conv ? conv + b0 : nullptr;
@@ -835,6 +994,12 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
         int waves = h->waves_per_wg;
         if (waves <= 0) waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+        // ring variant: each wavefront owns LDPC_RING_DEPTH slots of dynamic LDS; stay below the 160 KiB of a CU
+        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * LDPC_RING_DEPTH;
+        while (lds_per_wave * (size_t)waves > 144u * 1024u) --waves;
+        const size_t dyn_lds = lds_per_wave * (size_t)waves;
+        if (dyn_lds > 48u * 1024u)
+            HIPCHK(hipFuncSetAttribute((const void *)kern.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
         if (h->timed) {  // fold the previous chunk's time before the events are re-recorded
             float prev = 0.f;
             HIPCHK(hipEventSynchronize(h->ev1));
@@ -842,7 +1007,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             h->accumulated_ms += prev;
         }
         HIPCHK(hipEventRecord(h->ev0, st));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), 0, st, a);
+        hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());
