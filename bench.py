@@ -48,7 +48,7 @@ def main() -> None:
     ap.add_argument("--math", default="libm_exact", choices=["libm_exact", "fast"], help="device tanh/log (include/ldpc_hip.h)")
     ap.add_argument("--bp-method", default="product_sum", choices=["product_sum", "minimum_sum"],
                     help="product_sum is the BASELINE workload; minimum_sum (alpha 0.625) is a diagnostic memory-only run")
-    ap.add_argument("--no-ring", action="store_true", help="force the register-prefetch kernel variant (diagnostic)")
+    ap.add_argument("--ring", type=int, default=1, help="LDS-DMA ring: 0 = register-prefetch variant, 1 = default depth, 2/3 = depth (diagnostic)")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     args = ap.parse_args()
 
@@ -84,8 +84,7 @@ def main() -> None:
     if args.waves:
         eng.set_tuning(waves_per_workgroup=args.waves)
     eng.set_math(args.math)
-    if args.no_ring:
-        eng.set_ring(False)
+    eng.set_ring(args.ring)
 
     # inputs resident in HBM before the timed region; this rank's shard of the global shot stream
     synd = eng.gen_bsc_syndromes(7, args.p, shot0=rank * B, shots=B, device=dev)

@@ -261,7 +261,6 @@ __device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&
 // landed.  N must be a lower bound of that number (a smaller N only waits longer); the steady-state
 // constants below assume exactly-regular node degrees, which is why the ring variant is only selected
 // for such matrices (host side: rows all of weight DR, columns all of weight DC).
-#define LDPC_RING_DEPTH 3
 extern __shared__ __attribute__((aligned(16))) unsigned char ldpc_dyn_lds[];
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
@@ -306,10 +305,10 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     // ring geometry (RING variant): one slot holds a check row (DR segments) or a pair of bit columns (2*DC)
     constexpr int ROW_DMAS = (DR + 1) / 2;                       // 1 KiB DMA instructions per row
     constexpr int SLOT_BYTES = (ROW_DMAS > DC ? ROW_DMAS : DC) * 1024;
-    constexpr int N_CHECK = LDPC_RING_DEPTH * DR + (LDPC_RING_DEPTH - 1) * ROW_DMAS;
-    constexpr int N_BIT = LDPC_RING_DEPTH * (2 * DC + 2) + (LDPC_RING_DEPTH - 1) * DC;
-    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (LDPC_RING_DEPTH * SLOT_BYTES);
-    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (LDPC_RING_DEPTH * SLOT_BYTES));
+    constexpr int N_CHECK = RING * DR + (RING - 1) * ROW_DMAS;
+    constexpr int N_BIT = RING * (2 * DC + 2) + (RING - 1) * DC;
+    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
+    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
     const unsigned l16 = (unsigned)lane * 16u;
 
     // lanes beyond the batch (partial last tile) are born "done"
@@ -336,22 +335,22 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 for (int c = 0; c < ROW_DMAS; ++c)
                     lds_dma16(At.rsrc, l16, (unsigned)(i * DR + 2 * c) << 9, ring_addr + slot * SLOT_BYTES + c * 1024);
             };
-            for (int p = 0; p < LDPC_RING_DEPTH; ++p)
+            for (int p = 0; p < RING; ++p)
                 if (p < nsteps) issue_row(wave + p * nwaves, p);
             int slot = 0;
             for (int idx = 0; idx < nsteps; ++idx) {
                 const int i = wave + idx * nwaves;
-                if (idx >= LDPC_RING_DEPTH && idx + LDPC_RING_DEPTH - 1 < nsteps) wait_vmcnt<N_CHECK>();
+                if (idx >= RING && idx + RING - 1 < nsteps) wait_vmcnt<N_CHECK>();
                 else wait_vmcnt<0>();
                 double cur[DR];
 #pragma unroll
                 for (int k = 0; k < DR; ++k) cur[k] = ringp[slot * (SLOT_BYTES / 8) + k * LDPC_WAVE + lane];
                 wait_lds_reads();  // the slot is free once its values sit in registers
-                if (idx + LDPC_RING_DEPTH < nsteps) issue_row(i + LDPC_RING_DEPTH * nwaves, slot);
+                if (idx + RING < nsteps) issue_row(i + RING * nwaves, slot);
                 const bool neg = (nzm[i] >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
                 const int parity = (int)((par[i] >> lane) & 1ull);
                 check_row<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab);
-                slot = slot + 1 == LDPC_RING_DEPTH ? 0 : slot + 1;
+                slot = slot + 1 == RING ? 0 : slot + 1;
             }
         } else {
             // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
@@ -411,12 +410,12 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     lds_dma16(Ct.rsrc, voff, 0u, ring_addr + slot * SLOT_BYTES + c * 1024);
                 }
             };
-            for (int p = 0; p < LDPC_RING_DEPTH; ++p)
+            for (int p = 0; p < RING; ++p)
                 if (p < nsteps) issue_pair(wave + p * nwaves, p);
             int slot = 0;
             for (int idx = 0; idx < nsteps; ++idx) {
                 const int g = wave + idx * nwaves;
-                if (idx >= LDPC_RING_DEPTH && idx + LDPC_RING_DEPTH - 1 < nsteps) wait_vmcnt<N_BIT>();
+                if (idx >= RING && idx + RING - 1 < nsteps) wait_vmcnt<N_BIT>();
                 else wait_vmcnt<0>();
                 double c[2][DC];
 #pragma unroll
@@ -425,7 +424,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     for (int k = 0; k < DC; ++k)
                         c[u][k] = ringp[slot * (SLOT_BYTES / 8) + (u * DC + k) * LDPC_WAVE + lane];
                 wait_lds_reads();
-                if (idx + LDPC_RING_DEPTH < nsteps) issue_pair(g + LDPC_RING_DEPTH * nwaves, slot);
+                if (idx + RING < nsteps) issue_pair(g + RING * nwaves, slot);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int j = 2 * g + u;
@@ -439,7 +438,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                         if (last && want_llr && lane_live) Lt.st(l8, j, llr);
                     }
                 }
-                slot = slot + 1 == LDPC_RING_DEPTH ? 0 : slot + 1;
+                slot = slot + 1 == RING ? 0 : slot + 1;
             }
         } else {
             // UB columns per wavefront step: all their message loads are issued before the first is used.
@@ -686,7 +685,7 @@ struct ldpc_hip_bp {
     int32_t waves_per_wg = 0;  // 0 = auto
     int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
     bool regular = false;   // every row has the same weight and every column has the same weight
-    bool use_ring = true;   // LDS-DMA ring variant allowed (tuning knob)
+    int32_t ring_depth = 3; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
     std::vector<double> channel_probs;
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
@@ -869,7 +868,8 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_wg, int32_t max_chu
 
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    h->use_ring = enable != 0;
+    if (enable < 0 || enable > 3) return fail(LDPC_HIP_ERR_INVALID, "ring depth must be 0 (off), 1 (default depth), 2 or 3");
+    h->ring_depth = enable == 1 ? 3 : enable;
     return LDPC_HIP_OK;
 }
 
@@ -907,20 +907,22 @@ typedef void (*bp_kernel_t)(const BpArgs);
 struct KernelChoice {
     bp_kernel_t fn;
     int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
+    int ring_depth;
 };
 
 template <int METHOD, int MATH>
-static KernelChoice pick_kernel(int max_row, int max_col, bool regular) {
+static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
     // Register arrays are sized by the template bounds, so the common regular codes get exact fits:
     // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
-    if (regular && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 1>, 3 * 1024};
-    if (regular && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 1>, 4 * 1024};
-    if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0};
-    if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0};
-    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0};
-    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0};
-    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0};
-    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0};  // heavier nodes take the streaming path inside
+    if (ring_depth == 2 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 2>, 3 * 1024, 2};
+    if (ring_depth >= 3 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 3>, 3 * 1024, 3};
+    if (ring_depth >= 2 && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
+    if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0, 0};
+    if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0, 0};
+    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0};
+    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0, 0};
+    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0, 0};
+    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0};  // heavier nodes take the streaming path inside
 }
 
 // Everything below runs on h->stream with device pointers only.
@@ -954,11 +956,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
 
-    const bool regular = h->regular && h->use_ring;
+    const int ring = h->regular ? h->ring_depth : 0;
     KernelChoice kern;
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, regular);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, regular);
-    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, regular);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, ring);
+    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
     h->accumulated_ms = 0.f;
     h->timed = false;
     hipStream_t st = h->stream;
@@ -994,8 +996,9 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
         int waves = h->waves_per_wg;
         if (waves <= 0) waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
-        // ring variant: each wavefront owns LDPC_RING_DEPTH slots of dynamic LDS; stay below the 160 KiB of a CU
-        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * LDPC_RING_DEPTH;
+        if (waves > 16) waves = 16;
+        // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
+        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth;
         while (lds_per_wave * (size_t)waves > 144u * 1024u) --waves;
         const size_t dyn_lds = lds_per_wave * (size_t)waves;
         if (dyn_lds > 48u * 1024u)

@@ -74,9 +74,9 @@ class HipBpEngine:
         code = {"libm_exact": 0, "exact": 0, 0: 0, "fast": 1, 1: 1}[mode]
         _lib.check(self._lib.ldpc_hip_bp_set_math(self._h, code))
 
-    def set_ring(self, enable: bool):
-        """LDS-DMA ring variant for regular-degree matrices on/off (same results, different data movement)."""
-        _lib.check(self._lib.ldpc_hip_bp_set_ring(self._h, 1 if enable else 0))
+    def set_ring(self, depth):
+        """LDS-DMA ring for regular-degree matrices: False/0 = off, True/1 = default depth, 2 or 3 = slots per wave."""
+        _lib.check(self._lib.ldpc_hip_bp_set_ring(self._h, int(depth)))
 
     def workspace_bytes(self, batch):
         return int(self._lib.ldpc_hip_bp_workspace_bytes(self._h, int(batch)))
