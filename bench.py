@@ -128,6 +128,17 @@ def main() -> None:
         alg = algorithmic_bytes(iters, m, n, nnz)
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC run of this same workload (profiles/hbm_traffic.json,
+        # produced by tools/profile_bench.sh + tools/prof_parse.py); null when absent or for another workload
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tj) and world == 1 and method_id == 0:
+            try:
+                t = json.load(open(tj))
+                if t.get("batch_per_gpu") == B and t.get("p") == args.p and t.get("max_iter") == args.max_iter and t.get("n") == n:
+                    traffic = t["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         res = {
             "metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k" if method_id == 0 else "syndromes_per_sec_DIAGNOSTIC_min_sum",
             "value": total * args.steps / elapsed,
@@ -146,7 +157,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "bp_decode_kernel", "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg,
                 "note": "algorithmic bytes = sum over syndromes of iters_run*4*E*8 + (m+n+8n+5); kernel_ms = HIP events on the launch stream",

@@ -142,7 +142,7 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t 
  */
 /* For matrices whose rows all have one weight and whose columns all have one weight the BP kernel
  * streams messages through a per-wavefront LDS ring filled by asynchronous global->LDS loads
- * (default: 3 slots per wavefront).  depth 0 forces the register-prefetch variant used for irregular
+ * (default: 2 slots per wavefront).  depth 0 forces the register-prefetch variant used for irregular
  * matrices, 2 or 3 select the ring depth (1 = default); results are identical in every case. */
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 

@@ -685,7 +685,7 @@ struct ldpc_hip_bp {
     int32_t waves_per_wg = 0;  // 0 = auto
     int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
     bool regular = false;   // every row has the same weight and every column has the same weight
-    int32_t ring_depth = 3; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
+    int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
     std::vector<double> channel_probs;
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
@@ -869,7 +869,7 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_wg, int32_t max_chu
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (enable < 0 || enable > 3) return fail(LDPC_HIP_ERR_INVALID, "ring depth must be 0 (off), 1 (default depth), 2 or 3");
-    h->ring_depth = enable == 1 ? 3 : enable;
+    h->ring_depth = enable == 1 ? 2 : enable;
     return LDPC_HIP_OK;
 }
 
@@ -994,8 +994,15 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.conv = conv ? conv + b0 : nullptr;
 
         // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
+        // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,
+        // 16 wavefronts per CU -> 4-wave workgroups once there are >= 4 tiles per CU.  Ring variant:
+        // ~70 VGPRs and 6 KiB of LDS per wavefront -> 24 wavefronts per CU as three 8-wave workgroups
+        // (measured best on MI355X: profiles/; 6-wave workgroups place unevenly on the 4 SIMDs).
         int waves = h->waves_per_wg;
-        if (waves <= 0) waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+        if (waves <= 0) {
+            if (kern.ring_depth) waves = tiles >= 768 ? 8 : 16;
+            else waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+        }
         if (waves > 16) waves = 16;
         // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
         const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth;

@@ -237,3 +237,107 @@ def test_full_size_config2_properties():
     assert conv.mean() > 0.99
     chk = np.asarray((h.astype(np.int32) @ d.T.astype(np.int32)).T % 2, dtype=np.uint8)
     assert np.array_equal(chk[conv], s.cpu().numpy()[conv])
+
+
+@pytest.mark.parametrize("method,alpha", [("product_sum", 1.0), ("minimum_sum", 0.625)])
+@pytest.mark.parametrize("ring", [0, 2, 3])
+def test_kernel_variants_agree_bit_for_bit(method, alpha, ring, oracle_built):
+    """LDS-DMA ring (depth 2/3) and register-prefetch variants move data differently but compute identically."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import regular_ldpc_code
+    h = regular_ldpc_code(1200, 3, 6, seed=9)  # exactly regular -> the ring variant is eligible
+    synd = _synd(h, 0.07, seed=21, shots=300)
+    wd, wl, wi, wc = oracle_built.BpOracle(h, error_rate=0.07, max_iter=40, bp_method=method,
+                                           ms_scaling_factor=alpha).decode_batch(synd)
+    eng = HipBpEngine(h.indptr, h.indices, 1200, np.full(1200, 0.07), 40, 0 if method == "product_sum" else 1, alpha)
+    eng.set_ring(ring)
+    for waves in (0, 4, 16):
+        eng.set_tuning(waves_per_workgroup=waves)
+        dec, llr, it, cv = eng.decode_batch(synd)
+        assert np.array_equal(dec, wd) and np.array_equal(it, wi) and np.array_equal(cv, wc)
+        assert llr_close(llr, wl, rtol=LLR_RTOL)
+        if method == "minimum_sum" or _host_libm_is_glibc():
+            assert bits_equal(llr, wl)
+
+
+def test_odd_column_count_and_tiny_regular_code(oracle_built):
+    """Ring variant edge cases: odd n (last column pair has one member), fewer rows than wavefronts x depth."""
+    import scipy.sparse as sp
+    from ldpc_amd.engine import HipBpEngine
+    # (3,6)-regular with n = 6 * 3 = 18... use circulant construction: n = 9 columns of weight 2? keep (3,6): n=2m
+    rng = np.random.default_rng(4)
+    m, n = 7, 14  # rows of weight 6, columns of weight 3 via three shifted identity pairs
+    rows, cols = [], []
+    for i in range(m):
+        for t, sft in enumerate((0, 1, 3)):
+            rows += [i, i]
+            cols += [(i + sft) % m, m + (i + 2 * sft) % m]
+    h = sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, cols)), shape=(m, n))
+    h.sum_duplicates(); h.data[:] = 1; h.sort_indices()
+    assert set(np.diff(h.indptr)) == {6} and set(np.asarray(h.sum(0)).ravel()) == {3}
+    synd = rng.integers(0, 2, size=(70, m)).astype(np.uint8)
+    for method, alpha in (("product_sum", 1.0), ("minimum_sum", 0.8)):
+        wd, wl, wi, wc = oracle_built.BpOracle(h, error_rate=0.08, max_iter=12, bp_method=method,
+                                               ms_scaling_factor=alpha).decode_batch(synd)
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.08), 12, 0 if method == "product_sum" else 1, alpha)
+        for waves in (1, 4, 16):
+            eng.set_tuning(waves_per_workgroup=waves)
+            dec, llr, it, cv = eng.decode_batch(synd)
+            assert np.array_equal(dec, wd) and np.array_equal(it, wi) and np.array_equal(cv, wc)
+            assert llr_close(llr, wl, rtol=LLR_RTOL)
+
+
+def test_bpdecoder_api_matches_reference_known_answers():
+    """The reference's own Python tests (python_test/test_bp_decoder.py:175-211), run against the mirror class."""
+    from ldpc_amd.bp_decoder import BpDecoder
+    from ldpc_amd.codes import rep_code
+    H = rep_code(3)
+    bpd = BpDecoder(H, error_rate=0.1, input_vector_type="syndrome")
+    assert bpd.bp_method == "product_sum" and bpd.schedule == "parallel"
+    assert np.array_equal(bpd.error_channel, np.array([0.1, 0.1, 0.1]))
+    bpd.decode(np.array([1, 1]))
+    assert np.array_equal(bpd.decoding, np.array([0, 1, 0]))
+    bpd.error_channel = np.array([0.1, 0, 0.1])
+    bpd.decode(np.array([1, 1]))
+    assert np.array_equal(bpd.decoding, np.array([1, 0, 1]))
+    ms = BpDecoder(H, error_rate=0.1, bp_method="min_sum", ms_scaling_factor=1.0)
+    assert ms.bp_method == "minimum_sum"
+    ms.decode(np.array([1, 1]))
+    assert np.array_equal(ms.decoding, np.array([0, 1, 0]))
+    ms.error_channel = np.array([0.1, 0, 0.1])
+    ms.decode(np.array([1, 1]))
+    assert np.array_equal(ms.decoding, np.array([1, 0, 1]))
+
+
+def test_bpdecoder_decode_and_batch_semantics(oracle_built):
+    """decode(): dtype preserved, converge/iter/log_prob_ratios properties, received-vector mode, zero shortcut;
+    decode_batch(): row b == decode(row b)."""
+    from ldpc_amd.bp_decoder import BpDecoder
+    c = load_case("c1_hamming5_ps20")
+    h = c["h"]
+    d = BpDecoder(h, error_rate=0.1, max_iter=20, bp_method="product_sum")
+    s = c["syndromes"][3]
+    out = d.decode(s.astype(np.int64))
+    assert out.dtype == np.int64 and np.array_equal(out, c["decoding"][3])
+    assert d.converge == bool(c["converge"][3]) and d.iter == int(c["iterations"][3])
+    assert bits_equal(d.log_prob_ratios, c["llr"][3])
+    # received-vector mode (bp.hpp:162-180): input of length n -> syndrome = H r, output = bp(H r) XOR r
+    r = np.zeros(31, np.uint8); r[[2, 17]] = 1
+    got = d.decode(r)
+    syn = (h @ r) % 2
+    want, _, _, _ = oracle_built.BpOracle(h, error_rate=0.1, max_iter=20).decode_batch(syn[None, :].astype(np.uint8))
+    assert np.array_equal(got, want[0] ^ r)
+    # all-zero input: zeros, converge=True, BP state untouched (pyx:679-681)
+    before = d.log_prob_ratios.copy()
+    z = d.decode(np.zeros(5, np.uint8))
+    assert not z.any() and d.converge is True and bits_equal(d.log_prob_ratios, before)
+    # batch
+    batch = d.decode_batch(c["syndromes"])
+    nz = c["syndromes"].any(axis=1)
+    assert np.array_equal(batch[nz], c["decoding"][nz]) and not batch[~nz].any()
+    assert np.array_equal(d.converge_batch[nz], c["converge"][nz]) and d.converge_batch[~nz].all()
+    assert np.array_equal(d.iter_batch[nz], c["iterations"][nz])
+    with pytest.raises(ValueError):
+        d.decode(np.zeros(7, np.uint8))
+    with pytest.raises(NotImplementedError):
+        BpDecoder(h, error_rate=0.1, schedule="serial").decode(s)

@@ -29,3 +29,29 @@ for p in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
                              "group by kernel_name, counter_name order by kernel_name, counter_name"):
             if filt in r[0]:
                 print(f"  {r[0][:44]:44s} {r[1]:28s} {r[2]:.6g}  (dispatches {r[3]})")
+
+
+# HBM traffic per launch of the dominant kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+# prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2; both counters are in KiB.
+fetch = write = None
+nd = 0
+for p in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+    cur = sqlite3.connect(p).cursor()
+    try:
+        for name, cname, total, cnt in cur.execute(
+                "select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
+            if filt in name and cname == "FETCH_SIZE":
+                fetch, nd = total / cnt, cnt
+            if filt in name and cname == "WRITE_SIZE":
+                write = total / cnt
+    except sqlite3.Error:
+        pass
+if fetch is not None and write is not None:
+    import json
+    traffic = (2.0 * fetch + write) * 1024.0
+    print("# HBM traffic per launch (bytes) = (2*FETCH_SIZE + WRITE_SIZE) * 1024 =", f"{traffic:.6g}",
+          f"(FETCH_SIZE {fetch:.6g} KiB, WRITE_SIZE {write:.6g} KiB per dispatch)")
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            json.dump({"kernel": filt, "hbm_bytes_per_launch": traffic, "fetch_size_kib": fetch, "write_size_kib": write,
+                       "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE x1; both KiB", "source": root}, f, indent=1)

@@ -20,5 +20,5 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   echo "== pmc $grp" >> "$OUT/log.txt"
   timeout 600 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" -o pmc -- python bench.py $ARGS >> "$OUT/log.txt" 2>&1
 done
-python tools/prof_parse.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/prof_parse.py "$OUT" bp_decode "$OUT/hbm_traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
