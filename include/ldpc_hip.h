@@ -105,6 +105,24 @@ int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int
                                    uint8_t *converge);
 
 /*
+ * replaces: BpOsdDecoder.decode with osd_method = OSD_0 for `batch` syndromes
+ * (src_python/ldpc/bposd_decoder/_bposd_decoder.pyx:125-134): belief propagation as above, then for every
+ * row BP left unconverged ldpc::osd::OsdDecoder::decode with osd_order 0 (src_cpp/osd.hpp:110-117) =
+ * soft_decision_col_sort (sort.hpp:48-62; stable, ties by ascending column) + RowReduce::fast_solve
+ * (gf2sparse_linalg.hpp:298-401) + lu_solve (:237-288), all on the device.  `decoding` receives the BP
+ * decision for converged rows and the OSD-0 solution otherwise; llr / iterations / converge are BP's
+ * (bpd.log_prob_ratios, bpd.iterations, bpd.converge), any of them may be NULL.
+ * The bit-packed [H | s] of one syndrome must fit in LDS (m * ceil((n+1)/64) * 8 + 13 n + 4 m <= 150 KiB),
+ * else LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H (any H e does).
+ */
+int ldpc_hip_bposd0_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                                 uint8_t *decoding, double *llr, int32_t *iterations,
+                                 uint8_t *converge);
+int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                                       uint8_t *decoding, double *llr, int32_t *iterations,
+                                       uint8_t *converge);
+
+/*
  * replaces: GF2Sparse::mulvec (gf2sparse.hpp:177-214) over a batch:
  * out[b][i] = XOR_{j in row i} in[b][j].  Used by received-vector mode (bp.hpp:162-180).
  */

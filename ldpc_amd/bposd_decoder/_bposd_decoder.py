@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's ``BpOsdDecoder`` (src_python/ldpc/bposd_decoder/_bposd_decoder.pyx:8-299).
+
+BP runs in the HIP kernels; rows BP leaves unconverged get order-zero ordered-statistics decoding
+(``osd.hpp:110-117``) on the device as well (``ldpc_hip_bposd0_decode_batch``).  Only ``osd_method`` OSD_0 is
+available on this path: OSD_E / OSD_CS (``osd.hpp:119-187``) are listed as "next" in SURVEY.md §8f and raise
+``NotImplementedError`` at decode time -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from ldpc_amd.bp_decoder._bp_decoder import BpDecoderBase, PARALLEL, _UNSET, _check_pcm_type, _typed
+
+OSD_OFF, OSD_0, EXHAUSTIVE, COMBINATION_SWEEP = 0, 1, 2, 3  # ldpc::osd::OsdMethod, osd.hpp:18-23
+
+
+class BpOsdDecoder(BpDecoderBase):
+    """Belief propagation + OSD decoder (constructor keywords as in the reference, pyx:54-58)."""
+
+    def __init__(self, pcm, *, error_rate=_UNSET, error_channel=_UNSET, max_iter=_UNSET, bp_method=_UNSET,
+                 ms_scaling_factor=_UNSET, schedule=_UNSET, omp_thread_count=_UNSET, random_schedule_seed=_UNSET,
+                 serial_schedule_order=_UNSET, osd_method=0, osd_order: int = 0, input_vector_type: str = "syndrome",
+                 **kwargs):
+        for key in kwargs.keys():  # pyx:60-62 (the reference's message says BpDecoder here too)
+            if key not in ["channel_probs", "_device"]:
+                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
+        _check_pcm_type(pcm)
+        given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
+                     ms_scaling_factor=ms_scaling_factor, schedule=schedule, omp_thread_count=omp_thread_count,
+                     random_schedule_seed=random_schedule_seed, serial_schedule_order=serial_schedule_order)
+        passed = dict(kwargs)
+        passed.update({k: v for k, v in given.items() if v is not _UNSET})
+        _typed("error_rate", passed.get("error_rate"), float, "float")
+        _typed("max_iter", passed.get("max_iter"), int, "int")
+        _typed("bp_method", passed.get("bp_method"), str, "str")
+        _typed("schedule", passed.get("schedule"), str, "str")
+        super().__init__(pcm, **passed)
+        self._osd_method = OSD_OFF  # `new OsdDecoderCpp(pcm, OSD_OFF, 0, ...)`, pyx:67
+        self._osd_order = 0
+        self.osd_method = osd_method
+        self.osd_order = osd_order
+        self.input_vector_type = "syndrome"  # pyx:72
+        self._bp_decoding = np.zeros(self.n, np.uint8)
+        self._osd0_decoding = np.zeros(self.n, np.uint8)
+        self.bp_decoding_batch = None
+
+    # ---- OSD parameters (pyx:139-234) -------------------------------------------------------------
+    @property
+    def osd_method(self):
+        return {OSD_0: "OSD_0", EXHAUSTIVE: "OSD_E", COMBINATION_SWEEP: "OSD_CS", OSD_OFF: "OSD_OFF"}.get(self._osd_method)
+
+    @osd_method.setter
+    def osd_method(self, method) -> None:
+        key = str(method).lower()
+        if key in ["osd_0", "0", "osd0"]:
+            self._osd_method = OSD_0
+            self._osd_order = 0
+        elif key in ["osd_e", "e", "exhaustive"]:
+            self._osd_method = EXHAUSTIVE
+        elif key in ["osd_cs", "1", "cs", "combination_sweep"]:
+            self._osd_method = COMBINATION_SWEEP
+        elif key in ["off", "osd_off", "deactivated", -1]:
+            self._osd_method = OSD_OFF
+        else:
+            raise ValueError(f"ERROR: OSD method '{method}' invalid. Please choose from the following methods:\
+                'OSD_0', 'OSD_E' or 'OSD_CS'.")
+
+    @property
+    def osd_order(self) -> int:
+        return self._osd_order
+
+    @osd_order.setter
+    def osd_order(self, order: int) -> None:
+        if order < 0:
+            raise ValueError(f"ERROR: OSD order '{order}' invalid. Please choose a positive integer.")
+        if self._osd_method == OSD_0 and order != 0:
+            raise ValueError(f"ERROR: OSD order '{order}' invalid. The 'osd_method' is set to 'OSD_0'. The osd order must therefore be set to 0.")
+        if self._osd_method == EXHAUSTIVE and order > 15:
+            warnings.warn("WARNING: Running the 'OSD_E' (Exhaustive method) with search depth greater than 15 is not "
+                          "recommended. Use the 'osd_cs' method instead.")
+        self._osd_order = order
+
+    def _require_supported(self):
+        if self._schedule != PARALLEL:
+            self._require_parallel()
+        if not (self._osd_method == OSD_0 or (self._osd_method in (EXHAUSTIVE, COMBINATION_SWEEP) and self._osd_order == 0)):
+            raise NotImplementedError(
+                f"osd_method={self.osd_method} with osd_order={self._osd_order} is not available on the MI355X path yet: "
+                "only OSD-0 (osd.hpp:110-117) is implemented in HIP; there is no CPU fallback.")
+
+    # ---- decode (pyx:78-136) ----------------------------------------------------------------------
+    def decode(self, syndrome: np.ndarray) -> np.ndarray:
+        if not len(syndrome) == self.m:
+            raise ValueError(f"The syndrome must have length {self.m}. Not {len(syndrome)}.")
+        vec = np.asarray(syndrome).astype(np.uint8)
+        if not vec.any():  # pyx:118-123
+            self._converge = True
+            return np.zeros(self.n, dtype=syndrome.dtype)
+        self._require_supported()
+        eng = self._get_engine()
+        dec, llr, it, cv = eng.decode_batch(vec[None, :], osd0=True)
+        self._log_prob_ratios = llr[0]
+        self._iterations = int(it[0])
+        self._converge = bool(cv[0])
+        if self._converge:
+            self._bp_decoding = dec[0].copy()
+            self._decoding = dec[0].copy()
+        else:
+            self._osd0_decoding = dec[0].copy()
+        return dec[0].astype(syndrome.dtype)
+
+    def decode_batch(self, syndromes, want_log_prob_ratios: bool = True):
+        """Every row through BP (+ OSD-0 where BP does not converge) in one call; row b == ``decode(syndromes[b])``."""
+        if syndromes.ndim != 2 or syndromes.shape[1] != self.m:
+            raise ValueError(f"The syndrome must have length {self.m}. Not {syndromes.shape[-1]}.")
+        self._require_supported()
+        eng = self._get_engine()
+        dtype = syndromes.dtype
+        vec = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
+        dec, llr, it, cv = eng.decode_batch(vec, want_llr=want_log_prob_ratios, osd0=True)
+        zero = ~vec.any(axis=1)
+        dec[zero] = 0
+        cv[zero] = True
+        it[zero] = 0
+        if llr is not None:
+            llr[zero] = 0.0
+        self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv, it, llr
+        if len(vec):
+            self._converge = bool(cv[-1])
+        return dec.astype(dtype)
+
+    # ---- results (pyx:236-299) --------------------------------------------------------------------
+    @property
+    def bp_decoding(self) -> np.ndarray:
+        return np.array(self._bp_decoding).astype(int)
+
+    @property
+    def osd0_decoding(self) -> np.ndarray:
+        return np.array(self._bp_decoding if self._converge else self._osd0_decoding).astype(int)
+
+    @property
+    def osdw_decoding(self) -> np.ndarray:
+        return self.osd0_decoding  # order 0: osdw_decoding == osd0_decoding (osd.hpp:113)
+
+    @property
+    def decoding(self) -> np.ndarray:
+        # the reference's property reads a misspelt member (`self.osD`, pyx:247) and raises AttributeError;
+        # the intended value is osdw_decoding
+        return self.osdw_decoding

@@ -596,6 +596,104 @@ __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__rest
     }
 }
 
+// ---- OSD-0 (osd.hpp:110-117 = sort.hpp:48-62 + gf2sparse_linalg.hpp:298-401, 237-288) -------------
+// One wavefront per syndrome that BP left unconverged.  The reference sorts the columns by ascending
+// log-ratio (glibc qsort: stable, so ties keep ascending index), runs a greedy column-ordered Gaussian
+// elimination on a linked-list matrix until the syndrome is in the span of the pivots, and solves on
+// the pivot columns.  That solution is unique given the column order (the reference's min-row-weight
+// pivoting only picks which ROW carries a pivot), so here the augmented matrix [H | s] lives bit-packed
+// in LDS (lane l owns rows l, l+64, ...), columns are visited in rank order and eliminated
+// Gauss-Jordan style with wave ballots.  All LDS traffic is wave-private: no workgroup barriers.
+struct OsdArgs {
+    int32_t m, n, words;  // words = ceil((n + 1) / 64): n matrix bits + the syndrome bit per row
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx;
+    const uint8_t *synd;   // [batch][m]
+    const double *llr;     // [batch][n]  BP posteriors
+    const uint8_t *conv;   // [batch]     1 = BP converged: row left untouched
+    uint8_t *decoding;     // [batch][n]  in: BP decisions, out: OSD-0 solution for unconverged rows
+    int32_t lds_per_wave;  // bytes
+};
+
+__device__ __forceinline__ bool osd_less(double a, int ia, double b, int ib) {
+    const bool na = a != a, nb = b != b;
+    if (na || nb) return na == nb ? ia < ib : nb;  // numbers before NaNs (reference order undefined for NaN)
+    if (a < b) return true;
+    if (a > b) return false;
+    return ia < ib;  // stable: ties in ascending index, as glibc's merge-sort qsort leaves them
+}
+
+__global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
+    const int m = a.m, n = a.n, W = a.words;
+    unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
+    volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                  // [m][W]
+    volatile double *keys = reinterpret_cast<volatile double *>(base + (size_t)m * W * 8);  // [n]
+    volatile int32_t *order = reinterpret_cast<volatile int32_t *>(base + (size_t)m * W * 8 + (size_t)n * 8);  // [n]
+    volatile int32_t *pivot_col = order + n;                                                // [m]
+    volatile uint8_t *x = reinterpret_cast<volatile uint8_t *>(const_cast<int32_t *>(pivot_col + m));  // [n]
+
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int i = lane; i < m; i += 64) {
+        for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
+        for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+            const int c = a.col_idx[e];
+            mat[(size_t)i * W + (c >> 6)] = mat[(size_t)i * W + (c >> 6)] | (1ull << (c & 63));
+        }
+        if (a.synd[b * m + i]) mat[(size_t)i * W + sw] = mat[(size_t)i * W + sw] | sbit;  // `if (i)`, gf2sparse_linalg.hpp:309
+        pivot_col[i] = -1;
+    }
+    for (int j = lane; j < n; j += 64) { keys[j] = a.llr[b * n + j]; x[j] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    // soft_decision_col_sort: rank of column i = number of columns that sort before it
+    for (int i = lane; i < n; i += 64) {
+        const double ki = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += osd_less(keys[j], j, ki, i) ? 1 : 0;
+        order[r] = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int max_rank = m < n ? m : n;
+    int rank = 0;
+    for (int t = 0; t < n && rank < max_rank; ++t) {
+        const int c = order[t];
+        const int cw = c >> 6;
+        const uint64_t cb = 1ull << (c & 63);
+        // first unpivoted row with a one in column c
+        int p = -1;
+        for (int i0 = 0; i0 < m && p < 0; i0 += 64) {
+            const int i = i0 + lane;
+            const bool cand = i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + cw] & cb);
+            const uint64_t mask = __ballot(cand);
+            if (mask) p = i0 + __builtin_ctzll(mask);
+        }
+        if (p < 0) continue;
+        for (int i = lane; i < m; i += 64)
+            if (i != p && (mat[(size_t)i * W + cw] & cb))
+                for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = mat[(size_t)i * W + w] ^ mat[(size_t)p * W + w];
+        if (lane == 0) pivot_col[p] = c;
+        ++rank;
+        __builtin_amdgcn_wave_barrier();
+        // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
+        bool pending = false;
+        for (int i0 = 0; i0 < m && !pending; i0 += 64) {
+            const int i = i0 + lane;
+            pending = __ballot(i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + sw] & sbit)) != 0;
+        }
+        if (!pending) break;
+    }
+    for (int i = lane; i < m; i += 64)
+        if (pivot_col[i] >= 0 && (mat[(size_t)i * W + sw] & sbit)) x[pivot_col[i]] = 1;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = x[j];
+}
+
 // GF2Sparse::mulvec over a batch (gf2sparse.hpp:177-214): one thread per (vector, check)
 __global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
                                   const int32_t *__restrict__ col_idx, int m, int n,
@@ -698,6 +796,7 @@ struct ldpc_hip_bp {
 
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
+    DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
 };
 
@@ -816,7 +915,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc})
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
     if (h->d_col_idx) (void)hipFree(h->d_col_idx);
@@ -1037,7 +1136,49 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     return LDPC_HIP_OK;
 }
 
+
+// BP, then OSD-0 on the rows BP left unconverged; device pointers, on h->stream
+static int bposd0_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                         int32_t *iters, uint8_t *conv) {
+    const size_t B = (size_t)batch, n = (size_t)h->n;
+    int rc;
+    if (!llr) { if ((rc = h->osd_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; llr = (double *)h->osd_llr.p; }
+    if (!conv) { if ((rc = h->osd_conv.ensure(B ? B : 1))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv))) return rc;
+    if (h->m == 0 || h->n == 0) return LDPC_HIP_OK;
+    OsdArgs a;
+    a.m = h->m; a.n = h->n; a.words = (h->n + 1 + 63) / 64;
+    a.batch = batch;
+    a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
+    a.synd = synd; a.llr = llr; a.conv = conv; a.decoding = decoding;
+    size_t per_wave = (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
+    per_wave = (per_wave + 15) & ~(size_t)15;
+    if (per_wave > 150u * 1024u)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED,
+                    "OSD-0 on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB available", per_wave);
+    int waves = (int)((150u * 1024u) / per_wave);
+    if (waves > 4) waves = 4;
+    a.lds_per_wave = (int32_t)per_wave;
+    const size_t dyn = per_wave * (size_t)waves;
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)osd0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const int64_t blocks = (batch + waves - 1) / waves;
+    hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 extern "C" {
+
+int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
+                                       uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
+    HIPCHK(hipSetDevice(h->device));
+    return bposd0_device(h, synd, batch, decoding, llr, iters, conv);
+}
 
 int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
                                    uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
@@ -1050,8 +1191,21 @@ int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t 
     return decode_device(h, synd, batch, decoding, llr, iters, conv);
 }
 
+static int decode_batch_staged(ldpc_hip_bp *h, bool with_osd0, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                               double *llr, int32_t *iters, uint8_t *conv);
+
 int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                              double *llr, int32_t *iters, uint8_t *conv) {
+    return decode_batch_staged(h, false, synd, batch, decoding, llr, iters, conv);
+}
+
+int ldpc_hip_bposd0_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                 double *llr, int32_t *iters, uint8_t *conv) {
+    return decode_batch_staged(h, true, synd, batch, decoding, llr, iters, conv);
+}
+
+static int decode_batch_staged(ldpc_hip_bp *h, bool with_osd0, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                               double *llr, int32_t *iters, uint8_t *conv) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
     if (batch == 0) return LDPC_HIP_OK;
@@ -1077,7 +1231,8 @@ int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
     if (h_it) { if ((rc = h->st_iters.ensure(B * 4))) return rc; d_it = (int32_t *)h->st_iters.p; }
     if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
 
-    if ((rc = decode_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv))) return rc;
+    if ((rc = with_osd0 ? bposd0_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv)
+                        : decode_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv))) return rc;
 
     if (h_dec) HIPCHK(hipMemcpyAsync(decoding, d_dec, B * n, hipMemcpyDeviceToHost, h->stream));
     if (h_llr) HIPCHK(hipMemcpyAsync(llr, d_llr, B * n * 8, hipMemcpyDeviceToHost, h->stream));

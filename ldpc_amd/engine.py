@@ -87,8 +87,11 @@ class HipBpEngine:
         return float(ms.value)
 
     # -- data path --------------------------------------------------------------------------------
-    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False):
+    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False):
         """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
+
+        ``osd0=True`` runs BP + OSD-0 (``ldpc_hip_bposd0_decode_batch``): ``decoding`` holds the OSD-0 solution for
+        rows BP left unconverged; llr / iterations / converge remain BP's.
 
         NumPy in -> NumPy out (host pointers); torch CUDA tensor in -> torch CUDA tensors out.
         ``out`` may carry preallocated torch outputs ``(decoding, llr, iterations, converge)``.
@@ -109,7 +112,10 @@ class HipBpEngine:
                 llr = torch.empty((b, self.n), dtype=torch.float64, device=s.device) if want_llr else None
                 it = torch.empty((b,), dtype=torch.int32, device=s.device)
                 cv = torch.empty((b,), dtype=torch.uint8, device=s.device)
-            fn = self._lib.ldpc_hip_bp_decode_batch_async if asynchronous else self._lib.ldpc_hip_bp_decode_batch
+            if osd0:
+                fn = self._lib.ldpc_hip_bposd0_decode_batch_async if asynchronous else self._lib.ldpc_hip_bposd0_decode_batch
+            else:
+                fn = self._lib.ldpc_hip_bp_decode_batch_async if asynchronous else self._lib.ldpc_hip_bp_decode_batch
             _lib.check(fn(self._h, s.data_ptr(), b, dec.data_ptr(), llr.data_ptr() if llr is not None else None,
                           it.data_ptr(), cv.data_ptr()))
             return dec, llr, it, cv
@@ -121,9 +127,9 @@ class HipBpEngine:
         llr = np.zeros((b, self.n), np.float64) if want_llr else None
         it = np.zeros(b, np.int32)
         cv = np.zeros(b, np.uint8)
-        _lib.check(self._lib.ldpc_hip_bp_decode_batch(
-            self._h, s.ctypes.data, b, dec.ctypes.data, llr.ctypes.data if want_llr else None,
-            it.ctypes.data, cv.ctypes.data))
+        fn = self._lib.ldpc_hip_bposd0_decode_batch if osd0 else self._lib.ldpc_hip_bp_decode_batch
+        _lib.check(fn(self._h, s.ctypes.data, b, dec.ctypes.data, llr.ctypes.data if want_llr else None,
+                      it.ctypes.data, cv.ctypes.data))
         return dec, llr, it, cv.astype(bool)
 
     def mulvec_batch(self, vectors):

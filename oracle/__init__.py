@@ -86,6 +86,8 @@ class _OracleLib:
             lib.oracle_gen_bsc_syndromes.argtypes = [
                 C.c_int, C.c_int, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
                 _u8p, C.c_void_p]
+            lib.osd0_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _u8p]
+            lib.bposd0_oracle_decode_batch.argtypes = lib.bp_oracle_decode_batch.argtypes
             lib.oracle_sm64.restype = C.c_uint64
             lib.oracle_sm64.argtypes = [C.c_uint64, C.c_uint64]
             cls._lib = lib
@@ -125,6 +127,25 @@ class BpOracle:
         self.lib.bp_oracle_decode_batch(
             self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b, dec,
             llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def osd0(self, syndrome, llr):
+        """OSD-0 alone (osd.hpp:110-117 restated) on one syndrome and one vector of log-ratios."""
+        out = np.zeros(self.n, np.uint8)
+        self.lib.osd0_oracle(self.m, self.n, self.row_ptr, self.col_idx, np.ascontiguousarray(llr, np.float64),
+                             np.ascontiguousarray(syndrome, np.uint8), out)
+        return out
+
+    def bposd0_decode_batch(self, syndromes, want_llr=True):
+        """BpOsdDecoder.decode per row (_bposd_decoder.pyx:125-134): BP, then OSD-0 where BP did not converge."""
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.bposd0_oracle_decode_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b,
+                                            dec, llr.ctypes.data if want_llr else None, it, conv)
         return dec, llr, it, conv.astype(bool)
 
     def gen_bsc_syndromes(self, seed, p, shot0, shots, want_errors=False):
@@ -190,6 +211,47 @@ class RefBp:
     def mulvec(self, v):
         out = np.zeros(self.m, np.uint8)
         self.lib.ref_bp_mulvec(self._h, np.ascontiguousarray(v, np.uint8), out)
+        return out
+
+
+class RefBpOsd:
+    """The real reference BP + ``ldpc::osd::OsdDecoder`` (OSD_0) behind oracle/ref_harness.cpp."""
+
+    def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum", ms_scaling_factor=1.0):
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
+        lib = C.CDLL(REF_SO)
+        lib.ref_bposd_new.restype = C.c_void_p
+        lib.ref_bposd_new.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_double]
+        lib.ref_bposd_free.argtypes = [C.c_void_p]
+        lib.ref_bposd_decode_batch.argtypes = [C.c_void_p, _u8p, C.c_int64, _u8p, C.c_void_p, _i32p, _u8p]
+        lib.ref_osd0.argtypes = [C.c_void_p, _u8p, _f64p, _u8p]
+        self.lib = lib
+        self.m, self.n, row_ptr, col_idx = csr_arrays(h)
+        rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32)
+        self.channel_probs = _probs(self.n, error_rate, error_channel)
+        self.max_iter = int(max_iter) if max_iter else self.n
+        self._h = lib.ref_bposd_new(self.m, self.n, len(col_idx), np.ascontiguousarray(rows), col_idx, self.channel_probs,
+                                    self.max_iter, _method_id(bp_method), float(ms_scaling_factor))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.ref_bposd_free(self._h)
+            self._h = None
+
+    def decode_batch(self, syndromes, want_llr=True):
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.ref_bposd_decode_batch(self._h, s, b, dec, llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def osd0(self, syndrome, llr):
+        out = np.zeros(self.n, np.uint8)
+        self.lib.ref_osd0(self._h, np.ascontiguousarray(syndrome, np.uint8), np.ascontiguousarray(llr, np.float64), out)
         return out
 
 

@@ -232,3 +232,81 @@ void bp_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_i
     }
     free(tmp);
 }
+
+/* ============================================================================================== *
+ * OSD-0 (order-zero ordered-statistics decoding), the post-processing BpOsdDecoder applies when BP
+ * does not converge: ldpc::osd::OsdDecoder::decode with osd_order == 0 (src_cpp/osd.hpp:110-117) =
+ *   soft_decision_col_sort (sort.hpp:48-62: qsort of (llr, index) ascending by llr, comparator 0 on
+ *   ties; glibc's qsort is a stable merge sort for these sizes, so ties keep ascending index), then
+ *   RowReduce::fast_solve (gf2sparse_linalg.hpp:298-401): greedy Gaussian elimination taking the
+ *   columns in that order, stopping once the syndrome lies in the span of the pivots, and solving on
+ *   the pivot columns (lu_solve, :237-288).
+ * The result is the unique combination of the greedy-independent column prefix that equals the
+ * syndrome; the reference's min-row-weight pivoting (:327-340) only chooses WHICH row carries a
+ * pivot and cannot change that solution, so this restatement uses dense bit-packed Gauss-Jordan
+ * with first-row pivoting.  Requires the syndrome to be in the image of H (true for any H e).
+ * NaN log-ratios make the reference's column order implementation-defined (non-total comparator);
+ * here NaN sorts after every number.
+ * ============================================================================================== */
+static int osd_less(double a, int ia, double b, int ib) {
+    const int na = a != a, nb = b != b;
+    if (na || nb) return na == nb ? ia < ib : nb; /* numbers before NaNs */
+    if (a < b) return 1;
+    if (a > b) return 0;
+    return ia < ib;
+}
+
+void osd0_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                 const uint8_t *syndrome, uint8_t *decoding) {
+    const int words = (n + 1 + 63) / 64; /* n matrix bits + 1 augmented syndrome bit per row */
+    uint64_t *a = (uint64_t *)calloc((size_t)(m ? m : 1) * (size_t)words, sizeof(uint64_t));
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    int *pivot_col = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    for (int i = 0; i < m; i++) {
+        pivot_col[i] = -1;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) a[(size_t)i * words + col_idx[e] / 64] |= 1ull << (col_idx[e] % 64);
+        if (syndrome[i]) a[(size_t)i * words + n / 64] |= 1ull << (n % 64);
+    }
+    /* stable ascending order by counting (O(n^2), fine for a checker) */
+    for (int i = 0; i < n; i++) {
+        int r = 0;
+        for (int j = 0; j < n; j++) r += osd_less(llr[j], j, llr[i], i);
+        order[r] = i;
+    }
+    int rank = 0;
+    for (int t = 0; t < n && rank < m; t++) {
+        const int c = order[t];
+        int p = -1;
+        for (int i = 0; i < m; i++)
+            if (pivot_col[i] < 0 && ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1)) { p = i; break; }
+        if (p < 0) continue;
+        for (int i = 0; i < m; i++)
+            if (i != p && ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1))
+                for (int w = 0; w < words; w++) a[(size_t)i * words + w] ^= a[(size_t)p * words + w];
+        pivot_col[p] = c;
+        rank++;
+        int in_image = 1;
+        for (int i = 0; i < m; i++)
+            if (pivot_col[i] < 0 && ((a[(size_t)i * words + n / 64] >> (n % 64)) & 1)) { in_image = 0; break; }
+        if (in_image) break;
+    }
+    memset(decoding, 0, (size_t)n);
+    for (int i = 0; i < m; i++)
+        if (pivot_col[i] >= 0) decoding[pivot_col[i]] = (uint8_t)((a[(size_t)i * words + n / 64] >> (n % 64)) & 1);
+    free(a); free(order); free(pivot_col);
+}
+
+/* BpOsdDecoder.decode over a batch (_bposd_decoder.pyx:125-134): BP; rows that did not converge get OSD-0 */
+void bposd0_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                                double ms_scaling_factor, const uint8_t *syndromes, int64_t shots,
+                                uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    double *tmp = llr ? NULL : (double *)malloc(sizeof(double) * (size_t)(o->n ? o->n : 1));
+    for (int64_t b = 0; b < shots; b++) {
+        double *l = llr ? llr + b * o->n : tmp;
+        iterations[b] = 0;
+        bp_oracle_decode(o, channel_probs, max_iter, bp_method, ms_scaling_factor, syndromes + b * o->m,
+                         decodings + b * o->n, l, iterations + b, converge + b);
+        if (!converge[b]) osd0_oracle(o->m, o->n, o->row_ptr, o->col_idx, l, syndromes + b * o->m, decodings + b * o->n);
+    }
+    free(tmp);
+}

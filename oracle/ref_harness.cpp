@@ -79,3 +79,58 @@ void ref_bp_mulvec(ref_bp *r, const uint8_t *in, uint8_t *out) {
 }
 
 } /* extern "C" */
+
+/* ---- BP + OSD-0: the real ldpc::osd::OsdDecoder (osd.hpp:26-191) driven as BpOsdDecoder.decode does ---- */
+#include "osd.hpp"
+
+struct ref_bposd {
+    ref_bp *bp;
+    ldpc::osd::OsdDecoder *osd;
+};
+
+extern "C" {
+
+ref_bposd *ref_bposd_new(int m, int n, int nnz, const int32_t *rows, const int32_t *cols,
+                         const double *channel_probs, int max_iter, int bp_method, double ms_scaling_factor) {
+    auto *r = new ref_bposd;
+    r->bp = ref_bp_new(m, n, nnz, rows, cols, channel_probs, max_iter, bp_method, 1 /*PARALLEL*/, ms_scaling_factor, 0 /*SYNDROME*/);
+    r->osd = new ldpc::osd::OsdDecoder(*r->bp->pcm, ldpc::osd::OSD_0, 0, r->bp->dec->channel_probabilities);
+    return r;
+}
+
+void ref_bposd_free(ref_bposd *r) {
+    if (!r) return;
+    delete r->osd;
+    ref_bp_free(r->bp);
+    delete r;
+}
+
+/* _bposd_decoder.pyx:125-134 without the Python-side zero-syndrome shortcut */
+void ref_bposd_decode_batch(ref_bposd *r, const uint8_t *syndromes, int64_t shots, uint8_t *decodings, double *llr,
+                            int32_t *iterations, uint8_t *converge) {
+    const int m = r->bp->dec->check_count, n = r->bp->dec->bit_count;
+    for (int64_t b = 0; b < shots; b++) {
+        std::vector<uint8_t> s(syndromes + b * m, syndromes + (b + 1) * m);
+        r->bp->dec->decode(s);
+        iterations[b] = r->bp->dec->iterations;
+        converge[b] = r->bp->dec->converge ? 1 : 0;
+        if (llr) std::memcpy(llr + b * n, r->bp->dec->log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        if (r->bp->dec->converge) {
+            std::memcpy(decodings + b * n, r->bp->dec->decoding.data(), (size_t)n);
+        } else {
+            auto &x = r->osd->decode(s, r->bp->dec->log_prob_ratios);
+            std::memcpy(decodings + b * n, x.data(), (size_t)n);
+        }
+    }
+}
+
+/* OsdDecoder::decode alone (osd.hpp:110-117) on caller-supplied log-ratios */
+void ref_osd0(ref_bposd *r, const uint8_t *syndrome, const double *llr, uint8_t *decoding) {
+    const int m = r->bp->dec->check_count, n = r->bp->dec->bit_count;
+    std::vector<uint8_t> s(syndrome, syndrome + m);
+    std::vector<double> l(llr, llr + n);
+    auto &x = r->osd->decode(s, l);
+    std::memcpy(decoding, x.data(), (size_t)n);
+}
+
+} /* extern "C" */

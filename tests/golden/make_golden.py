@@ -27,7 +27,7 @@ import scipy.sparse as sp
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-from oracle import RefBp, csr_arrays, have_ref  # noqa: E402
+from oracle import RefBp, RefBpOsd, csr_arrays, have_ref  # noqa: E402
 from ldpc_amd import codes  # noqa: E402
 from ldpc_amd.prng import bernoulli_threshold, sm64  # noqa: E402
 
@@ -77,6 +77,24 @@ def run_case(name, h, syndromes, *, error_rate=None, error_channel=None, max_ite
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **payload)
     print(f"{name:34s} k={k:4d} conv={conv.mean():.3f} iters={it.mean():6.2f} "
+          f"{os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def run_osd_case(name, h, syndromes, *, error_rate, max_iter, bp_method="product_sum", ms_scaling_factor=1.0, note=""):
+    """BpOsdDecoder.decode (OSD_0) per row through the real reference (_bposd_decoder.pyx:125-134, osd.hpp:110-117)."""
+    h = sp.csr_matrix(h, dtype=np.uint8)
+    m, n, rp, ci = csr_arrays(h)
+    ref = RefBpOsd(h, error_rate=error_rate, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=ms_scaling_factor)
+    syndromes = np.ascontiguousarray(syndromes, np.uint8).reshape(-1, m)
+    dec, llr, it, conv = ref.decode_batch(syndromes)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, name=name, note=note, m=m, n=n, h_crc=np.uint32(h_crc(h)), row_ptr=rp, col_idx=ci, recipe="",
+                        channel_probs=ref.channel_probs, max_iter=np.int32(ref.max_iter),
+                        bp_method=np.int32(0 if bp_method in ("product_sum", "ps") else 1),
+                        ms_scaling_factor=np.float64(ms_scaling_factor), syndromes=np.packbits(syndromes, axis=1),
+                        syndromes_packed=np.bool_(True), decoding=np.packbits(dec, axis=1), converge=conv, iterations=it,
+                        llr=llr[:0], llr_rowsum=np.sum(np.where(np.abs(llr) < 1e100, llr, 0.0), axis=1))
+    print(f"{name:34s} k={len(syndromes):4d} conv={conv.mean():.3f} osd rows={int((~conv).sum()):4d} "
           f"{os.path.getsize(path) / 1024:8.1f} KiB")
 
 
@@ -147,6 +165,22 @@ def main():
              bp_method="product_sum", full_llr=64, note="BASELINE.json configs[4], BP stage")
     run_case("c5_bb144_ms50_p050", h, bsc_syndromes(h, 7, 0.05, 0, 256), error_rate=0.05, max_iter=50,
              bp_method="minimum_sum", ms_scaling_factor=0.625, full_llr=64)
+
+    # --- config 5: BP-50 + OSD-0 on BB [[144,12,12]] (and siblings whose H is rank deficient / irregular) ---
+    h = codes.bivariate_bicycle_hx()
+    run_osd_case("osd_c5_bb144_ps50_p050", h, bsc_syndromes(h, 7, 0.05, 0, 1024), error_rate=0.05, max_iter=50,
+                 note="BASELINE.json configs[4]")
+    run_osd_case("osd_bb144_ps50_p070", h, bsc_syndromes(h, 9, 0.07, 0, 512), error_rate=0.07, max_iter=50)
+    run_osd_case("osd_bb144_ms50_p060", h, bsc_syndromes(h, 9, 0.06, 0, 512), error_rate=0.06, max_iter=50,
+                 bp_method="minimum_sum", ms_scaling_factor=0.625)
+    hs = codes.rotated_surface_code_x(7)
+    run_osd_case("osd_surface7_ms30", hs, bsc_syndromes(hs, 7, 0.08, 0, 512), error_rate=0.08, max_iter=30,
+                 bp_method="minimum_sum", ms_scaling_factor=0.625, note="many exact LLR ties: the stable column order matters")
+    hh = codes.hamming_code(6)
+    run_osd_case("osd_hamming6_ps10", hh, bsc_syndromes(hh, 7, 0.06, 0, 256), error_rate=0.06, max_iter=10)
+    hr = codes.ring_code(40)
+    run_osd_case("osd_ring40_ps3", hr, bsc_syndromes(hr, 7, 0.12, 0, 256), error_rate=0.12, max_iter=3,
+                 note="rank-deficient H (m = n, rank n-1), BP cut short so OSD runs often")
 
     # --- edge cases (SURVEY.md §7 "Inf/NaN semantics", §8a a7/a9) ---
     rng_idx = np.arange(31, dtype=np.uint64)

@@ -12,7 +12,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def case_names(prefix: str = ""):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    """BP fixtures (``decoding`` = BpDecoder output).  BP+OSD-0 fixtures are listed by ``osd_case_names``."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in names if not n.startswith("osd_")]
+
+
+def osd_case_names():
+    """Fixtures whose ``decoding`` is BpOsdDecoder's (OSD_0) output; converge/iterations are BP's."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "osd_*.npz")))
 
 
 def _h_from_recipe(recipe: str):

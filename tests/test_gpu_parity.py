@@ -341,3 +341,62 @@ def test_bpdecoder_decode_and_batch_semantics(oracle_built):
         d.decode(np.zeros(7, np.uint8))
     with pytest.raises(NotImplementedError):
         BpDecoder(h, error_rate=0.1, schedule="serial").decode(s)
+
+
+# ---- BP + OSD-0 (BASELINE config 5) ---------------------------------------
+
+from golden_util import osd_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", osd_case_names())
+def test_bposd0_golden_fixture(name):
+    """BpOsdDecoder (OSD_0) outputs captured from the real reference vs ldpc_hip_bposd0_decode_batch."""
+    c = load_case(name)
+    eng = _engine(c)
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"], osd0=True)
+    assert np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert np.array_equal(dec, c["decoding"]), "BP+OSD-0 decisions differ from the reference"
+    chk = (dec.astype(np.int64) @ c["h"].T.toarray().astype(np.int64)) % 2
+    assert np.array_equal(chk, c["syndromes"])  # cpp_test/TestOsdDecoder.cpp:9-35
+    dec2, _, _, _ = eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)  # library-owned LLR buffer
+    assert np.array_equal(dec2, dec)
+
+
+def test_bposd0_config5_batch_and_device_pointers(oracle_built):
+    """Config 5 at its batch size: BB [[144,12,12]], product_sum 50 iterations + OSD-0, B = 8192, device resident."""
+    import torch
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    eng = HipBpEngine(h.indptr, h.indices, 144, np.full(144, 0.05), 50, 0, 1.0)
+    s = eng.gen_bsc_syndromes(7, 0.05, shot0=0, shots=8192, device="cuda:0")
+    dec, llr, it, cv = eng.decode_batch(s, osd0=True)
+    d, sh = dec.cpu().numpy(), s.cpu().numpy()
+    chk = (d.astype(np.int64) @ h.T.toarray().astype(np.int64)) % 2
+    assert np.array_equal(chk, sh), "every BP+OSD-0 output must reproduce its syndrome"
+    want, _, wi, wc = oracle_built.BpOracle(h, error_rate=0.05, max_iter=50).bposd0_decode_batch(sh[:1500])
+    assert np.array_equal(d[:1500], want) and np.array_equal(cv.cpu().numpy()[:1500].astype(bool), wc)
+    assert 0.02 < 1.0 - cv.float().mean().item() < 0.2  # a few percent of the rows needed OSD
+
+
+def test_bposd_decoder_api():
+    """BpOsdDecoder mirror: reference keywords/properties (pyx:54-58, 139-234) and decode semantics (pyx:78-136)."""
+    from ldpc_amd.bposd_decoder import BpOsdDecoder
+    c = load_case("osd_hamming6_ps10")
+    d = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_0")
+    assert d.osd_method == "OSD_0" and d.osd_order == 0 and d.input_vector_type == "syndrome"
+    k = int(np.flatnonzero(~c["converge"])[0])
+    out = d.decode(c["syndromes"][k].astype(np.int32))
+    assert out.dtype == np.int32 and np.array_equal(out, c["decoding"][k]) and d.converge is False
+    assert np.array_equal(d.osd0_decoding, c["decoding"][k]) and np.array_equal(d.osdw_decoding, c["decoding"][k])
+    batch = d.decode_batch(c["syndromes"])
+    nz = c["syndromes"].any(axis=1)
+    assert np.array_equal(batch[nz], c["decoding"][nz])
+    with pytest.raises(ValueError):
+        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="nope")
+    with pytest.raises(ValueError):
+        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_0", osd_order=3)
+    with pytest.raises(NotImplementedError):
+        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_cs", osd_order=4).decode(c["syndromes"][k])
+    with pytest.raises(ValueError):
+        d.decode(np.zeros(3, np.uint8))
