@@ -75,7 +75,10 @@ int ldpc_hip_bp_set_channel(ldpc_hip_bp *h, const double *channel_probs, int32_t
 int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method,
                            double ms_scaling_factor);
 
-/* Launch stream (a hipStream_t) for decode calls; NULL selects the handle's own stream. */
+/* Launch stream (a hipStream_t) for decode calls; NULL selects the handle's own (non-blocking) stream,
+ * LDPC_HIP_STREAM_LEGACY_DEFAULT the device's legacy default stream (hipStream_t 0, which is what
+ * e.g. torch.cuda.current_stream().cuda_stream reports when no stream context is active). */
+#define LDPC_HIP_STREAM_LEGACY_DEFAULT ((void *)1)
 int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *hip_stream);
 
 /*

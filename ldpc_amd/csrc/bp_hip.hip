@@ -913,7 +913,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
 void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
                          &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv})
         b->release();
@@ -952,7 +952,8 @@ int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method, 
 
 int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *s) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    h->stream = s ? (hipStream_t)s : h->own_stream;
+    if (s == LDPC_HIP_STREAM_LEGACY_DEFAULT) h->stream = nullptr;  // hipStream_t 0: the device's legacy default stream
+    else h->stream = s ? (hipStream_t)s : h->own_stream;
     return LDPC_HIP_OK;
 }
 

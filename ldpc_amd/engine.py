@@ -64,7 +64,14 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_set_params(self._h, int(max_iter), int(bp_method), float(ms_scaling_factor)))
 
     def set_stream(self, stream_ptr):
-        _lib.check(self._lib.ldpc_hip_bp_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+        """``None`` -> the handle's own stream; ``0`` -> the legacy default stream (torch's stream 0); else a hipStream_t."""
+        if stream_ptr is None:
+            ptr = 0
+        elif stream_ptr == 0:
+            ptr = 1  # LDPC_HIP_STREAM_LEGACY_DEFAULT
+        else:
+            ptr = stream_ptr
+        _lib.check(self._lib.ldpc_hip_bp_set_stream(self._h, C.c_void_p(ptr)))
 
     def set_tuning(self, waves_per_workgroup=0, max_chunk_tiles=0):
         _lib.check(self._lib.ldpc_hip_bp_set_tuning(self._h, int(waves_per_workgroup), int(max_chunk_tiles)))
