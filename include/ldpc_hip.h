@@ -167,6 +167,12 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t 
  * matrices, 2 or 3 select the ring depth (1 = default); results are identical in every case. */
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 
+/* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)
+ * are decoded by an on-chip kernel: messages live in LDS, a workgroup keeps several syndromes resident and
+ * replaces each one the moment it converges.  mode -1 = automatic (default), 0 = always use the streaming
+ * kernel, 1 = use the on-chip kernel whenever one syndrome fits in LDS.  Results are identical. */
+int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
+
 #define LDPC_HIP_MATH_LIBM_EXACT 0
 #define LDPC_HIP_MATH_FAST 1
 int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);

@@ -596,6 +596,212 @@ __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__rest
     }
 }
 
+// ---- on-chip variant for small codes (BASELINE configs 3 and 5) ------------------------------------
+// When both message arrays of a syndrome fit in a few KiB (rotated surface d=21: 13 KiB, BB [[144,12,12]]:
+// 7 KiB) nothing but the syndrome and the results needs to touch HBM.  A workgroup keeps SLOTS syndromes
+// resident in LDS and iterates them together; work items are (slot, node) pairs so lanes stay busy when
+// m or n is not a multiple of 64.  A slot whose syndrome converged (or hit max_iter) writes its outputs and
+// immediately pulls the next syndrome from a device-wide counter, so the work done is proportional to the
+// iterations each syndrome really needs (the streaming kernel's 64-lane tiles run until their slowest
+// lane finishes).  Per node the edges are walked sequentially in the reference's order with the
+// reference's two sweeps (bp.hpp:205-218, 278-281 + 313-316), so results are bit-identical to the
+// streaming kernel's and to the reference's.
+struct SmallArgs {
+    int32_t m, n, nnz, max_iter, slots;
+    double ms_scaling_factor;
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge;
+    const double *llr0;
+    const uint8_t *synd;        // [batch][m]
+    uint8_t *decoding;          // [batch][n]
+    double *llr;                // [batch][n] or nullptr
+    int32_t *iters;             // [batch] or nullptr
+    uint8_t *conv;              // [batch] or nullptr
+    unsigned long long *next;   // device-wide work counter (zeroed before launch)
+};
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_small_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_lds[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int m = a.m, n = a.n, nnz = a.nnz, S = a.slots;
+    // LDS carve-up: [log table 2 KiB][llr0 n][row_ptr m+1][col_idx nnz][col_ptr n+1][csc_edge nnz] then per slot
+    // [A nnz f64][C nnz f64][L n f64][hard n u8][sy m u8]
+    double *log_tab = reinterpret_cast<double *>(sm_lds);
+    double *prior = log_tab + 256;
+    int32_t *rp = reinterpret_cast<int32_t *>(prior + n);
+    int32_t *ci = rp + (m + 1);
+    int32_t *cp = ci + nnz;
+    int32_t *ce = cp + (n + 1);
+    size_t off = (size_t)(reinterpret_cast<unsigned char *>(ce + nnz) - sm_lds);
+    off = (off + 15) & ~(size_t)15;
+    const size_t slot_bytes = ((size_t)nnz * 16 + (size_t)n * 8 + (size_t)n + (size_t)m + 15) & ~(size_t)15;
+    __shared__ long long slot_synd[16];  // syndrome index held by the slot, -1 = idle
+    __shared__ int slot_iter[16];
+    __shared__ int slot_unsat[16];
+    __shared__ int slot_state[16];       // 0 running, 1 finished this iteration (write out + refill), 2 fresh (needs init)
+    __shared__ int n_active;
+
+    for (int q = tid; q < 256; q += T) log_tab[q] = ldpc_math::k_log_tab[q];
+    for (int q = tid; q < n; q += T) prior[q] = a.llr0[q];
+    for (int q = tid; q <= m; q += T) rp[q] = a.row_ptr[q];
+    for (int q = tid; q < nnz; q += T) { ci[q] = a.col_idx[q]; ce[q] = a.csc_edge[q]; }
+    for (int q = tid; q <= n; q += T) cp[q] = a.col_ptr[q];
+    if (tid < S) {
+        const unsigned long long idx = atomicAdd(a.next, 1ull);
+        slot_synd[tid] = idx < (unsigned long long)a.batch ? (long long)idx : -1;
+        slot_state[tid] = 2;
+        slot_iter[tid] = 0;
+        slot_unsat[tid] = 0;
+    }
+    __syncthreads();
+
+    const float inv_m = m > 0 ? 1.0f / (float)m : 0.f, inv_n = n > 0 ? 1.0f / (float)n : 0.f, inv_e = nnz > 0 ? 1.0f / (float)nnz : 0.f;
+    auto slot_base = [&](int s) { return sm_lds + off + (size_t)s * slot_bytes; };
+    auto split = [](int w, int len, float inv, int &s, int &r) {  // w = s * len + r, exact for w < 2^22
+        s = (int)(((float)w + 0.5f) * inv);
+        r = w - s * len;
+        if (r < 0) { --s; r += len; }
+        if (r >= len) { ++s; r -= len; }
+    };
+
+    for (;;) {
+        // ---- (re)initialise fresh slots: initialise_log_domain_bp (bp.hpp:147-157) + syndrome bytes ----
+        for (int w = tid; w < S * nnz; w += T) {
+            int s, e;
+            split(w, nnz, inv_e, s, e);
+            if (slot_state[s] == 2 && slot_synd[s] >= 0)
+                reinterpret_cast<double *>(slot_base(s))[e] = edge_form<METHOD, MATH>(prior[ci[e]]);
+        }
+        for (int w = tid; w < S * m; w += T) {
+            int s, i;
+            split(w, m, inv_m, s, i);
+            if (slot_state[s] == 2 && slot_synd[s] >= 0)
+                (slot_base(s) + (size_t)nnz * 16 + (size_t)n * 9)[i] = a.synd[slot_synd[s] * m + i];
+        }
+        __syncthreads();
+        if (tid < S && slot_state[tid] == 2) slot_state[tid] = 0;
+        if (tid == 0) {
+            int act = 0;
+            for (int s = 0; s < S; ++s) act += slot_synd[s] >= 0;
+            n_active = act;
+        }
+        __syncthreads();
+        if (n_active == 0) break;
+
+        // ---- check pass (bp.hpp:201-273): item = (slot, check) ----
+        for (int w = tid; w < S * m; w += T) {
+            int s, i;
+            split(w, m, inv_m, s, i);
+            if (slot_synd[s] < 0) continue;
+            double *A = reinterpret_cast<double *>(slot_base(s));
+            double *Cm = A + nnz;
+            const uint8_t sb = (slot_base(s) + (size_t)nnz * 16 + (size_t)n * 9)[i];
+            const int lo = rp[i], hi = rp[i + 1];
+            if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+                const bool neg = sb != 0;
+                double temp = 1.0;
+                for (int e = lo; e < hi; ++e) { Cm[e] = temp; temp *= A[e]; }
+                temp = 1.0;
+                for (int e = hi - 1; e >= lo; --e) {
+                    Cm[e] = ps_message<MATH>(Cm[e] * temp, neg, log_tab);
+                    temp *= A[e];
+                }
+            } else {
+                const int it = slot_iter[s] + 1;
+                const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+                int parity = sb & 1;
+                double temp = DBL_MAX;
+                for (int e = lo; e < hi; ++e) {
+                    const double bk = A[e];
+                    if (bk <= 0) parity ^= 1;
+                    Cm[e] = temp;
+                    const double ab = fabs(bk);
+                    if (ab < temp) temp = ab;
+                }
+                temp = DBL_MAX;
+                for (int e = hi - 1; e >= lo; --e) {
+                    const double bk = A[e];
+                    const int sgn = parity ^ (bk <= 0 ? 1 : 0);
+                    double mag = Cm[e];
+                    if (temp < mag) mag = temp;
+                    Cm[e] = mag * (sgn ? -alpha : alpha);
+                    const double ab = fabs(bk);
+                    if (ab < temp) temp = ab;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- bit pass (bp.hpp:276-298, 311-318): item = (slot, bit) ----
+        for (int w = tid; w < S * n; w += T) {
+            int s, j;
+            split(w, n, inv_n, s, j);
+            if (slot_synd[s] < 0) continue;
+            double *A = reinterpret_cast<double *>(slot_base(s));
+            double *Cm = A + nnz;
+            double *L = Cm + nnz;
+            uint8_t *hard = reinterpret_cast<uint8_t *>(L + n);
+            const int lo = cp[j], hi = cp[j + 1];
+            double temp = prior[j];
+            for (int p = lo; p < hi; ++p) { const int e = ce[p]; A[e] = temp; temp += Cm[e]; }
+            L[j] = temp;
+            hard[j] = temp <= 0 ? 1 : 0;
+            double sfx = 0.0;
+            for (int p = hi - 1; p >= lo; --p) {
+                const int e = ce[p];
+                A[e] = edge_form<METHOD, MATH>(A[e] + sfx);
+                sfx += Cm[e];
+            }
+        }
+        __syncthreads();
+
+        // ---- syndrome test (bp.hpp:292-294, 300-302): candidate parity of every check vs its syndrome BYTE ----
+        for (int w = tid; w < S * m; w += T) {
+            int s, i;
+            split(w, m, inv_m, s, i);
+            if (slot_synd[s] < 0) continue;
+            const uint8_t *hard = slot_base(s) + (size_t)nnz * 16 + (size_t)n * 8;
+            const uint8_t sb = (slot_base(s) + (size_t)nnz * 16 + (size_t)n * 9)[i];
+            uint8_t par = 0;
+            for (int e = rp[i]; e < rp[i + 1]; ++e) par ^= hard[ci[e]];
+            if (par != sb) atomicOr(&slot_unsat[s], 1);
+        }
+        __syncthreads();
+        if (tid < S && slot_synd[tid] >= 0) {
+            const int it = ++slot_iter[tid];
+            if (!slot_unsat[tid] || it >= a.max_iter) slot_state[tid] = 1;
+        }
+        __syncthreads();
+
+        // ---- finished slots: outputs (bp.hpp:62,65,69,71), then pull the next syndrome ----
+        for (int w = tid; w < S * n; w += T) {
+            int s, j;
+            split(w, n, inv_n, s, j);
+            if (slot_state[s] != 1) continue;
+            const double *L = reinterpret_cast<const double *>(slot_base(s)) + 2 * (size_t)nnz;
+            const uint8_t *hard = reinterpret_cast<const uint8_t *>(L + n);
+            const long long b = slot_synd[s];
+            a.decoding[b * n + j] = hard[j];
+            if (a.llr) a.llr[b * n + j] = L[j];
+        }
+        __syncthreads();
+        if (tid < S) {
+            if (slot_state[tid] == 1) {
+                const long long b = slot_synd[tid];
+                if (a.iters) a.iters[b] = slot_iter[tid];
+                if (a.conv) a.conv[b] = slot_unsat[tid] ? 0 : 1;
+                const unsigned long long idx = atomicAdd(a.next, 1ull);
+                slot_synd[tid] = idx < (unsigned long long)a.batch ? (long long)idx : -1;
+                slot_state[tid] = 2;
+                slot_iter[tid] = 0;
+            }
+            slot_unsat[tid] = 0;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- OSD-0 (osd.hpp:110-117 = sort.hpp:48-62 + gf2sparse_linalg.hpp:298-401, 237-288) -------------
 // One wavefront per syndrome that BP left unconverged.  The reference sorts the columns by ascending
 // log-ratio (glibc qsort: stable, so ties keep ascending index), runs a greedy column-ordered Gaussian
@@ -784,6 +990,8 @@ struct ldpc_hip_bp {
     int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
     bool regular = false;   // every row has the same weight and every column has the same weight
     int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
+    int32_t small_mode = -1; // on-chip kernel for small codes: -1 auto, 0 never, 1 whenever it fits
+    DeviceBuf counter;
     std::vector<double> channel_probs;
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
@@ -915,7 +1123,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv})
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
     if (h->d_col_idx) (void)hipFree(h->d_col_idx);
@@ -973,6 +1181,13 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
     return LDPC_HIP_OK;
 }
 
+int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (mode < -1 || mode > 1) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (whenever it fits)");
+    h->small_mode = mode;
+    return LDPC_HIP_OK;
+}
+
 int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (math_mode != LDPC_HIP_MATH_LIBM_EXACT && math_mode != LDPC_HIP_MATH_FAST)
@@ -1025,11 +1240,64 @@ static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
     return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0};  // heavier nodes take the streaming path inside
 }
 
+
+// LDS bytes of the on-chip kernel for `slots` resident syndromes; 0 if the code is too large for it
+static size_t small_lds_bytes(const ldpc_hip_bp *h, int slots) {
+    size_t fixed = 256 * 8 + (size_t)h->n * 8 + ((size_t)h->m + 1 + h->nnz + h->n + 1 + h->nnz) * 4;
+    fixed = (fixed + 15) & ~(size_t)15;
+    const size_t per_slot = ((size_t)h->nnz * 16 + (size_t)h->n * 9 + (size_t)h->m + 15) & ~(size_t)15;
+    return fixed + per_slot * (size_t)slots;
+}
+
+// On-chip variant (bp_small_kernel): chosen automatically when four resident syndromes per workgroup still
+// leave room for four workgroups per CU.  Device pointers, on h->stream.
+static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                        int32_t *iters, uint8_t *conv, int slots) {
+    int rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    SmallArgs a;
+    a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.slots = slots;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    void (*kern)(const SmallArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_small_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_small_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
+    else kern = bp_small_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    const size_t dyn = small_lds_bytes(h, slots);
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    // persistent workgroups: enough to fill the chip, never more than there are syndromes to hand out
+    int64_t groups = (batch + slots - 1) / slots;
+    const int64_t resident = 256 * (int64_t)((150u * 1024u) / dyn > 8 ? 8 : (150u * 1024u) / dyn);
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 // Everything below runs on h->stream with device pointers only.
 static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                          double *llr, int32_t *iters, uint8_t *conv) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
+    if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
+        // small code: keep the messages on chip.  auto: the most resident syndromes (<= 4) per workgroup that
+        // still leave four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
+        int slots = 0;
+        const size_t budget = h->small_mode == 1 ? 150u * 1024u : 39u * 1024u + 512u;
+        for (int sl = 4; sl >= 1 && !slots; --sl)
+            if (small_lds_bytes(h, sl) <= budget) slots = sl;
+        if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);
+    }
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
 

@@ -400,3 +400,22 @@ def test_bposd_decoder_api():
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_cs", osd_order=4).decode(c["syndromes"][k])
     with pytest.raises(ValueError):
         d.decode(np.zeros(3, np.uint8))
+
+
+@pytest.mark.parametrize("name", ["c5_bb144_ps50_p050", "c5_bb144_ms50_p050", "c3_surface21_ms30_p050", "surface5_ps30",
+                                  "edge_extreme_priors_ps", "edge_syndrome_bytes_gt1_ms", "edge_degree1_empty_ps",
+                                  "c1_hamming5_ps20", "ldpc36_n600_ps50_p070"])
+@pytest.mark.parametrize("small", [0, 1])
+def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
+    """Small codes are decoded by the LDS-resident kernel (auto); forcing either kernel gives the reference's bits."""
+    c = load_case(name)
+    eng = _engine(c)
+    eng.set_small_code_kernel(small)
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert bits_equal(llr[: len(c["llr"])], c["llr"])
+    big = np.tile(c["syndromes"], (40, 1))[:3001]  # many more syndromes than resident slots: exercises the work queue
+    d2, l2, i2, c2 = eng.decode_batch(big)
+    k = len(c["syndromes"])
+    for r in range(0, 3001 - k, k):
+        assert np.array_equal(d2[r:r + k], c["decoding"]) and np.array_equal(i2[r:r + k], c["iterations"])
