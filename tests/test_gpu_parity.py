@@ -414,8 +414,9 @@ def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
     dec, llr, it, cv = eng.decode_batch(c["syndromes"])
     assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
     assert bits_equal(llr[: len(c["llr"])], c["llr"])
-    big = np.tile(c["syndromes"], (40, 1))[:3001]  # many more syndromes than resident slots: exercises the work queue
-    d2, l2, i2, c2 = eng.decode_batch(big)
     k = len(c["syndromes"])
+    reps = 3001 // k + 2
+    big = np.tile(c["syndromes"], (reps, 1))[:3001]  # many more syndromes than resident slots: exercises the work queue
+    d2, l2, i2, c2 = eng.decode_batch(big)
     for r in range(0, 3001 - k, k):
         assert np.array_equal(d2[r:r + k], c["decoding"]) and np.array_equal(i2[r:r + k], c["iterations"])
