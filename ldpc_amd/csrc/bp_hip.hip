@@ -77,6 +77,15 @@ __device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin
     return z ^ (z >> 31);
 }
 
+// Read-only tables (CSR/CSC indices, priors, packed syndrome masks: all written by EARLIER launches) are
+// read through the constant address space: with a wave-uniform address that is an s_load on the scalar
+// cache, tracked by lgkmcnt.  As plain global loads they would be vector-memory operations whose
+// `s_waitcnt vmcnt(0)` also drains the asynchronous message prefetches queued behind them.
+template <class T>
+__device__ __forceinline__ T sload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // wave-uniform value -> SGPR pair
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -318,7 +327,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
 
     // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
-    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(llr0[col_idx[e]]));
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
     __syncthreads();
 
     for (int it = 1; it <= a.max_iter; ++it) {
@@ -347,8 +356,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 for (int k = 0; k < DR; ++k) cur[k] = ringp[slot * (SLOT_BYTES / 8) + k * LDPC_WAVE + lane];
                 wait_lds_reads();  // the slot is free once its values sit in registers
                 if (idx + RING < nsteps) issue_row(i + RING * nwaves, slot);
-                const bool neg = (nzm[i] >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
-                const int parity = (int)((par[i] >> lane) & 1ull);
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
                 check_row<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab);
                 slot = slot + 1 == RING ? 0 : slot + 1;
             }
@@ -358,8 +367,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
             double cur[DR];
             int rs = 0, d = 0;
             if (wave < m) {
-                rs = row_ptr[wave];
-                d = row_ptr[wave + 1] - rs;
+                rs = sload(row_ptr + wave);
+                d = sload(row_ptr + wave + 1) - rs;
                 if (d <= DR) {
 #pragma unroll
                     for (int k = 0; k < DR; ++k)
@@ -371,16 +380,16 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 double nxt[DR];
                 int rs_n = 0, d_n = 0;
                 if (inext < m) {
-                    rs_n = row_ptr[inext];
-                    d_n = row_ptr[inext + 1] - rs_n;
+                    rs_n = sload(row_ptr + inext);
+                    d_n = sload(row_ptr + inext + 1) - rs_n;
                     if (d_n <= DR) {
 #pragma unroll
                         for (int k = 0; k < DR; ++k)
                             if (k < d_n) nxt[k] = At.ld(l8, rs_n + k);
                     }
                 }
-                const bool neg = (nzm[i] >> lane) & 1ull;
-                const int parity = (int)((par[i] >> lane) & 1ull);
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
                 if (d <= DR) check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
                 else check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
                 rs = rs_n;
@@ -404,8 +413,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
                     const int q0 = base + 2 * c, q1 = base + 2 * c + 1;
-                    const unsigned ea = (unsigned)csc_edge[q0 < nnz ? q0 : 0];
-                    const unsigned eb = (unsigned)csc_edge[q1 < nnz ? q1 : 0];
+                    const unsigned ea = (unsigned)sload(csc_edge + (q0 < nnz ? q0 : 0));
+                    const unsigned eb = (unsigned)sload(csc_edge + (q1 < nnz ? q1 : 0));
                     const unsigned voff = ((lane < 32 ? ea : eb) << 9) + (unsigned)(lane & 31) * 16u;
                     lds_dma16(Ct.rsrc, voff, 0u, ring_addr + slot * SLOT_BYTES + c * 1024);
                 }
@@ -431,8 +440,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     if (j < n) {
                         int e[DC];
 #pragma unroll
-                        for (int k = 0; k < DC; ++k) e[k] = csc_edge[j * DC + k];
-                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, llr0[j], At, l8);
+                        for (int k = 0; k < DC; ++k) e[k] = sload(csc_edge + j * DC + k);
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, sload(llr0 + j), At, l8);
                         const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
                         if (lane == 0) dcur[j] = hard;
                         if (last && want_llr && lane_live) Lt.st(l8, j, llr);
@@ -451,13 +460,13 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     cs[u] = 0;
                     dg[u] = -1;  // -1: no such column
                     if (j < n) {
-                        cs[u] = col_ptr[j];
-                        dg[u] = col_ptr[j + 1] - cs[u];
+                        cs[u] = sload(col_ptr + j);
+                        dg[u] = sload(col_ptr + j + 1) - cs[u];
                         if (dg[u] <= DC) {
 #pragma unroll
                             for (int k = 0; k < DC; ++k)
                                 if (k < dg[u]) {
-                                    e[u][k] = csc_edge[cs[u] + k];
+                                    e[u][k] = sload(csc_edge + cs[u] + k);
                                     c[u][k] = Ct.ld(l8, e[u][k]);
                                 }
                         }
@@ -467,21 +476,21 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 for (int u = 0; u < UB; ++u) {
                     const int j = j0 + u;
                     if (dg[u] < 0) continue;
-                    const double prior = llr0[j];
+                    const double prior = sload(llr0 + j);
                     double llr;
                     if (dg[u] <= DC) {
                         llr = bit_column<METHOD, MATH, DC>(c[u], e[u], dg[u], prior, At, l8);
                     } else {  // heavy column: two streaming sweeps like the reference's
                         double temp = prior;
                         for (int k = 0; k < dg[u]; ++k) {
-                            const int ee = csc_edge[cs[u] + k];
+                            const int ee = sload(csc_edge + cs[u] + k);
                             At.st(l8, ee, temp);
                             temp += Ct.ld(l8, ee);
                         }
                         llr = temp;
                         double s = 0.0;
                         for (int k = dg[u] - 1; k >= 0; --k) {
-                            const int ee = csc_edge[cs[u] + k];
+                            const int ee = sload(csc_edge + cs[u] + k);
                             At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + s));
                             s += Ct.ld(l8, ee);
                         }
