@@ -1373,11 +1373,12 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
         // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,
         // 16 wavefronts per CU -> 4-wave workgroups once there are >= 4 tiles per CU.  Ring variant:
-        // ~70 VGPRs and 6 KiB of LDS per wavefront -> 24 wavefronts per CU as three 8-wave workgroups
-        // (measured best on MI355X: profiles/; 6-wave workgroups place unevenly on the 4 SIMDs).
+        // ~70 VGPRs and 6 KiB of LDS per wavefront -> 24 wavefronts per CU as two 12-wave workgroups
+        // (3 wavefronts on each SIMD; measured best on MI355X, profiles/; 6-wave workgroups place
+        // unevenly on the 4 SIMDs and 8-wave ones leave a ragged last round at 1024 tiles).
         int waves = h->waves_per_wg;
         if (waves <= 0) {
-            if (kern.ring_depth) waves = tiles >= 768 ? 8 : 16;
+            if (kern.ring_depth) waves = tiles >= 512 ? 12 : 16;
             else waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
         }
         if (waves > 16) waves = 16;
