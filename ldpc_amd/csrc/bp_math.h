@@ -160,22 +160,47 @@ LDPC_HD uint64_t as_u64(double x) { uint64_t u; memcpy(&u, &x, sizeof u); return
 LDPC_HD double as_f64(uint64_t u) { double x; memcpy(&x, &u, sizeof x); return x; }
 LDPC_HD double add_exponent(double y, int k) { return as_f64(as_u64(y) + ((uint64_t)(int64_t)k << 52)); }
 
-// fdlibm expm1 (glibc __expm1) restricted to what tanh hands it: w in [2, 44] or w in (-2, -2^-54].
-// Straight-line: every k-dependent tail of the original is evaluated and the right one selected, so a
-// wavefront whose lanes fall into different ranges does not serialise (each tail is 3-5 operations,
-// a divergent branch costs more).  Per lane the selected value is computed by exactly the original's
-// operations.  (k == 1 cannot occur on this domain and is not provided.)
-LDPC_HD double expm1_libm(double w) {
+// "does any lane of the wavefront need this rare fix-up?"  On the device the answer is wave-uniform, so a
+// rarely-true condition costs one compare + one scalar branch instead of selects on every call; on the
+// host it is just the condition.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LDPC_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+#else
+#define LDPC_ANY(cond) (cond)
+#endif
+
+// std::tanh(b / 2) exactly as glibc evaluates it (sysdeps/ieee754/dbl-64/s_tanh.c on top of fdlibm's
+// __expm1, s_expm1.c), any double b.
+//
+//   |x| >= 1 :  t = expm1( 2|x|),  z = 1 - 2/(t + 2)          |x| < 1 :  t = expm1(-2|x|),  z = -t/(t + 2)
+//
+// expm1 is inlined and restricted to those two argument ranges (w in [2, 44) with k >= 3, or w in (-2, 0)
+// with k in {0,-1,-2,-3}); every k-dependent tail of the original is evaluated by the original's operations
+// and selected, so lanes in different ranges do not serialise:
+//   k == 0      : x - e                          (with c = 0 the general e reduces to x*e0 - hxs)
+//   k == -1     : 0.5*(x - e) - 0.5              == -(0.5*(e - x) + 0.5)   (negation is exact)
+//   k <= -2     : scalb(1 - (e - x), k) - 1
+//   2 <= k < 20 : scalb((1 - 2^-k) - (e - x), k)
+//   k >= 20     : scalb((x - (e + 2^-k)) + 1, k)      (rare: |b| > 13.5; evaluated only if some lane needs it.
+//                 The original's separate k > 56 form only matters for |x| < 22 when it yields t > 2^56,
+//                 for which 1 - 2/(t+2) == 1.0 exactly, and this form gives t > 2^56 as well.)
+// Tiny (|x| < 2^-55), huge (|x| >= 22), infinite and NaN arguments are patched afterwards (rare).
+LDPC_HD double tanh_half_libm(double b) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
     const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
                  Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
                  Q5 = -2.01099218183624371326e-07;
-    const uint32_t hx = (uint32_t)(as_u64(w) >> 32) & 0x7fffffffu;
-    const bool neg = w < 0.0;
-    int k = (int)(invln2 * w + (neg ? -0.5 : 0.5));
-    k = hx < 0x3ff0a2b2u ? (neg ? -1 : 1) : k;  // 0.5 ln2 < |w| < 1.5 ln2
-    k = hx > 0x3fd62e42u ? k : 0;               // |w| <= 0.5 ln2: no reduction
+    const double xh = b * 0.5;  // == b / 2
+    const double ax = __builtin_fabs(xh);
+    const bool big = ax >= 1.0;
+    const double w2 = ax + ax;  // 2|x| exactly
+    const double w = big ? w2 : -w2;
+    // ---- __expm1(w): argument reduction (s_expm1.c) ----
+    const uint32_t hw = (uint32_t)(as_u64(w2) >> 32);  // high word of |w|
+    int k = (int)(invln2 * w + (big ? 0.5 : -0.5));
+    k = hw < 0x3ff0a2b2u ? -1 : k;  // 0.5 ln2 < |w| < 1.5 ln2 (only reachable for w < 0: big has |w| >= 2)
+    k = hw > 0x3fd62e42u ? k : 0;   // |w| <= 0.5 ln2: no reduction
     const double t_k = (double)k;
     const double hi = w - t_k * ln2_hi;  // k = 0: hi = w, lo = 0, c = 0 (identical to the unreduced path)
     const double lo = t_k * ln2_lo;
@@ -187,40 +212,33 @@ LDPC_HD double expm1_libm(double w) {
     const double R2 = Q2 + hxs * Q3, h4 = h2 * h2;
     const double R3 = Q4 + hxs * Q5;
     const double r1 = R1 + h2 * R2 + h4 * R3;
-    const double t = 3.0 - r1 * hfx;
-    const double e0 = hxs * div_cr(r1 - t, 6.0 - x * t);  // denominator in [5.6, 6.4]
-    const double res_k0 = x - (x * e0 - hxs);
+    const double tt = 3.0 - r1 * hfx;
+    const double e0 = hxs * div_cr(r1 - tt, 6.0 - x * tt);  // denominator in [5.6, 6.4]
     double e = (x * (e0 - c) - c);
     e -= hxs;
-    const double res_m1 = 0.5 * (x - e) - 0.5;
     const double emx = e - x;
-    const double res_far = add_exponent(1.0 - emx, k) - 1.0;                           // k <= -2 or k > 56
-    const int ks = k < 0 ? 0 : (k > 31 ? 31 : k);                                      // shift guard only
-    const double one_m = as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ks)) << 32);    // 1 - 2^-k
-    const double res_lt20 = add_exponent(one_m - emx, k);                              // 2 <= k < 20
-    const double two_mk = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);       // 2^-k
-    const double res_ge20 = add_exponent((x - (e + two_mk)) + 1.0, k);                 // 20 <= k <= 56
-    double r = res_far;
-    r = (k >= 2 && k < 20) ? res_lt20 : r;
-    r = (k >= 20 && k <= 56) ? res_ge20 : r;
-    r = k == -1 ? res_m1 : r;
-    r = k == 0 ? res_k0 : r;
-    return r;
-}
-
-// std::tanh(b / 2) exactly as glibc evaluates it (s_tanh.c), any double b; straight-line.
-LDPC_HD double tanh_half_libm(double b) {
-    const double x = b * 0.5;  // == b / 2
-    const double ax = __builtin_fabs(x);
-    const double axc = ax < 22.0 ? ax : 22.0;      // keeps the speculative main path in range (NaN -> 22)
-    const bool big = axc >= 1.0;
-    const double t = expm1_libm(big ? 2.0 * axc : -2.0 * axc);
+    // ---- tails ----
+    const int ks = k < 0 ? 0 : (k > 31 ? 31 : k);                                    // shift guard only
+    const double a1 = k >= 2 ? as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ks)) << 32) : 1.0;  // 1 - 2^-k | 1
+    const double y1 = add_exponent(a1 - emx, k);      // 2 <= k < 20: the result; k <= -2: result + 1
+    double t = k >= 2 ? y1 : y1 - 1.0;
+    t = k == -1 ? -(0.5 * emx + 0.5) : t;
+    t = k == 0 ? -emx : t;
+    if (LDPC_ANY(big && w2 >= 13.0)) {  // superset of k >= 20 (w >= 13.5) phrased on a value that is never poison
+        const double two_mk = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);  // 2^-k
+        const double y2 = add_exponent((x - (e + two_mk)) + 1.0, k);
+        t = k >= 20 ? y2 : t;
+    }
+    // ---- tanh from expm1 ----
     const double quo = div_cr(big ? 2.0 : -t, t + 2.0);  // denominator in [1.1, 2^64]
-    double z = big ? 1.0 - quo : quo;              // 1 - 2/(t+2)   |   -t/(t+2)
-    z = ax < 22.0 ? z : 1.0;                        // |x| >= 22, +-inf
-    z = __builtin_signbit(x) ? -z : z;
-    z = ax < 0x1p-55 ? x * (1.0 + x) : z;           // tiny and +-0 (carries its own sign)
-    z = x != x ? x + x : z;                         // NaN
+    double z = big ? 1.0 - quo : quo;
+    z = __builtin_copysign(z, xh);
+    const uint32_t hx = (uint32_t)(as_u64(ax) >> 32);
+    if (LDPC_ANY(hx - 0x3c800000u >= 0x40360000u - 0x3c800000u)) {  // |x| < 2^-55, |x| >= 22, inf or NaN
+        z = ax < 0x1p-55 ? xh * (1.0 + xh) : z;                      // tiny and +-0 (carries its own sign)
+        z = ax >= 22.0 ? __builtin_copysign(1.0, xh) : z;            // also +-inf
+        z = xh != xh ? xh + xh : z;                                   // NaN
+    }
     return z;
 }
 
@@ -274,6 +292,8 @@ LDPC_HD double log_libm(double q, const double *tab) {
         const double r2 = r * r;
         const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
         y = fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
+    }
+    if (LDPC_ANY(ix - 0x0010000000000000ull >= 0x7ff0000000000000ull - 0x0010000000000000ull)) {  // 0, inf, NaN (never subnormal here)
         y = q == 0.0 ? -INFINITY : y;
         y = q < INFINITY ? y : q;  // +inf -> +inf, NaN -> NaN
     }
@@ -285,8 +305,8 @@ LDPC_HD double log_libm(double q, const double *tab) {
 // 2 / 0 = +inf exactly as IEEE division does.
 LDPC_HD double ps_log_ratio_libm(double x, const double *tab) {
     const double den = 1.0 - x;
-    double q = div_cr(1.0 + x, den == 0.0 ? 1.0 : den);
-    q = den == 0.0 ? INFINITY : q;
+    double q = div_cr(1.0 + x, den);
+    if (LDPC_ANY(den == 0.0)) q = den == 0.0 ? INFINITY : q;  // x == 1: 2 / 0 (div_cr alone would give NaN)
     return log_libm(q, tab);
 }
 
