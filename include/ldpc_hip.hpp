@@ -1,0 +1,114 @@
+// ldpc_hip.hpp -- header-only C++ host class over the C ABI (include/ldpc_hip.h).
+//
+// `ldpc_hip::BpDecoder` carries the member surface the reference's Cython layer touches on
+// `ldpc::bp::BpDecoder` (src_cpp/bp.hpp:51-76, declared to Cython in _bp_decoder.pxd:47-83): public,
+// mutable `channel_probabilities`, `maximum_iterations`, `bp_method`, `ms_scaling_factor`, and the results
+// `decoding`, `log_prob_ratios`, `iterations`, `converge`; `decode(std::vector<uint8_t>&)` for one syndrome and
+// the additive `decode_batch`.  A binding written against the reference class therefore transliterates
+// (INTEGRATION.md §2).  As in the reference, construction throws on bad input (`except +` in the pxd) and
+// decode does not throw across the binding: it records `last_status` / `last_error` instead.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ldpc_hip.h"
+
+namespace ldpc_hip {
+
+enum BpMethod { PRODUCT_SUM = LDPC_HIP_PRODUCT_SUM, MINIMUM_SUM = LDPC_HIP_MINIMUM_SUM };  // bp.hpp:23-26
+
+class BpDecoder {
+public:
+    // ---- members named as in ldpc::bp::BpDecoder (bp.hpp:54-75) ----
+    std::vector<double> channel_probabilities;
+    int check_count = 0;
+    int bit_count = 0;
+    int maximum_iterations = 0;
+    BpMethod bp_method = PRODUCT_SUM;
+    double ms_scaling_factor = 1.0;
+    std::vector<uint8_t> decoding;
+    std::vector<double> log_prob_ratios;
+    int iterations = 0;
+    bool converge = false;
+    // ---- batch results (additive) ----
+    std::vector<uint8_t> decoding_batch;       // [batch][n]
+    std::vector<double> log_prob_ratios_batch; // [batch][n]
+    std::vector<int32_t> iterations_batch;     // [batch]
+    std::vector<uint8_t> converge_batch;       // [batch]
+    int last_status = LDPC_HIP_OK;
+    std::string last_error;
+
+    // H as CSR with strictly ascending column indices per row (what insert_entry maintains, sparse_matrix_base.hpp:423-482)
+    BpDecoder(int m, int n, const std::vector<int32_t> &csr_row_ptr, const std::vector<int32_t> &csr_col_idx,
+              std::vector<double> channel_probs, int max_iter = 0, BpMethod method = PRODUCT_SUM,
+              double min_sum_scaling_factor = 0.625, int device = -1)
+        : channel_probabilities(std::move(channel_probs)), check_count(m), bit_count(n),
+          maximum_iterations(max_iter > 0 ? max_iter : n), bp_method(method), ms_scaling_factor(min_sum_scaling_factor) {
+        if ((int)channel_probabilities.size() != n)  // bp.hpp:103-106
+            throw std::runtime_error("Channel probabilities vector must have length equal to the number of bits");
+        if ((int)csr_row_ptr.size() != m + 1) throw std::runtime_error("csr_row_ptr must have m + 1 entries");
+        ldpc_hip_bp_desc d;
+        d.m = m; d.n = n; d.nnz = (int32_t)csr_col_idx.size();
+        d.csr_row_ptr = csr_row_ptr.data(); d.csr_col_idx = csr_col_idx.data();
+        d.channel_probs = channel_probabilities.data();
+        d.max_iter = maximum_iterations; d.bp_method = (int32_t)bp_method; d.ms_scaling_factor = ms_scaling_factor;
+        d.device = device;
+        if (ldpc_hip_bp_create(&d, &h_) != LDPC_HIP_OK) throw std::runtime_error(ldpc_hip_last_error());
+        synced_probs_ = channel_probabilities;
+        decoding.assign((size_t)n, 0);
+        log_prob_ratios.assign((size_t)n, 0.0);
+    }
+    BpDecoder(const BpDecoder &) = delete;
+    BpDecoder &operator=(const BpDecoder &) = delete;
+    ~BpDecoder() { ldpc_hip_bp_destroy(h_); }
+
+    // one syndrome: ldpc::bp::BpDecoder::decode (bp.hpp:159-190, parallel schedule, syndrome input)
+    std::vector<uint8_t> &decode(std::vector<uint8_t> &syndrome) {
+        if ((int)syndrome.size() != check_count) { fail_(LDPC_HIP_ERR_INVALID, "syndrome has the wrong length"); return decoding; }
+        if (!sync_()) return decoding;
+        int32_t it = 0;
+        uint8_t cv = 0;
+        last_status = ldpc_hip_bp_decode_batch(h_, syndrome.data(), 1, decoding.data(), log_prob_ratios.data(), &it, &cv);
+        if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return decoding; }
+        iterations = it;
+        converge = cv != 0;
+        return decoding;
+    }
+
+    // `batch` syndromes, row-major [batch][m]; osd0 = true adds OSD-0 for unconverged rows (osd.hpp:110-117)
+    bool decode_batch(const uint8_t *syndromes, int64_t batch, bool want_llr = true, bool osd0 = false) {
+        if (!sync_()) return false;
+        decoding_batch.assign((size_t)batch * bit_count, 0);
+        if (want_llr) log_prob_ratios_batch.assign((size_t)batch * bit_count, 0.0);
+        iterations_batch.assign((size_t)batch, 0);
+        converge_batch.assign((size_t)batch, 0);
+        auto fn = osd0 ? ldpc_hip_bposd0_decode_batch : ldpc_hip_bp_decode_batch;
+        last_status = fn(h_, syndromes, batch, decoding_batch.data(), want_llr ? log_prob_ratios_batch.data() : nullptr,
+                         iterations_batch.data(), converge_batch.data());
+        if (last_status != LDPC_HIP_OK) last_error = ldpc_hip_last_error();
+        return last_status == LDPC_HIP_OK;
+    }
+
+    ldpc_hip_bp *handle() { return h_; }
+
+private:
+    // the reference lets callers write the public members between decodes; push them to the device handle
+    bool sync_() {
+        if (channel_probabilities != synced_probs_) {
+            last_status = ldpc_hip_bp_set_channel(h_, channel_probabilities.data(), (int32_t)channel_probabilities.size());
+            if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+            synced_probs_ = channel_probabilities;
+        }
+        last_status = ldpc_hip_bp_set_params(h_, maximum_iterations, (int32_t)bp_method, ms_scaling_factor);
+        if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+        return true;
+    }
+    void fail_(int code, const char *msg) { last_status = code; last_error = msg; }
+    ldpc_hip_bp *h_ = nullptr;
+    std::vector<double> synced_probs_;
+};
+
+}  // namespace ldpc_hip

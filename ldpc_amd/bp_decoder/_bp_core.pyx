@@ -1,0 +1,142 @@
+# cython: language_level=3, boundscheck=False, wraparound=False
+# distutils: language = c++
+"""Cython binding of the C++ host class ``ldpc_hip::BpDecoder`` (include/ldpc_hip.hpp) -- the same kind of
+binding the reference uses for ``ldpc::bp::BpDecoder`` (src_python/ldpc/bp_decoder/_bp_decoder.pxd:47-83,
+_bp_decoder.pyx:132): a ``cdef cppclass`` declaration with the reference's member names and a ``cdef class``
+that reads/writes those members.  ``CyBpCore`` is deliberately thin (construction, member access, decode,
+decode_batch); the user-facing validation/alias layer is ``ldpc_amd.bp_decoder.BpDecoder``, which can run on
+either this binding or the ctypes engine (``ldpc_amd/engine.py``) -- both drive the same C ABI.
+"""
+from libc.stdint cimport int32_t, int64_t, uint8_t
+from libcpp cimport bool as cbool
+from libcpp.vector cimport vector
+from libcpp.string cimport string
+
+import numpy as np
+
+cdef extern from "ldpc_hip.hpp" namespace "ldpc_hip":
+    cdef enum BpMethod:
+        PRODUCT_SUM
+        MINIMUM_SUM
+
+    cdef cppclass BpDecoderCpp "ldpc_hip::BpDecoder":
+        BpDecoderCpp(int m, int n, vector[int32_t]& csr_row_ptr, vector[int32_t]& csr_col_idx,
+                     vector[double] channel_probs, int max_iter, BpMethod method,
+                     double min_sum_scaling_factor, int device) except +
+        vector[double] channel_probabilities
+        int check_count
+        int bit_count
+        int maximum_iterations
+        BpMethod bp_method
+        double ms_scaling_factor
+        vector[uint8_t] decoding
+        vector[double] log_prob_ratios
+        int iterations
+        cbool converge
+        vector[uint8_t] decoding_batch
+        vector[double] log_prob_ratios_batch
+        vector[int32_t] iterations_batch
+        vector[uint8_t] converge_batch
+        int last_status
+        string last_error
+        vector[uint8_t]& decode(vector[uint8_t]& syndrome)
+        cbool decode_batch(const uint8_t *syndromes, int64_t batch, cbool want_llr, cbool osd0) nogil
+
+
+cdef class CyBpCore:
+    cdef BpDecoderCpp *bpd
+    cdef int m, n
+
+    def __cinit__(self, row_ptr, col_idx, int n, channel_probs, int max_iter, int bp_method, double ms_scaling_factor,
+                  int device=-1):
+        cdef vector[int32_t] rp = np.ascontiguousarray(row_ptr, dtype=np.int32).tolist()
+        cdef vector[int32_t] ci = np.ascontiguousarray(col_idx, dtype=np.int32).tolist()
+        cdef vector[double] probs = np.ascontiguousarray(channel_probs, dtype=np.float64).tolist()
+        self.m = <int>rp.size() - 1
+        self.n = n
+        self.bpd = new BpDecoderCpp(self.m, n, rp, ci, probs, max_iter,
+                                    MINIMUM_SUM if bp_method == 1 else PRODUCT_SUM, ms_scaling_factor, device)
+
+    def __dealloc__(self):
+        if self.bpd != NULL:
+            del self.bpd
+
+    # ---- members, as the reference's property layer accesses them (pyx:167-357) ----
+    @property
+    def channel_probabilities(self):
+        return np.array(self.bpd.channel_probabilities)
+
+    @channel_probabilities.setter
+    def channel_probabilities(self, value):
+        cdef int i
+        if len(value) != self.n:
+            raise ValueError(f"The error channel vector must have length {self.n}, not {len(value)}.")
+        for i in range(self.n):
+            self.bpd.channel_probabilities[i] = value[i]
+
+    @property
+    def maximum_iterations(self):
+        return self.bpd.maximum_iterations
+
+    @maximum_iterations.setter
+    def maximum_iterations(self, int value):
+        self.bpd.maximum_iterations = value
+
+    @property
+    def bp_method(self):
+        return <int>self.bpd.bp_method
+
+    @bp_method.setter
+    def bp_method(self, int value):
+        self.bpd.bp_method = MINIMUM_SUM if value == 1 else PRODUCT_SUM
+
+    @property
+    def ms_scaling_factor(self):
+        return self.bpd.ms_scaling_factor
+
+    @ms_scaling_factor.setter
+    def ms_scaling_factor(self, double value):
+        self.bpd.ms_scaling_factor = value
+
+    @property
+    def converge(self):
+        return self.bpd.converge
+
+    @property
+    def iterations(self):
+        return self.bpd.iterations
+
+    @property
+    def log_prob_ratios(self):
+        return np.array(self.bpd.log_prob_ratios)
+
+    @property
+    def decoding(self):
+        return np.array(self.bpd.decoding, dtype=np.uint8)
+
+    # ---- data path ----
+    def decode(self, syndrome):
+        """One syndrome (``BpDecoderCpp.decode``, reference pyx:682 / bp.hpp:159-190)."""
+        cdef vector[uint8_t] s = np.ascontiguousarray(syndrome, dtype=np.uint8).tolist()
+        self.bpd.decode(s)
+        if self.bpd.last_status != 0:
+            raise RuntimeError(self.bpd.last_error.decode("utf-8", "replace"))
+        return np.array(self.bpd.decoding, dtype=np.uint8)
+
+    def decode_batch(self, const uint8_t[:, ::1] syndromes, bint want_llr=True, bint osd0=False):
+        """``(B, m)`` uint8 -> ``(decoding (B, n), llr (B, n) | None, iterations (B,), converge (B,) bool)``."""
+        cdef int64_t b = syndromes.shape[0]
+        cdef cbool ok
+        cdef cbool c_llr = want_llr, c_osd = osd0
+        if syndromes.shape[1] != self.m:
+            raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding). Not length {syndromes.shape[1]}.")
+        if b == 0:
+            return (np.zeros((0, self.n), np.uint8), np.zeros((0, self.n)) if want_llr else None,
+                    np.zeros(0, np.int32), np.zeros(0, bool))
+        with nogil:
+            ok = self.bpd.decode_batch(&syndromes[0, 0], b, c_llr, c_osd)
+        if not ok:
+            raise RuntimeError(self.bpd.last_error.decode("utf-8", "replace"))
+        dec = np.array(self.bpd.decoding_batch, dtype=np.uint8).reshape(b, self.n)
+        llr = np.array(self.bpd.log_prob_ratios_batch).reshape(b, self.n) if want_llr else None
+        return dec, llr, np.array(self.bpd.iterations_batch, dtype=np.int32), np.array(self.bpd.converge_batch, dtype=np.uint8).astype(bool)

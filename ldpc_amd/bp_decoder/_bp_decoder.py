@@ -82,6 +82,10 @@ class BpDecoderBase:
         self._engine = None
         self._engine_key = None
         self._device = kwargs.get("_device", -1)
+        # "cython": NumPy inputs go through the Cython binding of the C++ host class (ldpc_amd/bp_decoder/_bp_core.pyx,
+        # the reference's own binding style); "ctypes": everything through ldpc_amd/engine.py.  Same C ABI underneath.
+        self._backend = kwargs.get("_backend", None)
+        self._cy = None
 
         self._h = _ingest(pcm)
         self.m, self.n = int(pcm.shape[0]), int(pcm.shape[1])
@@ -333,6 +337,38 @@ class BpDecoderBase:
             self._engine_key = key
         return self._engine
 
+    def _get_cy(self):
+        """The Cython-bound C++ host object (None if the extension is not built or the ctypes backend was requested)."""
+        if self._backend == "ctypes":
+            return None
+        if self._cy is None:
+            try:
+                import torch  # noqa: F401  (load torch's HIP runtime first, see ldpc_amd/_lib.py)
+                from ldpc_amd.bp_decoder import _bp_core
+            except ImportError:
+                if self._backend == "cython":
+                    raise
+                self._backend = "ctypes"
+                return None
+            self._cy = _bp_core.CyBpCore(self._h.indptr, self._h.indices, self.n, self._channel_probs, self._max_iter,
+                                         self._bp_method, self._ms_scaling_factor, self._device)
+            self._cy_channel = self._channel_probs.copy()
+        # push the mutable members, as the reference's setters write bpd.* directly (pyx:180-223, 342-394)
+        if not np.array_equal(self._cy_channel, self._channel_probs):
+            self._cy.channel_probabilities = self._channel_probs
+            self._cy_channel = self._channel_probs.copy()
+        self._cy.maximum_iterations = self._max_iter
+        self._cy.bp_method = self._bp_method
+        self._cy.ms_scaling_factor = self._ms_scaling_factor
+        return self._cy
+
+    def _decode_numpy(self, synd2d, want_llr=True, osd0=False):
+        """(B, m) uint8 NumPy -> (decoding, llr, iterations, converge) through the active backend."""
+        cy = self._get_cy()
+        if cy is not None:
+            return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, osd0)
+        return self._get_engine().decode_batch(synd2d, want_llr=want_llr, osd0=osd0)
+
     def _require_parallel(self):
         if self._schedule != PARALLEL:
             raise NotImplementedError(
@@ -359,7 +395,7 @@ class BpDecoder(BpDecoderBase):
         (pinned by python_test/test_bp_decoder.py:121-136).
         """
         for key in kwargs.keys():  # pyx:625-627
-            if key not in ["channel_probs", "_device"]:
+            if key not in ["channel_probs", "_device", "_backend"]:
                 raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
@@ -394,13 +430,12 @@ class BpDecoder(BpDecoderBase):
             return np.zeros(self.n, dtype=dtype)
         self._require_parallel()
         as_syndrome = self._bp_input_type == SYNDROME or (self._bp_input_type == AUTO and ln == self.m)
-        eng = self._get_engine()
         if as_syndrome:
-            dec, llr, it, cv = eng.decode_batch(vec[None, :])
+            dec, llr, it, cv = self._decode_numpy(vec[None, :])
             out = dec[0]
         else:  # bp.hpp:162-180: decode H r, then XOR the received vector back in
-            synd = eng.mulvec_batch(vec[None, :])
-            dec, llr, it, cv = eng.decode_batch(synd)
+            synd = self._get_engine().mulvec_batch(vec[None, :])
+            dec, llr, it, cv = self._decode_numpy(synd)
             out = dec[0] ^ vec
         self._decoding = out.astype(np.uint8)
         self._log_prob_ratios = llr[0]
@@ -452,7 +487,7 @@ class BpDecoder(BpDecoderBase):
         dtype = input_vectors.dtype
         vec = np.ascontiguousarray(np.asarray(input_vectors).astype(np.uint8))
         synd = vec if as_syndrome else eng.mulvec_batch(vec)
-        dec, llr, it, cv = eng.decode_batch(synd, want_llr=want_log_prob_ratios)
+        dec, llr, it, cv = self._decode_numpy(synd, want_llr=want_log_prob_ratios)
         if not as_syndrome:
             dec ^= vec
         zero = ~vec.any(axis=1)

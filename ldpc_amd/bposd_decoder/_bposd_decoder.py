@@ -24,7 +24,7 @@ class BpOsdDecoder(BpDecoderBase):
                  serial_schedule_order=_UNSET, osd_method=0, osd_order: int = 0, input_vector_type: str = "syndrome",
                  **kwargs):
         for key in kwargs.keys():  # pyx:60-62 (the reference's message says BpDecoder here too)
-            if key not in ["channel_probs", "_device"]:
+            if key not in ["channel_probs", "_device", "_backend"]:
                 raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
@@ -99,8 +99,7 @@ class BpOsdDecoder(BpDecoderBase):
             self._converge = True
             return np.zeros(self.n, dtype=syndrome.dtype)
         self._require_supported()
-        eng = self._get_engine()
-        dec, llr, it, cv = eng.decode_batch(vec[None, :], osd0=True)
+        dec, llr, it, cv = self._decode_numpy(vec[None, :], osd0=True)
         self._log_prob_ratios = llr[0]
         self._iterations = int(it[0])
         self._converge = bool(cv[0])
@@ -116,10 +115,9 @@ class BpOsdDecoder(BpDecoderBase):
         if syndromes.ndim != 2 or syndromes.shape[1] != self.m:
             raise ValueError(f"The syndrome must have length {self.m}. Not {syndromes.shape[-1]}.")
         self._require_supported()
-        eng = self._get_engine()
         dtype = syndromes.dtype
         vec = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
-        dec, llr, it, cv = eng.decode_batch(vec, want_llr=want_log_prob_ratios, osd0=True)
+        dec, llr, it, cv = self._decode_numpy(vec, want_llr=want_log_prob_ratios, osd0=True)
         zero = ~vec.any(axis=1)
         dec[zero] = 0
         cv[zero] = True
