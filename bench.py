@@ -173,6 +173,8 @@ def main() -> None:
             s_host = np.asarray((h.astype(np.int32) @ err.T.astype(np.int32)).T % 2, dtype=np.uint8)
             assert np.array_equal(s_host, synd[:sample].cpu().numpy()), "device shot generator differs from its host twin"
             cpu, (cd, cl, ci, cc) = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, s_host, cores=cores)
+            one, _ = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, s_host[:6], cores=1)  # (i) one thread alone
+            cpu["single_thread"] = {"value": one["value"], "unit": "syndromes/s", "sample": one["sample"]}
             gd = dec[:sample].cpu().numpy()
             ok = bool(np.array_equal(gd, cd) and np.array_equal(iters[:sample], ci) and np.array_equal(conv[:sample], cc))
             if llr is not None:
