@@ -75,6 +75,13 @@ int ldpc_hip_bp_set_channel(ldpc_hip_bp *h, const double *channel_probs, int32_t
 int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method,
                            double ms_scaling_factor);
 
+/* replaces: the schedule / serial_schedule_order setters (_bp_decoder.pyx:415-483).  `schedule` uses
+ * ldpc::bp::BpSchedule's values (bp.hpp:28-32): 1 = PARALLEL (flooding, default), 0 = SERIAL with a fixed
+ * bit order (`serial_schedule_order`, n entries, or NULL for 0..n-1; bp.hpp:120-124, 451-545).
+ * 2 = SERIAL_RELATIVE and the random serial order re-sort per syndrome and per iteration and are not
+ * available on the device (LDPC_HIP_ERR_UNSUPPORTED). */
+int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *serial_schedule_order);
+
 /* Launch stream (a hipStream_t) for decode calls; NULL selects the handle's own (non-blocking) stream,
  * LDPC_HIP_STREAM_LEGACY_DEFAULT the device's legacy default stream (hipStream_t 0, which is what
  * e.g. torch.cuda.current_stream().cuda_stream reports when no stream context is active). */

@@ -335,6 +335,13 @@ class BpDecoderBase:
         if key != self._engine_key:
             self._engine.set_params(*key)
             self._engine_key = key
+        sched = (self._schedule, None if self._schedule == PARALLEL else tuple(int(v) for v in self._serial_schedule_order))
+        if sched != getattr(self, "_engine_sched", (PARALLEL, None)):
+            if self._schedule == PARALLEL:
+                self._engine.set_schedule("parallel")
+            else:
+                self._engine.set_schedule("serial", np.asarray(self._serial_schedule_order, np.int32))
+            self._engine_sched = sched
         return self._engine
 
     def _get_cy(self):
@@ -364,16 +371,20 @@ class BpDecoderBase:
 
     def _decode_numpy(self, synd2d, want_llr=True, osd0=False):
         """(B, m) uint8 NumPy -> (decoding, llr, iterations, converge) through the active backend."""
-        cy = self._get_cy()
+        cy = self._get_cy() if self._schedule == PARALLEL else None  # the schedule setters live on the ctypes engine
         if cy is not None:
             return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, osd0)
         return self._get_engine().decode_batch(synd2d, want_llr=want_llr, osd0=osd0)
 
     def _require_parallel(self):
-        if self._schedule != PARALLEL:
+        """Schedules available on the device: 'parallel' (bp.hpp:192-325) and 'serial' with a FIXED bit order
+        (bp.hpp:451-545).  The per-syndrome orders (random serial, serial_relative) raise: no CPU fallback."""
+        if self._schedule == SERIAL_RELATIVE or (self._schedule == SERIAL and self._random_serial_schedule):
+            what = "schedule='serial_relative'" if self._schedule == SERIAL_RELATIVE else "random_serial_schedule=True"
             raise NotImplementedError(
-                f"schedule='{self.schedule}' is not available on the MI355X path yet: only the flooding "
-                "('parallel') schedule (bp.hpp:192-325) is implemented in HIP; there is no CPU fallback.")
+                f"{what} re-sorts the bit order per syndrome and per iteration (bp.hpp:467-483) and is not available on "
+                "the MI355X path yet: use schedule='parallel' or 'serial' with a fixed serial_schedule_order; "
+                "there is no CPU fallback.")
 
 
 class BpDecoder(BpDecoderBase):

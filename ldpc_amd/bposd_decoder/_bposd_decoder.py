@@ -83,8 +83,7 @@ class BpOsdDecoder(BpDecoderBase):
         self._osd_order = order
 
     def _require_supported(self):
-        if self._schedule != PARALLEL:
-            self._require_parallel()
+        self._require_parallel()
         if not (self._osd_method == OSD_0 or (self._osd_method in (EXHAUSTIVE, COMBINATION_SWEEP) and self._osd_order == 0)):
             raise NotImplementedError(
                 f"osd_method={self.osd_method} with osd_order={self._osd_order} is not available on the MI355X path yet: "

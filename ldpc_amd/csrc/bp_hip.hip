@@ -605,6 +605,180 @@ __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__rest
     }
 }
 
+// ---- serial schedule (bp.hpp:451-545) with a fixed bit order -----------------------------------------
+// The serial schedule is sequential in the bits of ONE syndrome (every bit update reads messages the
+// previous bits just wrote) but the syndromes of a batch stay independent, so the lane = syndrome tile
+// layout carries over: one wavefront walks the bits of its 64-syndrome tile in schedule order.  Per bit and
+// per incident check the message is the plain sequential product (min) over the row's other entries
+// (bp.hpp:493-498 / 507-517), signed by pow(-1, syndrome byte) (bp.hpp:499), in the reference's order.
+// Only one message array is needed: check->bit messages never outlive the bit update that computes them.
+// It holds tanh(b2c / 2) for product-sum (evaluated once per write instead of once per read: same value),
+// b2c for min-sum.  The random and LLR-sorted ("serial_relative") orders differ per syndrome and are not
+// provided on the device.
+struct SerialArgs {
+    int32_t m, n, nnz, max_iter, fast;
+    double ms_scaling_factor;
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
+    const double *llr0;
+    double *A;                    // [tiles][nnz][64]  tanh(b2c/2) | b2c
+    double *C;                    // [tiles][nnz][64]  scratch for nodes heavier than the register bounds
+    const uint64_t *par, *invalid;
+    uint64_t *dec, *dcur;
+    double *llr_t;
+    int32_t *iters;
+    uint8_t *conv;
+};
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
+    constexpr int DCS = 4, DRS = 8;  // register bounds of the fast path (column / row weight)
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    const uint64_t *par = a.par + tile * m;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    __shared__ __attribute__((aligned(16))) double log_tab[256];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = lane; q < 256; q += 64) log_tab[q] = ldpc_math::k_log_tab[q];
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    const uint64_t never = a.invalid[tile];
+    int my_iter = 0;
+
+    for (int e = 0; e < nnz; ++e) At.st(l8, e, edge_form<METHOD, MATH>(sload(a.llr0 + sload(a.col_idx + e))));
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+        const bool lane_live = !((done >> lane) & 1ull);
+        for (int t = 0; t < n; ++t) {
+            const int bit = a.order ? sload(a.order + t) : t;
+            const int cs = sload(a.col_ptr + bit);
+            const int d = sload(a.col_ptr + bit + 1) - cs;
+            double llr = sload(a.llr0 + bit);  // bp.hpp:488
+            // the (other) entries of one incident check row -> its check->bit message for this bit
+            auto row_message = [&](int chk, int e, const double *vals, int rs, int rd) {
+                const bool odd = (sload(par + chk) >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
+                if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+                    double c = 1.0;
+                    if (vals) {
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd && rs + q != e) c *= vals[q];
+                    } else {
+                        for (int g = rs; g < rs + rd; ++g)
+                            if (g != e) c *= At.ld(l8, g);
+                    }
+                    c = ps_message<MATH>(c, odd, log_tab);
+                    return c;
+                } else {
+                    int sgn = odd ? 1 : 0;
+                    double temp = DBL_MAX;
+                    if (vals) {
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd && rs + q != e) {
+                                const double ab = fabs(vals[q]);
+                                if (ab < temp) temp = ab;
+                                if (vals[q] <= 0) sgn ^= 1;
+                            }
+                    } else {
+                        for (int g = rs; g < rs + rd; ++g)
+                            if (g != e) {
+                                const double bg = At.ld(l8, g);
+                                const double ab = fabs(bg);
+                                if (ab < temp) temp = ab;
+                                if (bg <= 0) sgn ^= 1;
+                            }
+                    }
+                    return (alpha * (sgn ? -1.0 : 1.0)) * temp;  // alpha * message_sign * temp (bp.hpp:519)
+                }
+            };
+            if (a.fast) {
+                int e[DCS], chk[DCS], rs[DCS], rd[DCS];
+                double vals[DCS][DRS], c[DCS], pre[DCS];
+#pragma unroll
+                for (int k = 0; k < DCS; ++k)
+                    if (k < d) {
+                        e[k] = sload(a.csc_edge + cs + k);
+                        chk[k] = sload(a.csc_row + cs + k);
+                        rs[k] = sload(a.row_ptr + chk[k]);
+                        rd[k] = sload(a.row_ptr + chk[k] + 1) - rs[k];
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd[k] && rs[k] + q != e[k]) vals[k][q] = At.ld(l8, rs[k] + q);
+                    }
+#pragma unroll
+                for (int k = 0; k < DCS; ++k)
+                    if (k < d) {
+                        c[k] = row_message(chk[k], e[k], vals[k], rs[k], rd[k]);
+                        pre[k] = llr;  // bp.hpp:501 / 520
+                        llr += c[k];
+                        if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+                    }
+                double temp = 0.0;  // bp.hpp:530-534
+#pragma unroll
+                for (int k = DCS - 1; k >= 0; --k)
+                    if (k < d) {
+                        At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + temp));
+                        temp += c[k];
+                    }
+            } else {
+                for (int p = cs; p < cs + d; ++p) {
+                    const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+                    const int rs = sload(a.row_ptr + chk), rd = sload(a.row_ptr + chk + 1) - rs;
+                    const double c = row_message(chk, e, nullptr, rs, rd);
+                    Ct.st(l8, e, c);
+                    At.st(l8, e, llr);  // partial sum; rewritten below before any other bit reads it
+                    llr += c;
+                }
+                double temp = 0.0;
+                for (int p = cs + d - 1; p >= cs; --p) {
+                    const int e = sload(a.csc_edge + p);
+                    At.st(l8, e, edge_form<METHOD, MATH>(At.ld(l8, e) + temp));
+                    temp += Ct.ld(l8, e);
+                }
+            }
+            const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:525-529
+            if (lane == 0) dcur[bit] = hard;
+            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+        }
+        // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t unsat = 0;
+        for (int i = lane; i < m; i += 64) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ par[i];
+        }
+        unsat = wave_or(unsat) | never;
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+        }
+        if (done == ~0ull) break;
+    }
+    if (done != ~0ull)
+        for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    const int64_t b = tile * LDPC_WAVE + lane;
+    if (b < a.batch) {
+        const bool cv = ((done >> lane) & 1ull) != 0;
+        if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+        if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}
+
 // ---- on-chip variant for small codes (BASELINE configs 3 and 5) ------------------------------------
 // When both message arrays of a syndrome fit in a few KiB (rotated surface d=21: 13 KiB, BB [[144,12,12]]:
 // 7 KiB) nothing but the syndrome and the results needs to touch HBM.  A workgroup keeps SLOTS syndromes
@@ -1000,6 +1174,9 @@ struct ldpc_hip_bp {
     bool regular = false;   // every row has the same weight and every column has the same weight
     int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
     int32_t small_mode = -1; // on-chip kernel for small codes: -1 auto, 0 never, 1 whenever it fits
+    int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial (fixed order), 1 parallel
+    int32_t *d_csc_row = nullptr, *d_order = nullptr;
+    bool custom_order = false;
     DeviceBuf counter;
     std::vector<double> channel_probs;
 
@@ -1082,7 +1259,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     h->channel_probs.assign(d->channel_probs, d->channel_probs + d->n);
 
     // CSC view: csc_edge[p] = CSR edge id; filling by ascending row keeps rows ascending per column
-    std::vector<int32_t> col_ptr((size_t)d->n + 1, 0), csc_edge((size_t)(d->nnz ? d->nnz : 1));
+    std::vector<int32_t> col_ptr((size_t)d->n + 1, 0), csc_edge((size_t)(d->nnz ? d->nnz : 1)), csc_row((size_t)(d->nnz ? d->nnz : 1));
     for (int e = 0; e < d->nnz; ++e) col_ptr[(size_t)d->csr_col_idx[e] + 1]++;
     int32_t min_col = d->n ? INT32_MAX : 0;
     for (int j = 0; j < d->n; ++j) {
@@ -1095,7 +1272,11 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
         std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
         for (int i = 0; i < d->m; ++i)
             for (int e = d->csr_row_ptr[i]; e < d->csr_row_ptr[i + 1]; ++e)
-                csc_edge[(size_t)fill[(size_t)d->csr_col_idx[e]]++] = e;
+            {
+                const size_t pos = (size_t)fill[(size_t)d->csr_col_idx[e]]++;
+                csc_edge[pos] = e;
+                csc_row[pos] = i;
+            }
     }
 #define ALLOC_COPY(dst, src, count, T)                                                          \
     do {                                                                                        \
@@ -1111,6 +1292,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     ALLOC_COPY(h->d_col_idx, d->csr_col_idx, d->nnz, int32_t);
     ALLOC_COPY(h->d_col_ptr, col_ptr.data(), d->n + 1, int32_t);
     ALLOC_COPY(h->d_csc_edge, csc_edge.data(), d->nnz, int32_t);
+    ALLOC_COPY(h->d_csc_row, csc_row.data(), d->nnz, int32_t);
     ALLOC_COPY(h->d_llr0, d->channel_probs, d->n, double);  // overwritten by upload_priors
 #undef ALLOC_COPY
     int rc = upload_priors(h);
@@ -1138,6 +1320,8 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->d_col_idx) (void)hipFree(h->d_col_idx);
     if (h->d_col_ptr) (void)hipFree(h->d_col_ptr);
     if (h->d_csc_edge) (void)hipFree(h->d_csc_edge);
+    if (h->d_csc_row) (void)hipFree(h->d_csc_row);
+    if (h->d_order) (void)hipFree(h->d_order);
     if (h->d_llr0) (void)hipFree(h->d_llr0);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1187,6 +1371,27 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (enable < 0 || enable > 3) return fail(LDPC_HIP_ERR_INVALID, "ring depth must be 0 (off), 1 (default depth), 2 or 3");
     h->ring_depth = enable == 1 ? 2 : enable;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *serial_schedule_order) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (schedule == 2)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "serial_relative (per-syndrome LLR-sorted order, bp.hpp:470-483) is not available on the device");
+    if (schedule != 0 && schedule != 1) return fail(LDPC_HIP_ERR_INVALID, "Invalid BP schedule");  // bp.hpp:188
+    HIPCHK(hipSetDevice(h->device));
+    if (schedule == 0 && serial_schedule_order) {
+        for (int j = 0; j < h->n; ++j)
+            if (serial_schedule_order[j] < 0 || serial_schedule_order[j] >= h->n)
+                return fail(LDPC_HIP_ERR_INVALID, "serial_schedule_order[%d] is out of range", j);
+        if (!h->d_order) HIPCHK(hipMalloc((void **)&h->d_order, sizeof(int32_t) * (size_t)(h->n ? h->n : 1)));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->d_order, serial_schedule_order, sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
+        h->custom_order = true;
+    } else {
+        h->custom_order = false;
+    }
+    h->schedule = schedule;
     return LDPC_HIP_OK;
 }
 
@@ -1250,6 +1455,96 @@ static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
 }
 
 
+static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                         double *llr, int32_t *iters, uint8_t *conv);
+
+// Serial schedule: one wavefront per 64-syndrome tile (bp_serial_kernel).  Device pointers, on h->stream.
+static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                         int32_t *iters, uint8_t *conv) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
+    const bool fast = h->max_col_deg <= 4 && h->max_row_deg <= 8;
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = (fast ? 1 : 2) * per_tile_msg + per_tile_llr + 24 * (size_t)(h->m + h->n + 1);
+        int64_t fit = (int64_t)(budget / (per_tile ? per_tile : 1));
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(fast ? 16 : per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    void (*kern)(const SerialArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_serial_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
+    else kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    h->accumulated_ms = 0.f;
+    h->timed = false;
+    hipStream_t st = h->stream;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        SerialArgs a;
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.fast = fast ? 1 : 0;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
+        a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
+        a.par = (const uint64_t *)h->par.p; a.invalid = (const uint64_t *)h->invalid.p;
+        a.dec = (uint64_t *)h->dec.p; a.dcur = (uint64_t *)h->dcur.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st, (const uint64_t *)h->dec.p, nb, h->n,
+                               decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n,
+                                   llr + (size_t)b0 * h->n);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LDPC_HIP_OK;
+}
+
 // LDS bytes of the on-chip kernel for `slots` resident syndromes; 0 if the code is too large for it
 static size_t small_lds_bytes(const ldpc_hip_bp *h, int slots) {
     size_t fixed = 256 * 8 + (size_t)h->n * 8 + ((size_t)h->m + 1 + h->nnz + h->n + 1 + h->nnz) * 4;
@@ -1298,6 +1593,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                          double *llr, int32_t *iters, uint8_t *conv) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
+    if (h->schedule == 0) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
     if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
         // small code: keep the messages on chip.  auto: the most resident syndromes (<= 4) per workgroup that
         // still leave four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB

@@ -63,6 +63,17 @@ class HipBpEngine:
     def set_params(self, max_iter, bp_method, ms_scaling_factor):
         _lib.check(self._lib.ldpc_hip_bp_set_params(self._h, int(max_iter), int(bp_method), float(ms_scaling_factor)))
 
+    def set_schedule(self, schedule, serial_schedule_order=None):
+        """``'parallel'`` (1) or ``'serial'`` (0, fixed order; ``serial_schedule_order`` of n ints or None)."""
+        code = {"parallel": 1, "serial": 0, "serial_relative": 2, 0: 0, 1: 1, 2: 2}[schedule]
+        if serial_schedule_order is None:
+            _lib.check(self._lib.ldpc_hip_bp_set_schedule(self._h, code, None))
+        else:
+            order = np.ascontiguousarray(serial_schedule_order, np.int32)
+            if order.shape != (self.n,):
+                raise ValueError("serial_schedule_order must have length n")
+            _lib.check(self._lib.ldpc_hip_bp_set_schedule(self._h, code, order.ctypes.data))
+
     def set_stream(self, stream_ptr):
         """``None`` -> the handle's own stream; ``0`` -> the legacy default stream (torch's stream 0); else a hipStream_t."""
         if stream_ptr is None:

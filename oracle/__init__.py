@@ -86,6 +86,9 @@ class _OracleLib:
             lib.oracle_gen_bsc_syndromes.argtypes = [
                 C.c_int, C.c_int, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64,
                 _u8p, C.c_void_p]
+            lib.bp_oracle_decode_serial_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, C.c_void_p, _u8p, C.c_int64, _u8p,
+                C.c_void_p, _i32p, _u8p]
             lib.osd0_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _u8p]
             lib.bposd0_oracle_decode_batch.argtypes = lib.bp_oracle_decode_batch.argtypes
             lib.oracle_sm64.restype = C.c_uint64
@@ -127,6 +130,20 @@ class BpOracle:
         self.lib.bp_oracle_decode_batch(
             self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b, dec,
             llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def decode_serial_batch(self, syndromes, order=None, want_llr=True):
+        """Serial schedule with a fixed bit order (bp.hpp:451-545); ``order`` None = 0..n-1."""
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        od = None if order is None else np.ascontiguousarray(order, np.int32)
+        self.lib.bp_oracle_decode_serial_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha,
+                                               od.ctypes.data if od is not None else None, s, b, dec,
+                                               llr.ctypes.data if want_llr else None, it, conv)
         return dec, llr, it, conv.astype(bool)
 
     def osd0(self, syndrome, llr):
@@ -177,6 +194,7 @@ class RefBp:
         lib.ref_bp_decode_batch.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int64, _u8p, C.c_void_p,
                                             _i32p, _u8p]
         lib.ref_bp_mulvec.argtypes = [C.c_void_p, _u8p, _u8p]
+        lib.ref_bp_set_serial_order.argtypes = [C.c_void_p, _i32p]
         self.lib = lib
         self.m, self.n, row_ptr, col_idx = csr_arrays(h)
         rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32)
@@ -195,6 +213,9 @@ class RefBp:
     def set_channel(self, probs):
         self.channel_probs = np.ascontiguousarray(probs, np.float64)
         self.lib.ref_bp_set_channel(self._h, self.channel_probs)
+
+    def set_serial_order(self, order):
+        self.lib.ref_bp_set_serial_order(self._h, np.ascontiguousarray(order, np.int32))
 
     def decode_batch(self, inputs, want_llr=True):
         s = np.ascontiguousarray(inputs, np.uint8)

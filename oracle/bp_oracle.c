@@ -310,3 +310,81 @@ void bposd0_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int m
     }
     free(tmp);
 }
+
+/* ============================================================================================== *
+ * Serial schedule: ldpc::bp::BpDecoder::bp_decode_serial (src_cpp/bp.hpp:451-545) with a FIXED bit
+ * order (`serial_schedule_order`, default 0..n-1, bp.hpp:120-124).  The random (bp.hpp:468) and
+ * LLR-sorted "serial_relative" (bp.hpp:470-483) orders are not restated.
+ * Differences from the flooding schedule that matter for bits: the check->bit message of an edge is
+ * the plain sequential product over the row's OTHER entries (bp.hpp:493-498), its sign is
+ * pow(-1, syndrome byte) (bp.hpp:499), min-sum multiplies alpha * sign * magnitude (bp.hpp:519).
+ * ============================================================================================== */
+void bp_oracle_decode_serial(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                             double ms_scaling_factor, const int32_t *order, const uint8_t *syndrome,
+                             uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge) {
+    const int m = o->m, n = o->n;
+    *converge = 0;
+    for (int j = 0; j < n; j++) { /* initialise_log_domain_bp, bp.hpp:147-157 */
+        o->llr0[j] = log((1 - channel_probs[j]) / channel_probs[j]);
+        for (int p = o->col_ptr[j]; p < o->col_ptr[j + 1]; p++) o->b2c[o->csc_edge[p]] = o->llr0[j];
+    }
+    for (int it = 1; it <= max_iter; it++) {
+        double alpha;
+        if (ms_scaling_factor == 0.0) alpha = 1.0 - pow(2.0, -1.0 * it);
+        else alpha = ms_scaling_factor;
+        for (int t = 0; t < n; t++) {
+            const int bit = order ? order[t] : t;
+            log_prob_ratios[bit] = log((1 - channel_probs[bit]) / channel_probs[bit]);
+            for (int p = o->col_ptr[bit]; p < o->col_ptr[bit + 1]; p++) {
+                const int e = o->csc_edge[p], chk = o->csc_row[p];
+                if (bp_method == BP_PRODUCT_SUM) { /* bp.hpp:491-503 */
+                    o->c2b[e] = 1.0;
+                    for (int g = o->row_ptr[chk]; g < o->row_ptr[chk + 1]; g++)
+                        if (g != e) o->c2b[e] *= o->tanh_half ? o->tanh_half(o->b2c[g]) : tanh(o->b2c[g] / 2);
+                    o->c2b[e] = pow(-1, syndrome[chk]) * (o->log_ratio ? o->log_ratio(o->c2b[e]) : log((1 + o->c2b[e]) / (1 - o->c2b[e])));
+                } else { /* bp.hpp:504-523 */
+                    int sgn = syndrome[chk];
+                    double temp = DBL_MAX;
+                    for (int g = o->row_ptr[chk]; g < o->row_ptr[chk + 1]; g++)
+                        if (g != e) {
+                            const double a = fabs(o->b2c[g]);
+                            if (a < temp) temp = a;
+                            if (o->b2c[g] <= 0) sgn += 1;
+                        }
+                    const double message_sign = (sgn % 2 == 0) ? 1.0 : -1.0;
+                    o->c2b[e] = alpha * message_sign * temp;
+                }
+                o->b2c[e] = log_prob_ratios[bit];
+                log_prob_ratios[bit] += o->c2b[e];
+            }
+            decoding[bit] = log_prob_ratios[bit] <= 0 ? 1 : 0; /* bp.hpp:525-529 */
+            double temp = 0;
+            for (int p = o->col_ptr[bit + 1] - 1; p >= o->col_ptr[bit]; p--) { /* bp.hpp:530-534 */
+                const int e = o->csc_edge[p];
+                o->b2c[e] += temp;
+                temp += o->c2b[e];
+            }
+        }
+        /* candidate syndrome of the current hard decision, bp.hpp:537-543 */
+        int equal = 1;
+        for (int i = 0; i < m && equal; i++) {
+            uint8_t s = 0;
+            for (int g = o->row_ptr[i]; g < o->row_ptr[i + 1]; g++) s ^= decoding[o->col_idx[g]];
+            if (s != syndrome[i]) equal = 0;
+        }
+        *iterations = it;
+        if (equal) { *converge = 1; return; }
+    }
+}
+
+void bp_oracle_decode_serial_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                                   double ms_scaling_factor, const int32_t *order, const uint8_t *syndromes,
+                                   int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    double *tmp = llr ? NULL : (double *)malloc(sizeof(double) * (size_t)(o->n ? o->n : 1));
+    for (int64_t b = 0; b < shots; b++) {
+        iterations[b] = 0;
+        bp_oracle_decode_serial(o, channel_probs, max_iter, bp_method, ms_scaling_factor, order, syndromes + b * o->m,
+                                decodings + b * o->n, llr ? llr + b * o->n : tmp, iterations + b, converge + b);
+    }
+    free(tmp);
+}

@@ -51,6 +51,12 @@ void ref_bp_set_channel(ref_bp *r, const double *channel_probs) {
     for (int j = 0; j < r->dec->bit_count; j++) r->dec->channel_probabilities[j] = channel_probs[j];
 }
 
+/* serial_schedule_order (bp.hpp:67; the Cython setter writes it element-wise, _bp_decoder.pyx:465-483) */
+void ref_bp_set_serial_order(ref_bp *r, const int32_t *order) {
+    r->dec->serial_schedule_order.resize((size_t)r->dec->bit_count);
+    for (int j = 0; j < r->dec->bit_count; j++) r->dec->serial_schedule_order[(size_t)j] = order[j];
+}
+
 /* One BpDecoder::decode call (bp.hpp:159-190); `len` is m (syndrome) or n (received vector). */
 void ref_bp_decode(ref_bp *r, const uint8_t *input, int len, uint8_t *decoding, double *llr,
                    int32_t *iterations, uint8_t *converge) {

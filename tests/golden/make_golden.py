@@ -80,6 +80,32 @@ def run_case(name, h, syndromes, *, error_rate=None, error_channel=None, max_ite
           f"{os.path.getsize(path) / 1024:8.1f} KiB")
 
 
+def run_serial_case(name, h, syndromes, *, error_rate, max_iter, bp_method="product_sum", ms_scaling_factor=1.0,
+                    order=None, full_llr=None, note=""):
+    """bp_decode_serial (bp.hpp:451-545) through the real reference, default or custom serial_schedule_order."""
+    h = sp.csr_matrix(h, dtype=np.uint8)
+    m, n, rp, ci = csr_arrays(h)
+    ref = RefBp(h, error_rate=error_rate, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=ms_scaling_factor,
+                schedule="serial")
+    if order is not None:
+        ref.set_serial_order(order)
+    syndromes = np.ascontiguousarray(syndromes, np.uint8).reshape(-1, m)
+    dec, llr, it, conv = ref.decode_batch(syndromes)
+    k = len(syndromes) if full_llr is None else full_llr
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, name=name, note=note, m=m, n=n, h_crc=np.uint32(h_crc(h)), row_ptr=rp, col_idx=ci, recipe="",
+                        channel_probs=ref.channel_probs, max_iter=np.int32(ref.max_iter),
+                        bp_method=np.int32(0 if bp_method in ("product_sum", "ps") else 1),
+                        ms_scaling_factor=np.float64(ms_scaling_factor),
+                        syndromes=np.packbits(syndromes, axis=1) if syndromes.max(initial=0) <= 1 else syndromes,
+                        syndromes_packed=np.bool_(syndromes.max(initial=0) <= 1),
+                        decoding=np.packbits(dec, axis=1), converge=conv, iterations=it, llr=llr[:k],
+                        llr_rowsum=np.sum(np.where(np.abs(llr) < 1e100, llr, 0.0), axis=1),
+                        order=np.asarray(order if order is not None else [], np.int32))
+    print(f"{name:34s} k={len(syndromes):4d} conv={conv.mean():.3f} iters={it.mean():6.2f} "
+          f"{os.path.getsize(path) / 1024:8.1f} KiB")
+
+
 def run_osd_case(name, h, syndromes, *, error_rate, max_iter, bp_method="product_sum", ms_scaling_factor=1.0, note=""):
     """BpOsdDecoder.decode (OSD_0) per row through the real reference (_bposd_decoder.pyx:125-134, osd.hpp:110-117)."""
     h = sp.csr_matrix(h, dtype=np.uint8)
@@ -181,6 +207,26 @@ def main():
     hr = codes.ring_code(40)
     run_osd_case("osd_ring40_ps3", hr, bsc_syndromes(hr, 7, 0.12, 0, 256), error_rate=0.12, max_iter=3,
                  note="rank-deficient H (m = n, rank n-1), BP cut short so OSD runs often")
+
+    # --- serial schedule, fixed order ---
+    h = codes.bivariate_bicycle_hx()
+    perm = (sm64(13, np.arange(144, dtype=np.uint64)) % np.uint64(1 << 40)).argsort().astype(np.int32)
+    run_serial_case("serial_bb144_ps30", h, bsc_syndromes(h, 7, 0.06, 0, 192), error_rate=0.06, max_iter=30, full_llr=48)
+    run_serial_case("serial_bb144_ms30_custom_order", h, bsc_syndromes(h, 7, 0.06, 0, 192), error_rate=0.06, max_iter=30,
+                    bp_method="minimum_sum", ms_scaling_factor=0.625, order=perm, full_llr=48)
+    run_serial_case("serial_bb144_ms30_adaptive", h, bsc_syndromes(h, 8, 0.06, 0, 128), error_rate=0.06, max_iter=30,
+                    bp_method="minimum_sum", ms_scaling_factor=0.0, full_llr=32)
+    hs = codes.rotated_surface_code_x(7)
+    run_serial_case("serial_surface7_ps20", hs, bsc_syndromes(hs, 7, 0.07, 0, 192), error_rate=0.07, max_iter=20, full_llr=48)
+    hl = codes.regular_ldpc_code(600, 3, 6, seed=3)
+    run_serial_case("serial_ldpc36_n600_ps20", hl, bsc_syndromes(hl, 11, 0.08, 0, 96), error_rate=0.08, max_iter=20, full_llr=16)
+    hm6 = codes.hamming_code(6)  # row weight 32: beyond the register bounds -> streaming path of the kernel
+    sb = bsc_syndromes(hm6, 7, 0.05, 0, 96)
+    sb[::7, 2] = 2
+    sb[3::9, 4] = 3  # syndrome bytes > 1: pow(-1, byte) sign, never converges (bp.hpp:499, 540)
+    run_serial_case("serial_hamming6_ps10_bytes", hm6, sb, error_rate=0.05, max_iter=10, full_llr=24)
+    run_serial_case("serial_hamming6_ms10", hm6, bsc_syndromes(hm6, 7, 0.05, 0, 96), error_rate=0.05, max_iter=10,
+                    bp_method="minimum_sum", ms_scaling_factor=0.75, full_llr=24)
 
     # --- edge cases (SURVEY.md §7 "Inf/NaN semantics", §8a a7/a9) ---
     rng_idx = np.arange(31, dtype=np.uint64)

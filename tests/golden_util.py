@@ -14,7 +14,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def case_names(prefix: str = ""):
     """BP fixtures (``decoding`` = BpDecoder output).  BP+OSD-0 fixtures are listed by ``osd_case_names``."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith("osd_")]
+    return [n for n in names if not n.startswith(("osd_", "serial_"))]
+
+
+def serial_case_names():
+    """Fixtures captured with schedule = SERIAL (bp.hpp:451-545); ``order`` = serial_schedule_order or None."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "serial_*.npz")))
 
 
 def osd_case_names():
@@ -67,6 +72,7 @@ def load_case(name: str) -> dict:
         ms_scaling_factor=float(z["ms_scaling_factor"]), syndromes=np.ascontiguousarray(synd, np.uint8),
         decoding=dec, converge=z["converge"].astype(bool), iterations=z["iterations"].astype(np.int32),
         llr=z["llr"], llr_rowsum=z["llr_rowsum"], note=str(z["note"]),
+        order=(z["order"].astype(np.int32) if "order" in z.files and z["order"].size else None),
     )
 
 

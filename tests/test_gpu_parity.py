@@ -340,7 +340,9 @@ def test_bpdecoder_decode_and_batch_semantics(oracle_built):
     with pytest.raises(ValueError):
         d.decode(np.zeros(7, np.uint8))
     with pytest.raises(NotImplementedError):
-        BpDecoder(h, error_rate=0.1, schedule="serial").decode(s)
+        BpDecoder(h, error_rate=0.1, schedule="serial_relative").decode(s)
+    with pytest.raises(NotImplementedError):
+        BpDecoder(h, error_rate=0.1, schedule="serial", random_serial_schedule=True).decode(s)
 
 
 # ---- BP + OSD-0 (BASELINE config 5) ---------------------------------------
@@ -456,3 +458,48 @@ def test_cpp_host_class_demo_runs():
         pytest.skip("examples/cpp_host_demo not built")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+# ---- serial schedule with a fixed bit order (bp.hpp:451-545) ----------------------
+
+from golden_util import serial_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", serial_case_names())
+def test_serial_schedule_golden_fixture(name):
+    """Outputs of the real reference's bp_decode_serial (default and custom serial_schedule_order)."""
+    c = load_case(name)
+    eng = _engine(c)
+    eng.set_schedule("serial", c.get("order"))
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert bits_equal(llr[: len(c["llr"])], c["llr"])
+    eng.set_schedule("parallel")  # and back: the flooding schedule is unaffected
+    d2, _, i2, _ = eng.decode_batch(c["syndromes"][:8])
+    assert d2.shape == (8, c["n"])
+
+
+def test_serial_schedule_through_bpdecoder(oracle_built):
+    """python_test/test_bp_decoder.py:214-235 (rep code, serial schedule, reversed order) + batch vs the oracle."""
+    from ldpc_amd.bp_decoder import BpDecoder
+    from ldpc_amd.codes import rep_code, regular_ldpc_code
+    H = rep_code(3)
+    bpd = BpDecoder(H, error_rate=0.1, schedule="serial")
+    assert bpd.schedule == "serial" and np.array_equal(bpd.serial_schedule_order, np.array([0, 1, 2]))
+    bpd.serial_schedule_order = np.array([2, 1, 0])
+    bpd.decode(np.array([1, 1]))
+    assert np.array_equal(bpd.decoding, np.array([0, 1, 0]))
+    bpd.error_channel = np.array([0.1, 0, 0.1])
+    bpd.decode(np.array([1, 1]))
+    assert np.array_equal(bpd.decoding, np.array([1, 0, 1]))
+    h = regular_ldpc_code(600, 3, 6, seed=3)
+    synd = _synd(h, 0.07, seed=17, shots=200)
+    order = np.random.default_rng(2).permutation(600).astype(np.int32)
+    d = BpDecoder(h, error_rate=0.07, max_iter=25, bp_method="minimum_sum", ms_scaling_factor=0.8, schedule="serial",
+                  serial_schedule_order=[int(v) for v in order], input_vector_type="syndrome")
+    out = d.decode_batch(synd)
+    wd, wl, wi, wc = oracle_built.BpOracle(h, error_rate=0.07, max_iter=25, bp_method="ms",
+                                           ms_scaling_factor=0.8).decode_serial_batch(synd, order)
+    nz = synd.any(axis=1)
+    assert np.array_equal(out[nz], wd[nz]) and np.array_equal(d.iter_batch[nz], wi[nz])
+    assert bits_equal(d.log_prob_ratios_batch[nz], wl[nz])

@@ -43,3 +43,18 @@ def test_osd0_alone_vs_real_reference_with_ties_and_infinities(oracle_built):
             else:
                 llr = np.zeros(n)
             assert np.array_equal(o.osd0(s, llr), r.osd0(s, llr))
+
+
+from golden_util import serial_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", serial_case_names())
+def test_oracle_serial_schedule_reproduces_golden(name, oracle_built):
+    """oracle/bp_oracle.c: bp_oracle_decode_serial vs bp_decode_serial outputs captured from the real reference."""
+    from golden_util import bits_equal
+    c = load_case(name)
+    o = oracle_built.BpOracle(c["h"], error_channel=c["channel_probs"], max_iter=c["max_iter"], bp_method=c["bp_method"],
+                              ms_scaling_factor=c["ms_scaling_factor"])
+    dec, llr, it, cv = o.decode_serial_batch(c["syndromes"], c["order"])
+    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert bits_equal(llr[: len(c["llr"])], c["llr"]) or np.allclose(llr[: len(c["llr"])], c["llr"], rtol=1e-9, equal_nan=True)
