@@ -15,12 +15,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact"):
+def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel"):
     import torch
     from ldpc_amd.engine import HipBpEngine
     m, n = h.shape
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
     eng.set_math(math)
+    eng.set_schedule(schedule)
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
     out = eng.decode_batch(s, osd0=osd0)  # warm-up + result for statistics
     import time
@@ -35,7 +36,7 @@ def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_ex
     alg = float(np.sum(it.astype(np.float64) * 4.0 * h.nnz * 8.0 + (m + n + 8.0 * n + 5.0)))
     print(json.dumps({"config": name, "batch": batch, "syndromes_per_s": batch / ms * 1e3, "ms_per_decode": ms,
                       "bp_kernel_ms": eng.last_kernel_ms(), "mean_iterations": float(it.mean()),
-                      "bp_converged": float(cv.mean()), "algorithmic_GBps": alg / ms / 1e6, "math": math}), flush=True)
+                      "bp_converged": float(cv.mean()), "algorithmic_GBps": alg / ms / 1e6, "math": math, "schedule": schedule}), flush=True)
 
 
 def main():
@@ -47,12 +48,25 @@ def main():
         h = codes.rotated_surface_code_x(21)
         run("c3 surface d=21 min_sum 30 it p=0.05", h, 0.05, 30, 1, 0.625, 262144, False)
         run("c3 surface d=21 min_sum 30 it p=0.01", h, 0.01, 30, 1, 0.625, 262144, False)
+    if "serial" in args.which:
+        serial()
     if "c5" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05", h, 0.05, 50, 0, 1.0, 8192, True)
         run("c5 BB144 product_sum 50 it (BP only) p=0.05", h, 0.05, 50, 0, 1.0, 8192, False)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144 fast math", h, 0.05, 50, 0, 1.0, 262144, True, math="fast")
+
+
+def serial():
+    from ldpc_amd import codes
+    h = codes.bivariate_bicycle_hx()
+    run("serial: BB144 product_sum 50 it + OSD-0 p=0.05", h, 0.05, 50, 0, 1.0, 65536, True, schedule="serial")
+    run("serial: BB144 min_sum(0.625) 50 it p=0.05", h, 0.05, 50, 1, 0.625, 65536, False, schedule="serial")
+    h = codes.rotated_surface_code_x(21)
+    run("serial: surface d=21 min_sum 30 it p=0.05", h, 0.05, 30, 1, 0.625, 65536, False, schedule="serial")
+    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    run("serial: (3,6) n=10000 product_sum 50 it p=0.05", h, 0.05, 50, 0, 1.0, 65536, False, steps=1, schedule="serial")
 
 
 if __name__ == "__main__":
