@@ -48,6 +48,7 @@ def main() -> None:
     ap.add_argument("--math", default="libm_exact", choices=["libm_exact", "fast"], help="device tanh/log (include/ldpc_hip.h)")
     ap.add_argument("--bp-method", default="product_sum", choices=["product_sum", "minimum_sum"],
                     help="product_sum is the BASELINE workload; minimum_sum (alpha 0.625) is a diagnostic memory-only run")
+    ap.add_argument("--handoff", type=int, default=-1, help="straggler hand-off threshold in tiles (-1 auto, 0 off; diagnostic)")
     ap.add_argument("--ring", type=int, default=1, help="LDS-DMA ring: 0 = register-prefetch variant, 1 = default depth, 2/3 = depth (diagnostic)")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     args = ap.parse_args()
@@ -85,6 +86,7 @@ def main() -> None:
         eng.set_tuning(waves_per_workgroup=args.waves)
     eng.set_math(args.math)
     eng.set_ring(args.ring)
+    eng.set_handoff(args.handoff)
 
     # inputs resident in HBM before the timed region; this rank's shard of the global shot stream
     synd = eng.gen_bsc_syndromes(7, args.p, shot0=rank * B, shots=B, device=dev)

@@ -174,6 +174,14 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t 
  * matrices, 2 or 3 select the ring depth (1 = default); results are identical in every case. */
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 
+/* Straggler hand-off of the streaming BP kernel.  A 64-syndrome tile is decoded by one persistent workgroup,
+ * i.e. on one compute unit; when no more than `threshold_tiles` tiles are still running (a few syndromes that
+ * refuse to converge, a tiny batch, or the reference's default max_iter = n) those tiles park their state and
+ * their remaining iterations run as per-pass launches spread over the whole chip.  -1 = automatic (128 tiles,
+ * default), 0 = off.  Results are identical.  With the hand-off enabled decode_batch_async waits once for the
+ * persistent kernel (it needs the number of parked tiles). */
+int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
+
 /* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)
  * are decoded by an on-chip kernel: messages live in LDS, a workgroup keeps several syndromes resident and
  * replaces each one the moment it converges.  mode -1 = automatic (default), 0 = always use the streaming

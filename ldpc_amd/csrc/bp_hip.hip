@@ -68,6 +68,19 @@ struct BpArgs {
     double *llr_t;                      // [tiles][n][64] or nullptr
     int32_t *iters;                     // [batch] or nullptr
     uint8_t *conv;                      // [batch] or nullptr
+    // hand-off of straggler tiles to the chip-wide per-pass kernels (see bp_spread_*): 0 = never
+    struct TileState *state;            // [tiles]
+    unsigned *counters;                 // [0] tiles finished by the persistent kernel, [1] tiles handed off
+    int32_t *handoff_list;              // [tiles] ids of handed-off tiles
+    int32_t total_tiles, handoff_threshold;
+};
+
+// What a 64-syndrome tile needs besides its message arrays to continue in another kernel
+struct TileState {
+    uint64_t done;           // lanes whose syndrome has converged (or that lie beyond the batch)
+    int32_t it;              // iterations completed
+    int32_t finished;        // 1 once its outputs (iterations / converge / frozen decisions) are final
+    int32_t lane_iter[64];   // iteration at which each lane converged
 };
 
 __device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin of ldpc_amd/prng.py
@@ -307,6 +320,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     const int l8 = lane * 8;
 
     __shared__ uint64_t red[2][16];
+    __shared__ int red_i;
     __shared__ __attribute__((aligned(16))) double log_tab[256];  // glibc log's {1/c, log c} table, LDS-resident
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
@@ -534,6 +548,26 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
             __syncthreads();  // C is overwritten by the next check pass
         }
         if (done == ~0ull) break;
+        // Few tiles left running (stragglers, a tiny batch, or the tail of the launch): a lone tile is bound to
+        // ONE compute unit (~3 ms per iteration on the n = 10 000 code), so park its state and let the per-pass
+        // kernels below spread its remaining iterations over the whole chip.
+        if (a.handoff_threshold > 0 && it < a.max_iter) {
+            if (threadIdx.x == 0)
+                red_i = a.total_tiles - (int)__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (red_i <= a.handoff_threshold) {
+                TileState *stt = a.state + tile;
+                if (wave == 0) stt->lane_iter[lane] = my_iter;
+                if (threadIdx.x == 0) {
+                    stt->done = done;
+                    stt->it = it;
+                    stt->finished = 0;
+                    a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
+                }
+                return;
+            }
+            __syncthreads();  // red_i is rewritten next iteration
+        }
     }
 
     // syndromes that never converged report the last iteration's decisions (bp.hpp:320-322)
@@ -546,6 +580,147 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
             const bool cv = ((done >> lane) & 1ull) != 0;
             if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;  // bp.hpp:304
             if (a.conv) a.conv[b] = cv ? 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0 && a.counters) atomicAdd(&a.counters[0], 1u);
+}
+
+// ---- per-pass kernels for handed-off tiles ---------------------------------------------------------------
+// Same arithmetic, same arrays, but one launch per pass and one wavefront per NODE, so the rows / columns of a
+// single tile are spread over all 256 compute units.  Used for the tiles the persistent kernel parks when the
+// chip would otherwise idle; each launch handles every parked tile that is still running.
+struct SpreadArgs {
+    BpArgs bp;
+    int32_t n_tiles;  // entries of bp.handoff_list
+};
+
+__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st) {
+    tile = a.bp.handoff_list[slot];
+    st = a.bp.state + tile;
+    return !st->finished;
+}
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
+    __shared__ __attribute__((aligned(16))) double log_tab[256];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+    __syncthreads();
+    int64_t tile;
+    const TileState *st;
+    if (!spread_tile(a, blockIdx.y, tile, st)) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= a.bp.m) return;
+    const int nnz = a.bp.nnz, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const int it = st->it + 1;
+    const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
+    const int rs = a.bp.row_ptr[i], d = a.bp.row_ptr[i + 1] - rs;
+    const bool neg = (a.bp.nzm[tile * a.bp.m + i] >> lane) & 1ull;
+    const int parity = (int)((a.bp.par[tile * a.bp.m + i] >> lane) & 1ull);
+    check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+}
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
+    int64_t tile;
+    const TileState *st;
+    if (!spread_tile(a, blockIdx.y, tile, st)) return;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (j >= a.bp.n) return;
+    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const bool want_llr = a.bp.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+    const bool last = st->it + 1 == a.bp.max_iter;
+    const bool lane_live = !((st->done >> lane) & 1ull);
+    const int cs = a.bp.col_ptr[j], d = a.bp.col_ptr[j + 1] - cs;
+    double temp = a.bp.llr0[j];
+    for (int k = 0; k < d; ++k) {  // the reference's two sweeps (bp.hpp:278-281, 313-316)
+        const int ee = a.bp.csc_edge[cs + k];
+        At.st(l8, ee, temp);
+        temp += Ct.ld(l8, ee);
+    }
+    const double llr = temp;
+    double sfx = 0.0;
+    for (int k = d - 1; k >= 0; --k) {
+        const int ee = a.bp.csc_edge[cs + k];
+        At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
+        sfx += Ct.ld(l8, ee);
+    }
+    const uint64_t hard = __ballot(llr <= 0);
+    if (lane == 0) a.bp.dcur[tile * n + j] = hard;
+    if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+}
+
+// one workgroup per parked tile: syndrome test, freezing of newly converged lanes, outputs when the tile ends
+__global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a, unsigned *live_tiles) {
+    int64_t tile;
+    const TileState *cst;
+    if (!spread_tile(a, blockIdx.x, tile, cst)) return;
+    TileState *st = a.bp.state + tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int m = a.bp.m, n = a.bp.n, nnz = a.bp.nnz, l8 = lane * 8;
+    const uint64_t *par = a.bp.par + tile * m;
+    uint64_t *dec = a.bp.dec + tile * n;
+    const uint64_t *dcur = a.bp.dcur + tile * n;
+    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const bool want_llr = a.bp.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+    __shared__ uint64_t red[4];
+    uint64_t done = st->done;
+    const int it = st->it + 1;
+    const bool last = it == a.bp.max_iter;
+    uint64_t unsat = 0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        uint64_t cand = 0;
+        for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
+        unsat |= cand ^ par[i];
+    }
+    unsat = wave_or(unsat);
+    if (lane == 0) red[wave] = unsat;
+    __syncthreads();
+    unsat = a.bp.invalid[tile];
+    for (int w = 0; w < nwaves; ++w) unsat |= red[w];
+    const uint64_t newly = ~unsat & ~done;
+    if (newly) {
+        const bool mine = (newly >> lane) & 1ull;
+        if (wave == 0 && mine) st->lane_iter[lane] = it;
+        for (int j = wave; j < n; j += nwaves) {
+            if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            if (!last && want_llr) {
+                double temp = a.bp.llr0[j];
+                for (int p = a.bp.col_ptr[j]; p < a.bp.col_ptr[j + 1]; ++p) temp += Ct.ld(l8, a.bp.csc_edge[p]);
+                if (mine) Lt.st(l8, j, temp);
+            }
+        }
+        done |= newly;
+    }
+    __syncthreads();
+    const bool over = done == ~0ull || last;
+    if (over) {
+        if (done != ~0ull)
+            for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+        if (wave == 0) {
+            const int64_t b = tile * LDPC_WAVE + lane;
+            if (b < a.bp.batch) {
+                const bool cv = ((done >> lane) & 1ull) != 0;
+                if (a.bp.iters) a.bp.iters[b] = cv ? st->lane_iter[lane] : a.bp.max_iter;
+                if (a.bp.conv) a.bp.conv[b] = cv ? 1 : 0;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->done = done;
+        st->it = it;
+        if (over) {
+            st->finished = 1;
+            atomicSub(live_tiles, 1u);
         }
     }
 }
@@ -1174,6 +1349,9 @@ struct ldpc_hip_bp {
     bool regular = false;   // every row has the same weight and every column has the same weight
     int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
     int32_t small_mode = -1; // on-chip kernel for small codes: -1 auto, 0 never, 1 whenever it fits
+    int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (128), 0 off
+    DeviceBuf tile_state, handoff_list;
+    unsigned *h_counters = nullptr;  // pinned host copy of the device counters
     int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial (fixed order), 1 parallel
     int32_t *d_csc_row = nullptr, *d_order = nullptr;
     bool custom_order = false;
@@ -1314,7 +1492,8 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter})
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter,
+                         &h->tile_state, &h->handoff_list})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
     if (h->d_col_idx) (void)hipFree(h->d_col_idx);
@@ -1322,6 +1501,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->d_csc_edge) (void)hipFree(h->d_csc_edge);
     if (h->d_csc_row) (void)hipFree(h->d_csc_row);
     if (h->d_order) (void)hipFree(h->d_order);
+    if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->d_llr0) (void)hipFree(h->d_llr0);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1392,6 +1572,13 @@ int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *se
         h->custom_order = false;
     }
     h->schedule = schedule;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (threshold_tiles < -1) return fail(LDPC_HIP_ERR_INVALID, "threshold must be -1 (auto), 0 (off) or a tile count");
+    h->handoff = threshold_tiles > 32768 ? 32768 : threshold_tiles;
     return LDPC_HIP_OK;
 }
 
@@ -1628,6 +1815,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    const int handoff = h->handoff < 0 ? 128 : h->handoff;
+    if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
+    if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
+    if ((rc = h->counter.ensure(16))) return rc;
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
 
     const int ring = h->regular ? h->ring_depth : 0;
     KernelChoice kern;
@@ -1692,6 +1884,38 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         }
         HIPCHK(hipEventRecord(h->ev0, st));
         hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
+        HIPCHK(hipGetLastError());
+        if (handoff > 0 && h->max_iter > 1) {
+            // tiles parked by the persistent kernel: finish them with chip-wide per-pass launches.  The host needs
+            // their number (this is the one point where the otherwise asynchronous call waits for the device).
+            HIPCHK(hipMemcpyAsync(h->h_counters, h->counter.p, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            const unsigned parked = h->h_counters[1];
+            if (parked > 0) {
+                unsigned *live = (unsigned *)h->counter.p + 2;
+                HIPCHK(hipMemcpyAsync(live, &h->h_counters[1], sizeof(unsigned), hipMemcpyHostToDevice, st));
+                SpreadArgs sa;
+                sa.bp = a;
+                sa.n_tiles = (int32_t)parked;
+                void (*kc)(const SpreadArgs);
+                void (*kb)(const SpreadArgs);
+                if (h->bp_method == LDPC_HIP_MINIMUM_SUM) { kc = bp_spread_check_kernel<LDPC_HIP_MINIMUM_SUM, 0>; kb = bp_spread_bit_kernel<LDPC_HIP_MINIMUM_SUM, 0>; }
+                else if (h->math_mode == LDPC_HIP_MATH_FAST) { kc = bp_spread_check_kernel<LDPC_HIP_PRODUCT_SUM, 1>; kb = bp_spread_bit_kernel<LDPC_HIP_PRODUCT_SUM, 1>; }
+                else { kc = bp_spread_check_kernel<LDPC_HIP_PRODUCT_SUM, 0>; kb = bp_spread_bit_kernel<LDPC_HIP_PRODUCT_SUM, 0>; }
+                const dim3 gc((unsigned)((h->m + 3) / 4), parked), gb((unsigned)((h->n + 3) / 4), parked);
+                for (int round = 1; round < h->max_iter; ++round) {  // a parked tile has done >= 1 iteration
+                    hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(bp_spread_finish_kernel, dim3(parked), dim3(256), 0, st, sa, live);
+                    if ((round & 7) == 0 || round + 1 == h->max_iter) {
+                        HIPCHK(hipMemcpyAsync(&h->h_counters[2], live, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                        HIPCHK(hipStreamSynchronize(st));
+                        if (h->h_counters[2] == 0) break;
+                    }
+                }
+                HIPCHK(hipGetLastError());
+            }
+        }
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());

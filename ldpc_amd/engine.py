@@ -96,6 +96,10 @@ class HipBpEngine:
         """LDS-DMA ring for regular-degree matrices: False/0 = off, True/1 = default depth, 2 or 3 = slots per wave."""
         _lib.check(self._lib.ldpc_hip_bp_set_ring(self._h, int(depth)))
 
+    def set_handoff(self, threshold_tiles):
+        """Straggler hand-off of the streaming kernel: -1 automatic (default), 0 off, k = park when <= k tiles run."""
+        _lib.check(self._lib.ldpc_hip_bp_set_handoff(self._h, int(threshold_tiles)))
+
     def set_small_code_kernel(self, mode):
         """On-chip kernel for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))

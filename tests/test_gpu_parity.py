@@ -503,3 +503,46 @@ def test_serial_schedule_through_bpdecoder(oracle_built):
     nz = synd.any(axis=1)
     assert np.array_equal(out[nz], wd[nz]) and np.array_equal(d.iter_batch[nz], wi[nz])
     assert bits_equal(d.log_prob_ratios_batch[nz], wl[nz])
+
+
+# ---- straggler hand-off (persistent kernel -> chip-wide per-pass kernels) -----------------------------------
+
+@pytest.mark.parametrize("threshold", [0, 1, 3, 100000])
+@pytest.mark.parametrize("code,method,alpha,p,max_iter", [
+    ("ldpc36_n1200", "product_sum", 1.0, 0.075, 40),   # ring variant; some syndromes converge, some never do
+    ("ldpc36_n1200", "minimum_sum", 0.0, 0.06, 30),    # adaptive alpha depends on the per-tile iteration counter
+    ("hamming6", "product_sum", 1.0, 0.03, 25),        # irregular, heavy rows: register variant + streamed rows
+])
+def test_handoff_gives_identical_results(code, method, alpha, p, max_iter, threshold, oracle_built):
+    """Parking tiles after any number of iterations and finishing them with the per-pass kernels changes nothing:
+    decisions, flags, iteration counts and LLR bits equal the oracle's for every threshold (0 = never park,
+    100000 = every tile parks after its first iteration)."""
+    from ldpc_amd.engine import HipBpEngine
+    h = CODES[code]()
+    n = h.shape[1]
+    synd = _synd(h, p, seed=4321, shots=650)
+    synd[5, 0] = 2  # a syndrome byte > 1: that lane can never converge (bp.hpp:300)
+    wd, wl, wi, wc = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method,
+                                           ms_scaling_factor=alpha).decode_batch(synd)
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 0 if method == "product_sum" else 1, alpha)
+    eng.set_small_code_kernel(0)
+    eng.set_handoff(threshold)
+    dec, llr, it, cv = eng.decode_batch(synd)
+    assert np.array_equal(dec, wd) and np.array_equal(cv, wc) and np.array_equal(it, wi)
+    assert llr_close(llr, wl, rtol=LLR_RTOL)
+    if method == "minimum_sum" or _host_libm_is_glibc():
+        assert bits_equal(llr, wl)
+    dec2, _, it2, _ = eng.decode_batch(synd, want_llr=False)
+    assert np.array_equal(dec2, wd) and np.array_equal(it2, wi)
+
+
+def test_single_syndrome_latency_path_matches_golden():
+    """B = 1 on the big code: one tile, parked after the first iteration, finished by the per-pass kernels."""
+    from ldpc_amd.engine import HipBpEngine
+    c = load_case("c2_ldpc36_n10000_ps50_p090")
+    eng = _engine(c)
+    for k in range(3):
+        dec, llr, it, cv = eng.decode_batch(c["syndromes"][k:k + 1])
+        assert np.array_equal(dec[0], c["decoding"][k]) and int(it[0]) == int(c["iterations"][k])
+        if k < len(c["llr"]):
+            assert bits_equal(llr[0], c["llr"][k])
