@@ -1693,7 +1693,7 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
                                (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
         }
-        SerialArgs a;
+        SerialArgs a = {};
         a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.fast = fast ? 1 : 0;
         a.ms_scaling_factor = h->ms_scaling_factor;
         a.batch = nb;
@@ -1747,7 +1747,7 @@ static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint
     int rc;
     if ((rc = h->counter.ensure(8))) return rc;
     HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
-    SmallArgs a;
+    SmallArgs a = {};
     a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.slots = slots;
     a.ms_scaling_factor = h->ms_scaling_factor;
     a.batch = batch;
@@ -1842,7 +1842,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
                                (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
         }
-        BpArgs a;
+        BpArgs a = {};
         a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
         a.ms_scaling_factor = h->ms_scaling_factor;
         a.batch = nb;
@@ -1857,8 +1857,13 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
         a.iters = iters ? iters + b0 : nullptr;
         a.conv = conv ? conv + b0 : nullptr;
+        a.state = (TileState *)h->tile_state.p;
+        a.counters = (unsigned *)h->counter.p;
+        a.handoff_list = (int32_t *)h->handoff_list.p;
+        a.total_tiles = (int32_t)tiles;
+        a.handoff_threshold = handoff;
+        HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
 
-        // enough workgroups to fill 256 CUs at 16 wavefronts each; fewer, larger workgroups for small batches
         // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,
         // 16 wavefronts per CU -> 4-wave workgroups once there are >= 4 tiles per CU.  Ring variant:
         // ~70 VGPRs and 6 KiB of LDS per wavefront -> 24 wavefronts per CU as two 12-wave workgroups
@@ -1894,7 +1899,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             if (parked > 0) {
                 unsigned *live = (unsigned *)h->counter.p + 2;
                 HIPCHK(hipMemcpyAsync(live, &h->h_counters[1], sizeof(unsigned), hipMemcpyHostToDevice, st));
-                SpreadArgs sa;
+                SpreadArgs sa = {};
                 sa.bp = a;
                 sa.n_tiles = (int32_t)parked;
                 void (*kc)(const SpreadArgs);
@@ -1945,7 +1950,7 @@ static int bposd0_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if (!conv) { if ((rc = h->osd_conv.ensure(B ? B : 1))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv))) return rc;
     if (h->m == 0 || h->n == 0) return LDPC_HIP_OK;
-    OsdArgs a;
+    OsdArgs a = {};
     a.m = h->m; a.n = h->n; a.words = (h->n + 1 + 63) / 64;
     a.batch = batch;
     a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
