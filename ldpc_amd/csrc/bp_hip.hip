@@ -600,7 +600,9 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
     return !st->finished;
 }
 
-template <int METHOD, int MATH>
+#define LDPC_SPREAD_NODES 4  // rows / columns per wavefront of a per-pass launch (amortises the log-table load)
+
+template <int METHOD, int MATH, int DR>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
@@ -610,27 +612,36 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     const TileState *st;
     if (!spread_tile(a, blockIdx.y, tile, st)) return;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (i >= a.bp.m) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
     const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const int it = st->it + 1;
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
-    const int rs = a.bp.row_ptr[i], d = a.bp.row_ptr[i + 1] - rs;
-    const bool neg = (a.bp.nzm[tile * a.bp.m + i] >> lane) & 1ull;
-    const int parity = (int)((a.bp.par[tile * a.bp.m + i] >> lane) & 1ull);
-    check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+    const int i0 = (blockIdx.x * 4 + wave) * LDPC_SPREAD_NODES;
+    for (int i = i0; i < i0 + LDPC_SPREAD_NODES && i < a.bp.m; ++i) {
+        const int rs = sload(a.bp.row_ptr + i), d = sload(a.bp.row_ptr + i + 1) - rs;
+        const bool neg = (sload(a.bp.nzm + tile * a.bp.m + i) >> lane) & 1ull;
+        const int parity = (int)((sload(a.bp.par + tile * a.bp.m + i) >> lane) & 1ull);
+        if (d <= DR) {
+            double cur[DR];
+#pragma unroll
+            for (int k = 0; k < DR; ++k)
+                if (k < d) cur[k] = At.ld(l8, rs + k);
+            check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+        } else {
+            check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+        }
+    }
 }
 
-template <int METHOD, int MATH>
+template <int METHOD, int MATH, int DC>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
     int64_t tile;
     const TileState *st;
     if (!spread_tile(a, blockIdx.y, tile, st)) return;
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (j >= a.bp.n) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
     const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
@@ -638,23 +649,37 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
     const bool last = st->it + 1 == a.bp.max_iter;
     const bool lane_live = !((st->done >> lane) & 1ull);
-    const int cs = a.bp.col_ptr[j], d = a.bp.col_ptr[j + 1] - cs;
-    double temp = a.bp.llr0[j];
-    for (int k = 0; k < d; ++k) {  // the reference's two sweeps (bp.hpp:278-281, 313-316)
-        const int ee = a.bp.csc_edge[cs + k];
-        At.st(l8, ee, temp);
-        temp += Ct.ld(l8, ee);
+    const int j0 = (blockIdx.x * 4 + wave) * LDPC_SPREAD_NODES;
+    for (int j = j0; j < j0 + LDPC_SPREAD_NODES && j < n; ++j) {
+        const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
+        const double prior = sload(a.bp.llr0 + j);
+        double llr;
+        if (d <= DC) {
+            int e[DC];
+            double c[DC];
+#pragma unroll
+            for (int k = 0; k < DC; ++k)
+                if (k < d) { e[k] = sload(a.bp.csc_edge + cs + k); c[k] = Ct.ld(l8, e[k]); }
+            llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8);
+        } else {  // the reference's two sweeps (bp.hpp:278-281, 313-316) through memory
+            double temp = prior;
+            for (int k = 0; k < d; ++k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, temp);
+                temp += Ct.ld(l8, ee);
+            }
+            llr = temp;
+            double sfx = 0.0;
+            for (int k = d - 1; k >= 0; --k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
+                sfx += Ct.ld(l8, ee);
+            }
+        }
+        const uint64_t hard = __ballot(llr <= 0);
+        if (lane == 0) a.bp.dcur[tile * n + j] = hard;
+        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
     }
-    const double llr = temp;
-    double sfx = 0.0;
-    for (int k = d - 1; k >= 0; --k) {
-        const int ee = a.bp.csc_edge[cs + k];
-        At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
-        sfx += Ct.ld(l8, ee);
-    }
-    const uint64_t hard = __ballot(llr <= 0);
-    if (lane == 0) a.bp.dcur[tile * n + j] = hard;
-    if (last && want_llr && lane_live) Lt.st(l8, j, llr);
 }
 
 // one workgroup per parked tile: syndrome test, freezing of newly converged lanes, outputs when the tile ends
@@ -1619,6 +1644,13 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
 }  // extern "C"
 
 typedef void (*bp_kernel_t)(const BpArgs);
+typedef void (*spread_kernel_t)(const SpreadArgs);
+
+template <int METHOD, int MATH>
+static void pick_spread_m(int max_row, int max_col, spread_kernel_t &kc, spread_kernel_t &kb) {
+    kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8> : bp_spread_check_kernel<METHOD, MATH, 16>;
+    kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4> : bp_spread_bit_kernel<METHOD, MATH, 8>;
+}
 
 struct KernelChoice {
     bp_kernel_t fn;
@@ -1775,6 +1807,12 @@ static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint
     return LDPC_HIP_OK;
 }
 
+static void pick_spread(const ldpc_hip_bp *h, spread_kernel_t &kc, spread_kernel_t &kb) {
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, kc, kb);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, kc, kb);
+    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, kc, kb);
+}
+
 // Everything below runs on h->stream with device pointers only.
 static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                          double *llr, int32_t *iters, uint8_t *conv) {
@@ -1904,10 +1942,9 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                 sa.n_tiles = (int32_t)parked;
                 void (*kc)(const SpreadArgs);
                 void (*kb)(const SpreadArgs);
-                if (h->bp_method == LDPC_HIP_MINIMUM_SUM) { kc = bp_spread_check_kernel<LDPC_HIP_MINIMUM_SUM, 0>; kb = bp_spread_bit_kernel<LDPC_HIP_MINIMUM_SUM, 0>; }
-                else if (h->math_mode == LDPC_HIP_MATH_FAST) { kc = bp_spread_check_kernel<LDPC_HIP_PRODUCT_SUM, 1>; kb = bp_spread_bit_kernel<LDPC_HIP_PRODUCT_SUM, 1>; }
-                else { kc = bp_spread_check_kernel<LDPC_HIP_PRODUCT_SUM, 0>; kb = bp_spread_bit_kernel<LDPC_HIP_PRODUCT_SUM, 0>; }
-                const dim3 gc((unsigned)((h->m + 3) / 4), parked), gb((unsigned)((h->n + 3) / 4), parked);
+                pick_spread(h, kc, kb);
+                const unsigned per_wg = 4 * LDPC_SPREAD_NODES;
+                const dim3 gc((unsigned)((h->m + per_wg - 1) / per_wg), parked), gb((unsigned)((h->n + per_wg - 1) / per_wg), parked);
                 for (int round = 1; round < h->max_iter; ++round) {  // a parked tile has done >= 1 iteration
                     hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
                     hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
