@@ -592,6 +592,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
 struct SpreadArgs {
     BpArgs bp;
     int32_t n_tiles;  // entries of bp.handoff_list
+    int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4 otherwise: amortises the table load)
 };
 
 __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st) {
@@ -600,7 +601,6 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
     return !st->finished;
 }
 
-#define LDPC_SPREAD_NODES 4  // rows / columns per wavefront of a per-pass launch (amortises the log-table load)
 
 template <int METHOD, int MATH, int DR>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
@@ -618,8 +618,8 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const int it = st->it + 1;
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
-    const int i0 = (blockIdx.x * 4 + wave) * LDPC_SPREAD_NODES;
-    for (int i = i0; i < i0 + LDPC_SPREAD_NODES && i < a.bp.m; ++i) {
+    const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
         const int rs = sload(a.bp.row_ptr + i), d = sload(a.bp.row_ptr + i + 1) - rs;
         const bool neg = (sload(a.bp.nzm + tile * a.bp.m + i) >> lane) & 1ull;
         const int parity = (int)((sload(a.bp.par + tile * a.bp.m + i) >> lane) & 1ull);
@@ -649,8 +649,8 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
     const bool last = st->it + 1 == a.bp.max_iter;
     const bool lane_live = !((st->done >> lane) & 1ull);
-    const int j0 = (blockIdx.x * 4 + wave) * LDPC_SPREAD_NODES;
-    for (int j = j0; j < j0 + LDPC_SPREAD_NODES && j < n; ++j) {
+    const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
         const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
         const double prior = sload(a.bp.llr0 + j);
         double llr;
@@ -1940,10 +1940,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                 SpreadArgs sa = {};
                 sa.bp = a;
                 sa.n_tiles = (int32_t)parked;
+                sa.nodes = parked <= 8 ? 1 : 4;
                 void (*kc)(const SpreadArgs);
                 void (*kb)(const SpreadArgs);
                 pick_spread(h, kc, kb);
-                const unsigned per_wg = 4 * LDPC_SPREAD_NODES;
+                const unsigned per_wg = 4u * (unsigned)sa.nodes;
                 const dim3 gc((unsigned)((h->m + per_wg - 1) / per_wg), parked), gb((unsigned)((h->n + per_wg - 1) / per_wg), parked);
                 for (int round = 1; round < h->max_iter; ++round) {  // a parked tile has done >= 1 iteration
                     hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
