@@ -177,9 +177,11 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 /* Straggler hand-off of the streaming BP kernel.  A 64-syndrome tile is decoded by one persistent workgroup,
  * i.e. on one compute unit; when no more than `threshold_tiles` tiles are still running (a few syndromes that
  * refuse to converge, a tiny batch, or the reference's default max_iter = n) those tiles park their state and
- * their remaining iterations run as per-pass launches spread over the whole chip.  -1 = automatic (128 tiles,
- * default), 0 = off.  Results are identical.  With the hand-off enabled decode_batch_async waits once for the
- * persistent kernel (it needs the number of parked tiles). */
+ * their remaining iterations run as per-pass launches (check pass, bit pass, syndrome test, bookkeeping) spread
+ * over the whole chip; a batch of no more than `threshold_tiles` tiles runs that way from the first iteration.
+ * -1 = automatic (256 tiles, default), 0 = off.  Results are identical.  With the hand-off enabled
+ * decode_batch_async waits once for the persistent kernel (it needs the number of parked tiles) when the batch
+ * is larger than the threshold. */
 int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
 
 /* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)

@@ -75,12 +75,15 @@ struct BpArgs {
     int32_t total_tiles, handoff_threshold;
 };
 
-// What a 64-syndrome tile needs besides its message arrays to continue in another kernel
+// What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in
+// ROUNDS (one BP iteration each) of four launches; within a launch many workgroups read a tile's state while one
+// of them advances it, so everything that changes is double-buffered by round parity or written once.
 struct TileState {
-    uint64_t done;           // lanes whose syndrome has converged (or that lie beyond the batch)
-    int32_t it;              // iterations completed
-    int32_t finished;        // 1 once its outputs (iterations / converge / frozen decisions) are final
-    int32_t lane_iter[64];   // iteration at which each lane converged
+    uint64_t done[2];            // [round & 1]: lanes whose syndrome has converged (or that lie beyond the batch)
+    unsigned long long unsat[2]; // [round & 1]: OR over rows of (candidate parity ^ syndrome), filled by the syndrome pass
+    int32_t it0;                 // iterations completed before round 0
+    int32_t end_round;           // round in which the tile's outputs became final (INT32_MAX while it runs)
+    int32_t lane_iter[64];       // iteration at which each lane converged
 };
 
 __device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin of ldpc_amd/prng.py
@@ -559,9 +562,10 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 TileState *stt = a.state + tile;
                 if (wave == 0) stt->lane_iter[lane] = my_iter;
                 if (threadIdx.x == 0) {
-                    stt->done = done;
-                    stt->it = it;
-                    stt->finished = 0;
+                    stt->done[0] = done;
+                    stt->it0 = it;
+                    stt->end_round = INT32_MAX;
+                    stt->unsat[0] = stt->unsat[1] = 0ull;
                     a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
                 }
                 return;
@@ -593,12 +597,16 @@ struct SpreadArgs {
     BpArgs bp;
     int32_t n_tiles;  // entries of bp.handoff_list
     int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4 otherwise: amortises the table load)
+    int32_t round;    // 0-based per-pass round; a tile's iteration number is it0 + round + 1
 };
 
-__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st) {
+// tile handled by workgroup row `slot`, its iteration number and converged mask in this round; false: already final
+__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
     tile = a.bp.handoff_list[slot];
     st = a.bp.state + tile;
-    return !st->finished;
+    it = st->it0 + a.round + 1;
+    done = st->done[a.round & 1];
+    return a.round <= st->end_round;
 }
 
 
@@ -610,13 +618,14 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     __syncthreads();
     int64_t tile;
     const TileState *st;
-    if (!spread_tile(a, blockIdx.y, tile, st)) return;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
     const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    const int it = st->it + 1;
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
     const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
     for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
@@ -639,7 +648,9 @@ template <int METHOD, int MATH, int DC>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
     int64_t tile;
     const TileState *st;
-    if (!spread_tile(a, blockIdx.y, tile, st)) return;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
@@ -647,8 +658,8 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const bool want_llr = a.bp.llr_t != nullptr;
     const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
-    const bool last = st->it + 1 == a.bp.max_iter;
-    const bool lane_live = !((st->done >> lane) & 1ull);
+    const bool last = it == a.bp.max_iter;
+    const bool lane_live = !((done >> lane) & 1ull);
     const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
     for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
         const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
@@ -682,69 +693,108 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     }
 }
 
-// one workgroup per parked tile: syndrome test, freezing of newly converged lanes, outputs when the tile ends
+// candidate syndrome vs syndrome (bp.hpp:292-294, 300-302) for the parked tiles, one thread per (tile, row); the
+// per-tile verdict is OR-accumulated into TileState::unsat for bp_spread_finish_kernel
+__global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a) {
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t unsat = 0;
+    if (i < a.bp.m) {
+        const uint64_t *dcur = a.bp.dcur + tile * a.bp.n;
+        uint64_t cand = 0;
+        for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
+        unsat = cand ^ a.bp.par[tile * a.bp.m + i];
+    }
+    unsat = wave_or(unsat);
+    if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
+}
+
+// batches of only a few tiles skip the persistent kernel altogether: state + message initialisation for the per-pass path
+__global__ void __launch_bounds__(256) bp_spread_state_init_kernel(const SpreadArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    TileState *st = a.bp.state + t;
+    const int64_t valid = a.bp.batch - (int64_t)t * LDPC_WAVE;
+    st->done[0] = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    st->unsat[0] = st->unsat[1] = 0ull;
+    st->it0 = 0;
+    st->end_round = INT32_MAX;
+    for (int l = 0; l < 64; ++l) st->lane_iter[l] = 0;
+    a.bp.handoff_list[t] = t;
+}
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_spread_init_kernel(const SpreadArgs a) {  // bp.hpp:147-157
+    const int64_t tile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const int e0 = (blockIdx.x * 4 + wave) * 16;
+    for (int e = e0; e < e0 + 16 && e < nnz; ++e)
+        At.st(l8, e, edge_form<METHOD, MATH>(sload(a.bp.llr0 + sload(a.bp.col_idx + e))));
+}
+
+// convergence bookkeeping of a round (bp.hpp:296-311, 320-322): lanes whose candidate syndrome matched are frozen
+// (decisions + posterior of THIS iteration), a tile whose lanes are all frozen or that reached max_iter gets its
+// outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
+// to freeze and every workgroup but the first leaves at once.
 __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a, unsigned *live_tiles) {
     int64_t tile;
     const TileState *cst;
-    if (!spread_tile(a, blockIdx.x, tile, cst)) return;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, cst, it, done)) return;
     TileState *st = a.bp.state + tile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int m = a.bp.m, n = a.bp.n, nnz = a.bp.nnz, l8 = lane * 8;
-    const uint64_t *par = a.bp.par + tile * m;
-    uint64_t *dec = a.bp.dec + tile * n;
-    const uint64_t *dcur = a.bp.dcur + tile * n;
-    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    const bool want_llr = a.bp.llr_t != nullptr;
-    const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
-    __shared__ uint64_t red[4];
-    uint64_t done = st->done;
-    const int it = st->it + 1;
+    const int par = a.round & 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = a.bp.n, nnz = a.bp.nnz, l8 = lane * 8;
     const bool last = it == a.bp.max_iter;
-    uint64_t unsat = 0;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        uint64_t cand = 0;
-        for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
-        unsat |= cand ^ par[i];
-    }
-    unsat = wave_or(unsat);
-    if (lane == 0) red[wave] = unsat;
-    __syncthreads();
-    unsat = a.bp.invalid[tile];
-    for (int w = 0; w < nwaves; ++w) unsat |= red[w];
+    const uint64_t unsat = cst->unsat[par] | a.bp.invalid[tile];
     const uint64_t newly = ~unsat & ~done;
-    if (newly) {
-        const bool mine = (newly >> lane) & 1ull;
-        if (wave == 0 && mine) st->lane_iter[lane] = it;
-        for (int j = wave; j < n; j += nwaves) {
-            if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
-            if (!last && want_llr) {
+    const uint64_t ndone = done | newly;
+    const bool over = ndone == ~0ull || last;
+    const bool mine = (newly >> lane) & 1ull;
+    if (newly || (over && ndone != ~0ull)) {
+        uint64_t *dec = a.bp.dec + tile * n;
+        const uint64_t *dcur = a.bp.dcur + tile * n;
+        const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+        const bool want_llr = a.bp.llr_t != nullptr;
+        const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+        const int j0 = blockIdx.x * 64 + wave * 16;
+        for (int j = j0; j < j0 + 16 && j < n; ++j) {
+            if (lane == 0) {
+                const uint64_t cur = dcur[j];
+                uint64_t d = (dec[j] & ~newly) | (cur & newly);
+                if (over) d = (d & ndone) | (cur & ~ndone);  // never converged: the last iteration's decisions
+                dec[j] = d;
+            }
+            if (newly && !last && want_llr) {  // at the last iteration the bit pass has stored the posterior already
                 double temp = a.bp.llr0[j];
                 for (int p = a.bp.col_ptr[j]; p < a.bp.col_ptr[j + 1]; ++p) temp += Ct.ld(l8, a.bp.csc_edge[p]);
                 if (mine) Lt.st(l8, j, temp);
             }
         }
-        done |= newly;
     }
-    __syncthreads();
-    const bool over = done == ~0ull || last;
-    if (over) {
-        if (done != ~0ull)
-            for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
-        if (wave == 0) {
-            const int64_t b = tile * LDPC_WAVE + lane;
-            if (b < a.bp.batch) {
-                const bool cv = ((done >> lane) & 1ull) != 0;
-                if (a.bp.iters) a.bp.iters[b] = cv ? st->lane_iter[lane] : a.bp.max_iter;
-                if (a.bp.conv) a.bp.conv[b] = cv ? 1 : 0;
-            }
+    if (blockIdx.x != 0) return;
+    if (wave == 0) {
+        if (mine) st->lane_iter[lane] = it;
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (over && b < a.bp.batch) {
+            const bool cv = ((ndone >> lane) & 1ull) != 0;
+            if (a.bp.iters) a.bp.iters[b] = cv ? (mine ? it : st->lane_iter[lane]) : a.bp.max_iter;  // bp.hpp:304
+            if (a.bp.conv) a.bp.conv[b] = cv ? 1 : 0;
         }
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        st->done = done;
-        st->it = it;
+        st->done[par ^ 1] = ndone;
+        st->unsat[par ^ 1] = 0ull;
         if (over) {
-            st->finished = 1;
+            st->end_round = a.round;
             atomicSub(live_tiles, 1u);
         }
     }
@@ -1374,7 +1424,7 @@ struct ldpc_hip_bp {
     bool regular = false;   // every row has the same weight and every column has the same weight
     int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
     int32_t small_mode = -1; // on-chip kernel for small codes: -1 auto, 0 never, 1 whenever it fits
-    int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (128), 0 off
+    int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
     int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial (fixed order), 1 parallel
@@ -1853,7 +1903,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
-    const int handoff = h->handoff < 0 ? 128 : h->handoff;
+    const int handoff = h->handoff < 0 ? 256 : h->handoff;
     if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
     if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
     if ((rc = h->counter.ensure(16))) return rc;
@@ -1926,38 +1976,58 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             h->accumulated_ms += prev;
         }
         HIPCHK(hipEventRecord(h->ev0, st));
-        hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
-        HIPCHK(hipGetLastError());
-        if (handoff > 0 && h->max_iter > 1) {
-            // tiles parked by the persistent kernel: finish them with chip-wide per-pass launches.  The host needs
-            // their number (this is the one point where the otherwise asynchronous call waits for the device).
-            HIPCHK(hipMemcpyAsync(h->h_counters, h->counter.p, 16, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            const unsigned parked = h->h_counters[1];
-            if (parked > 0) {
-                unsigned *live = (unsigned *)h->counter.p + 2;
-                HIPCHK(hipMemcpyAsync(live, &h->h_counters[1], sizeof(unsigned), hipMemcpyHostToDevice, st));
-                SpreadArgs sa = {};
-                sa.bp = a;
-                sa.n_tiles = (int32_t)parked;
-                sa.nodes = parked <= 8 ? 1 : 4;
-                void (*kc)(const SpreadArgs);
-                void (*kb)(const SpreadArgs);
-                pick_spread(h, kc, kb);
-                const unsigned per_wg = 4u * (unsigned)sa.nodes;
-                const dim3 gc((unsigned)((h->m + per_wg - 1) / per_wg), parked), gb((unsigned)((h->n + per_wg - 1) / per_wg), parked);
-                for (int round = 1; round < h->max_iter; ++round) {  // a parked tile has done >= 1 iteration
-                    hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
-                    hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
-                    hipLaunchKernelGGL(bp_spread_finish_kernel, dim3(parked), dim3(256), 0, st, sa, live);
-                    if ((round & 7) == 0 || round + 1 == h->max_iter) {
-                        HIPCHK(hipMemcpyAsync(&h->h_counters[2], live, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-                        HIPCHK(hipStreamSynchronize(st));
-                        if (h->h_counters[2] == 0) break;
-                    }
-                }
-                HIPCHK(hipGetLastError());
+        SpreadArgs sa = {};
+        sa.bp = a;
+        unsigned parked = 0;
+        int first_round = 1;  // a tile parked by the persistent kernel has completed >= 1 iteration
+        if (handoff > 0 && tiles <= handoff && h->max_iter > 1) {
+            // so few tiles that they would each sit on one compute unit: per-pass launches from the start
+            parked = (unsigned)tiles;
+            sa.n_tiles = (int32_t)parked;
+            first_round = 0;
+            hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((parked + 255) / 256), dim3(256), 0, st, sa);
+            const dim3 gi((unsigned)((h->nnz + 63) / 64), parked);
+            if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
+            else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), gi, dim3(256), 0, st, sa);
+            else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
+            HIPCHK(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
+            HIPCHK(hipGetLastError());
+            if (handoff > 0 && h->max_iter > 1) {
+                // tiles parked by the persistent kernel: the host needs their number (this is the one point where the
+                // otherwise asynchronous call waits for the device)
+                HIPCHK(hipMemcpyAsync(h->h_counters, h->counter.p, 16, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                parked = h->h_counters[1];
             }
+        }
+        if (parked > 0) {
+            // finish the parked tiles with chip-wide per-pass launches: check, bit, syndrome test, bookkeeping
+            unsigned *live = (unsigned *)h->counter.p + 2;
+            h->h_counters[3] = parked;
+            HIPCHK(hipMemcpyAsync(live, &h->h_counters[3], sizeof(unsigned), hipMemcpyHostToDevice, st));
+            sa.n_tiles = (int32_t)parked;
+            sa.nodes = parked <= 8 ? 1 : 4;
+            spread_kernel_t kc, kb;
+            pick_spread(h, kc, kb);
+            const unsigned per_wg = 4u * (unsigned)sa.nodes;
+            const dim3 gc((unsigned)((h->m + per_wg - 1) / per_wg), parked), gb((unsigned)((h->n + per_wg - 1) / per_wg), parked);
+            const dim3 gs((unsigned)((h->m + 255) / 256), parked), gf((unsigned)((h->n + 63) / 64), parked);
+            const int rounds = h->max_iter - first_round;
+            for (int round = 0; round < rounds; ++round) {
+                sa.round = round;
+                hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_synd_kernel, gs, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_finish_kernel, gf, dim3(256), 0, st, sa, live);
+                if ((round & 7) == 7 && round + 1 < rounds) {  // everything converged early?
+                    HIPCHK(hipMemcpyAsync(&h->h_counters[2], live, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    if (h->h_counters[2] == 0) break;
+                }
+            }
+            HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
