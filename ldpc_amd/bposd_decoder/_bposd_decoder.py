@@ -114,6 +114,18 @@ class BpOsdDecoder(BpDecoderBase):
         if syndromes.ndim != 2 or syndromes.shape[1] != self.m:
             raise ValueError(f"The syndrome must have length {self.m}. Not {syndromes.shape[-1]}.")
         self._require_supported()
+        from ldpc_amd.engine import _is_torch
+        if _is_torch(syndromes):  # device tensors in, device tensors out (nothing crosses PCIe)
+            dec, llr, it, cv = self._get_engine().decode_batch(syndromes, want_llr=want_log_prob_ratios, osd0=True)
+            zero = ~syndromes.any(dim=1)
+            if bool(zero.any()):
+                dec[zero] = 0
+                cv[zero] = 1
+                it[zero] = 0
+                if llr is not None:
+                    llr[zero] = 0
+            self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv.bool(), it, llr
+            return dec
         dtype = syndromes.dtype
         vec = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
         dec, llr, it, cv = self._decode_numpy(vec, want_llr=want_log_prob_ratios, osd0=True)

@@ -26,6 +26,7 @@ class HipBpEngine:
                  device: int = -1):
         self._lib = _lib.load()
         self._h = C.c_void_p()
+        self.device = int(device)
         row_ptr = np.ascontiguousarray(row_ptr, np.int32)
         col_idx = np.ascontiguousarray(col_idx, np.int32)
         probs = np.ascontiguousarray(channel_probs, np.float64)
