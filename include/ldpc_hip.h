@@ -133,6 +133,29 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes,
                                        uint8_t *converge);
 
 /*
+ * BP + ordered-statistics decoding of any order: replaces BpOsdDecoder.decode's per-shot path for
+ * osd_method OSD_E / OSD_CS as well (ldpc::osd::OsdDecoder::decode, src_cpp/osd.hpp:103-187; candidate strings
+ * osd.hpp:75-101).  ldpc_hip_bp_set_osd stores the method and order the BpOsdDecoder setters write
+ * (_bposd_decoder.pyx:161-234): osd_method 0 = OSD_OFF, 1 = OSD_0, 2 = OSD_E (exhaustive), 3 = OSD_CS
+ * (combination sweep) -- the values of ldpc::osd::OsdMethod (osd.hpp:18-23); osd_order >= 0, 0 with OSD_0.
+ * ldpc_hip_bposd_decode_batch then post-processes every row BP left unconverged: column sort by log-ratio,
+ * reduced row echelon form over that order, the OSD-0 solution, and the sweep over the candidate strings on the
+ * non-pivot columns; a candidate replaces the current solution only if its weight sum_j x_j log(1 / p_j)
+ * (added up in ascending j, as osd.hpp:171-176 does) is STRICTLY smaller.  osd_order == 0 takes the OSD-0
+ * branch whatever the method (osd.hpp:114).  Outputs as for ldpc_hip_bposd0_decode_batch.
+ * Limits: the LDS bound of OSD-0 (plus 8 m + 4 n bytes); OSD_E osd_order <= 24; OSD_CS osd_order <= 64 (pairs
+ * whose second index reaches past the k = n - rank non-pivot columns are skipped -- undefined behaviour in the
+ * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H.
+ */
+int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
+int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                                uint8_t *decoding, double *llr, int32_t *iterations,
+                                uint8_t *converge);
+int ldpc_hip_bposd_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
+                                      uint8_t *decoding, double *llr, int32_t *iterations,
+                                      uint8_t *converge);
+
+/*
  * replaces: GF2Sparse::mulvec (gf2sparse.hpp:177-214) over a batch:
  * out[b][i] = XOR_{j in row i} in[b][j].  Used by received-vector mode (bp.hpp:162-180).
  */

@@ -78,14 +78,20 @@ public:
         return decoding;
     }
 
-    // `batch` syndromes, row-major [batch][m]; osd0 = true adds OSD-0 for unconverged rows (osd.hpp:110-117)
-    bool decode_batch(const uint8_t *syndromes, int64_t batch, bool want_llr = true, bool osd0 = false) {
+    // `batch` syndromes, row-major [batch][m]; osd = true post-processes unconverged rows with ordered-statistics
+    // decoding (osd.hpp:103-187) of method `osd_method` (1 OSD_0, 2 OSD_E, 3 OSD_CS; osd.hpp:18-23) and `osd_order`
+    int osd_method = 1, osd_order = 0;
+    bool decode_batch(const uint8_t *syndromes, int64_t batch, bool want_llr = true, bool osd = false) {
         if (!sync_()) return false;
+        if (osd) {
+            last_status = ldpc_hip_bp_set_osd(h_, osd_method, osd_order);
+            if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+        }
         decoding_batch.assign((size_t)batch * bit_count, 0);
         if (want_llr) log_prob_ratios_batch.assign((size_t)batch * bit_count, 0.0);
         iterations_batch.assign((size_t)batch, 0);
         converge_batch.assign((size_t)batch, 0);
-        auto fn = osd0 ? ldpc_hip_bposd0_decode_batch : ldpc_hip_bp_decode_batch;
+        auto fn = osd ? ldpc_hip_bposd_decode_batch : ldpc_hip_bp_decode_batch;
         last_status = fn(h_, syndromes, batch, decoding_batch.data(), want_llr ? log_prob_ratios_batch.data() : nullptr,
                          iterations_batch.data(), converge_batch.data());
         if (last_status != LDPC_HIP_OK) last_error = ldpc_hip_last_error();

@@ -39,6 +39,8 @@ cdef extern from "ldpc_hip.hpp" namespace "ldpc_hip":
         vector[uint8_t] converge_batch
         int last_status
         string last_error
+        int osd_method
+        int osd_order
         vector[uint8_t]& decode(vector[uint8_t]& syndrome)
         cbool decode_batch(const uint8_t *syndromes, int64_t batch, cbool want_llr, cbool osd0) nogil
 
@@ -113,6 +115,22 @@ cdef class CyBpCore:
     @property
     def decoding(self):
         return np.array(self.bpd.decoding, dtype=np.uint8)
+
+    @property
+    def osd_method(self):
+        return self.bpd.osd_method
+
+    @osd_method.setter
+    def osd_method(self, int value):
+        self.bpd.osd_method = value
+
+    @property
+    def osd_order(self):
+        return self.bpd.osd_order
+
+    @osd_order.setter
+    def osd_order(self, int value):
+        self.bpd.osd_order = value
 
     # ---- data path ----
     def decode(self, syndrome):

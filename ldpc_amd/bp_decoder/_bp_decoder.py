@@ -486,7 +486,7 @@ class BpDecoder(BpDecoderBase):
             dec, llr, it, cv = eng.decode_batch(synd, want_llr=want_log_prob_ratios)
             if not as_syndrome:
                 dec ^= vec
-            zero = ~vec.any(dim=1)  # all-zero shortcut rows (pyx:679-681)
+            zero = vec.any(dim=1).logical_not()  # all-zero shortcut rows (pyx:679-681); uint8.any() is uint8
             if bool(zero.any()):
                 dec[zero] = 0
                 cv[zero] = 1

@@ -1,9 +1,8 @@
 """Host-side mirror of the reference's ``BpOsdDecoder`` (src_python/ldpc/bposd_decoder/_bposd_decoder.pyx:8-299).
 
-BP runs in the HIP kernels; rows BP leaves unconverged get order-zero ordered-statistics decoding
-(``osd.hpp:110-117``) on the device as well (``ldpc_hip_bposd0_decode_batch``).  Only ``osd_method`` OSD_0 is
-available on this path: OSD_E / OSD_CS (``osd.hpp:119-187``) are listed as "next" in SURVEY.md §8f and raise
-``NotImplementedError`` at decode time -- there is no CPU fallback.
+BP runs in the HIP kernels; rows BP leaves unconverged get ordered-statistics decoding on the device as well
+(``ldpc_hip_bposd_decode_batch``): OSD_0 (``osd.hpp:110-117``), OSD_E and OSD_CS (``osd.hpp:119-187``; OSD_E up to
+order 24, OSD_CS up to order 64).  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -44,6 +43,8 @@ class BpOsdDecoder(BpDecoderBase):
         self.input_vector_type = "syndrome"  # pyx:72
         self._bp_decoding = np.zeros(self.n, np.uint8)
         self._osd0_decoding = np.zeros(self.n, np.uint8)
+        self._osdw_decoding = np.zeros(self.n, np.uint8)
+        self._last_syndrome = np.zeros(self.m, np.uint8)
         self.bp_decoding_batch = None
 
     # ---- OSD parameters (pyx:139-234) -------------------------------------------------------------
@@ -84,10 +85,24 @@ class BpOsdDecoder(BpDecoderBase):
 
     def _require_supported(self):
         self._require_parallel()
-        if not (self._osd_method == OSD_0 or (self._osd_method in (EXHAUSTIVE, COMBINATION_SWEEP) and self._osd_order == 0)):
+        if self._osd_method == OSD_OFF:
+            raise NotImplementedError("osd_method='OSD_OFF': the reference dereferences an unset LU object here (osd.hpp:63, 110); "
+                                      "choose OSD_0, OSD_E or OSD_CS.")
+        if (self._osd_method == EXHAUSTIVE and self._osd_order > 24) or (self._osd_method == COMBINATION_SWEEP and self._osd_order > 64):
             raise NotImplementedError(
-                f"osd_method={self.osd_method} with osd_order={self._osd_order} is not available on the MI355X path yet: "
-                "only OSD-0 (osd.hpp:110-117) is implemented in HIP; there is no CPU fallback.")
+                f"osd_method={self.osd_method} with osd_order={self._osd_order} is not available on the MI355X path "
+                "(OSD_E up to order 24, OSD_CS up to order 64); there is no CPU fallback.")
+
+    def _decode_osd(self, synd2d, want_llr=True, force_osd0=False):
+        """BP + OSD through the active backend with this decoder's osd_method / osd_order."""
+        method, order = (OSD_0, 0) if force_osd0 else (self._osd_method, self._osd_order)
+        cy = self._get_cy()
+        if cy is not None:
+            cy.osd_method, cy.osd_order = method, order
+            return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, True)
+        eng = self._get_engine()
+        eng.set_osd(method, order)
+        return eng.decode_batch(synd2d, want_llr=want_llr, osd=True)
 
     # ---- decode (pyx:78-136) ----------------------------------------------------------------------
     def decode(self, syndrome: np.ndarray) -> np.ndarray:
@@ -98,7 +113,7 @@ class BpOsdDecoder(BpDecoderBase):
             self._converge = True
             return np.zeros(self.n, dtype=syndrome.dtype)
         self._require_supported()
-        dec, llr, it, cv = self._decode_numpy(vec[None, :], osd0=True)
+        dec, llr, it, cv = self._decode_osd(vec[None, :])
         self._log_prob_ratios = llr[0]
         self._iterations = int(it[0])
         self._converge = bool(cv[0])
@@ -106,7 +121,9 @@ class BpOsdDecoder(BpDecoderBase):
             self._bp_decoding = dec[0].copy()
             self._decoding = dec[0].copy()
         else:
-            self._osd0_decoding = dec[0].copy()
+            self._osdw_decoding = dec[0].copy()
+            self._osd0_decoding = None  # evaluated on demand (osd0_decoding) when the order is > 0
+            self._last_syndrome = vec.copy()
         return dec[0].astype(syndrome.dtype)
 
     def decode_batch(self, syndromes, want_log_prob_ratios: bool = True):
@@ -116,8 +133,10 @@ class BpOsdDecoder(BpDecoderBase):
         self._require_supported()
         from ldpc_amd.engine import _is_torch
         if _is_torch(syndromes):  # device tensors in, device tensors out (nothing crosses PCIe)
-            dec, llr, it, cv = self._get_engine().decode_batch(syndromes, want_llr=want_log_prob_ratios, osd0=True)
-            zero = ~syndromes.any(dim=1)
+            eng = self._get_engine()
+            eng.set_osd(self._osd_method, self._osd_order)
+            dec, llr, it, cv = eng.decode_batch(syndromes, want_llr=want_log_prob_ratios, osd=True)
+            zero = syndromes.any(dim=1).logical_not()
             if bool(zero.any()):
                 dec[zero] = 0
                 cv[zero] = 1
@@ -128,7 +147,7 @@ class BpOsdDecoder(BpDecoderBase):
             return dec
         dtype = syndromes.dtype
         vec = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
-        dec, llr, it, cv = self._decode_numpy(vec, want_llr=want_log_prob_ratios, osd0=True)
+        dec, llr, it, cv = self._decode_osd(vec, want_llr=want_log_prob_ratios)
         zero = ~vec.any(axis=1)
         dec[zero] = 0
         cv[zero] = True
@@ -147,11 +166,19 @@ class BpOsdDecoder(BpDecoderBase):
 
     @property
     def osd0_decoding(self) -> np.ndarray:
-        return np.array(self._bp_decoding if self._converge else self._osd0_decoding).astype(int)
+        if self._converge:
+            return np.array(self._bp_decoding).astype(int)
+        if self._osd0_decoding is None:
+            higher = self._osd_method in (EXHAUSTIVE, COMBINATION_SWEEP) and self._osd_order > 0
+            if not higher:  # order 0: osdw_decoding == osd0_decoding (osd.hpp:113)
+                self._osd0_decoding = self._osdw_decoding.copy()
+            else:  # the device returns the swept solution only; the OSD-0 one is recomputed when somebody asks
+                self._osd0_decoding = self._decode_osd(self._last_syndrome[None, :], want_llr=False, force_osd0=True)[0][0].copy()
+        return np.array(self._osd0_decoding).astype(int)
 
     @property
     def osdw_decoding(self) -> np.ndarray:
-        return self.osd0_decoding  # order 0: osdw_decoding == osd0_decoding (osd.hpp:113)
+        return np.array(self._bp_decoding if self._converge else self._osdw_decoding).astype(int)
 
     @property
     def decoding(self) -> np.ndarray:

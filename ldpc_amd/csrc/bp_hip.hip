@@ -1250,8 +1250,10 @@ struct OsdArgs {
     const uint8_t *synd;   // [batch][m]
     const double *llr;     // [batch][n]  BP posteriors
     const uint8_t *conv;   // [batch]     1 = BP converged: row left untouched
-    uint8_t *decoding;     // [batch][n]  in: BP decisions, out: OSD-0 solution for unconverged rows
+    uint8_t *decoding;     // [batch][n]  in: BP decisions, out: OSD solution for unconverged rows
     int32_t lds_per_wave;  // bytes
+    int32_t method, order; // osdw_kernel: 2 = exhaustive (OSD_E), 3 = combination sweep (OSD_CS); order > 0
+    const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
 };
 
 __device__ __forceinline__ bool osd_less(double a, int ia, double b, int ib) {
@@ -1331,6 +1333,174 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
         if (pivot_col[i] >= 0 && (mat[(size_t)i * W + sw] & sbit)) x[pivot_col[i]] = 1;
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = x[j];
+}
+
+// ---- higher-order OSD (osd.hpp:119-187): OSD_E / OSD_CS, one wavefront per unconverged syndrome ---------------
+// After the column sort the matrix is brought to REDUCED row echelon form over the sorted columns (no early
+// stop).  Then no candidate needs a solve of its own: flipping the non-pivot columns F changes the solution on
+// the pivot column of row r by XOR_{f in F} R[r][f] (R = the reduced matrix), so a candidate is the OSD-0
+// solution, a mask over the non-pivot columns, and one parity per pivot row.  Candidates are spread over the
+// lanes; each lane adds up its candidate's weight in ascending bit order exactly as the reference does
+// (sequential FP64 sum of log(1/p_j) over the support), and the first strictly lightest candidate wins.
+struct OsdCandidate {
+    uint64_t mask;  // chosen columns among the first 64 non-pivot columns (sorted order)
+    int32_t single; // a chosen non-pivot column beyond the first 64 (OSD_CS weight-one strings), else -1
+    bool valid;
+};
+
+__device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int k, long c) {
+    OsdCandidate r;
+    r.mask = 0;
+    r.single = -1;
+    r.valid = true;
+    const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    if (method == 2) {  // numbers 1 .. 2^order - 1, bit j -> j-th non-pivot column, bits >= k dropped (util.hpp:12-38)
+        r.mask = (uint64_t)(c + 1) & kmask;
+    } else if (c < k) {  // weight one, every non-pivot column (osd.hpp:84-89)
+        if (c < 64) r.mask = 1ull << c; else r.single = (int32_t)c;
+    } else {  // pairs (i, j), i < j < order, i-major (osd.hpp:91-99)
+        long p = c - k;
+        int i = 0;
+        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
+        const int j = i + 1 + (int)p;
+        if (j >= k) r.valid = false;  // past the candidate string in the reference
+        else r.mask = (1ull << i) | (1ull << j);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
+    const int m = a.m, n = a.n, W = a.words;
+    unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
+    volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                         // [m][W]
+    volatile uint64_t *T = mat + (size_t)m * W;                                                   // [m]
+    volatile double *keys = reinterpret_cast<volatile double *>(const_cast<uint64_t *>(T + m));   // [n] log-ratios, later weights
+    volatile int32_t *order = reinterpret_cast<volatile int32_t *>(const_cast<double *>(keys + n));  // [n]
+    volatile int32_t *code = order + n;       // [n] pivot column: its row; non-pivot column: -1 - position among the non-pivots
+    volatile int32_t *npcol = code + n;       // [n] non-pivot columns in sorted order
+    volatile int32_t *pivot_col = npcol + n;  // [m]
+
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int i = lane; i < m; i += 64) {
+        for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
+        for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+            const int c = a.col_idx[e];
+            mat[(size_t)i * W + (c >> 6)] = mat[(size_t)i * W + (c >> 6)] | (1ull << (c & 63));
+        }
+        if (a.synd[b * m + i]) mat[(size_t)i * W + sw] = mat[(size_t)i * W + sw] | sbit;
+        pivot_col[i] = -1;
+    }
+    for (int j = lane; j < n; j += 64) { keys[j] = a.llr[b * n + j]; code[j] = INT32_MIN; }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) {  // soft_decision_col_sort (sort.hpp:48-62)
+        const double ki = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += osd_less(keys[j], j, ki, i) ? 1 : 0;
+        order[r] = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // rref over the sorted columns (gf2sparse_linalg.hpp:132-226), rows fully reduced
+    const int max_rank = m < n ? m : n;
+    int rank = 0;
+    for (int t = 0; t < n && rank < max_rank; ++t) {
+        const int c = order[t];
+        const int cw = c >> 6;
+        const uint64_t cb = 1ull << (c & 63);
+        int p = -1;
+        for (int i0 = 0; i0 < m && p < 0; i0 += 64) {
+            const int i = i0 + lane;
+            const bool cand = i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + cw] & cb);
+            const uint64_t mask = __ballot(cand);
+            if (mask) p = i0 + __builtin_ctzll(mask);
+        }
+        if (p < 0) continue;
+        for (int i = lane; i < m; i += 64)
+            if (i != p && (mat[(size_t)i * W + cw] & cb))
+                for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = mat[(size_t)i * W + w] ^ mat[(size_t)p * W + w];
+        if (lane == 0) { pivot_col[p] = c; code[c] = p; }
+        ++rank;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
+    int k = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = t < n ? order[t] : 0;
+        const bool np = t < n && code[c] < 0;
+        const uint64_t mask = __ballot(np);
+        if (np) {
+            const int q = k + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            npcol[q] = c;
+            code[c] = -1 - q;
+        }
+        k += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int k64 = k < 64 ? k : 64;
+    for (int r = lane; r < m; r += 64) {  // the reduced matrix on the first 64 non-pivot columns, one word per row
+        uint64_t t = 0;
+        for (int q = 0; q < k64; ++q) {
+            const int c = npcol[q];
+            t |= ((mat[(size_t)r * W + (c >> 6)] >> (c & 63)) & 1ull) << q;
+        }
+        T[r] = t;
+    }
+    for (int j = lane; j < n; j += 64) keys[j] = a.wt[j];
+    __builtin_amdgcn_wave_barrier();
+
+    // weight of a candidate: sum over its support in ascending bit order (osd.hpp:171-176)
+    auto bit_of = [&](const OsdCandidate &cd, int i) -> bool {
+        const int cdi = code[i];
+        if (cdi >= 0) {
+            uint64_t v = (mat[(size_t)cdi * W + sw] >> (n & 63)) ^ (uint64_t)__builtin_popcountll(T[cdi] & cd.mask);
+            if (cd.single >= 0) {
+                const int c = npcol[cd.single];
+                v ^= mat[(size_t)cdi * W + (c >> 6)] >> (c & 63);
+            }
+            return (v & 1ull) != 0;
+        }
+        const int q = -1 - cdi;
+        return (q < 64 && ((cd.mask >> q) & 1ull)) || q == cd.single;
+    };
+    auto weight_of = [&](const OsdCandidate &cd) -> double {
+        double acc = 0;
+        for (int i = 0; i < n; ++i)
+            if (bit_of(cd, i)) acc += keys[i];
+        return acc;
+    };
+    OsdCandidate none;
+    none.mask = 0; none.single = -1; none.valid = true;
+    const double w0 = weight_of(none);  // the OSD-0 solution (osd.hpp:131-136)
+    const long ncand = a.method == 2 ? (1L << a.order) - 1 : (long)k + (long)a.order * (a.order - 1) / 2;
+    double best_w = w0;
+    long best_c = -1;
+    for (long c0 = 0; c0 < ncand; c0 += 64) {
+        const long c = c0 + lane;
+        if (c < ncand) {
+            const OsdCandidate cd = osd_candidate(a.method, a.order, k, c);
+            if (cd.valid) {
+                const double w = weight_of(cd);
+                if (w < best_w) { best_w = w; best_c = c; }  // strict: the first lightest candidate stays (osd.hpp:177)
+            }
+        }
+    }
+    // across lanes: lightest, then earliest
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ow = __shfl_xor(best_w, off);
+        const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
+        const bool mine_set = best_c >= 0, other_set = oc >= 0;
+        if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+    }
+    OsdCandidate win = none;
+    if (best_c >= 0) win = osd_candidate(a.method, a.order, k, best_c);
+    for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = bit_of(win, j) ? 1 : 0;
 }
 
 // GF2Sparse::mulvec over a batch (gf2sparse.hpp:177-214): one thread per (vector, check)
@@ -1435,6 +1605,8 @@ struct ldpc_hip_bp {
 
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
     double *d_llr0 = nullptr;
+    double *d_osd_wt = nullptr;  // [n] log(1 / p_j), the candidate weights of higher-order OSD
+    int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1453,6 +1625,8 @@ static int upload_priors(ldpc_hip_bp *h) {
     for (int j = 0; j < h->n; ++j)
         llr0[(size_t)j] = std::log((1 - h->channel_probs[(size_t)j]) / h->channel_probs[(size_t)j]);
     HIPCHK(hipMemcpy(h->d_llr0, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
+    for (int j = 0; j < h->n; ++j) llr0[(size_t)j] = std::log(1 / h->channel_probs[(size_t)j]);  // osd.hpp:134
+    HIPCHK(hipMemcpy(h->d_osd_wt, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1547,6 +1721,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     ALLOC_COPY(h->d_csc_edge, csc_edge.data(), d->nnz, int32_t);
     ALLOC_COPY(h->d_csc_row, csc_row.data(), d->nnz, int32_t);
     ALLOC_COPY(h->d_llr0, d->channel_probs, d->n, double);  // overwritten by upload_priors
+    ALLOC_COPY(h->d_osd_wt, d->channel_probs, d->n, double);  // likewise
 #undef ALLOC_COPY
     int rc = upload_priors(h);
     if (rc) { ldpc_hip_bp_destroy(h); return rc; }
@@ -1578,6 +1753,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->d_order) (void)hipFree(h->d_order);
     if (h->h_counters) (void)hipHostFree(h->h_counters);
     if (h->d_llr0) (void)hipFree(h->d_llr0);
+    if (h->d_osd_wt) (void)hipFree(h->d_osd_wt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -2050,8 +2226,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 
 
 // BP, then OSD-0 on the rows BP left unconverged; device pointers, on h->stream
-static int bposd0_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                         int32_t *iters, uint8_t *conv) {
+static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                        double *llr, int32_t *iters, uint8_t *conv) {
+    if (osd_method == 0)  // OSD_OFF: BpOsdDecoder still calls OsdDecoder::decode, which then has no LU object -- refuse instead
+        return fail(LDPC_HIP_ERR_INVALID, "osd_method is OSD_OFF");
+    const bool higher = osd_method >= 2 && osd_order > 0;  // osd_order == 0 takes the OSD-0 branch whatever the method (osd.hpp:114)
     const size_t B = (size_t)batch, n = (size_t)h->n;
     int rc;
     if (!llr) { if ((rc = h->osd_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; llr = (double *)h->osd_llr.p; }
@@ -2063,19 +2242,22 @@ static int bposd0_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     a.batch = batch;
     a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
     a.synd = synd; a.llr = llr; a.conv = conv; a.decoding = decoding;
-    size_t per_wave = (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
+    a.method = osd_method; a.order = osd_order; a.wt = h->d_osd_wt;
+    size_t per_wave = higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
+                             : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
     if (per_wave > 150u * 1024u)
         return fail(LDPC_HIP_ERR_UNSUPPORTED,
-                    "OSD-0 on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB available", per_wave);
+                    "OSD on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB available", per_wave);
     int waves = (int)((150u * 1024u) / per_wave);
     if (waves > 4) waves = 4;
     a.lds_per_wave = (int32_t)per_wave;
     const size_t dyn = per_wave * (size_t)waves;
-    if (dyn > 48u * 1024u)
-        HIPCHK(hipFuncSetAttribute((const void *)osd0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const void *fn = higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
+    if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const int64_t blocks = (batch + waves - 1) / waves;
-    hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
 }
@@ -2089,7 +2271,31 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int6
     if (batch == 0) return LDPC_HIP_OK;
     if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
     HIPCHK(hipSetDevice(h->device));
-    return bposd0_device(h, synd, batch, decoding, llr, iters, conv);
+    return bposd_device(h, 1, 0, synd, batch, decoding, llr, iters, conv);
+}
+
+int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (osd_method < 0 || osd_method > 3) return fail(LDPC_HIP_ERR_INVALID, "osd_method must be 0 (off), 1 (OSD_0), 2 (OSD_E) or 3 (OSD_CS)");
+    if (osd_order < 0) return fail(LDPC_HIP_ERR_INVALID, "osd_order must not be negative");  // _bposd_decoder.pyx:222-223
+    if (osd_method == 1 && osd_order != 0) return fail(LDPC_HIP_ERR_INVALID, "osd_method OSD_0 requires osd_order 0");  // pyx:225-226
+    if (osd_method == 2 && osd_order > 24)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_E with osd_order > 24 (more than 16 million candidates per syndrome) is not available");
+    if (osd_method == 3 && osd_order > 64)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_CS with osd_order > 64 is not available on the device");
+    h->osd_method = osd_method;
+    h->osd_order = osd_order;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bposd_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
+                                      uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
+    HIPCHK(hipSetDevice(h->device));
+    return bposd_device(h, h->osd_method, h->osd_order, synd, batch, decoding, llr, iters, conv);
 }
 
 int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
@@ -2103,20 +2309,26 @@ int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t 
     return decode_device(h, synd, batch, decoding, llr, iters, conv);
 }
 
-static int decode_batch_staged(ldpc_hip_bp *h, bool with_osd0, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+// osd: -1 BP only, 0 BP + OSD-0, 1 BP + the handle's osd_method / osd_order
+static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                double *llr, int32_t *iters, uint8_t *conv);
 
 int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                              double *llr, int32_t *iters, uint8_t *conv) {
-    return decode_batch_staged(h, false, synd, batch, decoding, llr, iters, conv);
+    return decode_batch_staged(h, -1, synd, batch, decoding, llr, iters, conv);
 }
 
 int ldpc_hip_bposd0_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                  double *llr, int32_t *iters, uint8_t *conv) {
-    return decode_batch_staged(h, true, synd, batch, decoding, llr, iters, conv);
+    return decode_batch_staged(h, 0, synd, batch, decoding, llr, iters, conv);
 }
 
-static int decode_batch_staged(ldpc_hip_bp *h, bool with_osd0, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                double *llr, int32_t *iters, uint8_t *conv) {
+    return decode_batch_staged(h, 1, synd, batch, decoding, llr, iters, conv);
+}
+
+static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                double *llr, int32_t *iters, uint8_t *conv) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
@@ -2143,8 +2355,8 @@ static int decode_batch_staged(ldpc_hip_bp *h, bool with_osd0, const uint8_t *sy
     if (h_it) { if ((rc = h->st_iters.ensure(B * 4))) return rc; d_it = (int32_t *)h->st_iters.p; }
     if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
 
-    if ((rc = with_osd0 ? bposd0_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv)
-                        : decode_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv))) return rc;
+    if ((rc = osd >= 0 ? bposd_device(h, osd ? h->osd_method : 1, osd ? h->osd_order : 0, d_synd, batch, d_dec, d_llr, d_it, d_cv)
+                       : decode_device(h, d_synd, batch, d_dec, d_llr, d_it, d_cv))) return rc;
 
     if (h_dec) HIPCHK(hipMemcpyAsync(decoding, d_dec, B * n, hipMemcpyDeviceToHost, h->stream));
     if (h_llr) HIPCHK(hipMemcpyAsync(llr, d_llr, B * n * 8, hipMemcpyDeviceToHost, h->stream));

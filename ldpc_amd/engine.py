@@ -101,6 +101,10 @@ class HipBpEngine:
         """Straggler hand-off of the streaming kernel: -1 automatic (default), 0 off, k = park when <= k tiles run."""
         _lib.check(self._lib.ldpc_hip_bp_set_handoff(self._h, int(threshold_tiles)))
 
+    def set_osd(self, osd_method, osd_order):
+        """OSD method / order for ``decode_batch(osd=True)``: 0 off, 1 OSD_0, 2 OSD_E, 3 OSD_CS (osd.hpp:18-23)."""
+        _lib.check(self._lib.ldpc_hip_bp_set_osd(self._h, int(osd_method), int(osd_order)))
+
     def set_small_code_kernel(self, mode):
         """On-chip kernel for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))
@@ -114,11 +118,12 @@ class HipBpEngine:
         return float(ms.value)
 
     # -- data path --------------------------------------------------------------------------------
-    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False):
+    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False, osd=False):
         """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
 
         ``osd0=True`` runs BP + OSD-0 (``ldpc_hip_bposd0_decode_batch``): ``decoding`` holds the OSD-0 solution for
-        rows BP left unconverged; llr / iterations / converge remain BP's.
+        rows BP left unconverged; llr / iterations / converge remain BP's.  ``osd=True`` does the same with the
+        method and order given to ``set_osd`` (``ldpc_hip_bposd_decode_batch``: OSD_0, OSD_E or OSD_CS).
 
         NumPy in -> NumPy out (host pointers); torch CUDA tensor in -> torch CUDA tensors out.
         ``out`` may carry preallocated torch outputs ``(decoding, llr, iterations, converge)``.
@@ -139,7 +144,9 @@ class HipBpEngine:
                 llr = torch.empty((b, self.n), dtype=torch.float64, device=s.device) if want_llr else None
                 it = torch.empty((b,), dtype=torch.int32, device=s.device)
                 cv = torch.empty((b,), dtype=torch.uint8, device=s.device)
-            if osd0:
+            if osd:
+                fn = self._lib.ldpc_hip_bposd_decode_batch_async if asynchronous else self._lib.ldpc_hip_bposd_decode_batch
+            elif osd0:
                 fn = self._lib.ldpc_hip_bposd0_decode_batch_async if asynchronous else self._lib.ldpc_hip_bposd0_decode_batch
             else:
                 fn = self._lib.ldpc_hip_bp_decode_batch_async if asynchronous else self._lib.ldpc_hip_bp_decode_batch
@@ -154,7 +161,8 @@ class HipBpEngine:
         llr = np.zeros((b, self.n), np.float64) if want_llr else None
         it = np.zeros(b, np.int32)
         cv = np.zeros(b, np.uint8)
-        fn = self._lib.ldpc_hip_bposd0_decode_batch if osd0 else self._lib.ldpc_hip_bp_decode_batch
+        fn = (self._lib.ldpc_hip_bposd_decode_batch if osd else
+              self._lib.ldpc_hip_bposd0_decode_batch if osd0 else self._lib.ldpc_hip_bp_decode_batch)
         _lib.check(fn(self._h, s.ctypes.data, b, dec.ctypes.data, llr.ctypes.data if want_llr else None,
                       it.ctypes.data, cv.ctypes.data))
         return dec, llr, it, cv.astype(bool)

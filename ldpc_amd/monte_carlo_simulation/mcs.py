@@ -86,7 +86,7 @@ class MonteCarloBscSimulation:
         device = torch.device("cuda", eng.device if eng.device >= 0 else torch.cuda.current_device())
         syndromes, errors = eng.gen_bsc_syndromes(seed, self.error_rate, shot0, shots, device=device, want_errors=True)
         decodings = self.Decoder.decode_batch(syndromes)
-        return int(torch.count_nonzero((decodings != errors).any(dim=1)).item())
+        return int(torch.count_nonzero((decodings != errors).any(dim=1).bool()).item())
 
     def run(self) -> Dict:
         """Runs ``run_count + 1 .. target_run_count`` (mcs.py:104-150), ``batch_size`` runs per launch."""

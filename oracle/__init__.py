@@ -91,6 +91,10 @@ class _OracleLib:
                 C.c_void_p, _i32p, _u8p]
             lib.osd0_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _u8p]
             lib.bposd0_oracle_decode_batch.argtypes = lib.bp_oracle_decode_batch.argtypes
+            lib.osdw_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _f64p, C.c_int, C.c_int, _u8p, C.c_void_p]
+            lib.bposdw_oracle_decode_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _u8p, C.c_int64, _u8p,
+                C.c_void_p, _i32p, _u8p]
             lib.oracle_sm64.restype = C.c_uint64
             lib.oracle_sm64.argtypes = [C.c_uint64, C.c_uint64]
             cls._lib = lib
@@ -163,6 +167,30 @@ class BpOracle:
         conv = np.zeros(b, np.uint8)
         self.lib.bposd0_oracle_decode_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b,
                                             dec, llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def osdw(self, syndrome, llr, osd_method, osd_order, channel_probs=None):
+        """OSD of any order alone (osd.hpp:103-187 restated): ``osd_method`` 1 OSD_0, 2 OSD_E, 3 OSD_CS.
+        Returns (osdw_decoding, osd0_decoding)."""
+        out = np.zeros(self.n, np.uint8)
+        out0 = np.zeros(self.n, np.uint8)
+        probs = self.channel_probs if channel_probs is None else np.ascontiguousarray(channel_probs, np.float64)
+        self.lib.osdw_oracle(self.m, self.n, self.row_ptr, self.col_idx, np.ascontiguousarray(llr, np.float64),
+                             np.ascontiguousarray(syndrome, np.uint8), probs, int(osd_method), int(osd_order), out,
+                             out0.ctypes.data)
+        return out, out0
+
+    def bposd_decode_batch(self, syndromes, osd_method, osd_order, want_llr=True):
+        """BpOsdDecoder.decode per row with any OSD method / order."""
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.bposdw_oracle_decode_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha,
+                                            int(osd_method), int(osd_order), s, b, dec,
+                                            llr.ctypes.data if want_llr else None, it, conv)
         return dec, llr, it, conv.astype(bool)
 
     def gen_bsc_syndromes(self, seed, p, shot0, shots, want_errors=False):
@@ -238,10 +266,13 @@ class RefBp:
 class RefBpOsd:
     """The real reference BP + ``ldpc::osd::OsdDecoder`` (OSD_0) behind oracle/ref_harness.cpp."""
 
-    def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum", ms_scaling_factor=1.0):
+    def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum", ms_scaling_factor=1.0,
+                 osd_method=1, osd_order=0):
         if not have_ref():
             raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
         lib = C.CDLL(REF_SO)
+        lib.ref_bposd_set_osd.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.ref_bposd_k.argtypes = [C.c_void_p]
         lib.ref_bposd_new.restype = C.c_void_p
         lib.ref_bposd_new.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_double]
         lib.ref_bposd_free.argtypes = [C.c_void_p]
@@ -254,6 +285,9 @@ class RefBpOsd:
         self.max_iter = int(max_iter) if max_iter else self.n
         self._h = lib.ref_bposd_new(self.m, self.n, len(col_idx), np.ascontiguousarray(rows), col_idx, self.channel_probs,
                                     self.max_iter, _method_id(bp_method), float(ms_scaling_factor))
+        if (int(osd_method), int(osd_order)) != (1, 0):
+            lib.ref_bposd_set_osd(self._h, int(osd_method), int(osd_order))
+        self.k = int(lib.ref_bposd_k(self._h))
 
     def __del__(self):
         if getattr(self, "_h", None):

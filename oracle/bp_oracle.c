@@ -296,6 +296,144 @@ void osd0_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, c
     free(a); free(order); free(pivot_col);
 }
 
+/* ============================================================================================== *
+ * Higher-order OSD: ldpc::osd::OsdDecoder::decode with osd_order > 0 (src_cpp/osd.hpp:119-187), for
+ * osd_method EXHAUSTIVE (2, "OSD_E") and COMBINATION_SWEEP (3, "OSD_CS").  Restated literally:
+ *   1. column order by log-ratio as for OSD-0 (sort.hpp:48-62);
+ *   2. rref over that order (gf2sparse_linalg.hpp:132-226): greedy pivot columns; `cols` afterwards lists
+ *      the pivot columns, then the NON-pivot columns, each group in sorted order (:210-224);
+ *   3. OSD-0 solution = lu_solve(syndrome), weight = sum_i x_i log(1 / p_i) in ascending i (osd.hpp:131-136);
+ *   4. candidate strings over the k = n - rank non-pivot columns (osd.hpp:75-101): OSD_E the numbers
+ *      1 .. 2^order - 1, bit j -> j-th non-pivot column (util.hpp:12-38, bits >= k dropped); OSD_CS the k
+ *      weight-one strings, then the pairs (i, j), i < j < order, i-major;
+ *   5. per candidate: flip the syndrome by the chosen non-pivot columns, solve on the pivot columns, set the
+ *      chosen bits, weigh; keep it if STRICTLY lighter (osd.hpp:156-183).
+ * The elimination is dense Gauss-Jordan on [H | I_m]: the right block E records the row operations, so the
+ * solve of step 5 is y = E t and x[pivot_col[r]] = y[r] (equal to the reference's forward/back substitution
+ * whenever t lies in the image of H; like OSD-0 this restatement requires that).
+ * OSD_CS with osd_order > k writes past the candidate string in the reference (osd.hpp:92-96, undefined
+ * behaviour); here such pairs are skipped.
+ * ============================================================================================== */
+void osdw_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                 const uint8_t *syndrome, const double *channel_probs, int osd_method, int osd_order,
+                 uint8_t *decoding, uint8_t *osd0_decoding) {
+    if (osd_order <= 0 || osd_method < 2) {
+        osd0_oracle(m, n, row_ptr, col_idx, llr, syndrome, decoding);
+        if (osd0_decoding) memcpy(osd0_decoding, decoding, (size_t)n);
+        return;
+    }
+    const int hw = (n + 63) / 64, ew = (m + 63) / 64, words = hw + ew;
+    uint64_t *a = (uint64_t *)calloc((size_t)(m ? m : 1) * words, sizeof(uint64_t));  /* [H | I] */
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    int *pivot_col = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    uint8_t *is_pivot = (uint8_t *)calloc((size_t)(n ? n : 1), 1);
+    for (int i = 0; i < m; i++) {
+        pivot_col[i] = -1;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) a[(size_t)i * words + col_idx[e] / 64] |= 1ull << (col_idx[e] % 64);
+        a[(size_t)i * words + hw + i / 64] |= 1ull << (i % 64);
+    }
+    for (int i = 0; i < n; i++) {
+        int r = 0;
+        for (int j = 0; j < n; j++) r += osd_less(llr[j], j, llr[i], i);
+        order[r] = i;
+    }
+    int rank = 0;
+    const int max_rank = m < n ? m : n;
+    for (int t = 0; t < n && rank < max_rank; t++) {
+        const int c = order[t];
+        int p = -1;
+        for (int i = 0; i < m; i++)
+            if (pivot_col[i] < 0 && ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1)) { p = i; break; }
+        if (p < 0) continue;
+        for (int i = 0; i < m; i++)
+            if (i != p && ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1))
+                for (int w = 0; w < words; w++) a[(size_t)i * words + w] ^= a[(size_t)p * words + w];
+        pivot_col[p] = c;
+        is_pivot[c] = 1;
+        rank++;
+    }
+    const int k = n - rank;
+    int *non_pivot = (int *)malloc(sizeof(int) * (size_t)(k ? k : 1));
+    for (int t = 0, q = 0; t < n; t++)
+        if (!is_pivot[order[t]]) non_pivot[q++] = order[t];
+
+    uint8_t *t_syn = (uint8_t *)malloc((size_t)(m ? m : 1));
+    uint8_t *cand = (uint8_t *)malloc((size_t)(n ? n : 1));
+    uint8_t *string = (uint8_t *)calloc((size_t)(k ? k : 1), 1);
+#define OSDW_SOLVE(out)                                                                          \
+    do {                                                                                         \
+        memset((out), 0, (size_t)n);                                                             \
+        for (int r_ = 0; r_ < m; r_++) {                                                         \
+            if (pivot_col[r_] < 0) continue;                                                     \
+            int y_ = 0;                                                                          \
+            for (int i_ = 0; i_ < m; i_++)                                                       \
+                if (t_syn[i_] && ((a[(size_t)r_ * words + hw + i_ / 64] >> (i_ % 64)) & 1)) y_ ^= 1; \
+            (out)[pivot_col[r_]] = (uint8_t)y_;                                                  \
+        }                                                                                        \
+    } while (0)
+    for (int i = 0; i < m; i++) t_syn[i] = syndrome[i] ? 1 : 0;
+    OSDW_SOLVE(decoding);
+    if (osd0_decoding) memcpy(osd0_decoding, decoding, (size_t)n);
+    double min_weight = 0;
+    for (int i = 0; i < n; i++)
+        if (decoding[i] == 1) min_weight += log(1 / channel_probs[i]);
+
+    const long n_exh = osd_method == 2 ? (1L << osd_order) - 1 : 0;
+    const long n_single = osd_method == 3 ? k : 0;
+    const long n_pair = osd_method == 3 ? (long)osd_order * (osd_order - 1) / 2 : 0;
+    long pi = 0, pj = 0;  /* next pair */
+    for (long c = 0; c < n_exh + n_single + n_pair; c++) {
+        memset(string, 0, (size_t)k);
+        if (osd_method == 2) {
+            for (int j = 0; j < k && j < 31; j++) string[j] = (uint8_t)(((c + 1) >> j) & 1);
+        } else if (c < n_single) {
+            string[c] = 1;
+        } else {
+            if (c == n_single) { pi = 0; pj = 1; }
+            while (pj >= osd_order) { pi++; pj = pi + 1; }
+            const long i0 = pi, j0 = pj;
+            pj++;
+            if (j0 >= k) continue;  /* out of range in the reference (see header) */
+            string[i0] = 1;
+            string[j0] = 1;
+        }
+        for (int i = 0; i < m; i++) t_syn[i] = syndrome[i] ? 1 : 0;
+        for (int q = 0; q < k; q++)
+            if (string[q])
+                for (int i = 0; i < m; i++)  /* column non_pivot[q] of H */
+                    for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++)
+                        if (col_idx[e] == non_pivot[q]) t_syn[i] ^= 1;
+        OSDW_SOLVE(cand);
+        for (int q = 0; q < k; q++) cand[non_pivot[q]] = string[q];
+        double w = 0;
+        for (int i = 0; i < n; i++)
+            if (cand[i] == 1) w += log(1 / channel_probs[i]);
+        if (w < min_weight) {
+            min_weight = w;
+            memcpy(decoding, cand, (size_t)n);
+        }
+    }
+#undef OSDW_SOLVE
+    free(a); free(order); free(pivot_col); free(is_pivot); free(non_pivot); free(t_syn); free(cand); free(string);
+}
+
+/* BpOsdDecoder.decode over a batch with any osd_method / osd_order (_bposd_decoder.pyx:125-134) */
+void bposdw_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                                double ms_scaling_factor, int osd_method, int osd_order, const uint8_t *syndromes,
+                                int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    double *tmp = llr ? NULL : (double *)malloc(sizeof(double) * (size_t)(o->n ? o->n : 1));
+    for (int64_t b = 0; b < shots; b++) {
+        double *l = llr ? llr + b * o->n : tmp;
+        iterations[b] = 0;
+        bp_oracle_decode(o, channel_probs, max_iter, bp_method, ms_scaling_factor, syndromes + b * o->m,
+                         decodings + b * o->n, l, iterations + b, converge + b);
+        if (!converge[b])
+            osdw_oracle(o->m, o->n, o->row_ptr, o->col_idx, l, syndromes + b * o->m, channel_probs, osd_method, osd_order,
+                        decodings + b * o->n, NULL);
+    }
+    free(tmp);
+}
+
 /* BpOsdDecoder.decode over a batch (_bposd_decoder.pyx:125-134): BP; rows that did not converge get OSD-0 */
 void bposd0_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
                                 double ms_scaling_factor, const uint8_t *syndromes, int64_t shots,

@@ -130,7 +130,19 @@ void ref_bposd_decode_batch(ref_bposd *r, const uint8_t *syndromes, int64_t shot
     }
 }
 
-/* OsdDecoder::decode alone (osd.hpp:110-117) on caller-supplied log-ratios */
+/* osd_method / osd_order as BpOsdDecoder's setters write them, followed by osd_setup() (_bposd_decoder.pyx:64-70):
+ * 1 = OSD_0, 2 = EXHAUSTIVE (OSD_E), 3 = COMBINATION_SWEEP (OSD_CS); osd.hpp:18-23, 59-101 */
+void ref_bposd_set_osd(ref_bposd *r, int osd_method, int osd_order) {
+    delete r->osd->LuDecomposition;
+    r->osd->LuDecomposition = nullptr;
+    r->osd->osd_method = static_cast<ldpc::osd::OsdMethod>(osd_method);
+    r->osd->osd_order = osd_order;
+    r->osd->osd_setup();
+}
+
+int ref_bposd_k(ref_bposd *r) { return r->osd->k; }
+
+/* OsdDecoder::decode alone (osd.hpp:110-191) on caller-supplied log-ratios */
 void ref_osd0(ref_bposd *r, const uint8_t *syndrome, const double *llr, uint8_t *decoding) {
     const int m = r->bp->dec->check_count, n = r->bp->dec->bit_count;
     std::vector<uint8_t> s(syndrome, syndrome + m);

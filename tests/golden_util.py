@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def case_names(prefix: str = ""):
     """BP fixtures (``decoding`` = BpDecoder output).  BP+OSD-0 fixtures are listed by ``osd_case_names``."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith(("osd_", "serial_", "mcs_"))]
+    return [n for n in names if not n.startswith(("osd_", "osdw_", "serial_", "mcs_"))]
 
 
 def serial_case_names():
@@ -25,6 +25,12 @@ def serial_case_names():
 def osd_case_names():
     """Fixtures whose ``decoding`` is BpOsdDecoder's (OSD_0) output; converge/iterations are BP's."""
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "osd_*.npz")))
+
+
+def osdw_case_names():
+    """Fixtures of BpOsdDecoder with osd_method OSD_E / OSD_CS and osd_order > 0 (``osd_method``, ``osd_order``,
+    ``osd0_decoding`` stored besides the usual fields; ``decoding`` is the swept solution)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "osdw_*.npz")))
 
 
 def _h_from_recipe(recipe: str):
@@ -73,6 +79,9 @@ def load_case(name: str) -> dict:
         decoding=dec, converge=z["converge"].astype(bool), iterations=z["iterations"].astype(np.int32),
         llr=z["llr"], llr_rowsum=z["llr_rowsum"], note=str(z["note"]),
         order=(z["order"].astype(np.int32) if "order" in z.files and z["order"].size else None),
+        osd_method=int(z["osd_method"]) if "osd_method" in z.files else 1,
+        osd_order=int(z["osd_order"]) if "osd_order" in z.files else 0,
+        osd0_decoding=np.unpackbits(z["osd0_decoding"], axis=1, count=n) if "osd0_decoding" in z.files else None,
     )
 
 

@@ -399,9 +399,73 @@ def test_bposd_decoder_api():
     with pytest.raises(ValueError):
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_0", osd_order=3)
     with pytest.raises(NotImplementedError):
-        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_cs", osd_order=4).decode(c["syndromes"][k])
+        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_cs", osd_order=65).decode(c["syndromes"][k])
+    with pytest.raises(NotImplementedError):
+        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_e", osd_order=25).decode(c["syndromes"][k])
     with pytest.raises(ValueError):
         d.decode(np.zeros(3, np.uint8))
+
+
+# ---- higher-order OSD (osd.hpp:119-187) ------------------------------------------
+
+from golden_util import osdw_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", osdw_case_names())
+def test_bposdw_golden_fixture(name):
+    """BpOsdDecoder with OSD_E / OSD_CS captured from the real reference vs ldpc_hip_bposd_decode_batch."""
+    c = load_case(name)
+    eng = _engine(c)
+    eng.set_osd(c["osd_method"], c["osd_order"])
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"], osd=True)
+    assert np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    bad = np.flatnonzero((dec != c["decoding"]).any(axis=1))
+    assert bad.size == 0, f"{bad.size} rows differ from the reference's swept solution (first {bad[:5]})"
+    eng.set_osd(c["osd_method"], 0)  # order 0 takes the OSD-0 branch whatever the method (osd.hpp:114)
+    assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"])
+    eng.set_osd(1, 0)
+    assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"])
+
+
+def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
+    """Config-5 code, OSD_CS order 10 (the setting most BP+OSD papers use), B = 4096 device resident vs the CPU oracle."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    eng = HipBpEngine(h.indptr, h.indices, 144, np.full(144, 0.06), 30, 0, 1.0)
+    eng.set_osd(3, 10)
+    s = eng.gen_bsc_syndromes(7, 0.06, shot0=0, shots=4096, device="cuda:0")
+    dec, llr, it, cv = eng.decode_batch(s, osd=True)
+    d, sh = dec.cpu().numpy(), s.cpu().numpy()
+    assert np.array_equal((d.astype(np.int64) @ h.T.toarray().astype(np.int64)) % 2, sh)
+    want, _, wi, wc = oracle_built.BpOracle(h, error_rate=0.06, max_iter=30).bposd_decode_batch(sh[:768], 3, 10)
+    assert np.array_equal(d[:768], want) and np.array_equal(cv.cpu().numpy()[:768].astype(bool), wc)
+    with pytest.raises(Exception, match="osd_order"):
+        eng.set_osd(3, 65)
+    with pytest.raises(Exception, match="OSD_0"):
+        eng.set_osd(1, 2)
+
+
+@pytest.mark.parametrize("backend", ["cython", "ctypes"])
+def test_bposd_decoder_api_higher_order(backend):
+    from ldpc_amd.bposd_decoder import BpOsdDecoder
+    c = load_case("osdw_cs10_bb144_ps8")
+    d = BpOsdDecoder(c["h"], error_rate=0.08, max_iter=8, bp_method="product_sum", osd_method="osd_cs", osd_order=10,
+                     _backend=backend)
+    assert d.osd_method == "OSD_CS" and d.osd_order == 10
+    rows = np.flatnonzero((c["decoding"] != c["osd0_decoding"]).any(axis=1))[:3]
+    for k in rows:
+        out = d.decode(c["syndromes"][k])
+        assert np.array_equal(out, c["decoding"][k]) and d.converge is False
+        assert np.array_equal(d.osdw_decoding, c["decoding"][k])
+        assert np.array_equal(d.osd0_decoding, c["osd0_decoding"][k])
+    batch = d.decode_batch(c["syndromes"])
+    nz = c["syndromes"].any(axis=1)
+    assert np.array_equal(batch[nz], c["decoding"][nz])
+    d.osd_method = "osd_e"
+    d.osd_order = 8
+    e = load_case("osdw_e8_bb144_ps8")
+    assert np.array_equal(d.decode_batch(e["syndromes"])[e["syndromes"].any(axis=1)], e["decoding"][e["syndromes"].any(axis=1)])
 
 
 @pytest.mark.parametrize("name", ["c5_bb144_ps50_p050", "c5_bb144_ms50_p050", "c3_surface21_ms30_p050", "surface5_ps30",
@@ -546,3 +610,23 @@ def test_single_syndrome_latency_path_matches_golden():
         assert np.array_equal(dec[0], c["decoding"][k]) and int(it[0]) == int(c["iterations"][k])
         if k < len(c["llr"]):
             assert bits_equal(llr[0], c["llr"][k])
+
+
+def test_bpdecoder_decode_batch_device_tensors():
+    """decode_batch on torch CUDA tensors (syndromes and received vectors), including the all-zero shortcut rows."""
+    import torch
+    from ldpc_amd.bp_decoder import BpDecoder
+    c = load_case("c1_hamming5_ps20")
+    d = BpDecoder(c["h"], error_channel=c["channel_probs"], max_iter=c["max_iter"], bp_method=c["bp_method"])
+    s = np.concatenate([c["syndromes"], np.zeros((3, c["m"]), np.uint8)])
+    want = d.decode_batch(s)
+    st = torch.from_numpy(s).cuda()
+    got = d.decode_batch(st)
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+    assert bool(d.converge_batch[-3:].all()) and int(d.iter_batch[-3:].abs().sum()) == 0
+    assert float(d.log_prob_ratios_batch[-3:].abs().sum()) == 0.0
+    rng = np.random.default_rng(4)
+    r = (rng.random((40, c["n"])) < 0.04).astype(np.uint8)
+    r[5] = 0
+    drv = BpDecoder(c["h"], error_rate=0.04, max_iter=20, input_vector_type="received_vector")
+    assert np.array_equal(drv.decode_batch(torch.from_numpy(r).cuda()).cpu().numpy(), drv.decode_batch(r))
