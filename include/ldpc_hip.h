@@ -156,6 +156,22 @@ int ldpc_hip_bposd_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, 
                                       uint8_t *converge);
 
 /*
+ * Bit-packed shot data in, bit-packed predictions out: replaces the per-shot loop of the reference's sinter decoders
+ * (sinter_decoders/sinter_bposd_decoder.py:115-130, sinter_belief_find_decoder.py; `decode_via_files` reads detection
+ * events and writes observable predictions in stim's "b8" format: bit i of a shot is bit i % 8 of its byte i / 8, every
+ * shot starts on a byte boundary).
+ * ldpc_hip_bp_set_observables uploads the k x n observables matrix L (CSR, as `matrices.observables_matrix`).
+ * ldpc_hip_bp_decode_b8: dets_b8 [batch][ceil(m/8)] -> decode every shot (BP; with_osd != 0: BP + the handle's OSD
+ * method, see ldpc_hip_bp_set_osd) -> obs_b8 [batch][ceil(k/8)] = L x mod 2 (`(observables_matrix @ corr) % 2`) and/or
+ * decoding_b8 [batch][ceil(n/8)] = x.  Either output may be NULL; iterations / converge as for decode_batch (NULL
+ * allowed).  All-zero shots yield the zero correction, converge 1, iterations 0 (the Python-level shortcut,
+ * _bposd_decoder.pyx:118-123).  Host or device pointers.
+ */
+int ldpc_hip_bp_set_observables(ldpc_hip_bp *h, int32_t k, const int32_t *csr_row_ptr, const int32_t *csr_col_idx);
+int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch, int32_t with_osd, uint8_t *obs_b8,
+                          uint8_t *decoding_b8, int32_t *iterations, uint8_t *converge);
+
+/*
  * replaces: GF2Sparse::mulvec (gf2sparse.hpp:177-214) over a batch:
  * out[b][i] = XOR_{j in row i} in[b][j].  Used by received-vector mode (bp.hpp:162-180).
  */

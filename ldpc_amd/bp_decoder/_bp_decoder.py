@@ -35,6 +35,18 @@ _MS_ALIASES = ("min_sum", "minimum_sum", "ms", "1", "minimum sum", "min sum")  #
 _UNSET = object()  # "keyword not passed by the caller"
 
 
+def _bp_method_code(value) -> int:
+    """The alias table of the ``bp_method`` setter (pyx:384-394) as a function."""
+    key = str(value).lower()
+    if key in _PS_ALIASES:
+        return PRODUCT_SUM
+    if key in _MS_ALIASES:
+        return MINIMUM_SUM
+    raise ValueError(f"BP method '{value}' is invalid. \
+                    Please choose from the following methods: \
+                    'product_sum', 'minimum_sum'")
+
+
 def _check_pcm_type(pcm):
     if not isinstance(pcm, (np.ndarray, scipy.sparse.spmatrix)):  # pyx:17-21, 113-117
         raise TypeError(f"The input matrix is of an invalid type. Please input\
@@ -226,15 +238,7 @@ class BpDecoderBase:
 
     @bp_method.setter
     def bp_method(self, value: Union[str, int]) -> None:
-        key = str(value).lower()
-        if key in _PS_ALIASES:
-            self._bp_method = PRODUCT_SUM
-        elif key in _MS_ALIASES:
-            self._bp_method = MINIMUM_SUM
-        else:
-            raise ValueError(f"BP method '{value}' is invalid. \
-                    Please choose from the following methods: \
-                    'product_sum', 'minimum_sum'")
+        self._bp_method = _bp_method_code(value)
 
     @property
     def schedule(self) -> str:

@@ -1516,6 +1516,65 @@ __global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
     out[t] = s;
 }
 
+// ---- bit-packed shot data ("b8": bit i of a shot is bit i % 8 of its byte i / 8; every shot starts on a byte) --
+// the wire format of the reference's sinter decoders (sinter_decoders/sinter_bposd_decoder.py:57-130)
+__global__ void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * bits) return;
+    const int64_t b = t / bits;
+    const int i = (int)(t - b * bits);
+    out[t] = (in[b * ((bits + 7) >> 3) + (i >> 3)] >> (i & 7)) & 1;
+}
+
+__global__ void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+    const int nb = (bits + 7) >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * nb) return;
+    const int64_t b = t / nb;
+    const int byte = (int)(t - b * nb);
+    uint8_t v = 0;
+    for (int q = 0; q < 8 && byte * 8 + q < bits; ++q) v |= (uint8_t)((in[b * bits + byte * 8 + q] & 1) << q);
+    out[t] = v;
+}
+
+// BpDecoder.decode / BpOsdDecoder.decode return the zero vector for an all-zero input without running BP
+// (_bp_decoder.pyx:679-681, _bposd_decoder.pyx:118-123): converge = True, iterations reported as 0 by the batch API
+__global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, int64_t batch, int m, int n, uint8_t *dec,
+                                          int32_t *iters, uint8_t *conv) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int mb = (m + 7) >> 3;
+    uint8_t any = 0;
+    for (int q = 0; q < mb; ++q) {
+        uint8_t v = dets_b8[b * mb + q];
+        if (q == mb - 1 && (m & 7)) v &= (uint8_t)((1u << (m & 7)) - 1u);  // padding bits carry no data
+        any |= v;
+    }
+    if (any) return;
+    for (int j = 0; j < n; ++j) dec[b * n + j] = 0;
+    if (iters) iters[b] = 0;
+    if (conv) conv[b] = 1;
+}
+
+// predicted observables L x (mod 2) of every decoding, bit-packed: one thread per (shot, output byte)
+// (SinterBpOsdDecoder.decode: `(observables_matrix @ corr) % 2`, sinter_bposd_decoder.py:128-130)
+__global__ void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx, int k, int n,
+                                      const uint8_t *__restrict__ dec, int64_t batch, uint8_t *__restrict__ out) {
+    const int nb = (k + 7) >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * nb) return;
+    const int64_t b = t / nb;
+    const int byte = (int)(t - b * nb);
+    uint8_t v = 0;
+    for (int q = 0; q < 8 && byte * 8 + q < k; ++q) {
+        const int o = byte * 8 + q;
+        uint8_t s = 0;
+        for (int e = row_ptr[o]; e < row_ptr[o + 1]; ++e) s ^= dec[b * n + col_idx[e]];
+        v |= (uint8_t)((s & 1) << q);
+    }
+    out[t] = v;
+}
+
 // synthetic BSC shots: syndrome[b][i] = XOR_{j in row i} bernoulli(seed, (shot0+b)*n + j)
 __global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
                                          const int32_t *__restrict__ col_idx, int m, int n,
@@ -1616,6 +1675,8 @@ struct ldpc_hip_bp {
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
+    int32_t obs_k = -1;                                              // rows of the observables matrix (-1: not set)
     int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
 };
 
@@ -1743,6 +1804,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
                          &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter,
+                         &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
@@ -2388,6 +2450,79 @@ int ldpc_hip_gf2_mulvec_batch(ldpc_hip_bp *h, const uint8_t *vectors, int64_t ba
                        h->d_row_ptr, h->d_col_idx, h->m, h->n, d_in, batch, d_out);
     HIPCHK(hipGetLastError());
     if (h_out) HIPCHK(hipMemcpyAsync(out, d_out, B * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_observables(ldpc_hip_bp *h, int32_t k, const int32_t *csr_row_ptr, const int32_t *csr_col_idx) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (k < 0 || !csr_row_ptr) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: k < 0 or null row pointer");
+    if (csr_row_ptr[0] != 0) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: csr_row_ptr[0] must be 0");
+    for (int i = 0; i < k; ++i)
+        if (csr_row_ptr[i + 1] < csr_row_ptr[i]) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: csr_row_ptr must not decrease");
+    const int32_t nnz = csr_row_ptr[k];
+    if (nnz > 0 && !csr_col_idx) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: null column indices");
+    for (int e = 0; e < nnz; ++e)
+        if (csr_col_idx[e] < 0 || csr_col_idx[e] >= h->n) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: column index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int rc;
+    if ((rc = h->obs_row_ptr.ensure(sizeof(int32_t) * (size_t)(k + 1)))) return rc;
+    if ((rc = h->obs_col_idx.ensure(sizeof(int32_t) * (size_t)(nnz ? nnz : 1)))) return rc;
+    HIPCHK(hipMemcpy(h->obs_row_ptr.p, csr_row_ptr, sizeof(int32_t) * (size_t)(k + 1), hipMemcpyHostToDevice));
+    if (nnz) HIPCHK(hipMemcpy(h->obs_col_idx.p, csr_col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+    h->obs_k = k;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch, int32_t with_osd, uint8_t *obs_b8,
+                          uint8_t *decoding_b8, int32_t *iters, uint8_t *conv) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!dets_b8) return fail(LDPC_HIP_ERR_INVALID, "null detection-event buffer");
+    if (!obs_b8 && !decoding_b8) return fail(LDPC_HIP_ERR_INVALID, "neither obs_b8 nor decoding_b8 requested");
+    if (obs_b8 && h->obs_k < 0) return fail(LDPC_HIP_ERR_INVALID, "obs_b8 requested but ldpc_hip_bp_set_observables was never called");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = (size_t)batch, m = (size_t)h->m, n = (size_t)h->n;
+    const size_t mb = (m + 7) / 8, nb = (n + 7) / 8, kb = obs_b8 ? ((size_t)h->obs_k + 7) / 8 : 0;
+    int rc;
+    const uint8_t *d_in = dets_b8;
+    if (!is_device_ptr(dets_b8)) {
+        if ((rc = h->b8_in.ensure(B * mb ? B * mb : 1))) return rc;
+        HIPCHK(hipMemcpyAsync(h->b8_in.p, dets_b8, B * mb, hipMemcpyHostToDevice, h->stream));
+        d_in = (const uint8_t *)h->b8_in.p;
+    }
+    if ((rc = h->b8_synd.ensure(B * m ? B * m : 1))) return rc;
+    if ((rc = h->b8_dec.ensure(B * n ? B * n : 1))) return rc;
+    uint8_t *d_synd = (uint8_t *)h->b8_synd.p, *d_dec = (uint8_t *)h->b8_dec.p;
+    if (m) hipLaunchKernelGGL(unpack_b8_kernel, dim3((unsigned)((B * m + 255) / 256)), dim3(256), 0, h->stream, d_in, batch, h->m, d_synd);
+    HIPCHK(hipGetLastError());
+    const bool h_it = iters && !is_device_ptr(iters), h_cv = conv && !is_device_ptr(conv);
+    int32_t *d_it = iters;
+    uint8_t *d_cv = conv;
+    if (h_it) { if ((rc = h->st_iters.ensure(B * 4))) return rc; d_it = (int32_t *)h->st_iters.p; }
+    if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
+    if ((rc = with_osd ? bposd_device(h, h->osd_method, h->osd_order, d_synd, batch, d_dec, nullptr, d_it, d_cv)
+                       : decode_device(h, d_synd, batch, d_dec, nullptr, d_it, d_cv))) return rc;
+    hipLaunchKernelGGL(zero_shot_shortcut_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, d_in, batch, h->m, h->n,
+                       d_dec, d_it, d_cv);
+    size_t off = 0;
+    if ((rc = h->b8_out.ensure(B * (kb + nb) ? B * (kb + nb) : 1))) return rc;
+    uint8_t *d_obs = obs_b8, *d_dec8 = decoding_b8;
+    const bool h_obs = obs_b8 && !is_device_ptr(obs_b8), h_dec8 = decoding_b8 && !is_device_ptr(decoding_b8);
+    if (h_obs) { d_obs = (uint8_t *)h->b8_out.p; off = B * kb; }
+    if (h_dec8) d_dec8 = (uint8_t *)h->b8_out.p + off;
+    if (obs_b8 && kb)
+        hipLaunchKernelGGL(observables_b8_kernel, dim3((unsigned)((B * kb + 255) / 256)), dim3(256), 0, h->stream,
+                           (const int32_t *)h->obs_row_ptr.p, (const int32_t *)h->obs_col_idx.p, h->obs_k, h->n, d_dec, batch, d_obs);
+    if (decoding_b8 && nb)
+        hipLaunchKernelGGL(pack_b8_kernel, dim3((unsigned)((B * nb + 255) / 256)), dim3(256), 0, h->stream, d_dec, batch, h->n, d_dec8);
+    HIPCHK(hipGetLastError());
+    if (h_obs && kb) HIPCHK(hipMemcpyAsync(obs_b8, d_obs, B * kb, hipMemcpyDeviceToHost, h->stream));
+    if (h_dec8 && nb) HIPCHK(hipMemcpyAsync(decoding_b8, d_dec8, B * nb, hipMemcpyDeviceToHost, h->stream));
+    if (h_it) HIPCHK(hipMemcpyAsync(iters, d_it, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (h_cv) HIPCHK(hipMemcpyAsync(conv, d_cv, B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return LDPC_HIP_OK;
 }

@@ -167,6 +167,53 @@ class HipBpEngine:
                       it.ctypes.data, cv.ctypes.data))
         return dec, llr, it, cv.astype(bool)
 
+    def set_observables(self, observables_matrix):
+        """The k x n matrix whose product with a decoding gives the predicted observables (``decode_b8``)."""
+        import scipy.sparse as sp
+        obs = sp.csr_matrix(observables_matrix)
+        obs.eliminate_zeros()
+        obs.sort_indices()
+        if obs.shape[1] != self.n:
+            raise ValueError(f"observables_matrix must have {self.n} columns")
+        rp = np.ascontiguousarray(obs.indptr, np.int32)
+        ci = np.ascontiguousarray(obs.indices, np.int32)
+        self.k = int(obs.shape[0])
+        _lib.check(self._lib.ldpc_hip_bp_set_observables(self._h, self.k, rp.ctypes.data, ci.ctypes.data if len(ci) else None))
+
+    def decode_b8(self, dets_b8, with_osd=False, want_decoding=False):
+        """Bit-packed shots in (``(B, ceil(m/8))`` uint8, stim "b8"), bit-packed predictions out.
+
+        Returns ``(obs_b8 (B, ceil(k/8)), decoding_b8 (B, ceil(n/8)) | None, iterations, converge)``; NumPy or torch
+        CUDA tensors as for ``decode_batch``.  ``with_osd`` uses the method / order given to ``set_osd``."""
+        mb, nb, kb = (self.m + 7) // 8, (self.n + 7) // 8, (getattr(self, "k", 0) + 7) // 8
+        if not hasattr(self, "k"):
+            raise ValueError("call set_observables first")
+        if _is_torch(dets_b8):
+            import torch
+            d = dets_b8.contiguous()
+            if d.dtype != torch.uint8 or d.dim() != 2 or d.shape[1] != mb or not d.is_cuda:
+                raise ValueError(f"dets_b8 must be a CUDA uint8 tensor of shape (B, {mb})")
+            b = int(d.shape[0])
+            self.set_stream(torch.cuda.current_stream(d.device).cuda_stream)
+            obs = torch.empty((b, kb), dtype=torch.uint8, device=d.device)
+            dec = torch.empty((b, nb), dtype=torch.uint8, device=d.device) if want_decoding else None
+            it = torch.empty((b,), dtype=torch.int32, device=d.device)
+            cv = torch.empty((b,), dtype=torch.uint8, device=d.device)
+            _lib.check(self._lib.ldpc_hip_bp_decode_b8(self._h, d.data_ptr(), b, int(bool(with_osd)), obs.data_ptr(),
+                                                       dec.data_ptr() if want_decoding else None, it.data_ptr(), cv.data_ptr()))
+            return obs, dec, it, cv
+        d = np.ascontiguousarray(dets_b8, np.uint8)
+        if d.ndim != 2 or d.shape[1] != mb:
+            raise ValueError(f"dets_b8 must have shape (B, {mb})")
+        b = d.shape[0]
+        obs = np.zeros((b, kb), np.uint8)
+        dec = np.zeros((b, nb), np.uint8) if want_decoding else None
+        it = np.zeros(b, np.int32)
+        cv = np.zeros(b, np.uint8)
+        _lib.check(self._lib.ldpc_hip_bp_decode_b8(self._h, d.ctypes.data, b, int(bool(with_osd)), obs.ctypes.data,
+                                                   dec.ctypes.data if want_decoding else None, it.ctypes.data, cv.ctypes.data))
+        return obs, dec, it, cv.astype(bool)
+
     def mulvec_batch(self, vectors):
         """``GF2Sparse::mulvec`` (gf2sparse.hpp:177-214) for every row of ``vectors`` (B, n)."""
         if _is_torch(vectors):

@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel"):
+def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel", osd=None):
     import torch
     from ldpc_amd.engine import HipBpEngine
     m, n = h.shape
@@ -23,12 +23,14 @@ def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_ex
     eng.set_math(math)
     eng.set_schedule(schedule)
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
-    out = eng.decode_batch(s, osd0=osd0)  # warm-up + result for statistics
+    if osd is not None:  # (osd_method, osd_order): 2 = OSD_E, 3 = OSD_CS
+        eng.set_osd(*osd)
+    out = eng.decode_batch(s, osd0=osd0, osd=osd is not None)  # warm-up + result for statistics
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.decode_batch(s, out=out, osd0=osd0, asynchronous=True)
+        eng.decode_batch(s, out=out, osd0=osd0, osd=osd is not None, asynchronous=True)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     it = out[2].cpu().numpy()
@@ -50,6 +52,13 @@ def main():
         run("c3 surface d=21 min_sum 30 it p=0.01", h, 0.01, 30, 1, 0.625, 262144, False)
     if "serial" in args.which:
         serial()
+    if "osdw" in args.which:
+        h = codes.bivariate_bicycle_hx()
+        run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05", h, 0.05, 50, 0, 1.0, 8192, False, osd=(3, 10))
+        run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, False, osd=(3, 10))
+        run("c5 BB144 product_sum 50 it + OSD_CS order 60 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, False, osd=(3, 60))
+        run("c5 BB144 product_sum 50 it + OSD_E order 10 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, False, osd=(2, 10))
+        run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
     if "c5" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05", h, 0.05, 50, 0, 1.0, 8192, True)
