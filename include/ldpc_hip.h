@@ -156,6 +156,22 @@ int ldpc_hip_bposd_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, 
                                       uint8_t *converge);
 
 /*
+ * replaces: ldpc::bp::BpDecoder::soft_info_decode_serial (src_cpp/bp.hpp:547-660), the method behind
+ * SoftInfoBpDecoder.decode (_bp_decoder.pyx:712-785), over a batch of analog syndromes.
+ * soft_syndromes [batch][m] FP64 readouts; each is scaled to 2 s / sigma^2, its sign gives the hard syndrome, and the
+ * serial minimum-sum sweep treats a check whose scaled magnitude is below `cutoff` (and below the smallest incoming
+ * message) as a virtual variable node that may be updated or flipped (bp.hpp:597-621).  Uses the handle's
+ * max_iter, ms_scaling_factor (taken literally, no adaptive mode), channel probabilities and -- if one was set with
+ * ldpc_hip_bp_set_schedule(serial, order) -- serial_schedule_order; bp_method and schedule are ignored (the reference
+ * class forces minimum_sum / serial, pyx:751-752).  Outputs: decoding [batch][n]; llr, iterations, converge as for
+ * decode_batch; soft_syndromes_out [batch][m] = the decoder's soft_syndrome member afterwards (pyx:787-798).  Any
+ * output but decoding may be NULL.  Host or device pointers.  m <= 19200 (one word per check in LDS).
+ */
+int ldpc_hip_bp_soft_info_decode_batch(ldpc_hip_bp *h, const double *soft_syndromes, int64_t batch, double cutoff,
+                                       double sigma, uint8_t *decoding, double *llr, int32_t *iterations,
+                                       uint8_t *converge, double *soft_syndromes_out);
+
+/*
  * Bit-packed shot data in, bit-packed predictions out: replaces the per-shot loop of the reference's sinter decoders
  * (sinter_decoders/sinter_bposd_decoder.py:115-130, sinter_belief_find_decoder.py; `decode_via_files` reads detection
  * events and writes observable predictions in stim's "b8" format: bit i of a shot is bit i % 8 of its byte i / 8, every

@@ -526,3 +526,67 @@ class BpDecoder(BpDecoderBase):
     @property
     def decoding(self) -> np.ndarray:
         return np.array(self._decoding).astype(int)  # pyx:698-709
+
+
+class SoftInfoBpDecoder(BpDecoderBase):
+    """Serial minimum-sum BP with analog syndrome information (drop-in for ``ldpc.bp_decoder.SoftInfoBpDecoder``,
+    pyx:712-812; algorithm ``soft_info_decode_serial``, bp.hpp:547-660).
+
+    Keywords as in the reference (pyx:743-745): ``error_rate``, ``error_channel``, ``max_iter = 0`` (-> n),
+    ``bp_method`` (ignored: always minimum_sum, pyx:752), ``ms_scaling_factor = 1.0``, ``cutoff = inf``,
+    ``sigma = 2.0``.  ``decode`` takes one vector of ``m`` analog readouts; ``decode_batch`` (additive) takes ``(B, m)``.
+    """
+
+    def __init__(self, pcm, *, error_rate=_UNSET, error_channel=_UNSET, max_iter=_UNSET, bp_method=_UNSET,
+                 ms_scaling_factor=_UNSET, cutoff=np.inf, sigma: float = 2.0, **kwargs):
+        _check_pcm_type(pcm)
+        given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
+                     ms_scaling_factor=ms_scaling_factor)
+        passed = dict(kwargs)
+        passed.update({k: v for k, v in given.items() if v is not _UNSET})
+        super().__init__(pcm, **passed)
+        self.cutoff = float(cutoff)
+        if not isinstance(sigma, float) or sigma <= 0:  # pyx:748-749
+            raise ValueError("The sigma value must be a float greater than 0.")
+        self.sigma = sigma
+        self.schedule = "serial"
+        self.bp_method = "minimum_sum"
+        self.input_vector_type = "syndrome"
+        self._soft_syndrome = np.zeros(self.m, np.float64)
+        self.soft_syndrome_batch = None
+
+    def _soft_decode(self, soft2d):
+        if self._random_serial_schedule:
+            raise NotImplementedError("random_serial_schedule reshuffles a persistent order every iteration (bp.hpp:573-577) and is "
+                                      "not available on the MI355X path; there is no CPU fallback.")
+        return self._get_engine().soft_info_decode_batch(soft2d, self.cutoff, self.sigma)
+
+    def decode(self, soft_info_syndrome: np.ndarray) -> np.ndarray:
+        """One analog syndrome (pyx:761-785); returns the decoding as uint8."""
+        soft = np.asarray([soft_info_syndrome[i] for i in range(self.m)], dtype=np.float64)  # pyx:776-779
+        dec, llr, it, cv, so = self._soft_decode(soft[None, :])
+        self._decoding = dec[0].copy()
+        self._log_prob_ratios = llr[0]
+        self._iterations = int(it[0])
+        self._converge = bool(cv[0])
+        self._soft_syndrome = so[0]
+        return dec[0].astype(np.uint8)
+
+    def decode_batch(self, soft_info_syndromes):
+        """``(B, m)`` analog syndromes in one launch; row b equals ``decode(soft_info_syndromes[b])``.  Afterwards
+        ``converge_batch``, ``iter_batch``, ``log_prob_ratios_batch`` and ``soft_syndrome_batch`` describe every row."""
+        if soft_info_syndromes.ndim != 2 or soft_info_syndromes.shape[1] != self.m:
+            raise ValueError(f"The soft syndromes must have shape (batch, {self.m}).")
+        from ldpc_amd.engine import _is_torch
+        soft = soft_info_syndromes if _is_torch(soft_info_syndromes) else np.ascontiguousarray(soft_info_syndromes, np.float64)
+        dec, llr, it, cv, so = self._soft_decode(soft)
+        self.converge_batch, self.iter_batch, self.log_prob_ratios_batch, self.soft_syndrome_batch = cv, it, llr, so
+        return dec
+
+    @property
+    def soft_syndrome(self) -> np.ndarray:
+        return np.array(self._soft_syndrome, dtype=np.float64)
+
+    @property
+    def decoding(self) -> np.ndarray:
+        return np.array(self._decoding).astype(int)

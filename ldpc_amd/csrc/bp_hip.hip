@@ -1243,6 +1243,152 @@ __global__ void __launch_bounds__(256) bp_small_kernel(const SmallArgs a) {
 // pivoting only picks which ROW carries a pivot), so here the augmented matrix [H | s] lives bit-packed
 // in LDS (lane l owns rows l, l+64, ...), columns are visited in rank order and eliminated
 // Gauss-Jordan style with wave ballots.  All LDS traffic is wave-private: no workgroup barriers.
+// ---- soft-syndrome serial min-sum: BpDecoder::soft_info_decode_serial (bp.hpp:547-660) ---------------------
+// One wavefront per 64-shot tile, lane = shot.  The scaled analog syndrome S[tile][check][lane] and the hard
+// syndrome (one ballot word per check, in LDS) are part of the decoder state: a check whose |S| is below the
+// cutoff and below the smallest incoming magnitude behaves as a virtual variable node (bp.hpp:597-621).
+struct SoftArgs {
+    int32_t m, n, nnz, max_iter;
+    double ms_scaling_factor, cutoff;
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
+    const double *llr0;
+    double *A;        // [tiles][nnz][64] bit->check messages
+    double *C;        // [tiles][nnz][64] check->bit messages of the bit being updated
+    double *S;        // [tiles][m][64]   in: 2 s / sigma^2, out: the soft syndrome after decoding
+    const uint64_t *syn;  // [tiles][m]   hard syndrome (S <= 0) at the start
+    uint64_t *dec, *dcur;
+    double *llr_t;
+    int32_t *iters;
+    uint8_t *conv;
+};
+
+// soft_info_decode_serial's preamble (bp.hpp:551-559): scale, take the sign, lay out lane-minor
+__global__ void __launch_bounds__(256) softinfo_prepare_kernel(const double *__restrict__ soft, int64_t batch, int m, double sigma,
+                                                               double *__restrict__ S, uint64_t *__restrict__ syn) {
+    const int64_t tile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int64_t b = tile * LDPC_WAVE + lane;
+    double v = 1.0;
+    if (b < batch) v = 2 * soft[b * m + i] / (sigma * sigma);
+    S[((size_t)tile * m + i) * LDPC_WAVE + lane] = v;
+    const uint64_t ones = __ballot(v <= 0);
+    if (lane == 0) syn[tile * m + i] = ones;
+}
+
+__global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
+    volatile uint64_t *syn = reinterpret_cast<volatile uint64_t *>(soft_lds);  // [m] current hard syndrome
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf St = make_msgbuf(a.S + (size_t)tile * (size_t)m * LDPC_WAVE, (unsigned)m);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    for (int i = lane; i < m; i += 64) syn[i] = a.syn[tile * m + i];
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    int my_iter = 0;
+    for (int e = 0; e < nnz; ++e) At.st(l8, e, sload(a.llr0 + sload(a.col_idx + e)));  // bp.hpp:147-157
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
+        for (int t = 0; t < n; ++t) {
+            const int bit = a.order ? sload(a.order + t) : t;
+            const int cs = sload(a.col_ptr + bit);
+            const int d = sload(a.col_ptr + bit + 1) - cs;
+            double llr = sload(a.llr0 + bit);  // bp.hpp:583-584
+            for (int p = cs; p < cs + d; ++p) {
+                const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+                const int rs = sload(a.row_ptr + chk), re = sload(a.row_ptr + chk + 1);
+                int sgn = 0;
+                double temp = DBL_MAX;
+                for (int g = rs; g < re; ++g)
+                    if (g != e) {  // bp.hpp:590-599
+                        const double bg = At.ld(l8, g);
+                        if (fabs(bg) < temp) temp = fabs(bg);
+                        if (bg <= 0) sgn ^= 1;
+                    }
+                const double own = At.ld(l8, e);
+                const double min_msg = temp;
+                double propagated = min_msg;
+                double soft = St.ld(l8, chk);
+                const double magnitude = fabs(soft);
+                uint64_t word = syn[chk];
+                int hard = (int)((word >> lane) & 1ull);
+                bool flip = false;
+                if (magnitude < a.cutoff && magnitude < fabs(min_msg)) {  // bp.hpp:604-621
+                    propagated = magnitude;
+                    const int check_node_sgn = sgn ^ (own <= 0 ? 1 : 0);
+                    if (check_node_sgn == hard) {
+                        const double mag = fabs(own) < min_msg ? fabs(own) : min_msg;
+                        soft = hard ? -mag : mag;  // pow(-1, syndrome) * magnitude
+                    } else {
+                        flip = true;
+                        soft = -soft;
+                    }
+                    if (lane_live) St.st(l8, chk, soft);
+                }
+                const uint64_t flips = __ballot(flip);
+                if (flips) {  // wave-uniform
+                    word ^= flips;
+                    if (lane == 0) syn[chk] = word;
+                    hard = (int)((word >> lane) & 1ull);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                sgn ^= hard;
+                const double c = (a.ms_scaling_factor * (sgn ? -1.0 : 1.0)) * propagated;  // bp.hpp:624
+                Ct.st(l8, e, c);
+                At.st(l8, e, llr);  // partial sum; completed by the reverse sweep below
+                llr += c;
+            }
+            double back = 0.0;  // bp.hpp:634-638
+            for (int p = cs + d - 1; p >= cs; --p) {
+                const int e = sload(a.csc_edge + p);
+                At.st(l8, e, At.ld(l8, e) + back);
+                back += Ct.ld(l8, e);
+            }
+            const uint64_t hard_bits = __ballot(llr <= 0);  // bp.hpp:628-633
+            if (lane == 0) dcur[bit] = hard_bits;
+            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+        }
+        // H x against the CURRENT hard syndrome (bp.hpp:640-655)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t unsat = 0;
+        for (int i = lane; i < m; i += 64) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ syn[i];
+        }
+        unsat = wave_or(unsat);
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+        }
+        if (done == ~0ull) break;
+    }
+    if (done != ~0ull)
+        for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    const int64_t b = tile * LDPC_WAVE + lane;
+    if (b < a.batch) {
+        const bool cv = ((done >> lane) & 1ull) != 0;
+        if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+        if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}
+
 struct OsdArgs {
     int32_t m, n, words;  // words = ceil((n + 1) / 64): n matrix bits + the syndrome bit per row
     int64_t batch;
@@ -1675,6 +1821,7 @@ struct ldpc_hip_bp {
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
     int32_t obs_k = -1;                                              // rows of the observables matrix (-1: not set)
     int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
@@ -1804,7 +1951,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
                          &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter,
-                         &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
+                         &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
     if (h->d_row_ptr) (void)hipFree(h->d_row_ptr);
@@ -2046,6 +2193,99 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                 hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n,
                                    llr + (size_t)b0 * h->n);
             }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LDPC_HIP_OK;
+}
+
+// soft_info_decode_serial over a batch (bp_softinfo_kernel).  Device pointers, on h->stream.
+static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, double cutoff, double sigma, uint8_t *decoding,
+                            double *llr, int32_t *iters, uint8_t *conv, double *soft_out) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    if (tiles_total == 0) return LDPC_HIP_OK;
+    const size_t m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * n1 * LDPC_WAVE : 0;
+    const size_t per_tile_soft = sizeof(double) * m1 * LDPC_WAVE;
+    const size_t lds = sizeof(uint64_t) * m1;
+    if (lds > 150u * 1024u)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "soft-syndrome decoding keeps one hard-syndrome word per check in LDS: m <= 19200");
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap + h->soft_S.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = 2 * per_tile_msg + per_tile_llr + per_tile_soft + 24 * (m1 + n1);
+        int64_t fit = (int64_t)(budget / per_tile);
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-shot tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->soft_S.ensure(per_tile_soft * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * m1 * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    if (lds > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)bp_softinfo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->accumulated_ms = 0.f;
+    h->timed = false;
+    hipStream_t st = h->stream;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 3) / 4), (unsigned)tiles);
+            hipLaunchKernelGGL(softinfo_prepare_kernel, g, dim3(256), 0, st, soft + (size_t)b0 * h->m, nb, h->m, sigma,
+                               (double *)h->soft_S.p, (uint64_t *)h->par.p);
+        }
+        SoftArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor; a.cutoff = cutoff;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
+        a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.S = (double *)h->soft_S.p;
+        a.syn = (const uint64_t *)h->par.p;
+        a.dec = (uint64_t *)h->dec.p; a.dcur = (uint64_t *)h->dcur.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        hipLaunchKernelGGL(bp_softinfo_kernel, dim3((unsigned)tiles), dim3(64), (unsigned)lds, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st, (const uint64_t *)h->dec.p, nb, h->n,
+                               decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n,
+                                   llr + (size_t)b0 * h->n);
+            }
+        }
+        if (soft_out && h->m > 0) {
+            dim3 gt((unsigned)((h->m + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+            hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->soft_S.p, nb, h->m,
+                               soft_out + (size_t)b0 * h->m);
         }
         HIPCHK(hipGetLastError());
     }
@@ -2450,6 +2690,44 @@ int ldpc_hip_gf2_mulvec_batch(ldpc_hip_bp *h, const uint8_t *vectors, int64_t ba
                        h->d_row_ptr, h->d_col_idx, h->m, h->n, d_in, batch, d_out);
     HIPCHK(hipGetLastError());
     if (h_out) HIPCHK(hipMemcpyAsync(out, d_out, B * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_soft_info_decode_batch(ldpc_hip_bp *h, const double *soft_syndromes, int64_t batch, double cutoff, double sigma,
+                                       uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv, double *soft_syndromes_out) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch");
+    if (batch == 0) return LDPC_HIP_OK;
+    if (!soft_syndromes || !decoding) return fail(LDPC_HIP_ERR_INVALID, "soft syndromes and decoding must not be NULL");
+    if (!(sigma > 0)) return fail(LDPC_HIP_ERR_INVALID, "The sigma value must be a float greater than 0.");  // _bp_decoder.pyx:748-749
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = (size_t)batch, m = (size_t)h->m, n = (size_t)h->n;
+    int rc;
+    const double *d_soft = soft_syndromes;
+    uint8_t *d_dec = decoding;
+    double *d_llr = llr, *d_so = soft_syndromes_out;
+    int32_t *d_it = iters;
+    uint8_t *d_cv = conv;
+    const bool h_soft = !is_device_ptr(soft_syndromes), h_dec = !is_device_ptr(decoding);
+    const bool h_llr = llr && !is_device_ptr(llr), h_it = iters && !is_device_ptr(iters), h_cv = conv && !is_device_ptr(conv);
+    const bool h_so = soft_syndromes_out && !is_device_ptr(soft_syndromes_out);
+    if (h_soft) {
+        if ((rc = h->soft_in.ensure(B * m * 8 ? B * m * 8 : 1))) return rc;
+        HIPCHK(hipMemcpyAsync(h->soft_in.p, soft_syndromes, B * m * 8, hipMemcpyHostToDevice, h->stream));
+        d_soft = (const double *)h->soft_in.p;
+    }
+    if (h_dec) { if ((rc = h->st_dec.ensure(B * n ? B * n : 1))) return rc; d_dec = (uint8_t *)h->st_dec.p; }
+    if (h_llr) { if ((rc = h->st_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; d_llr = (double *)h->st_llr.p; }
+    if (h_it) { if ((rc = h->st_iters.ensure(B * 4))) return rc; d_it = (int32_t *)h->st_iters.p; }
+    if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
+    if (h_so) { if ((rc = h->soft_out.ensure(B * m * 8 ? B * m * 8 : 1))) return rc; d_so = (double *)h->soft_out.p; }
+    if ((rc = soft_info_device(h, d_soft, batch, cutoff, sigma, d_dec, d_llr, d_it, d_cv, d_so))) return rc;
+    if (h_dec) HIPCHK(hipMemcpyAsync(decoding, d_dec, B * n, hipMemcpyDeviceToHost, h->stream));
+    if (h_llr) HIPCHK(hipMemcpyAsync(llr, d_llr, B * n * 8, hipMemcpyDeviceToHost, h->stream));
+    if (h_it) HIPCHK(hipMemcpyAsync(iters, d_it, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (h_cv) HIPCHK(hipMemcpyAsync(conv, d_cv, B, hipMemcpyDeviceToHost, h->stream));
+    if (h_so) HIPCHK(hipMemcpyAsync(soft_syndromes_out, d_so, B * m * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return LDPC_HIP_OK;
 }

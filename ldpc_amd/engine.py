@@ -167,6 +167,39 @@ class HipBpEngine:
                       it.ctypes.data, cv.ctypes.data))
         return dec, llr, it, cv.astype(bool)
 
+    def soft_info_decode_batch(self, soft_syndromes, cutoff, sigma, want_llr=True):
+        """``(B, m)`` float64 analog syndromes -> ``(decoding, llr|None, iterations, converge, soft_syndrome)``
+        (``ldpc_hip_bp_soft_info_decode_batch``; NumPy or torch CUDA tensors)."""
+        if _is_torch(soft_syndromes):
+            import torch
+            s = soft_syndromes.contiguous()
+            if s.dtype != torch.float64 or s.dim() != 2 or s.shape[1] != self.m or not s.is_cuda:
+                raise ValueError(f"soft_syndromes must be a CUDA float64 tensor of shape (B, {self.m})")
+            b = int(s.shape[0])
+            self.set_stream(torch.cuda.current_stream(s.device).cuda_stream)
+            dec = torch.empty((b, self.n), dtype=torch.uint8, device=s.device)
+            llr = torch.empty((b, self.n), dtype=torch.float64, device=s.device) if want_llr else None
+            it = torch.empty((b,), dtype=torch.int32, device=s.device)
+            cv = torch.empty((b,), dtype=torch.uint8, device=s.device)
+            so = torch.empty((b, self.m), dtype=torch.float64, device=s.device)
+            _lib.check(self._lib.ldpc_hip_bp_soft_info_decode_batch(
+                self._h, s.data_ptr(), b, float(cutoff), float(sigma), dec.data_ptr(), llr.data_ptr() if want_llr else None,
+                it.data_ptr(), cv.data_ptr(), so.data_ptr()))
+            return dec, llr, it, cv, so
+        s = np.ascontiguousarray(soft_syndromes, np.float64)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"soft_syndromes must have shape (B, {self.m})")
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        cv = np.zeros(b, np.uint8)
+        so = np.zeros((b, self.m), np.float64)
+        _lib.check(self._lib.ldpc_hip_bp_soft_info_decode_batch(
+            self._h, s.ctypes.data, b, float(cutoff), float(sigma), dec.ctypes.data, llr.ctypes.data if want_llr else None,
+            it.ctypes.data, cv.ctypes.data, so.ctypes.data))
+        return dec, llr, it, cv.astype(bool), so
+
     def set_observables(self, observables_matrix):
         """The k x n matrix whose product with a decoding gives the predicted observables (``decode_b8``)."""
         import scipy.sparse as sp

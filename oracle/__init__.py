@@ -91,6 +91,9 @@ class _OracleLib:
                 C.c_void_p, _i32p, _u8p]
             lib.osd0_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _u8p]
             lib.bposd0_oracle_decode_batch.argtypes = lib.bp_oracle_decode_batch.argtypes
+            lib.bp_oracle_soft_info_decode_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_double, C.c_void_p, _f64p, C.c_int64, C.c_double, C.c_double, _u8p,
+                C.c_void_p, _i32p, _u8p, C.c_void_p]
             lib.osdw_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _f64p, C.c_int, C.c_int, _u8p, C.c_void_p]
             lib.bposdw_oracle_decode_batch.argtypes = [
                 C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _u8p, C.c_int64, _u8p,
@@ -168,6 +171,21 @@ class BpOracle:
         self.lib.bposd0_oracle_decode_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha, s, b,
                                             dec, llr.ctypes.data if want_llr else None, it, conv)
         return dec, llr, it, conv.astype(bool)
+
+    def soft_info_decode_batch(self, soft_syndromes, cutoff, sigma, order=None):
+        """soft_info_decode_serial (bp.hpp:547-660) per row -> (decoding, llr, iterations, converge, soft_syndrome)."""
+        s = np.ascontiguousarray(soft_syndromes, np.float64)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        soft = np.zeros((b, self.m), np.float64)
+        od = None if order is None else np.ascontiguousarray(order, np.int32)
+        self.lib.bp_oracle_soft_info_decode_batch(self._h, self.channel_probs, self.max_iter, self.alpha,
+                                                  od.ctypes.data if od is not None else None, s, b, float(cutoff), float(sigma),
+                                                  dec, llr.ctypes.data, it, conv, soft.ctypes.data)
+        return dec, llr, it, conv.astype(bool), soft
 
     def osdw(self, syndrome, llr, osd_method, osd_order, channel_probs=None):
         """OSD of any order alone (osd.hpp:103-187 restated): ``osd_method`` 1 OSD_0, 2 OSD_E, 3 OSD_CS.
@@ -261,6 +279,20 @@ class RefBp:
         out = np.zeros(self.m, np.uint8)
         self.lib.ref_bp_mulvec(self._h, np.ascontiguousarray(v, np.uint8), out)
         return out
+
+    def soft_info_decode_batch(self, soft_syndromes, cutoff, sigma):
+        """The real soft_info_decode_serial (bp.hpp:547-660); construct with schedule='serial', bp_method='minimum_sum'."""
+        s = np.ascontiguousarray(soft_syndromes, np.float64)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        soft = np.zeros((b, self.m), np.float64)
+        self.lib.ref_bp_soft_info_decode_batch.argtypes = [C.c_void_p, _f64p, C.c_int64, C.c_double, C.c_double, _u8p, _f64p,
+                                                           _i32p, _u8p, _f64p]
+        self.lib.ref_bp_soft_info_decode_batch(self._h, s, b, float(cutoff), float(sigma), dec, llr, it, conv, soft)
+        return dec, llr, it, conv.astype(bool), soft
 
 
 class RefBpOsd:

@@ -515,6 +515,101 @@ void bp_oracle_decode_serial(bp_oracle *o, const double *channel_probs, int max_
     }
 }
 
+/* ============================================================================================== *
+ * Soft-syndrome serial min-sum: BpDecoder::soft_info_decode_serial (bp.hpp:547-660), what
+ * SoftInfoBpDecoder.decode runs (_bp_decoder.pyx:761-785).  The analog syndrome s_i is scaled to
+ * 2 s_i / sigma^2 (:553), its sign gives the hard syndrome (:554-558); during the serial sweep a check
+ * whose scaled magnitude is below `cutoff` and below the smallest incoming magnitude acts as a virtual
+ * variable node: it caps the outgoing magnitude and is itself updated or flipped (:597-621).
+ * ms_scaling_factor is used as it is (no adaptive 1 - 2^-it here); the convergence test compares H x with
+ * the CURRENT (possibly flipped) hard syndrome (:645-653).  `order` may be NULL (0 .. n-1).
+ * ============================================================================================== */
+void bp_oracle_soft_info_decode(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
+                                const int32_t *order, const double *soft_info_syndrome, double cutoff, double sigma,
+                                uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge,
+                                double *soft_syndrome) {
+    const int m = o->m, n = o->n;
+    uint8_t *syndrome = (uint8_t *)malloc((size_t)(m ? m : 1));
+    for (int i = 0; i < m; i++) {
+        soft_syndrome[i] = 2 * soft_info_syndrome[i] / (sigma * sigma);
+        syndrome[i] = soft_syndrome[i] <= 0 ? 1 : 0;
+    }
+    *converge = 0;
+    for (int j = 0; j < n; j++) { /* initialise_log_domain_bp, bp.hpp:147-157 */
+        o->llr0[j] = log((1 - channel_probs[j]) / channel_probs[j]);
+        for (int p = o->col_ptr[j]; p < o->col_ptr[j + 1]; p++) o->b2c[o->csc_edge[p]] = o->llr0[j];
+    }
+    int converged = 0;
+    for (int it = 1; it <= max_iter; it++) {
+        if (converged) continue;
+        for (int t = 0; t < n; t++) {
+            const int bit = order ? order[t] : t;
+            log_prob_ratios[bit] = log((1 - channel_probs[bit]) / channel_probs[bit]);
+            for (int p = o->col_ptr[bit]; p < o->col_ptr[bit + 1]; p++) {
+                const int e = o->csc_edge[p], chk = o->csc_row[p];
+                int sgn = 0;
+                double temp = DBL_MAX;
+                for (int g = o->row_ptr[chk]; g < o->row_ptr[chk + 1]; g++)
+                    if (g != e) {
+                        if (fabs(o->b2c[g]) < temp) temp = fabs(o->b2c[g]);
+                        if (o->b2c[g] <= 0) sgn ^= 1;
+                    }
+                const double min_b2c = temp;
+                double propagated = min_b2c;
+                const double magnitude = fabs(soft_syndrome[chk]);
+                if (magnitude < cutoff) {
+                    if (magnitude < fabs(min_b2c)) {
+                        propagated = magnitude;
+                        int check_node_sgn = sgn;
+                        if (o->b2c[e] <= 0) check_node_sgn ^= 1;
+                        if (check_node_sgn == syndrome[chk]) {
+                            if (fabs(o->b2c[e]) < min_b2c) soft_syndrome[chk] = pow(-1, syndrome[chk]) * fabs(o->b2c[e]);
+                            else soft_syndrome[chk] = pow(-1, syndrome[chk]) * min_b2c;
+                        } else {
+                            syndrome[chk] ^= 1;
+                            soft_syndrome[chk] *= -1;
+                        }
+                    }
+                }
+                sgn ^= syndrome[chk];
+                o->c2b[e] = ms_scaling_factor * pow(-1, sgn) * propagated;
+                o->b2c[e] = log_prob_ratios[bit];
+                log_prob_ratios[bit] += o->c2b[e];
+            }
+            decoding[bit] = log_prob_ratios[bit] <= 0 ? 1 : 0;
+            double temp = 0;
+            for (int p = o->col_ptr[bit + 1] - 1; p >= o->col_ptr[bit]; p--) {
+                const int e = o->csc_edge[p];
+                o->b2c[e] += temp;
+                temp += o->c2b[e];
+            }
+        }
+        converged = 1;
+        for (int i = 0; i < m && converged; i++) {
+            uint8_t c = 0;
+            for (int g = o->row_ptr[i]; g < o->row_ptr[i + 1]; g++) c ^= decoding[o->col_idx[g]];
+            if (c != syndrome[i]) converged = 0;
+        }
+        *iterations = it;
+    }
+    *converge = (uint8_t)converged;
+    free(syndrome);
+}
+
+void bp_oracle_soft_info_decode_batch(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
+                                      const int32_t *order, const double *soft_syndromes, int64_t shots, double cutoff,
+                                      double sigma, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge,
+                                      double *soft_syndromes_out) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)(o->n + o->m + 1));
+    for (int64_t b = 0; b < shots; b++) {
+        iterations[b] = 0;
+        bp_oracle_soft_info_decode(o, channel_probs, max_iter, ms_scaling_factor, order, soft_syndromes + b * o->m, cutoff, sigma,
+                                   decodings + b * o->n, llr ? llr + b * o->n : tmp, iterations + b, converge + b,
+                                   soft_syndromes_out ? soft_syndromes_out + b * o->m : tmp + o->n);
+    }
+    free(tmp);
+}
+
 void bp_oracle_decode_serial_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
                                    double ms_scaling_factor, const int32_t *order, const uint8_t *syndromes,
                                    int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {

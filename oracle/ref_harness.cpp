@@ -77,6 +77,23 @@ void ref_bp_decode_batch(ref_bp *r, const uint8_t *inputs, int len, int64_t shot
                       iterations + b, converge + b);
 }
 
+/* BpDecoder::soft_info_decode_serial (bp.hpp:547-660) as SoftInfoBpDecoder.decode drives it (_bp_decoder.pyx:761-785);
+ * the decoder must have been created with schedule SERIAL (0) and bp_method MINIMUM_SUM (1), pyx:751-752 */
+void ref_bp_soft_info_decode_batch(ref_bp *r, const double *soft_syndromes, int64_t shots, double cutoff, double sigma,
+                                   uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge,
+                                   double *soft_syndromes_out) {
+    const int m = r->dec->check_count, n = r->dec->bit_count;
+    for (int64_t b = 0; b < shots; b++) {
+        std::vector<double> s(soft_syndromes + b * m, soft_syndromes + (b + 1) * m);
+        r->dec->soft_info_decode_serial(s, cutoff, sigma);
+        std::memcpy(decodings + b * n, r->dec->decoding.data(), (size_t)n);
+        if (llr) std::memcpy(llr + b * n, r->dec->log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        if (soft_syndromes_out) std::memcpy(soft_syndromes_out + b * m, r->dec->soft_syndrome.data(), sizeof(double) * (size_t)m);
+        iterations[b] = r->dec->iterations;
+        converge[b] = r->dec->converge ? 1 : 0;
+    }
+}
+
 /* GF2Sparse::mulvec (gf2sparse.hpp:177-214) */
 void ref_bp_mulvec(ref_bp *r, const uint8_t *in, uint8_t *out) {
     std::vector<uint8_t> v(in, in + r->pcm->n);
