@@ -1,0 +1,269 @@
+// bp_device_common.h -- argument blocks, message addressing and the per-node arithmetic shared by every BP kernel
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_hip.h"
+#include "bp_math.h"
+
+// math modes of the product-sum kernel (ldpc_hip_bp_set_math): 0 = bit-identical twins of the host
+// glibc the reference runs on (default), 1 = fast ~1-ulp routines (bp_math.h)
+
+#define LDPC_WAVE 64  // gfx950 wavefront; also the tile width (syndromes per workgroup)
+
+
+struct BpArgs {
+    int32_t m, n, nnz, max_iter;
+    double ms_scaling_factor;
+    int64_t batch;       // syndromes in this launch (last tile may be partial)
+    const int32_t *row_ptr, *col_idx;   // CSR
+    const int32_t *col_ptr, *csc_edge;  // CSC: CSR edge id of each column entry, rows ascending
+    const double *llr0;                 // initial_log_prob_ratios (bp.hpp:66), host-computed
+    double *A;                          // bit_to_check_msg  [tiles][nnz][64]  (bp.hpp:44)
+    double *C;                          // check_to_bit_msg  [tiles][nnz][64]  (bp.hpp:45)
+    const uint64_t *par;                // [tiles][m]  bit l = syndrome byte & 1 of lane l
+    const uint64_t *nzm;                // [tiles][m]  bit l = syndrome byte != 0 of lane l
+    const uint64_t *invalid;            // [tiles]     bit l = some syndrome byte > 1 (never converges)
+    uint64_t *dec;                      // [tiles][n]  frozen hard decisions, bit l = lane l (zero-initialised)
+    uint64_t *dcur;                     // [tiles][n]  hard decisions of the running iteration
+    double *llr_t;                      // [tiles][n][64] or nullptr
+    int32_t *iters;                     // [batch] or nullptr
+    uint8_t *conv;                      // [batch] or nullptr
+    // hand-off of straggler tiles to the chip-wide per-pass kernels (see bp_spread_*): 0 = never
+    struct TileState *state;            // [tiles]
+    unsigned *counters;                 // [0] tiles finished by the persistent kernel, [1] tiles handed off
+    int32_t *handoff_list;              // [tiles] ids of handed-off tiles
+    int32_t total_tiles, handoff_threshold;
+};
+
+// What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in
+// ROUNDS (one BP iteration each) of four launches; within a launch many workgroups read a tile's state while one
+// of them advances it, so everything that changes is double-buffered by round parity or written once.
+struct TileState {
+    uint64_t done[2];            // [round & 1]: lanes whose syndrome has converged (or that lie beyond the batch)
+    unsigned long long unsat[2]; // [round & 1]: OR over rows of (candidate parity ^ syndrome), filled by the syndrome pass
+    int32_t it0;                 // iterations completed before round 0
+    int32_t end_round;           // round in which the tile's outputs became final (INT32_MAX while it runs)
+    int32_t lane_iter[64];       // iteration at which each lane converged
+};
+
+__device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin of ldpc_amd/prng.py
+    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Read-only tables (CSR/CSC indices, priors, packed syndrome masks: all written by EARLIER launches) are
+// read through the constant address space: with a wave-uniform address that is an s_load on the scalar
+// cache, tracked by lgkmcnt.  As plain global loads they would be vector-memory operations whose
+// `s_waitcnt vmcnt(0)` also drains the asynchronous message prefetches queued behind them.
+template <class T>
+__device__ __forceinline__ T sload(const T *p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // wave-uniform value -> SGPR pair
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_or(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo |= __shfl_xor(lo, off, LDPC_WAVE);
+        hi |= __shfl_xor(hi, off, LDPC_WAVE);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Message arrays are reached through buffer descriptors: "SGPR descriptor + SGPR edge offset + VGPR
+// lane offset", so an access costs no per-lane 64-bit address arithmetic and no address VGPR pairs
+// (flat global_load needs a VGPR pair per distinct address; with ~30 addresses live that alone cost
+// an occupancy step).  One descriptor covers one tile's [nnz][64] doubles: nnz * 512 bytes < 4 GiB.
+typedef unsigned int ldpc_v2u __attribute__((ext_vector_type(2)));
+struct MsgBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ double ld(int lane8, int edge) const {  // edge is wave-uniform
+        ldpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (int)((unsigned)edge << 9), 0);
+        return __builtin_bit_cast(double, v);
+    }
+    __device__ __forceinline__ void st(int lane8, int edge, double x) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ldpc_v2u, x), rsrc, lane8,
+                                              (int)((unsigned)edge << 9), 0);
+    }
+};
+__device__ __forceinline__ MsgBuf make_msgbuf(double *base, unsigned rows) {
+    MsgBuf b;
+    b.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows << 9), 0x00020000);
+    return b;
+}
+
+// check -> bit, product-sum, one lane: message_sign * log((1 + x) / (1 - x))  (bp.hpp:211-216),
+// x = (exclusive prefix product) * (exclusive suffix product) of the tanh values of the row
+template <int MATH>
+__device__ __forceinline__ double ps_message(double x, bool negate, const double *log_tab) {
+    const double c = MATH == 0 ? ldpc_math::ps_log_ratio_libm(x, log_tab) : ldpc_math::ps_log_ratio(x);
+    return negate ? -c : c;
+}
+
+// tanh(b / 2) of bp.hpp:208,217
+template <int MATH>
+__device__ __forceinline__ double ps_tanh_half(double b) {
+    return MATH == 0 ? ldpc_math::tanh_half_libm(b) : ldpc_math::tanh_half(b);
+}
+
+// Keeps the scheduler from interleaving the (independent) per-edge transcendental chains: each chain
+// needs ~20 VGPRs of temporaries and interleaving 6-8 of them costs occupancy for no gain -- latency is
+// hidden by the other wavefronts of the SIMD, not by ILP inside one.
+#define LDPC_EDGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// What array A holds per edge: product-sum stores tanh(b2c / 2) (the only form the check update
+// reads; evaluating it in the BIT pass puts half of the transcendental work next to each of the two
+// memory passes), min-sum stores b2c itself.  Same value either way: one tanh per edge per iteration
+// of the same argument the reference uses (it evaluates it twice, bp.hpp:208 and :217).
+template <int METHOD, int MATH>
+__device__ __forceinline__ double edge_form(double b2c) {
+    return METHOD == LDPC_HIP_PRODUCT_SUM ? ps_tanh_half<MATH>(b2c) : b2c;
+}
+
+// ---- per-node arithmetic, shared by the register-prefetch and the LDS-ring variants ----------------
+
+// One check row held in registers: cur[0..d) are the row's A values in ascending column order.
+// Computes the d check->bit messages (bp.hpp:201-219 / 220-273) and stores them to C[rs + k].
+template <int METHOD, int MATH, int DR>
+__device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs, bool neg, int parity0,
+                                          double alpha, const MsgBuf &Ct, int l8, const double *log_tab) {
+    double pre[DR];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+        double temp = 1.0;
+#pragma unroll
+        for (int k = 0; k < DR; ++k)
+            if (k < d) { pre[k] = temp; temp *= cur[k]; }
+        temp = 1.0;
+#pragma unroll
+        for (int k = DR - 1; k >= 0; --k)
+            if (k < d) {
+                Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg, log_tab));
+                temp *= cur[k];
+                LDPC_EDGE_FENCE();
+            }
+    } else {
+        // total_sgn = syndrome[i] + #{b2c <= 0}; only its parity is used (bp.hpp:236-262)
+        int parity = parity0;
+        double temp = DBL_MAX;
+#pragma unroll
+        for (int k = 0; k < DR; ++k)
+            if (k < d) {
+                if (cur[k] <= 0) parity ^= 1;
+                pre[k] = temp;
+                const double ab = fabs(cur[k]);
+                if (ab < temp) temp = ab;
+            }
+        temp = DBL_MAX;
+#pragma unroll
+        for (int k = DR - 1; k >= 0; --k)
+            if (k < d) {
+                const int sgn = parity ^ (cur[k] <= 0 ? 1 : 0);
+                double mag = pre[k];
+                if (temp < mag) mag = temp;
+                const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
+                Ct.st(l8, rs + k, mag * signed_alpha);
+                const double ab = fabs(cur[k]);
+                if (ab < temp) temp = ab;
+            }
+    }
+}
+
+// A row heavier than the register bound: two streaming sweeps, exactly the reference's loops.
+template <int METHOD, int MATH>
+__device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int parity, double alpha,
+                                                   const MsgBuf &At, const MsgBuf &Ct, int l8,
+                                                   const double *log_tab) {
+    if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+        double temp = 1.0;
+        for (int k = 0; k < d; ++k) {
+            Ct.st(l8, rs + k, temp);
+            temp *= At.ld(l8, rs + k);
+        }
+        temp = 1.0;
+        for (int k = d - 1; k >= 0; --k) {
+            Ct.st(l8, rs + k, ps_message<MATH>(Ct.ld(l8, rs + k) * temp, neg, log_tab));
+            temp *= At.ld(l8, rs + k);
+        }
+    } else {
+        double temp = DBL_MAX;
+        for (int k = 0; k < d; ++k) {
+            const double bk = At.ld(l8, rs + k);
+            if (bk <= 0) parity ^= 1;
+            Ct.st(l8, rs + k, temp);
+            const double ab = fabs(bk);
+            if (ab < temp) temp = ab;
+        }
+        temp = DBL_MAX;
+        for (int k = d - 1; k >= 0; --k) {
+            const double bk = At.ld(l8, rs + k);
+            const int sgn = parity ^ (bk <= 0 ? 1 : 0);
+            double mag = Ct.ld(l8, rs + k);
+            if (temp < mag) mag = temp;
+            const double signed_alpha = sgn ? -alpha : alpha;
+            Ct.st(l8, rs + k, mag * signed_alpha);
+            const double ab = fabs(bk);
+            if (ab < temp) temp = ab;
+        }
+    }
+}
+
+// One bit column held in registers: c[0..d) are its check->bit messages in ascending row order, e[] the
+// CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored.
+template <int METHOD, int MATH, int DC>
+__device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&e)[DC], int d, double prior,
+                                             const MsgBuf &At, int l8) {
+    double pre[DC];
+    double temp = prior;
+#pragma unroll
+    for (int k = 0; k < DC; ++k)
+        if (k < d) { pre[k] = temp; temp += c[k]; }
+    const double llr = temp;
+    double s = 0.0;
+#pragma unroll
+    for (int k = DC - 1; k >= 0; --k)
+        if (k < d) {
+            At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + s));
+            s += c[k];
+            if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+        }
+    return llr;
+}
+
+// ---- LDS-DMA ring ------------------------------------------------------------------------------------
+// A wavefront keeps RING_DEPTH rows (check pass) or bit pairs (bit pass) of message data in flight into
+// its private LDS ring with `buffer_load_dwordx4 ... lds`: 64 lanes x 16 B = two whole 512-byte edge
+// segments per instruction, no VGPRs held while the data is in flight.  hipcc does not count these loads,
+// so the waits are explicit: vector-memory operations complete in issue order, hence "at most N
+// operations outstanding", with N = the number of operations issued AFTER the wanted load, proves it has
+// landed.  N must be a lower bound of that number (a smaller N only waits longer); the steady-state
+// constants below assume exactly-regular node degrees, which is why the ring variant is only selected
+// for such matrices (host side: rows all of weight DR, columns all of weight DC).
+extern __shared__ __attribute__((aligned(16))) unsigned char ldpc_dyn_lds[];
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;  // M0 carries the LDS destination; it is compiler-reserved, so save/restore it in the same statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N < 63 ? N : 63) : "memory"); }
+__device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

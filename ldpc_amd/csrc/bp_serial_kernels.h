@@ -1,0 +1,325 @@
+// bp_serial_kernels.h -- serial schedule (bp.hpp:451-545) and soft-syndrome serial min-sum (bp.hpp:547-660)
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// ---- serial schedule (bp.hpp:451-545) with a fixed bit order -----------------------------------------
+// The serial schedule is sequential in the bits of ONE syndrome (every bit update reads messages the
+// previous bits just wrote) but the syndromes of a batch stay independent, so the lane = syndrome tile
+// layout carries over: one wavefront walks the bits of its 64-syndrome tile in schedule order.  Per bit and
+// per incident check the message is the plain sequential product (min) over the row's other entries
+// (bp.hpp:493-498 / 507-517), signed by pow(-1, syndrome byte) (bp.hpp:499), in the reference's order.
+// Only one message array is needed: check->bit messages never outlive the bit update that computes them.
+// It holds tanh(b2c / 2) for product-sum (evaluated once per write instead of once per read: same value),
+// b2c for min-sum.  The random and LLR-sorted ("serial_relative") orders differ per syndrome and are not
+// provided on the device.
+struct SerialArgs {
+    int32_t m, n, nnz, max_iter, fast;
+    double ms_scaling_factor;
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
+    const double *llr0;
+    double *A;                    // [tiles][nnz][64]  tanh(b2c/2) | b2c
+    double *C;                    // [tiles][nnz][64]  scratch for nodes heavier than the register bounds
+    const uint64_t *par, *invalid;
+    uint64_t *dec, *dcur;
+    double *llr_t;
+    int32_t *iters;
+    uint8_t *conv;
+};
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
+    constexpr int DCS = 4, DRS = 8;  // register bounds of the fast path (column / row weight)
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    const uint64_t *par = a.par + tile * m;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    __shared__ __attribute__((aligned(16))) double log_tab[256];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = lane; q < 256; q += 64) log_tab[q] = ldpc_math::k_log_tab[q];
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    const uint64_t never = a.invalid[tile];
+    int my_iter = 0;
+
+    for (int e = 0; e < nnz; ++e) At.st(l8, e, edge_form<METHOD, MATH>(sload(a.llr0 + sload(a.col_idx + e))));
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+        const bool lane_live = !((done >> lane) & 1ull);
+        for (int t = 0; t < n; ++t) {
+            const int bit = a.order ? sload(a.order + t) : t;
+            const int cs = sload(a.col_ptr + bit);
+            const int d = sload(a.col_ptr + bit + 1) - cs;
+            double llr = sload(a.llr0 + bit);  // bp.hpp:488
+            // the (other) entries of one incident check row -> its check->bit message for this bit
+            auto row_message = [&](int chk, int e, const double *vals, int rs, int rd) {
+                const bool odd = (sload(par + chk) >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
+                if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+                    double c = 1.0;
+                    if (vals) {
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd && rs + q != e) c *= vals[q];
+                    } else {
+                        for (int g = rs; g < rs + rd; ++g)
+                            if (g != e) c *= At.ld(l8, g);
+                    }
+                    c = ps_message<MATH>(c, odd, log_tab);
+                    return c;
+                } else {
+                    int sgn = odd ? 1 : 0;
+                    double temp = DBL_MAX;
+                    if (vals) {
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd && rs + q != e) {
+                                const double ab = fabs(vals[q]);
+                                if (ab < temp) temp = ab;
+                                if (vals[q] <= 0) sgn ^= 1;
+                            }
+                    } else {
+                        for (int g = rs; g < rs + rd; ++g)
+                            if (g != e) {
+                                const double bg = At.ld(l8, g);
+                                const double ab = fabs(bg);
+                                if (ab < temp) temp = ab;
+                                if (bg <= 0) sgn ^= 1;
+                            }
+                    }
+                    return (alpha * (sgn ? -1.0 : 1.0)) * temp;  // alpha * message_sign * temp (bp.hpp:519)
+                }
+            };
+            if (a.fast) {
+                int e[DCS], chk[DCS], rs[DCS], rd[DCS];
+                double vals[DCS][DRS], c[DCS], pre[DCS];
+#pragma unroll
+                for (int k = 0; k < DCS; ++k)
+                    if (k < d) {
+                        e[k] = sload(a.csc_edge + cs + k);
+                        chk[k] = sload(a.csc_row + cs + k);
+                        rs[k] = sload(a.row_ptr + chk[k]);
+                        rd[k] = sload(a.row_ptr + chk[k] + 1) - rs[k];
+#pragma unroll
+                        for (int q = 0; q < DRS; ++q)
+                            if (q < rd[k] && rs[k] + q != e[k]) vals[k][q] = At.ld(l8, rs[k] + q);
+                    }
+#pragma unroll
+                for (int k = 0; k < DCS; ++k)
+                    if (k < d) {
+                        c[k] = row_message(chk[k], e[k], vals[k], rs[k], rd[k]);
+                        pre[k] = llr;  // bp.hpp:501 / 520
+                        llr += c[k];
+                        if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+                    }
+                double temp = 0.0;  // bp.hpp:530-534
+#pragma unroll
+                for (int k = DCS - 1; k >= 0; --k)
+                    if (k < d) {
+                        At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + temp));
+                        temp += c[k];
+                    }
+            } else {
+                for (int p = cs; p < cs + d; ++p) {
+                    const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+                    const int rs = sload(a.row_ptr + chk), rd = sload(a.row_ptr + chk + 1) - rs;
+                    const double c = row_message(chk, e, nullptr, rs, rd);
+                    Ct.st(l8, e, c);
+                    At.st(l8, e, llr);  // partial sum; rewritten below before any other bit reads it
+                    llr += c;
+                }
+                double temp = 0.0;
+                for (int p = cs + d - 1; p >= cs; --p) {
+                    const int e = sload(a.csc_edge + p);
+                    At.st(l8, e, edge_form<METHOD, MATH>(At.ld(l8, e) + temp));
+                    temp += Ct.ld(l8, e);
+                }
+            }
+            const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:525-529
+            if (lane == 0) dcur[bit] = hard;
+            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+        }
+        // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t unsat = 0;
+        for (int i = lane; i < m; i += 64) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ par[i];
+        }
+        unsat = wave_or(unsat) | never;
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+        }
+        if (done == ~0ull) break;
+    }
+    if (done != ~0ull)
+        for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    const int64_t b = tile * LDPC_WAVE + lane;
+    if (b < a.batch) {
+        const bool cv = ((done >> lane) & 1ull) != 0;
+        if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+        if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}
+
+// ---- soft-syndrome serial min-sum: BpDecoder::soft_info_decode_serial (bp.hpp:547-660) ---------------------
+// One wavefront per 64-shot tile, lane = shot.  The scaled analog syndrome S[tile][check][lane] and the hard
+// syndrome (one ballot word per check, in LDS) are part of the decoder state: a check whose |S| is below the
+// cutoff and below the smallest incoming magnitude behaves as a virtual variable node (bp.hpp:597-621).
+struct SoftArgs {
+    int32_t m, n, nnz, max_iter;
+    double ms_scaling_factor, cutoff;
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
+    const double *llr0;
+    double *A;        // [tiles][nnz][64] bit->check messages
+    double *C;        // [tiles][nnz][64] check->bit messages of the bit being updated
+    double *S;        // [tiles][m][64]   in: 2 s / sigma^2, out: the soft syndrome after decoding
+    const uint64_t *syn;  // [tiles][m]   hard syndrome (S <= 0) at the start
+    uint64_t *dec, *dcur;
+    double *llr_t;
+    int32_t *iters;
+    uint8_t *conv;
+};
+
+// soft_info_decode_serial's preamble (bp.hpp:551-559): scale, take the sign, lay out lane-minor
+__global__ void __launch_bounds__(256) softinfo_prepare_kernel(const double *__restrict__ soft, int64_t batch, int m, double sigma,
+                                                               double *__restrict__ S, uint64_t *__restrict__ syn) {
+    const int64_t tile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int64_t b = tile * LDPC_WAVE + lane;
+    double v = 1.0;
+    if (b < batch) v = 2 * soft[b * m + i] / (sigma * sigma);
+    S[((size_t)tile * m + i) * LDPC_WAVE + lane] = v;
+    const uint64_t ones = __ballot(v <= 0);
+    if (lane == 0) syn[tile * m + i] = ones;
+}
+
+__global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
+    volatile uint64_t *syn = reinterpret_cast<volatile uint64_t *>(soft_lds);  // [m] current hard syndrome
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf St = make_msgbuf(a.S + (size_t)tile * (size_t)m * LDPC_WAVE, (unsigned)m);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    for (int i = lane; i < m; i += 64) syn[i] = a.syn[tile * m + i];
+    __builtin_amdgcn_wave_barrier();
+
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    int my_iter = 0;
+    for (int e = 0; e < nnz; ++e) At.st(l8, e, sload(a.llr0 + sload(a.col_idx + e)));  // bp.hpp:147-157
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
+        for (int t = 0; t < n; ++t) {
+            const int bit = a.order ? sload(a.order + t) : t;
+            const int cs = sload(a.col_ptr + bit);
+            const int d = sload(a.col_ptr + bit + 1) - cs;
+            double llr = sload(a.llr0 + bit);  // bp.hpp:583-584
+            for (int p = cs; p < cs + d; ++p) {
+                const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+                const int rs = sload(a.row_ptr + chk), re = sload(a.row_ptr + chk + 1);
+                int sgn = 0;
+                double temp = DBL_MAX;
+                for (int g = rs; g < re; ++g)
+                    if (g != e) {  // bp.hpp:590-599
+                        const double bg = At.ld(l8, g);
+                        if (fabs(bg) < temp) temp = fabs(bg);
+                        if (bg <= 0) sgn ^= 1;
+                    }
+                const double own = At.ld(l8, e);
+                const double min_msg = temp;
+                double propagated = min_msg;
+                double soft = St.ld(l8, chk);
+                const double magnitude = fabs(soft);
+                uint64_t word = syn[chk];
+                int hard = (int)((word >> lane) & 1ull);
+                bool flip = false;
+                if (magnitude < a.cutoff && magnitude < fabs(min_msg)) {  // bp.hpp:604-621
+                    propagated = magnitude;
+                    const int check_node_sgn = sgn ^ (own <= 0 ? 1 : 0);
+                    if (check_node_sgn == hard) {
+                        const double mag = fabs(own) < min_msg ? fabs(own) : min_msg;
+                        soft = hard ? -mag : mag;  // pow(-1, syndrome) * magnitude
+                    } else {
+                        flip = true;
+                        soft = -soft;
+                    }
+                    if (lane_live) St.st(l8, chk, soft);
+                }
+                const uint64_t flips = __ballot(flip);
+                if (flips) {  // wave-uniform
+                    word ^= flips;
+                    if (lane == 0) syn[chk] = word;
+                    hard = (int)((word >> lane) & 1ull);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                sgn ^= hard;
+                const double c = (a.ms_scaling_factor * (sgn ? -1.0 : 1.0)) * propagated;  // bp.hpp:624
+                Ct.st(l8, e, c);
+                At.st(l8, e, llr);  // partial sum; completed by the reverse sweep below
+                llr += c;
+            }
+            double back = 0.0;  // bp.hpp:634-638
+            for (int p = cs + d - 1; p >= cs; --p) {
+                const int e = sload(a.csc_edge + p);
+                At.st(l8, e, At.ld(l8, e) + back);
+                back += Ct.ld(l8, e);
+            }
+            const uint64_t hard_bits = __ballot(llr <= 0);  // bp.hpp:628-633
+            if (lane == 0) dcur[bit] = hard_bits;
+            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+        }
+        // H x against the CURRENT hard syndrome (bp.hpp:640-655)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t unsat = 0;
+        for (int i = lane; i < m; i += 64) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ syn[i];
+        }
+        unsat = wave_or(unsat);
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+        }
+        if (done == ~0ull) break;
+    }
+    if (done != ~0ull)
+        for (int j = lane; j < n; j += 64) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    const int64_t b = tile * LDPC_WAVE + lane;
+    if (b < a.batch) {
+        const bool cv = ((done >> lane) & 1ull) != 0;
+        if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+        if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}

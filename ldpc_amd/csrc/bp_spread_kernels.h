@@ -1,0 +1,216 @@
+// bp_spread_kernels.h -- per-pass kernels: check pass, bit pass, syndrome test and bookkeeping spread over the whole chip
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// ---- per-pass kernels for handed-off tiles ---------------------------------------------------------------
+// Same arithmetic, same arrays, but one launch per pass and one wavefront per NODE, so the rows / columns of a
+// single tile are spread over all 256 compute units.  Used for the tiles the persistent kernel parks when the
+// chip would otherwise idle; each launch handles every parked tile that is still running.
+struct SpreadArgs {
+    BpArgs bp;
+    int32_t n_tiles;  // entries of bp.handoff_list
+    int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4 otherwise: amortises the table load)
+    int32_t round;    // 0-based per-pass round; a tile's iteration number is it0 + round + 1
+};
+
+// tile handled by workgroup row `slot`, its iteration number and converged mask in this round; false: already final
+__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
+    tile = a.bp.handoff_list[slot];
+    st = a.bp.state + tile;
+    it = st->it0 + a.round + 1;
+    done = st->done[a.round & 1];
+    return a.round <= st->end_round;
+}
+
+
+template <int METHOD, int MATH, int DR>
+__global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
+    __shared__ __attribute__((aligned(16))) double log_tab[256];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+    __syncthreads();
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
+    const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
+        const int rs = sload(a.bp.row_ptr + i), d = sload(a.bp.row_ptr + i + 1) - rs;
+        const bool neg = (sload(a.bp.nzm + tile * a.bp.m + i) >> lane) & 1ull;
+        const int parity = (int)((sload(a.bp.par + tile * a.bp.m + i) >> lane) & 1ull);
+        if (d <= DR) {
+            double cur[DR];
+#pragma unroll
+            for (int k = 0; k < DR; ++k)
+                if (k < d) cur[k] = At.ld(l8, rs + k);
+            check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+        } else {
+            check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+        }
+    }
+}
+
+template <int METHOD, int MATH, int DC>
+__global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const bool want_llr = a.bp.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+    const bool last = it == a.bp.max_iter;
+    const bool lane_live = !((done >> lane) & 1ull);
+    const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
+        const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
+        const double prior = sload(a.bp.llr0 + j);
+        double llr;
+        if (d <= DC) {
+            int e[DC];
+            double c[DC];
+#pragma unroll
+            for (int k = 0; k < DC; ++k)
+                if (k < d) { e[k] = sload(a.bp.csc_edge + cs + k); c[k] = Ct.ld(l8, e[k]); }
+            llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8);
+        } else {  // the reference's two sweeps (bp.hpp:278-281, 313-316) through memory
+            double temp = prior;
+            for (int k = 0; k < d; ++k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, temp);
+                temp += Ct.ld(l8, ee);
+            }
+            llr = temp;
+            double sfx = 0.0;
+            for (int k = d - 1; k >= 0; --k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
+                sfx += Ct.ld(l8, ee);
+            }
+        }
+        const uint64_t hard = __ballot(llr <= 0);
+        if (lane == 0) a.bp.dcur[tile * n + j] = hard;
+        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+    }
+}
+
+// candidate syndrome vs syndrome (bp.hpp:292-294, 300-302) for the parked tiles, one thread per (tile, row); the
+// per-tile verdict is OR-accumulated into TileState::unsat for bp_spread_finish_kernel
+__global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a) {
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t unsat = 0;
+    if (i < a.bp.m) {
+        const uint64_t *dcur = a.bp.dcur + tile * a.bp.n;
+        uint64_t cand = 0;
+        for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
+        unsat = cand ^ a.bp.par[tile * a.bp.m + i];
+    }
+    unsat = wave_or(unsat);
+    if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
+}
+
+// batches of only a few tiles skip the persistent kernel altogether: state + message initialisation for the per-pass path
+__global__ void __launch_bounds__(256) bp_spread_state_init_kernel(const SpreadArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_tiles) return;
+    TileState *st = a.bp.state + t;
+    const int64_t valid = a.bp.batch - (int64_t)t * LDPC_WAVE;
+    st->done[0] = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    st->unsat[0] = st->unsat[1] = 0ull;
+    st->it0 = 0;
+    st->end_round = INT32_MAX;
+    for (int l = 0; l < 64; ++l) st->lane_iter[l] = 0;
+    a.bp.handoff_list[t] = t;
+}
+
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_spread_init_kernel(const SpreadArgs a) {  // bp.hpp:147-157
+    const int64_t tile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, l8 = lane * 8;
+    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const int e0 = (blockIdx.x * 4 + wave) * 16;
+    for (int e = e0; e < e0 + 16 && e < nnz; ++e)
+        At.st(l8, e, edge_form<METHOD, MATH>(sload(a.bp.llr0 + sload(a.bp.col_idx + e))));
+}
+
+// convergence bookkeeping of a round (bp.hpp:296-311, 320-322): lanes whose candidate syndrome matched are frozen
+// (decisions + posterior of THIS iteration), a tile whose lanes are all frozen or that reached max_iter gets its
+// outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
+// to freeze and every workgroup but the first leaves at once.
+__global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a, unsigned *live_tiles) {
+    int64_t tile;
+    const TileState *cst;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, cst, it, done)) return;
+    TileState *st = a.bp.state + tile;
+    const int par = a.round & 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = a.bp.n, nnz = a.bp.nnz, l8 = lane * 8;
+    const bool last = it == a.bp.max_iter;
+    const uint64_t unsat = cst->unsat[par] | a.bp.invalid[tile];
+    const uint64_t newly = ~unsat & ~done;
+    const uint64_t ndone = done | newly;
+    const bool over = ndone == ~0ull || last;
+    const bool mine = (newly >> lane) & 1ull;
+    if (newly || (over && ndone != ~0ull)) {
+        uint64_t *dec = a.bp.dec + tile * n;
+        const uint64_t *dcur = a.bp.dcur + tile * n;
+        const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+        const bool want_llr = a.bp.llr_t != nullptr;
+        const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+        const int j0 = blockIdx.x * 64 + wave * 16;
+        for (int j = j0; j < j0 + 16 && j < n; ++j) {
+            if (lane == 0) {
+                const uint64_t cur = dcur[j];
+                uint64_t d = (dec[j] & ~newly) | (cur & newly);
+                if (over) d = (d & ndone) | (cur & ~ndone);  // never converged: the last iteration's decisions
+                dec[j] = d;
+            }
+            if (newly && !last && want_llr) {  // at the last iteration the bit pass has stored the posterior already
+                double temp = a.bp.llr0[j];
+                for (int p = a.bp.col_ptr[j]; p < a.bp.col_ptr[j + 1]; ++p) temp += Ct.ld(l8, a.bp.csc_edge[p]);
+                if (mine) Lt.st(l8, j, temp);
+            }
+        }
+    }
+    if (blockIdx.x != 0) return;
+    if (wave == 0) {
+        if (mine) st->lane_iter[lane] = it;
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (over && b < a.bp.batch) {
+            const bool cv = ((ndone >> lane) & 1ull) != 0;
+            if (a.bp.iters) a.bp.iters[b] = cv ? (mine ? it : st->lane_iter[lane]) : a.bp.max_iter;  // bp.hpp:304
+            if (a.bp.conv) a.bp.conv[b] = cv ? 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->done[par ^ 1] = ndone;
+        st->unsat[par ^ 1] = 0ull;
+        if (over) {
+            st->end_round = a.round;
+            atomicSub(live_tiles, 1u);
+        }
+    }
+}

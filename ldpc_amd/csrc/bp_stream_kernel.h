@@ -1,0 +1,303 @@
+// bp_stream_kernel.h -- bp_decode_kernel: the persistent one-workgroup-per-tile streaming kernel (bp.hpp:192-325)
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// One workgroup owns one 64-syndrome tile for the whole decode: check pass, barrier, bit pass, barrier, syndrome
+// test, up to max_iter times (design notes at the top of bp_hip.hip and in DESIGN.md section 4).
+//   METHOD  LDPC_HIP_PRODUCT_SUM | LDPC_HIP_MINIMUM_SUM      MATH  0 libm-exact | 1 fast (product-sum only)
+//   DR, DC  register bounds on row / column weight; heavier nodes are streamed through memory in two sweeps
+//   RING    0: next row / bits prefetched into VGPRs;  2 or 3: slots of the per-wavefront LDS ring filled by
+//           `buffer_load_dwordx4 ... lds` (only for matrices with a single row weight DR and column weight DC)
+template <int METHOD, int MATH, int DR, int DC, int RING>
+__global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
+    constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
+    const int lane = threadIdx.x & (LDPC_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+
+    const int32_t *__restrict__ row_ptr = a.row_ptr;
+    const int32_t *__restrict__ col_idx = a.col_idx;
+    const int32_t *__restrict__ col_ptr = a.col_ptr;
+    const int32_t *__restrict__ csc_edge = a.csc_edge;
+    const double *__restrict__ llr0 = a.llr0;
+    const uint64_t *__restrict__ par = a.par + tile * m;
+    const uint64_t *__restrict__ nzm = a.nzm + tile * m;
+
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    uint64_t *dec = a.dec + tile * n;    // frozen decisions of converged syndromes (zero-initialised)
+    uint64_t *dcur = a.dcur + tile * n;  // this iteration's hard decisions, all lanes
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+
+    __shared__ uint64_t red[2][16];
+    __shared__ int red_i;
+    __shared__ __attribute__((aligned(16))) double log_tab[256];  // glibc log's {1/c, log c} table, LDS-resident
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+
+    // ring geometry (RING variant): one slot holds a check row (DR segments) or a pair of bit columns (2*DC)
+    constexpr int ROW_DMAS = (DR + 1) / 2;                       // 1 KiB DMA instructions per row
+    constexpr int SLOT_BYTES = (ROW_DMAS > DC ? ROW_DMAS : DC) * 1024;
+    constexpr int N_CHECK = RING * DR + (RING - 1) * ROW_DMAS;
+    constexpr int N_BIT = RING * (2 * DC + 2) + (RING - 1) * DC;
+    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
+    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
+    const unsigned l16 = (unsigned)lane * 16u;
+
+    // lanes beyond the batch (partial last tile) are born "done"
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    const uint64_t never = a.invalid[tile];
+    int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
+
+    // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
+    __syncthreads();
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        // ---------------- check pass (bp.hpp:201-273) ----------------
+        double alpha = 0.0;
+        if (METHOD == LDPC_HIP_MINIMUM_SUM)
+            alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+
+        if (RING) {
+            // every row has exactly DR entries: row i starts at edge i * DR
+            const int nsteps = wave < m ? (m - wave + nwaves - 1) / nwaves : 0;
+            auto issue_row = [&](int i, int slot) {
+#pragma unroll
+                for (int c = 0; c < ROW_DMAS; ++c)
+                    lds_dma16(At.rsrc, l16, (unsigned)(i * DR + 2 * c) << 9, ring_addr + slot * SLOT_BYTES + c * 1024);
+            };
+            for (int p = 0; p < RING; ++p)
+                if (p < nsteps) issue_row(wave + p * nwaves, p);
+            int slot = 0;
+            for (int idx = 0; idx < nsteps; ++idx) {
+                const int i = wave + idx * nwaves;
+                if (idx >= RING && idx + RING - 1 < nsteps) wait_vmcnt<N_CHECK>();
+                else wait_vmcnt<0>();
+                double cur[DR];
+#pragma unroll
+                for (int k = 0; k < DR; ++k) cur[k] = ringp[slot * (SLOT_BYTES / 8) + k * LDPC_WAVE + lane];
+                wait_lds_reads();  // the slot is free once its values sit in registers
+                if (idx + RING < nsteps) issue_row(i + RING * nwaves, slot);
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
+                check_row<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab);
+                slot = slot + 1 == RING ? 0 : slot + 1;
+            }
+        } else {
+            // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
+            // works on row i its loads for row i + nwaves are already in flight.
+            double cur[DR];
+            int rs = 0, d = 0;
+            if (wave < m) {
+                rs = sload(row_ptr + wave);
+                d = sload(row_ptr + wave + 1) - rs;
+                if (d <= DR) {
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) cur[k] = At.ld(l8, rs + k);
+                }
+            }
+            for (int i = wave; i < m; i += nwaves) {
+                const int inext = i + nwaves;
+                double nxt[DR];
+                int rs_n = 0, d_n = 0;
+                if (inext < m) {
+                    rs_n = sload(row_ptr + inext);
+                    d_n = sload(row_ptr + inext + 1) - rs_n;
+                    if (d_n <= DR) {
+#pragma unroll
+                        for (int k = 0; k < DR; ++k)
+                            if (k < d_n) nxt[k] = At.ld(l8, rs_n + k);
+                    }
+                }
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
+                if (d <= DR) check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+                else check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+                rs = rs_n;
+                d = d_n;
+#pragma unroll
+                for (int k = 0; k < DR; ++k) cur[k] = nxt[k];
+            }
+        }
+        __syncthreads();
+
+        // ---------------- bit pass (bp.hpp:276-298 and 311-318, fused) ----------------
+        const bool last = (it == a.max_iter);
+        const bool lane_live = !((done >> lane) & 1ull);
+        if (RING) {
+            // every column has exactly DC entries; a step handles the column pair (2g, 2g + 1), whose
+            // 2*DC gathered segments arrive as DC DMA instructions (lanes 0-31 one segment, 32-63 the next)
+            const int ngroups = (n + 1) / 2;
+            const int nsteps = wave < ngroups ? (ngroups - wave + nwaves - 1) / nwaves : 0;
+            auto issue_pair = [&](int g, int slot) {
+                const int base = 2 * g * DC;
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const int q0 = base + 2 * c, q1 = base + 2 * c + 1;
+                    const unsigned ea = (unsigned)sload(csc_edge + (q0 < nnz ? q0 : 0));
+                    const unsigned eb = (unsigned)sload(csc_edge + (q1 < nnz ? q1 : 0));
+                    const unsigned voff = ((lane < 32 ? ea : eb) << 9) + (unsigned)(lane & 31) * 16u;
+                    lds_dma16(Ct.rsrc, voff, 0u, ring_addr + slot * SLOT_BYTES + c * 1024);
+                }
+            };
+            for (int p = 0; p < RING; ++p)
+                if (p < nsteps) issue_pair(wave + p * nwaves, p);
+            int slot = 0;
+            for (int idx = 0; idx < nsteps; ++idx) {
+                const int g = wave + idx * nwaves;
+                if (idx >= RING && idx + RING - 1 < nsteps) wait_vmcnt<N_BIT>();
+                else wait_vmcnt<0>();
+                double c[2][DC];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int k = 0; k < DC; ++k)
+                        c[u][k] = ringp[slot * (SLOT_BYTES / 8) + (u * DC + k) * LDPC_WAVE + lane];
+                wait_lds_reads();
+                if (idx + RING < nsteps) issue_pair(g + RING * nwaves, slot);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = 2 * g + u;
+                    if (j < n) {
+                        int e[DC];
+#pragma unroll
+                        for (int k = 0; k < DC; ++k) e[k] = sload(csc_edge + j * DC + k);
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, sload(llr0 + j), At, l8);
+                        const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                        if (lane == 0) dcur[j] = hard;
+                        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                    }
+                }
+                slot = slot + 1 == RING ? 0 : slot + 1;
+            }
+        } else {
+            // UB columns per wavefront step: all their message loads are issued before the first is used.
+            for (int j0 = wave * UB; j0 < n; j0 += nwaves * UB) {
+                int cs[UB], dg[UB], e[UB][DC];
+                double c[UB][DC];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = j0 + u;
+                    cs[u] = 0;
+                    dg[u] = -1;  // -1: no such column
+                    if (j < n) {
+                        cs[u] = sload(col_ptr + j);
+                        dg[u] = sload(col_ptr + j + 1) - cs[u];
+                        if (dg[u] <= DC) {
+#pragma unroll
+                            for (int k = 0; k < DC; ++k)
+                                if (k < dg[u]) {
+                                    e[u][k] = sload(csc_edge + cs[u] + k);
+                                    c[u][k] = Ct.ld(l8, e[u][k]);
+                                }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int j = j0 + u;
+                    if (dg[u] < 0) continue;
+                    const double prior = sload(llr0 + j);
+                    double llr;
+                    if (dg[u] <= DC) {
+                        llr = bit_column<METHOD, MATH, DC>(c[u], e[u], dg[u], prior, At, l8);
+                    } else {  // heavy column: two streaming sweeps like the reference's
+                        double temp = prior;
+                        for (int k = 0; k < dg[u]; ++k) {
+                            const int ee = sload(csc_edge + cs[u] + k);
+                            At.st(l8, ee, temp);
+                            temp += Ct.ld(l8, ee);
+                        }
+                        llr = temp;
+                        double s = 0.0;
+                        for (int k = dg[u] - 1; k >= 0; --k) {
+                            const int ee = sload(csc_edge + cs[u] + k);
+                            At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + s));
+                            s += Ct.ld(l8, ee);
+                        }
+                    }
+                    const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                    if (lane == 0) dcur[j] = hard;
+                    if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- syndrome test (bp.hpp:292-294, 300-308) ----------------
+        uint64_t unsat = 0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            uint64_t cand = 0;
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) cand ^= dcur[col_idx[e]];
+            unsat |= cand ^ par[i];
+        }
+        unsat = wave_or(unsat);
+        uint64_t *slot_red = red[it & 1];  // double-buffered: no barrier needed before the next reuse
+        if (lane == 0) slot_red[wave] = unsat;
+        __syncthreads();
+        unsat = never;
+        for (int w = 0; w < nwaves; ++w) unsat |= slot_red[w];
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            // these syndromes stop here (bp.hpp:300-308): freeze their decisions, and their posteriors are
+            // those of THIS iteration (its check->bit messages are still intact in C)
+            if ((newly >> lane) & 1ull) my_iter = it;
+            const bool mine = (newly >> lane) & 1ull;
+            for (int j = wave; j < n; j += nwaves) {
+                if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+                if (!last && want_llr) {
+                    double temp = llr0[j];
+                    for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p) temp += Ct.ld(l8, csc_edge[p]);
+                    if (mine) Lt.st(l8, j, temp);
+                }
+            }
+            done |= newly;
+            __syncthreads();  // C is overwritten by the next check pass
+        }
+        if (done == ~0ull) break;
+        // Few tiles left running (stragglers, a tiny batch, or the tail of the launch): a lone tile is bound to
+        // ONE compute unit (~3 ms per iteration on the n = 10 000 code), so park its state and let the per-pass
+        // kernels below spread its remaining iterations over the whole chip.
+        if (a.handoff_threshold > 0 && it < a.max_iter) {
+            if (threadIdx.x == 0)
+                red_i = a.total_tiles - (int)__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (red_i <= a.handoff_threshold) {
+                TileState *stt = a.state + tile;
+                if (wave == 0) stt->lane_iter[lane] = my_iter;
+                if (threadIdx.x == 0) {
+                    stt->done[0] = done;
+                    stt->it0 = it;
+                    stt->end_round = INT32_MAX;
+                    stt->unsat[0] = stt->unsat[1] = 0ull;
+                    a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
+                }
+                return;
+            }
+            __syncthreads();  // red_i is rewritten next iteration
+        }
+    }
+
+    // syndromes that never converged report the last iteration's decisions (bp.hpp:320-322)
+    if (done != ~0ull)
+        for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+
+    if (wave == 0) {
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (b < a.batch) {
+            const bool cv = ((done >> lane) & 1ull) != 0;
+            if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;  // bp.hpp:304
+            if (a.conv) a.conv[b] = cv ? 1 : 0;
+        }
+    }
+    if (threadIdx.x == 0 && a.counters) atomicAdd(&a.counters[0], 1u);
+}

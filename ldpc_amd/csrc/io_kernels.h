@@ -1,0 +1,156 @@
+// io_kernels.h -- layout changes either side of the decoders: pack / unpack / transpose, H v, b8 shot data, synthetic shots
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// syndromes [batch][m] u8  ->  par / nzm [tiles][m] u64, invalid [tiles] u64 (pre-zeroed)
+__global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch, int m,
+                                      uint64_t *par, uint64_t *nzm, uint64_t *invalid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = blockIdx.y;
+    if (i >= m) return;
+    uint64_t p = 0, z = 0, inv = 0;
+    const int64_t b0 = tile * LDPC_WAVE;
+    for (int l = 0; l < LDPC_WAVE; ++l) {
+        const int64_t b = b0 + l;
+        if (b < batch) {
+            const uint8_t v = synd[b * m + i];
+            p |= (uint64_t)(v & 1u) << l;
+            z |= (uint64_t)(v != 0u) << l;
+            inv |= (uint64_t)(v > 1u) << l;
+        }
+    }
+    par[tile * m + i] = p;
+    nzm[tile * m + i] = z;
+    if (inv) atomicOr((unsigned long long *)&invalid[tile], (unsigned long long)inv);
+}
+
+// dec [tiles][n] u64 -> decoding [batch][n] u8
+__global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch, int n,
+                                       uint8_t *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = blockIdx.y;
+    if (j >= n) return;
+    const uint64_t v = dec[tile * n + j];
+    const int64_t b0 = tile * LDPC_WAVE;
+    for (int l = 0; l < LDPC_WAVE; ++l) {
+        const int64_t b = b0 + l;
+        if (b < batch) out[b * n + j] = (uint8_t)((v >> l) & 1ull);
+    }
+}
+
+// llr_t [tiles][n][64] f64 -> llr [batch][n] f64, 64x64 tiles through LDS
+__global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__restrict__ llr_t,
+                                                            int64_t batch, int n, double *out) {
+    __shared__ double tilebuf[LDPC_WAVE][LDPC_WAVE + 1];
+    const int j0 = blockIdx.x * LDPC_WAVE;
+    const int64_t tile = blockIdx.y;
+    const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+    for (int r = 0; r < 16; ++r) {
+        const int jj = r * 4 + hi;
+        if (j0 + jj < n) tilebuf[jj][lo] = llr_t[((size_t)tile * n + j0 + jj) * LDPC_WAVE + lo];
+    }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+        const int l = r * 4 + hi;
+        const int64_t b = tile * LDPC_WAVE + l;
+        if (b < batch && j0 + lo < n) out[(size_t)b * n + j0 + lo] = tilebuf[lo][l];
+    }
+}
+
+// GF2Sparse::mulvec over a batch (gf2sparse.hpp:177-214): one thread per (vector, check)
+__global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
+                                  const int32_t *__restrict__ col_idx, int m, int n,
+                                  const uint8_t *__restrict__ in, int64_t batch, uint8_t *out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * m) return;
+    const int64_t b = t / m;
+    const int i = (int)(t - b * m);
+    uint8_t s = 0;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) s ^= in[b * n + col_idx[e]];
+    out[t] = s;
+}
+
+// ---- bit-packed shot data ("b8": bit i of a shot is bit i % 8 of its byte i / 8; every shot starts on a byte) --
+// the wire format of the reference's sinter decoders (sinter_decoders/sinter_bposd_decoder.py:57-130)
+__global__ void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * bits) return;
+    const int64_t b = t / bits;
+    const int i = (int)(t - b * bits);
+    out[t] = (in[b * ((bits + 7) >> 3) + (i >> 3)] >> (i & 7)) & 1;
+}
+
+__global__ void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+    const int nb = (bits + 7) >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * nb) return;
+    const int64_t b = t / nb;
+    const int byte = (int)(t - b * nb);
+    uint8_t v = 0;
+    for (int q = 0; q < 8 && byte * 8 + q < bits; ++q) v |= (uint8_t)((in[b * bits + byte * 8 + q] & 1) << q);
+    out[t] = v;
+}
+
+// BpDecoder.decode / BpOsdDecoder.decode return the zero vector for an all-zero input without running BP
+// (_bp_decoder.pyx:679-681, _bposd_decoder.pyx:118-123): converge = True, iterations reported as 0 by the batch API
+__global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, int64_t batch, int m, int n, uint8_t *dec,
+                                          int32_t *iters, uint8_t *conv) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int mb = (m + 7) >> 3;
+    uint8_t any = 0;
+    for (int q = 0; q < mb; ++q) {
+        uint8_t v = dets_b8[b * mb + q];
+        if (q == mb - 1 && (m & 7)) v &= (uint8_t)((1u << (m & 7)) - 1u);  // padding bits carry no data
+        any |= v;
+    }
+    if (any) return;
+    for (int j = 0; j < n; ++j) dec[b * n + j] = 0;
+    if (iters) iters[b] = 0;
+    if (conv) conv[b] = 1;
+}
+
+// predicted observables L x (mod 2) of every decoding, bit-packed: one thread per (shot, output byte)
+// (SinterBpOsdDecoder.decode: `(observables_matrix @ corr) % 2`, sinter_bposd_decoder.py:128-130)
+__global__ void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx, int k, int n,
+                                      const uint8_t *__restrict__ dec, int64_t batch, uint8_t *__restrict__ out) {
+    const int nb = (k + 7) >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * nb) return;
+    const int64_t b = t / nb;
+    const int byte = (int)(t - b * nb);
+    uint8_t v = 0;
+    for (int q = 0; q < 8 && byte * 8 + q < k; ++q) {
+        const int o = byte * 8 + q;
+        uint8_t s = 0;
+        for (int e = row_ptr[o]; e < row_ptr[o + 1]; ++e) s ^= dec[b * n + col_idx[e]];
+        v |= (uint8_t)((s & 1) << q);
+    }
+    out[t] = v;
+}
+
+// synthetic BSC shots: syndrome[b][i] = XOR_{j in row i} bernoulli(seed, (shot0+b)*n + j)
+__global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
+                                         const int32_t *__restrict__ col_idx, int m, int n,
+                                         uint64_t seed, uint64_t threshold, int64_t shot0,
+                                         int64_t batch, uint8_t *synd) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * m) return;
+    const int64_t b = t / m;
+    const int i = (int)(t - b * m);
+    const uint64_t base = (uint64_t)(shot0 + b) * (uint64_t)n;
+    uint8_t s = 0;
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+        s ^= (uint8_t)((sm64(seed, base + (uint64_t)col_idx[e]) >> 11) < threshold);
+    synd[t] = s;
+}
+
+__global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, int64_t shot0,
+                                      int64_t batch, uint8_t *err) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * n) return;
+    const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
+    err[t] = (uint8_t)((sm64(seed, idx) >> 11) < threshold);
+}

@@ -1,0 +1,273 @@
+// osd_kernels.h -- ordered-statistics decoding of the rows BP left unconverged (osd.hpp:103-187)
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// ---- OSD-0 (osd.hpp:110-117 = sort.hpp:48-62 + gf2sparse_linalg.hpp:298-401, 237-288) -------------
+// One wavefront per syndrome that BP left unconverged.  The reference sorts the columns by ascending
+// log-ratio (glibc qsort: stable, so ties keep ascending index), runs a greedy column-ordered Gaussian
+// elimination on a linked-list matrix until the syndrome is in the span of the pivots, and solves on
+// the pivot columns.  That solution is unique given the column order (the reference's min-row-weight
+// pivoting only picks which ROW carries a pivot), so here the augmented matrix [H | s] lives bit-packed
+// in LDS (lane l owns rows l, l+64, ...), columns are visited in rank order and eliminated
+// Gauss-Jordan style with wave ballots.  All LDS traffic is wave-private: no workgroup barriers.
+struct OsdArgs {
+    int32_t m, n, words;  // words = ceil((n + 1) / 64): n matrix bits + the syndrome bit per row
+    int64_t batch;
+    const int32_t *row_ptr, *col_idx;
+    const uint8_t *synd;   // [batch][m]
+    const double *llr;     // [batch][n]  BP posteriors
+    const uint8_t *conv;   // [batch]     1 = BP converged: row left untouched
+    uint8_t *decoding;     // [batch][n]  in: BP decisions, out: OSD solution for unconverged rows
+    int32_t lds_per_wave;  // bytes
+    int32_t method, order; // osdw_kernel: 2 = exhaustive (OSD_E), 3 = combination sweep (OSD_CS); order > 0
+    const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
+};
+
+__device__ __forceinline__ bool osd_less(double a, int ia, double b, int ib) {
+    const bool na = a != a, nb = b != b;
+    if (na || nb) return na == nb ? ia < ib : nb;  // numbers before NaNs (reference order undefined for NaN)
+    if (a < b) return true;
+    if (a > b) return false;
+    return ia < ib;  // stable: ties in ascending index, as glibc's merge-sort qsort leaves them
+}
+
+__global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
+    const int m = a.m, n = a.n, W = a.words;
+    unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
+    volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                  // [m][W]
+    volatile double *keys = reinterpret_cast<volatile double *>(base + (size_t)m * W * 8);  // [n]
+    volatile int32_t *order = reinterpret_cast<volatile int32_t *>(base + (size_t)m * W * 8 + (size_t)n * 8);  // [n]
+    volatile int32_t *pivot_col = order + n;                                                // [m]
+    volatile uint8_t *x = reinterpret_cast<volatile uint8_t *>(const_cast<int32_t *>(pivot_col + m));  // [n]
+
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int i = lane; i < m; i += 64) {
+        for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
+        for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+            const int c = a.col_idx[e];
+            mat[(size_t)i * W + (c >> 6)] = mat[(size_t)i * W + (c >> 6)] | (1ull << (c & 63));
+        }
+        if (a.synd[b * m + i]) mat[(size_t)i * W + sw] = mat[(size_t)i * W + sw] | sbit;  // `if (i)`, gf2sparse_linalg.hpp:309
+        pivot_col[i] = -1;
+    }
+    for (int j = lane; j < n; j += 64) { keys[j] = a.llr[b * n + j]; x[j] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    // soft_decision_col_sort: rank of column i = number of columns that sort before it
+    for (int i = lane; i < n; i += 64) {
+        const double ki = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += osd_less(keys[j], j, ki, i) ? 1 : 0;
+        order[r] = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int max_rank = m < n ? m : n;
+    int rank = 0;
+    for (int t = 0; t < n && rank < max_rank; ++t) {
+        const int c = order[t];
+        const int cw = c >> 6;
+        const uint64_t cb = 1ull << (c & 63);
+        // first unpivoted row with a one in column c
+        int p = -1;
+        for (int i0 = 0; i0 < m && p < 0; i0 += 64) {
+            const int i = i0 + lane;
+            const bool cand = i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + cw] & cb);
+            const uint64_t mask = __ballot(cand);
+            if (mask) p = i0 + __builtin_ctzll(mask);
+        }
+        if (p < 0) continue;
+        for (int i = lane; i < m; i += 64)
+            if (i != p && (mat[(size_t)i * W + cw] & cb))
+                for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = mat[(size_t)i * W + w] ^ mat[(size_t)p * W + w];
+        if (lane == 0) pivot_col[p] = c;
+        ++rank;
+        __builtin_amdgcn_wave_barrier();
+        // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
+        bool pending = false;
+        for (int i0 = 0; i0 < m && !pending; i0 += 64) {
+            const int i = i0 + lane;
+            pending = __ballot(i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + sw] & sbit)) != 0;
+        }
+        if (!pending) break;
+    }
+    for (int i = lane; i < m; i += 64)
+        if (pivot_col[i] >= 0 && (mat[(size_t)i * W + sw] & sbit)) x[pivot_col[i]] = 1;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = x[j];
+}
+
+// ---- higher-order OSD (osd.hpp:119-187): OSD_E / OSD_CS, one wavefront per unconverged syndrome ---------------
+// After the column sort the matrix is brought to REDUCED row echelon form over the sorted columns (no early
+// stop).  Then no candidate needs a solve of its own: flipping the non-pivot columns F changes the solution on
+// the pivot column of row r by XOR_{f in F} R[r][f] (R = the reduced matrix), so a candidate is the OSD-0
+// solution, a mask over the non-pivot columns, and one parity per pivot row.  Candidates are spread over the
+// lanes; each lane adds up its candidate's weight in ascending bit order exactly as the reference does
+// (sequential FP64 sum of log(1/p_j) over the support), and the first strictly lightest candidate wins.
+struct OsdCandidate {
+    uint64_t mask;  // chosen columns among the first 64 non-pivot columns (sorted order)
+    int32_t single; // a chosen non-pivot column beyond the first 64 (OSD_CS weight-one strings), else -1
+    bool valid;
+};
+
+__device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int k, long c) {
+    OsdCandidate r;
+    r.mask = 0;
+    r.single = -1;
+    r.valid = true;
+    const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    if (method == 2) {  // numbers 1 .. 2^order - 1, bit j -> j-th non-pivot column, bits >= k dropped (util.hpp:12-38)
+        r.mask = (uint64_t)(c + 1) & kmask;
+    } else if (c < k) {  // weight one, every non-pivot column (osd.hpp:84-89)
+        if (c < 64) r.mask = 1ull << c; else r.single = (int32_t)c;
+    } else {  // pairs (i, j), i < j < order, i-major (osd.hpp:91-99)
+        long p = c - k;
+        int i = 0;
+        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
+        const int j = i + 1 + (int)p;
+        if (j >= k) r.valid = false;  // past the candidate string in the reference
+        else r.mask = (1ull << i) | (1ull << j);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
+    const int m = a.m, n = a.n, W = a.words;
+    unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
+    volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                         // [m][W]
+    volatile uint64_t *T = mat + (size_t)m * W;                                                   // [m]
+    volatile double *keys = reinterpret_cast<volatile double *>(const_cast<uint64_t *>(T + m));   // [n] log-ratios, later weights
+    volatile int32_t *order = reinterpret_cast<volatile int32_t *>(const_cast<double *>(keys + n));  // [n]
+    volatile int32_t *code = order + n;       // [n] pivot column: its row; non-pivot column: -1 - position among the non-pivots
+    volatile int32_t *npcol = code + n;       // [n] non-pivot columns in sorted order
+    volatile int32_t *pivot_col = npcol + n;  // [m]
+
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int i = lane; i < m; i += 64) {
+        for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
+        for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+            const int c = a.col_idx[e];
+            mat[(size_t)i * W + (c >> 6)] = mat[(size_t)i * W + (c >> 6)] | (1ull << (c & 63));
+        }
+        if (a.synd[b * m + i]) mat[(size_t)i * W + sw] = mat[(size_t)i * W + sw] | sbit;
+        pivot_col[i] = -1;
+    }
+    for (int j = lane; j < n; j += 64) { keys[j] = a.llr[b * n + j]; code[j] = INT32_MIN; }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) {  // soft_decision_col_sort (sort.hpp:48-62)
+        const double ki = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += osd_less(keys[j], j, ki, i) ? 1 : 0;
+        order[r] = i;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // rref over the sorted columns (gf2sparse_linalg.hpp:132-226), rows fully reduced
+    const int max_rank = m < n ? m : n;
+    int rank = 0;
+    for (int t = 0; t < n && rank < max_rank; ++t) {
+        const int c = order[t];
+        const int cw = c >> 6;
+        const uint64_t cb = 1ull << (c & 63);
+        int p = -1;
+        for (int i0 = 0; i0 < m && p < 0; i0 += 64) {
+            const int i = i0 + lane;
+            const bool cand = i < m && pivot_col[i] < 0 && (mat[(size_t)i * W + cw] & cb);
+            const uint64_t mask = __ballot(cand);
+            if (mask) p = i0 + __builtin_ctzll(mask);
+        }
+        if (p < 0) continue;
+        for (int i = lane; i < m; i += 64)
+            if (i != p && (mat[(size_t)i * W + cw] & cb))
+                for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = mat[(size_t)i * W + w] ^ mat[(size_t)p * W + w];
+        if (lane == 0) { pivot_col[p] = c; code[c] = p; }
+        ++rank;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
+    int k = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = t < n ? order[t] : 0;
+        const bool np = t < n && code[c] < 0;
+        const uint64_t mask = __ballot(np);
+        if (np) {
+            const int q = k + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            npcol[q] = c;
+            code[c] = -1 - q;
+        }
+        k += __builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int k64 = k < 64 ? k : 64;
+    for (int r = lane; r < m; r += 64) {  // the reduced matrix on the first 64 non-pivot columns, one word per row
+        uint64_t t = 0;
+        for (int q = 0; q < k64; ++q) {
+            const int c = npcol[q];
+            t |= ((mat[(size_t)r * W + (c >> 6)] >> (c & 63)) & 1ull) << q;
+        }
+        T[r] = t;
+    }
+    for (int j = lane; j < n; j += 64) keys[j] = a.wt[j];
+    __builtin_amdgcn_wave_barrier();
+
+    // weight of a candidate: sum over its support in ascending bit order (osd.hpp:171-176)
+    auto bit_of = [&](const OsdCandidate &cd, int i) -> bool {
+        const int cdi = code[i];
+        if (cdi >= 0) {
+            uint64_t v = (mat[(size_t)cdi * W + sw] >> (n & 63)) ^ (uint64_t)__builtin_popcountll(T[cdi] & cd.mask);
+            if (cd.single >= 0) {
+                const int c = npcol[cd.single];
+                v ^= mat[(size_t)cdi * W + (c >> 6)] >> (c & 63);
+            }
+            return (v & 1ull) != 0;
+        }
+        const int q = -1 - cdi;
+        return (q < 64 && ((cd.mask >> q) & 1ull)) || q == cd.single;
+    };
+    auto weight_of = [&](const OsdCandidate &cd) -> double {
+        double acc = 0;
+        for (int i = 0; i < n; ++i)
+            if (bit_of(cd, i)) acc += keys[i];
+        return acc;
+    };
+    OsdCandidate none;
+    none.mask = 0; none.single = -1; none.valid = true;
+    const double w0 = weight_of(none);  // the OSD-0 solution (osd.hpp:131-136)
+    const long ncand = a.method == 2 ? (1L << a.order) - 1 : (long)k + (long)a.order * (a.order - 1) / 2;
+    double best_w = w0;
+    long best_c = -1;
+    for (long c0 = 0; c0 < ncand; c0 += 64) {
+        const long c = c0 + lane;
+        if (c < ncand) {
+            const OsdCandidate cd = osd_candidate(a.method, a.order, k, c);
+            if (cd.valid) {
+                const double w = weight_of(cd);
+                if (w < best_w) { best_w = w; best_c = c; }  // strict: the first lightest candidate stays (osd.hpp:177)
+            }
+        }
+    }
+    // across lanes: lightest, then earliest
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ow = __shfl_xor(best_w, off);
+        const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
+        const bool mine_set = best_c >= 0, other_set = oc >= 0;
+        if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+    }
+    OsdCandidate win = none;
+    if (best_c >= 0) win = osd_candidate(a.method, a.order, k, best_c);
+    for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = bit_of(win, j) ? 1 : 0;
+}
