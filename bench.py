@@ -102,8 +102,8 @@ def main() -> None:
         eng.decode_batch(synd, want_llr=llr is not None, out=out, asynchronous=True)
         if record:
             kernel_ms.append(eng.last_kernel_ms())  # HIP events around the BP kernel on the launch stream
-        if world > 1:  # the only collective: gather decoded rows (+ flags) onto rank 0
-            gather_rows(dec, total, 0)
+        if world > 1:  # the only collective: gather decoded rows (bit-packed on the device first) + flags onto rank 0
+            gather_rows(eng.pack_b8(dec), total, 0)
             gather_rows(cv, total, 0)
             gather_rows(it, total, 0)
 

@@ -184,6 +184,11 @@ int ldpc_hip_bp_soft_info_decode_batch(ldpc_hip_bp *h, const double *soft_syndro
  * _bposd_decoder.pyx:118-123).  Host or device pointers.
  */
 int ldpc_hip_bp_set_observables(ldpc_hip_bp *h, int32_t k, const int32_t *csr_row_ptr, const int32_t *csr_col_idx);
+/* [batch][bits] one byte per bit <-> [batch][ceil(bits/8)] b8 rows, device pointers only, queued on the handle's
+ * stream without synchronisation.  For packing decodings before they cross a link (the multi-GPU gather of
+ * bench.py / ldpc_amd.sharding sends 1/8 of the bytes this way). */
+int ldpc_hip_pack_b8(ldpc_hip_bp *h, const uint8_t *bytes, int64_t batch, int32_t bits, uint8_t *packed);
+int ldpc_hip_unpack_b8(ldpc_hip_bp *h, const uint8_t *packed, int64_t batch, int32_t bits, uint8_t *bytes);
 int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch, int32_t with_osd, uint8_t *obs_b8,
                           uint8_t *decoding_b8, int32_t *iterations, uint8_t *converge);
 

@@ -1033,6 +1033,34 @@ int ldpc_hip_bp_soft_info_decode_batch(ldpc_hip_bp *h, const double *soft_syndro
     return LDPC_HIP_OK;
 }
 
+// device-side conversion between one byte per bit and b8 rows; both buffers are device pointers, work is queued on the
+// handle's stream (no synchronisation): meant for packing results before they cross a link (PCIe, xGMI)
+int ldpc_hip_pack_b8(ldpc_hip_bp *h, const uint8_t *bytes, int64_t batch, int32_t bits, uint8_t *packed) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0 || bits < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch or bits");
+    if (batch == 0 || bits == 0) return LDPC_HIP_OK;
+    if (!bytes || !packed) return fail(LDPC_HIP_ERR_INVALID, "null buffer");
+    if (!is_device_ptr(bytes) || !is_device_ptr(packed)) return fail(LDPC_HIP_ERR_INVALID, "ldpc_hip_pack_b8 takes device pointers");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t total = (size_t)batch * (size_t)((bits + 7) / 8);
+    hipLaunchKernelGGL(pack_b8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, bytes, batch, bits, packed);
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_unpack_b8(ldpc_hip_bp *h, const uint8_t *packed, int64_t batch, int32_t bits, uint8_t *bytes) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (batch < 0 || bits < 0) return fail(LDPC_HIP_ERR_INVALID, "negative batch or bits");
+    if (batch == 0 || bits == 0) return LDPC_HIP_OK;
+    if (!bytes || !packed) return fail(LDPC_HIP_ERR_INVALID, "null buffer");
+    if (!is_device_ptr(bytes) || !is_device_ptr(packed)) return fail(LDPC_HIP_ERR_INVALID, "ldpc_hip_unpack_b8 takes device pointers");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t total = (size_t)batch * (size_t)bits;
+    hipLaunchKernelGGL(unpack_b8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, packed, batch, bits, bytes);
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 int ldpc_hip_bp_set_observables(ldpc_hip_bp *h, int32_t k, const int32_t *csr_row_ptr, const int32_t *csr_col_idx) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     if (k < 0 || !csr_row_ptr) return fail(LDPC_HIP_ERR_INVALID, "observables matrix: k < 0 or null row pointer");

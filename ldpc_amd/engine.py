@@ -200,6 +200,25 @@ class HipBpEngine:
             it.ctypes.data, cv.ctypes.data, so.ctypes.data))
         return dec, llr, it, cv.astype(bool), so
 
+    def pack_b8(self, bits_tensor):
+        """``(B, bits)`` uint8 CUDA tensor (one byte per bit) -> ``(B, ceil(bits / 8))`` packed, on the tensor's stream."""
+        import torch
+        t = bits_tensor.contiguous()
+        b, bits = int(t.shape[0]), int(t.shape[1])
+        self.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+        out = torch.empty((b, (bits + 7) // 8), dtype=torch.uint8, device=t.device)
+        _lib.check(self._lib.ldpc_hip_pack_b8(self._h, t.data_ptr(), b, bits, out.data_ptr()))
+        return out
+
+    def unpack_b8(self, packed_tensor, bits):
+        import torch
+        t = packed_tensor.contiguous()
+        b = int(t.shape[0])
+        self.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+        out = torch.empty((b, int(bits)), dtype=torch.uint8, device=t.device)
+        _lib.check(self._lib.ldpc_hip_unpack_b8(self._h, t.data_ptr(), b, int(bits), out.data_ptr()))
+        return out
+
     def set_observables(self, observables_matrix):
         """The k x n matrix whose product with a decoding gives the predicted observables (``decode_b8``)."""
         import scipy.sparse as sp

@@ -54,13 +54,17 @@ def gather_rows(local: torch.Tensor, total_rows: int, dst: int = 0) -> Optional[
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
-def decode_sharded(decode_fn, syndromes_local: torch.Tensor, total_rows: int, dst: int = 0):
+def decode_sharded(decode_fn, syndromes_local: torch.Tensor, total_rows: int, dst: int = 0, pack=None):
     """Decode this rank's shard with ``decode_fn`` and gather ``(decoding, converge, iterations)`` on ``dst``.
+
+    ``pack`` (e.g. ``HipBpEngine.pack_b8``) is applied to the decoded rows before the collective: bit-packed rows
+    are 1/8 of the bytes on the wire; ``dst`` then receives ``(total_rows, ceil(n / 8))`` b8 rows.
 
     ``decode_fn(syndromes) -> (decoding, llr_or_None, iterations, converge)`` is e.g.
     ``HipBpEngine.decode_batch``.  LLRs stay sharded on the rank that produced them (they are 8x the
     size of the decisions and normally consumed locally).
     """
     dec, llr, it, cv = decode_fn(syndromes_local)
-    out = (gather_rows(dec, total_rows, dst), gather_rows(cv, total_rows, dst), gather_rows(it, total_rows, dst))
+    out = (gather_rows(pack(dec) if pack is not None else dec, total_rows, dst), gather_rows(cv, total_rows, dst),
+           gather_rows(it, total_rows, dst))
     return out, llr

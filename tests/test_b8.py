@@ -108,3 +108,17 @@ def test_b8_argument_errors():
         eng.decode_b8(np.zeros((2, 2), np.uint8))
     obs, _, it, cv = eng.decode_b8(np.array([[0b101], [0]], np.uint8))
     assert obs.shape == (2, 1) and cv[1] and it[1] == 0
+
+
+@pytest.mark.gpu
+def test_pack_unpack_b8_on_device():
+    import torch
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(codes.hamming_code(3))
+    eng = HipBpEngine(h.indptr, h.indices, 7, np.full(7, 0.1), 5, 0, 1.0)
+    rng = np.random.default_rng(1)
+    for bits in (1, 7, 8, 9, 441, 10000):
+        x = (rng.random((67, bits)) < 0.4).astype(np.uint8)
+        packed = eng.pack_b8(torch.from_numpy(x).cuda())
+        assert np.array_equal(packed.cpu().numpy(), _pack(x))
+        assert np.array_equal(eng.unpack_b8(packed, bits).cpu().numpy(), x)
