@@ -1,0 +1,111 @@
+"""Randomised differential test of the device path against the CPU oracle (which is itself pinned to the real reference):
+random sparse matrices (irregular degrees, empty rows and columns, rows heavier than every register bound), random
+priors including 0.5 and above, every kernel family (streaming, per-pass, on-chip, serial, OSD, soft syndromes), ragged
+batches.  Seeds are fixed: a failure is reproducible."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_code(rng, kind):
+    if kind == "tiny":
+        m, n, dens = int(rng.integers(1, 9)), int(rng.integers(2, 13)), rng.uniform(0.15, 0.7)
+    elif kind == "wide_rows":  # rows far heavier than the 16-entry register bound
+        m, n, dens = int(rng.integers(3, 8)), int(rng.integers(40, 90)), rng.uniform(0.3, 0.6)
+    elif kind == "tall_cols":
+        m, n, dens = int(rng.integers(30, 70)), int(rng.integers(4, 12)), rng.uniform(0.3, 0.7)
+    else:
+        m, n, dens = int(rng.integers(10, 60)), int(rng.integers(20, 130)), rng.uniform(0.03, 0.15)
+    h = (rng.random((m, n)) < dens).astype(np.uint8)
+    if kind == "sparse" and m > 3:
+        h[int(rng.integers(m))] = 0  # an empty check
+        h[:, int(rng.integers(n))] = 0  # an isolated bit
+    return sp.csr_matrix(h)
+
+
+def _priors(rng, n, style):
+    if style == 0:
+        return np.full(n, float(rng.uniform(0.01, 0.2)))
+    p = rng.uniform(0.005, 0.3, size=n)
+    if style == 2:
+        p[rng.integers(n)] = 0.5
+        p[rng.integers(n)] = 0.8
+    return p
+
+
+def _syndromes(rng, h, batch, raw_bytes):
+    m, n = h.shape
+    e = (rng.random((batch, n)) < 0.1).astype(np.uint8)
+    s = np.ascontiguousarray((h @ e.T % 2).T.astype(np.uint8)).reshape(batch, m)
+    if raw_bytes and m:
+        s[rng.integers(batch), rng.integers(m)] = 3  # a byte > 1: never converges, sign / parity semantics differ
+    return s
+
+
+CASES = [(seed, kind) for seed in range(6) for kind in ("tiny", "wide_rows", "tall_cols", "sparse")]
+
+
+@pytest.mark.parametrize("seed,kind", CASES)
+def test_parallel_schedule_random_codes(seed, kind, oracle_built):
+    from ldpc_amd.engine import HipBpEngine
+    rng = np.random.default_rng(1000 + seed * 17 + ("tiny", "wide_rows", "tall_cols", "sparse").index(kind))
+    h = _random_code(rng, kind)
+    m, n = h.shape
+    for method, alpha in (("product_sum", 1.0), ("minimum_sum", float(rng.choice([0.0, 0.625, 1.0])))):
+        probs = _priors(rng, n, int(rng.integers(3)))
+        max_iter = int(rng.integers(1, 12))
+        batch = int(rng.choice([1, 63, 64, 65, 130]))
+        s = _syndromes(rng, h, batch, raw_bytes=seed % 2 == 0)
+        o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
+        want = o.decode_batch(s)
+        eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 0 if method == "product_sum" else 1, alpha)
+        for small, handoff in ((-1, -1), (0, 0), (0, 100000), (1, -1)):
+            eng.set_small_code_kernel(small)
+            eng.set_handoff(handoff)
+            got = eng.decode_batch(s)
+            tag = f"{kind} seed {seed} {method} small={small} handoff={handoff} m={m} n={n} B={batch} it={max_iter}"
+            assert np.array_equal(got[0], want[0]), "decoding: " + tag
+            assert np.array_equal(got[3], want[3]) and np.array_equal(got[2], want[2]), "converge / iterations: " + tag
+            assert bits_equal(got[1], want[1]), "log-ratios: " + tag
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_serial_osd_and_soft_random_codes(seed, oracle_built):
+    from ldpc_amd.engine import HipBpEngine
+    rng = np.random.default_rng(77 + seed)
+    h = _random_code(rng, "sparse" if seed % 2 else "tiny")
+    m, n = h.shape
+    probs = _priors(rng, n, 1)
+    max_iter = int(rng.integers(1, 8))
+    batch = int(rng.choice([5, 64, 97]))
+    s = _syndromes(rng, h, batch, raw_bytes=False)
+    for method, alpha in (("product_sum", 1.0), ("minimum_sum", 0.75)):
+        o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
+        eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 0 if method == "product_sum" else 1, alpha)
+        # serial schedule with a random order
+        order = rng.permutation(n).astype(np.int32)
+        want = o.decode_serial_batch(s, order)
+        eng.set_schedule("serial", order)
+        got = eng.decode_batch(s)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+        assert bits_equal(got[1], want[1])
+        eng.set_schedule("parallel")
+        # BP + OSD of every kind (syndromes are H e, hence in the image of H)
+        for osd_method, osd_order in ((1, 0), (3, int(rng.integers(1, 9))), (2, int(rng.integers(1, 7)))):
+            want = o.bposd_decode_batch(s, osd_method, osd_order)
+            eng.set_osd(osd_method, osd_order)
+            got = eng.decode_batch(s, osd=True)
+            assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} seed {seed} {method} m={m} n={n}"
+            assert np.array_equal(got[3], want[3])
+    # soft syndromes (always serial minimum-sum)
+    soft = rng.normal(scale=2.0, size=(batch, m))
+    o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method="minimum_sum", ms_scaling_factor=0.9)
+    eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 1, 0.9)
+    want = o.soft_info_decode_batch(soft, 3.0, 1.5)
+    got = eng.soft_info_decode_batch(soft, 3.0, 1.5)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    assert bits_equal(got[1], want[1]) and bits_equal(got[4], want[4])
