@@ -245,9 +245,11 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
 
 /* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)
- * are decoded by an on-chip kernel: messages live in LDS, a workgroup keeps several syndromes resident and
- * replaces each one the moment it converges.  mode -1 = automatic (default), 0 = always use the streaming
- * kernel, 1 = use the on-chip kernel whenever one syndrome fits in LDS.  Results are identical. */
+ * are decoded by on-chip kernels: messages live in LDS and a syndrome that converges is replaced at once.
+ * Two variants: one wavefront per syndrome with no workgroup barrier in the loop (row and column weights <= 8),
+ * and a workgroup that keeps up to four syndromes resident (any degrees).  mode -1 = automatic (default),
+ * 0 = always use the streaming kernel, 1 = use an on-chip kernel whenever one syndrome fits in LDS,
+ * 2 = as 1 but only the workgroup ("slot") variant.  Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 
 #define LDPC_HIP_MATH_LIBM_EXACT 0

@@ -33,7 +33,8 @@
 //   bp_math.h            tanh / log / division: bit-identical twins of the host libm + the fast variants
 //   bp_stream_kernel.h   bp_decode_kernel        persistent workgroup per 64-syndrome tile (register / LDS-ring variants)
 //   bp_spread_kernels.h  bp_spread_*_kernel      one launch per pass, a tile spread over the chip (small batches, stragglers)
-//   bp_small_kernel.h    bp_small_kernel         messages resident in LDS (surface / bivariate-bicycle sized codes)
+//   bp_small_kernel.h    bp_small_kernel         messages resident in LDS (surface / bivariate-bicycle sized codes), slots per workgroup
+//   bp_wave_kernel.h     bp_wave_kernel          same regime, bounded degrees: one wavefront per syndrome, no workgroup barriers
 //   bp_serial_kernels.h  bp_serial_kernel, bp_softinfo_kernel   serial schedule, soft-syndrome serial min-sum
 //   osd_kernels.h        osd0_kernel, osdw_kernel               OSD-0 / OSD-E / OSD-CS post-processing
 //   io_kernels.h         pack / unpack / transpose, H v, b8 shot data, synthetic BSC shots
@@ -43,6 +44,7 @@
 #include "bp_spread_kernels.h"
 #include "bp_serial_kernels.h"
 #include "bp_small_kernel.h"
+#include "bp_wave_kernel.h"
 #include "osd_kernels.h"
 #include "io_kernels.h"
 
@@ -99,7 +101,10 @@ struct ldpc_hip_bp {
     int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
     bool regular = false;   // every row has the same weight and every column has the same weight
     int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
-    int32_t small_mode = -1; // on-chip kernel for small codes: -1 auto, 0 never, 1 whenever it fits
+    int32_t small_mode = -1; // on-chip kernels for small codes: -1 auto, 0 never, 1 whenever one fits, 2 the slot kernel only
+    std::vector<int32_t> h_row_ptr, h_col_idx;  // host copy of the CSR arrays
+    int wave_dr = 0, wave_dc = 0;  // template bounds the uploaded SoA position tables of bp_wave_kernel were built for (0: none)
+    DeviceBuf w_rdeg, w_cdeg, w_col, w_cpos, w_apos;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
@@ -234,6 +239,8 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
 #undef ALLOC_COPY
     int rc = upload_priors(h);
     if (rc) { ldpc_hip_bp_destroy(h); return rc; }
+    h->h_row_ptr.assign(d->csr_row_ptr, d->csr_row_ptr + d->m + 1);  // kept for tables that are built on first use
+    h->h_col_idx.assign(d->csr_col_idx, d->csr_col_idx + d->nnz);
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -251,7 +258,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_cpos, &h->w_apos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -345,7 +352,7 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
 
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 1) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (whenever it fits)");
+    if (mode < -1 || mode > 2) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits) or 2 (slot kernel only)");
     h->small_mode = mode;
     return LDPC_HIP_OK;
 }
@@ -636,6 +643,109 @@ static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint
     return LDPC_HIP_OK;
 }
 
+// bp_wave_kernel: template bounds, launch shape and LDS split; waves == 0: not applicable (degrees, table range, LDS)
+struct WavePlan {
+    int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, mp = 0, np = 0;
+    size_t shared = 0, per_wave = 0;
+    void (*kern)(const WaveArgs) = nullptr;
+};
+
+template <int METHOD, int MATH>
+static void pick_wave(int max_row, int max_col, WavePlan &p) {
+    if (max_row <= 4 && max_col <= 2) { p.dr = 4; p.dc = 2; p.kern = bp_wave_kernel<METHOD, MATH, 4, 2>; return; }
+    if (max_row <= 4 && max_col <= 4) { p.dr = 4; p.dc = 4; p.kern = bp_wave_kernel<METHOD, MATH, 4, 4>; return; }
+    if (max_row <= 6 && max_col <= 3) { p.dr = 6; p.dc = 3; p.kern = bp_wave_kernel<METHOD, MATH, 6, 3>; return; }
+    if (max_col <= 4) { p.dr = 8; p.dc = 4; p.kern = bp_wave_kernel<METHOD, MATH, 8, 4>; return; }
+    p.dr = 8; p.dc = 8; p.kern = bp_wave_kernel<METHOD, MATH, 8, 8>;
+}
+
+static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced) {
+    WavePlan p;
+    if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 8) return p;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_wave<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, p);
+    else pick_wave<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
+    p.mp = (h->m + 63) / 64 * 64;
+    p.np = (h->n + 63) / 64 * 64;
+    const size_t rm = (size_t)p.dr * p.mp, cn = (size_t)p.dc * p.np;
+    if (rm + 2 >= 65536 || cn + 2 >= 65536) return p;                 // positions are 16 bits
+    if (!forced && rm + cn > 3 * (size_t)h->nnz + 1024) return p;      // a few heavy nodes would pad every row / column
+    p.shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc);
+    p.per_wave = wave_lds_private(p.mp, p.np, p.dr, p.dc);
+    const size_t lds = 160u * 1024u;  // per compute unit
+    for (int w : {4, 2, 1})
+        if (p.shared + (size_t)w * p.per_wave <= (forced ? lds : lds / 2)) { p.waves = w; break; }
+    if (!p.waves) return p;
+    p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
+    if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;  // 32 wavefronts per compute unit
+    return p;
+}
+
+// structure-of-arrays position tables of bp_wave_kernel for the bounds (dr, dc): see bp_wave_kernel.h
+static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
+    if (h->wave_dr == p.dr && h->wave_dc == p.dc) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n, mp = p.mp, np = p.np;
+    const size_t rm = (size_t)p.dr * mp, cn = (size_t)p.dc * np;
+    std::vector<uint8_t> rdeg((size_t)mp, 0), cdeg((size_t)np, 0);
+    std::vector<uint16_t> wcol(rm, (uint16_t)np), wcpos(rm, (uint16_t)cn), wapos(cn, (uint16_t)rm);  // phantom defaults
+    std::vector<int32_t> seen((size_t)n, 0);  // entries of column j met so far = rank of the next one inside the column
+    for (int i = 0; i < m; ++i) {
+        const int lo = h->h_row_ptr[(size_t)i];
+        rdeg[(size_t)i] = (uint8_t)(h->h_row_ptr[(size_t)i + 1] - lo);
+        for (int e = lo; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int k = e - lo, j = h->h_col_idx[(size_t)e], kc = seen[(size_t)j]++;  // rows ascend: kc is the CSC order
+            wcol[(size_t)k * mp + i] = (uint16_t)j;
+            wcpos[(size_t)k * mp + i] = (uint16_t)((size_t)kc * np + j);
+            wapos[(size_t)kc * np + j] = (uint16_t)((size_t)k * mp + i);
+        }
+    }
+    for (int j = 0; j < n; ++j) cdeg[(size_t)j] = (uint8_t)seen[(size_t)j];
+    int rc;
+    if ((rc = h->w_rdeg.ensure(rdeg.size())) || (rc = h->w_cdeg.ensure(cdeg.size())) || (rc = h->w_col.ensure(rm * 2)) ||
+        (rc = h->w_cpos.ensure(rm * 2)) || (rc = h->w_apos.ensure(cn * 2))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
+    HIPCHK(hipMemcpy(h->w_rdeg.p, rdeg.data(), rdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_cdeg.p, cdeg.data(), cdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_col.p, wcol.data(), rm * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_cpos.p, wcpos.data(), rm * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_apos.p, wapos.data(), cn * 2, hipMemcpyHostToDevice));
+    h->wave_dr = p.dr;
+    h->wave_dc = p.dc;
+    return LDPC_HIP_OK;
+}
+
+// Wavefront-per-syndrome on-chip variant (bp_wave_kernel).  Device pointers, on h->stream.
+static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                       int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_wave_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    WaveArgs a = {};
+    a.m = h->m; a.n = h->n; a.mp = p.mp; a.np = p.np; a.max_iter = h->max_iter;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.rdeg = (const uint8_t *)h->w_rdeg.p; a.cdeg = (const uint8_t *)h->w_cdeg.p;
+    a.col = (const uint16_t *)h->w_col.p; a.cpos = (const uint16_t *)h->w_cpos.p; a.apos = (const uint16_t *)h->w_apos.p;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+    const size_t dyn = p.shared + (size_t)p.waves * p.per_wave;
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int64_t groups = (batch + p.waves - 1) / p.waves;
+    const int64_t resident = 256 * (int64_t)p.groups_per_cu;
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 static void pick_spread(const ldpc_hip_bp *h, spread_kernel_t &kc, spread_kernel_t &kb) {
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, kc, kb);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, kc, kb);
@@ -649,10 +759,15 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if (tiles_total == 0) return LDPC_HIP_OK;
     if (h->schedule == 0) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
     if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
-        // small code: keep the messages on chip.  auto: the most resident syndromes (<= 4) per workgroup that
-        // still leave four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
+        // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
+        // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
+        // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
+        if (h->small_mode != 2) {
+            const WavePlan wp = plan_wave(h, h->small_mode == 1);
+            if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
+        }
         int slots = 0;
-        const size_t budget = h->small_mode == 1 ? 150u * 1024u : 39u * 1024u + 512u;
+        const size_t budget = h->small_mode >= 1 ? 150u * 1024u : 39u * 1024u + 512u;
         for (int sl = 4; sl >= 1 && !slots; --sl)
             if (small_lds_bytes(h, sl) <= budget) slots = sl;
         if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);

@@ -106,7 +106,7 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_set_osd(self._h, int(osd_method), int(osd_order)))
 
     def set_small_code_kernel(self, mode):
-        """On-chip kernel for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS."""
+        """On-chip kernels for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS, 2 slot kernel only."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))
 
     def workspace_bytes(self, batch):
