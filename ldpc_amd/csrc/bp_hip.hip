@@ -104,7 +104,7 @@ struct ldpc_hip_bp {
     int32_t small_mode = -1; // on-chip kernels for small codes: -1 auto, 0 never, 1 whenever one fits, 2 the slot kernel only
     std::vector<int32_t> h_row_ptr, h_col_idx;  // host copy of the CSR arrays
     int wave_dr = 0, wave_dc = 0;  // template bounds the uploaded SoA position tables of bp_wave_kernel were built for (0: none)
-    DeviceBuf w_rdeg, w_cdeg, w_col, w_cpos, w_apos;
+    DeviceBuf w_rdeg, w_cdeg, w_col, w_apos;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
@@ -258,7 +258,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_cpos, &h->w_apos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -659,7 +659,7 @@ static void pick_wave(int max_row, int max_col, WavePlan &p) {
     p.dr = 8; p.dc = 8; p.kern = bp_wave_kernel<METHOD, MATH, 8, 8>;
 }
 
-static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced) {
+static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     WavePlan p;
     if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 8) return p;
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_wave<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
@@ -668,16 +668,22 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced) {
     p.mp = (h->m + 63) / 64 * 64;
     p.np = (h->n + 63) / 64 * 64;
     const size_t rm = (size_t)p.dr * p.mp, cn = (size_t)p.dc * p.np;
-    if (rm + 2 >= 65536 || cn + 2 >= 65536) return p;                 // positions are 16 bits
-    if (!forced && rm + cn > 3 * (size_t)h->nnz + 1024) return p;      // a few heavy nodes would pad every row / column
-    p.shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc);
-    p.per_wave = wave_lds_private(p.mp, p.np, p.dr, p.dc);
-    const size_t lds = 160u * 1024u;  // per compute unit
-    for (int w : {4, 2, 1})
-        if (p.shared + (size_t)w * p.per_wave <= (forced ? lds : lds / 2)) { p.waves = w; break; }
-    if (!p.waves) return p;
+    if (rm + 2 >= 65536 || p.np + 1 >= 65536) return p;               // positions and column numbers are 16 bits
+    if (!forced && rm > 2 * (size_t)h->nnz + 1024) return p;          // a few heavy rows would pad every row
+    p.shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc, h->bp_method == LDPC_HIP_PRODUCT_SUM);
+    p.per_wave = wave_lds_private(p.mp, p.np, p.dr, want_llr);
+    (void)cn;
+    // one workgroup per compute unit with as many wavefronts as LDS (160 KiB) and the 16-wave workgroup limit allow;
+    // small codes fit several such workgroups
+    const size_t lds = 160u * 1024u;
+    if (p.shared + p.per_wave > lds) return p;
+    size_t w = (lds - p.shared) / p.per_wave;
+    if (w > 16) w = 16;
+    if (!forced && w < 4) return p;  // too few wavefronts to hide any latency: the slot kernel or streaming does better
+    p.waves = (int)w;
     p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
     if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;  // 32 wavefronts per compute unit
+    if (p.groups_per_cu < 1) p.groups_per_cu = 1;
     return p;
 }
 
@@ -687,7 +693,7 @@ static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
     const int m = h->m, n = h->n, mp = p.mp, np = p.np;
     const size_t rm = (size_t)p.dr * mp, cn = (size_t)p.dc * np;
     std::vector<uint8_t> rdeg((size_t)mp, 0), cdeg((size_t)np, 0);
-    std::vector<uint16_t> wcol(rm, (uint16_t)np), wcpos(rm, (uint16_t)cn), wapos(cn, (uint16_t)rm);  // phantom defaults
+    std::vector<uint16_t> wcol(rm, (uint16_t)np), wapos(cn, (uint16_t)(rm + 1));  // phantom defaults
     std::vector<int32_t> seen((size_t)n, 0);  // entries of column j met so far = rank of the next one inside the column
     for (int i = 0; i < m; ++i) {
         const int lo = h->h_row_ptr[(size_t)i];
@@ -695,19 +701,17 @@ static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
         for (int e = lo; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
             const int k = e - lo, j = h->h_col_idx[(size_t)e], kc = seen[(size_t)j]++;  // rows ascend: kc is the CSC order
             wcol[(size_t)k * mp + i] = (uint16_t)j;
-            wcpos[(size_t)k * mp + i] = (uint16_t)((size_t)kc * np + j);
             wapos[(size_t)kc * np + j] = (uint16_t)((size_t)k * mp + i);
         }
     }
     for (int j = 0; j < n; ++j) cdeg[(size_t)j] = (uint8_t)seen[(size_t)j];
     int rc;
     if ((rc = h->w_rdeg.ensure(rdeg.size())) || (rc = h->w_cdeg.ensure(cdeg.size())) || (rc = h->w_col.ensure(rm * 2)) ||
-        (rc = h->w_cpos.ensure(rm * 2)) || (rc = h->w_apos.ensure(cn * 2))) return rc;
+        (rc = h->w_apos.ensure(cn * 2))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
     HIPCHK(hipMemcpy(h->w_rdeg.p, rdeg.data(), rdeg.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->w_cdeg.p, cdeg.data(), cdeg.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->w_col.p, wcol.data(), rm * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->w_cpos.p, wcpos.data(), rm * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->w_apos.p, wapos.data(), cn * 2, hipMemcpyHostToDevice));
     h->wave_dr = p.dr;
     h->wave_dc = p.dc;
@@ -726,7 +730,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     a.ms_scaling_factor = h->ms_scaling_factor;
     a.batch = batch;
     a.rdeg = (const uint8_t *)h->w_rdeg.p; a.cdeg = (const uint8_t *)h->w_cdeg.p;
-    a.col = (const uint16_t *)h->w_col.p; a.cpos = (const uint16_t *)h->w_cpos.p; a.apos = (const uint16_t *)h->w_apos.p;
+    a.col = (const uint16_t *)h->w_col.p; a.apos = (const uint16_t *)h->w_apos.p;
     a.llr0 = h->d_llr0;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.next = (unsigned long long *)h->counter.p;
@@ -763,7 +767,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
         if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1);
+            const WavePlan wp = plan_wave(h, h->small_mode == 1, llr != nullptr);
             if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
         }
         int slots = 0;

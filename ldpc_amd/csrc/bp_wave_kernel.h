@@ -5,30 +5,32 @@
 #include "bp_device_common.h"
 
 // ---- wavefront-per-syndrome variant for small codes with bounded degrees (BASELINE configs 3 and 5) --------
-// Lane = NODE.  A wavefront owns one syndrome: its two message arrays live in a wave-private LDS region, the check
-// pass gives lane l the checks l, l+64, ..., the bit pass the bits l, l+64, ...  Nothing but wave-level ordering is
-// needed between the passes (LDS operations of a wavefront complete in order), so there is NO workgroup barrier in
-// the decode loop and a wavefront that finishes its syndrome pulls the next one from a device-wide counter at once:
-// work is proportional to the iterations each syndrome really needs.
+// Lane = NODE.  A wavefront owns one syndrome; its messages live in a wave-private LDS region, the check pass gives
+// lane l the checks l, l+64, ..., the bit pass the bits l, l+64, ...  Nothing but wave-level ordering is needed between
+// the passes (LDS operations of a wavefront complete in order), so there is NO workgroup barrier in the decode loop and
+// a wavefront that finishes its syndrome pulls the next one from a device-wide counter at once: work is proportional
+// to the iterations each syndrome really needs.
 //
-// Both arrays are kept "structure of arrays" with padded strides mp = roundup(m, 64), np = roundup(n, 64): the k-th
-// entry of row i sits at A[k * mp + i], the k-th entry of column j at C[k * np + j], k < DR resp. DC (the template
-// bounds).  Every READ of a pass is a unit-stride, conflict-free LDS access with no index lookup; the writes go
-// through position tables (u16) built once per decoder.  Rows and columns lighter than the bound, and the padding
-// nodes, own PHANTOM entries that hold the neutral element of the pass (min-sum: +DBL_MAX, product-sum: 1.0 for the
-// check pass; +0.0 for the bit pass) and whose results are written to a dummy slot, so the min-sum arithmetic runs
-// without a single per-entry branch; product-sum only guards its transcendentals.  Neutral elements do not change a
-// single bit: min(x, DBL_MAX) = x, x * 1.0 = x, and a partial sum is never -0.0 (priors are log((1-p)/p), never
-// -0.0), so x + 0.0 = x.  Per node the entries are walked in the reference's order with the reference's two sweeps
-// (bp.hpp:205-218, 278-281 + 313-316): results are bit-identical to every other kernel here and to the reference.
+// ONE message array M, updated in place by both passes (bit->check messages before a check pass, check->bit messages
+// after it): LDS capacity is what limits the wavefronts per compute unit here, and latency hiding needs them.
+// M is "structure of arrays" by rows with the padded stride mp = roundup(m, 64): the k-th entry of row i sits at
+// M[k * mp + i], k < DR (the template bound).  The check pass reads and writes unit-stride, conflict-free, with no
+// index lookup; the bit pass reaches the k-th entry of column j through a position table apos[k * np + j] (u16).
+// Rows / columns lighter than the bound and the padding nodes own PHANTOM entries: in a row they hold the neutral
+// element of the check update for good (min-sum +DBL_MAX, product-sum 1.0; never written: the stores of phantom results
+// are redirected to a dummy slot), in a column they all point at one slot that holds +0.0 for good.  Neutral
+// elements do not change a single bit -- min(x, DBL_MAX) = x, x * 1.0 = x, and a partial sum is never -0.0 (priors are
+// log((1-p)/p), never -0.0), so x + 0.0 = x -- and they let the min-sum arithmetic run without a per-entry branch;
+// product-sum only guards its transcendentals.  Per node the entries are walked in the reference's order with the
+// reference's two sweeps (bp.hpp:205-218, 278-281 + 313-316): results are bit-identical to every other kernel here
+// and to the reference.
 struct WaveArgs {
     int32_t m, n, mp, np, max_iter;
     double ms_scaling_factor;
     int64_t batch;
     const uint8_t *rdeg, *cdeg;  // [mp], [np] node degrees (0 for padding nodes)
     const uint16_t *col;         // [DR * mp] column of the k-th entry of row i at [k * mp + i]; phantom: np
-    const uint16_t *cpos;        // [DR * mp] position in C of that entry; phantom: DC * np (the dummy slot)
-    const uint16_t *apos;        // [DC * np] position in A of the k-th entry of column j at [k * np + j]; phantom: DR * mp
+    const uint16_t *apos;        // [DC * np] position in M of the k-th entry of column j at [k * np + j]; phantom: DR * mp + 1
     const double *llr0;          // [n]
     const uint8_t *synd;         // [batch][m]
     uint8_t *decoding;           // [batch][n]
@@ -40,17 +42,19 @@ struct WaveArgs {
 };
 
 // LDS bytes: shared tables of a workgroup / private region of one wavefront (host and device agree through these)
-__host__ __device__ inline size_t wave_lds_shared(int mp, int np, int DR, int DC) {
-    size_t b = 256 * 8 + (size_t)np * 8 + (size_t)(np + 2) * 8 + (size_t)DR * mp * 4 + (size_t)DC * np * 2 + (size_t)mp + (size_t)np;
+__host__ __device__ inline size_t wave_lds_shared(int mp, int np, int DR, int DC, bool product_sum) {
+    size_t b = (size_t)(np + 2) * 8 + (size_t)DR * mp * 2 + (size_t)DC * np * 2 + (size_t)mp + (size_t)np;
+    b = (b + 15) & ~(size_t)15;
+    if (product_sum) b += (size_t)(np + 2) * 8 + 256 * 8;  // edge form of the priors, log table
     return (b + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t wave_lds_private(int mp, int np, int DR, int DC) {
-    size_t b = ((size_t)DR * mp + 2 + (size_t)DC * np + 2) * 8 + (size_t)(np / 64 + 1) * 8 + (size_t)mp;
+__host__ __device__ inline size_t wave_lds_private(int mp, int np, int DR, bool want_llr) {
+    size_t b = ((size_t)DR * mp + 2) * 8 + (want_llr ? (size_t)np * 8 : 0) + (size_t)(np / 64 + 1) * 8 + (size_t)mp;
     return (b + 15) & ~(size_t)15;
 }
 
 template <int METHOD, int MATH, int DR, int DC>
-__global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
+__global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     // nodes per lane in flight: min-sum has few live values per node, the transcendental chains of product-sum many
     constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : 2) : (DR <= 6 ? 2 : 1);
     constexpr bool PS = METHOD == LDPC_HIP_PRODUCT_SUM;
@@ -59,6 +63,7 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, n = a.n, mp = a.mp, np = a.np, rm = DR * mp, cn = DC * np;
+    const bool want_llr = a.llr != nullptr;
     // Every LDS pointer is typed in the LDS address space from the start: generic ("flat") pointers into LDS make this
     // compiler emit null checks against the shared aperture that it then fails to select for some template variants.
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -66,36 +71,40 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
     typedef __attribute__((address_space(3))) uint16_t lds_u16;
     typedef __attribute__((address_space(3))) uint64_t lds_u64;
     lds_u8 *base = (lds_u8 *)wv_lds;
-    // shared, read-only after the barriers below:
-    // [log table][llr0 np][edge form of llr0, np + 2: entry np = neutral][col][cpos][apos][rdeg][cdeg]
-    lds_f64 *log_tab_l = (lds_f64 *)base;
-    const double *log_tab = reinterpret_cast<const double *>(wv_lds);  // same place, for the math routines' signature
-    lds_f64 *prior = log_tab_l + 256;
-    lds_f64 *pform = prior + np;
-    lds_u16 *col = (lds_u16 *)(pform + np + 2);
-    lds_u16 *cpos = col + rm;
-    lds_u16 *apos = cpos + rm;
+    // shared, read-only after the barriers below: [llr0, np + 2][col][apos][rdeg][cdeg] and for product-sum
+    // [edge form of llr0, np + 2][log table].  Entry np of llr0 / its edge form = what a phantom entry of a row holds.
+    lds_f64 *prior = (lds_f64 *)base;
+    lds_u16 *col = (lds_u16 *)(prior + np + 2);
+    lds_u16 *apos = col + rm;
     lds_u8 *rdeg = (lds_u8 *)(apos + cn);
     lds_u8 *cdeg = rdeg + mp;
-    for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
+    const int ps_off = (int)((((size_t)(np + 2) * 8 + (size_t)rm * 2 + (size_t)cn * 2 + (size_t)mp + (size_t)np) + 15) & ~(size_t)15);
+    lds_f64 *pform = PS ? (lds_f64 *)(base + ps_off) : prior;
+    lds_f64 *log_tab_l = pform + np + 2;
+    const double *log_tab = reinterpret_cast<const double *>(wv_lds + ps_off) + np + 2;  // same place, for the math routines' signature
+    if (PS)
+        for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
     for (int q = tid; q < np; q += T) { prior[q] = q < n ? a.llr0[q] : 1.0; cdeg[q] = a.cdeg[q]; }
     for (int q = tid; q < mp; q += T) rdeg[q] = a.rdeg[q];
-    for (int q = tid; q < rm; q += T) { col[q] = a.col[q]; cpos[q] = a.cpos[q]; }
+    for (int q = tid; q < rm; q += T) col[q] = a.col[q];
     for (int q = tid; q < cn; q += T) apos[q] = a.apos[q];
+    if (tid == 0) prior[np] = DBL_MAX;
     __syncthreads();
-    for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
-    if (tid == 0) pform[np] = PS ? 1.0 : DBL_MAX;  // what a phantom entry of A holds
-    __syncthreads();
+    if (PS) {
+        for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
+        if (tid == 0) pform[np] = 1.0;
+        __syncthreads();
+    }
 
-    // wave-private: [A DR*mp + dummy][C DC*np + dummy][hard decisions np/64 + 1 words, the last one zero][syndrome bytes mp]
+    // wave-private: [M DR*mp][dummy][+0.0][posteriors np, if asked for][hard decisions np/64 + 1 words, the last one zero][syndrome bytes mp]
     lds_u8 *mine = base + a.lds_shared + wave * a.lds_per_wave;
-    lds_f64 *A = (lds_f64 *)mine;
-    lds_f64 *C = A + rm + 2;
-    volatile lds_u64 *hardw = (volatile lds_u64 *)(C + cn + 2);
+    lds_f64 *M = (lds_f64 *)mine;
+    lds_f64 *L = M + rm + 2;
+    volatile lds_u64 *hardw = (volatile lds_u64 *)(L + (want_llr ? np : 0));
     volatile lds_u8 *sy = (volatile lds_u8 *)(hardw + np / 64 + 1);
-    for (int q = lane; q <= cn; q += 64) C[q] = 0.0;  // phantom entries of C stay +0.0 for good (cpos never points at them)
+    const int DUMMY = rm, ZERO = rm + 1;
+    if (lane == 0) { M[ZERO] = 0.0; hardw[np / 64] = 0; }
     for (int q = lane; q < mp; q += 64) sy[q] = 0;
-    if (lane == 0) hardw[np / 64] = 0;
     __builtin_amdgcn_wave_barrier();
 
     for (;;) {
@@ -106,7 +115,7 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
         if (b >= a.batch) break;
         // initialise_log_domain_bp (bp.hpp:147-157) + this syndrome's bytes; phantom entries get the neutral element
         for (int i = lane; i < m; i += 64) sy[i] = a.synd[b * m + i];
-        for (int q = lane; q < rm; q += 64) A[q] = pform[col[q]];
+        for (int q = lane; q < rm; q += 64) M[q] = pform[col[q]];
         __builtin_amdgcn_wave_barrier();
 
         int it = 0;
@@ -114,7 +123,7 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
         do {
             ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
-            // ---- check pass (bp.hpp:201-273), U rows per lane in flight: all loads, then the arithmetic, then the stores ----
+            // ---- check pass (bp.hpp:201-273), in place, U rows per lane in flight: loads, arithmetic, stores ----
             for (int i0 = 0; i0 < mp; i0 += 64 * U) {
                 uint8_t sb[U];
                 int d[U];
@@ -124,9 +133,9 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
                     if (i0 + u * 64 < mp) {  // wave-uniform
                         const int i = i0 + u * 64 + lane;
                         sb[u] = sy[i];
-                        if (PS) d[u] = rdeg[i];
+                        d[u] = rdeg[i];
 #pragma unroll
-                        for (int k = 0; k < DR; ++k) cur[u][k] = A[k * mp + i];
+                        for (int k = 0; k < DR; ++k) cur[u][k] = M[k * mp + i];
                     }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -170,13 +179,13 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
                     if (i0 + u * 64 < mp) {
                         const int i = i0 + u * 64 + lane;
 #pragma unroll
-                        for (int k = 0; k < DR; ++k) C[cpos[k * mp + i]] = out[u][k];  // phantom entries land in the dummy slot
+                        for (int k = 0; k < DR; ++k) M[k < d[u] ? k * mp + i : DUMMY] = out[u][k];  // phantom entries keep their neutral value
                     }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- bit pass (bp.hpp:276-298, 311-318), U bits per lane in flight ----
+            // ---- bit pass (bp.hpp:276-298, 311-318), in place through the position table, U bits per lane in flight ----
             for (int j0 = 0; j0 < np; j0 += 64 * U) {
-                int d[U];
+                int d[U], pos[U][DC];
                 double c[U][DC], pre[U][DC], pr[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
                         pr[u] = prior[j];
                         if (PS) d[u] = cdeg[j];
 #pragma unroll
-                        for (int k = 0; k < DC; ++k) c[u][k] = C[k * np + j];
+                        for (int k = 0; k < DC; ++k) { pos[u][k] = apos[k * np + j]; c[u][k] = M[pos[u][k]]; }  // phantom: the +0.0 slot
                     }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -193,6 +202,7 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
                         double temp = pr[u];
 #pragma unroll
                         for (int k = 0; k < DC; ++k) { pre[u][k] = temp; temp += c[u][k]; }
+                        if (want_llr) L[j0 + u * 64 + lane] = temp;
                         const uint64_t word = __ballot(temp <= 0);  // padding bits: prior 1.0, no entries -> 0
                         if (lane == 0) hardw[(j0 >> 6) + u] = word;
                         double sfx = 0.0;
@@ -210,9 +220,8 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     if (j0 + u * 64 < np) {
-                        const int j = j0 + u * 64 + lane;
 #pragma unroll
-                        for (int k = 0; k < DC; ++k) A[apos[k * np + j]] = pre[u][k];
+                        for (int k = 0; k < DC; ++k) M[pos[u][k] == ZERO ? DUMMY : pos[u][k]] = pre[u][k];
                     }
             }
             __builtin_amdgcn_wave_barrier();
@@ -231,15 +240,10 @@ __global__ void __launch_bounds__(512) bp_wave_kernel(const WaveArgs a) {
             unsat_any = __ballot(unsat) != 0;
         } while (unsat_any && it < a.max_iter);
 
-        // ---- outputs (bp.hpp:62,65,69,71): C still holds this iteration's check->bit messages ----
+        // ---- outputs (bp.hpp:62,65,69,71) ----
         for (int j = lane; j < n; j += 64) {
             a.decoding[b * n + j] = (uint8_t)((hardw[j >> 6] >> (j & 63)) & 1ull);
-            if (a.llr) {
-                double temp = prior[j];
-#pragma unroll
-                for (int k = 0; k < DC; ++k) temp += C[k * np + j];
-                a.llr[b * n + j] = temp;
-            }
+            if (want_llr) a.llr[b * n + j] = L[j];
         }
         if (lane == 0) {
             if (a.iters) a.iters[b] = it;
