@@ -211,6 +211,9 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
 /* Duration in milliseconds of the BP kernel launch of the last decode call on this handle,
  * measured with HIP events on the launch stream (0 if none yet). */
 int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms);
+/* Split of that time for the streaming path: the persistent kernel (bp_decode_kernel) and the per-pass launches
+ * (bp_spread_*_kernel: small batches from the first iteration, stragglers of large ones).  Both 0 for other kernels. */
+int ldpc_hip_bp_last_phase_ms(ldpc_hip_bp *h, float *persistent_ms, float *per_pass_ms);
 
 /* Bytes of device workspace a decode of `batch` syndromes needs (message arrays dominate:
  * 2 * 8 * nnz bytes per syndrome). */

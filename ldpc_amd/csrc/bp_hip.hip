@@ -120,9 +120,9 @@ struct ldpc_hip_bp {
     int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
 
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    float accumulated_ms = 0.f;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: end of the persistent kernel, when one ran
+    bool timed = false, timed_mid = false;
+    float accumulated_ms = 0.f, accumulated_persistent_ms = 0.f;
 
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
@@ -244,6 +244,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_mid);
     if (e != hipSuccess) {
         ldpc_hip_bp_destroy(h);
         return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -273,6 +274,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->d_osd_wt) (void)hipFree(h->d_osd_wt);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -384,6 +386,23 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
     return LDPC_HIP_OK;
 }
 
+int ldpc_hip_bp_last_phase_ms(ldpc_hip_bp *h, float *persistent_ms, float *per_pass_ms) {
+    if (!h || !persistent_ms || !per_pass_ms) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    *persistent_ms = *per_pass_ms = 0.f;
+    float total = 0.f;
+    int rc = ldpc_hip_bp_last_kernel_ms(h, &total);
+    if (rc) return rc;
+    float pers = h->accumulated_persistent_ms;
+    if (h->timed && h->timed_mid) {
+        float last = 0.f;
+        HIPCHK(hipEventElapsedTime(&last, h->ev0, h->ev_mid));
+        pers += last;
+    }
+    *persistent_ms = pers;
+    *per_pass_ms = total - pers;
+    return LDPC_HIP_OK;
+}
+
 }  // extern "C"
 
 typedef void (*bp_kernel_t)(const BpArgs);
@@ -454,7 +473,9 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
     else kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
     h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
     h->timed = false;
+    h->timed_mid = false;
     hipStream_t st = h->stream;
     for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
         const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
@@ -543,7 +564,9 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     if (lds > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)bp_softinfo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
     h->timed = false;
+    h->timed_mid = false;
     hipStream_t st = h->stream;
     for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
         const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
@@ -813,7 +836,9 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, ring);
     else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
     h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
     h->timed = false;
+    h->timed_mid = false;
     hipStream_t st = h->stream;
 
     for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
@@ -872,7 +897,12 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             HIPCHK(hipEventSynchronize(h->ev1));
             HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
             h->accumulated_ms += prev;
+            if (h->timed_mid) {
+                HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev_mid));
+                h->accumulated_persistent_ms += prev;
+            }
         }
+        h->timed_mid = false;
         HIPCHK(hipEventRecord(h->ev0, st));
         SpreadArgs sa = {};
         sa.bp = a;
@@ -892,6 +922,8 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         } else {
             hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(h->ev_mid, st));
+            h->timed_mid = true;
             if (handoff > 0 && h->max_iter > 1) {
                 // tiles parked by the persistent kernel: the host needs their number (this is the one point where the
                 // otherwise asynchronous call waits for the device)

@@ -117,6 +117,12 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def last_phase_ms(self):
+        """(persistent kernel ms, per-pass kernels ms) of the last streaming decode; (0, total) or (0, 0) otherwise."""
+        a, b = C.c_float(0.0), C.c_float(0.0)
+        _lib.check(self._lib.ldpc_hip_bp_last_phase_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     # -- data path --------------------------------------------------------------------------------
     def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False, osd=False):
         """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
