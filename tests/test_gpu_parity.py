@@ -157,6 +157,26 @@ def test_chunked_batches_match_single_launch(oracle_built):
     assert bits_equal(l0, l1)
 
 
+@pytest.mark.parametrize("handoff", [-1, 0, 2])
+def test_chunked_streaming_kernel_with_handoff(handoff):
+    """The streaming path proper (on-chip kernels off) cut into chunks of 3 tiles, with and without parking tiles."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import regular_ldpc_code
+    h = regular_ldpc_code(600, 3, 6, seed=3)
+    synd = _synd(h, 0.06, seed=5, shots=700)  # 11 tiles: chunks of 3, 3, 3, 2
+    for method, alpha in ((0, 1.0), (1, 0.75)):
+        eng = HipBpEngine(h.indptr, h.indices, 600, np.full(600, 0.06), 40, method, alpha)
+        eng.set_small_code_kernel(0)
+        eng.set_handoff(0)
+        d0, l0, i0, c0 = eng.decode_batch(synd)
+        eng.set_handoff(handoff)
+        eng.set_tuning(max_chunk_tiles=3)
+        d1, l1, i1, c1 = eng.decode_batch(synd)
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1)
+        assert bits_equal(l0, l1)
+        assert 0 < c0.mean() < 1  # both converging and non-converging rows in the batch
+
+
 def test_batch_independence_and_determinism():
     """Lane/tile position never influences a syndrome's result: permuted and duplicated rows agree."""
     from ldpc_amd.engine import HipBpEngine
