@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
     const unsigned l16 = (unsigned)lane * 16u;
 
+    bool llr_each = false;  // tile-uniform: posteriors are stored by every bit pass (set at the first convergence event)
     // lanes beyond the batch (partial last tile) are born "done"
     const int64_t valid = a.batch - tile * LDPC_WAVE;
     uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                         const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, sload(llr0 + j), At, l8);
                         const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
                         if (lane == 0) dcur[j] = hard;
-                        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                        if ((last || llr_each) && want_llr && lane_live) Lt.st(l8, j, llr);
                     }
                 }
                 slot = slot + 1 == RING ? 0 : slot + 1;
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     }
                     const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
                     if (lane == 0) dcur[j] = hard;
-                    if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+                    if ((last || llr_each) && want_llr && lane_live) Lt.st(l8, j, llr);
                 }
             }
         }
@@ -252,14 +253,22 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
             // those of THIS iteration (its check->bit messages are still intact in C)
             if ((newly >> lane) & 1ull) my_iter = it;
             const bool mine = (newly >> lane) & 1ull;
-            for (int j = wave; j < n; j += nwaves) {
-                if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
-                if (!last && want_llr) {
+            if (!last && want_llr && !llr_each) {
+                // first convergence in this tile: rebuild the posteriors of the lanes that stop from C, once
+                for (int j = wave; j < n; j += nwaves) {
+                    if (lane == 0) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
                     double temp = llr0[j];
                     for (int p = col_ptr[j]; p < col_ptr[j + 1]; ++p) temp += Ct.ld(l8, csc_edge[p]);
                     if (mine) Lt.st(l8, j, temp);
                 }
+            } else {
+                // the bit pass has stored this iteration's posteriors already (last iteration, or llr_each)
+                for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
             }
+            // Once syndromes of a tile start to converge the others usually follow within a few iterations: from now
+            // on the bit pass stores the posteriors of the live lanes every iteration (+8 % traffic) instead of this
+            // tile paying a full extra sweep over C per convergence event.
+            llr_each = true;
             done |= newly;
             __syncthreads();  // C is overwritten by the next check pass
         }
