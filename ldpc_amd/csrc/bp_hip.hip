@@ -127,6 +127,7 @@ struct ldpc_hip_bp {
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
     int32_t obs_k = -1;                                              // rows of the observables matrix (-1: not set)
@@ -259,7 +260,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1009,7 +1010,19 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     const size_t dyn = per_wave * (size_t)waves;
     const void *fn = higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    const int64_t blocks = (batch + waves - 1) / waves;
+    // list the unconverged rows, then persistent wavefronts (as many as LDS lets reside) pull rows from the list
+    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    a.list = (const int32_t *)h->osd_list.p;
+    a.counters = (unsigned *)h->osd_counters.p;
+    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    int groups_per_cu = (int)((160u * 1024u) / dyn);
+    if (groups_per_cu * waves > 32) groups_per_cu = 32 / waves;
+    if (groups_per_cu < 1) groups_per_cu = 1;
+    int64_t blocks = 256 * (int64_t)groups_per_cu;
+    if (blocks > (batch + waves - 1) / waves) blocks = (batch + waves - 1) / waves;
     if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());

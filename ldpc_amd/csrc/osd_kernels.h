@@ -23,7 +23,32 @@ struct OsdArgs {
     int32_t lds_per_wave;  // bytes
     int32_t method, order; // osdw_kernel: 2 = exhaustive (OSD_E), 3 = combination sweep (OSD_CS); order > 0
     const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
+    const int32_t *list;   // rows BP left unconverged, any order (osd_collect_kernel)
+    unsigned *counters;    // [0] number of entries of `list`, [1] next entry to hand out (both zeroed before the collect)
 };
+
+// Rows that need OSD are a few percent of a batch and scattered: list them first, then persistent wavefronts pull rows
+// from the list, so every resident wavefront has work (one wavefront per batch row would leave the chip almost empty).
+__global__ void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restrict__ conv, int64_t batch, int32_t *list, unsigned *counters) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool need = b < batch && !conv[b];
+    const uint64_t mask = __ballot(need);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&counters[0], (unsigned)__builtin_popcountll(mask));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (need) list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
+}
+
+// next unconverged row for this wavefront, -1 when the list is exhausted
+__device__ __forceinline__ int64_t osd_next_row(const OsdArgs &a, int lane) {
+    unsigned idx = 0;
+    if (lane == 0) idx = atomicAdd(&a.counters[1], 1u);
+    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+    const unsigned count = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return idx < count ? (int64_t)a.list[idx] : -1;
+}
 
 __device__ __forceinline__ bool osd_less(double a, int ia, double b, int ib) {
     const bool na = a != a, nb = b != b;
@@ -37,8 +62,6 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
     const int m = a.m, n = a.n, W = a.words;
     unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
     volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                  // [m][W]
@@ -49,6 +72,7 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
 
     const int sw = n >> 6;
     const uint64_t sbit = 1ull << (n & 63);
+    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
     for (int i = lane; i < m; i += 64) {
         for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
         for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
@@ -102,6 +126,8 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
         if (pivot_col[i] >= 0 && (mat[(size_t)i * W + sw] & sbit)) x[pivot_col[i]] = 1;
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = x[j];
+    __builtin_amdgcn_wave_barrier();
+    }  // next row
 }
 
 // ---- higher-order OSD (osd.hpp:119-187): OSD_E / OSD_CS, one wavefront per unconverged syndrome ---------------
@@ -142,8 +168,6 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (b >= a.batch || a.conv[b]) return;  // wave-uniform
     const int m = a.m, n = a.n, W = a.words;
     unsigned char *base = osd_lds + (size_t)wave * a.lds_per_wave;
     volatile uint64_t *mat = reinterpret_cast<volatile uint64_t *>(base);                         // [m][W]
@@ -156,6 +180,7 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
 
     const int sw = n >> 6;
     const uint64_t sbit = 1ull << (n & 63);
+    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
     for (int i = lane; i < m; i += 64) {
         for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
         for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
@@ -270,4 +295,6 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
     OsdCandidate win = none;
     if (best_c >= 0) win = osd_candidate(a.method, a.order, k, best_c);
     for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = bit_of(win, j) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    }  // next row
 }
