@@ -148,6 +148,9 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes,
  * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H.
  */
 int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
+/* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
+ * bit-packed in LDS), 0 = always LDS.  Results are identical. */
+int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode);
 int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
                                 uint8_t *decoding, double *llr, int32_t *iterations,
                                 uint8_t *converge);

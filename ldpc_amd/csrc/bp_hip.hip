@@ -117,6 +117,7 @@ struct ldpc_hip_bp {
     int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
     double *d_llr0 = nullptr;
     double *d_osd_wt = nullptr;  // [n] log(1 / p_j), the candidate weights of higher-order OSD
+    bool osd_reg = true;  // register-resident elimination for small matrices (ldpc_hip_bp_set_osd_kernel)
     int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
 
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -998,7 +999,15 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
     a.synd = synd; a.llr = llr; a.conv = conv; a.decoding = decoding;
     a.method = osd_method; a.order = osd_order; a.wt = h->d_osd_wt;
-    size_t per_wave = higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
+    // small matrices: the elimination runs in registers (osd0_reg_kernel<R, W>), LDS only holds the column order
+    void (*reg0)(const OsdArgs) = nullptr;
+    if (!higher && h->osd_reg) {
+        if (a.m <= 64 && a.words <= 2) reg0 = osd0_reg_kernel<1, 2>;
+        else if (a.m <= 128 && a.words <= 4) reg0 = osd0_reg_kernel<2, 4>;
+        else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
+    }
+    size_t per_wave = reg0 ? (size_t)a.n * 4
+                    : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
     if (per_wave > 150u * 1024u)
@@ -1008,7 +1017,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     if (waves > 4) waves = 4;
     a.lds_per_wave = (int32_t)per_wave;
     const size_t dyn = per_wave * (size_t)waves;
-    const void *fn = higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
+    const void *fn = reg0 ? (const void *)reg0 : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     // list the unconverged rows, then persistent wavefronts (as many as LDS lets reside) pull rows from the list
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
@@ -1023,7 +1032,8 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     if (groups_per_cu < 1) groups_per_cu = 1;
     int64_t blocks = 256 * (int64_t)groups_per_cu;
     if (blocks > (batch + waves - 1) / waves) blocks = (batch + waves - 1) / waves;
-    if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    if (reg0) hipLaunchKernelGGL(reg0, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    else if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
@@ -1052,6 +1062,13 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_CS with osd_order > 64 is not available on the device");
     h->osd_method = osd_method;
     h->osd_order = osd_order;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (mode < -1 || mode > 0) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic) or 0 (matrix in LDS)");
+    h->osd_reg = mode != 0;
     return LDPC_HIP_OK;
 }
 

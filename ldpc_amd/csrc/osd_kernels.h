@@ -130,6 +130,186 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
     }  // next row
 }
 
+// ---- register-resident elimination for small matrices ------------------------------------------------------
+// For m <= 64 R rows and n + 1 <= 64 W bits the augmented matrix of a syndrome fits in the wavefront's registers:
+// lane l holds rows l, l + 64, ... (R of them, W words each).  A pivot step is then a ballot (first unpivoted row
+// with the bit), W x v_readlane (broadcast of the pivot row) and predicated XORs -- no LDS traffic at all; only the
+// column order goes through LDS once.  R and W are template bounds, so every register index is a compile-time one.
+template <int R, int W>
+struct OsdRows {
+    uint64_t w[R][W];
+    int32_t pcol[R];  // pivot column carried by the row, -1: none
+};
+
+__device__ __forceinline__ uint64_t osd_readlane64(uint64_t v, int src_lane) {  // src_lane wave-uniform
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double osd_readlane_f64(double v, int src_lane) {
+    return __builtin_bit_cast(double, osd_readlane64(__builtin_bit_cast(uint64_t, v), src_lane));
+}
+template <int W>
+__device__ __forceinline__ uint64_t osd_word(const uint64_t (&row)[W], int word) {  // word wave-uniform
+    // masked OR, not a select chain: the compiler turns a select chain into a dynamically indexed load from a scratch
+    // copy of the rows
+    uint64_t v = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) v |= row[w] & (0ull - (uint64_t)(word == w));
+    return v;
+}
+
+// [H | s] of batch row b into registers (bit n of a row = its syndrome byte != 0, gf2sparse_linalg.hpp:309)
+template <int R, int W>
+__device__ __forceinline__ void osd_load_rows(const OsdArgs &a, int64_t b, int lane, OsdRows<R, W> &rows) {
+    const int m = a.m, n = a.n;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r * 64 + lane;
+        rows.pcol[r] = -1;
+#pragma unroll
+        for (int w = 0; w < W; ++w) rows.w[r][w] = 0;
+        if (i < m) {
+            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+                const int c = a.col_idx[e];
+#pragma unroll
+                for (int w = 0; w < W; ++w) rows.w[r][w] |= (c >> 6) == w ? 1ull << (c & 63) : 0ull;
+            }
+            if (a.synd[b * m + i]) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) rows.w[r][w] |= (n >> 6) == w ? 1ull << (n & 63) : 0ull;
+            }
+        }
+    }
+}
+
+// osd_less as one unsigned compare: numbers ascending (-0.0 == +0.0), NaNs after every number
+__device__ __forceinline__ uint64_t osd_sort_key(double x) {
+    if (x != x) return ~0ull;
+    if (x == 0.0) x = 0.0;  // -0.0 ties with +0.0 (neither a < b nor a > b in the comparator)
+    const uint64_t u = __builtin_bit_cast(uint64_t, x);
+    return (u >> 63) ? ~u : u | (1ull << 63);
+}
+
+// soft_decision_col_sort (sort.hpp:48-62) with the keys in registers: order[rank of column i] = i
+template <int W, class OrderPtr>
+__device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, int lane, OrderPtr order) {
+    uint64_t key[W];
+    int rk[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const int j = q * 64 + lane;
+        key[q] = j < n ? osd_sort_key(llr_row[j]) : ~0ull;
+        rk[q] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
+        for (int l = 0; l < cnt; ++l) {
+            const uint64_t kj = osd_readlane64(key[q], l);
+            const int jj = q * 64 + l;
+#pragma unroll
+            for (int q2 = 0; q2 < W; ++q2)  // column jj sorts before column q2 * 64 + lane: smaller key, ties by index
+                rk[q2] += (kj < key[q2] || (kj == key[q2] && jj < q2 * 64 + lane)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q)
+        if (q * 64 + lane < n) order[rk[q]] = q * 64 + lane;
+}
+
+// Greedy elimination over the sorted columns (gf2sparse_linalg.hpp:132-226 / 298-401), rows fully reduced.
+// EARLY_STOP: leave as soon as the syndrome lies in the span of the pivots (fast_solve, :373-383).  Returns the rank reached.
+// one pivot step for a column whose bit lives in word CW (compile-time) of a row; false: no unpivoted row has the bit
+template <int R, int W, int CW>
+__device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, uint64_t cb, int c, int m, int lane) {
+    int p_lane = -1, p_r = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {  // first unpivoted row (ascending row index) with a one in column c
+        const uint64_t mask = __ballot(r * 64 + lane < m && rows.pcol[r] < 0 && (rows.w[r][CW] & cb));
+        if (p_lane < 0 && mask) { p_lane = __builtin_ctzll(mask); p_r = r; }
+    }
+    if (p_lane < 0) return false;
+    uint64_t prow[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint64_t src = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) src |= rows.w[r][w] & (0ull - (uint64_t)(p_r == r));
+        prow[w] = osd_readlane64(src, p_lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool is_pivot_row = p_r == r && lane == p_lane;
+        const uint64_t hit = 0ull - (uint64_t)((rows.w[r][CW] & cb) != 0 && !is_pivot_row);
+#pragma unroll
+        for (int w = 0; w < W; ++w) rows.w[r][w] ^= prow[w] & hit;
+        if (is_pivot_row) rows.pcol[r] = c;
+    }
+    return true;
+}
+
+// Greedy elimination over the sorted columns (gf2sparse_linalg.hpp:132-226 / 298-401), rows fully reduced.
+// EARLY_STOP: leave as soon as the syndrome lies in the span of the pivots (fast_solve, :373-383).  Returns the rank reached.
+template <int R, int W, bool EARLY_STOP, class OrderPtr>
+__device__ __forceinline__ int osd_eliminate(OsdRows<R, W> &rows, OrderPtr order, int m, int n, int lane) {
+    const int max_rank = m < n ? m : n;
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    int rank = 0;
+    for (int t = 0; t < n && rank < max_rank; ++t) {
+        const int c = order[t];
+        const int cw = __builtin_amdgcn_readfirstlane(c >> 6);  // wave-uniform: a scalar branch picks the specialisation
+        const uint64_t cb = 1ull << (c & 63);
+        bool found = false;
+        if (cw == 0) found = osd_pivot_step<R, W, 0>(rows, cb, c, m, lane);
+        if constexpr (W > 1) { if (cw == 1) found = osd_pivot_step<R, W, 1>(rows, cb, c, m, lane); }
+        if constexpr (W > 2) { if (cw == 2) found = osd_pivot_step<R, W, 2>(rows, cb, c, m, lane); }
+        if constexpr (W > 3) { if (cw == 3) found = osd_pivot_step<R, W, 3>(rows, cb, c, m, lane); }
+        if constexpr (W > 4) { if (cw == 4) found = osd_pivot_step<R, W, 4>(rows, cb, c, m, lane); }
+        if constexpr (W > 5) { if (cw == 5) found = osd_pivot_step<R, W, 5>(rows, cb, c, m, lane); }
+        if constexpr (W > 6) { if (cw == 6) found = osd_pivot_step<R, W, 6>(rows, cb, c, m, lane); }
+        if constexpr (W > 7) { if (cw == 7) found = osd_pivot_step<R, W, 7>(rows, cb, c, m, lane); }
+        if (!found) continue;
+        ++rank;
+        if (EARLY_STOP) {
+            bool pending = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                pending |= __ballot(r * 64 + lane < m && rows.pcol[r] < 0 && (osd_word<W>(rows.w[r], sw) & sbit)) != 0;
+            if (!pending) break;
+        }
+    }
+    return rank;
+}
+
+// OSD-0 with the matrix in registers (same result as osd0_kernel; chosen by the host when m <= 64 R, n + 1 <= 64 W)
+template <int R, int W>
+__global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = a.m, n = a.n;
+    volatile lds_i32 *order = (volatile lds_i32 *)((__attribute__((address_space(3))) unsigned char *)osd_lds + wave * a.lds_per_wave);  // [n]
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+        OsdRows<R, W> rows;
+        osd_load_rows<R, W>(a, b, lane, rows);
+        osd_sort_columns<W>(a.llr + b * n, n, lane, order);
+        __builtin_amdgcn_wave_barrier();
+        osd_eliminate<R, W, true>(rows, order, m, n, lane);
+        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
+        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (rows.pcol[r] >= 0 && (osd_word<W>(rows.w[r], sw) & sbit)) a.decoding[b * n + rows.pcol[r]] = 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- higher-order OSD (osd.hpp:119-187): OSD_E / OSD_CS, one wavefront per unconverged syndrome ---------------
 // After the column sort the matrix is brought to REDUCED row echelon form over the sorted columns (no early
 // stop).  Then no candidate needs a solve of its own: flipping the non-pivot columns F changes the solution on

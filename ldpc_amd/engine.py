@@ -105,6 +105,10 @@ class HipBpEngine:
         """OSD method / order for ``decode_batch(osd=True)``: 0 off, 1 OSD_0, 2 OSD_E, 3 OSD_CS (osd.hpp:18-23)."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd(self._h, int(osd_method), int(osd_order)))
 
+    def set_osd_kernel(self, mode):
+        """OSD elimination: -1 automatic (registers for small matrices), 0 always the LDS kernels."""
+        _lib.check(self._lib.ldpc_hip_bp_set_osd_kernel(self._h, int(mode)))
+
     def set_small_code_kernel(self, mode):
         """On-chip kernels for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS, 2 slot kernel only."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))

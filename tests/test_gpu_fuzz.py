@@ -98,9 +98,11 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
         for osd_method, osd_order in ((1, 0), (3, int(rng.integers(1, 9))), (2, int(rng.integers(1, 7)))):
             want = o.bposd_decode_batch(s, osd_method, osd_order)
             eng.set_osd(osd_method, osd_order)
-            got = eng.decode_batch(s, osd=True)
-            assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} seed {seed} {method} m={m} n={n}"
-            assert np.array_equal(got[3], want[3])
+            for osd_kernel in (-1, 0):
+                eng.set_osd_kernel(osd_kernel)
+                got = eng.decode_batch(s, osd=True)
+                assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} kernel {osd_kernel} seed {seed} {method} m={m} n={n}"
+                assert np.array_equal(got[3], want[3])
     # soft syndromes (always serial minimum-sum)
     soft = rng.normal(scale=2.0, size=(batch, m))
     o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method="minimum_sum", ms_scaling_factor=0.9)

@@ -382,6 +382,8 @@ def test_bposd0_golden_fixture(name):
     assert np.array_equal(chk, c["syndromes"])  # cpp_test/TestOsdDecoder.cpp:9-35
     dec2, _, _, _ = eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)  # library-owned LLR buffer
     assert np.array_equal(dec2, dec)
+    eng.set_osd_kernel(0)  # the LDS-resident elimination (what larger matrices use)
+    assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)[0], dec)
 
 
 def test_bposd0_config5_batch_and_device_pointers(oracle_built):
@@ -445,6 +447,9 @@ def test_bposdw_golden_fixture(name):
     assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"])
     eng.set_osd(1, 0)
     assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"])
+    eng.set_osd_kernel(0)
+    eng.set_osd(c["osd_method"], c["osd_order"])
+    assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["decoding"])
 
 
 def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
