@@ -148,6 +148,11 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes,
  * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H.
  */
 int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
+/* Serial schedule: a 64-syndrome tile is decoded by one wavefront, which runs until its slowest syndrome is done.  With
+ * repacking a first pass of `first_pass_iters` iterations runs over the whole batch and the rows it leaves unconverged are
+ * packed into dense tiles and decoded again from the start with the full max_iter (deterministic: same results).
+ * -1 = automatic (max_iter / 8, default), 0 = off.  With repacking the call waits once for the device. */
+int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
 /* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
  * bit-packed in LDS), 0 = always LDS.  Results are identical. */
 int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode);

@@ -129,6 +129,8 @@ struct ldpc_hip_bp {
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
+    DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
+    int32_t repack_iters = -1;                                      // first-pass iterations: -1 auto (max_iter / 8), 0 = no repacking
     DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
     int32_t obs_k = -1;                                              // rows of the observables matrix (-1: not set)
@@ -261,7 +263,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -442,8 +444,15 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                          double *llr, int32_t *iters, uint8_t *conv);
 
 // Serial schedule: one wavefront per 64-syndrome tile (bp_serial_kernel).  Device pointers, on h->stream.
-static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                         int32_t *iters, uint8_t *conv) {
+template <int METHOD, int MATH>
+static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
+    if (max_row <= 4 && max_col <= 2) return bp_serial_kernel<METHOD, MATH, 2, 4>;
+    if (max_row <= 6 && max_col <= 3) return bp_serial_kernel<METHOD, MATH, 3, 6>;
+    return bp_serial_kernel<METHOD, MATH, 4, 8>;  // also the variant that streams heavier nodes (SerialArgs::fast == 0)
+}
+
+static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                              int32_t *iters, uint8_t *conv) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
@@ -471,9 +480,9 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
     void (*kern)(const SerialArgs);
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_serial_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
-    else kern = bp_serial_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
+    else kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed = false;
@@ -492,7 +501,7 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                                (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
         }
         SerialArgs a = {};
-        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.fast = fast ? 1 : 0;
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = max_iter; a.fast = fast ? 1 : 0;
         a.ms_scaling_factor = h->ms_scaling_factor;
         a.batch = nb;
         a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
@@ -527,6 +536,55 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         }
         HIPCHK(hipGetLastError());
     }
+    return LDPC_HIP_OK;
+}
+
+
+// The serial kernel decodes a 64-syndrome tile with one wavefront, which runs until its slowest lane is done: one
+// syndrome that never converges keeps 63 finished ones waiting for max_iter iterations.  Repacking: a first pass with
+// few iterations over everything, then the rows it left unconverged -- packed densely into new tiles -- are decoded
+// again from the start with the full iteration budget (BP is deterministic: restarting gives what continuing would),
+// and their results replace the first pass's.  Work ~ k1 + f * max_iter instead of max_iter (f = unconverged fraction).
+static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                         int32_t *iters, uint8_t *conv) {
+    int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
+    if (h->repack_iters < 0 && k1 < 2) k1 = 2;
+    if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
+        return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
+    const size_t B = (size_t)batch, m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
+    int rc;
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+    if ((rc = decode_serial_pass(h, k1, synd, batch, decoding, llr, iters, conv))) return rc;
+    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
+    const int64_t cnt = (int64_t)h->h_counters[2];
+    if (cnt == 0) return LDPC_HIP_OK;
+    float ms1 = 0.f;
+    (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
+    const size_t C = (size_t)cnt;
+    if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
+        (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
+    const int32_t *list = (const int32_t *)h->osd_list.p;
+    auto grid = [](size_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    if (h->m > 0)
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * h->m), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = decode_serial_pass(h, h->max_iter, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p,
+                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
+    h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
+    if (h->n > 0) {
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * h->n), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
+        if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * h->n), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);
+    }
+    if (iters) hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
+    hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
+    HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
 }
 
@@ -1062,6 +1120,13 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_CS with osd_order > 64 is not available on the device");
     h->osd_method = osd_method;
     h->osd_order = osd_order;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (first_pass_iters < -1) return fail(LDPC_HIP_ERR_INVALID, "first_pass_iters must be -1 (automatic), 0 (off) or an iteration count");
+    h->repack_iters = first_pass_iters;
     return LDPC_HIP_OK;
 }
 

@@ -29,9 +29,10 @@ struct SerialArgs {
     uint8_t *conv;
 };
 
-template <int METHOD, int MATH>
+// DCS / DRS: register bounds of the fast path (column / row weight); tighter bounds leave more wavefronts per SIMD, and
+// this kernel is one dependent chain per bit, so the wavefronts in flight are what hides its latency
+template <int METHOD, int MATH, int DCS, int DRS>
 __global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
-    constexpr int DCS = 4, DRS = 8;  // register bounds of the fast path (column / row weight)
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int m = a.m, n = a.n, nnz = a.nnz;

@@ -154,3 +154,22 @@ __global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, 
     const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
     err[t] = (uint8_t)((sm64(seed, idx) >> 11) < threshold);
 }
+
+
+// ---- row gather / scatter by an index list (repacking of the syndromes a first short pass left unconverged) ----
+template <class T>
+__global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ list, int64_t count, int width,
+                                   T *__restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * width) return;
+    const int64_t r = t / width;
+    dst[t] = src[(int64_t)list[r] * width + (t - r * width)];
+}
+template <class T>
+__global__ void scatter_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ list, int64_t count, int width,
+                                    T *__restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * width) return;
+    const int64_t r = t / width;
+    dst[(int64_t)list[r] * width + (t - r * width)] = src[t];
+}

@@ -105,6 +105,10 @@ class HipBpEngine:
         """OSD method / order for ``decode_batch(osd=True)``: 0 off, 1 OSD_0, 2 OSD_E, 3 OSD_CS (osd.hpp:18-23)."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd(self._h, int(osd_method), int(osd_order)))
 
+    def set_repack(self, first_pass_iters):
+        """Serial schedule: iterations of the first pass before unconverged rows are repacked (-1 auto, 0 off)."""
+        _lib.check(self._lib.ldpc_hip_bp_set_repack(self._h, int(first_pass_iters)))
+
     def set_osd_kernel(self, mode):
         """OSD elimination: -1 automatic (registers for small matrices), 0 always the LDS kernels."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd_kernel(self._h, int(mode)))

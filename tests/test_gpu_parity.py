@@ -655,3 +655,29 @@ def test_bpdecoder_decode_batch_device_tensors():
     r[5] = 0
     drv = BpDecoder(c["h"], error_rate=0.04, max_iter=20, input_vector_type="received_vector")
     assert np.array_equal(drv.decode_batch(torch.from_numpy(r).cuda()).cpu().numpy(), drv.decode_batch(r))
+
+
+@pytest.mark.parametrize("first_pass", [-1, 0, 1, 3, 49])
+def test_serial_repacking_gives_identical_results(first_pass, oracle_built):
+    """Serial schedule with the two-pass repacking (ldpc_hip_bp_set_repack): same bits as one pass and as the oracle."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    synd = _synd(h, 0.06, seed=21, shots=1500)
+    for method, alpha in ((0, 1.0), (1, 0.625)):
+        eng = HipBpEngine(h.indptr, h.indices, 144, np.full(144, 0.06), 50, method, alpha)
+        eng.set_schedule("serial")
+        eng.set_repack(0)
+        d0, l0, i0, c0 = eng.decode_batch(synd)
+        eng.set_repack(first_pass)
+        d1, l1, i1, c1 = eng.decode_batch(synd)
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1) and bits_equal(l0, l1)
+        d2, l2, i2, c2 = eng.decode_batch(synd, want_llr=False)
+        assert l2 is None and np.array_equal(d2, d0) and np.array_equal(i2, i0)
+        eng.set_osd(3, 4)
+        d3 = eng.decode_batch(synd, osd=True)[0]
+        eng.set_repack(0)
+        assert np.array_equal(d3, eng.decode_batch(synd, osd=True)[0])
+        assert 0.02 < 1 - c0.mean() < 0.9
+    want = oracle_built.BpOracle(h, error_rate=0.06, max_iter=50, bp_method="minimum_sum", ms_scaling_factor=0.625).decode_serial_batch(synd[:300], None)
+    assert np.array_equal(d1[:300], want[0]) and np.array_equal(i1[:300], want[2])

@@ -52,6 +52,8 @@ def main():
         run("c3 surface d=21 min_sum 30 it p=0.01", h, 0.01, 30, 1, 0.625, 262144, False)
     if "serial" in args.which:
         serial()
+    if "serial_big" in args.which:
+        serial_big()
     if "osdw" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05", h, 0.05, 50, 0, 1.0, 8192, False, osd=(3, 10))
@@ -65,6 +67,17 @@ def main():
         run("c5 BB144 product_sum 50 it (BP only) p=0.05", h, 0.05, 50, 0, 1.0, 8192, False)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144 fast math", h, 0.05, 50, 0, 1.0, 262144, True, math="fast")
+
+
+def serial_big():
+    """The serial kernel is one wavefront per 64-syndrome tile: it needs a large batch to fill the chip."""
+    from ldpc_amd import codes
+    h = codes.bivariate_bicycle_hx()
+    for b in (262144, 1048576):
+        run(f"serial: BB144 product_sum 50 it p=0.05, B={b}", h, 0.05, 50, 0, 1.0, b, False, schedule="serial")
+    h = codes.rotated_surface_code_x(21)
+    for b in (262144, 1048576):
+        run(f"serial: surface d=21 min_sum 30 it p=0.05, B={b}", h, 0.05, 30, 1, 0.625, b, False, schedule="serial")
 
 
 def serial():
