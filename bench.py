@@ -111,6 +111,9 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step(False)
+    if world > 1 and args.warmup == 0:
+        # RCCL sets up its peer-to-peer connections at the first gather: keep that out of the timed region
+        gather_rows(torch.zeros((8, 8), dtype=torch.uint8, device=dev), 8 * world, 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
