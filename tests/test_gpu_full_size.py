@@ -1,0 +1,97 @@
+"""BASELINE.json's configurations at their full sizes, checked through size-independent properties (the CPU oracle only
+sees a sample): H x == s for exactly the rows flagged converged, iteration counts consistent with the flags, agreement
+with the oracle on a random subset, invariance under the kernel family, and for config 5 that every OSD output solves
+its syndrome.  Everything stays in HBM; only flags and small samples come back."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_flags_against_syndromes(eng, synd, dec, cv, it, max_iter):
+    import torch
+    resid = eng.mulvec_batch(dec) ^ synd          # H x + s on the device
+    solved = ~resid.any(dim=1).bool()
+    cvb = cv.bool()
+    assert bool((solved == cvb).all()), "converge flag <=> H x == s must hold for every row (bp.hpp:300-308)"
+    assert bool((it[~cvb] == max_iter).all()) and bool((it[cvb] >= 1).all()) and bool((it <= max_iter).all())
+    return cvb
+
+
+def _subset_vs_oracle(oracle_built, h, p, max_iter, method, alpha, synd, dec, it, cv, llr, rows):
+    o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
+    s = synd[rows].cpu().numpy()
+    want = o.decode_batch(s)
+    assert np.array_equal(dec[rows].cpu().numpy(), want[0])
+    assert np.array_equal(it[rows].cpu().numpy(), want[2]) and np.array_equal(cv[rows].cpu().numpy().astype(bool), want[3])
+    if llr is not None:
+        from golden_util import bits_equal
+        assert bits_equal(llr[rows].cpu().numpy(), want[1])
+
+
+@pytest.mark.parametrize("p", [0.05, 0.09])
+def test_config2_full_batch(p, oracle_built):
+    """(3,6)-regular n = 10 000, product_sum, 50 iterations, B = 65 536 (bench.py's workload)."""
+    import torch
+    from ldpc_amd.codes import regular_ldpc_code
+    from ldpc_amd.engine import HipBpEngine
+    h = regular_ldpc_code(10000, 3, 6, seed=1)
+    eng = HipBpEngine(h.indptr, h.indices, 10000, np.full(10000, p), 50, 0, 1.0)
+    B = 65536
+    synd, err = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=torch.device("cuda", 0), want_errors=True)
+    dec, llr, it, cv = eng.decode_batch(synd, want_llr=True)
+    cvb = _check_flags_against_syndromes(eng, synd, dec, cv, it, 50)
+    if p == 0.05:  # below threshold: (almost) everything converges, and to the error that was injected
+        assert cvb.float().mean().item() > 0.999
+        assert ((dec == err).all(dim=1) == cvb).float().mean().item() > 0.999
+        assert 6.0 < it.float().mean().item() < 8.0
+    else:          # above threshold: (almost) nothing does
+        assert cvb.float().mean().item() < 0.05
+    rows = torch.from_numpy(np.random.default_rng(1).choice(B, 24 if p == 0.09 else 96, replace=False)).cuda()
+    _subset_vs_oracle(oracle_built, h, p, 50, "product_sum", 1.0, synd, dec, it, cv, llr, rows)
+    # the per-pass kernels alone give the same batch (first 16 384 rows = 256 tiles: per-pass from the first iteration)
+    d2, _, i2, c2 = eng.decode_batch(synd[:16384].contiguous(), want_llr=False)
+    assert bool((d2 == dec[:16384]).all()) and bool((i2 == it[:16384]).all()) and bool((c2 == cv[:16384]).all())
+
+
+def test_config3_full_batch(oracle_built):
+    """Rotated surface code d = 21, minimum_sum 0.625, 30 iterations, B = 262 144."""
+    import torch
+    from ldpc_amd.codes import rotated_surface_code_x
+    from ldpc_amd.engine import HipBpEngine
+    h = rotated_surface_code_x(21)
+    m, n = h.shape
+    B = 262144
+    for p in (0.05, 0.01):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), 30, 1, 0.625)
+        synd = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=torch.device("cuda", 0))
+        dec, llr, it, cv = eng.decode_batch(synd)
+        _check_flags_against_syndromes(eng, synd, dec, cv, it, 30)
+        rows = torch.from_numpy(np.random.default_rng(2).choice(B, 512, replace=False)).cuda()
+        _subset_vs_oracle(oracle_built, h, p, 30, "minimum_sum", 0.625, synd, dec, it, cv, llr, rows)
+        eng.set_small_code_kernel(0)  # the streaming kernel on the same batch
+        d2, _, i2, c2 = eng.decode_batch(synd[:32768].contiguous(), want_llr=False)
+        assert bool((d2 == dec[:32768]).all()) and bool((i2 == it[:32768]).all()) and bool((c2 == cv[:32768]).all())
+
+
+def test_config5_full_batch_osd_orders(oracle_built):
+    """BB [[144,12,12]], product_sum 50 iterations + OSD (0 / CS-10), B = 8 192: every output solves its syndrome and the
+    sweep never raises the weight."""
+    import torch
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    from ldpc_amd.engine import HipBpEngine
+    h = bivariate_bicycle_hx()
+    eng = HipBpEngine(h.indptr, h.indices, 144, np.full(144, 0.05), 50, 0, 1.0)
+    synd = eng.gen_bsc_syndromes(7, 0.05, shot0=0, shots=8192, device=torch.device("cuda", 0))
+    eng.set_osd(1, 0)
+    d0, _, it, cv = eng.decode_batch(synd, osd=True)
+    eng.set_osd(3, 10)
+    d1, _, it1, cv1 = eng.decode_batch(synd, osd=True)
+    for d in (d0, d1):
+        assert not bool((eng.mulvec_batch(d) ^ synd).any()), "every BP+OSD output must reproduce its syndrome"
+    assert bool((it == it1).all()) and bool((cv == cv1).all())
+    assert bool((d0[cv.bool()] == d1[cv.bool()]).all())  # converged rows are BP's own decision either way
+    assert bool((d1.sum(dim=1) <= d0.sum(dim=1)).all())   # uniform priors: weight = Hamming weight (osd.hpp:171-177)
+    rows = np.random.default_rng(3).choice(8192, 600, replace=False)
+    want = oracle_built.BpOracle(h, error_rate=0.05, max_iter=50).bposd_decode_batch(synd.cpu().numpy()[rows], 3, 10)
+    assert np.array_equal(d1.cpu().numpy()[rows], want[0])
