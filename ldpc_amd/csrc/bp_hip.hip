@@ -17,7 +17,7 @@
 //   * every lane walks its node's <= DR (row) / <= DC (column) edges SEQUENTIALLY in ascending
 //     column / row order, i.e. in the reference's linked-list order (sparse_matrix_base.hpp:423-482
 //     keeps both lists sorted), so every floating-point operation is performed in the reference's
-//     association order -- min-sum is bit-identical, product-sum differs only by libm vs ocml ulps,
+//     association order -- min-sum is bit-identical, and so is product-sum with the libm-exact routines of bp_math.h,
 //   * hard decisions are kept bit-packed per (tile, bit) as the wavefront's ballot; the syndrome
 //     test of bp.hpp:300-302 is an XOR-gather of those 64-bit words per check,
 //   * a syndrome that converges freezes its outputs (bp.hpp:300-308 early return); a tile whose 64
