@@ -260,7 +260,8 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * Two variants: one wavefront per syndrome with no workgroup barrier in the loop (row and column weights <= 8),
  * and a workgroup that keeps up to four syndromes resident (any degrees).  mode -1 = automatic (default),
  * 0 = always use the streaming kernel, 1 = use an on-chip kernel whenever one syndrome fits in LDS,
- * 2 = as 1 but only the workgroup ("slot") variant.  Results are identical. */
+ * 2 = as 1 but only the workgroup ("slot") variant, 3 = as 1 but only the lane = node wavefront variant (product-sum
+ * otherwise prefers a lane = entry variant that keeps every lane busy with one transcendental).  Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 
 #define LDPC_HIP_MATH_LIBM_EXACT 0

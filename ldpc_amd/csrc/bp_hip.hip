@@ -34,7 +34,8 @@
 //   bp_stream_kernel.h   bp_decode_kernel        persistent workgroup per 64-syndrome tile (register / LDS-ring variants)
 //   bp_spread_kernels.h  bp_spread_*_kernel      one launch per pass, a tile spread over the chip (small batches, stragglers)
 //   bp_small_kernel.h    bp_small_kernel         messages resident in LDS (surface / bivariate-bicycle sized codes), slots per workgroup
-//   bp_wave_kernel.h     bp_wave_kernel          same regime, bounded degrees: one wavefront per syndrome, no workgroup barriers
+//   bp_wave_kernel.h     bp_wave_kernel, bp_wave_ps_kernel   same regime, bounded degrees: one wavefront per syndrome, no workgroup barriers
+//                        (lane = node; for product-sum lane = entry)
 //   bp_serial_kernels.h  bp_serial_kernel, bp_softinfo_kernel   serial schedule, soft-syndrome serial min-sum
 //   osd_kernels.h        osd0_kernel, osdw_kernel               OSD-0 / OSD-E / OSD-CS post-processing
 //   io_kernels.h         pack / unpack / transpose, H v, b8 shot data, synthetic BSC shots
@@ -104,6 +105,8 @@ struct ldpc_hip_bp {
     int32_t small_mode = -1; // on-chip kernels for small codes: -1 auto, 0 never, 1 whenever one fits, 2 the slot kernel only
     std::vector<int32_t> h_row_ptr, h_col_idx;  // host copy of the CSR arrays
     int wave_dr = 0, wave_dc = 0;  // template bounds the uploaded SoA position tables of bp_wave_kernel were built for (0: none)
+    int wave_ps_dr = 0, wave_ps_dc = 0;  // likewise for bp_wave_ps_kernel
+    DeviceBuf wp_rdeg, wp_col, wp_epos;
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
@@ -263,7 +266,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -358,7 +361,8 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
 
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 2) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits) or 2 (slot kernel only)");
+    if (mode < -1 || mode > 3)
+        return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits), 2 (slot kernel only) or 3 (lane = node wavefront kernel)");
     h->small_mode = mode;
     return LDPC_HIP_OK;
 }
@@ -801,6 +805,100 @@ static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
     return LDPC_HIP_OK;
 }
 
+// bp_wave_ps_kernel (product-sum, lane = entry): bounds, launch shape, LDS split; waves == 0: not applicable
+struct WavePsPlan {
+    int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, np = 0;
+    size_t shared = 0, per_wave = 0;
+    void (*kern)(const WavePsArgs) = nullptr;
+};
+
+template <int MATH>
+static void pick_wave_ps(int max_row, int max_col, WavePsPlan &p) {
+    if (max_row <= 4 && max_col <= 2) { p.dr = 4; p.dc = 2; p.kern = bp_wave_ps_kernel<MATH, 4, 2>; return; }
+    if (max_row <= 4 && max_col <= 4) { p.dr = 4; p.dc = 4; p.kern = bp_wave_ps_kernel<MATH, 4, 4>; return; }
+    if (max_row <= 6 && max_col <= 3) { p.dr = 6; p.dc = 3; p.kern = bp_wave_ps_kernel<MATH, 6, 3>; return; }
+    p.dr = 8; p.dc = 4; p.kern = bp_wave_ps_kernel<MATH, 8, 4>;
+}
+
+static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr) {
+    WavePsPlan p;
+    if (h->bp_method != LDPC_HIP_PRODUCT_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 4) return p;
+    if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave_ps<1>(h->max_row_deg, h->max_col_deg, p);
+    else pick_wave_ps<0>(h->max_row_deg, h->max_col_deg, p);
+    p.np = (h->n + 63) / 64 * 64;
+    const size_t rm = (size_t)p.dr * h->m;
+    if (rm + 2 >= 65536 || (size_t)p.np + 1 >= 65536) return p;
+    if (!forced && (rm > 2 * (size_t)h->nnz || (size_t)p.dc * h->n > 2 * (size_t)h->nnz)) return p;  // padding would dominate
+    p.shared = wave_ps_lds_shared(h->m, p.np, p.dr, p.dc);
+    p.per_wave = wave_ps_lds_private(h->m, p.np, p.dr, want_llr);
+    const size_t lds = 160u * 1024u;
+    if (p.shared + p.per_wave > lds) return p;
+    size_t w = (lds - p.shared) / p.per_wave;
+    if (w > 16) w = 16;
+    if (!forced && w < 8) return p;
+    p.waves = (int)w;
+    p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
+    if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;
+    if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+    return p;
+}
+
+static int ensure_wave_ps_tables(ldpc_hip_bp *h, const WavePsPlan &p) {
+    if (h->wave_ps_dr == p.dr && h->wave_ps_dc == p.dc) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n, np = p.np;
+    const size_t rm = (size_t)p.dr * m, cn = (size_t)p.dc * np;
+    std::vector<uint8_t> rdeg((size_t)m, 0);
+    std::vector<uint16_t> wcol(rm, (uint16_t)np), wepos(cn, (uint16_t)rm);  // phantom defaults
+    std::vector<int32_t> seen((size_t)n, 0);
+    for (int i = 0; i < m; ++i) {
+        const int lo = h->h_row_ptr[(size_t)i];
+        rdeg[(size_t)i] = (uint8_t)(h->h_row_ptr[(size_t)i + 1] - lo);
+        for (int e = lo; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int k = e - lo, j = h->h_col_idx[(size_t)e], kc = seen[(size_t)j]++;
+            wcol[(size_t)i * p.dr + k] = (uint16_t)j;
+            wepos[(size_t)j * p.dc + kc] = (uint16_t)((size_t)i * p.dr + k);
+        }
+    }
+    int rc;
+    if ((rc = h->wp_rdeg.ensure(rdeg.size())) || (rc = h->wp_col.ensure(rm * 2)) || (rc = h->wp_epos.ensure(cn * 2))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->wp_rdeg.p, rdeg.data(), rdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wp_col.p, wcol.data(), rm * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wp_epos.p, wepos.data(), cn * 2, hipMemcpyHostToDevice));
+    h->wave_ps_dr = p.dr;
+    h->wave_ps_dc = p.dc;
+    return LDPC_HIP_OK;
+}
+
+static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                          int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_wave_ps_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    WavePsArgs a = {};
+    a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
+    a.batch = batch;
+    a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+    const size_t dyn = p.shared + (size_t)p.waves * p.per_wave;
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int64_t groups = (batch + p.waves - 1) / p.waves;
+    const int64_t resident = 256 * (int64_t)p.groups_per_cu;
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 // Wavefront-per-syndrome on-chip variant (bp_wave_kernel).  Device pointers, on h->stream.
 static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                        int32_t *iters, uint8_t *conv) {
@@ -849,12 +947,16 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
+        if (h->small_mode != 2 && h->small_mode != 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
+            const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr);
+            if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
+        }
         if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1, llr != nullptr);
+            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode == 3, llr != nullptr);
             if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
         }
         int slots = 0;
-        const size_t budget = h->small_mode >= 1 ? 150u * 1024u : 39u * 1024u + 512u;
+        const size_t budget = (h->small_mode == 1 || h->small_mode == 2) ? 150u * 1024u : 39u * 1024u + 512u;
         for (int sl = 4; sl >= 1 && !slots; --sl)
             if (small_lds_bytes(h, sl) <= budget) slots = sl;
         if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);

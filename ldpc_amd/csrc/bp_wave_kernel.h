@@ -252,3 +252,168 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// ---- product-sum, lane = ENTRY ---------------------------------------------------------------------------------
+// For product-sum the cost of a pass is its transcendentals -- one log per entry in the check pass, one tanh per
+// entry in the bit pass -- and with lane = node a code like BB [[144,12,12]] (m = 72, n = 144) leaves a third of the
+// lanes idle in the last round of each pass while the busy ones evaluate 6 resp. 3 of them in sequence.  Here a lane
+// owns ONE entry: it reads its whole row (column), forms the reference's sequential prefix and suffix products (sums)
+// exactly as the node-owning lane would -- a dozen cheap operations, redundantly -- and evaluates one transcendental.
+// 432 entries fill 7 rounds of 64 lanes at 96 %, instead of 12 + 9 transcendental slots per iteration there are 7 + 7.
+// Entries live row-padded, entry k of row i at i * DR + k (phantoms hold 1.0), in TWO arrays (a lane overwriting its
+// entry in place would pull the inputs away from the other lanes of its row); the bit pass reaches the k-th entry of
+// column j through epos[j * DC + k] (phantom: a slot that holds +0.0 for good).
+struct WavePsArgs {
+    int32_t m, n, np, max_iter;
+    int64_t batch;
+    const uint8_t *rdeg;     // [m]
+    const uint16_t *col;     // [m * DR] column of entry k of row i at [i * DR + k]; phantom: np
+    const uint16_t *epos;    // [np * DC] position (i * DR + k) of the k-th entry of column j; phantom: m * DR
+    const double *llr0;      // [n]
+    const uint8_t *synd;
+    uint8_t *decoding;
+    double *llr;
+    int32_t *iters;
+    uint8_t *conv;
+    unsigned long long *next;
+    int32_t lds_shared, lds_per_wave;
+};
+
+__host__ __device__ inline size_t wave_ps_lds_shared(int m, int np, int DR, int DC) {
+    size_t b = 256 * 8 + (size_t)(np + 2) * 16 + (size_t)m * DR * 2 + (size_t)np * DC * 2 + (size_t)m;
+    return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t wave_ps_lds_private(int m, int np, int DR, bool want_llr) {
+    size_t b = 2 * ((size_t)m * DR + 2) * 8 + (want_llr ? (size_t)np * 8 : 0) + (size_t)(np + 16) + (size_t)m;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int MATH, int DR, int DC>
+__global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
+    constexpr int METHOD = LDPC_HIP_PRODUCT_SUM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wv_lds[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, n = a.n, np = a.np, rm = m * DR, cn = n * DC;
+    const bool want_llr = a.llr != nullptr;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) double lds_f64;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    lds_u8 *base = (lds_u8 *)wv_lds;
+    // shared: [log table][llr0 np + 2][edge form of llr0 np + 2][col][epos][rdeg]
+    lds_f64 *log_tab_l = (lds_f64 *)base;
+    const double *log_tab = reinterpret_cast<const double *>(wv_lds);
+    lds_f64 *prior = log_tab_l + 256;
+    lds_f64 *pform = prior + np + 2;
+    lds_u16 *col = (lds_u16 *)(pform + np + 2);
+    lds_u16 *epos = col + rm;
+    lds_u8 *rdeg = (lds_u8 *)(epos + np * DC);
+    for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
+    for (int q = tid; q < np; q += T) prior[q] = q < n ? a.llr0[q] : 1.0;
+    for (int q = tid; q < m; q += T) rdeg[q] = a.rdeg[q];
+    for (int q = tid; q < rm; q += T) col[q] = a.col[q];
+    for (int q = tid; q < np * DC; q += T) epos[q] = a.epos[q];
+    __syncthreads();
+    for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
+    if (tid == 0) pform[np] = 1.0;  // phantom entries of a row: neutral for the products
+    __syncthreads();
+
+    // wave-private: [A rm + 2][C rm + 2 (entry rm = the +0.0 slot)][posteriors np, if asked for][hard decisions np + 16 bytes][syndrome bytes m]
+    lds_u8 *mine = base + a.lds_shared + wave * a.lds_per_wave;
+    lds_f64 *A = (lds_f64 *)mine;
+    lds_f64 *C = A + rm + 2;
+    lds_f64 *L = C + rm + 2;
+    volatile lds_u8 *hard = (volatile lds_u8 *)(L + (want_llr ? np : 0));
+    volatile lds_u8 *sy = hard + np + 16;
+    const int ZERO = rm;
+    if (lane == 0) { C[ZERO] = 0.0; hard[np] = 0; }
+    __builtin_amdgcn_wave_barrier();
+
+    for (;;) {
+        unsigned long long pulled = 0;
+        if (lane == 0) pulled = atomicAdd(a.next, 1ull);
+        const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        if (b >= a.batch) break;
+        for (int i = lane; i < m; i += 64) sy[i] = a.synd[b * m + i];
+        for (int q = lane; q < rm; q += 64) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
+        __builtin_amdgcn_wave_barrier();
+
+        int it = 0;
+        bool unsat_any = true;
+        do {
+            ++it;
+            // ---- check pass (bp.hpp:201-219): lane = entry (i, k) ----
+            for (int s0 = 0; s0 < rm; s0 += 64) {
+                const int slot = s0 + lane;
+                const int sc = slot < rm ? slot : rm - 1;
+                const int i = sc / DR, k = sc - i * DR;
+                const bool valid = slot < rm && k < rdeg[i];
+                double av[DR], pre[DR];
+#pragma unroll
+                for (int kk = 0; kk < DR; ++kk) av[kk] = A[i * DR + kk];
+                double temp = 1.0;
+#pragma unroll
+                for (int kk = 0; kk < DR; ++kk) { pre[kk] = temp; temp *= av[kk]; }  // the reference's forward sweep
+                double mine_pre = pre[0], mine_suf = 1.0;
+                temp = 1.0;
+#pragma unroll
+                for (int kk = DR - 1; kk >= 0; --kk) {  // and its backward sweep; keep what belongs to entry k
+                    mine_pre = kk == k ? pre[kk] : mine_pre;
+                    mine_suf = kk == k ? temp : mine_suf;
+                    temp *= av[kk];
+                }
+                if (valid) C[slot] = ps_message<MATH>(mine_pre * mine_suf, sy[i] != 0, log_tab);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- bit pass (bp.hpp:276-298, 311-318): lane = entry (j, k) of the column ----
+            for (int s0 = 0; s0 < cn; s0 += 64) {
+                const int slot = s0 + lane;
+                const int sc = slot < cn ? slot : cn - 1;
+                const int j = sc / DC, k = sc - j * DC;
+                int pos[DC];
+                double cv[DC], pre[DC];
+#pragma unroll
+                for (int kk = 0; kk < DC; ++kk) { pos[kk] = epos[j * DC + kk]; cv[kk] = C[pos[kk]]; }  // phantom: the +0.0 slot
+                double temp = prior[j];
+#pragma unroll
+                for (int kk = 0; kk < DC; ++kk) { pre[kk] = temp; temp += cv[kk]; }
+                if (slot < cn && k == 0) {
+                    hard[j] = temp <= 0 ? 1 : 0;
+                    if (want_llr) L[j] = temp;
+                }
+                double mine_pre = pre[0], mine_sfx = 0.0, sfx = 0.0;
+                int mine_pos = pos[0];
+#pragma unroll
+                for (int kk = DC - 1; kk >= 0; --kk) {
+                    mine_pre = kk == k ? pre[kk] : mine_pre;
+                    mine_sfx = kk == k ? sfx : mine_sfx;
+                    mine_pos = kk == k ? pos[kk] : mine_pos;
+                    sfx += cv[kk];
+                }
+                if (slot < cn && mine_pos != ZERO) A[mine_pos] = edge_form<METHOD, MATH>(mine_pre + mine_sfx);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- syndrome test (bp.hpp:292-294, 300-302) ----
+            bool unsat = false;
+            for (int i = lane; i < m; i += 64) {
+                unsigned par = 0;
+#pragma unroll
+                for (int kk = 0; kk < DR; ++kk) par ^= hard[col[i * DR + kk]];  // phantom: byte np, always zero
+                unsat |= par != (unsigned)sy[i];
+            }
+            unsat_any = __ballot(unsat) != 0;
+        } while (unsat_any && it < a.max_iter);
+
+        for (int j = lane; j < n; j += 64) {
+            a.decoding[b * n + j] = hard[j];
+            if (want_llr) a.llr[b * n + j] = L[j];
+        }
+        if (lane == 0) {
+            if (a.iters) a.iters[b] = it;
+            if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}

@@ -63,7 +63,7 @@ def test_parallel_schedule_random_codes(seed, kind, oracle_built):
         o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
         want = o.decode_batch(s)
         eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 0 if method == "product_sum" else 1, alpha)
-        for small, handoff in ((-1, -1), (0, 0), (0, 100000), (1, -1), (2, -1)):
+        for small, handoff in ((-1, -1), (0, 0), (0, 100000), (1, -1), (2, -1), (3, -1)):
             eng.set_small_code_kernel(small)
             eng.set_handoff(handoff)
             got = eng.decode_batch(s)

@@ -496,7 +496,7 @@ def test_bposd_decoder_api_higher_order(backend):
 @pytest.mark.parametrize("name", ["c5_bb144_ps50_p050", "c5_bb144_ms50_p050", "c3_surface21_ms30_p050", "surface5_ps30",
                                   "edge_extreme_priors_ps", "edge_syndrome_bytes_gt1_ms", "edge_degree1_empty_ps",
                                   "c1_hamming5_ps20", "ldpc36_n600_ps50_p070"])
-@pytest.mark.parametrize("small", [0, 1, 2])
+@pytest.mark.parametrize("small", [0, 1, 2, 3])
 def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
     """Small codes are decoded by the LDS-resident kernel (auto); forcing either kernel gives the reference's bits."""
     c = load_case(name)
