@@ -153,6 +153,11 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
  * packed into dense tiles and decoded again from the start with the full max_iter (deterministic: same results).
  * -1 = automatic (max_iter / 8, default), 0 = off.  With repacking the call waits once for the device. */
 int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
+/* Serial schedule kernels: bits that share no check commute, so the schedule is cut into levels of mutually check-disjoint
+ * bits (level = 1 + the highest level among the EARLIER bits sharing a check) and a workgroup runs a tile level by level
+ * with its wavefronts sharing each level's bits -- same results as the bit-by-bit walk.  -1 = automatic (level-parallel
+ * when a level holds >= 2 bits on average), 0 = one wavefront walks the tile bit by bit, 1 = always level-parallel. */
+int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
  * bit-packed in LDS), 0 = always LDS.  Results are identical. */
 int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libldpc_hip.so")
 SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
     "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
-    "ldpc_hip_bp_set_osd", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
+    "ldpc_hip_bp_set_osd", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
     "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
@@ -75,6 +75,7 @@ def load():
     lib.ldpc_hip_bp_set_osd.argtypes = [vp, i32, i32]
     lib.ldpc_hip_bp_set_osd_kernel.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_repack.argtypes = [vp, i32]
+    lib.ldpc_hip_bp_set_serial_kernel.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_observables.argtypes = [vp, i32, vp, vp]
     lib.ldpc_hip_bp_decode_b8.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
     lib.ldpc_hip_pack_b8.argtypes = [vp, vp, i64, i32, vp]

@@ -133,6 +133,11 @@ struct ldpc_hip_bp {
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
+    int32_t serial_kernel = -1;                                     // -1 auto, 0 one wavefront per tile, 1 level-parallel workgroup per tile
+    bool order_visits_all = true;                                   // false: some bit is never updated (its outputs stay 0)
+    bool levels_valid = false;                                      // lvl_* describe the current schedule order
+    int32_t n_levels = 0;
+    DeviceBuf lvl_ptr, lvl_bits;
     int32_t repack_iters = -1;                                      // first-pass iterations: -1 auto (max_iter / 8), 0 = no repacking
     DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
@@ -266,7 +271,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -345,10 +350,23 @@ int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *se
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(h->d_order, serial_schedule_order, sizeof(int32_t) * (size_t)h->n, hipMemcpyHostToDevice));
         h->custom_order = true;
+        std::vector<char> seen((size_t)(h->n ? h->n : 1), 0);
+        for (int j = 0; j < h->n; ++j) seen[(size_t)serial_schedule_order[j]] = 1;
+        h->order_visits_all = true;
+        for (int j = 0; j < h->n; ++j) h->order_visits_all = h->order_visits_all && seen[(size_t)j];
     } else {
         h->custom_order = false;
+        h->order_visits_all = true;
     }
     h->schedule = schedule;
+    h->levels_valid = false;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    if (mode < -1 || mode > 1) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic), 0 (one wavefront per tile) or 1 (level-parallel)");
+    h->serial_kernel = mode;
     return LDPC_HIP_OK;
 }
 
@@ -448,6 +466,51 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                          double *llr, int32_t *iters, uint8_t *conv);
 
 // Serial schedule: one wavefront per 64-syndrome tile (bp_serial_kernel).  Device pointers, on h->stream.
+// levels of the serial schedule: see bp_serial_level_kernel
+static int ensure_serial_levels(ldpc_hip_bp *h) {
+    if (h->levels_valid) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n;
+    std::vector<int32_t> order((size_t)n);
+    if (h->custom_order) HIPCHK(hipMemcpy(order.data(), h->d_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    else for (int j = 0; j < n; ++j) order[(size_t)j] = j;
+    std::vector<std::vector<int32_t>> checks_of((size_t)n);
+    for (int i = 0; i < m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) checks_of[(size_t)h->h_col_idx[(size_t)e]].push_back(i);
+    // (the order need not be a permutation -- the reference accepts any n bit numbers -- so levels belong to POSITIONS)
+    std::vector<int32_t> check_level((size_t)(m ? m : 1), 0), level((size_t)(n ? n : 1), 1);
+    int32_t n_levels = n ? 1 : 0;
+    for (int t = 0; t < n; ++t) {
+        const int j = order[(size_t)t];
+        int32_t l = 1;
+        for (int i : checks_of[(size_t)j]) l = std::max(l, check_level[(size_t)i] + 1);
+        for (int i : checks_of[(size_t)j]) check_level[(size_t)i] = l;
+        level[(size_t)t] = l;
+        n_levels = std::max(n_levels, l);
+    }
+    std::vector<int32_t> ptr((size_t)n_levels + 1, 0), bits((size_t)(n ? n : 1));
+    for (int t = 0; t < n; ++t) ptr[(size_t)level[(size_t)t]]++;
+    for (int l = 0; l < n_levels; ++l) ptr[(size_t)l + 1] += ptr[(size_t)l];
+    {
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int t = 0; t < n; ++t) bits[(size_t)fill[(size_t)level[(size_t)t] - 1]++] = order[(size_t)t];  // schedule order inside a level
+    }
+    int rc;
+    if ((rc = h->lvl_ptr.ensure(sizeof(int32_t) * ((size_t)n_levels + 1))) || (rc = h->lvl_bits.ensure(sizeof(int32_t) * (size_t)(n ? n : 1)))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->lvl_ptr.p, ptr.data(), sizeof(int32_t) * ((size_t)n_levels + 1), hipMemcpyHostToDevice));
+    if (n) HIPCHK(hipMemcpy(h->lvl_bits.p, bits.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    h->n_levels = n_levels;
+    h->levels_valid = true;
+    return LDPC_HIP_OK;
+}
+
+template <int METHOD, int MATH>
+static void (*pick_serial_level(int max_row, int max_col))(const SerialArgs) {
+    if (max_row <= 4 && max_col <= 2) return bp_serial_level_kernel<METHOD, MATH, 2, 4>;
+    if (max_row <= 6 && max_col <= 3) return bp_serial_level_kernel<METHOD, MATH, 3, 6>;
+    return bp_serial_level_kernel<METHOD, MATH, 4, 8>;
+}
+
 template <int METHOD, int MATH>
 static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
     if (max_row <= 4 && max_col <= 2) return bp_serial_kernel<METHOD, MATH, 2, 4>;
@@ -484,7 +547,22 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
     void (*kern)(const SerialArgs);
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    // level-parallel variant when the schedule has at least two bits per level on average (or when asked for)
+    int level_waves = 0;
+    if (h->serial_kernel != 0 && h->n > 0) {
+        if ((rc = ensure_serial_levels(h))) return rc;
+        const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+        if (h->serial_kernel == 1 || per_level >= 2.0) {
+            level_waves = (int)(per_level + 0.999);
+            if (level_waves > 8) level_waves = 8;
+            if (level_waves < 1) level_waves = 1;
+        }
+    }
+    if (level_waves) {
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_level<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
+        else kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    } else if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
     else kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
     h->accumulated_ms = 0.f;
@@ -499,6 +577,8 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
         HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
         HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        if (llr && !h->order_visits_all)  // bits the order never visits report 0 (the reference leaves them stale)
+            HIPCHK(hipMemsetAsync(h->llr_t.p, 0, per_tile_llr * (size_t)tiles, st));
         if (h->m > 0) {
             dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
@@ -524,7 +604,8 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
             h->accumulated_ms += prev;
         }
         HIPCHK(hipEventRecord(h->ev0, st));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());

@@ -27,7 +27,109 @@ struct SerialArgs {
     double *llr_t;
     int32_t *iters;
     uint8_t *conv;
+    // bp_serial_level_kernel: the schedule cut into levels of mutually check-disjoint bits (see below)
+    const int32_t *lvl_ptr;   // [n_levels + 1]
+    const int32_t *lvl_bits;  // [n] bits in level-major order (schedule order inside a level)
+    int32_t n_levels;
 };
+
+// One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the
+// message from the row's other entries as they are NOW, the posterior, the hard decision, and the bit's new bit->check
+// messages.  Shared by the single-wavefront kernel and the level-parallel one.
+template <int METHOD, int MATH, int DCS, int DRS>
+__device__ __forceinline__ void serial_update_bit(const SerialArgs &a, int bit, const MsgBuf &At, const MsgBuf &Ct, const MsgBuf &Lt,
+                                                  const uint64_t *par, uint64_t *dcur, int lane, int l8, double alpha,
+                                                  const double *log_tab, bool want_llr, bool lane_live) {
+    const int cs = sload(a.col_ptr + bit);
+    const int d = sload(a.col_ptr + bit + 1) - cs;
+    double llr = sload(a.llr0 + bit);  // bp.hpp:488
+    // the (other) entries of one incident check row -> its check->bit message for this bit
+    auto row_message = [&](int chk, int e, const double *vals, int rs, int rd) {
+        const bool odd = (sload(par + chk) >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
+        if (METHOD == LDPC_HIP_PRODUCT_SUM) {
+            double c = 1.0;
+            if (vals) {
+#pragma unroll
+                for (int q = 0; q < DRS; ++q)
+                    if (q < rd && rs + q != e) c *= vals[q];
+            } else {
+                for (int g = rs; g < rs + rd; ++g)
+                    if (g != e) c *= At.ld(l8, g);
+            }
+            c = ps_message<MATH>(c, odd, log_tab);
+            return c;
+        } else {
+            int sgn = odd ? 1 : 0;
+            double temp = DBL_MAX;
+            if (vals) {
+#pragma unroll
+                for (int q = 0; q < DRS; ++q)
+                    if (q < rd && rs + q != e) {
+                        const double ab = fabs(vals[q]);
+                        if (ab < temp) temp = ab;
+                        if (vals[q] <= 0) sgn ^= 1;
+                    }
+            } else {
+                for (int g = rs; g < rs + rd; ++g)
+                    if (g != e) {
+                        const double bg = At.ld(l8, g);
+                        const double ab = fabs(bg);
+                        if (ab < temp) temp = ab;
+                        if (bg <= 0) sgn ^= 1;
+                    }
+            }
+            return (alpha * (sgn ? -1.0 : 1.0)) * temp;  // alpha * message_sign * temp (bp.hpp:519)
+        }
+    };
+    if (a.fast) {
+        int e[DCS], chk[DCS], rs[DCS], rd[DCS];
+        double vals[DCS][DRS], c[DCS], pre[DCS];
+#pragma unroll
+        for (int k = 0; k < DCS; ++k)
+            if (k < d) {
+                e[k] = sload(a.csc_edge + cs + k);
+                chk[k] = sload(a.csc_row + cs + k);
+                rs[k] = sload(a.row_ptr + chk[k]);
+                rd[k] = sload(a.row_ptr + chk[k] + 1) - rs[k];
+#pragma unroll
+                for (int q = 0; q < DRS; ++q)
+                    if (q < rd[k] && rs[k] + q != e[k]) vals[k][q] = At.ld(l8, rs[k] + q);
+            }
+#pragma unroll
+        for (int k = 0; k < DCS; ++k)
+            if (k < d) {
+                c[k] = row_message(chk[k], e[k], vals[k], rs[k], rd[k]);
+                pre[k] = llr;  // bp.hpp:501 / 520
+                llr += c[k];
+                if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+            }
+        double temp = 0.0;  // bp.hpp:530-534
+#pragma unroll
+        for (int k = DCS - 1; k >= 0; --k)
+            if (k < d) {
+                At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + temp));
+                temp += c[k];
+            }
+    } else {
+        for (int p = cs; p < cs + d; ++p) {
+            const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+            const int rs = sload(a.row_ptr + chk), rd = sload(a.row_ptr + chk + 1) - rs;
+            const double c = row_message(chk, e, nullptr, rs, rd);
+            Ct.st(l8, e, c);
+            At.st(l8, e, llr);  // partial sum; rewritten below before any other bit reads it
+            llr += c;
+        }
+        double temp = 0.0;
+        for (int p = cs + d - 1; p >= cs; --p) {
+            const int e = sload(a.csc_edge + p);
+            At.st(l8, e, edge_form<METHOD, MATH>(At.ld(l8, e) + temp));
+            temp += Ct.ld(l8, e);
+        }
+    }
+    const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:525-529
+    if (lane == 0) dcur[bit] = hard;
+    if (want_llr && lane_live) Lt.st(l8, bit, llr);
+}
 
 // DCS / DRS: register bounds of the fast path (column / row weight); tighter bounds leave more wavefronts per SIMD, and
 // this kernel is one dependent chain per bit, so the wavefronts in flight are what hides its latency
@@ -61,95 +163,7 @@ __global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
         const bool lane_live = !((done >> lane) & 1ull);
         for (int t = 0; t < n; ++t) {
             const int bit = a.order ? sload(a.order + t) : t;
-            const int cs = sload(a.col_ptr + bit);
-            const int d = sload(a.col_ptr + bit + 1) - cs;
-            double llr = sload(a.llr0 + bit);  // bp.hpp:488
-            // the (other) entries of one incident check row -> its check->bit message for this bit
-            auto row_message = [&](int chk, int e, const double *vals, int rs, int rd) {
-                const bool odd = (sload(par + chk) >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
-                if (METHOD == LDPC_HIP_PRODUCT_SUM) {
-                    double c = 1.0;
-                    if (vals) {
-#pragma unroll
-                        for (int q = 0; q < DRS; ++q)
-                            if (q < rd && rs + q != e) c *= vals[q];
-                    } else {
-                        for (int g = rs; g < rs + rd; ++g)
-                            if (g != e) c *= At.ld(l8, g);
-                    }
-                    c = ps_message<MATH>(c, odd, log_tab);
-                    return c;
-                } else {
-                    int sgn = odd ? 1 : 0;
-                    double temp = DBL_MAX;
-                    if (vals) {
-#pragma unroll
-                        for (int q = 0; q < DRS; ++q)
-                            if (q < rd && rs + q != e) {
-                                const double ab = fabs(vals[q]);
-                                if (ab < temp) temp = ab;
-                                if (vals[q] <= 0) sgn ^= 1;
-                            }
-                    } else {
-                        for (int g = rs; g < rs + rd; ++g)
-                            if (g != e) {
-                                const double bg = At.ld(l8, g);
-                                const double ab = fabs(bg);
-                                if (ab < temp) temp = ab;
-                                if (bg <= 0) sgn ^= 1;
-                            }
-                    }
-                    return (alpha * (sgn ? -1.0 : 1.0)) * temp;  // alpha * message_sign * temp (bp.hpp:519)
-                }
-            };
-            if (a.fast) {
-                int e[DCS], chk[DCS], rs[DCS], rd[DCS];
-                double vals[DCS][DRS], c[DCS], pre[DCS];
-#pragma unroll
-                for (int k = 0; k < DCS; ++k)
-                    if (k < d) {
-                        e[k] = sload(a.csc_edge + cs + k);
-                        chk[k] = sload(a.csc_row + cs + k);
-                        rs[k] = sload(a.row_ptr + chk[k]);
-                        rd[k] = sload(a.row_ptr + chk[k] + 1) - rs[k];
-#pragma unroll
-                        for (int q = 0; q < DRS; ++q)
-                            if (q < rd[k] && rs[k] + q != e[k]) vals[k][q] = At.ld(l8, rs[k] + q);
-                    }
-#pragma unroll
-                for (int k = 0; k < DCS; ++k)
-                    if (k < d) {
-                        c[k] = row_message(chk[k], e[k], vals[k], rs[k], rd[k]);
-                        pre[k] = llr;  // bp.hpp:501 / 520
-                        llr += c[k];
-                        if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
-                    }
-                double temp = 0.0;  // bp.hpp:530-534
-#pragma unroll
-                for (int k = DCS - 1; k >= 0; --k)
-                    if (k < d) {
-                        At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + temp));
-                        temp += c[k];
-                    }
-            } else {
-                for (int p = cs; p < cs + d; ++p) {
-                    const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
-                    const int rs = sload(a.row_ptr + chk), rd = sload(a.row_ptr + chk + 1) - rs;
-                    const double c = row_message(chk, e, nullptr, rs, rd);
-                    Ct.st(l8, e, c);
-                    At.st(l8, e, llr);  // partial sum; rewritten below before any other bit reads it
-                    llr += c;
-                }
-                double temp = 0.0;
-                for (int p = cs + d - 1; p >= cs; --p) {
-                    const int e = sload(a.csc_edge + p);
-                    At.st(l8, e, edge_form<METHOD, MATH>(At.ld(l8, e) + temp));
-                    temp += Ct.ld(l8, e);
-                }
-            }
-            const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:525-529
-            if (lane == 0) dcur[bit] = hard;
-            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+            serial_update_bit<METHOD, MATH, DCS, DRS>(a, bit, At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab, want_llr, lane_live);
         }
         // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -176,6 +190,86 @@ __global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
         const bool cv = ((done >> lane) & 1ull) != 0;
         if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
         if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}
+
+// ---- the same schedule, level-parallel -----------------------------------------------------------------
+// Two bits that share no check touch disjoint messages, so their serial updates commute.  Give every bit the level
+// 1 + max(level of the EARLIER bits of the schedule it shares a check with): bits of one level are pairwise
+// check-disjoint, and running level after level -- any order inside a level -- is indistinguishable from the serial
+// order, because every bit still sees all and only the updates of the conflicting bits that precede it.  The (3,6)
+// n = 10 000 code has 35 levels of ~286 bits, BB [[144,12,12]] 27 of ~5, the d = 21 surface code 61 of ~7.  So a
+// WORKGROUP owns the tile and its wavefronts share each level's bits, with one workgroup barrier per level: the
+// dependent chain per iteration shrinks from n bit updates to n_levels, and a tile keeps several wavefronts busy.
+template <int METHOD, int MATH, int DCS, int DRS>
+__global__ void __launch_bounds__(1024) bp_serial_level_kernel(const SerialArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    const uint64_t *par = a.par + tile * m;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    __shared__ __attribute__((aligned(16))) double log_tab[256];
+    __shared__ uint64_t red[2][16];
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    const uint64_t never = a.invalid[tile];
+    int my_iter = 0;
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(a.llr0 + sload(a.col_idx + e))));
+    __syncthreads();
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+        const bool lane_live = !((done >> lane) & 1ull);
+        for (int l = 0; l < a.n_levels; ++l) {
+            const int p1 = sload(a.lvl_ptr + l + 1);
+            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves)
+                serial_update_bit<METHOD, MATH, DCS, DRS>(a, sload(a.lvl_bits + p), At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab,
+                                                          want_llr, lane_live);
+            __syncthreads();  // the next level reads what this one wrote
+        }
+        // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)
+        uint64_t unsat = 0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ par[i];
+        }
+        unsat = wave_or(unsat);
+        uint64_t *slot_red = red[it & 1];  // double-buffered: no barrier needed before the next reuse
+        if (lane == 0) slot_red[wave] = unsat;
+        __syncthreads();
+        unsat = never;
+        for (int w = 0; w < nwaves; ++w) unsat |= slot_red[w];
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+            __syncthreads();  // (newly is workgroup-uniform) the next iteration overwrites dcur
+        }
+        if (done == ~0ull) break;
+    }
+    __syncthreads();
+    if (done != ~0ull)
+        for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    if (wave == 0) {
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (b < a.batch) {
+            const bool cv = ((done >> lane) & 1ull) != 0;
+            if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+            if (a.conv) a.conv[b] = cv ? 1 : 0;
+        }
     }
 }
 

@@ -109,6 +109,10 @@ class HipBpEngine:
         """Serial schedule: iterations of the first pass before unconverged rows are repacked (-1 auto, 0 off)."""
         _lib.check(self._lib.ldpc_hip_bp_set_repack(self._h, int(first_pass_iters)))
 
+    def set_serial_kernel(self, mode):
+        """Serial schedule: -1 automatic, 0 one wavefront per tile (bit by bit), 1 level-parallel workgroup per tile."""
+        _lib.check(self._lib.ldpc_hip_bp_set_serial_kernel(self._h, int(mode)))
+
     def set_osd_kernel(self, mode):
         """OSD elimination: -1 automatic (registers for small matrices), 0 always the LDS kernels."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd_kernel(self._h, int(mode)))

@@ -90,9 +90,19 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
         order = rng.permutation(n).astype(np.int32)
         want = o.decode_serial_batch(s, order)
         eng.set_schedule("serial", order)
-        got = eng.decode_batch(s)
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
-        assert bits_equal(got[1], want[1])
+        for serial_kernel in (-1, 0, 1):
+            eng.set_serial_kernel(serial_kernel)
+            got = eng.decode_batch(s)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), serial_kernel
+            assert bits_equal(got[1], want[1]), serial_kernel
+        # an order that is not a permutation (the reference accepts any n bit numbers)
+        dup = rng.integers(0, n, size=n).astype(np.int32)
+        want_d = o.decode_serial_batch(s, dup)
+        eng.set_schedule("serial", dup)
+        for serial_kernel in (0, 1):
+            eng.set_serial_kernel(serial_kernel)
+            got = eng.decode_batch(s)
+            assert np.array_equal(got[0], want_d[0]) and np.array_equal(got[2], want_d[2]) and bits_equal(got[1], want_d[1]), serial_kernel
         eng.set_schedule("parallel")
         # BP + OSD of every kind (syndromes are H e, hence in the image of H)
         for osd_method, osd_order in ((1, 0), (3, int(rng.integers(1, 9))), (2, int(rng.integers(1, 7)))):

@@ -560,9 +560,11 @@ def test_serial_schedule_golden_fixture(name):
     c = load_case(name)
     eng = _engine(c)
     eng.set_schedule("serial", c.get("order"))
-    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
-    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
-    assert bits_equal(llr[: len(c["llr"])], c["llr"])
+    for serial_kernel in (-1, 0, 1):  # automatic, bit by bit, level-parallel
+        eng.set_serial_kernel(serial_kernel)
+        dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+        assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+        assert bits_equal(llr[: len(c["llr"])], c["llr"])
     eng.set_schedule("parallel")  # and back: the flooding schedule is unaffected
     d2, _, i2, _ = eng.decode_batch(c["syndromes"][:8])
     assert d2.shape == (8, c["n"])
@@ -668,6 +670,7 @@ def test_serial_repacking_gives_identical_results(first_pass, oracle_built):
         eng = HipBpEngine(h.indptr, h.indices, 144, np.full(144, 0.06), 50, method, alpha)
         eng.set_schedule("serial")
         eng.set_repack(0)
+        eng.set_serial_kernel(0 if first_pass == 3 else -1)
         d0, l0, i0, c0 = eng.decode_batch(synd)
         eng.set_repack(first_pass)
         d1, l1, i1, c1 = eng.decode_batch(synd)
