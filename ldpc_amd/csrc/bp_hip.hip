@@ -682,7 +682,7 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * n1 * LDPC_WAVE : 0;
     const size_t per_tile_soft = sizeof(double) * m1 * LDPC_WAVE;
-    const size_t lds = sizeof(uint64_t) * m1;
+    const size_t lds = sizeof(uint64_t) * (m1 + 32);  // hard-syndrome words + the level kernel's reduction slots
     if (lds > 150u * 1024u)
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "soft-syndrome decoding keeps one hard-syndrome word per check in LDS: m <= 19200");
     int64_t chunk = tiles_total;
@@ -706,8 +706,19 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     if ((rc = h->dec.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    int level_waves = 0;  // level-parallel variant: as for the serial schedule
+    if (h->serial_kernel != 0 && h->n > 0) {
+        if ((rc = ensure_serial_levels(h))) return rc;
+        const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+        if (h->serial_kernel == 1 || per_level >= 2.0) {
+            level_waves = (int)(per_level + 0.999);
+            if (level_waves > 8) level_waves = 8;
+            if (level_waves < 1) level_waves = 1;
+        }
+    }
+    void (*soft_kern)(const SoftArgs) = level_waves ? bp_softinfo_level_kernel : bp_softinfo_kernel;
     if (lds > 48u * 1024u)
-        HIPCHK(hipFuncSetAttribute((const void *)bp_softinfo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)soft_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed = false;
@@ -744,7 +755,8 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
             h->accumulated_ms += prev;
         }
         HIPCHK(hipEventRecord(h->ev0, st));
-        hipLaunchKernelGGL(bp_softinfo_kernel, dim3((unsigned)tiles), dim3(64), (unsigned)lds, st, a);
+        a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+        hipLaunchKernelGGL(soft_kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), (unsigned)lds, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());

@@ -291,6 +291,8 @@ struct SoftArgs {
     double *llr_t;
     int32_t *iters;
     uint8_t *conv;
+    const int32_t *lvl_ptr, *lvl_bits;  // bp_softinfo_level_kernel: levels of check-disjoint bits (as for the serial schedule)
+    int32_t n_levels;
 };
 
 // soft_info_decode_serial's preamble (bp.hpp:551-559): scale, take the sign, lay out lane-minor
@@ -306,6 +308,70 @@ __global__ void __launch_bounds__(256) softinfo_prepare_kernel(const double *__r
     S[((size_t)tile * m + i) * LDPC_WAVE + lane] = v;
     const uint64_t ones = __ballot(v <= 0);
     if (lane == 0) syn[tile * m + i] = ones;
+}
+
+// One bit update of soft_info_decode_serial (bp.hpp:580-639) for the 64 shots of a tile; `syn` = the tile's current hard
+// syndrome words in LDS.  Shared by the single-wavefront kernel and the level-parallel one.
+template <class SynPtr>
+__device__ __forceinline__ void soft_update_bit(const SoftArgs &a, int bit, const MsgBuf &At, const MsgBuf &Ct, const MsgBuf &St,
+                                                const MsgBuf &Lt, SynPtr syn, uint64_t *dcur, int lane, int l8, bool want_llr,
+                                                bool lane_live) {
+    const int cs = sload(a.col_ptr + bit);
+    const int d = sload(a.col_ptr + bit + 1) - cs;
+    double llr = sload(a.llr0 + bit);  // bp.hpp:583-584
+    for (int p = cs; p < cs + d; ++p) {
+        const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
+        const int rs = sload(a.row_ptr + chk), re = sload(a.row_ptr + chk + 1);
+        int sgn = 0;
+        double temp = DBL_MAX;
+        for (int g = rs; g < re; ++g)
+            if (g != e) {  // bp.hpp:590-599
+                const double bg = At.ld(l8, g);
+                if (fabs(bg) < temp) temp = fabs(bg);
+                if (bg <= 0) sgn ^= 1;
+            }
+        const double own = At.ld(l8, e);
+        const double min_msg = temp;
+        double propagated = min_msg;
+        double soft = St.ld(l8, chk);
+        const double magnitude = fabs(soft);
+        uint64_t word = syn[chk];
+        int hard = (int)((word >> lane) & 1ull);
+        bool flip = false;
+        if (magnitude < a.cutoff && magnitude < fabs(min_msg)) {  // bp.hpp:604-621
+            propagated = magnitude;
+            const int check_node_sgn = sgn ^ (own <= 0 ? 1 : 0);
+            if (check_node_sgn == hard) {
+                const double mag = fabs(own) < min_msg ? fabs(own) : min_msg;
+                soft = hard ? -mag : mag;  // pow(-1, syndrome) * magnitude
+            } else {
+                flip = true;
+                soft = -soft;
+            }
+            if (lane_live) St.st(l8, chk, soft);
+        }
+        const uint64_t flips = __ballot(flip);
+        if (flips) {  // wave-uniform
+            word ^= flips;
+            if (lane == 0) syn[chk] = word;
+            hard = (int)((word >> lane) & 1ull);
+            __builtin_amdgcn_wave_barrier();
+        }
+        sgn ^= hard;
+        const double c = (a.ms_scaling_factor * (sgn ? -1.0 : 1.0)) * propagated;  // bp.hpp:624
+        Ct.st(l8, e, c);
+        At.st(l8, e, llr);  // partial sum; completed by the reverse sweep below
+        llr += c;
+    }
+    double back = 0.0;  // bp.hpp:634-638
+    for (int p = cs + d - 1; p >= cs; --p) {
+        const int e = sload(a.csc_edge + p);
+        At.st(l8, e, At.ld(l8, e) + back);
+        back += Ct.ld(l8, e);
+    }
+    const uint64_t hard_bits = __ballot(llr <= 0);  // bp.hpp:628-633
+    if (lane == 0) dcur[bit] = hard_bits;
+    if (want_llr && lane_live) Lt.st(l8, bit, llr);
 }
 
 __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
@@ -334,62 +400,7 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
         const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
         for (int t = 0; t < n; ++t) {
             const int bit = a.order ? sload(a.order + t) : t;
-            const int cs = sload(a.col_ptr + bit);
-            const int d = sload(a.col_ptr + bit + 1) - cs;
-            double llr = sload(a.llr0 + bit);  // bp.hpp:583-584
-            for (int p = cs; p < cs + d; ++p) {
-                const int e = sload(a.csc_edge + p), chk = sload(a.csc_row + p);
-                const int rs = sload(a.row_ptr + chk), re = sload(a.row_ptr + chk + 1);
-                int sgn = 0;
-                double temp = DBL_MAX;
-                for (int g = rs; g < re; ++g)
-                    if (g != e) {  // bp.hpp:590-599
-                        const double bg = At.ld(l8, g);
-                        if (fabs(bg) < temp) temp = fabs(bg);
-                        if (bg <= 0) sgn ^= 1;
-                    }
-                const double own = At.ld(l8, e);
-                const double min_msg = temp;
-                double propagated = min_msg;
-                double soft = St.ld(l8, chk);
-                const double magnitude = fabs(soft);
-                uint64_t word = syn[chk];
-                int hard = (int)((word >> lane) & 1ull);
-                bool flip = false;
-                if (magnitude < a.cutoff && magnitude < fabs(min_msg)) {  // bp.hpp:604-621
-                    propagated = magnitude;
-                    const int check_node_sgn = sgn ^ (own <= 0 ? 1 : 0);
-                    if (check_node_sgn == hard) {
-                        const double mag = fabs(own) < min_msg ? fabs(own) : min_msg;
-                        soft = hard ? -mag : mag;  // pow(-1, syndrome) * magnitude
-                    } else {
-                        flip = true;
-                        soft = -soft;
-                    }
-                    if (lane_live) St.st(l8, chk, soft);
-                }
-                const uint64_t flips = __ballot(flip);
-                if (flips) {  // wave-uniform
-                    word ^= flips;
-                    if (lane == 0) syn[chk] = word;
-                    hard = (int)((word >> lane) & 1ull);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                sgn ^= hard;
-                const double c = (a.ms_scaling_factor * (sgn ? -1.0 : 1.0)) * propagated;  // bp.hpp:624
-                Ct.st(l8, e, c);
-                At.st(l8, e, llr);  // partial sum; completed by the reverse sweep below
-                llr += c;
-            }
-            double back = 0.0;  // bp.hpp:634-638
-            for (int p = cs + d - 1; p >= cs; --p) {
-                const int e = sload(a.csc_edge + p);
-                At.st(l8, e, At.ld(l8, e) + back);
-                back += Ct.ld(l8, e);
-            }
-            const uint64_t hard_bits = __ballot(llr <= 0);  // bp.hpp:628-633
-            if (lane == 0) dcur[bit] = hard_bits;
-            if (want_llr && lane_live) Lt.st(l8, bit, llr);
+            soft_update_bit(a, bit, At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
         }
         // H x against the CURRENT hard syndrome (bp.hpp:640-655)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -416,5 +427,73 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
         const bool cv = ((done >> lane) & 1ull) != 0;
         if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
         if (a.conv) a.conv[b] = cv ? 1 : 0;
+    }
+}
+
+// The same, level-parallel (see bp_serial_level_kernel): bits of a level share no check, hence touch disjoint messages,
+// disjoint soft-syndrome entries and disjoint hard-syndrome words -- a workgroup runs the tile level by level.
+__global__ void __launch_bounds__(1024) bp_softinfo_level_kernel(const SoftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
+    volatile uint64_t *syn = reinterpret_cast<volatile uint64_t *>(soft_lds);  // [m] current hard syndrome, then [2][16] reduction slots
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int64_t tile = blockIdx.x;
+    const int m = a.m, n = a.n, nnz = a.nnz;
+    volatile uint64_t *red = syn + m;
+    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBuf St = make_msgbuf(a.S + (size_t)tile * (size_t)m * LDPC_WAVE, (unsigned)m);
+    uint64_t *dec = a.dec + tile * n;
+    uint64_t *dcur = a.dcur + tile * n;
+    const bool want_llr = a.llr_t != nullptr;
+    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const int l8 = lane * 8;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) syn[i] = a.syn[tile * m + i];
+    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
+    int my_iter = 0;
+    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, sload(a.llr0 + sload(a.col_idx + e)));
+    __syncthreads();
+
+    for (int it = 1; it <= a.max_iter; ++it) {
+        const bool lane_live = !((done >> lane) & 1ull);
+        for (int l = 0; l < a.n_levels; ++l) {
+            const int p1 = sload(a.lvl_ptr + l + 1);
+            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves)
+                soft_update_bit(a, sload(a.lvl_bits + p), At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+            __syncthreads();
+        }
+        uint64_t unsat = 0;
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            uint64_t cand = 0;
+            for (int g = a.row_ptr[i]; g < a.row_ptr[i + 1]; ++g) cand ^= dcur[a.col_idx[g]];
+            unsat |= cand ^ syn[i];
+        }
+        unsat = wave_or(unsat);
+        volatile uint64_t *slot_red = red + (it & 1) * 16;
+        if (lane == 0) slot_red[wave] = unsat;
+        __syncthreads();
+        unsat = 0;
+        for (int w = 0; w < nwaves; ++w) unsat |= slot_red[w];
+        const uint64_t newly = uniform64(~unsat & ~done);
+        if (newly) {
+            if ((newly >> lane) & 1ull) my_iter = it;
+            for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & ~newly) | (dcur[j] & newly);
+            done |= newly;
+            __syncthreads();
+        }
+        if (done == ~0ull) break;
+    }
+    __syncthreads();
+    if (done != ~0ull)
+        for (int j = threadIdx.x; j < n; j += blockDim.x) dec[j] = (dec[j] & done) | (dcur[j] & ~done);
+    if (wave == 0) {
+        const int64_t b = tile * LDPC_WAVE + lane;
+        if (b < a.batch) {
+            const bool cv = ((done >> lane) & 1ull) != 0;
+            if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;
+            if (a.conv) a.conv[b] = cv ? 1 : 0;
+        }
     }
 }

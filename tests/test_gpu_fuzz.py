@@ -118,6 +118,8 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
     o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method="minimum_sum", ms_scaling_factor=0.9)
     eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 1, 0.9)
     want = o.soft_info_decode_batch(soft, 3.0, 1.5)
-    got = eng.soft_info_decode_batch(soft, 3.0, 1.5)
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
-    assert bits_equal(got[1], want[1]) and bits_equal(got[4], want[4])
+    for serial_kernel in (0, 1):
+        eng.set_serial_kernel(serial_kernel)
+        got = eng.soft_info_decode_batch(soft, 3.0, 1.5)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), serial_kernel
+        assert bits_equal(got[1], want[1]) and bits_equal(got[4], want[4]), serial_kernel

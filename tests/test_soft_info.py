@@ -88,7 +88,9 @@ def test_device_reproduces_golden(name):
     c = load_soft(name)
     h = c["h"]
     eng = HipBpEngine(h.indptr, h.indices, c["n"], c["channel_probs"], c["max_iter"], 1, c["ms_scaling_factor"])
-    _same(eng.soft_info_decode_batch(c["soft"], c["cutoff"], c["sigma"]), c)
+    for serial_kernel in (-1, 0, 1):  # automatic, bit by bit, level-parallel
+        eng.set_serial_kernel(serial_kernel)
+        _same(eng.soft_info_decode_batch(c["soft"], c["cutoff"], c["sigma"]), c)
     import torch
     t = eng.soft_info_decode_batch(torch.from_numpy(c["soft"]).cuda(), c["cutoff"], c["sigma"])
     _same(tuple(x.cpu().numpy() for x in t), c)

@@ -54,6 +54,8 @@ def main():
         serial()
     if "serial_big" in args.which:
         serial_big()
+    if "soft" in args.which:
+        soft()
     if "osdw" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05", h, 0.05, 50, 0, 1.0, 8192, False, osd=(3, 10))
@@ -67,6 +69,33 @@ def main():
         run("c5 BB144 product_sum 50 it (BP only) p=0.05", h, 0.05, 50, 0, 1.0, 8192, False)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144 fast math", h, 0.05, 50, 0, 1.0, 262144, True, math="fast")
+
+
+def soft():
+    """SoftInfoBpDecoder path: analog syndromes (+-2 by the true bit, triangular noise), serial minimum-sum."""
+    import time
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    for name, h, p, max_iter, alpha in (("BB144", codes.bivariate_bicycle_hx(), 0.05, 50, 0.9),
+                                        ("surface d=21", codes.rotated_surface_code_x(21), 0.05, 30, 0.625)):
+        m, n = h.shape
+        for batch in (65536, 262144):
+            eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 1, alpha)
+            s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
+            g = torch.Generator(device="cuda").manual_seed(1)
+            soft = (1.0 - 2.0 * s.double()) * 2.0 + 2.5 * (torch.rand(s.shape, generator=g, device="cuda", dtype=torch.float64)
+                                                           + torch.rand(s.shape, generator=g, device="cuda", dtype=torch.float64) - 1.0)
+            out = eng.soft_info_decode_batch(soft, 2.0, 0.7)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                out = eng.soft_info_decode_batch(soft, 2.0, 0.7)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
+            print(json.dumps({"config": f"soft-info: {name} serial min_sum {max_iter} it, cutoff 2, sigma 0.7, B={batch}", "batch": batch,
+                              "syndromes_per_s": batch / ms * 1e3, "ms_per_decode": ms, "mean_iterations": float(out[2].float().mean()),
+                              "bp_converged": float(out[3].float().mean())}), flush=True)
 
 
 def serial_big():
