@@ -684,3 +684,24 @@ def test_serial_repacking_gives_identical_results(first_pass, oracle_built):
         assert 0.02 < 1 - c0.mean() < 0.9
     want = oracle_built.BpOracle(h, error_rate=0.06, max_iter=50, bp_method="minimum_sum", ms_scaling_factor=0.625).decode_serial_batch(synd[:300], None)
     assert np.array_equal(d1[:300], want[0]) and np.array_equal(i1[:300], want[2])
+
+
+@pytest.mark.parametrize("dv,dc", [(4, 8), (2, 4), (3, 9), (5, 10)])
+def test_streaming_variants_for_other_regular_codes(dv, dc, oracle_built):
+    """(4,8)-regular takes the second LDS-ring instantiation, (2,4) the <4,3> register bounds, (3,9) / (5,10) the
+    register variants with wider bounds: every template family of the streaming kernel against the oracle."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import regular_ldpc_code
+    n = 720
+    h = regular_ldpc_code(n, dv, dc, seed=11)
+    synd = _synd(h, 0.03, seed=4, shots=200)
+    for method, alpha in (("product_sum", 1.0), ("minimum_sum", 0.8)):
+        want = oracle_built.BpOracle(h, error_rate=0.03, max_iter=12, bp_method=method, ms_scaling_factor=alpha).decode_batch(synd)
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.03), 12, 0 if method == "product_sum" else 1, alpha)
+        eng.set_small_code_kernel(0)
+        for handoff, ring in ((0, 1), (0, 0), (100000, 1)):
+            eng.set_handoff(handoff)
+            eng.set_ring(ring)
+            got = eng.decode_batch(synd)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+            assert bits_equal(got[1], want[1])
