@@ -1,0 +1,17 @@
+import time, numpy as np, sys
+sys.path.insert(0, '.')
+from ldpc_amd.bp_decoder import BpDecoder
+from ldpc_amd import codes
+for name, h, p, mi in (("hamming(5) 5x31", codes.hamming_code(5), 0.05, 20), ("BB144", codes.bivariate_bicycle_hx(), 0.05, 50), ("ldpc n=10000", codes.regular_ldpc_code(10000, 3, 6, seed=1), 0.05, 50)):
+    m, n = h.shape
+    rng = np.random.default_rng(0)
+    e = (rng.random(n) < p).astype(np.uint8)
+    s = (h @ e % 2).astype(np.uint8)
+    for backend in ("cython", "ctypes"):
+        d = BpDecoder(h, error_rate=p, max_iter=mi, bp_method="product_sum", _backend=backend)
+        d.decode(s)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            d.decode(s)
+        dt = (time.perf_counter() - t0) / 200
+        print(f"{name:16s} {backend:7s} decode() {dt*1e6:8.1f} us per call, iterations {d.iter}")
