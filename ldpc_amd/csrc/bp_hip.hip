@@ -1169,7 +1169,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             sa.n_tiles = (int32_t)parked;
             first_round = 0;
             hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((parked + 255) / 256), dim3(256), 0, st, sa);
-            const dim3 gi((unsigned)((h->nnz + 63) / 64), parked);
+            const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), parked);  // (a grid dimension must not be 0: empty matrices)
             if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
             else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), gi, dim3(256), 0, st, sa);
             else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
@@ -1197,8 +1197,8 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             spread_kernel_t kc, kb;
             pick_spread(h, kc, kb);
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
-            const dim3 gc((unsigned)((h->m + per_wg - 1) / per_wg), parked), gb((unsigned)((h->n + per_wg - 1) / per_wg), parked);
-            const dim3 gs((unsigned)((h->m + 255) / 256), parked), gf((unsigned)((h->n + 63) / 64), parked);
+            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), parked), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), parked);
+            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), parked), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), parked);
             const int rounds = h->max_iter - first_round;
             for (int round = 0; round < rounds; ++round) {
                 sa.round = round;

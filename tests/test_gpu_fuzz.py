@@ -123,3 +123,31 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
         got = eng.soft_info_decode_batch(soft, 3.0, 1.5)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), serial_kernel
         assert bits_equal(got[1], want[1]) and bits_equal(got[4], want[4]), serial_kernel
+
+
+def test_matrix_without_entries(oracle_built):
+    """An all-zero parity-check matrix (nnz = 0): every kernel family must launch (no zero-sized grid) and agree with the oracle."""
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(np.zeros((3, 5), np.uint8))
+    s = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 1]], np.uint8)
+    for method in ("product_sum", "minimum_sum"):
+        o = oracle_built.BpOracle(h, error_rate=0.1, max_iter=4, bp_method=method, ms_scaling_factor=0.9)
+        want = o.decode_batch(s)
+        eng = HipBpEngine(h.indptr, h.indices, 5, np.full(5, 0.1), 4, 0 if method == "product_sum" else 1, 0.9)
+        for small, handoff in ((-1, -1), (0, 0), (0, 100000)):
+            eng.set_small_code_kernel(small)
+            eng.set_handoff(handoff)
+            got = eng.decode_batch(s)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+            assert bits_equal(got[1], want[1])
+        eng.set_schedule("serial")
+        ws = o.decode_serial_batch(s, None)
+        for serial_kernel in (0, 1):
+            eng.set_serial_kernel(serial_kernel)
+            got = eng.decode_batch(s)
+            assert np.array_equal(got[0], ws[0]) and np.array_equal(got[2], ws[2]) and np.array_equal(got[3], ws[3])
+    eng = HipBpEngine(h.indptr, h.indices, 5, np.full(5, 0.1), 4, 1, 0.9)
+    soft = np.array([[1.0, 2.0, 0.5], [-1.0, 2.0, 0.5]])
+    want = oracle_built.BpOracle(h, error_rate=0.1, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.9).soft_info_decode_batch(soft, 3.0, 2.0)
+    got = eng.soft_info_decode_batch(soft, 3.0, 2.0)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
