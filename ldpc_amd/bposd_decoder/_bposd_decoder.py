@@ -96,7 +96,7 @@ class BpOsdDecoder(BpDecoderBase):
     def _decode_osd(self, synd2d, want_llr=True, force_osd0=False):
         """BP + OSD through the active backend with this decoder's osd_method / osd_order."""
         method, order = (OSD_0, 0) if force_osd0 else (self._osd_method, self._osd_order)
-        cy = self._get_cy()
+        cy = self._get_cy() if self._schedule == PARALLEL else None  # the schedule setters live on the ctypes engine
         if cy is not None:
             cy.osd_method, cy.osd_order = method, order
             return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, True)

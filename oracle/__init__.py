@@ -299,7 +299,7 @@ class RefBpOsd:
     """The real reference BP + ``ldpc::osd::OsdDecoder`` (OSD_0) behind oracle/ref_harness.cpp."""
 
     def __init__(self, h, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum", ms_scaling_factor=1.0,
-                 osd_method=1, osd_order=0):
+                 osd_method=1, osd_order=0, schedule="parallel"):
         if not have_ref():
             raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
         lib = C.CDLL(REF_SO)
@@ -315,8 +315,11 @@ class RefBpOsd:
         rows = np.repeat(np.arange(self.m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32)
         self.channel_probs = _probs(self.n, error_rate, error_channel)
         self.max_iter = int(max_iter) if max_iter else self.n
-        self._h = lib.ref_bposd_new(self.m, self.n, len(col_idx), np.ascontiguousarray(rows), col_idx, self.channel_probs,
-                                    self.max_iter, _method_id(bp_method), float(ms_scaling_factor))
+        lib.ref_bposd_new2.restype = C.c_void_p
+        lib.ref_bposd_new2.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_double, C.c_int]
+        self._h = lib.ref_bposd_new2(self.m, self.n, len(col_idx), np.ascontiguousarray(rows), col_idx, self.channel_probs,
+                                     self.max_iter, _method_id(bp_method), float(ms_scaling_factor),
+                                     {"parallel": 1, "serial": 0}[schedule])
         if (int(osd_method), int(osd_order)) != (1, 0):
             lib.ref_bposd_set_osd(self._h, int(osd_method), int(osd_order))
         self.k = int(lib.ref_bposd_k(self._h))

@@ -113,6 +113,14 @@ struct ref_bposd {
 
 extern "C" {
 
+ref_bposd *ref_bposd_new2(int m, int n, int nnz, const int32_t *rows, const int32_t *cols,
+                          const double *channel_probs, int max_iter, int bp_method, double ms_scaling_factor, int schedule) {
+    auto *r = new ref_bposd;
+    r->bp = ref_bp_new(m, n, nnz, rows, cols, channel_probs, max_iter, bp_method, schedule, ms_scaling_factor, 0 /*SYNDROME*/);
+    r->osd = new ldpc::osd::OsdDecoder(*r->bp->pcm, ldpc::osd::OSD_0, 0, r->bp->dec->channel_probabilities);
+    return r;
+}
+
 ref_bposd *ref_bposd_new(int m, int n, int nnz, const int32_t *rows, const int32_t *cols,
                          const double *channel_probs, int max_iter, int bp_method, double ms_scaling_factor) {
     auto *r = new ref_bposd;
