@@ -151,3 +151,67 @@ def test_matrix_without_entries(oracle_built):
     want = oracle_built.BpOracle(h, error_rate=0.1, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.9).soft_info_decode_batch(soft, 3.0, 2.0)
     got = eng.soft_info_decode_batch(soft, 3.0, 2.0)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_one_handle_through_a_random_sequence_of_settings(seed, oracle_built):
+    """A handle is stateful (workspace reuse, cached tables, schedule levels, OSD settings): drive ONE handle through a random
+    sequence of parameter changes and batch sizes and compare every decode with a fresh oracle for the current settings."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd import codes
+    rng = np.random.default_rng(500 + seed)
+    h = sp.csr_matrix([codes.bivariate_bicycle_hx(), codes.rotated_surface_code_x(5), codes.regular_ldpc_code(96, 3, 6, seed=3),
+                       codes.hamming_code(4)][seed])
+    m, n = h.shape
+    st = dict(p=np.full(n, 0.06), max_iter=6, method=0, alpha=1.0, schedule="parallel", order=None)
+    eng = HipBpEngine(h.indptr, h.indices, n, st["p"], st["max_iter"], st["method"], st["alpha"])
+    for step in range(40):
+        op = int(rng.integers(8))
+        if op == 0:
+            st["p"] = rng.uniform(0.01, 0.2, size=n) if rng.random() < 0.5 else np.full(n, float(rng.uniform(0.02, 0.12)))
+            eng.set_channel(st["p"])
+        elif op == 1:
+            st["max_iter"], st["method"] = int(rng.integers(1, 10)), int(rng.integers(2))
+            st["alpha"] = 1.0 if st["method"] == 0 else float(rng.choice([0.0, 0.625, 0.9]))
+            eng.set_params(st["max_iter"], st["method"], st["alpha"])
+        elif op == 2:
+            if rng.random() < 0.5:
+                st["schedule"], st["order"] = "parallel", None
+                eng.set_schedule("parallel")
+            else:
+                st["schedule"] = "serial"
+                st["order"] = rng.permutation(n).astype(np.int32) if rng.random() < 0.6 else None
+                eng.set_schedule("serial", st["order"])
+        elif op == 3:
+            eng.set_small_code_kernel(int(rng.choice([-1, 0, 1, 2, 3])))
+            eng.set_handoff(int(rng.choice([-1, 0, 2, 100000])))
+        elif op == 4:
+            eng.set_serial_kernel(int(rng.choice([-1, 0, 1])))
+            eng.set_repack(int(rng.choice([-1, 0, 2])))
+            eng.set_osd_kernel(int(rng.choice([-1, 0])))
+        batch = int(rng.choice([1, 7, 64, 65, 200, 700]))
+        e = (rng.random((batch, n)) < 0.07).astype(np.uint8)
+        s = np.ascontiguousarray((h @ e.T % 2).T.astype(np.uint8))
+        o = oracle_built.BpOracle(h, error_channel=st["p"], max_iter=st["max_iter"], bp_method=("product_sum", "minimum_sum")[st["method"]],
+                                  ms_scaling_factor=st["alpha"])
+        want_llr = bool(rng.random() < 0.7)
+        osd = [None, (1, 0), (3, 4), (2, 3)][int(rng.integers(4))]
+        if st["schedule"] == "serial":
+            want = list(o.decode_serial_batch(s, st["order"]))
+            if osd is not None:
+                for b in np.flatnonzero(~want[3]):
+                    want[0][b] = o.osdw(s[b], want[1][b], osd[0], osd[1], channel_probs=st["p"])[0]
+        elif osd is not None:
+            want = o.bposd_decode_batch(s, osd[0], osd[1])
+        else:
+            want = o.decode_batch(s)
+        if osd is not None:
+            eng.set_osd(*osd)
+        got = eng.decode_batch(s, want_llr=want_llr, osd=osd is not None)
+        tag = f"seed {seed} step {step} {st['schedule']} method {st['method']} it {st['max_iter']} B {batch} osd {osd}"
+        assert np.array_equal(got[0], want[0]), "decoding: " + tag
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), "iterations / converge: " + tag
+        if want_llr:
+            assert bits_equal(got[1], want[1]), "log-ratios: " + tag
+        else:
+            assert got[1] is None
