@@ -716,7 +716,11 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
             if (level_waves < 1) level_waves = 1;
         }
     }
-    void (*soft_kern)(const SoftArgs) = level_waves ? bp_softinfo_level_kernel : bp_softinfo_kernel;
+    void (*soft_kern)(const SoftArgs);
+    if (h->max_row_deg <= 4 && h->max_col_deg <= 2) soft_kern = level_waves ? bp_softinfo_level_kernel<2, 4> : bp_softinfo_kernel<2, 4>;
+    else if (h->max_row_deg <= 6 && h->max_col_deg <= 3) soft_kern = level_waves ? bp_softinfo_level_kernel<3, 6> : bp_softinfo_kernel<3, 6>;
+    else if (h->max_row_deg <= 8 && h->max_col_deg <= 4) soft_kern = level_waves ? bp_softinfo_level_kernel<4, 8> : bp_softinfo_kernel<4, 8>;
+    else soft_kern = level_waves ? bp_softinfo_level_kernel<0, 0> : bp_softinfo_kernel<0, 0>;
     if (lds > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)soft_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->accumulated_ms = 0.f;

@@ -312,6 +312,88 @@ __global__ void __launch_bounds__(256) softinfo_prepare_kernel(const double *__r
 
 // One bit update of soft_info_decode_serial (bp.hpp:580-639) for the 64 shots of a tile; `syn` = the tile's current hard
 // syndrome words in LDS.  Shared by the single-wavefront kernel and the level-parallel one.
+// The same bit update with everything the bit needs loaded up front (its <= DCS incident rows of <= DRS entries and their
+// soft-syndrome values are distinct rows, so the loads are independent of what the update writes): one round of memory
+// latency per bit instead of one per entry.  Used when the matrix respects the bounds.
+template <int DCS, int DRS, class SynPtr>
+__device__ __forceinline__ void soft_update_bit_fast(const SoftArgs &a, int bit, const MsgBuf &At, const MsgBuf &St, const MsgBuf &Lt,
+                                                     SynPtr syn, uint64_t *dcur, int lane, int l8, bool want_llr, bool lane_live) {
+    const int cs = sload(a.col_ptr + bit);
+    const int d = sload(a.col_ptr + bit + 1) - cs;
+    int e[DCS], chk[DCS], rs[DCS], rd[DCS];
+    double vals[DCS][DRS], softv[DCS], c[DCS], pre[DCS];
+#pragma unroll
+    for (int k = 0; k < DCS; ++k)
+        if (k < d) {
+            e[k] = sload(a.csc_edge + cs + k);
+            chk[k] = sload(a.csc_row + cs + k);
+            rs[k] = sload(a.row_ptr + chk[k]);
+            rd[k] = sload(a.row_ptr + chk[k] + 1) - rs[k];
+#pragma unroll
+            for (int q = 0; q < DRS; ++q)
+                if (q < rd[k]) vals[k][q] = At.ld(l8, rs[k] + q);
+            softv[k] = St.ld(l8, chk[k]);
+        }
+    double llr = sload(a.llr0 + bit);  // bp.hpp:583-584
+#pragma unroll
+    for (int k = 0; k < DCS; ++k)
+        if (k < d) {
+            int sgn = 0;
+            double temp = DBL_MAX, own = 0.0;
+#pragma unroll
+            for (int q = 0; q < DRS; ++q)
+                if (q < rd[k]) {
+                    const double bg = vals[k][q];
+                    if (rs[k] + q == e[k]) {
+                        own = bg;
+                    } else {  // bp.hpp:590-599
+                        if (fabs(bg) < temp) temp = fabs(bg);
+                        if (bg <= 0) sgn ^= 1;
+                    }
+                }
+            const double min_msg = temp;
+            double propagated = min_msg;
+            double soft = softv[k];
+            const double magnitude = fabs(soft);
+            uint64_t word = syn[chk[k]];
+            int hard = (int)((word >> lane) & 1ull);
+            bool flip = false;
+            if (magnitude < a.cutoff && magnitude < fabs(min_msg)) {  // bp.hpp:604-621
+                propagated = magnitude;
+                const int check_node_sgn = sgn ^ (own <= 0 ? 1 : 0);
+                if (check_node_sgn == hard) {
+                    const double mag = fabs(own) < min_msg ? fabs(own) : min_msg;
+                    soft = hard ? -mag : mag;
+                } else {
+                    flip = true;
+                    soft = -soft;
+                }
+                if (lane_live) St.st(l8, chk[k], soft);
+            }
+            const uint64_t flips = __ballot(flip);
+            if (flips) {  // wave-uniform
+                word ^= flips;
+                if (lane == 0) syn[chk[k]] = word;
+                hard = (int)((word >> lane) & 1ull);
+                __builtin_amdgcn_wave_barrier();
+            }
+            sgn ^= hard;
+            c[k] = (a.ms_scaling_factor * (sgn ? -1.0 : 1.0)) * propagated;  // bp.hpp:624
+            pre[k] = llr;
+            llr += c[k];
+        }
+    double back = 0.0;  // bp.hpp:634-638
+#pragma unroll
+    for (int k = DCS - 1; k >= 0; --k)
+        if (k < d) {
+            At.st(l8, e[k], pre[k] + back);
+            back += c[k];
+        }
+    const uint64_t hard_bits = __ballot(llr <= 0);  // bp.hpp:628-633
+    if (lane == 0) dcur[bit] = hard_bits;
+    if (want_llr && lane_live) Lt.st(l8, bit, llr);
+}
+
 template <class SynPtr>
 __device__ __forceinline__ void soft_update_bit(const SoftArgs &a, int bit, const MsgBuf &At, const MsgBuf &Ct, const MsgBuf &St,
                                                 const MsgBuf &Lt, SynPtr syn, uint64_t *dcur, int lane, int l8, bool want_llr,
@@ -374,6 +456,8 @@ __device__ __forceinline__ void soft_update_bit(const SoftArgs &a, int bit, cons
     if (want_llr && lane_live) Lt.st(l8, bit, llr);
 }
 
+// DCS / DRS > 0: the register path above (the matrix respects the bounds); DCS == 0: run-time loops for any degrees
+template <int DCS, int DRS>
 __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
     volatile uint64_t *syn = reinterpret_cast<volatile uint64_t *>(soft_lds);  // [m] current hard syndrome
@@ -400,7 +484,8 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
         const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
         for (int t = 0; t < n; ++t) {
             const int bit = a.order ? sload(a.order + t) : t;
-            soft_update_bit(a, bit, At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+            if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, bit, At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+            else soft_update_bit(a, bit, At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
         }
         // H x against the CURRENT hard syndrome (bp.hpp:640-655)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -432,6 +517,7 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
 
 // The same, level-parallel (see bp_serial_level_kernel): bits of a level share no check, hence touch disjoint messages,
 // disjoint soft-syndrome entries and disjoint hard-syndrome words -- a workgroup runs the tile level by level.
+template <int DCS, int DRS>
 __global__ void __launch_bounds__(1024) bp_softinfo_level_kernel(const SoftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char soft_lds[];
     volatile uint64_t *syn = reinterpret_cast<volatile uint64_t *>(soft_lds);  // [m] current hard syndrome, then [2][16] reduction slots
@@ -460,8 +546,10 @@ __global__ void __launch_bounds__(1024) bp_softinfo_level_kernel(const SoftArgs 
         const bool lane_live = !((done >> lane) & 1ull);
         for (int l = 0; l < a.n_levels; ++l) {
             const int p1 = sload(a.lvl_ptr + l + 1);
-            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves)
-                soft_update_bit(a, sload(a.lvl_bits + p), At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves) {
+                if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, sload(a.lvl_bits + p), At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+                else soft_update_bit(a, sload(a.lvl_bits + p), At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+            }
             __syncthreads();
         }
         uint64_t unsat = 0;
