@@ -121,6 +121,7 @@ struct ldpc_hip_bp {
     double *d_llr0 = nullptr;
     double *d_osd_wt = nullptr;  // [n] log(1 / p_j), the candidate weights of higher-order OSD
     bool osd_reg = true;  // register-resident elimination for small matrices (ldpc_hip_bp_set_osd_kernel)
+    int osd_k_cached = -1;  // n - rank(H), computed on first use
     int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
 
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -1239,6 +1240,32 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 
 
 // BP, then OSD-0 on the rows BP left unconverged; device pointers, on h->stream
+// k = n - rank(H) over GF(2): how many non-pivot columns an OSD elimination leaves (independent of the column order)
+static int osd_k(ldpc_hip_bp *h) {
+    if (h->osd_k_cached >= 0) return h->osd_k_cached;
+    const int m = h->m, n = h->n, W = (n + 63) / 64;
+    std::vector<uint64_t> mat((size_t)(m ? m : 1) * (size_t)(W ? W : 1), 0);
+    for (int i = 0; i < m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int c = h->h_col_idx[(size_t)e];
+            mat[(size_t)i * W + (size_t)(c >> 6)] |= 1ull << (c & 63);
+        }
+    int rank = 0;
+    for (int c = 0; c < n && rank < m; ++c) {
+        int p = -1;
+        for (int i = rank; i < m; ++i)
+            if ((mat[(size_t)i * W + (size_t)(c >> 6)] >> (c & 63)) & 1ull) { p = i; break; }
+        if (p < 0) continue;
+        for (int w = 0; w < W; ++w) std::swap(mat[(size_t)p * W + w], mat[(size_t)rank * W + w]);
+        for (int i = 0; i < m; ++i)
+            if (i != rank && ((mat[(size_t)i * W + (size_t)(c >> 6)] >> (c & 63)) & 1ull))
+                for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] ^= mat[(size_t)rank * W + w];
+        ++rank;
+    }
+    h->osd_k_cached = n - rank;
+    return h->osd_k_cached;
+}
+
 static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                         double *llr, int32_t *iters, uint8_t *conv) {
     if (osd_method == 0)  // OSD_OFF: BpOsdDecoder still calls OsdDecoder::decode, which then has no LU object -- refuse instead
@@ -1263,7 +1290,14 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         else if (a.m <= 128 && a.words <= 4) reg0 = osd0_reg_kernel<2, 4>;
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
     }
+    void (*regw)(const OsdArgs) = nullptr;
+    if (higher && h->osd_reg && a.m <= 256 && a.words <= 8 && osd_k(h) <= 128) {
+        if (a.m <= 64 && a.words <= 2) regw = osdw_reg_kernel<1, 2>;
+        else if (a.m <= 128 && a.words <= 4) regw = osdw_reg_kernel<2, 4>;
+        else regw = osdw_reg_kernel<4, 8>;
+    }
     size_t per_wave = reg0 ? (size_t)a.n * 4
+                    : regw ? (size_t)a.n * (8 + 8 + 8 + 4 + 4 + 1) + 128 * 4
                     : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
@@ -1274,7 +1308,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     if (waves > 4) waves = 4;
     a.lds_per_wave = (int32_t)per_wave;
     const size_t dyn = per_wave * (size_t)waves;
-    const void *fn = reg0 ? (const void *)reg0 : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
+    const void *fn = reg0 ? (const void *)reg0 : regw ? (const void *)regw : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     // list the unconverged rows, then persistent wavefronts (as many as LDS lets reside) pull rows from the list
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
@@ -1290,6 +1324,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     int64_t blocks = 256 * (int64_t)groups_per_cu;
     if (blocks > (batch + waves - 1) / waves) blocks = (batch + waves - 1) / waves;
     if (reg0) hipLaunchKernelGGL(reg0, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
+    else if (regw) hipLaunchKernelGGL(regw, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());

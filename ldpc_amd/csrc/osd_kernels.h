@@ -478,3 +478,137 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
     __builtin_amdgcn_wave_barrier();
     }  // next row
 }
+
+
+// ---- higher-order OSD with the elimination in registers (small matrices, k = n - rank <= 128) -------------------
+// As osdw_kernel, but (i) the reduced row echelon form is computed in registers (osd_eliminate), and (ii) what a
+// candidate needs is laid out per COLUMN once: for column i a 128-bit word colT[i] and a bit colS[i] such that the
+// candidate with non-pivot mask M has x_i = parity(colT[i] & M) ^ colS[i] -- for a pivot column colT is its row of the
+// reduced matrix restricted to the non-pivot columns and colS the reduced syndrome bit, for the q-th non-pivot column
+// colT = 1 << q and colS = 0.  Weighing a candidate is then one pass of independent LDS reads in ascending bit order,
+// accumulated sequentially as the reference does (osd.hpp:171-176); no dependent look-ups, no per-candidate solve.
+struct OsdCandidate128 {
+    uint64_t lo, hi;
+    bool valid;
+};
+
+__device__ __forceinline__ OsdCandidate128 osd_candidate128(int method, int order, int k, long c) {
+    OsdCandidate128 r;
+    r.lo = r.hi = 0;
+    r.valid = true;
+    if (method == 2) {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
+        r.lo = (uint64_t)(c + 1) & (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
+    } else if (c < k) {  // weight one (osd.hpp:84-89); k <= 128 here
+        if (c < 64) r.lo = 1ull << c; else r.hi = 1ull << (c - 64);
+    } else {  // pairs (i, j), i < j < order <= 64, i-major (osd.hpp:91-99)
+        long p = c - k;
+        int i = 0;
+        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
+        const int j = i + 1 + (int)p;
+        if (j >= k) r.valid = false;
+        else r.lo = (1ull << i) | (1ull << j);
+    }
+    return r;
+}
+
+template <int R, int W>
+__global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64;
+    typedef __attribute__((address_space(3))) double lds_f64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int m = a.m, n = a.n;
+    lds_u8 *base = (lds_u8 *)osd_lds + wave * a.lds_per_wave;
+    volatile lds_u64 *colTa = (volatile lds_u64 *)base;            // [n]
+    volatile lds_u64 *colTb = colTa + n;                           // [n]
+    volatile lds_f64 *keys = (volatile lds_f64 *)(colTb + n);      // [n] weights log(1 / p_j)
+    volatile lds_i32 *order = (volatile lds_i32 *)(keys + n);      // [n]
+    volatile lds_i32 *colQ = order + n;                            // [n] -1: pivot column, q >= 0: the q-th non-pivot column
+    volatile lds_i32 *npcol = colQ + n;                            // [128]
+    volatile lds_u8 *colS = (volatile lds_u8 *)(npcol + 128);      // [n]
+    const int sw = n >> 6;
+    const uint64_t sbit = 1ull << (n & 63);
+    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+        OsdRows<R, W> rows;
+        osd_load_rows<R, W>(a, b, lane, rows);
+        osd_sort_columns<W>(a.llr + b * n, n, lane, order);
+        for (int j = lane; j < n; j += 64) { colQ[j] = -2; keys[j] = a.wt[j]; }
+        __builtin_amdgcn_wave_barrier();
+        osd_eliminate<R, W, false>(rows, order, m, n, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (rows.pcol[r] >= 0) {
+                colQ[rows.pcol[r]] = -1;
+                colS[rows.pcol[r]] = (osd_word<W>(rows.w[r], sw) & sbit) ? 1 : 0;
+            }
+        __builtin_amdgcn_wave_barrier();
+        int k = 0;  // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            const int t = t0 + lane;
+            const int c = t < n ? order[t] : 0;
+            const bool np = t < n && colQ[c] == -2;
+            const uint64_t mask = __ballot(np);
+            if (np) {
+                const int q = k + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                colQ[c] = q;
+                colS[c] = 0;
+                colTa[c] = q < 64 ? 1ull << q : 0ull;
+                colTb[c] = (q >= 64 && q < 128) ? 1ull << (q - 64) : 0ull;
+                if (q < 128) npcol[q] = c;
+            }
+            k += __builtin_popcountll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int k128 = k < 128 ? k : 128;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {  // the reduced matrix on the non-pivot columns: two words per pivot row, filed under its pivot column
+            uint64_t ta = 0, tb = 0;
+            for (int q = 0; q < k128; ++q) {
+                const int c = npcol[q];
+                const uint64_t bit = (osd_word<W>(rows.w[r], c >> 6) >> (c & 63)) & 1ull;
+                if (q < 64) ta |= bit << q; else tb |= bit << (q - 64);
+            }
+            if (rows.pcol[r] >= 0) { colTa[rows.pcol[r]] = ta; colTb[rows.pcol[r]] = tb; }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        auto bit_of = [&](const OsdCandidate128 &cd, int i) -> bool {
+            return ((__builtin_popcountll(colTa[i] & cd.lo) + __builtin_popcountll(colTb[i] & cd.hi) + (int)colS[i]) & 1) != 0;
+        };
+        auto weight_of = [&](const OsdCandidate128 &cd) -> double {
+            double acc = 0;
+            for (int i = 0; i < n; ++i)
+                if (bit_of(cd, i)) acc += keys[i];
+            return acc;
+        };
+        OsdCandidate128 none;
+        none.lo = none.hi = 0; none.valid = true;
+        const double w0 = weight_of(none);  // the OSD-0 solution (osd.hpp:131-136)
+        const long ncand = a.method == 2 ? (1L << a.order) - 1 : (long)k + (long)a.order * (a.order - 1) / 2;
+        double best_w = w0;
+        long best_c = -1;
+        for (long c0 = 0; c0 < ncand; c0 += 64) {
+            const long c = c0 + lane;
+            if (c < ncand) {
+                const OsdCandidate128 cd = osd_candidate128(a.method, a.order, k, c);
+                if (cd.valid) {
+                    const double w = weight_of(cd);
+                    if (w < best_w) { best_w = w; best_c = c; }  // strict: the first lightest candidate stays (osd.hpp:177)
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {  // across lanes: lightest, then earliest
+            const double ow = __shfl_xor(best_w, off);
+            const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
+            const bool mine_set = best_c >= 0, other_set = oc >= 0;
+            if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+        }
+        OsdCandidate128 win = none;
+        if (best_c >= 0) win = osd_candidate128(a.method, a.order, k, best_c);
+        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = bit_of(win, j) ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
