@@ -132,6 +132,7 @@ struct ldpc_hip_bp {
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
     int32_t serial_kernel = -1;                                     // -1 auto, 0 one wavefront per tile, 1 level-parallel workgroup per tile
@@ -272,7 +273,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1291,21 +1292,44 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
     }
     void (*regw)(const OsdArgs) = nullptr;
-    if (higher && h->osd_reg && a.m <= 256 && a.words <= 8 && osd_k(h) <= 128) {
+    if (higher && h->osd_reg && a.m <= 256 && a.words <= 8) {
+        a.kwords = (osd_k(h) + 63) / 64;
+        if (a.kwords < 1) a.kwords = 1;
         if (a.m <= 64 && a.words <= 2) regw = osdw_reg_kernel<1, 2>;
         else if (a.m <= 128 && a.words <= 4) regw = osdw_reg_kernel<2, 4>;
         else regw = osdw_reg_kernel<4, 8>;
     }
+    if (reg0 || regw) {  // H bit-packed by rows, once per handle
+        a.rank = a.n - osd_k(h);
+        if (!h->osd_packed.p) {
+            std::vector<uint64_t> packed((size_t)a.m * (size_t)a.words, 0);
+            for (int i = 0; i < a.m; ++i)
+                for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+                    const int c = h->h_col_idx[(size_t)e];
+                    packed[(size_t)i * (size_t)a.words + (size_t)(c >> 6)] |= 1ull << (c & 63);
+                }
+            if ((rc = h->osd_packed.ensure(packed.size() * 8))) return rc;
+            HIPCHK(hipMemcpy(h->osd_packed.p, packed.data(), packed.size() * 8, hipMemcpyHostToDevice));
+        }
+        a.packed = (const uint64_t *)h->osd_packed.p;
+    }
     size_t per_wave = reg0 ? (size_t)a.n * 4
-                    : regw ? (size_t)a.n * (8 + 8 + 8 + 4 + 4 + 1) + 128 * 4
+                    : regw ? (size_t)a.n * (8 * ((size_t)a.kwords + 2) + 4 + 4) + 64 * (size_t)a.kwords * 4
                     : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
     if (per_wave > 150u * 1024u)
         return fail(LDPC_HIP_ERR_UNSUPPORTED,
                     "OSD on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB available", per_wave);
-    int waves = (int)((150u * 1024u) / per_wave);
-    if (waves > 4) waves = 4;
+    // wavefronts per workgroup: whichever of 1..4 lets most wavefronts reside on a CU (a workgroup's LDS is one
+    // allocation, so large per-wavefront tables pack better in small workgroups); ties go to the larger workgroup
+    int waves = 1, resident_best = 0;
+    for (int w = 1; w <= 4; ++w) {
+        if ((size_t)w * per_wave > 150u * 1024u) break;
+        int resident = (int)((160u * 1024u) / ((size_t)w * per_wave)) * w;
+        if (resident > 32) resident = 32;
+        if (resident >= resident_best) { resident_best = resident; waves = w; }
+    }
     a.lds_per_wave = (int32_t)per_wave;
     const size_t dyn = per_wave * (size_t)waves;
     const void *fn = reg0 ? (const void *)reg0 : regw ? (const void *)regw : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
@@ -1646,3 +1670,11 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
 }
 
 }  // extern "C"
+
+#ifdef LDPC_HIP_OSD_CLOCKS
+extern "C" int ldpc_hip_debug_osd_clocks(unsigned long long *out, int reset) {
+    if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(osd_phase_clocks), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(osd_phase_clocks), z, sizeof z)); }
+    return LDPC_HIP_OK;
+}
+#endif

@@ -4,6 +4,16 @@
 
 #include "bp_device_common.h"
 
+#ifdef LDPC_HIP_OSD_CLOCKS  // profiling aid (tools/osd_phase_clocks.py): cycles per phase of osdw_reg_kernel, summed over wavefronts
+__device__ unsigned long long osd_phase_clocks[8];
+#define OSD_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                           if (lane == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
+#define OSD_CLK_START() unsigned long long clk_ = __builtin_readcyclecounter()
+#else
+#define OSD_CLK(slot) do { } while (0)
+#define OSD_CLK_START() do { } while (0)
+#endif
+
 // ---- OSD-0 (osd.hpp:110-117 = sort.hpp:48-62 + gf2sparse_linalg.hpp:298-401, 237-288) -------------
 // One wavefront per syndrome that BP left unconverged.  The reference sorts the columns by ascending
 // log-ratio (glibc qsort: stable, so ties keep ascending index), runs a greedy column-ordered Gaussian
@@ -16,12 +26,15 @@ struct OsdArgs {
     int32_t m, n, words;  // words = ceil((n + 1) / 64): n matrix bits + the syndrome bit per row
     int64_t batch;
     const int32_t *row_ptr, *col_idx;
+    const uint64_t *packed;  // [m][words] H bit-packed by rows (bit n, the syndrome's place, clear): register kernels
     const uint8_t *synd;   // [batch][m]
     const double *llr;     // [batch][n]  BP posteriors
     const uint8_t *conv;   // [batch]     1 = BP converged: row left untouched
     uint8_t *decoding;     // [batch][n]  in: BP decisions, out: OSD solution for unconverged rows
     int32_t lds_per_wave;  // bytes
     int32_t method, order; // osdw_kernel: 2 = exhaustive (OSD_E), 3 = combination sweep (OSD_CS); order > 0
+    int32_t kwords;        // osdw_reg_kernel: ceil((n - rank H) / 64), at least 1
+    int32_t rank;          // register kernels: rank of H over GF(2)
     const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
     const int32_t *list;   // rows BP left unconverged, any order (osd_collect_kernel)
     unsigned *counters;    // [0] number of entries of `list`, [1] next entry to hand out (both zeroed before the collect)
@@ -137,8 +150,10 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
 // column order goes through LDS once.  R and W are template bounds, so every register index is a compile-time one.
 template <int R, int W>
 struct OsdRows {
-    uint64_t w[R][W];
-    int32_t pcol[R];  // pivot column carried by the row, -1: none
+    uint64_t w[R][W];  // H (bit j = column j); bits >= n stay clear
+    uint32_t s[R];     // the syndrome column of [H | s], kept apart so that no step has to index a word by n / 64
+    int32_t pcol[R];   // pivot column carried by the row, -1: none
+    uint64_t unp[R];   // wave-uniform: lanes whose row r carries no pivot yet
 };
 
 __device__ __forceinline__ uint64_t osd_readlane64(uint64_t v, int src_lane) {  // src_lane wave-uniform
@@ -149,37 +164,19 @@ __device__ __forceinline__ uint64_t osd_readlane64(uint64_t v, int src_lane) {  
 __device__ __forceinline__ double osd_readlane_f64(double v, int src_lane) {
     return __builtin_bit_cast(double, osd_readlane64(__builtin_bit_cast(uint64_t, v), src_lane));
 }
-template <int W>
-__device__ __forceinline__ uint64_t osd_word(const uint64_t (&row)[W], int word) {  // word wave-uniform
-    // masked OR, not a select chain: the compiler turns a select chain into a dynamically indexed load from a scratch
-    // copy of the rows
-    uint64_t v = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) v |= row[w] & (0ull - (uint64_t)(word == w));
-    return v;
-}
-
-// [H | s] of batch row b into registers (bit n of a row = its syndrome byte != 0, gf2sparse_linalg.hpp:309)
+// [H | s] of batch row b into registers (bit n of a row = its syndrome byte != 0, gf2sparse_linalg.hpp:309); H comes
+// bit-packed (a.packed), so a row is W independent loads rather than a walk over its CSR entries
 template <int R, int W>
 __device__ __forceinline__ void osd_load_rows(const OsdArgs &a, int64_t b, int lane, OsdRows<R, W> &rows) {
-    const int m = a.m, n = a.n;
+    const int m = a.m;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = r * 64 + lane;
         rows.pcol[r] = -1;
+        rows.unp[r] = ~0ull;
 #pragma unroll
-        for (int w = 0; w < W; ++w) rows.w[r][w] = 0;
-        if (i < m) {
-            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
-                const int c = a.col_idx[e];
-#pragma unroll
-                for (int w = 0; w < W; ++w) rows.w[r][w] |= (c >> 6) == w ? 1ull << (c & 63) : 0ull;
-            }
-            if (a.synd[b * m + i]) {
-#pragma unroll
-                for (int w = 0; w < W; ++w) rows.w[r][w] |= (n >> 6) == w ? 1ull << (n & 63) : 0ull;
-            }
-        }
+        for (int w = 0; w < W; ++w) rows.w[r][w] = (i < m && w < a.words) ? a.packed[(size_t)i * a.words + w] : 0ull;
+        rows.s[r] = (i < m && a.synd[b * m + i]) ? 1u : 0u;
     }
 }
 
@@ -207,10 +204,14 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
         const int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
         for (int l = 0; l < cnt; ++l) {
             const uint64_t kj = osd_readlane64(key[q], l);
-            const int jj = q * 64 + l;
+            // column jj sorts before column q2 * 64 + lane: smaller key, ties by index -- and which index is smaller is
+            // known at compile time unless both sit in the same group of 64
 #pragma unroll
-            for (int q2 = 0; q2 < W; ++q2)  // column jj sorts before column q2 * 64 + lane: smaller key, ties by index
-                rk[q2] += (kj < key[q2] || (kj == key[q2] && jj < q2 * 64 + lane)) ? 1 : 0;
+            for (int q2 = 0; q2 < W; ++q2) {
+                if (q < q2) rk[q2] += kj <= key[q2] ? 1 : 0;
+                else if (q > q2) rk[q2] += kj < key[q2] ? 1 : 0;
+                else rk[q2] += (kj < key[q2] || (kj == key[q2] && l < lane)) ? 1 : 0;
+            }
         }
     }
 #pragma unroll
@@ -218,67 +219,88 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
         if (q * 64 + lane < n) order[rk[q]] = q * 64 + lane;
 }
 
-// Greedy elimination over the sorted columns (gf2sparse_linalg.hpp:132-226 / 298-401), rows fully reduced.
-// EARLY_STOP: leave as soon as the syndrome lies in the span of the pivots (fast_solve, :373-383).  Returns the rank reached.
-// one pivot step for a column whose bit lives in word CW (compile-time) of a row; false: no unpivoted row has the bit
+// One pivot step for column c, whose bit lives in word CW (compile-time) of a row; false: no unpivoted row has the bit.
+// Everything that steers the step is scalar: `has` (which lanes' rows carry the bit) comes out of a compare, the set
+// of unpivoted rows is kept as one 64-bit lane mask per register row, the pivot row is fetched with v_readlane from
+// the right register under a scalar branch, and the XOR runs under the execution mask of the rows that have the bit.
 template <int R, int W, int CW>
-__device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, uint64_t cb, int c, int m, int lane) {
+__device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, int c, int lane) {
+    uint64_t has[R];
+    const uint32_t cb = 1u << (c & 31);
+    if (c & 32) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) has[r] = __ballot(((uint32_t)(rows.w[r][CW] >> 32) & cb) != 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) has[r] = __ballot(((uint32_t)rows.w[r][CW] & cb) != 0);
+    }
     int p_lane = -1, p_r = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {  // first unpivoted row (ascending row index) with a one in column c
-        const uint64_t mask = __ballot(r * 64 + lane < m && rows.pcol[r] < 0 && (rows.w[r][CW] & cb));
+    for (int r = 0; r < R; ++r) {  // first unpivoted row (ascending row index) with a one in column c; rows >= m are zero
+        const uint64_t mask = has[r] & rows.unp[r];
         if (p_lane < 0 && mask) { p_lane = __builtin_ctzll(mask); p_r = r; }
     }
     if (p_lane < 0) return false;
     uint64_t prow[W];
+    uint32_t psy = 0;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-        uint64_t src = 0;
+    for (int w = 0; w < W; ++w) prow[w] = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) src |= rows.w[r][w] & (0ull - (uint64_t)(p_r == r));
-        prow[w] = osd_readlane64(src, p_lane);
-    }
+    for (int r = 0; r < R; ++r)
+        if (p_r == r) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) prow[w] = osd_readlane64(rows.w[r][w], p_lane);
+            psy = (uint32_t)__builtin_amdgcn_readlane((int)rows.s[r], p_lane);
+            rows.unp[r] &= ~(1ull << p_lane);
+            rows.pcol[r] = lane == p_lane ? c : rows.pcol[r];
+            has[r] &= ~(1ull << p_lane);  // the pivot row keeps its own bit
+        }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bool is_pivot_row = p_r == r && lane == p_lane;
-        const uint64_t hit = 0ull - (uint64_t)((rows.w[r][CW] & cb) != 0 && !is_pivot_row);
+        if (__builtin_amdgcn_inverse_ballot_w64(has[r])) {
 #pragma unroll
-        for (int w = 0; w < W; ++w) rows.w[r][w] ^= prow[w] & hit;
-        if (is_pivot_row) rows.pcol[r] = c;
+            for (int w = 0; w < W; ++w) rows.w[r][w] ^= prow[w];
+            rows.s[r] ^= psy;
+        }
     }
     return true;
 }
 
 // Greedy elimination over the sorted columns (gf2sparse_linalg.hpp:132-226 / 298-401), rows fully reduced.
 // EARLY_STOP: leave as soon as the syndrome lies in the span of the pivots (fast_solve, :373-383).  Returns the rank reached.
+// The column order is read 64 entries at a time (one per lane) and handed out with v_readlane.
 template <int R, int W, bool EARLY_STOP, class OrderPtr>
-__device__ __forceinline__ int osd_eliminate(OsdRows<R, W> &rows, OrderPtr order, int m, int n, int lane) {
-    const int max_rank = m < n ? m : n;
-    const int sw = n >> 6;
-    const uint64_t sbit = 1ull << (n & 63);
+__device__ __forceinline__ int osd_eliminate(OsdRows<R, W> &rows, OrderPtr order, int max_rank, int n, int lane) {
+    // max_rank = rank H (the host knows it): once that many pivots exist every unpivoted row is zero, and the columns
+    // not visited yet are non-pivot columns whatever they hold
     int rank = 0;
-    for (int t = 0; t < n && rank < max_rank; ++t) {
-        const int c = order[t];
-        const int cw = __builtin_amdgcn_readfirstlane(c >> 6);  // wave-uniform: a scalar branch picks the specialisation
-        const uint64_t cb = 1ull << (c & 63);
-        bool found = false;
-        if (cw == 0) found = osd_pivot_step<R, W, 0>(rows, cb, c, m, lane);
-        if constexpr (W > 1) { if (cw == 1) found = osd_pivot_step<R, W, 1>(rows, cb, c, m, lane); }
-        if constexpr (W > 2) { if (cw == 2) found = osd_pivot_step<R, W, 2>(rows, cb, c, m, lane); }
-        if constexpr (W > 3) { if (cw == 3) found = osd_pivot_step<R, W, 3>(rows, cb, c, m, lane); }
-        if constexpr (W > 4) { if (cw == 4) found = osd_pivot_step<R, W, 4>(rows, cb, c, m, lane); }
-        if constexpr (W > 5) { if (cw == 5) found = osd_pivot_step<R, W, 5>(rows, cb, c, m, lane); }
-        if constexpr (W > 6) { if (cw == 6) found = osd_pivot_step<R, W, 6>(rows, cb, c, m, lane); }
-        if constexpr (W > 7) { if (cw == 7) found = osd_pivot_step<R, W, 7>(rows, cb, c, m, lane); }
-        if (!found) continue;
-        ++rank;
-        if (EARLY_STOP) {
-            bool pending = false;
+    for (int t0 = 0; t0 < n && rank < max_rank; t0 += 64) {
+        const int mine = t0 + lane < n ? order[t0 + lane] : 0;
+        const int cnt = n - t0 < 64 ? n - t0 : 64;
+        bool done = false;
+        for (int tt = 0; tt < cnt && rank < max_rank; ++tt) {
+            const int c = __builtin_amdgcn_readlane(mine, tt);
+            const int cw = c >> 6;  // scalar: a scalar branch picks the specialisation
+            bool found = false;
+            if (cw == 0) found = osd_pivot_step<R, W, 0>(rows, c, lane);
+            if constexpr (W > 1) { if (cw == 1) found = osd_pivot_step<R, W, 1>(rows, c, lane); }
+            if constexpr (W > 2) { if (cw == 2) found = osd_pivot_step<R, W, 2>(rows, c, lane); }
+            if constexpr (W > 3) { if (cw == 3) found = osd_pivot_step<R, W, 3>(rows, c, lane); }
+            if constexpr (W > 4) { if (cw == 4) found = osd_pivot_step<R, W, 4>(rows, c, lane); }
+            if constexpr (W > 5) { if (cw == 5) found = osd_pivot_step<R, W, 5>(rows, c, lane); }
+            if constexpr (W > 6) { if (cw == 6) found = osd_pivot_step<R, W, 6>(rows, c, lane); }
+            if constexpr (W > 7) { if (cw == 7) found = osd_pivot_step<R, W, 7>(rows, c, lane); }
+            if (!found) continue;
+            ++rank;
+            if (EARLY_STOP) {
+                bool pending = false;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                pending |= __ballot(r * 64 + lane < m && rows.pcol[r] < 0 && (osd_word<W>(rows.w[r], sw) & sbit)) != 0;
-            if (!pending) break;
+                for (int r = 0; r < R; ++r)
+                    pending |= (__ballot(rows.s[r] != 0) & rows.unp[r]) != 0;
+                if (!pending) { done = true; break; }
+            }
         }
+        if (done) break;
     }
     return rank;
 }
@@ -290,22 +312,20 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
     typedef __attribute__((address_space(3))) int32_t lds_i32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int m = a.m, n = a.n;
+    const int n = a.n;
     volatile lds_i32 *order = (volatile lds_i32 *)((__attribute__((address_space(3))) unsigned char *)osd_lds + wave * a.lds_per_wave);  // [n]
-    const int sw = n >> 6;
-    const uint64_t sbit = 1ull << (n & 63);
     for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
         osd_sort_columns<W>(a.llr + b * n, n, lane, order);
         __builtin_amdgcn_wave_barrier();
-        osd_eliminate<R, W, true>(rows, order, m, n, lane);
+        osd_eliminate<R, W, true>(rows, order, a.rank, n, lane);
         // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
         for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (rows.pcol[r] >= 0 && (osd_word<W>(rows.w[r], sw) & sbit)) a.decoding[b * n + rows.pcol[r]] = 1;
+            if (rows.pcol[r] >= 0 && rows.s[r]) a.decoding[b * n + rows.pcol[r]] = 1;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -480,35 +500,28 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
 }
 
 
-// ---- higher-order OSD with the elimination in registers (small matrices, k = n - rank <= 128) -------------------
+// ---- higher-order OSD with the elimination in registers (m <= 256, n <= 511) --------------------------------------
 // As osdw_kernel, but (i) the reduced row echelon form is computed in registers (osd_eliminate), and (ii) what a
-// candidate needs is laid out per COLUMN once: for column i a 128-bit word colT[i] and a bit colS[i] such that the
-// candidate with non-pivot mask M has x_i = parity(colT[i] & M) ^ colS[i] -- for a pivot column colT is its row of the
-// reduced matrix restricted to the non-pivot columns and colS the reduced syndrome bit, for the q-th non-pivot column
-// colT = 1 << q and colS = 0.  Weighing a candidate is then one pass of independent LDS reads in ascending bit order,
-// accumulated sequentially as the reference does (osd.hpp:171-176); no dependent look-ups, no per-candidate solve.
-struct OsdCandidate128 {
-    uint64_t lo, hi;
-    bool valid;
-};
-
-__device__ __forceinline__ OsdCandidate128 osd_candidate128(int method, int order, int k, long c) {
-    OsdCandidate128 r;
-    r.lo = r.hi = 0;
-    r.valid = true;
-    if (method == 2) {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
-        r.lo = (uint64_t)(c + 1) & (k >= 64 ? ~0ull : ((1ull << k) - 1ull));
-    } else if (c < k) {  // weight one (osd.hpp:84-89); k <= 128 here
-        if (c < 64) r.lo = 1ull << c; else r.hi = 1ull << (c - 64);
-    } else {  // pairs (i, j), i < j < order <= 64, i-major (osd.hpp:91-99)
-        long p = c - k;
-        int i = 0;
-        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
-        const int j = i + 1 + (int)p;
-        if (j >= k) r.valid = false;
-        else r.lo = (1ull << i) | (1ull << j);
+// candidate needs is laid out per COLUMN once: for column i a record {weight log(1 / p_i), S_i, T_i[0 .. KW)} with
+// KW = ceil(k / 64), k = n - rank, such that the candidate flipping the set M of non-pivot columns has
+//     x_i = parity(T_i & M) ^ S_i
+// -- for a pivot column T is its row of the reduced matrix restricted to the non-pivot columns (bit q = the q-th
+// non-pivot column in sorted order) and S the reduced syndrome bit; for the q-th non-pivot column T = 1 << q, S = 0.
+// The candidate strings of the reference are of two shapes only: ONE non-pivot column q (OSD_CS, osd.hpp:84-89) -- x_i
+// = bit q of T_i ^ S_i, and with lane = q - 64 v one broadcast read of word v per column serves 64 candidates -- or a
+// mask inside the first 64 non-pivot columns (OSD_CS pairs, osd.hpp:91-99; every OSD_E string, util.hpp:12-38) -- one
+// AND + popcount of word 0.  Weighing is one pass of broadcast LDS reads in ascending bit order, accumulated
+// sequentially as the reference does (osd.hpp:171-176); no dependent look-ups, no per-candidate solve.
+// acc[r] |= (bit `cbit` of word CW of row r) << qq for the R rows of this lane; cbit, qq scalar
+template <int R, int W, int CW>
+__device__ __forceinline__ void osd_gather_step(const OsdRows<R, W> &rows, uint32_t (&acc)[R], int cbit, int qq) {
+    if (cbit & 32) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] |= (((uint32_t)(rows.w[r][CW] >> 32) >> (cbit & 31)) & 1u) << qq;
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] |= (((uint32_t)rows.w[r][CW] >> cbit) & 1u) << qq;
     }
-    return r;
 }
 
 template <int R, int W>
@@ -516,33 +529,32 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef __attribute__((address_space(3))) int32_t lds_i32;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) uint64_t lds_u64;
-    typedef __attribute__((address_space(3))) double lds_f64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int m = a.m, n = a.n;
+    const int n = a.n, KW = a.kwords, RS = a.kwords + 2;  // RS: 64-bit words of a column record
     lds_u8 *base = (lds_u8 *)osd_lds + wave * a.lds_per_wave;
-    volatile lds_u64 *colTa = (volatile lds_u64 *)base;            // [n]
-    volatile lds_u64 *colTb = colTa + n;                           // [n]
-    volatile lds_f64 *keys = (volatile lds_f64 *)(colTb + n);      // [n] weights log(1 / p_j)
-    volatile lds_i32 *order = (volatile lds_i32 *)(keys + n);      // [n]
-    volatile lds_i32 *colQ = order + n;                            // [n] -1: pivot column, q >= 0: the q-th non-pivot column
-    volatile lds_i32 *npcol = colQ + n;                            // [128]
-    volatile lds_u8 *colS = (volatile lds_u8 *)(npcol + 128);      // [n]
-    const int sw = n >> 6;
-    const uint64_t sbit = 1ull << (n & 63);
+    volatile lds_u64 *rec = (volatile lds_u64 *)base;              // [n][RS]  {weight, S, T[KW]}
+    volatile lds_i32 *order = (volatile lds_i32 *)(rec + (size_t)n * RS);  // [n]
+    volatile lds_i32 *colQ = order + n;                            // [n] -2: unseen, -1: pivot column, q >= 0: the q-th non-pivot column
+    volatile lds_i32 *npcol = colQ + n;                            // [64 KW]
     for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+        OSD_CLK_START();
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
+        OSD_CLK(0);
         osd_sort_columns<W>(a.llr + b * n, n, lane, order);
-        for (int j = lane; j < n; j += 64) { colQ[j] = -2; keys[j] = a.wt[j]; }
+        OSD_CLK(1);
+        for (int j = lane; j < n; j += 64) { colQ[j] = -2; rec[(size_t)j * RS] = __builtin_bit_cast(uint64_t, a.wt[j]); }
         __builtin_amdgcn_wave_barrier();
-        osd_eliminate<R, W, false>(rows, order, m, n, lane);
+        osd_eliminate<R, W, false>(rows, order, a.rank, n, lane);
+        OSD_CLK(2);
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (rows.pcol[r] >= 0) {
                 colQ[rows.pcol[r]] = -1;
-                colS[rows.pcol[r]] = (osd_word<W>(rows.w[r], sw) & sbit) ? 1 : 0;
+                rec[(size_t)rows.pcol[r] * RS + 1] = rows.s[r];
             }
         __builtin_amdgcn_wave_barrier();
         int k = 0;  // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
@@ -554,61 +566,133 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
             if (np) {
                 const int q = k + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 colQ[c] = q;
-                colS[c] = 0;
-                colTa[c] = q < 64 ? 1ull << q : 0ull;
-                colTb[c] = (q >= 64 && q < 128) ? 1ull << (q - 64) : 0ull;
-                if (q < 128) npcol[q] = c;
+                rec[(size_t)c * RS + 1] = 0;
+                for (int v = 0; v < KW; ++v) rec[(size_t)c * RS + 2 + v] = (q >> 6) == v ? 1ull << (q & 63) : 0ull;
+                if (q < 64 * KW) npcol[q] = c;
             }
             k += __builtin_popcountll(mask);
         }
         __builtin_amdgcn_wave_barrier();
-        const int k128 = k < 128 ? k : 128;
+        OSD_CLK(3);
+        if (k > 64 * KW) k = 64 * KW;  // cannot happen: the host sized KW from the rank of H
+        // the reduced matrix on the non-pivot columns, 32 columns at a time: their numbers sit one per lane and come
+        // out with v_readlane, a scalar branch picks the register word, each row adds its bit
+        volatile lds_u32 *rec32 = (volatile lds_u32 *)rec;
+        for (int v2 = 0; v2 * 32 < k; ++v2) {
+            const int cnt = k - v2 * 32 < 32 ? k - v2 * 32 : 32;
+            const int mine = lane < cnt ? npcol[v2 * 32 + lane] : 0;
+            uint32_t acc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {  // the reduced matrix on the non-pivot columns: two words per pivot row, filed under its pivot column
-            uint64_t ta = 0, tb = 0;
-            for (int q = 0; q < k128; ++q) {
-                const int c = npcol[q];
-                const uint64_t bit = (osd_word<W>(rows.w[r], c >> 6) >> (c & 63)) & 1ull;
-                if (q < 64) ta |= bit << q; else tb |= bit << (q - 64);
+            for (int r = 0; r < R; ++r) acc[r] = 0;
+            for (int qq = 0; qq < cnt; ++qq) {
+                const int c = __builtin_amdgcn_readlane(mine, qq);
+                const int cw = c >> 6, cbit = c & 63;
+                if (cw == 0) osd_gather_step<R, W, 0>(rows, acc, cbit, qq);
+                if constexpr (W > 1) { if (cw == 1) osd_gather_step<R, W, 1>(rows, acc, cbit, qq); }
+                if constexpr (W > 2) { if (cw == 2) osd_gather_step<R, W, 2>(rows, acc, cbit, qq); }
+                if constexpr (W > 3) { if (cw == 3) osd_gather_step<R, W, 3>(rows, acc, cbit, qq); }
+                if constexpr (W > 4) { if (cw == 4) osd_gather_step<R, W, 4>(rows, acc, cbit, qq); }
+                if constexpr (W > 5) { if (cw == 5) osd_gather_step<R, W, 5>(rows, acc, cbit, qq); }
+                if constexpr (W > 6) { if (cw == 6) osd_gather_step<R, W, 6>(rows, acc, cbit, qq); }
+                if constexpr (W > 7) { if (cw == 7) osd_gather_step<R, W, 7>(rows, acc, cbit, qq); }
             }
-            if (rows.pcol[r] >= 0) { colTa[rows.pcol[r]] = ta; colTb[rows.pcol[r]] = tb; }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rows.pcol[r] >= 0) rec32[((size_t)rows.pcol[r] * RS + 2) * 2 + v2] = acc[r];
+        }
+        if ((k & 63) != 0 && (k & 63) <= 32) {  // an odd number of 32-column groups: clear the upper half of the last word
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rows.pcol[r] >= 0) rec32[((size_t)rows.pcol[r] * RS + 2) * 2 + (k >> 6) * 2 + 1] = 0;
+        }
+        for (int v = (k + 63) >> 6; v < KW; ++v) {  // k = 0 (KW is at least 1)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rows.pcol[r] >= 0) rec[(size_t)rows.pcol[r] * RS + 2 + v] = 0;
         }
         __builtin_amdgcn_wave_barrier();
-
-        auto bit_of = [&](const OsdCandidate128 &cd, int i) -> bool {
-            return ((__builtin_popcountll(colTa[i] & cd.lo) + __builtin_popcountll(colTb[i] & cd.hi) + (int)colS[i]) & 1) != 0;
-        };
-        auto weight_of = [&](const OsdCandidate128 &cd) -> double {
-            double acc = 0;
-            for (int i = 0; i < n; ++i)
-                if (bit_of(cd, i)) acc += keys[i];
+        OSD_CLK(4);
+        // the records are complete and only read from here on: plain (non-volatile) views let the loads of several
+        // columns be in flight together
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        const lds_u64 *rec_r = (const lds_u64 *)rec;
+        const uint32_t lm_lo = lane < 32 ? 1u << lane : 0u, lm_hi = lane >= 32 ? 1u << (lane - 32) : 0u;
+        // (`acc += flip ? weight : 0.0` adds the same numbers as the reference's conditional sum: acc starts at +0.0
+        // and x + 0.0 == x bit for bit for every x an accumulator that started at +0.0 can hold)
+        auto weigh_single = [&](int v) -> double {  // this lane's candidate: the non-pivot column 64 v + lane alone
+            double acc = 0;  // added in column order, as the reference does
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) {
+                const uint64_t t = rec_r[(size_t)i * RS + 2 + v];
+                const uint32_t flip = (((uint32_t)t & lm_lo) | ((uint32_t)(t >> 32) & lm_hi)) != 0 ? 1u : 0u;
+                const double wgt = __builtin_bit_cast(double, rec_r[(size_t)i * RS]);
+                acc += (flip ^ (uint32_t)rec_r[(size_t)i * RS + 1]) ? wgt : 0.0;
+            }
             return acc;
         };
-        OsdCandidate128 none;
-        none.lo = none.hi = 0; none.valid = true;
-        const double w0 = weight_of(none);  // the OSD-0 solution (osd.hpp:131-136)
-        const long ncand = a.method == 2 ? (1L << a.order) - 1 : (long)k + (long)a.order * (a.order - 1) / 2;
-        double best_w = w0;
-        long best_c = -1;
-        for (long c0 = 0; c0 < ncand; c0 += 64) {
-            const long c = c0 + lane;
-            if (c < ncand) {
-                const OsdCandidate128 cd = osd_candidate128(a.method, a.order, k, c);
-                if (cd.valid) {
-                    const double w = weight_of(cd);
-                    if (w < best_w) { best_w = w; best_c = c; }  // strict: the first lightest candidate stays (osd.hpp:177)
-                }
+        auto weigh_mask = [&](uint64_t mask) -> double {  // this lane's candidate: a set of the first 64 non-pivot columns
+            double acc = 0;
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) {
+                const uint64_t t = rec_r[(size_t)i * RS + 2] & mask;  // (v_bcnt_u32_b32 adds its second operand: S rides along)
+                const int par = __builtin_popcount((uint32_t)(t >> 32)) + (__builtin_popcount((uint32_t)t) + (int)(uint32_t)rec_r[(size_t)i * RS + 1]);
+                const double wgt = __builtin_bit_cast(double, rec_r[(size_t)i * RS]);
+                acc += (par & 1) ? wgt : 0.0;
+            }
+            return acc;
+        };
+        auto pair_mask = [&](long p, bool &valid) -> uint64_t {  // pairs (i, j), i < j < order <= 64, i-major (osd.hpp:91-99)
+            int i = 0;
+            while (p >= a.order - 1 - i) { p -= a.order - 1 - i; ++i; }
+            const int j = i + 1 + (int)p;
+            valid = j < k;  // past the candidate string in the reference
+            return valid ? (1ull << i) | (1ull << j) : 0ull;
+        };
+        double best_w = weigh_mask(0);  // the OSD-0 solution (osd.hpp:131-136)
+        long best_c = -1;               // index in the reference's candidate list; -1: the OSD-0 solution
+        const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+        const long npairs = (long)a.order * (a.order - 1) / 2;
+        if (a.method == 3) {
+            for (int v = 0; v * 64 < k; ++v) {
+                const double w = weigh_single(v);
+                if (v * 64 + lane < k && w < best_w) { best_w = w; best_c = v * 64 + lane; }  // strict: the first lightest candidate stays (osd.hpp:177)
+            }
+            for (long p0 = 0; p0 < npairs; p0 += 64) {
+                const long pp = p0 + lane;
+                bool valid = false;
+                const uint64_t mask = pp < npairs ? pair_mask(pp, valid) : 0ull;
+                const double w = weigh_mask(mask);
+                if (valid && w < best_w) { best_w = w; best_c = k + pp; }
+            }
+        } else {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
+            const long total = (1L << a.order) - 1;
+            for (long c0 = 0; c0 < total; c0 += 64) {
+                const long c = c0 + lane;
+                const double w = weigh_mask((uint64_t)(c + 1) & kmask);
+                if (c < total && w < best_w) { best_w = w; best_c = c; }
             }
         }
+        OSD_CLK(5);
         for (int off = 32; off > 0; off >>= 1) {  // across lanes: lightest, then earliest
             const double ow = __shfl_xor(best_w, off);
             const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
             const bool mine_set = best_c >= 0, other_set = oc >= 0;
             if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
         }
-        OsdCandidate128 win = none;
-        if (best_c >= 0) win = osd_candidate128(a.method, a.order, k, best_c);
-        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = bit_of(win, j) ? 1 : 0;
+        const bool single = a.method == 3 && best_c >= 0 && best_c < k;
+        uint64_t win = 0;
+        if (best_c >= 0 && !single) {
+            bool valid;
+            win = a.method == 3 ? pair_mask(best_c - k, valid) : (uint64_t)(best_c + 1) & kmask;
+        }
+        for (int j = lane; j < n; j += 64) {
+            uint64_t x = rec_r[(size_t)j * RS + 1];
+            if (single) x ^= rec_r[(size_t)j * RS + 2 + (best_c >> 6)] >> (best_c & 63);
+            else x ^= (uint64_t)__builtin_popcountll(rec_r[(size_t)j * RS + 2] & win);
+            a.decoding[b * n + j] = (uint8_t)(x & 1ull);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         __builtin_amdgcn_wave_barrier();
+        OSD_CLK(6);
     }
 }

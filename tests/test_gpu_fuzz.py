@@ -125,6 +125,29 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
         assert bits_equal(got[1], want[1]) and bits_equal(got[4], want[4]), serial_kernel
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_higher_order_osd_across_null_space_sizes(seed, oracle_built):
+    """OSD_E / OSD_CS on matrices whose n - rank falls below 128, in (128, 256] and above 256: the three regimes the
+    host picks a kernel by (register rows with a 2- or 4-word candidate mask, matrix in LDS)."""
+    from ldpc_amd.engine import HipBpEngine
+    rng = np.random.default_rng(4242 + seed)
+    n = int([90, 200, 300, 420, 500, 511][seed])
+    m = int([40, 70, 120, 200, 150, 256][seed])
+    h = sp.csr_matrix((rng.random((m, n)) < 3.0 / m).astype(np.uint8))
+    probs = rng.uniform(0.01, 0.1, size=n)
+    s = _syndromes(rng, h, 70, raw_bytes=False)
+    o = oracle_built.BpOracle(h, error_channel=probs, max_iter=3, bp_method="minimum_sum", ms_scaling_factor=0.625)
+    eng = HipBpEngine(h.indptr, h.indices, n, probs, 3, 1, 0.625)
+    for osd_method, osd_order in ((3, 7), (2, 5), (1, 0)):
+        want = o.bposd_decode_batch(s, osd_method, osd_order)
+        eng.set_osd(osd_method, osd_order)
+        for osd_kernel in (-1, 0):
+            eng.set_osd_kernel(osd_kernel)
+            got = eng.decode_batch(s, osd=True)
+            assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} kernel {osd_kernel} m={m} n={n}"
+            assert np.array_equal(got[3], want[3])
+
+
 def test_matrix_without_entries(oracle_built):
     """An all-zero parity-check matrix (nnz = 0): every kernel family must launch (no zero-sized grid) and agree with the oracle."""
     from ldpc_amd.engine import HipBpEngine

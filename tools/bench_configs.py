@@ -56,6 +56,8 @@ def main():
         serial_big()
     if "soft" in args.which:
         soft()
+    if "hgp" in args.which:
+        hgp()
     if "osdw" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05", h, 0.05, 50, 0, 1.0, 8192, False, osd=(3, 10))
@@ -69,6 +71,17 @@ def main():
         run("c5 BB144 product_sum 50 it (BP only) p=0.05", h, 0.05, 50, 0, 1.0, 8192, False)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144 fast math", h, 0.05, 50, 0, 1.0, 262144, True, math="fast")
+
+
+def hgp():
+    """The [[400,16,6]] hypergraph-product code of the reference's test_qcodes.py (matrix taken from the committed fixture):
+    min-sum 0.625, 30 iterations, OSD_0 / OSD_CS 10 at p = 0.02."""
+    import scipy.sparse as sp
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "qcodes_400_16_6_ms_par_osd0.npz"))
+    h = sp.csr_matrix((np.ones(len(z["col_idx"]), np.uint8), z["col_idx"], z["row_ptr"]), shape=(int(z["m"]), int(z["n"])))
+    run("hgp [[400,16,6]] min_sum 30 it (BP only) p=0.02", h, 0.02, 30, 1, 0.625, 65536, False)
+    run("hgp [[400,16,6]] min_sum 30 it + OSD-0 p=0.02", h, 0.02, 30, 1, 0.625, 65536, True)
+    run("hgp [[400,16,6]] min_sum 30 it + OSD_CS order 10 p=0.02", h, 0.02, 30, 1, 0.625, 65536, False, osd=(3, 10))
 
 
 def soft():

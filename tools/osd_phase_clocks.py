@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Cycles per phase of osdw_reg_kernel (higher-order OSD with the elimination in registers).
+
+Builds a second copy of the library with -DLDPC_HIP_OSD_CLOCKS (tools/_dbg/, git-ignored; build it in the container:
+`python tools/osd_phase_clocks.py --build`), loads THAT copy, decodes one batch of the [[400,16,6]] HGP code (or BB144
+with --bb) with OSD_CS and prints the share of each phase.  A profiling aid, not part of the product path."""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DBG = os.path.join(ROOT, "tools", "_dbg", "libldpc_hip.so")
+PHASES = ["load rows", "sort columns", "eliminate", "number non-pivot columns", "gather reduced rows", "weigh candidates", "pick + write"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--bb", action="store_true")
+    ap.add_argument("--order", type=int, default=10)
+    args = ap.parse_args()
+    if args.build:
+        os.makedirs(os.path.dirname(DBG), exist_ok=True)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ldpc_amd", "csrc"), "OUT=" + DBG,
+                               "FLAGS=-O3 -std=c++17 -ffp-contract=off -fPIC -shared --offload-arch=gfx950 -Wall "
+                               "-Wno-unused-function -DLDPC_HIP_OSD_CLOCKS"])
+        return
+    import ldpc_amd._lib as lib
+    lib.LIB_PATH = DBG
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd import codes
+    import scipy.sparse as sp
+    import torch
+    if args.bb:
+        h, p, it, method, alpha = codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "qcodes_400_16_6_ms_par_osd0.npz"))
+        h = sp.csr_matrix((np.ones(len(z["col_idx"]), np.uint8), z["col_idx"], z["row_ptr"]), shape=(int(z["m"]), int(z["n"])))
+        p, it, method, alpha = 0.02, 30, 1, 0.625
+    n = h.shape[1]
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), it, method, alpha)
+    s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=65536, device="cuda:0")
+    eng.set_osd(3, args.order)
+    out = eng.decode_batch(s, osd=True)
+    torch.cuda.synchronize()
+    dll = lib.load()
+    buf = (C.c_ulonglong * 8)()
+    dll.ldpc_hip_debug_osd_clocks(buf, 1)
+    eng.decode_batch(s, out=out, osd=True)
+    torch.cuda.synchronize()
+    dll.ldpc_hip_debug_osd_clocks(buf, 0)
+    rows = int((out[3].cpu().numpy() == 0).sum())
+    tot = sum(buf[:7])
+    print(f"{rows} rows through OSD; cycles per row (s_memtime, 100 MHz-class counter units):")
+    for name, c in zip(PHASES, buf[:7]):
+        print(f"  {name:28s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
