@@ -6,9 +6,8 @@ The reference reads every shot of a ``b8`` file, calls ``BpOsdDecoder.decode`` o
 observables -- neither the syndromes nor the corrections are ever materialised on the host.
 
 ``decode_b8_files`` is the stim-free core (check matrix, priors and observables matrix given explicitly).
-``SinterBpOsdDecoder.decode_via_files`` has the reference's signature; turning the detector error model at ``dem_path``
-into matrices needs ``stim`` exactly as in the reference (ckt_noise/dem_matrices.py), which this image does not
-ship -- the method raises ImportError there and is therefore only exercised through ``decode_b8_files``.
+``SinterBpOsdDecoder.decode_via_files`` has the reference's signature; the detector error model at ``dem_path`` is
+turned into matrices by ``ldpc_amd.ckt_noise.dem_matrices``, which reads the ``.dem`` text itself (no ``stim``).
 """
 from __future__ import annotations
 
@@ -87,14 +86,8 @@ class SinterBpOsdDecoder:
                          dets_b8_in_path: pathlib.Path, obs_predictions_b8_out_path: pathlib.Path, tmp_dir: pathlib.Path) -> None:
         if self.schedule != "parallel":
             raise NotImplementedError("the packed-shot path runs the parallel schedule")
-        try:
-            import stim  # noqa: F401
-            from ldpc.ckt_noise.dem_matrices import detector_error_model_to_check_matrices
-        except ImportError as exc:  # this image has neither stim nor the reference package
-            raise ImportError("decode_via_files needs stim and ldpc.ckt_noise.dem_matrices to turn the detector error model into "
-                              "matrices; call ldpc_amd.sinter_decoders.decode_b8_files with explicit matrices instead") from exc
-        dem = stim.DetectorErrorModel.from_file(dem_path)
-        mats = detector_error_model_to_check_matrices(dem, allow_undecomposed_hyperedges=True)
+        from ldpc_amd.ckt_noise.dem_matrices import detector_error_model_to_check_matrices  # reads the .dem text itself
+        mats = detector_error_model_to_check_matrices(pathlib.Path(dem_path), allow_undecomposed_hyperedges=True)
         if mats.check_matrix.shape[0] != num_dets or mats.observables_matrix.shape[0] != num_obs:
             raise ValueError("detector error model does not match num_dets / num_obs")
         decode_b8_files(mats.check_matrix, list(mats.priors), mats.observables_matrix, num_shots=num_shots,

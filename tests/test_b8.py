@@ -26,11 +26,12 @@ def test_b8_file_round_trip(tmp_path):
         read_b8(path, 9)  # 2-byte shots do not divide 111 bytes
 
 
-def test_sinter_decoder_keywords_and_stim_requirement(tmp_path):
+def test_sinter_decoder_keywords_and_model_check(tmp_path):
     d = SinterBpOsdDecoder()
     assert (d.max_iter, d.bp_method, d.ms_scaling_factor, d.schedule, d.osd_method, d.osd_order) == (0, "ms", 0.625, "parallel", "osd0", 0)
-    with pytest.raises(ImportError, match="decode_b8_files"):
-        d.decode_via_files(num_shots=1, num_dets=1, num_obs=1, dem_path=tmp_path / "a.dem", dets_b8_in_path=tmp_path / "d.b8",
+    (tmp_path / "a.dem").write_text("error(0.1) D0 D1 L0\nerror(0.1) D1\n")  # read without stim; 2 detectors, 1 observable
+    with pytest.raises(ValueError, match="does not match num_dets / num_obs"):
+        d.decode_via_files(num_shots=1, num_dets=3, num_obs=1, dem_path=tmp_path / "a.dem", dets_b8_in_path=tmp_path / "d.b8",
                            obs_predictions_b8_out_path=tmp_path / "o.b8", tmp_dir=tmp_path)
 
 

@@ -1,0 +1,134 @@
+"""Host side of ldpc_amd.ckt_noise: the DEM text reader, DEM -> matrices, window indices, and the window checker."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from ldpc_amd.ckt_noise.dem_text import parse_dem_text
+from ldpc_amd.ckt_noise.dem_matrices import detector_error_model_to_check_matrices
+from ldpc_amd.ckt_noise.base_overlapping_window_decoder import current_round_inds
+from window_util import phenomenological_dem, phenomenological_matrices, ring_code
+
+
+def test_reader_flattens_repeat_blocks_and_shifts():
+    text = """
+        error(0.1) D0 D1 L0   # a comment
+        repeat 2 {
+            error[tagged](0.2) D0 ^ D1 D2 L1
+            shift_detectors(1.5) 3
+            repeat 2 { error(0.05) D0
+                       shift_detectors 1 }
+        }
+        detector(1, 2) D4
+        logical_observable L3
+        ERROR(0.3) D1
+    """
+    dem = parse_dem_text(text)
+    got = [(e.probability, e.detectors, e.observables) for e in dem.errors]
+    assert got == [
+        (0.1, [[0, 1]], [[0]]),
+        (0.2, [[0], [1, 2]], [[], [1]]),
+        (0.05, [[3]], [[]]), (0.05, [[4]], [[]]),
+        (0.2, [[5], [6, 7]], [[], [1]]),
+        (0.05, [[8]], [[]]), (0.05, [[9]], [[]]),
+        (0.3, [[11]], [[]]),
+    ]
+    assert dem.num_detectors == 15  # detector D4 after a shift of 10
+    assert dem.num_observables == 4
+
+
+def test_matrices_merge_repeated_detector_sets_and_keep_the_last_observables():
+    text = "error(0.1) D0 D1 L0\nerror(0.2) D2\nerror(0.25) D1 D0\nerror(0.5) D0 ^ D0 D3\n"
+    mats = detector_error_model_to_check_matrices(text)
+    assert mats.check_matrix.shape == (4, 3)
+    assert np.array_equal(mats.check_matrix.toarray(), np.array([[1, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.uint8))
+    # {D0, D1} seen twice: 0.1 then 0.25 -> 0.1 * 0.75 + 0.25 * 0.9; its observables are those of the LAST occurrence (none)
+    assert np.allclose(mats.priors, [0.1 * 0.75 + 0.25 * 0.9, 0.2, 0.5])
+    assert mats.observables_matrix.shape == (1, 3) and mats.observables_matrix.nnz == 0
+    # edges: {D0,D1}, {D2}, {D0}, {D0,D3}; the third hyperedge {D3} decomposes into the edges {D0} and {D0, D3}
+    assert mats.edge_check_matrix.shape == (4, 4)
+    assert np.array_equal(mats.hyperedge_to_edge_matrix.toarray()[:, 2], [0, 0, 1, 1])
+
+
+def test_undecomposed_hyperedge_raises_unless_allowed():
+    text = "error(0.1) D0 D1 D2\n"
+    with pytest.raises(ValueError, match="not decomposed"):
+        detector_error_model_to_check_matrices(text)
+    mats = detector_error_model_to_check_matrices(text, allow_undecomposed_hyperedges=True)
+    assert mats.check_matrix.shape == (3, 1) and mats.edge_check_matrix.shape == (3, 0)
+
+
+@pytest.mark.parametrize("rounds", [2, 5])
+def test_phenomenological_text_gives_the_directly_built_matrices(rounds, tmp_path):
+    h = ring_code(6)
+    p = np.linspace(0.01, 0.06, 6)
+    text = phenomenological_dem(h, rounds, p, 0.02, logical=(0, 3))
+    check, obs, pri = phenomenological_matrices(h, rounds, p, 0.02, logical=(0, 3))
+    path = tmp_path / "model.dem"
+    path.write_text(text)
+    for source in (text, path, str(path)):
+        mats = detector_error_model_to_check_matrices(source, allow_undecomposed_hyperedges=True)
+        assert (mats.check_matrix != check).nnz == 0
+        assert (mats.observables_matrix != obs).nnz == 0
+        assert np.array_equal(mats.priors, pri)
+
+
+def test_window_indices():
+    h = ring_code(5)
+    check, _, _ = phenomenological_matrices(h, 6, 0.01, 0.01)
+    dcm = sp.csr_matrix(check)
+    # round t: columns [10 t, 10 t + 5) data, [10 t + 5, 10 t + 10) measurement (none in the last round)
+    c, d, sc, sd = current_round_inds(dcm, decoding=0, window=3, commit=2, num_checks=5)
+    assert (sc, sd) == (slice(0, 10), slice(0, 15))
+    assert (c.start, c.stop, d.start, d.stop) == (0, 20, 0, 30)
+    c, d, sc, sd = current_round_inds(dcm, decoding=1, window=3, commit=2, num_checks=5)
+    assert (sc, sd) == (slice(10, 20), slice(10, 25))
+    assert (c.start, c.stop, d.start, d.stop) == (15, 40, 15, 50)  # round 2's detectors also see round 1's measurement errors
+
+
+def test_window_checker_with_one_window_is_plain_bposd(oracle_built):
+    from oracle.window_oracle import WindowOracle
+    h = ring_code(6)
+    check, obs, pri = phenomenological_matrices(h, 3, 0.05, 0.03)
+    rng = np.random.default_rng(3)
+    e = (rng.random((20, check.shape[1])) < 0.08).astype(np.uint8)
+    shots = np.ascontiguousarray((sp.csr_matrix(check) @ e.T % 2).T.astype(np.uint8))
+    w = WindowOracle(check, obs, pri, decodings=1, window=3, commit=3, num_checks=6, max_iter=10, inner="oracle")
+    preds, corrs, _ = w.decode_batch(shots)
+    plain = oracle_built.BpOracle(sp.csr_matrix(check), error_channel=pri, max_iter=10, bp_method="minimum_sum", ms_scaling_factor=1.0)
+    want = plain.bposd_decode_batch(shots, 1, 0, want_llr=False)[0]
+    want[~shots.any(axis=1)] = 0
+    assert np.array_equal(corrs, want)
+    assert np.array_equal(preds[:, 0], (corrs @ obs.toarray()[0]) % 2 == 1)
+
+
+def _window_fixture(path):
+    z = np.load(path, allow_pickle=False)
+    cfg = {}
+    for k, v in zip(z["config_keys"], z["config_vals"]):
+        cfg[str(k)] = str(v) if str(k) in ("bp_method", "osd_method") else (float(v) if "." in str(v) else int(v))
+    nd = int(z["num_detectors"])
+    unpack = lambda a: np.ascontiguousarray(np.unpackbits(a, axis=1, bitorder="little")[:, :nd])  # noqa: E731
+    return dict(text=str(z["dem_text"]), num_checks=int(z["num_checks"]), decodings=int(z["decodings"]), window=int(z["window"]),
+                commit=int(z["commit"]), cfg=cfg, shots=unpack(z["shots"]), predictions=z["predictions"], corrections=z["corrections"],
+                shots_after=unpack(z["shots_after"]), priors_after=z["priors_after"])
+
+
+def window_fixtures():
+    import glob
+    import os
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "window_*.npz")))
+
+
+@pytest.mark.parametrize("path", window_fixtures(), ids=lambda p: p.split("/")[-1][:-4])
+def test_window_checker_with_the_c_oracle_inside_reproduces_the_fixtures(path, oracle_built):
+    """The fixtures were made with the real reference decoding each window; the C restatement must give the same."""
+    from oracle.window_oracle import WindowOracle
+    fx = _window_fixture(path)
+    mats = detector_error_model_to_check_matrices(fx["text"], allow_undecomposed_hyperedges=True)
+    w = WindowOracle(mats.check_matrix, mats.observables_matrix, mats.priors, decodings=fx["decodings"], window=fx["window"],
+                     commit=fx["commit"], num_checks=fx["num_checks"], inner="oracle", **fx["cfg"])
+    preds, corrs, after = w.decode_batch(fx["shots"])
+    assert np.array_equal(corrs, fx["corrections"])
+    assert np.array_equal(preds, fx["predictions"])
+    assert np.array_equal(after, fx["shots_after"])
+    assert np.array_equal(w.weights, fx["priors_after"])

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Throughput of overlapping-window decoding (ldpc_amd.ckt_noise.BpOsdOverlappingWindowDecoder.decode_batch).
+
+Model: BB [[144,12,12]] hx measured for 12 rounds with phenomenological noise (tests/window_util.py), 3 windows of 6
+rounds committing 3 (864 detectors x 2520 errors; a window is 432 x ~1370 after dropping untouched columns), min-sum
+30 iterations + OSD-0 (the reference's defaults, ckt_noise/config.py).  Host arrays in, predictions out, so the figure
+includes the PCIe copies.  --cpu N also times the shot-by-shot checker (real reference BP+OSD inside) on N shots.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shots", type=int, default=32768)
+    ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--cpu", type=int, default=0)
+    args = ap.parse_args()
+    from ldpc_amd import codes
+    from ldpc_amd.ckt_noise import BpOsdOverlappingWindowDecoder
+    from window_util import phenomenological_dem, phenomenological_matrices, sample_shots
+    h = codes.bivariate_bicycle_hx()
+    rounds, decodings, window, commit = 12, 3, 6, 3
+    text = phenomenological_dem(h, rounds, args.p, args.p, logical=tuple(range(12)))
+    check, obs, pri = phenomenological_matrices(h, rounds, args.p, args.p, logical=tuple(range(12)))
+    shots, _ = sample_shots(check, pri, args.shots, seed=11)
+    cfg = dict(max_iter=30, bp_method="minimum_sum", ms_scaling_factor=0.625)
+    dec = BpOsdOverlappingWindowDecoder(text, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], decoder_config=cfg)
+    dec.decode_batch(shots[:256].copy())  # builds the window decoders
+    t0 = time.perf_counter()
+    preds = dec.decode_batch(shots.copy())
+    dt = time.perf_counter() - t0
+    out = {"config": f"BB144 x {rounds} rounds, {decodings} windows of {window} committing {commit}, min_sum 30 it + OSD-0, p={args.p}",
+           "shots": args.shots, "detectors": check.shape[0], "errors": check.shape[1],
+           "window_columns": [int(len(d.cols)) for d in dec._decoders.values()],
+           "shots_per_s": args.shots / dt, "seconds": dt, "flipped_observables": int(preds.sum())}
+    if args.cpu:
+        from oracle.window_oracle import WindowOracle
+        w = WindowOracle(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], **cfg)
+        t0 = time.perf_counter()
+        want = w.decode_batch(shots[: args.cpu])[0]
+        out["cpu_shots_per_s"] = args.cpu / (time.perf_counter() - t0)
+        out["cpu_inner"] = w.inner
+        out["cpu_matches"] = bool(np.array_equal(want, preds[: args.cpu]))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
