@@ -121,6 +121,7 @@ struct ldpc_hip_bp {
     double *d_llr0 = nullptr;
     double *d_osd_wt = nullptr;  // [n] log(1 / p_j), the candidate weights of higher-order OSD
     bool osd_reg = true;  // register-resident elimination for small matrices (ldpc_hip_bp_set_osd_kernel)
+    bool osd_big = false; // OSD-0 through osd0_big_kernel whatever the size (testing)
     int osd_k_cached = -1;  // n - rank(H), computed on first use
     int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
 
@@ -132,6 +133,7 @@ struct ldpc_hip_bp {
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
@@ -273,7 +275,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -865,7 +867,11 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     if (p.shared + p.per_wave > lds) return p;
     size_t w = (lds - p.shared) / p.per_wave;
     if (w > 16) w = 16;
-    if (!forced && w < 4) return p;  // too few wavefronts to hide any latency: the slot kernel or streaming does better
+    // Few resident wavefronts hide little latency, but a wavefront stops when ITS syndrome has converged while a streamed
+    // tile runs until its slowest of 64 has.  Measured on 432..864-row window matrices (tools/bench_window.py): min-sum
+    // with 3 / 2 / 1 wavefronts per CU is 12x / 7x / 1.5x faster than streaming when most syndromes converge early and
+    // 2.2x faster at 3 when most do not; product-sum 3x / 2.4x / 0.7x and about level.
+    if (!forced && w < (h->bp_method == LDPC_HIP_MINIMUM_SUM ? 2 : 3)) return p;
     p.waves = (int)w;
     p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
     if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;  // 32 wavefronts per compute unit
@@ -1286,7 +1292,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.method = osd_method; a.order = osd_order; a.wt = h->d_osd_wt;
     // small matrices: the elimination runs in registers (osd0_reg_kernel<R, W>), LDS only holds the column order
     void (*reg0)(const OsdArgs) = nullptr;
-    if (!higher && h->osd_reg) {
+    if (!higher && h->osd_reg && !h->osd_big) {
         if (a.m <= 64 && a.words <= 2) reg0 = osd0_reg_kernel<1, 2>;
         else if (a.m <= 128 && a.words <= 4) reg0 = osd0_reg_kernel<2, 4>;
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
@@ -1299,8 +1305,16 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         else if (a.m <= 128 && a.words <= 4) regw = osdw_reg_kernel<2, 4>;
         else regw = osdw_reg_kernel<4, 8>;
     }
-    if (reg0 || regw) {  // H bit-packed by rows, once per handle
-        a.rank = a.n - osd_k(h);
+    size_t per_wave = reg0 ? (size_t)a.n * 4
+                    : regw ? (size_t)a.n * (8 * ((size_t)a.kwords + 2) + 4 + 4) + 64 * (size_t)a.kwords * 4
+                    : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
+                             : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
+    per_wave = (per_wave + 15) & ~(size_t)15;
+    const bool big0 = !higher && !reg0 && (per_wave > 150u * 1024u || h->osd_big);  // OSD-0 with the matrix in HBM (osd0_big_kernel)
+    if (reg0 || regw || big0) {  // H bit-packed by rows, once per handle
+        // rank H bounds the pivots; working it out is a dense elimination on the host, worth it only for moderate sizes
+        const bool host_rank = reg0 || regw || (double)a.m * a.m * a.words < 4e9;
+        a.rank = host_rank ? a.n - osd_k(h) : (a.m < a.n ? a.m : a.n);
         if (!h->osd_packed.p) {
             std::vector<uint64_t> packed((size_t)a.m * (size_t)a.words, 0);
             for (int i = 0; i < a.m; ++i)
@@ -1313,14 +1327,10 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         }
         a.packed = (const uint64_t *)h->osd_packed.p;
     }
-    size_t per_wave = reg0 ? (size_t)a.n * 4
-                    : regw ? (size_t)a.n * (8 * ((size_t)a.kwords + 2) + 4 + 4) + 64 * (size_t)a.kwords * 4
-                    : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
-                             : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
-    per_wave = (per_wave + 15) & ~(size_t)15;
-    if (per_wave > 150u * 1024u)
+    if (per_wave > 150u * 1024u && !big0)
         return fail(LDPC_HIP_ERR_UNSUPPORTED,
-                    "OSD on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB available", per_wave);
+                    "higher-order OSD on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB "
+                    "available (OSD-0 has a path for larger matrices)", per_wave);
     // wavefronts per workgroup: whichever of 1..4 lets most wavefronts reside on a CU (a workgroup's LDS is one
     // allocation, so large per-wavefront tables pack better in small workgroups); ties go to the larger workgroup
     int waves = 1, resident_best = 0;
@@ -1333,7 +1343,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.lds_per_wave = (int32_t)per_wave;
     const size_t dyn = per_wave * (size_t)waves;
     const void *fn = reg0 ? (const void *)reg0 : regw ? (const void *)regw : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
-    if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    if (!big0 && dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     // list the unconverged rows, then persistent wavefronts (as many as LDS lets reside) pull rows from the list
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
     if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
@@ -1342,6 +1352,37 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.counters = (unsigned *)h->osd_counters.p;
     hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
                        (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    if (big0) {
+        OsdBigArgs A = {};
+        A.hwords = (a.n + 63) / 64;
+        A.pow2 = 1;
+        while (A.pow2 < a.n) A.pow2 <<= 1;
+        A.max_rank = a.rank;
+        // LDS: [keys 8 n | later: pivot columns, hit list, pivot row, syndrome column] [column order 4 pow2]
+        size_t region0 = (size_t)a.n * 8;
+        const size_t after = (size_t)a.m * 4 * 2 + 8 + (size_t)A.hwords * 8 + (size_t)a.m;
+        if (after > region0) region0 = after;
+        region0 = (region0 + 15) & ~(size_t)15;
+        const size_t lds = region0 + (size_t)A.pow2 * 4;
+        if (lds > 150u * 1024u)
+            return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD-0 on the device sorts the columns in LDS: %zu bytes needed, 150 KiB available", lds);
+        a.lds_per_wave = (int32_t)region0;
+        A.slot_stride = (int64_t)A.hwords * a.m;
+        int per_cu = (int)((160u * 1024u) / lds);
+        if (per_cu > 4) per_cu = 4;
+        if (per_cu < 1) per_cu = 1;
+        int64_t slots = 256 * (int64_t)per_cu;
+        if (slots > batch) slots = batch;
+        const int64_t cap = (int64_t)(4ull << 30) / (A.slot_stride * 8);  // at most 4 GiB of working copies
+        if (slots > cap) slots = cap > 0 ? cap : 1;
+        if ((rc = h->osd_scratch.ensure((size_t)slots * (size_t)A.slot_stride * 8))) return rc;
+        A.scratch = (uint64_t *)h->osd_scratch.p;
+        A.o = a;
+        if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)osd0_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(osd0_big_kernel, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
+        HIPCHK(hipGetLastError());
+        return LDPC_HIP_OK;
+    }
     int groups_per_cu = (int)((160u * 1024u) / dyn);
     if (groups_per_cu * waves > 32) groups_per_cu = 32 / waves;
     if (groups_per_cu < 1) groups_per_cu = 1;
@@ -1390,8 +1431,10 @@ int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters) {
 
 int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 0) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic) or 0 (matrix in LDS)");
+    if (mode < -1 || mode > 2 || mode == 1)
+        return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic), 0 (matrix in LDS) or 2 (OSD-0: matrix in HBM)");
     h->osd_reg = mode != 0;
+    h->osd_big = mode == 2;
     return LDPC_HIP_OK;
 }
 

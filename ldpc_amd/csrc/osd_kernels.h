@@ -696,3 +696,115 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
         OSD_CLK(6);
     }
 }
+
+// ---- OSD-0 for matrices beyond LDS: one WORKGROUP per syndrome, [H] in a global scratch slot ------------------------
+// Same result as osd0_kernel.  The working copy of H lives in HBM / L2, word-plane major -- plane w holds word w of
+// every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of the
+// pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
+// touched all the time: the column order, the syndrome column, the pivot columns, the pivot row and the hit list.
+// The columns are sorted by a bitonic network over column numbers (comparing (key, number), hence stable).
+struct OsdBigArgs {
+    OsdArgs o;
+    uint64_t *scratch;      // [slots][hwords][m]
+    int64_t slot_stride;    // 64-bit words per slot
+    int32_t hwords;         // ceil(n / 64)
+    int32_t pow2;           // bitonic size: smallest power of two >= n
+    int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
+};
+
+__global__ void __launch_bounds__(256) osd0_big_kernel(const OsdBigArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    const OsdArgs &a = A.o;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int m = a.m, n = a.n, HW = A.hwords, P = A.pow2;
+    // during the sort: keys [n] u64, then ord [P] i32.  Afterwards the keys' room is reused.
+    uint64_t *keys = reinterpret_cast<uint64_t *>(osd_lds);
+    int32_t *ord = reinterpret_cast<int32_t *>(osd_lds + (size_t)a.lds_per_wave);  // lds_per_wave: bytes before `ord`
+    int32_t *pivcol = reinterpret_cast<int32_t *>(osd_lds);            // [m]
+    int32_t *hits = pivcol + m;                                        // [m]
+    uint64_t *prow = reinterpret_cast<uint64_t *>(hits + m + (m & 1));  // [HW]
+    uint8_t *sy = reinterpret_cast<uint8_t *>(prow + HW);              // [m]
+    __shared__ int sh_row, sh_pivot, sh_nhits;
+    uint64_t *mat = A.scratch + (int64_t)blockIdx.x * A.slot_stride;
+
+    for (;;) {
+        if (tid == 0) {
+            const unsigned idx = atomicAdd(&a.counters[1], 1u);
+            const unsigned count = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_row = idx < count ? a.list[idx] : -1;
+        }
+        __syncthreads();
+        const int64_t b = sh_row;
+        if (b < 0) return;
+        // working copy of H, word-plane major (a.packed is row-major with a.words words per row)
+        for (int64_t e = tid; e < (int64_t)HW * m; e += T) {
+            const int w = (int)(e / m), i = (int)(e - (int64_t)w * m);
+            mat[e] = a.packed[(size_t)i * a.words + w];
+        }
+        for (int j = tid; j < n; j += T) keys[j] = osd_sort_key(a.llr[b * n + j]);
+        for (int j = tid; j < P; j += T) ord[j] = j;
+        __syncthreads();
+        // soft_decision_col_sort (sort.hpp:48-62): ascending key, ties by column number; numbers >= n pad the network
+        for (int k = 2; k <= P; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += T) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const int x = ord[i], y = ord[l];
+                        const uint64_t kx = x < n ? keys[x] : ~0ull, ky = y < n ? keys[y] : ~0ull;
+                        const bool y_first = ky < kx || (ky == kx && y < x);
+                        if (y_first == ((i & k) == 0)) { ord[i] = y; ord[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }  // (overwrites the keys)
+        if (tid == 0) { sh_nhits = 0; sh_pivot = INT32_MAX; }
+        __syncthreads();
+
+        int rank = 0;
+        for (int t = 0; t < n && rank < A.max_rank; ++t) {
+            const int c = ord[t];
+            const uint64_t *plane = mat + (int64_t)(c >> 6) * m;
+            const uint64_t cb = 1ull << (c & 63);
+            for (int i = tid; i < m; i += T)
+                if (plane[i] & cb) {
+                    hits[atomicAdd(&sh_nhits, 1)] = i;
+                    if (pivcol[i] < 0) atomicMin(&sh_pivot, i);
+                }
+            __syncthreads();
+            const int p = sh_pivot, nh = sh_nhits;
+            if (p == INT32_MAX) {  // no unpivoted row has the bit
+                __syncthreads();
+                if (tid == 0) sh_nhits = 0;
+                __syncthreads();
+                continue;
+            }
+            for (int w = tid; w < HW; w += T) prow[w] = mat[(int64_t)w * m + p];
+            __syncthreads();
+            const uint8_t psy = sy[p];
+            for (int hI = tid; hI < nh; hI += T) {
+                const int r = hits[hI];
+                if (r == p) continue;
+                for (int w = 0; w < HW; ++w) {
+                    const uint64_t pw = prow[w];
+                    if (pw) mat[(int64_t)w * m + r] ^= pw;
+                }
+                sy[r] ^= psy;
+            }
+            if (tid == 0) { pivcol[p] = c; sh_nhits = 0; sh_pivot = INT32_MAX; }
+            ++rank;
+            __syncthreads();
+            // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
+            int pending = 0;
+            for (int i = tid; i < m; i += T) pending |= (pivcol[i] < 0 && sy[i]) ? 1 : 0;
+            if (!__syncthreads_or(pending)) break;
+        }
+        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
+        for (int j = tid; j < n; j += T) a.decoding[b * n + j] = 0;
+        __syncthreads();
+        for (int i = tid; i < m; i += T)
+            if (pivcol[i] >= 0 && sy[i]) a.decoding[b * n + pivcol[i]] = 1;
+        __syncthreads();
+    }
+}

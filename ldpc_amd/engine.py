@@ -114,7 +114,7 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_set_serial_kernel(self._h, int(mode)))
 
     def set_osd_kernel(self, mode):
-        """OSD elimination: -1 automatic (registers for small matrices), 0 always the LDS kernels."""
+        """OSD elimination: -1 automatic (registers / LDS / HBM by size), 0 the LDS kernels, 2 OSD-0 through the HBM kernel."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd_kernel(self._h, int(mode)))
 
     def set_small_code_kernel(self, mode):

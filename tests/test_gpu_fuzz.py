@@ -108,11 +108,12 @@ def test_serial_osd_and_soft_random_codes(seed, oracle_built):
         for osd_method, osd_order in ((1, 0), (3, int(rng.integers(1, 9))), (2, int(rng.integers(1, 7)))):
             want = o.bposd_decode_batch(s, osd_method, osd_order)
             eng.set_osd(osd_method, osd_order)
-            for osd_kernel in (-1, 0):
+            for osd_kernel in (-1, 0, 2):  # 2: the OSD-0 path for matrices beyond LDS (higher orders ignore it)
                 eng.set_osd_kernel(osd_kernel)
                 got = eng.decode_batch(s, osd=True)
                 assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} kernel {osd_kernel} seed {seed} {method} m={m} n={n}"
                 assert np.array_equal(got[3], want[3])
+            eng.set_osd_kernel(-1)
     # soft syndromes (always serial minimum-sum)
     soft = rng.normal(scale=2.0, size=(batch, m))
     o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method="minimum_sum", ms_scaling_factor=0.9)
@@ -141,11 +142,40 @@ def test_higher_order_osd_across_null_space_sizes(seed, oracle_built):
     for osd_method, osd_order in ((3, 7), (2, 5), (1, 0)):
         want = o.bposd_decode_batch(s, osd_method, osd_order)
         eng.set_osd(osd_method, osd_order)
-        for osd_kernel in (-1, 0):
+        for osd_kernel in (-1, 0, 2):
             eng.set_osd_kernel(osd_kernel)
             got = eng.decode_batch(s, osd=True)
             assert np.array_equal(got[0], want[0]), f"OSD {osd_method}/{osd_order} kernel {osd_kernel} m={m} n={n}"
             assert np.array_equal(got[3], want[3])
+
+
+def test_osd0_beyond_lds(oracle_built):
+    """A 900 x 1700 matrix: [H | s] is 190 KiB bit-packed, more than LDS holds -- OSD-0 runs with H in an HBM scratch slot;
+    higher-order OSD refuses."""
+    from ldpc_amd._lib import LdpcHipError
+    from ldpc_amd.engine import HipBpEngine
+    rng = np.random.default_rng(99)
+    m, n = 900, 1700
+    rows = np.repeat(np.arange(m), 6)
+    cols = rng.integers(0, n, size=m * 6)
+    h = sp.csr_matrix((np.ones(m * 6, np.uint8), (rows, cols)), shape=(m, n))
+    h.data[:] = 1
+    h.sum_duplicates()
+    h.data[:] = 1
+    probs = rng.uniform(0.01, 0.08, size=n)
+    e = (rng.random((40, n)) < 0.04).astype(np.uint8)
+    s = np.ascontiguousarray((h @ e.T % 2).T.astype(np.uint8))
+    o = oracle_built.BpOracle(h, error_channel=probs, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.7)
+    want = o.bposd_decode_batch(s, 1, 0)
+    assert not want[3].all(), "the case needs rows that go through OSD"
+    eng = HipBpEngine(h.indptr, h.indices, n, probs, 4, 1, 0.7)
+    eng.set_osd(1, 0)
+    got = eng.decode_batch(s, osd=True)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3])
+    assert not np.any((h @ got[0].T % 2).T != s), "every OSD solution satisfies its syndrome"
+    eng.set_osd(3, 4)
+    with pytest.raises(LdpcHipError, match="higher-order OSD"):
+        eng.decode_batch(s, osd=True)
 
 
 def test_matrix_without_entries(oracle_built):

@@ -24,25 +24,33 @@ def main():
     ap.add_argument("--shots", type=int, default=32768)
     ap.add_argument("--p", type=float, default=0.003)
     ap.add_argument("--cpu", type=int, default=0)
+    ap.add_argument("--windowing", default="3,6,3", help="decodings,window,commit (12 rounds in all)")
+    ap.add_argument("--bp-method", default="minimum_sum")
+    ap.add_argument("--small-mode", type=int, default=None, help="ldpc_hip_bp_set_small_code_kernel for every window engine")
     args = ap.parse_args()
     from ldpc_amd import codes
     from ldpc_amd.ckt_noise import BpOsdOverlappingWindowDecoder
     from window_util import phenomenological_dem, phenomenological_matrices, sample_shots
     h = codes.bivariate_bicycle_hx()
-    rounds, decodings, window, commit = 12, 3, 6, 3
+    decodings, window, commit = (int(x) for x in args.windowing.split(","))
+    rounds = (window - commit) + decodings * commit
     text = phenomenological_dem(h, rounds, args.p, args.p, logical=tuple(range(12)))
     check, obs, pri = phenomenological_matrices(h, rounds, args.p, args.p, logical=tuple(range(12)))
     shots, _ = sample_shots(check, pri, args.shots, seed=11)
-    cfg = dict(max_iter=30, bp_method="minimum_sum", ms_scaling_factor=0.625)
+    cfg = dict(max_iter=30, bp_method=args.bp_method, ms_scaling_factor=0.625)
     dec = BpOsdOverlappingWindowDecoder(text, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], decoder_config=cfg)
     dec.decode_batch(shots[:256].copy())  # builds the window decoders
+    if args.small_mode is not None:
+        for d in dec._decoders.values():
+            d.inner._get_engine().set_small_code_kernel(args.small_mode)
+        dec.decode_batch(shots[:256].copy())
     t0 = time.perf_counter()
     preds = dec.decode_batch(shots.copy())
     dt = time.perf_counter() - t0
     out = {"config": f"BB144 x {rounds} rounds, {decodings} windows of {window} committing {commit}, min_sum 30 it + OSD-0, p={args.p}",
            "shots": args.shots, "detectors": check.shape[0], "errors": check.shape[1],
            "window_columns": [int(len(d.cols)) for d in dec._decoders.values()],
-           "shots_per_s": args.shots / dt, "seconds": dt, "flipped_observables": int(preds.sum())}
+           "small_mode": args.small_mode, "bp_method": args.bp_method, "mean_iterations": [float(d.inner.iter_batch.float().mean()) for d in dec._decoders.values()], "bp_kernel_ms": [d.inner._get_engine().last_kernel_ms() for d in dec._decoders.values()], "shots_per_s": args.shots / dt, "seconds": dt, "flipped_observables": int(preds.sum())}
     if args.cpu:
         from oracle.window_oracle import WindowOracle
         w = WindowOracle(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], **cfg)
