@@ -37,7 +37,7 @@
 //   bp_wave_kernel.h     bp_wave_kernel, bp_wave_ps_kernel   same regime, bounded degrees: one wavefront per syndrome, no workgroup barriers
 //                        (lane = node; for product-sum lane = entry)
 //   bp_serial_kernels.h  bp_serial_kernel, bp_softinfo_kernel   serial schedule, soft-syndrome serial min-sum
-//   osd_kernels.h        osd0_kernel, osdw_kernel               OSD-0 / OSD-E / OSD-CS post-processing
+//   osd_kernels.h        osd0[_reg]_kernel, osdw[_reg]_kernel, osd_big_kernel   OSD-0 / OSD-E / OSD-CS post-processing
 //   io_kernels.h         pack / unpack / transpose, H v, b8 shot data, synthetic BSC shots
 
 #include "bp_device_common.h"
@@ -142,6 +142,12 @@ struct ldpc_hip_bp {
     bool levels_valid = false;                                      // lvl_* describe the current schedule order
     int32_t n_levels = 0;
     DeviceBuf lvl_ptr, lvl_bits;
+    // repacking of the streamed parallel schedule (decode_stream_repacked), steered by what the previous decode looked like
+    DeviceBuf sp_hist, sp_iters;     // iteration histogram of the last streamed decode (256 bins) / iteration counts when the caller wants none
+    unsigned *h_hist = nullptr;      // pinned copy of the histogram
+    hipEvent_t ev_hist = nullptr;    // the copy has landed
+    bool hist_pending = false;
+    int32_t hist_max_iter = 0;
     int32_t repack_iters = -1;                                      // first-pass iterations: -1 auto (max_iter / 8), 0 = no repacking
     DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
@@ -261,6 +267,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_mid);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_hist);
     if (e != hipSuccess) {
         ldpc_hip_bp_destroy(h);
         return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -275,7 +282,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -291,6 +298,8 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+    if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
+    if (h->h_hist) (void)hipHostFree(h->h_hist);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -467,7 +476,7 @@ static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
 
 
 static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
-                         double *llr, int32_t *iters, uint8_t *conv);
+                         double *llr, int32_t *iters, uint8_t *conv, bool may_repack = true);
 
 // Serial schedule: one wavefront per 64-syndrome tile (bp_serial_kernel).  Device pointers, on h->stream.
 // levels of the serial schedule: see bp_serial_level_kernel
@@ -1043,8 +1052,10 @@ static void pick_spread(const ldpc_hip_bp *h, spread_kernel_t &kc, spread_kernel
 }
 
 // Everything below runs on h->stream with device pointers only.
+static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                  double *llr, int32_t *iters, uint8_t *conv);
 static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
-                         double *llr, int32_t *iters, uint8_t *conv) {
+                         double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
     if (h->schedule == 0) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
@@ -1066,6 +1077,10 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             if (small_lds_bytes(h, sl) <= budget) slots = sl;
         if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);
     }
+    // streamed tiles: a tile runs until the slowest of its 64 syndromes is done.  Where most syndromes converge early
+    // a short first pass + a second pass over the compacted rest does the same work in a fraction of the tile-iterations
+    if (may_repack && h->repack_iters != 0 && h->max_iter >= 8 && tiles_total >= 512 && h->m > 0 && h->n > 0)
+        return decode_stream_repacked(h, synd, batch, decoding, llr, iters, conv);
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
 
@@ -1246,6 +1261,102 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 }
 
 
+// Two passes of the streamed parallel schedule: k1 iterations for everyone, then the rows that have not converged are
+// gathered into a dense batch and decoded again from the start with the full budget (BP is deterministic: the second
+// pass repeats the first k1 iterations of those rows and carries on; its results replace the first pass's).  Whether
+// that pays depends on the noise, which the host cannot see -- so every streamed decode leaves a histogram of its
+// iteration counts behind (one tiny kernel, copied asynchronously), and the next decode on the handle prices both
+// ways with it: a tile costs as many iterations as its slowest syndrome, i.e. sum_j (1 - F(j-1)^64) for the plain run
+// (F = fraction converged within j iterations) against the same sum up to k1 plus (1 - F(k1)) max_iter for the
+// repacked one, minimised over k1.  No work is wasted when nothing converges (the first call and every call whose
+// predecessor says "plain" run plain), and results do not depend on any of this.
+static int stream_first_pass_length(ldpc_hip_bp *h) {
+    if (h->repack_iters > 0) return h->repack_iters;
+    if (!h->hist_pending || h->hist_max_iter != h->max_iter) return 0;
+    if (hipEventSynchronize(h->ev_hist) != hipSuccess) return 0;
+    const int full = h->max_iter, top = full < 255 ? full : 255;
+    double total = 0;
+    for (int j = 0; j < 256; ++j) total += h->h_hist[j];
+    if (total <= 0) return 0;
+    std::vector<double> F((size_t)top + 1, 0.0);  // F[j]: converged within j iterations
+    double acc = 0;
+    for (int j = 1; j <= top; ++j) { acc += h->h_hist[j]; F[(size_t)j] = acc / total; }
+    auto tile_runs = [&](int j) { return 1.0 - std::pow(F[(size_t)(j - 1 < top ? j - 1 : top)], 64.0); };  // still going at iteration j
+    double plain = 0;
+    for (int j = 1; j <= full; ++j) plain += tile_runs(j);
+    double best = plain, prefix = 0;
+    int best_k = 0;
+    for (int k = 1; k <= full / 2 && k <= top; ++k) {
+        prefix += tile_runs(k);
+        if (k < 2) continue;
+        const double cost = prefix + (1.0 - F[(size_t)k]) * full + 0.5;  // + gather / scatter / a second launch, in iterations
+        if (cost < best) { best = cost; best_k = k; }
+    }
+    return best < 0.85 * plain ? best_k : 0;
+}
+
+static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
+    int rc;
+    if ((rc = h->sp_hist.ensure(256 * sizeof(unsigned)))) return rc;
+    if (!h->h_hist) HIPCHK(hipHostMalloc((void **)&h->h_hist, 256 * sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(h->sp_hist.p, 0, 256 * sizeof(unsigned), h->stream));
+    int64_t blocks = (batch + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(iteration_histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, iters, conv, batch, (unsigned *)h->sp_hist.p);
+    HIPCHK(hipMemcpyAsync(h->h_hist, h->sp_hist.p, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_hist, h->stream));
+    h->hist_pending = true;
+    h->hist_max_iter = h->max_iter;
+    return LDPC_HIP_OK;
+}
+
+static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                  double *llr, int32_t *iters, uint8_t *conv) {
+    const int full = h->max_iter;
+    const size_t B = (size_t)batch, m1 = (size_t)h->m, n1 = (size_t)h->n;
+    int rc;
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+    const int k1 = stream_first_pass_length(h);
+    if (k1 < 2 || k1 >= full) {
+        if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false))) return rc;
+        return stream_leave_histogram(h, iters, conv, batch);
+    }
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+    h->max_iter = k1;
+    rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+    h->max_iter = full;
+    if (rc) return rc;
+    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
+    const int64_t cnt = (int64_t)h->h_counters[2];
+    if (cnt > 0) {
+        float ms1 = 0.f;
+        (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
+        const size_t C = (size_t)cnt;
+        if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
+            (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
+        const int32_t *list = (const int32_t *)h->osd_list.p;
+        auto grid = [](size_t items) { return dim3((unsigned)((items + 255) / 256)); };
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
+                                (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, false))) return rc;
+        h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * n1), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
+        if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * n1), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);
+        hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
+        HIPCHK(hipGetLastError());
+    }
+    return stream_leave_histogram(h, iters, conv, batch);
+}
+
 // BP, then OSD-0 on the rows BP left unconverged; device pointers, on h->stream
 // k = n - rank(H) over GF(2): how many non-pivot columns an OSD elimination leaves (independent of the column order)
 static int osd_k(ldpc_hip_bp *h) {
@@ -1298,7 +1409,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
     }
     void (*regw)(const OsdArgs) = nullptr;
-    if (higher && h->osd_reg && a.m <= 256 && a.words <= 8) {
+    if (higher && h->osd_reg && !h->osd_big && a.m <= 256 && a.words <= 8) {
         a.kwords = (osd_k(h) + 63) / 64;
         if (a.kwords < 1) a.kwords = 1;
         if (a.m <= 64 && a.words <= 2) regw = osdw_reg_kernel<1, 2>;
@@ -1310,10 +1421,11 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
                     : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
-    const bool big0 = !higher && !reg0 && (per_wave > 150u * 1024u || h->osd_big);  // OSD-0 with the matrix in HBM (osd0_big_kernel)
+    const bool big0 = !reg0 && !regw && (per_wave > 150u * 1024u || h->osd_big);  // matrix in HBM (osd_big_kernel)  // OSD-0 with the matrix in HBM (osd0_big_kernel)
+    bool host_rank = false;
     if (reg0 || regw || big0) {  // H bit-packed by rows, once per handle
         // rank H bounds the pivots; working it out is a dense elimination on the host, worth it only for moderate sizes
-        const bool host_rank = reg0 || regw || (double)a.m * a.m * a.words < 4e9;
+        host_rank = reg0 || regw || (double)a.m * a.m * a.words < 4e9;
         a.rank = host_rank ? a.n - osd_k(h) : (a.m < a.n ? a.m : a.n);
         if (!h->osd_packed.p) {
             std::vector<uint64_t> packed((size_t)a.m * (size_t)a.words, 0);
@@ -1327,10 +1439,6 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         }
         a.packed = (const uint64_t *)h->osd_packed.p;
     }
-    if (per_wave > 150u * 1024u && !big0)
-        return fail(LDPC_HIP_ERR_UNSUPPORTED,
-                    "higher-order OSD on the device keeps the bit-packed [H|s] of one syndrome in LDS: %zu bytes needed, 150 KiB "
-                    "available (OSD-0 has a path for larger matrices)", per_wave);
     // wavefronts per workgroup: whichever of 1..4 lets most wavefronts reside on a CU (a workgroup's LDS is one
     // allocation, so large per-wavefront tables pack better in small workgroups); ties go to the larger workgroup
     int waves = 1, resident_best = 0;
@@ -1358,16 +1466,22 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         A.pow2 = 1;
         while (A.pow2 < a.n) A.pow2 <<= 1;
         A.max_rank = a.rank;
+        A.kwords = !higher ? 0 : host_rank ? (a.n - a.rank + 63) / 64 : A.hwords;  // planes of T; rank unknown: room for every column
+        if (higher && A.kwords < 1) A.kwords = 1;
         // LDS: [keys 8 n | later: pivot columns, hit list, pivot row, syndrome column] [column order 4 pow2]
+        //      higher order: [column info 4 n] [non-pivot columns 4 n] [four T planes 32 m]
         size_t region0 = (size_t)a.n * 8;
         const size_t after = (size_t)a.m * 4 * 2 + 8 + (size_t)A.hwords * 8 + (size_t)a.m;
         if (after > region0) region0 = after;
         region0 = (region0 + 15) & ~(size_t)15;
-        const size_t lds = region0 + (size_t)A.pow2 * 4;
+        size_t lds = region0 + (size_t)A.pow2 * 4;
+        A.extra_off = (int32_t)lds;
+        if (higher) lds += (size_t)a.n * 8 + 8 + (size_t)a.m * 32;
         if (lds > 150u * 1024u)
-            return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD-0 on the device sorts the columns in LDS: %zu bytes needed, 150 KiB available", lds);
+            return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: the column order%s of a %d x %d matrix need%s %zu bytes of LDS, 150 KiB available",
+                        higher ? " and the candidate tables" : "", a.m, a.n, higher ? "" : "s", lds);
         a.lds_per_wave = (int32_t)region0;
-        A.slot_stride = (int64_t)A.hwords * a.m;
+        A.slot_stride = (int64_t)(A.hwords + A.kwords) * a.m;
         int per_cu = (int)((160u * 1024u) / lds);
         if (per_cu > 4) per_cu = 4;
         if (per_cu < 1) per_cu = 1;
@@ -1378,8 +1492,10 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if ((rc = h->osd_scratch.ensure((size_t)slots * (size_t)A.slot_stride * 8))) return rc;
         A.scratch = (uint64_t *)h->osd_scratch.p;
         A.o = a;
-        if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)osd0_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(osd0_big_kernel, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
+        const void *bfn = higher ? (const void *)osd_big_kernel<true> : (const void *)osd_big_kernel<false>;
+        if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute(bfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (higher) hipLaunchKernelGGL(osd_big_kernel<true>, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
+        else hipLaunchKernelGGL(osd_big_kernel<false>, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
         HIPCHK(hipGetLastError());
         return LDPC_HIP_OK;
     }

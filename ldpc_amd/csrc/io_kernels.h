@@ -173,3 +173,19 @@ __global__ void scatter_rows_kernel(const T *__restrict__ src, const int32_t *__
     const int64_t r = t / width;
     dst[(int64_t)list[r] * width + (t - r * width)] = src[t];
 }
+
+// How many rows converged after exactly j iterations (bin j, j capped at 255) and how many did not converge (bin 0):
+// what the host needs to see whether a short first pass + a second pass over the rest would have been cheaper
+__global__ void __launch_bounds__(256) iteration_histogram_kernel(const int32_t *__restrict__ iters, const uint8_t *__restrict__ conv,
+                                                                  int64_t batch, unsigned *__restrict__ hist) {
+    __shared__ unsigned local[256];
+    local[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
+        const int it = iters[b];
+        atomicAdd(&local[conv[b] ? (it < 1 ? 1 : it > 255 ? 255 : it) : 0], 1u);
+    }
+    __syncthreads();
+    if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+

@@ -697,25 +697,32 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
     }
 }
 
-// ---- OSD-0 for matrices beyond LDS: one WORKGROUP per syndrome, [H] in a global scratch slot ------------------------
-// Same result as osd0_kernel.  The working copy of H lives in HBM / L2, word-plane major -- plane w holds word w of
-// every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of the
-// pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
+// ---- OSD for matrices beyond LDS: one WORKGROUP per syndrome, [H] in a global scratch slot ---------------------------
+// Same results as osd0_kernel / osdw_kernel.  The working copy of H lives in HBM / L2, word-plane major -- plane w holds
+// word w of every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of
+// the pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
 // touched all the time: the column order, the syndrome column, the pivot columns, the pivot row and the hit list.
 // The columns are sorted by a bitonic network over column numbers (comparing (key, number), hence stable).
+// HIGHER (OSD_E / OSD_CS): no early stop; afterwards the reduced rows are compressed to the non-pivot columns (T, again
+// plane-major, behind the matrix in the slot) and the candidates are weighed as in osdw_reg_kernel: thread = candidate,
+// 256 at a time, each wavefront with the T plane of its 64 one-column candidates staged in LDS.
 struct OsdBigArgs {
     OsdArgs o;
-    uint64_t *scratch;      // [slots][hwords][m]
+    uint64_t *scratch;      // [slots][hwords + kwords][m]
     int64_t slot_stride;    // 64-bit words per slot
     int32_t hwords;         // ceil(n / 64)
     int32_t pow2;           // bitonic size: smallest power of two >= n
     int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
+    int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
+    int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i32, npcol [n] i32, planes [4][m] u64}
 };
 
-__global__ void __launch_bounds__(256) osd0_big_kernel(const OsdBigArgs A) {
+template <bool HIGHER>
+__global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const OsdArgs &a = A.o;
     const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int m = a.m, n = a.n, HW = A.hwords, P = A.pow2;
     // during the sort: keys [n] u64, then ord [P] i32.  Afterwards the keys' room is reused.
     uint64_t *keys = reinterpret_cast<uint64_t *>(osd_lds);
@@ -724,8 +731,14 @@ __global__ void __launch_bounds__(256) osd0_big_kernel(const OsdBigArgs A) {
     int32_t *hits = pivcol + m;                                        // [m]
     uint64_t *prow = reinterpret_cast<uint64_t *>(hits + m + (m & 1));  // [HW]
     uint8_t *sy = reinterpret_cast<uint8_t *>(prow + HW);              // [m]
-    __shared__ int sh_row, sh_pivot, sh_nhits;
+    int32_t *colinfo = reinterpret_cast<int32_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
+    int32_t *npcol = colinfo + n;                                      // [n] non-pivot columns in sorted order
+    uint64_t *planes = reinterpret_cast<uint64_t *>(npcol + n + (n & 1));  // [4][m]
+    __shared__ int sh_row, sh_pivot, sh_nhits, sh_cnt[4];
+    __shared__ double sh_w[4];
+    __shared__ long sh_c[4];
     uint64_t *mat = A.scratch + (int64_t)blockIdx.x * A.slot_stride;
+    uint64_t *Tm = mat + (int64_t)HW * m;  // [kwords][m]
 
     for (;;) {
         if (tid == 0) {
@@ -795,16 +808,167 @@ __global__ void __launch_bounds__(256) osd0_big_kernel(const OsdBigArgs A) {
             if (tid == 0) { pivcol[p] = c; sh_nhits = 0; sh_pivot = INT32_MAX; }
             ++rank;
             __syncthreads();
-            // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
-            int pending = 0;
-            for (int i = tid; i < m; i += T) pending |= (pivcol[i] < 0 && sy[i]) ? 1 : 0;
-            if (!__syncthreads_or(pending)) break;
+            if (!HIGHER) {  // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
+                int pending = 0;
+                for (int i = tid; i < m; i += T) pending |= (pivcol[i] < 0 && sy[i]) ? 1 : 0;
+                if (!__syncthreads_or(pending)) break;
+            }
         }
-        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
-        for (int j = tid; j < n; j += T) a.decoding[b * n + j] = 0;
+        if (!HIGHER) {
+            // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
+            for (int j = tid; j < n; j += T) a.decoding[b * n + j] = 0;
+            __syncthreads();
+            for (int i = tid; i < m; i += T)
+                if (pivcol[i] >= 0 && sy[i]) a.decoding[b * n + pivcol[i]] = 1;
+            __syncthreads();
+            continue;
+        }
+
+        // ---- higher order (osd.hpp:119-187) ----
+        for (int j = tid; j < n; j += T) colinfo[j] = INT32_MIN;
         __syncthreads();
         for (int i = tid; i < m; i += T)
-            if (pivcol[i] >= 0 && sy[i]) a.decoding[b * n + pivcol[i]] = 1;
+            if (pivcol[i] >= 0) colinfo[pivcol[i]] = i;
+        __syncthreads();
+        int k = 0;  // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
+        for (int t0 = 0; t0 < n; t0 += T) {
+            const int t = t0 + tid;
+            const int c = t < n ? ord[t] : 0;
+            const bool np = t < n && colinfo[c] == INT32_MIN;
+            const uint64_t mask = __ballot(np);
+            if (lane == 0) sh_cnt[wave] = __builtin_popcountll(mask);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 4; ++w) { before += w < wave ? sh_cnt[w] : 0; total += sh_cnt[w]; }
+            if (np) {
+                const int q = k + before + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                colinfo[c] = -1 - q;
+                npcol[q] = c;
+            }
+            k += total;
+            __syncthreads();
+        }
+        const int KW = (k + 63) >> 6;  // <= A.kwords by the host's sizing
+        // T: the reduced rows on the non-pivot columns (bit q = the q-th of them), plane v = word v of every row
+        for (int r = tid; r < m; r += T) {
+            const bool pivoted = pivcol[r] >= 0;
+            for (int v = 0; v < KW; ++v) {
+                uint64_t word = 0;
+                if (pivoted) {
+                    const int cnt = k - 64 * v < 64 ? k - 64 * v : 64;
+                    for (int qq = 0; qq < cnt; ++qq) {
+                        const int c = npcol[64 * v + qq];
+                        word |= ((mat[(int64_t)(c >> 6) * m + r] >> (c & 63)) & 1ull) << qq;
+                    }
+                }
+                Tm[(int64_t)v * m + r] = word;
+            }
+        }
+        __syncthreads();
+        // x_i of a candidate: pivot column with row r: S_r ^ parity(T_r & candidate); q-th non-pivot column: the candidate's bit q.
+        // Weights are added in column order (osd.hpp:171-176); `acc += bit ? w : 0.0` adds the same numbers.
+        const double *wt = a.wt;
+        auto weigh_single = [&](const uint64_t *pl, int q, bool live) -> double {  // candidate: non-pivot column q alone; pl = T plane q / 64
+            double acc = 0;
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);  // the same for every lane: a scalar branch
+                bool bit;
+                if (ci >= 0) bit = (((pl[ci] >> (q & 63)) & 1ull) != 0) != (sy[ci] != 0);
+                else bit = live && (-1 - ci) == q;
+                acc += bit ? wt[i] : 0.0;
+            }
+            return acc;
+        };
+        auto weigh_mask = [&](const uint64_t *pl0, uint64_t mask) -> double {  // candidate: a set of the first 64 non-pivot columns
+            double acc = 0;
+            for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
+                bool bit;
+                if (ci >= 0) bit = ((__builtin_popcountll(pl0[ci] & mask) + (int)sy[ci]) & 1) != 0;
+                else bit = (-1 - ci) < 64 && ((mask >> (-1 - ci)) & 1ull) != 0;
+                acc += bit ? wt[i] : 0.0;
+            }
+            return acc;
+        };
+        auto pair_mask = [&](long p, bool &valid) -> uint64_t {  // pairs (i, j), i < j < order <= 64, i-major (osd.hpp:91-99)
+            int i = 0;
+            while (p >= a.order - 1 - i) { p -= a.order - 1 - i; ++i; }
+            const int j = i + 1 + (int)p;
+            valid = j < k;
+            return valid ? (1ull << i) | (1ull << j) : 0ull;
+        };
+        const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+        const long npairs = (long)a.order * (a.order - 1) / 2;
+        // plane 0 for the mask candidates and the OSD-0 weight
+        for (int r = tid; r < m; r += T) planes[r] = KW > 0 ? Tm[r] : 0ull;
+        __syncthreads();
+        double best_w = weigh_mask(planes, 0);  // the OSD-0 solution (osd.hpp:131-136)
+        long best_c = -1;                       // index in the reference's candidate list; -1: the OSD-0 solution
+        if (a.method == 3) {
+            for (long p0 = 0; p0 < npairs; p0 += T) {
+                const long pp = p0 + tid;
+                bool valid = false;
+                const uint64_t mask = pp < npairs ? pair_mask(pp, valid) : 0ull;
+                const double w = weigh_mask(planes, mask);
+                if (valid && (w < best_w || (w == best_w && best_c >= 0 && k + pp < best_c))) { best_w = w; best_c = k + pp; }
+            }
+            // one-column candidates come FIRST in the reference's list: an equal weight met here replaces a later pair
+            for (int v0 = 0; v0 < KW; v0 += 4) {
+                __syncthreads();
+                const int v = v0 + wave;
+                uint64_t *pl = planes + (size_t)wave * m;
+                if (v < KW)
+                    for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)v * m + r];
+                __syncthreads();
+                const int q = 64 * v + lane;
+                const bool live = v < KW && q < k;
+                const double w = weigh_single(pl, q, live);
+                if (live && (w < best_w || (w == best_w && best_c >= 0 && q < best_c))) { best_w = w; best_c = q; }
+            }
+        } else {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
+            const long total = (1L << a.order) - 1;
+            for (long c0 = 0; c0 < total; c0 += T) {
+                const long c = c0 + tid;
+                const double w = weigh_mask(planes, (uint64_t)(c + 1) & kmask);
+                if (c < total && w < best_w) { best_w = w; best_c = c; }
+            }
+        }
+        // lightest, then earliest: across the lanes of a wavefront, then across the wavefronts
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ow = __shfl_xor(best_w, off);
+            const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
+            const bool mine_set = best_c >= 0, other_set = oc >= 0;
+            if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+        }
+        __syncthreads();
+        if (lane == 0) { sh_w[wave] = best_w; sh_c[wave] = best_c; }
+        __syncthreads();
+        best_w = sh_w[0]; best_c = sh_c[0];
+        for (int w = 1; w < 4; ++w) {
+            const double ow = sh_w[w];
+            const long oc = sh_c[w];
+            if (oc >= 0 && (best_c < 0 || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+        }
+        const bool single = a.method == 3 && best_c >= 0 && best_c < k;
+        uint64_t win = 0;
+        if (best_c >= 0 && !single) {
+            bool valid;
+            win = a.method == 3 ? pair_mask(best_c - k, valid) : (uint64_t)(best_c + 1) & kmask;
+        }
+        const uint64_t *plw = single ? Tm + (int64_t)(best_c >> 6) * m : Tm;
+        for (int j = tid; j < n; j += T) {
+            const int ci = colinfo[j];
+            bool bit;
+            if (ci >= 0) {
+                const uint64_t tw = KW > 0 ? plw[ci] : 0ull;
+                bit = single ? ((((tw >> (best_c & 63)) & 1ull) != 0) != (sy[ci] != 0))
+                             : (((__builtin_popcountll(tw & win) + (int)sy[ci]) & 1) != 0);
+            } else {
+                const int q = -1 - ci;
+                bit = single ? q == (int)best_c : (q < 64 && ((win >> q) & 1ull) != 0);
+            }
+            a.decoding[b * n + j] = bit ? 1 : 0;
+        }
         __syncthreads();
     }
 }

@@ -150,8 +150,7 @@ def test_higher_order_osd_across_null_space_sizes(seed, oracle_built):
 
 
 def test_osd0_beyond_lds(oracle_built):
-    """A 900 x 1700 matrix: [H | s] is 190 KiB bit-packed, more than LDS holds -- OSD-0 runs with H in an HBM scratch slot;
-    higher-order OSD refuses."""
+    """A 900 x 1700 matrix: [H | s] is 190 KiB bit-packed, more than LDS holds -- OSD runs with H in an HBM scratch slot."""
     from ldpc_amd._lib import LdpcHipError
     from ldpc_amd.engine import HipBpEngine
     rng = np.random.default_rng(99)
@@ -173,9 +172,19 @@ def test_osd0_beyond_lds(oracle_built):
     got = eng.decode_batch(s, osd=True)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3])
     assert not np.any((h @ got[0].T % 2).T != s), "every OSD solution satisfies its syndrome"
-    eng.set_osd(3, 4)
-    with pytest.raises(LdpcHipError, match="higher-order OSD"):
-        eng.decode_batch(s, osd=True)
+    for osd_method, osd_order in ((3, 6), (2, 5)):
+        want = o.bposd_decode_batch(s, osd_method, osd_order)
+        eng.set_osd(osd_method, osd_order)
+        got = eng.decode_batch(s, osd=True)
+        assert np.array_equal(got[0], want[0]), (osd_method, osd_order)
+    # the column order and the candidate tables still live in LDS: a 6000 x 12000 matrix is refused, not mis-decoded
+    big = sp.csr_matrix((np.ones(12000, np.uint8), (np.arange(12000) % 6000, np.arange(12000))), shape=(6000, 12000))
+    eng = HipBpEngine(big.indptr, big.indices, 12000, np.full(12000, 0.05), 2, 1, 1.0)
+    eng.set_osd(1, 0)
+    s_big = np.zeros((2, 6000), np.uint8)
+    s_big[:, 5] = 3  # a byte > 1 never converges, so both rows reach OSD
+    with pytest.raises(LdpcHipError, match="150 KiB available"):
+        eng.decode_batch(s_big, osd=True)
 
 
 def test_matrix_without_entries(oracle_built):
@@ -268,3 +277,38 @@ def test_one_handle_through_a_random_sequence_of_settings(seed, oracle_built):
             assert bits_equal(got[1], want[1]), "log-ratios: " + tag
         else:
             assert got[1] is None
+
+
+def test_streamed_parallel_schedule_repacks_from_the_previous_histogram(oracle_built):
+    """A code kept off the on-chip kernels, a batch of 40 000 where most syndromes converge early: the first decode runs
+    plain and leaves its iteration histogram, the second is steered by it (two passes), a fixed first-pass length forces
+    two passes, and `set_repack(0)` switches it off -- all four give the same arrays, and those match the oracle."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(codes.regular_ldpc_code(n=1200, dv=3, dc=6, seed=3))
+    n = h.shape[1]
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.03), 24, 1, 0.8)
+    eng.set_small_code_kernel(0)
+    # 95 % of the shots from mild noise (converge in a few iterations), 5 % from noise the code cannot handle, shuffled
+    s = torch.cat([eng.gen_bsc_syndromes(5, 0.02, shot0=0, shots=38000, device="cuda:0"),
+                   eng.gen_bsc_syndromes(6, 0.08, shot0=0, shots=2000, device="cuda:0")])
+    s = s[torch.randperm(40000, generator=torch.Generator().manual_seed(1)).to(s.device)].contiguous()
+    runs = {}
+    for tag, repack in (("first", -1), ("steered", -1), ("fixed", 5), ("off", 0)):
+        eng.set_repack(repack)
+        out = eng.decode_batch(s)
+        runs[tag] = [t.cpu().numpy() for t in out]
+        runs[tag + "_ms"] = eng.last_kernel_ms()
+    for tag in ("steered", "fixed", "off"):
+        for a, b in zip(runs["first"], runs[tag]):
+            assert bits_equal(a, b) if a.dtype == np.float64 else np.array_equal(a, b), tag
+    conv = runs["first"][3].astype(bool)
+    assert 0.8 < conv.mean() < 0.999 and runs["first"][2][conv].mean() < 8, "the case is meant to converge early, with stragglers"
+    assert runs["steered_ms"] < 0.8 * runs["first_ms"], (runs["first_ms"], runs["steered_ms"], conv.mean())
+    pick = np.r_[0:64, np.flatnonzero(~conv)[:64]]
+    o = oracle_built.BpOracle(h, error_rate=0.03, max_iter=24, bp_method="minimum_sum", ms_scaling_factor=0.8)
+    want = o.decode_batch(s.cpu().numpy()[pick])
+    assert np.array_equal(runs["steered"][0][pick], want[0]) and np.array_equal(runs["steered"][2][pick], want[2])
+    assert np.array_equal(runs["steered"][3][pick].astype(bool), want[3].astype(bool)) and bits_equal(runs["steered"][1][pick], want[1])
+

@@ -58,6 +58,8 @@ def main():
         soft()
     if "hgp" in args.which:
         hgp()
+    if "hgp1600" in args.which:
+        hgp1600()
     if "osdw" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD_CS order 10 p=0.05", h, 0.05, 50, 0, 1.0, 8192, False, osd=(3, 10))
@@ -82,6 +84,21 @@ def hgp():
     run("hgp [[400,16,6]] min_sum 30 it (BP only) p=0.02", h, 0.02, 30, 1, 0.625, 65536, False)
     run("hgp [[400,16,6]] min_sum 30 it + OSD-0 p=0.02", h, 0.02, 30, 1, 0.625, 65536, True)
     run("hgp [[400,16,6]] min_sum 30 it + OSD_CS order 10 p=0.02", h, 0.02, 30, 1, 0.625, 65536, False, osd=(3, 10))
+
+
+def hgp1600():
+    """A [[1600, 64]] hypergraph product of a random (3,4)-regular 24 x 32 code with itself: hx is 768 x 1600, [H|s] is 156 KiB
+    bit-packed -- beyond LDS, so OSD runs through osd_big_kernel (H in an HBM scratch slot)."""
+    import scipy.sparse as sp
+    from ldpc_amd import codes
+    h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
+    m1, n1 = h1.shape
+    hx = sp.hstack([sp.kron(h1, sp.identity(n1, dtype=np.uint8)), sp.kron(sp.identity(m1, dtype=np.uint8), h1.T)]).tocsr().astype(np.uint8)
+    hx.sort_indices()
+    for p in (0.02, 0.04):
+        run(f"hgp [[1600,64]] min_sum 30 it (BP only) p={p}", hx, p, 30, 1, 0.625, 65536, False)
+        run(f"hgp [[1600,64]] min_sum 30 it + OSD-0 p={p}", hx, p, 30, 1, 0.625, 65536, True)
+        run(f"hgp [[1600,64]] min_sum 30 it + OSD_CS order 10 p={p}", hx, p, 30, 1, 0.625, 65536, False, osd=(3, 10))
 
 
 def soft():
