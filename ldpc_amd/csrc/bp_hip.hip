@@ -844,6 +844,7 @@ static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint
 struct WavePlan {
     int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, mp = 0, np = 0;
     size_t shared = 0, per_wave = 0;
+    bool llr_direct = false;
     void (*kern)(const WaveArgs) = nullptr;
 };
 
@@ -873,6 +874,14 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     // one workgroup per compute unit with as many wavefronts as LDS (160 KiB) and the 16-wave workgroup limit allow;
     // small codes fit several such workgroups
     const size_t lds = 160u * 1024u;
+    if (want_llr) {
+        // the LDS copy of the log-ratios is a convenience (the store of every iteration stays on chip); where it costs a
+        // resident wavefront and few are resident, every bit pass stores them straight to HBM instead
+        const size_t lean = wave_lds_private(p.mp, p.np, p.dr, false);
+        const size_t w_copy = p.shared + p.per_wave > lds ? 0 : (lds - p.shared) / p.per_wave;
+        const size_t w_lean = p.shared + lean > lds ? 0 : (lds - p.shared) / lean;
+        if (w_copy < 4 && w_lean > w_copy) { p.per_wave = lean; p.llr_direct = true; }
+    }
     if (p.shared + p.per_wave > lds) return p;
     size_t w = (lds - p.shared) / p.per_wave;
     if (w > 16) w = 16;
@@ -1028,6 +1037,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     a.col = (const uint16_t *)h->w_col.p; a.apos = (const uint16_t *)h->w_apos.p;
     a.llr0 = h->d_llr0;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.llr_direct = p.llr_direct ? 1 : 0;
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
     const size_t dyn = p.shared + (size_t)p.waves * p.per_wave;

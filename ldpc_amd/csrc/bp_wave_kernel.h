@@ -26,6 +26,7 @@
 // and to the reference.
 struct WaveArgs {
     int32_t m, n, mp, np, max_iter;
+    int32_t llr_direct;          // 1: every bit pass stores its log-ratios straight to a.llr (no LDS copy; lets one more wavefront fit)
     double ms_scaling_factor;
     int64_t batch;
     const uint8_t *rdeg, *cdeg;  // [mp], [np] node degrees (0 for padding nodes)
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, n = a.n, mp = a.mp, np = a.np, rm = DR * mp, cn = DC * np;
-    const bool want_llr = a.llr != nullptr;
+    const bool want_llr = a.llr != nullptr && !a.llr_direct, llr_direct = a.llr != nullptr && a.llr_direct;
     // Every LDS pointer is typed in the LDS address space from the start: generic ("flat") pointers into LDS make this
     // compiler emit null checks against the shared aperture that it then fails to select for some template variants.
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
 #pragma unroll
                         for (int k = 0; k < DC; ++k) { pre[u][k] = temp; temp += c[u][k]; }
                         if (want_llr) L[j0 + u * 64 + lane] = temp;
+                        if (llr_direct && j0 + u * 64 + lane < n) a.llr[b * n + j0 + u * 64 + lane] = temp;  // the last pass's stay
                         const uint64_t word = __ballot(temp <= 0);  // padding bits: prior 1.0, no entries -> 0
                         if (lane == 0) hardw[(j0 >> 6) + u] = word;
                         double sfx = 0.0;
