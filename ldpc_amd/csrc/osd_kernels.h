@@ -796,14 +796,20 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             for (int w = tid; w < HW; w += T) prow[w] = mat[(int64_t)w * m + p];
             __syncthreads();
             const uint8_t psy = sy[p];
-            for (int hI = tid; hI < nh; hI += T) {
+            // one (row, 8 planes) piece per thread: the eight loads are in flight together, and a step with few hit
+            // rows still spreads over the workgroup
+            const int pieces = (HW + 7) >> 3;
+            for (int item = tid; item < nh * pieces; item += T) {
+                const int hI = item / pieces, w0 = (item - hI * pieces) << 3;
                 const int r = hits[hI];
                 if (r == p) continue;
-                for (int w = 0; w < HW; ++w) {
-                    const uint64_t pw = prow[w];
-                    if (pw) mat[(int64_t)w * m + r] ^= pw;
-                }
-                sy[r] ^= psy;
+                uint64_t v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = w0 + q < HW ? mat[(int64_t)(w0 + q) * m + r] : 0ull;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (w0 + q < HW && prow[w0 + q]) mat[(int64_t)(w0 + q) * m + r] = v[q] ^ prow[w0 + q];
+                if (w0 == 0) sy[r] ^= psy;
             }
             if (tid == 0) { pivcol[p] = c; sh_nhits = 0; sh_pivot = INT32_MAX; }
             ++rank;
