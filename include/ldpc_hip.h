@@ -162,9 +162,10 @@ int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
  * when a level holds >= 2 bits on average), 0 = one wavefront walks the tile bit by bit, 1 = always level-parallel. */
 int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
- * bit-packed in LDS while it fits 150 KiB; OSD-0 beyond that: one workgroup per syndrome, H in an HBM scratch slot, as
- * long as the column sort fits LDS, n <= ~11 000; higher-order OSD beyond LDS is LDPC_HIP_ERR_UNSUPPORTED), 0 = LDS,
- * 2 = OSD-0 through the HBM path whatever the size.  Results are identical. */
+ * one wavefront per syndrome with [H | s] bit-packed in LDS while four of them fit a CU, else one workgroup per syndrome
+ * with H in LDS or, beyond 150 KiB, in an HBM scratch slot -- as long as the column order and, for OSD_E / OSD_CS, the
+ * candidate tables fit LDS: OSD-0 n <= ~11 000; otherwise LDPC_HIP_ERR_UNSUPPORTED), 0 = the one-wavefront LDS kernels
+ * while they fit at all, 2 = a workgroup per syndrome with H in HBM whatever the size.  Results are identical. */
 int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode);
 int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
                                 uint8_t *decoding, double *llr, int32_t *iterations,

@@ -1431,7 +1431,9 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
                     : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;
     per_wave = (per_wave + 15) & ~(size_t)15;
-    const bool big0 = !reg0 && !regw && (per_wave > 150u * 1024u || h->osd_big);  // matrix in HBM (osd_big_kernel)  // OSD-0 with the matrix in HBM (osd0_big_kernel)
+    // one workgroup per syndrome (osd_big_kernel: H in LDS if it fits, else in HBM) once the one-wavefront kernels would
+    // leave fewer than four wavefronts on a CU; mode 0 keeps the one-wavefront kernels while they fit at all
+    const bool big0 = !reg0 && !regw && (per_wave > 150u * 1024u || h->osd_big || (h->osd_reg && per_wave > 40u * 1024u));  // OSD-0 with the matrix in HBM (osd0_big_kernel)
     bool host_rank = false;
     if (reg0 || regw || big0) {  // H bit-packed by rows, once per handle
         // rank H bounds the pivots; working it out is a dense elimination on the host, worth it only for moderate sizes
@@ -1479,7 +1481,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         A.kwords = !higher ? 0 : host_rank ? (a.n - a.rank + 63) / 64 : A.hwords;  // planes of T; rank unknown: room for every column
         if (higher && A.kwords < 1) A.kwords = 1;
         // LDS: [keys 8 n | later: pivot columns, hit list, pivot row, syndrome column] [column order 4 pow2]
-        //      higher order: [column info 4 n] [non-pivot columns 4 n] [four T planes 32 m]
+        //      higher order: [column info 4 n] [non-pivot columns 4 n] [four T planes 32 m];  [H: hwords planes of m words, if it fits]
         size_t region0 = (size_t)a.n * 8;
         const size_t after = (size_t)a.m * 4 * 2 + 8 + (size_t)A.hwords * 8 + (size_t)a.m;
         if (after > region0) region0 = after;
@@ -1490,8 +1492,13 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if (lds > 150u * 1024u)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: the column order%s of a %d x %d matrix need%s %zu bytes of LDS, 150 KiB available",
                         higher ? " and the candidate tables" : "", a.m, a.n, higher ? "" : "s", lds);
+        lds = (lds + 15) & ~(size_t)15;
+        const size_t mat_bytes = (size_t)A.hwords * a.m * 8;
+        const bool mat_lds = !h->osd_big && lds + mat_bytes <= 150u * 1024u;
+        if (mat_lds) { A.mat_off = (int32_t)lds; lds += mat_bytes; }
         a.lds_per_wave = (int32_t)region0;
-        A.slot_stride = (int64_t)(A.hwords + A.kwords) * a.m;
+        A.slot_stride = (int64_t)((mat_lds ? 0 : A.hwords) + A.kwords) * a.m;
+        if (A.slot_stride < 1) A.slot_stride = 1;
         int per_cu = (int)((160u * 1024u) / lds);
         if (per_cu > 4) per_cu = 4;
         if (per_cu < 1) per_cu = 1;
@@ -1502,10 +1509,10 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if ((rc = h->osd_scratch.ensure((size_t)slots * (size_t)A.slot_stride * 8))) return rc;
         A.scratch = (uint64_t *)h->osd_scratch.p;
         A.o = a;
-        const void *bfn = higher ? (const void *)osd_big_kernel<true> : (const void *)osd_big_kernel<false>;
-        if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute(bfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (higher) hipLaunchKernelGGL(osd_big_kernel<true>, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
-        else hipLaunchKernelGGL(osd_big_kernel<false>, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
+        void (*bk)(const OsdBigArgs) = higher ? (mat_lds ? osd_big_kernel<true, true> : osd_big_kernel<true, false>)
+                                              : (mat_lds ? osd_big_kernel<false, true> : osd_big_kernel<false, false>);
+        if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bk, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
         HIPCHK(hipGetLastError());
         return LDPC_HIP_OK;
     }

@@ -697,8 +697,8 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
     }
 }
 
-// ---- OSD for matrices beyond LDS: one WORKGROUP per syndrome, [H] in a global scratch slot ---------------------------
-// Same results as osd0_kernel / osdw_kernel.  The working copy of H lives in HBM / L2, word-plane major -- plane w holds
+// ---- OSD with one WORKGROUP per syndrome: [H] in LDS (mid-size matrices) or in a global scratch slot (beyond LDS) ------
+// Same results as osd0_kernel / osdw_kernel.  The working copy of H lives in LDS or in HBM / L2, word-plane major -- plane w holds
 // word w of every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of
 // the pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
 // touched all the time: the column order, the syndrome column, the pivot columns, the pivot row and the hit list.
@@ -715,9 +715,10 @@ struct OsdBigArgs {
     int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
     int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i32, npcol [n] i32, planes [4][m] u64}
+    int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
 };
 
-template <bool HIGHER>
+template <bool HIGHER, bool MAT_LDS>
 __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const OsdArgs &a = A.o;
@@ -737,8 +738,11 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     __shared__ int sh_row, sh_pivot, sh_nhits, sh_cnt[4];
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
-    uint64_t *mat = A.scratch + (int64_t)blockIdx.x * A.slot_stride;
-    uint64_t *Tm = mat + (int64_t)HW * m;  // [kwords][m]
+    // MAT_LDS: the working copy of H fits LDS next to everything else (mid-size matrices: a whole workgroup on one
+    // syndrome where the one-wavefront kernels would leave a CU with one or two wavefronts); the slot then only holds T
+    uint64_t *slot = A.scratch + (int64_t)blockIdx.x * A.slot_stride;
+    uint64_t *mat = MAT_LDS ? reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.mat_off) : slot;
+    uint64_t *Tm = MAT_LDS ? slot : slot + (int64_t)HW * m;  // [kwords][m]
 
     for (;;) {
         if (tid == 0) {

@@ -149,12 +149,14 @@ def test_higher_order_osd_across_null_space_sizes(seed, oracle_built):
             assert np.array_equal(got[3], want[3])
 
 
-def test_osd0_beyond_lds(oracle_built):
-    """A 900 x 1700 matrix: [H | s] is 190 KiB bit-packed, more than LDS holds -- OSD runs with H in an HBM scratch slot."""
+@pytest.mark.parametrize("m,n,kernels", [(900, 1700, (-1,)), (400, 900, (-1, 0, 2))])
+def test_osd_with_a_workgroup_per_syndrome(m, n, kernels, oracle_built):
+    """900 x 1700: [H | s] is 190 KiB bit-packed, more than LDS holds -- OSD runs with H in an HBM scratch slot.
+    400 x 900: it would fit LDS three times, i.e. three wavefronts per CU with the one-wavefront kernels (mode 0) -- the
+    automatic choice is a workgroup per syndrome with H in LDS; mode 2 puts H in HBM.  All against the oracle."""
     from ldpc_amd._lib import LdpcHipError
     from ldpc_amd.engine import HipBpEngine
     rng = np.random.default_rng(99)
-    m, n = 900, 1700
     rows = np.repeat(np.arange(m), 6)
     cols = rng.integers(0, n, size=m * 6)
     h = sp.csr_matrix((np.ones(m * 6, np.uint8), (rows, cols)), shape=(m, n))
@@ -165,18 +167,18 @@ def test_osd0_beyond_lds(oracle_built):
     e = (rng.random((40, n)) < 0.04).astype(np.uint8)
     s = np.ascontiguousarray((h @ e.T % 2).T.astype(np.uint8))
     o = oracle_built.BpOracle(h, error_channel=probs, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.7)
-    want = o.bposd_decode_batch(s, 1, 0)
-    assert not want[3].all(), "the case needs rows that go through OSD"
     eng = HipBpEngine(h.indptr, h.indices, n, probs, 4, 1, 0.7)
-    eng.set_osd(1, 0)
-    got = eng.decode_batch(s, osd=True)
-    assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3])
-    assert not np.any((h @ got[0].T % 2).T != s), "every OSD solution satisfies its syndrome"
-    for osd_method, osd_order in ((3, 6), (2, 5)):
+    for osd_method, osd_order in ((1, 0), (3, 6), (2, 5)):
         want = o.bposd_decode_batch(s, osd_method, osd_order)
+        assert not want[3].all(), "the case needs rows that go through OSD"
         eng.set_osd(osd_method, osd_order)
-        got = eng.decode_batch(s, osd=True)
-        assert np.array_equal(got[0], want[0]), (osd_method, osd_order)
+        for kernel in kernels:
+            eng.set_osd_kernel(kernel)
+            got = eng.decode_batch(s, osd=True)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3]), (osd_method, osd_order, kernel)
+            assert not np.any((h @ got[0].T % 2).T != s), "every OSD solution satisfies its syndrome"
+    if m != 900:
+        return
     # the column order and the candidate tables still live in LDS: a 6000 x 12000 matrix is refused, not mis-decoded
     big = sp.csr_matrix((np.ones(12000, np.uint8), (np.arange(12000) % 6000, np.arange(12000))), shape=(6000, 12000))
     eng = HipBpEngine(big.indptr, big.indices, 12000, np.full(12000, 0.05), 2, 1, 1.0)
