@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
 // Same results as osd0_kernel / osdw_kernel.  The working copy of H lives in LDS or in HBM / L2, word-plane major -- plane w holds
 // word w of every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of
 // the pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
-// touched all the time: the column order, the syndrome column, the pivot columns, the pivot row and the hit list.
+// touched all the time: the column order, the syndrome column, the pivot columns and the hit list.
 // The columns are sorted by a bitonic network over column numbers (comparing (key, number), hence stable).
 // HIGHER (OSD_E / OSD_CS): no early stop; afterwards the reduced rows are compressed to the non-pivot columns (T, again
 // plane-major, behind the matrix in the slot) and the candidates are weighed as in osdw_reg_kernel: thread = candidate,
@@ -730,12 +730,11 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     int32_t *ord = reinterpret_cast<int32_t *>(osd_lds + (size_t)a.lds_per_wave);  // lds_per_wave: bytes before `ord`
     int32_t *pivcol = reinterpret_cast<int32_t *>(osd_lds);            // [m]
     int32_t *hits = pivcol + m;                                        // [m]
-    uint64_t *prow = reinterpret_cast<uint64_t *>(hits + m + (m & 1));  // [HW]
-    uint8_t *sy = reinterpret_cast<uint8_t *>(prow + HW);              // [m]
+    uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m]
     int32_t *colinfo = reinterpret_cast<int32_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
     int32_t *npcol = colinfo + n;                                      // [n] non-pivot columns in sorted order
     uint64_t *planes = reinterpret_cast<uint64_t *>(npcol + n + (n & 1));  // [4][m]
-    __shared__ int sh_row, sh_pivot, sh_nhits, sh_cnt[4];
+    __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
     // MAT_LDS: the working copy of H fits LDS next to everything else (mid-size matrices: a whole workgroup on one
@@ -776,54 +775,61 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 __syncthreads();
             }
         for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }  // (overwrites the keys)
-        if (tid == 0) { sh_nhits = 0; sh_pivot = INT32_MAX; }
+        if (tid < 3) { sh_nhits[tid] = 0; sh_pivot[tid] = INT32_MAX; }
         __syncthreads();
 
+        // One column per step, two barriers when it yields a pivot, one when not.  The hit counter and the pivot slot
+        // exist three times over: step t uses copy t % 3 and, once past its first barrier, re-arms copy (t + 2) % 3,
+        // which nobody has touched since step t - 1 and nobody will before step t + 2.
         int rank = 0;
         for (int t = 0; t < n && rank < A.max_rank; ++t) {
-            const int c = ord[t];
+            const int c = ord[t], cur = t % 3;
             const uint64_t *plane = mat + (int64_t)(c >> 6) * m;
             const uint64_t cb = 1ull << (c & 63);
-            for (int i = tid; i < m; i += T)
+            int pending = 0;
+            for (int i = tid; i < m; i += T) {
+                const bool unpivoted = pivcol[i] < 0;
                 if (plane[i] & cb) {
-                    hits[atomicAdd(&sh_nhits, 1)] = i;
-                    if (pivcol[i] < 0) atomicMin(&sh_pivot, i);
+                    hits[atomicAdd(&sh_nhits[cur], 1)] = i;
+                    if (unpivoted) atomicMin(&sh_pivot[cur], i);
                 }
-            __syncthreads();
-            const int p = sh_pivot, nh = sh_nhits;
-            if (p == INT32_MAX) {  // no unpivoted row has the bit
-                __syncthreads();
-                if (tid == 0) sh_nhits = 0;
-                __syncthreads();
-                continue;
+                if (!HIGHER && unpivoted && sy[i]) pending = 1;
             }
-            for (int w = tid; w < HW; w += T) prow[w] = mat[(int64_t)w * m + p];
-            __syncthreads();
+            if (!HIGHER) {
+                // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383): the test the
+                // reference makes after a pivot is made here before the next one -- the same state
+                if (!__syncthreads_or(pending)) break;
+            } else {
+                __syncthreads();
+            }
+            const int p = sh_pivot[cur], nh = sh_nhits[cur];
+            if (tid == 0) { sh_nhits[(t + 2) % 3] = 0; sh_pivot[(t + 2) % 3] = INT32_MAX; }
+            if (p == INT32_MAX) continue;  // no unpivoted row has the bit
             const uint8_t psy = sy[p];
-            // one (row, 8 planes) piece per thread: the eight loads are in flight together, and a step with few hit
-            // rows still spreads over the workgroup
+            // one (row, 8 planes) piece per thread: the loads are in flight together, and a step with few hit rows
+            // still spreads over the workgroup; the pivot row is read in place (nothing writes it in this step)
             const int pieces = (HW + 7) >> 3;
             for (int item = tid; item < nh * pieces; item += T) {
                 const int hI = item / pieces, w0 = (item - hI * pieces) << 3;
                 const int r = hits[hI];
                 if (r == p) continue;
-                uint64_t v[8];
+                uint64_t v[8], pw[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = w0 + q < HW ? mat[(int64_t)(w0 + q) * m + r] : 0ull;
+                for (int q = 0; q < 8; ++q) {
+                    const bool in = w0 + q < HW;
+                    v[q] = in ? mat[(int64_t)(w0 + q) * m + r] : 0ull;
+                    pw[q] = in ? mat[(int64_t)(w0 + q) * m + p] : 0ull;
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (w0 + q < HW && prow[w0 + q]) mat[(int64_t)(w0 + q) * m + r] = v[q] ^ prow[w0 + q];
+                    if (pw[q]) mat[(int64_t)(w0 + q) * m + r] = v[q] ^ pw[q];
                 if (w0 == 0) sy[r] ^= psy;
             }
-            if (tid == 0) { pivcol[p] = c; sh_nhits = 0; sh_pivot = INT32_MAX; }
+            if (tid == 0) pivcol[p] = c;
             ++rank;
             __syncthreads();
-            if (!HIGHER) {  // stop once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383)
-                int pending = 0;
-                for (int i = tid; i < m; i += T) pending |= (pivcol[i] < 0 && sy[i]) ? 1 : 0;
-                if (!__syncthreads_or(pending)) break;
-            }
         }
+        __syncthreads();
         if (!HIGHER) {
             // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
             for (int j = tid; j < n; j += T) a.decoding[b * n + j] = 0;
@@ -866,7 +872,8 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 uint64_t word = 0;
                 if (pivoted) {
                     const int cnt = k - 64 * v < 64 ? k - 64 * v : 64;
-                    for (int qq = 0; qq < cnt; ++qq) {
+#pragma unroll 8
+                    for (int qq = 0; qq < cnt; ++qq) {  // (unrolled: eight independent loads in flight)
                         const int c = npcol[64 * v + qq];
                         word |= ((mat[(int64_t)(c >> 6) * m + r] >> (c & 63)) & 1ull) << qq;
                     }
