@@ -1488,7 +1488,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         region0 = (region0 + 15) & ~(size_t)15;
         size_t lds = region0 + (size_t)A.pow2 * 4;
         A.extra_off = (int32_t)lds;
-        if (higher) lds += (size_t)a.n * 8 + 8 + (size_t)a.m * 32;
+        if (higher) lds += (size_t)a.n * 8 + 8 + ((size_t)a.m + 1) * 32;
         if (lds > 150u * 1024u)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: the column order%s of a %d x %d matrix need%s %zu bytes of LDS, 150 KiB available",
                         higher ? " and the candidate tables" : "", a.m, a.n, higher ? "" : "s", lds);

@@ -9,9 +9,12 @@ __device__ unsigned long long osd_phase_clocks[8];
 #define OSD_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
                            if (lane == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
 #define OSD_CLK_START() unsigned long long clk_ = __builtin_readcyclecounter()
+#define OSD_WG_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                              if (tid == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
 #else
 #define OSD_CLK(slot) do { } while (0)
 #define OSD_CLK_START() do { } while (0)
+#define OSD_WG_CLK(slot) do { } while (0)
 #endif
 
 // ---- OSD-0 (osd.hpp:110-117 = sort.hpp:48-62 + gf2sparse_linalg.hpp:298-401, 237-288) -------------
@@ -733,7 +736,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m]
     int32_t *colinfo = reinterpret_cast<int32_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
     int32_t *npcol = colinfo + n;                                      // [n] non-pivot columns in sorted order
-    uint64_t *planes = reinterpret_cast<uint64_t *>(npcol + n + (n & 1));  // [4][m]
+    uint64_t *planes = reinterpret_cast<uint64_t *>(npcol + n + (n & 1));  // [4][m + 1] (entry m: the all-zero dummy row)
     __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
@@ -752,6 +755,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         __syncthreads();
         const int64_t b = sh_row;
         if (b < 0) return;
+        OSD_CLK_START();
         // working copy of H, word-plane major (a.packed is row-major with a.words words per row)
         for (int64_t e = tid; e < (int64_t)HW * m; e += T) {
             const int w = (int)(e / m), i = (int)(e - (int64_t)w * m);
@@ -774,6 +778,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 }
                 __syncthreads();
             }
+        OSD_WG_CLK(1);  // copy + sort
         for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }  // (overwrites the keys)
         if (tid < 3) { sh_nhits[tid] = 0; sh_pivot[tid] = INT32_MAX; }
         __syncthreads();
@@ -840,6 +845,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             continue;
         }
 
+        OSD_WG_CLK(2);  // elimination
         // ---- higher order (osd.hpp:119-187) ----
         for (int j = tid; j < n; j += T) colinfo[j] = INT32_MIN;
         __syncthreads();
@@ -865,6 +871,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             __syncthreads();
         }
         const int KW = (k + 63) >> 6;  // <= A.kwords by the host's sizing
+        OSD_WG_CLK(3);  // numbering
         // T: the reduced rows on the non-pivot columns (bit q = the q-th of them), plane v = word v of every row
         for (int r = tid; r < m; r += T) {
             const bool pivoted = pivcol[r] >= 0;
@@ -884,25 +891,42 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         __syncthreads();
         // x_i of a candidate: pivot column with row r: S_r ^ parity(T_r & candidate); q-th non-pivot column: the candidate's bit q.
         // Weights are added in column order (osd.hpp:171-176); `acc += bit ? w : 0.0` adds the same numbers.
+        OSD_WG_CLK(4);  // gather
         const double *wt = a.wt;
-        auto weigh_single = [&](const uint64_t *pl, int q, bool live) -> double {  // candidate: non-pivot column q alone; pl = T plane q / 64
+        // Branch-free, so that the loads of several columns are in flight together: a non-pivot column reads the all-zero
+        // dummy row m and adds its own term; for the one-column candidates S is folded into the staged plane.
+        // (four columns per trip, written out: the compiler does not unroll these loops on request)
+        auto weigh_single = [&](const uint64_t *pl, int q, bool live) -> double {  // candidate: non-pivot column q alone; pl[r] = T plane q / 64 of row r, XOR all-ones if S_r
             double acc = 0;
-            for (int i = 0; i < n; ++i) {
-                const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);  // the same for every lane: a scalar branch
-                bool bit;
-                if (ci >= 0) bit = (((pl[ci] >> (q & 63)) & 1ull) != 0) != (sy[ci] != 0);
-                else bit = live && (-1 - ci) == q;
+            const int sh = q & 63;
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                int ci[4], r[4];
+                uint64_t t[4];
+                double w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);  // the same for every lane
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { r[u] = ci[u] >= 0 ? ci[u] : m; t[u] = pl[r[u]]; w[u] = wt[i + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool bit = (((t[u] >> sh) & 1ull) != 0) || (live && -1 - ci[u] == q);
+                    acc += bit ? w[u] : 0.0;
+                }
+            }
+            for (; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
+                const bool bit = (((pl[ci >= 0 ? ci : m] >> sh) & 1ull) != 0) || (live && -1 - ci == q);
                 acc += bit ? wt[i] : 0.0;
             }
             return acc;
         };
-        auto weigh_mask = [&](const uint64_t *pl0, uint64_t mask) -> double {  // candidate: a set of the first 64 non-pivot columns
+        auto weigh_mask = [&](const uint64_t *pl0, uint64_t mask) -> double {  // candidate: a set of the first 64 non-pivot columns; pl0 = T plane 0
             double acc = 0;
             for (int i = 0; i < n; ++i) {
                 const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
-                bool bit;
-                if (ci >= 0) bit = ((__builtin_popcountll(pl0[ci] & mask) + (int)sy[ci]) & 1) != 0;
-                else bit = (-1 - ci) < 64 && ((mask >> (-1 - ci)) & 1ull) != 0;
+                const int r = ci >= 0 ? ci : m, qn = ci >= 0 ? 64 : -1 - ci;
+                const bool bit = (((__builtin_popcountll(pl0[r] & mask) + (int)sy[r]) & 1) != 0) || (qn < 64 && ((mask >> qn) & 1ull) != 0);
                 acc += bit ? wt[i] : 0.0;
             }
             return acc;
@@ -918,6 +942,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         const long npairs = (long)a.order * (a.order - 1) / 2;
         // plane 0 for the mask candidates and the OSD-0 weight
         for (int r = tid; r < m; r += T) planes[r] = KW > 0 ? Tm[r] : 0ull;
+        if (tid == 0) { planes[m] = 0; sy[m] = 0; }  // the dummy row of the non-pivot columns
         __syncthreads();
         double best_w = weigh_mask(planes, 0);  // the OSD-0 solution (osd.hpp:131-136)
         long best_c = -1;                       // index in the reference's candidate list; -1: the OSD-0 solution
@@ -933,9 +958,10 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             for (int v0 = 0; v0 < KW; v0 += 4) {
                 __syncthreads();
                 const int v = v0 + wave;
-                uint64_t *pl = planes + (size_t)wave * m;
+                uint64_t *pl = planes + (size_t)wave * (m + 1);
                 if (v < KW)
-                    for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)v * m + r];
+                    for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)v * m + r] ^ (sy[r] ? ~0ull : 0ull);
+                if (lane == 0) pl[m] = 0;
                 __syncthreads();
                 const int q = 64 * v + lane;
                 const bool live = v < KW && q < k;
@@ -950,6 +976,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 if (c < total && w < best_w) { best_w = w; best_c = c; }
             }
         }
+        OSD_WG_CLK(5);  // weighing
         // lightest, then earliest: across the lanes of a wavefront, then across the wavefronts
         for (int off = 32; off > 0; off >>= 1) {
             const double ow = __shfl_xor(best_w, off);

@@ -16,12 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 DBG = os.path.join(ROOT, "tools", "_dbg", "libldpc_hip.so")
 PHASES = ["load rows", "sort columns", "eliminate", "number non-pivot columns", "gather reduced rows", "weigh candidates", "pick + write"]
+# (the workgroup kernel reports: slot 1 copy + sort, 2 elimination, 3 numbering, 4 gather, 5 weighing)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--bb", action="store_true")
+    ap.add_argument("--hgp1600", action="store_true", help="the [[1600,64]] code of bench_configs.py: workgroup kernel, H in HBM")
     ap.add_argument("--order", type=int, default=10)
     args = ap.parse_args()
     if args.build:
@@ -36,7 +38,12 @@ def main():
     from ldpc_amd import codes
     import scipy.sparse as sp
     import torch
-    if args.bb:
+    if args.hgp1600:
+        h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
+        h = sp.hstack([sp.kron(h1, sp.identity(32, dtype=np.uint8)), sp.kron(sp.identity(24, dtype=np.uint8), h1.T)]).tocsr().astype(np.uint8)
+        h.sort_indices()
+        p, it, method, alpha = 0.02, 30, 1, 0.625
+    elif args.bb:
         h, p, it, method, alpha = codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0
     else:
         z = np.load(os.path.join(ROOT, "tests", "golden", "qcodes_400_16_6_ms_par_osd0.npz"))
