@@ -305,6 +305,17 @@ def test_streamed_parallel_schedule_repacks_from_the_previous_histogram(oracle_b
     for tag in ("steered", "fixed", "off"):
         for a, b in zip(runs["first"], runs[tag]):
             assert bits_equal(a, b) if a.dtype == np.float64 else np.array_equal(a, b), tag
+    # without log-ratios, in chunks of 200 tiles, and through the bit-packed entry point: the same decisions
+    eng.set_repack(-1)
+    lean = eng.decode_batch(s, want_llr=False)
+    assert lean[1] is None and np.array_equal(lean[0].cpu().numpy(), runs["first"][0]) and np.array_equal(lean[2].cpu().numpy(), runs["first"][2])
+    eng.set_tuning(max_chunk_tiles=200)
+    chunked = eng.decode_batch(s)
+    eng.set_tuning(max_chunk_tiles=0)
+    assert np.array_equal(chunked[0].cpu().numpy(), runs["first"][0]) and bits_equal(chunked[1].cpu().numpy(), runs["first"][1])
+    eng.set_observables(sp.identity(n, dtype=np.uint8, format="csr")[:16])
+    obs, packed, it8, cv8 = eng.decode_b8(eng.pack_b8(s), want_decoding=True)
+    assert np.array_equal(eng.unpack_b8(packed, n).cpu().numpy(), runs["first"][0]) and np.array_equal(it8.cpu().numpy(), runs["first"][2])
     conv = runs["first"][3].astype(bool)
     assert 0.8 < conv.mean() < 0.999 and runs["first"][2][conv].mean() < 8, "the case is meant to converge early, with stragglers"
     assert runs["steered_ms"] < 0.8 * runs["first_ms"], (runs["first_ms"], runs["steered_ms"], conv.mean())
