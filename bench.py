@@ -51,6 +51,7 @@ def main() -> None:
     ap.add_argument("--handoff", type=int, default=-1, help="straggler hand-off threshold in tiles (-1 auto, 0 off; diagnostic)")
     ap.add_argument("--ring", type=int, default=1, help="LDS-DMA ring: 0 = register-prefetch variant, 1 = default depth, 2/3 = depth (diagnostic)")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
+    ap.add_argument("--repack", type=int, default=-1, help="first-pass iterations of the repacked schedule (-1 = steered by the previous decode, 0 = off; diagnostic)")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +88,7 @@ def main() -> None:
     eng.set_math(args.math)
     eng.set_ring(args.ring)
     eng.set_handoff(args.handoff)
+    eng.set_repack(args.repack)
 
     # inputs resident in HBM before the timed region; this rank's shard of the global shot stream
     synd = eng.gen_bsc_syndromes(7, args.p, shot0=rank * B, shots=B, device=dev)
