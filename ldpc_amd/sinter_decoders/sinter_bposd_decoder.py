@@ -68,8 +68,15 @@ def decode_b8_files(check_matrix, priors, observables_matrix, *, num_shots: int,
     eng.close()
 
 
-class SinterBpOsdDecoder:
-    """Constructor keywords and defaults of the reference class (sinter_bposd_decoder.py:37-56)."""
+try:  # pragma: no cover - sinter is not part of this image
+    from sinter import Decoder as _SinterDecoder
+except ImportError:
+    _SinterDecoder = object
+
+
+class SinterBpOsdDecoder(_SinterDecoder):
+    """Constructor keywords and defaults of the reference class (sinter_bposd_decoder.py:37-56); a ``sinter.Decoder``
+    when sinter is installed, a plain class with the same methods otherwise."""
 
     def __init__(self, max_iter=0, bp_method="ms", ms_scaling_factor=0.625, schedule="parallel", omp_thread_count=1,
                  serial_schedule_order=None, osd_method="osd0", osd_order=0):
@@ -82,15 +89,36 @@ class SinterBpOsdDecoder:
         self.osd_method = osd_method
         self.osd_order = osd_order
 
+    def _configure(self, dem_path):
+        """``self.matrices`` and ``self.bposd`` as the reference sets them (:97-113); the model text is read without stim."""
+        from ldpc_amd.bposd_decoder import BpOsdDecoder
+        from ldpc_amd.ckt_noise.dem_matrices import detector_error_model_to_check_matrices
+        self.matrices = detector_error_model_to_check_matrices(pathlib.Path(dem_path), allow_undecomposed_hyperedges=True)
+        self.bposd = BpOsdDecoder(self.matrices.check_matrix, error_channel=list(self.matrices.priors), max_iter=self.max_iter,
+                                  bp_method=self.bp_method, ms_scaling_factor=self.ms_scaling_factor, schedule=self.schedule,
+                                  omp_thread_count=self.omp_thread_count, serial_schedule_order=self.serial_schedule_order,
+                                  osd_method=self.osd_method, osd_order=self.osd_order)
+
     def decode_via_files(self, *, num_shots: int, num_dets: int, num_obs: int, dem_path: pathlib.Path,
                          dets_b8_in_path: pathlib.Path, obs_predictions_b8_out_path: pathlib.Path, tmp_dir: pathlib.Path) -> None:
-        if self.schedule != "parallel":
-            raise NotImplementedError("the packed-shot path runs the parallel schedule")
-        from ldpc_amd.ckt_noise.dem_matrices import detector_error_model_to_check_matrices  # reads the .dem text itself
-        mats = detector_error_model_to_check_matrices(pathlib.Path(dem_path), allow_undecomposed_hyperedges=True)
+        self._configure(dem_path)
+        mats = self.matrices
         if mats.check_matrix.shape[0] != num_dets or mats.observables_matrix.shape[0] != num_obs:
             raise ValueError("detector error model does not match num_dets / num_obs")
-        decode_b8_files(mats.check_matrix, list(mats.priors), mats.observables_matrix, num_shots=num_shots,
-                        dets_b8_in_path=dets_b8_in_path, obs_predictions_b8_out_path=obs_predictions_b8_out_path,
-                        max_iter=self.max_iter, bp_method=self.bp_method, ms_scaling_factor=self.ms_scaling_factor,
-                        osd_method=self.osd_method, osd_order=self.osd_order)
+        if self.schedule == "parallel":  # the packed file goes to the device as it is
+            decode_b8_files(mats.check_matrix, list(mats.priors), mats.observables_matrix, num_shots=num_shots,
+                            dets_b8_in_path=dets_b8_in_path, obs_predictions_b8_out_path=obs_predictions_b8_out_path,
+                            max_iter=self.max_iter, bp_method=self.bp_method, ms_scaling_factor=self.ms_scaling_factor,
+                            osd_method=self.osd_method, osd_order=self.osd_order)
+            return
+        # other schedules: unpack on the host, one decode_batch, pack the predictions (reference :115-126, shot by shot there)
+        import scipy.sparse as sp
+        shots = np.unpackbits(read_b8(dets_b8_in_path, num_dets, num_shots), axis=1, bitorder="little", count=num_dets)
+        corr = self.bposd.decode_batch(np.ascontiguousarray(shots), want_log_prob_ratios=False)
+        predictions = np.asarray((sp.csr_matrix(mats.observables_matrix) @ corr.T.astype(np.int64)) % 2).T.astype(np.uint8)
+        write_b8(obs_predictions_b8_out_path, np.packbits(predictions, axis=1, bitorder="little"))
+
+    def decode(self, syndrome: np.ndarray) -> np.ndarray:
+        """One shot, after ``decode_via_files`` has configured the decoder (reference :128-130)."""
+        corr = self.bposd.decode(syndrome)
+        return (self.matrices.observables_matrix @ corr) % 2

@@ -84,6 +84,18 @@ def test_sinter_adaptors_through_files(tmp_path):
         dets_b8_in_path=tmp_path / "single.b8", obs_predictions_b8_out_path=tmp_path / "single_out.b8", tmp_dir=tmp_path)
     got = np.fromfile(tmp_path / "single_out.b8", np.uint8).reshape(len(single["shots"]), -1)
     assert np.array_equal(got, np.packbits(single["predictions"], axis=1, bitorder="little"))
+    # ... and keeps the configured decoder for single shots (reference :128-130); a serial schedule takes the unpacked route
+    plain = SinterBpOsdDecoder(max_iter=single["cfg"]["max_iter"], bp_method="minimum_sum", ms_scaling_factor=1.0)
+    kw1 = dict(num_shots=len(single["shots"]), num_dets=single["shots"].shape[1], num_obs=1, dem_path=tmp_path / "single.dem",
+               dets_b8_in_path=tmp_path / "single.b8", tmp_dir=tmp_path)
+    plain.decode_via_files(obs_predictions_b8_out_path=tmp_path / "p.b8", **kw1)
+    for b in (0, 3, 17):
+        assert np.array_equal(np.asarray(plain.decode(single["shots"][b].copy())).astype(bool), single["predictions"][b])
+    serial = SinterBpOsdDecoder(max_iter=single["cfg"]["max_iter"], bp_method="minimum_sum", ms_scaling_factor=1.0, schedule="serial")
+    serial.decode_via_files(obs_predictions_b8_out_path=tmp_path / "s.b8", **kw1)
+    out = np.unpackbits(np.fromfile(tmp_path / "s.b8", np.uint8).reshape(len(single["shots"]), -1), axis=1, bitorder="little", count=1)
+    for b in (0, 3, 17, 40):
+        assert np.array_equal(out[b], np.asarray(serial.decode(single["shots"][b].copy())).astype(np.uint8))
 
 
 def test_window_columns_are_compressed_and_priors_above_one_half_survive(oracle_built):
