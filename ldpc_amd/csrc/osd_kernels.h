@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
             return (v & 1ull) != 0;
         }
         const int q = -1 - cdi;
-        return (q < 64 && ((cd.mask >> q) & 1ull)) || q == cd.single;
+        return (q < 64 && ((cd.mask >> (q & 63)) & 1ull)) || q == cd.single;  // (q & 63: the shift is defined whichever way the test is compiled)
     };
     auto weight_of = [&](const OsdCandidate &cd) -> double {
         double acc = 0;
@@ -926,7 +926,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             for (int i = 0; i < n; ++i) {
                 const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
                 const int r = ci >= 0 ? ci : m, qn = ci >= 0 ? 64 : -1 - ci;
-                const bool bit = (((__builtin_popcountll(pl0[r] & mask) + (int)sy[r]) & 1) != 0) || (qn < 64 && ((mask >> qn) & 1ull) != 0);
+                const bool bit = (((__builtin_popcountll(pl0[r] & mask) + (int)sy[r]) & 1) != 0) || (qn < 64 && ((mask >> (qn & 63)) & 1ull) != 0);
                 acc += bit ? wt[i] : 0.0;
             }
             return acc;
@@ -1009,7 +1009,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                              : (((__builtin_popcountll(tw & win) + (int)sy[ci]) & 1) != 0);
             } else {
                 const int q = -1 - ci;
-                bit = single ? q == (int)best_c : (q < 64 && ((win >> q) & 1ull) != 0);
+                bit = single ? q == (int)best_c : (q < 64 && ((win >> (q & 63)) & 1ull) != 0);
             }
             a.decoding[b * n + j] = bit ? 1 : 0;
         }
