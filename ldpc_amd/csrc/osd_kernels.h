@@ -922,11 +922,32 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             return acc;
         };
         auto weigh_mask = [&](const uint64_t *pl0, uint64_t mask) -> double {  // candidate: a set of the first 64 non-pivot columns; pl0 = T plane 0
+            // (bitwise, not `||`: with the short-circuit form and four columns per trip this compiler drops the weight of
+            // the lanes whose bit comes from the second term)
             double acc = 0;
-            for (int i = 0; i < n; ++i) {
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                int ci[4], r[4];
+                uint64_t t[4];
+                unsigned sv[4];
+                double w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { r[u] = ci[u] >= 0 ? ci[u] : m; t[u] = pl0[r[u]]; sv[u] = sy[r[u]]; w[u] = wt[i + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qn = ci[u] >= 0 ? 64 : -1 - ci[u];
+                    const unsigned own = (unsigned)((mask >> (qn & 63)) & 1ull) & (qn < 64 ? 1u : 0u);
+                    const unsigned bit = (((unsigned)__builtin_popcountll(t[u] & mask) + sv[u]) & 1u) | own;
+                    acc += bit ? w[u] : 0.0;
+                }
+            }
+            for (; i < n; ++i) {
                 const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
                 const int r = ci >= 0 ? ci : m, qn = ci >= 0 ? 64 : -1 - ci;
-                const bool bit = (((__builtin_popcountll(pl0[r] & mask) + (int)sy[r]) & 1) != 0) || (qn < 64 && ((mask >> (qn & 63)) & 1ull) != 0);
+                const unsigned own = (unsigned)((mask >> (qn & 63)) & 1ull) & (qn < 64 ? 1u : 0u);
+                const unsigned bit = (((unsigned)__builtin_popcountll(pl0[r] & mask) + (unsigned)sy[r]) & 1u) | own;
                 acc += bit ? wt[i] : 0.0;
             }
             return acc;
