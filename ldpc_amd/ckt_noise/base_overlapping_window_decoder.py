@@ -80,8 +80,16 @@ class BaseOverlappingWindowDecoder:
 
     # ---- a batch of shots (:139-214) ------------------------------------------------------------------------------
     def decode_batch(self, shots: np.ndarray, *, bit_packed_shots: bool = False, bit_packed_predictions: bool = False) -> np.ndarray:
-        if bit_packed_shots:
-            shots = np.unpackbits(shots, axis=1, bitorder="little")[:, : self.num_detectors]
+        if bit_packed_shots:  # the packed rows cross PCIe (1/8 of the bytes) and are unpacked on the device
+            import torch
+            packed = np.ascontiguousarray(shots, dtype=np.uint8)
+            if packed.ndim != 2 or packed.shape[1] != (self.num_detectors + 7) // 8:
+                raise ValueError(f"bit-packed shots must have shape (num_shots, {(self.num_detectors + 7) // 8})")
+            if packed.shape[0]:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                shots = self._observables_engine().unpack_b8(torch.from_numpy(packed).to(dev), self.num_detectors)
+            else:
+                shots = np.zeros((0, self.num_detectors), np.uint8)
         total, synd = self._corr_on_device(shots)
         if not bit_packed_shots and total is not None and isinstance(shots, np.ndarray) and shots.dtype == np.uint8:
             shots[...] = synd.cpu().numpy()  # as in the reference, the caller's unpacked shots end up updated (:208)
@@ -131,14 +139,16 @@ class BaseOverlappingWindowDecoder:
         """The window loop (:189-214) with every array resident on the GPU: (corrections, updated syndromes) as tensors."""
         import torch
         plan = self._window_plan()
-        host = np.asarray(shots)
-        if host.ndim != 2 or host.shape[1] != self.num_detectors:
+        if tuple(shots.shape[1:]) != (self.num_detectors,):
             raise ValueError(f"shots must have shape (num_shots, {self.num_detectors})")
-        num_shots, num_errors = host.shape[0], self.dcm.shape[1]
+        num_shots, num_errors = shots.shape[0], self.dcm.shape[1]
         if num_shots == 0:
             return None, None
-        dev = torch.device("cuda", torch.cuda.current_device())
-        synd = torch.from_numpy(np.ascontiguousarray(host.astype(np.uint8, copy=False))).to(dev)
+        if isinstance(shots, torch.Tensor):  # already on the device (bit-packed input): worked on in place
+            synd, dev = shots, shots.device
+        else:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            synd = torch.from_numpy(np.ascontiguousarray(np.asarray(shots).astype(np.uint8, copy=False))).to(dev)
         total = torch.zeros((num_shots, num_errors), dtype=torch.uint8, device=dev)
         for decoding, (commit_inds, dec_inds, synd_dec_inds, decoder) in enumerate(plan):
             corr = decoder.decode_batch(synd[:, synd_dec_inds].contiguous(), want_log_prob_ratios=False)

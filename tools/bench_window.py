@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--shots", type=int, default=32768)
     ap.add_argument("--p", type=float, default=0.003)
     ap.add_argument("--cpu", type=int, default=0)
+    ap.add_argument("--packed", action="store_true", help="bit-packed shots in, bit-packed predictions out (sinter's decode_shots_bit_packed)")
     ap.add_argument("--windowing", default="3,6,3", help="decodings,window,commit (12 rounds in all)")
     ap.add_argument("--bp-method", default="minimum_sum")
     ap.add_argument("--small-mode", type=int, default=None, help="ldpc_hip_bp_set_small_code_kernel for every window engine")
@@ -44,11 +45,19 @@ def main():
         for d in dec._decoders.values():
             d.inner._get_engine().set_small_code_kernel(args.small_mode)
         dec.decode_batch(shots[:256].copy())
-    t0 = time.perf_counter()
-    preds = dec.decode_batch(shots.copy())
-    dt = time.perf_counter() - t0
+    if args.packed:
+        packed = np.packbits(shots, axis=1, bitorder="little")
+        t0 = time.perf_counter()
+        preds = dec.decode_batch(packed, bit_packed_shots=True, bit_packed_predictions=True)
+        dt = time.perf_counter() - t0
+        preds = np.unpackbits(preds, axis=1, bitorder="little", count=obs.shape[0]).astype(bool)
+    else:
+        work = shots.copy()
+        t0 = time.perf_counter()
+        preds = dec.decode_batch(work)
+        dt = time.perf_counter() - t0
     out = {"config": f"BB144 x {rounds} rounds, {decodings} windows of {window} committing {commit}, min_sum 30 it + OSD-0, p={args.p}",
-           "shots": args.shots, "detectors": check.shape[0], "errors": check.shape[1],
+           "shots": args.shots, "packed_io": bool(args.packed), "detectors": check.shape[0], "errors": check.shape[1],
            "window_columns": [int(len(d.cols)) for d in dec._decoders.values()],
            "small_mode": args.small_mode, "bp_method": args.bp_method, "mean_iterations": [float(d.inner.iter_batch.float().mean()) for d in dec._decoders.values()], "bp_kernel_ms": [d.inner._get_engine().last_kernel_ms() for d in dec._decoders.values()], "shots_per_s": args.shots / dt, "seconds": dt, "flipped_observables": int(preds.sum())}
     if args.cpu:
