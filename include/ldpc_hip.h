@@ -164,7 +164,7 @@ int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
  * one wavefront per syndrome with [H | s] bit-packed in LDS while four of them fit a CU, else one workgroup per syndrome
  * with H in LDS or, beyond 150 KiB, in an HBM scratch slot -- as long as the column order and, for OSD_E / OSD_CS, the
- * candidate tables fit LDS: OSD-0 n <= ~11 000; otherwise LDPC_HIP_ERR_UNSUPPORTED), 0 = the one-wavefront LDS kernels
+ * candidate tables fit LDS: OSD-0 n <= ~14 000; otherwise LDPC_HIP_ERR_UNSUPPORTED), 0 = the one-wavefront LDS kernels
  * while they fit at all, 2 = a workgroup per syndrome with H in HBM whatever the size.  Results are identical. */
 int ldpc_hip_bp_set_osd_kernel(ldpc_hip_bp *h, int32_t mode);
 int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,

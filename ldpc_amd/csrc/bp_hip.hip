@@ -1480,15 +1480,18 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         A.max_rank = a.rank;
         A.kwords = !higher ? 0 : host_rank ? (a.n - a.rank + 63) / 64 : A.hwords;  // planes of T; rank unknown: room for every column
         if (higher && A.kwords < 1) A.kwords = 1;
-        // LDS: [keys 8 n | later: pivot columns, hit list, pivot row, syndrome column] [column order 4 pow2]
-        //      higher order: [column info 4 n] [non-pivot columns 4 n] [four T planes 32 m];  [H: hwords planes of m words, if it fits]
+        // LDS: [keys 8 n | later: pivot columns 2 m, hit list 2 m, syndrome column m + 1] [column order 2 pow2]
+        //      higher order: [column info 2 n] [non-pivot columns 2 n] [four T planes 32 (m + 1)];  [H: hwords planes of m words, if it fits]
+        if (a.m > 32767 || a.n > 32767)
+            return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: %d x %d is beyond the 16-bit row / column tables of the workgroup kernel", a.m, a.n);
         size_t region0 = (size_t)a.n * 8;
-        const size_t after = (size_t)a.m * 4 * 2 + 8 + (size_t)A.hwords * 8 + (size_t)a.m;
+        const size_t after = (size_t)a.m * 5 + 1;
         if (after > region0) region0 = after;
         region0 = (region0 + 15) & ~(size_t)15;
-        size_t lds = region0 + (size_t)A.pow2 * 4;
+        size_t lds = region0 + (size_t)A.pow2 * 2;
+        lds = (lds + 7) & ~(size_t)7;
         A.extra_off = (int32_t)lds;
-        if (higher) lds += (size_t)a.n * 8 + 8 + ((size_t)a.m + 1) * 32;
+        if (higher) lds = ((lds + 4 * (size_t)a.n + 7) & ~(size_t)7) + ((size_t)a.m + 1) * 32;
         if (lds > 150u * 1024u)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: the column order%s of a %d x %d matrix need%s %zu bytes of LDS, 150 KiB available",
                         higher ? " and the candidate tables" : "", a.m, a.n, higher ? "" : "s", lds);

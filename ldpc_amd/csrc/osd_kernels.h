@@ -717,7 +717,7 @@ struct OsdBigArgs {
     int32_t pow2;           // bitonic size: smallest power of two >= n
     int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
-    int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i32, npcol [n] i32, planes [4][m] u64}
+    int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i16, npcol [n] u16, (8-aligned) planes [4][m + 1] u64}
     int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
 };
 
@@ -730,13 +730,14 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     const int m = a.m, n = a.n, HW = A.hwords, P = A.pow2;
     // during the sort: keys [n] u64, then ord [P] i32.  Afterwards the keys' room is reused.
     uint64_t *keys = reinterpret_cast<uint64_t *>(osd_lds);
-    int32_t *ord = reinterpret_cast<int32_t *>(osd_lds + (size_t)a.lds_per_wave);  // lds_per_wave: bytes before `ord`
-    int32_t *pivcol = reinterpret_cast<int32_t *>(osd_lds);            // [m]
-    int32_t *hits = pivcol + m;                                        // [m]
-    uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m]
-    int32_t *colinfo = reinterpret_cast<int32_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
-    int32_t *npcol = colinfo + n;                                      // [n] non-pivot columns in sorted order
-    uint64_t *planes = reinterpret_cast<uint64_t *>(npcol + n + (n & 1));  // [4][m + 1] (entry m: the all-zero dummy row)
+    // (16-bit tables: m, n < 32768 here -- the host checks --, and the LDS they save is a third resident workgroup)
+    uint16_t *ord = reinterpret_cast<uint16_t *>(osd_lds + (size_t)a.lds_per_wave);  // lds_per_wave: bytes before `ord`
+    int16_t *pivcol = reinterpret_cast<int16_t *>(osd_lds);            // [m]
+    uint16_t *hits = reinterpret_cast<uint16_t *>(pivcol + m);         // [m]
+    uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m + 1]
+    int16_t *colinfo = reinterpret_cast<int16_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
+    uint16_t *npcol = reinterpret_cast<uint16_t *>(colinfo + n);       // [n] non-pivot columns in sorted order
+    uint64_t *planes = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 4 * (size_t)n + 7) & ~(size_t)7));  // [4][m + 1] (entry m: the all-zero dummy row)
     __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
@@ -762,7 +763,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             mat[e] = a.packed[(size_t)i * a.words + w];
         }
         for (int j = tid; j < n; j += T) keys[j] = osd_sort_key(a.llr[b * n + j]);
-        for (int j = tid; j < P; j += T) ord[j] = j;
+        for (int j = tid; j < P; j += T) ord[j] = (uint16_t)j;
         __syncthreads();
         // soft_decision_col_sort (sort.hpp:48-62): ascending key, ties by column number; numbers >= n pad the network
         for (int k = 2; k <= P; k <<= 1)
@@ -773,7 +774,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                         const int x = ord[i], y = ord[l];
                         const uint64_t kx = x < n ? keys[x] : ~0ull, ky = y < n ? keys[y] : ~0ull;
                         const bool y_first = ky < kx || (ky == kx && y < x);
-                        if (y_first == ((i & k) == 0)) { ord[i] = y; ord[l] = x; }
+                        if (y_first == ((i & k) == 0)) { ord[i] = (uint16_t)y; ord[l] = (uint16_t)x; }
                     }
                 }
                 __syncthreads();
@@ -795,7 +796,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             for (int i = tid; i < m; i += T) {
                 const bool unpivoted = pivcol[i] < 0;
                 if (plane[i] & cb) {
-                    hits[atomicAdd(&sh_nhits[cur], 1)] = i;
+                    hits[atomicAdd(&sh_nhits[cur], 1)] = (uint16_t)i;
                     if (unpivoted) atomicMin(&sh_pivot[cur], i);
                 }
                 if (!HIGHER && unpivoted && sy[i]) pending = 1;
@@ -830,7 +831,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                     if (pw[q]) mat[(int64_t)(w0 + q) * m + r] = v[q] ^ pw[q];
                 if (w0 == 0) sy[r] ^= psy;
             }
-            if (tid == 0) pivcol[p] = c;
+            if (tid == 0) pivcol[p] = (int16_t)c;
             ++rank;
             __syncthreads();
         }
@@ -847,16 +848,16 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
 
         OSD_WG_CLK(2);  // elimination
         // ---- higher order (osd.hpp:119-187) ----
-        for (int j = tid; j < n; j += T) colinfo[j] = INT32_MIN;
+        for (int j = tid; j < n; j += T) colinfo[j] = INT16_MIN;
         __syncthreads();
         for (int i = tid; i < m; i += T)
-            if (pivcol[i] >= 0) colinfo[pivcol[i]] = i;
+            if (pivcol[i] >= 0) colinfo[pivcol[i]] = (int16_t)i;
         __syncthreads();
         int k = 0;  // non-pivot columns in sorted order (`cols[rank ..]`, gf2sparse_linalg.hpp:210-224)
         for (int t0 = 0; t0 < n; t0 += T) {
             const int t = t0 + tid;
             const int c = t < n ? ord[t] : 0;
-            const bool np = t < n && colinfo[c] == INT32_MIN;
+            const bool np = t < n && colinfo[c] == INT16_MIN;
             const uint64_t mask = __ballot(np);
             if (lane == 0) sh_cnt[wave] = __builtin_popcountll(mask);
             __syncthreads();
@@ -864,8 +865,8 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             for (int w = 0; w < 4; ++w) { before += w < wave ? sh_cnt[w] : 0; total += sh_cnt[w]; }
             if (np) {
                 const int q = k + before + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                colinfo[c] = -1 - q;
-                npcol[q] = c;
+                colinfo[c] = (int16_t)(-1 - q);
+                npcol[q] = (uint16_t)c;
             }
             k += total;
             __syncthreads();

@@ -179,11 +179,11 @@ def test_osd_with_a_workgroup_per_syndrome(m, n, kernels, oracle_built):
             assert not np.any((h @ got[0].T % 2).T != s), "every OSD solution satisfies its syndrome"
     if m != 900:
         return
-    # the column order and the candidate tables still live in LDS: a 6000 x 12000 matrix is refused, not mis-decoded
-    big = sp.csr_matrix((np.ones(12000, np.uint8), (np.arange(12000) % 6000, np.arange(12000))), shape=(6000, 12000))
-    eng = HipBpEngine(big.indptr, big.indices, 12000, np.full(12000, 0.05), 2, 1, 1.0)
+    # the column order and the candidate tables still live in LDS: a 10000 x 20000 matrix is refused, not mis-decoded
+    big = sp.csr_matrix((np.ones(20000, np.uint8), (np.arange(20000) % 10000, np.arange(20000))), shape=(10000, 20000))
+    eng = HipBpEngine(big.indptr, big.indices, 20000, np.full(20000, 0.05), 2, 1, 1.0)
     eng.set_osd(1, 0)
-    s_big = np.zeros((2, 6000), np.uint8)
+    s_big = np.zeros((2, 10000), np.uint8)
     s_big[:, 5] = 3  # a byte > 1 never converges, so both rows reach OSD
     with pytest.raises(LdpcHipError, match="150 KiB available"):
         eng.decode_batch(s_big, osd=True)
