@@ -4,6 +4,7 @@ with the oracle on a random subset, invariance under the kernel family, and for 
 its syndrome.  Everything stays in HBM; only flags and small samples come back."""
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
 
@@ -95,3 +96,21 @@ def test_config5_full_batch_osd_orders(oracle_built):
     rows = np.random.default_rng(3).choice(8192, 600, replace=False)
     want = oracle_built.BpOracle(h, error_rate=0.05, max_iter=50).bposd_decode_batch(synd.cpu().numpy()[rows], 3, 10)
     assert np.array_equal(d1.cpu().numpy()[rows], want[0])
+
+
+def test_config2_code_with_osd0(oracle_built):
+    """BP + OSD-0 on the headline code itself (5000 x 10000: [H | s] is 980 KiB per syndrome, the elimination runs with H
+    in an HBM scratch slot): a few syndromes against the oracle, and every OSD solution satisfies its syndrome."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(codes.regular_ldpc_code(10000, 3, 6, seed=1))
+    m, n = h.shape
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.09), 5, 0, 1.0)
+    s = eng.gen_bsc_syndromes(3, 0.09, shot0=0, shots=6, device="cuda:0").cpu().numpy()
+    eng.set_osd(1, 0)
+    dec, _, it, cv = eng.decode_batch(s, want_llr=False, osd=True)
+    assert not cv.any(), "five iterations at p = 0.09 leave everything to OSD"
+    assert not np.any((h @ dec.T % 2).T != s)
+    o = oracle_built.BpOracle(h, error_rate=0.09, max_iter=5, bp_method="product_sum")
+    want = o.bposd_decode_batch(s[:2], 1, 0, want_llr=False)
+    assert np.array_equal(dec[:2], want[0])
