@@ -115,3 +115,28 @@ def test_window_columns_are_compressed_and_priors_above_one_half_survive(oracle_
     assert len(dec._decoders[0].cols) < check.shape[1] and len(dec._decoders[0].static_ones) > 0
     assert np.array_equal(got_c, want_c) and np.array_equal(got_s, want_s)
     assert np.array_equal(dec.decode_batch(shots.copy()), want_p)
+
+
+def test_bench_model_against_the_checker(oracle_built, capsys):
+    """The model tools/bench_window.py times (BB144 x 12 rounds, 3 windows of 6 committing 3): 100 shots against the
+    shot-by-shot checker, whose pace is printed (pytest -s) -- the CPU figure quoted next to the device's in DESIGN.md."""
+    import time
+    from oracle.window_oracle import WindowOracle
+    from ldpc_amd import codes
+    from ldpc_amd.ckt_noise import BpOsdOverlappingWindowDecoder
+    h = codes.bivariate_bicycle_hx()
+    text = phenomenological_dem(h, 12, 0.003, 0.003, logical=tuple(range(12)))
+    check, obs, pri = phenomenological_matrices(h, 12, 0.003, 0.003, logical=tuple(range(12)))
+    shots, _ = sample_shots(check, pri, 100, seed=11)
+    cfg = dict(max_iter=30, bp_method="minimum_sum", ms_scaling_factor=0.625)
+    w = WindowOracle(check, obs, pri, decodings=3, window=6, commit=3, num_checks=h.shape[0], **cfg)
+    t0 = time.perf_counter()
+    want = w.decode_batch(shots)[0]
+    pace = len(shots) / (time.perf_counter() - t0)
+    dec = BpOsdOverlappingWindowDecoder(text, decodings=3, window=6, commit=3, num_checks=h.shape[0], decoder_config=cfg)
+    assert np.array_equal(dec.decode_batch(shots.copy()), want)
+    packed = dec.decode_batch(np.packbits(shots, axis=1, bitorder="little"), bit_packed_shots=True, bit_packed_predictions=True)
+    assert np.array_equal(packed, np.packbits(want, axis=1, bitorder="little"))
+    with capsys.disabled():
+        print(f"\n[window checker, inner decodes by {w.inner}: {pace:.0f} shots/s on one core]")
+

@@ -4,7 +4,8 @@
 Model: BB [[144,12,12]] hx measured for 12 rounds with phenomenological noise (tests/window_util.py), 3 windows of 6
 rounds committing 3 (864 detectors x 2520 errors; a window is 432 x ~1370 after dropping untouched columns), min-sum
 30 iterations + OSD-0 (the reference's defaults, ckt_noise/config.py).  Host arrays in, predictions out, so the figure
-includes the PCIe copies.  --cpu N also times the shot-by-shot checker (real reference BP+OSD inside) on N shots.
+includes the PCIe copies.  (The same model is checked against the shot-by-shot checker, and that loop timed, in
+tests/test_ckt_noise_gpu.py::test_bench_model_against_the_checker.)
 """
 import argparse
 import json
@@ -23,7 +24,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shots", type=int, default=32768)
     ap.add_argument("--p", type=float, default=0.003)
-    ap.add_argument("--cpu", type=int, default=0)
     ap.add_argument("--packed", action="store_true", help="bit-packed shots in, bit-packed predictions out (sinter's decode_shots_bit_packed)")
     ap.add_argument("--windowing", default="3,6,3", help="decodings,window,commit (12 rounds in all)")
     ap.add_argument("--bp-method", default="minimum_sum")
@@ -60,14 +60,6 @@ def main():
            "shots": args.shots, "packed_io": bool(args.packed), "detectors": check.shape[0], "errors": check.shape[1],
            "window_columns": [int(len(d.cols)) for d in dec._decoders.values()],
            "small_mode": args.small_mode, "bp_method": args.bp_method, "mean_iterations": [float(d.inner.iter_batch.float().mean()) for d in dec._decoders.values()], "bp_kernel_ms": [d.inner._get_engine().last_kernel_ms() for d in dec._decoders.values()], "shots_per_s": args.shots / dt, "seconds": dt, "flipped_observables": int(preds.sum())}
-    if args.cpu:
-        from oracle.window_oracle import WindowOracle
-        w = WindowOracle(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], **cfg)
-        t0 = time.perf_counter()
-        want = w.decode_batch(shots[: args.cpu])[0]
-        out["cpu_shots_per_s"] = args.cpu / (time.perf_counter() - t0)
-        out["cpu_inner"] = w.inner
-        out["cpu_matches"] = bool(np.array_equal(want, preds[: args.cpu]))
     print(json.dumps(out))
 
 
