@@ -15,7 +15,7 @@ def _py_files(sub):
 
 def test_product_package_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    for path in _py_files("ldpc_amd"):
+    for path in list(_py_files("ldpc_amd")) + list(_py_files("tools")):
         tree = ast.parse(open(path).read())
         for node in ast.walk(tree):
             names = []
