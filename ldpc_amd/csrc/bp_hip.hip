@@ -1480,12 +1480,12 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         A.max_rank = a.rank;
         A.kwords = !higher ? 0 : host_rank ? (a.n - a.rank + 63) / 64 : A.hwords;  // planes of T; rank unknown: room for every column
         if (higher && A.kwords < 1) A.kwords = 1;
-        // LDS: [keys 8 n | later: pivot columns 2 m, hit list 2 m, syndrome column m + 1] [column order 2 pow2]
+        // LDS: [keys 8 n | later: pivot columns 2 m, hit list 2 m, syndrome column m + 1, look-ahead words 8 m] [column order 2 pow2]
         //      higher order: [column info 2 n] [non-pivot columns 2 n] [four T planes 32 (m + 1)];  [H: hwords planes of m words, if it fits]
         if (a.m > 32767 || a.n > 32767)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: %d x %d is beyond the 16-bit row / column tables of the workgroup kernel", a.m, a.n);
         size_t region0 = (size_t)a.n * 8;
-        const size_t after = (size_t)a.m * 5 + 1;
+        const size_t after = (((size_t)a.m * 5 + 1 + 7) & ~(size_t)7) + (size_t)a.m * 8;
         if (after > region0) region0 = after;
         region0 = (region0 + 15) & ~(size_t)15;
         size_t lds = region0 + (size_t)A.pow2 * 2;

@@ -735,6 +735,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     int16_t *pivcol = reinterpret_cast<int16_t *>(osd_lds);            // [m]
     uint16_t *hits = reinterpret_cast<uint16_t *>(pivcol + m);         // [m]
     uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m + 1]
+    uint64_t *look = reinterpret_cast<uint64_t *>(osd_lds + ((5 * (size_t)m + 1 + 7) & ~(size_t)7));  // [m] bits of the next 64 columns, per row
     int16_t *colinfo = reinterpret_cast<int16_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
     uint16_t *npcol = reinterpret_cast<uint16_t *>(colinfo + n);       // [n] non-pivot columns in sorted order
     uint64_t *planes = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 4 * (size_t)n + 7) & ~(size_t)7));  // [4][m + 1] (entry m: the all-zero dummy row)
@@ -787,15 +788,30 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         // One column per step, two barriers when it yields a pivot, one when not.  The hit counter and the pivot slot
         // exist three times over: step t uses copy t % 3 and, once past its first barrier, re-arms copy (t + 2) % 3,
         // which nobody has touched since step t - 1 and nobody will before step t + 2.
+        // Which rows have a one in the column of a step is not read from the planes step by step (a dependent round
+        // trip to L2 / MALL each time when H lives in HBM): every 64 steps each thread gathers, for its rows, the bits of
+        // the NEXT 64 columns into one word per row (64 independent loads in flight), and from then on the owner of a
+        // row keeps that word current -- a row that takes the pivot row takes the pivot row's word as well.
         int rank = 0;
         for (int t = 0; t < n && rank < A.max_rank; ++t) {
-            const int c = ord[t], cur = t % 3;
-            const uint64_t *plane = mat + (int64_t)(c >> 6) * m;
-            const uint64_t cb = 1ull << (c & 63);
+            const int c = ord[t], cur = t % 3, kk = t & 63;
+            if (kk == 0) {
+                const int ahead = n - t < 64 ? n - t : 64;
+                for (int i = tid; i < m; i += T) {
+                    uint64_t word = 0;
+#pragma unroll 8
+                    for (int q = 0; q < ahead; ++q) {
+                        const int cq = ord[t + q];
+                        word |= ((mat[(int64_t)(cq >> 6) * m + i] >> (cq & 63)) & 1ull) << q;
+                    }
+                    look[i] = word;
+                }
+                __syncthreads();
+            }
             int pending = 0;
             for (int i = tid; i < m; i += T) {
                 const bool unpivoted = pivcol[i] < 0;
-                if (plane[i] & cb) {
+                if ((look[i] >> kk) & 1ull) {
                     hits[atomicAdd(&sh_nhits[cur], 1)] = (uint16_t)i;
                     if (unpivoted) atomicMin(&sh_pivot[cur], i);
                 }
@@ -830,6 +846,11 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 for (int q = 0; q < 8; ++q)
                     if (pw[q]) mat[(int64_t)(w0 + q) * m + r] = v[q] ^ pw[q];
                 if (w0 == 0) sy[r] ^= psy;
+            }
+            {   // the look-ahead words follow the rows (look[p] itself is read only: row p is not a target)
+                const uint64_t plook = look[p];
+                for (int i = tid; i < m; i += T)
+                    if (i != p && ((look[i] >> kk) & 1ull)) look[i] ^= plook;
             }
             if (tid == 0) pivcol[p] = (int16_t)c;
             ++rank;
