@@ -132,3 +132,80 @@ def test_window_checker_with_the_c_oracle_inside_reproduces_the_fixtures(path, o
     assert np.array_equal(preds, fx["predictions"])
     assert np.array_equal(after, fx["shots_after"])
     assert np.array_equal(w.weights, fx["priors_after"])
+
+
+def _random_dem_ast(rng, depth=0):
+    """A random program: list of ("error", p, groups) / ("shift", k) / ("detector", d) / ("obs", l) / ("repeat", count, body)."""
+    prog = []
+    for _ in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["error", "error", "shift", "detector", "obs", "repeat"] if depth < 2 else ["error", "shift", "detector"])
+        if kind == "error":
+            groups = []
+            for _ in range(int(rng.integers(1, 4))):
+                dets = sorted(set(int(x) for x in rng.integers(0, 6, size=int(rng.integers(0, 4)))))
+                obs = sorted(set(int(x) for x in rng.integers(0, 3, size=int(rng.integers(0, 2)))))
+                groups.append((dets, obs))
+            prog.append(("error", round(float(rng.uniform(0.001, 0.4)), 6), groups))
+        elif kind == "shift":
+            prog.append(("shift", int(rng.integers(0, 5))))
+        elif kind == "detector":
+            prog.append(("detector", int(rng.integers(0, 8))))
+        elif kind == "obs":
+            prog.append(("obs", int(rng.integers(0, 4))))
+        else:
+            prog.append(("repeat", int(rng.integers(0, 4)), _random_dem_ast(rng, depth + 1)))
+    return prog
+
+
+def _dem_text(prog, indent=""):
+    out = []
+    for ins in prog:
+        if ins[0] == "error":
+            tg = " ^ ".join(" ".join([f"D{d}" for d in dets] + [f"L{o}" for o in obs]) for dets, obs in ins[2])
+            out.append(f"{indent}error({ins[1]}) {tg}".rstrip())
+        elif ins[0] == "shift":
+            out.append(f"{indent}shift_detectors(0.5, 1) {ins[1]}")
+        elif ins[0] == "detector":
+            out.append(f"{indent}detector(1, 2, 3) D{ins[1]}  # declared")
+        elif ins[0] == "obs":
+            out.append(f"{indent}logical_observable L{ins[1]}")
+        else:
+            out.append(f"{indent}repeat {ins[1]} {{")
+            out.extend(_dem_text(ins[2], indent + "    "))
+            out.append(f"{indent}}}")
+    return out
+
+
+def _dem_flatten(prog, state):
+    for ins in prog:
+        if ins[0] == "error":
+            dets = [[d + state["shift"] for d in g[0]] for g in ins[2]]
+            obs = [list(g[1]) for g in ins[2]]
+            state["errors"].append((ins[1], dets, obs))
+            for g in dets:
+                for d in g:
+                    state["nd"] = max(state["nd"], d + 1)
+            for g in obs:
+                for o in g:
+                    state["no"] = max(state["no"], o + 1)
+        elif ins[0] == "shift":
+            state["shift"] += ins[1]
+        elif ins[0] == "detector":
+            state["nd"] = max(state["nd"], ins[1] + state["shift"] + 1)
+        elif ins[0] == "obs":
+            state["no"] = max(state["no"], ins[1] + 1)
+        else:
+            for _ in range(ins[1]):
+                _dem_flatten(ins[2], state)
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_reader_against_an_independent_flattening_of_random_programs(seed):
+    rng = np.random.default_rng(seed)
+    prog = _random_dem_ast(rng)
+    text = "\n".join(_dem_text(prog)) + "\n"
+    want = dict(shift=0, errors=[], nd=0, no=0)
+    _dem_flatten(prog, want)
+    got = parse_dem_text(text)
+    assert [(e.probability, e.detectors, e.observables) for e in got.errors] == want["errors"], text
+    assert (got.num_detectors, got.num_observables) == (want["nd"], want["no"]), text
