@@ -1,6 +1,7 @@
 // cpp_host_demo.cpp -- the C++ host side over the C ABI, no Python: decodes the reference's own
 // known-answer cases (cpp_test/TestBPDecoder.cpp:166-231: repetition code 5, five syndromes, product-sum
-// and min-sum) through ldpc_hip::BpDecoder and checks the expected hard decisions.
+// and min-sum) through ldpc_hip::BpDecoder and checks the expected hard decisions; then the serial schedule, a received
+// vector and analog syndromes against outputs of the reference on the same inputs.
 //   g++ -std=c++17 -Iinclude examples/cpp_host_demo.cpp -Lldpc_amd/lib -lldpc_hip -Wl,-rpath,'$ORIGIN/../ldpc_amd/lib' -o examples/cpp_host_demo
 #include <cstdio>
 #include "ldpc_hip.hpp"
@@ -30,6 +31,36 @@ int main() {
         auto s = syndromes[4];
         dec.decode(s);
         if (dec.iterations != 1) { ++bad; std::printf("maximum_iterations member not honoured\n"); }
+    }
+    {   // serial schedule, received-vector input and analog syndromes: expected values from the reference itself
+        // (bp.hpp:451-545, 162-180, 547-660 run through oracle/ref_harness.cpp on these inputs)
+        ldpc_hip::BpDecoder dec(m, n, rp, ci, std::vector<double>(n, 0.1), n, ldpc_hip::PRODUCT_SUM, 1.0);
+        dec.schedule = ldpc_hip::SERIAL;
+        for (size_t k = 0; k < syndromes.size(); ++k) {
+            auto s = syndromes[k];
+            if (dec.decode(s) != expected[k] || dec.last_status != 0) { ++bad; std::printf("serial schedule, syndrome %zu: wrong decoding\n", k); }
+        }
+        dec.serial_schedule_order = {4, 3, 2, 1, 0};
+        auto s1 = syndromes[1];
+        if (dec.decode(s1) != expected[1]) { ++bad; std::printf("serial schedule with an order: wrong decoding\n"); }
+        dec.schedule = ldpc_hip::PARALLEL;
+        dec.bp_input_type = ldpc_hip::AUTO;
+        std::vector<uint8_t> r{0, 0, 0, 0, 1};  // n entries: taken as a received vector; the single flip is removed
+        if (dec.decode(r) != std::vector<uint8_t>{0, 0, 0, 0, 0}) { ++bad; std::printf("received-vector input: wrong decoding\n"); }
+        dec.bp_input_type = ldpc_hip::SYNDROME;
+        dec.bp_method = ldpc_hip::MINIMUM_SUM;
+        dec.maximum_iterations = 5;
+        const std::vector<std::vector<double>> soft{{2.0, 2.0, 2.0, -2.0}, {2.0, -0.3, 2.0, -2.0}, {0.2, -0.1, 0.3, -0.2}, {-2.0, 2.0, -2.0, 2.0}};
+        const std::vector<std::vector<uint8_t>> want_soft{{0, 0, 0, 0, 1}, {0, 0, 0, 0, 1}, {0, 0, 0, 0, 0}, {0, 1, 1, 0, 0}};  // cutoff 2, sigma 0.7
+        const int want_iters[4] = {1, 1, 1, 4};
+        for (size_t k = 0; k < soft.size(); ++k) {
+            auto a = soft[k];
+            if (dec.soft_info_decode_serial(a, 2.0, 0.7) != want_soft[k] || dec.iterations != want_iters[k] || !dec.converge) {
+                ++bad;
+                std::printf("soft_info_decode_serial %zu: wrong result\n", k);
+            }
+        }
+        if (dec.soft_syndrome.size() != 4 || dec.soft_syndrome[1] < 8.16 || dec.soft_syndrome[1] > 8.17) { ++bad; std::printf("soft_syndrome member not filled\n"); }
     }
     std::printf(bad ? "FAIL (%d)\n" : "cpp_host_demo: all reference known answers reproduced (PASS)\n", bad);
     return bad ? 1 : 0;

@@ -4,7 +4,9 @@
 // `ldpc::bp::BpDecoder` (src_cpp/bp.hpp:51-76, declared to Cython in _bp_decoder.pxd:47-83): public,
 // mutable `channel_probabilities`, `maximum_iterations`, `bp_method`, `ms_scaling_factor`, and the results
 // `decoding`, `log_prob_ratios`, `iterations`, `converge`; `decode(std::vector<uint8_t>&)` for one syndrome and
-// the additive `decode_batch`.  A binding written against the reference class therefore transliterates
+// the additive `decode_batch`; also `schedule` / `serial_schedule_order` (fixed-order serial sweep, bp.hpp:451-545),
+// `bp_input_type` (syndrome or received vector, bp.hpp:162-180) and `soft_info_decode_serial` with its `soft_syndrome`
+// result (bp.hpp:547-660).  A binding written against the reference class therefore transliterates
 // (INTEGRATION.md §2).  As in the reference, construction throws on bad input (`except +` in the pxd) and
 // decode does not throw across the binding: it records `last_status` / `last_error` instead.
 #pragma once
@@ -19,6 +21,8 @@
 namespace ldpc_hip {
 
 enum BpMethod { PRODUCT_SUM = LDPC_HIP_PRODUCT_SUM, MINIMUM_SUM = LDPC_HIP_MINIMUM_SUM };  // bp.hpp:23-26
+enum BpSchedule { SERIAL = 0, PARALLEL = 1, SERIAL_RELATIVE = 2 };                        // bp.hpp:28-32
+enum BpInputType { SYNDROME = 0, RECEIVED_VECTOR = 1, AUTO = 2 };                          // bp.hpp:34-38
 
 class BpDecoder {
 public:
@@ -28,7 +32,11 @@ public:
     int bit_count = 0;
     int maximum_iterations = 0;
     BpMethod bp_method = PRODUCT_SUM;
+    BpSchedule schedule = PARALLEL;            // SERIAL_RELATIVE is refused by the device (LDPC_HIP_ERR_UNSUPPORTED)
+    BpInputType bp_input_type = SYNDROME;
     double ms_scaling_factor = 1.0;
+    std::vector<int> serial_schedule_order;    // empty: 0 .. n-1 (bp.hpp:120-124)
+    std::vector<double> soft_syndrome;         // after soft_info_decode_serial (bp.hpp:65, 547-660)
     std::vector<uint8_t> decoding;
     std::vector<double> log_prob_ratios;
     int iterations = 0;
@@ -65,13 +73,41 @@ public:
     BpDecoder &operator=(const BpDecoder &) = delete;
     ~BpDecoder() { ldpc_hip_bp_destroy(h_); }
 
-    // one syndrome: ldpc::bp::BpDecoder::decode (bp.hpp:159-190, parallel schedule, syndrome input)
-    std::vector<uint8_t> &decode(std::vector<uint8_t> &syndrome) {
-        if ((int)syndrome.size() != check_count) { fail_(LDPC_HIP_ERR_INVALID, "syndrome has the wrong length"); return decoding; }
+    // one input vector: ldpc::bp::BpDecoder::decode (bp.hpp:159-190).  A received vector r (bp_input_type
+    // RECEIVED_VECTOR, or AUTO and n entries) is turned into the syndrome H r on the device, decoded, and XORed back in.
+    std::vector<uint8_t> &decode(std::vector<uint8_t> &input_vector) {
+        const bool received = bp_input_type == RECEIVED_VECTOR || (bp_input_type == AUTO && (int)input_vector.size() == bit_count);
+        if ((int)input_vector.size() != (received ? bit_count : check_count)) { fail_(LDPC_HIP_ERR_INVALID, "input vector has the wrong length"); return decoding; }
         if (!sync_()) return decoding;
+        std::vector<uint8_t> syndrome_of_r;
+        const uint8_t *synd = input_vector.data();
+        if (received) {
+            syndrome_of_r.assign((size_t)check_count, 0);
+            last_status = ldpc_hip_gf2_mulvec_batch(h_, input_vector.data(), 1, syndrome_of_r.data());
+            if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return decoding; }
+            synd = syndrome_of_r.data();
+        }
         int32_t it = 0;
         uint8_t cv = 0;
-        last_status = ldpc_hip_bp_decode_batch(h_, syndrome.data(), 1, decoding.data(), log_prob_ratios.data(), &it, &cv);
+        last_status = ldpc_hip_bp_decode_batch(h_, synd, 1, decoding.data(), log_prob_ratios.data(), &it, &cv);
+        if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return decoding; }
+        if (received)
+            for (int j = 0; j < bit_count; ++j) decoding[(size_t)j] ^= input_vector[(size_t)j];
+        iterations = it;
+        converge = cv != 0;
+        return decoding;
+    }
+
+    // ldpc::bp::BpDecoder::soft_info_decode_serial (bp.hpp:547-660): analog syndrome readouts, serial minimum-sum with
+    // `ms_scaling_factor` taken literally, virtual check nodes below `cutoff`.  Fills `soft_syndrome` as the reference does.
+    std::vector<uint8_t> &soft_info_decode_serial(std::vector<double> &soft_info_syndrome, double cutoff, double sigma) {
+        if ((int)soft_info_syndrome.size() != check_count) { fail_(LDPC_HIP_ERR_INVALID, "soft syndrome has the wrong length"); return decoding; }
+        if (!sync_()) return decoding;
+        soft_syndrome.assign((size_t)check_count, 0.0);
+        int32_t it = 0;
+        uint8_t cv = 0;
+        last_status = ldpc_hip_bp_soft_info_decode_batch(h_, soft_info_syndrome.data(), 1, cutoff, sigma, decoding.data(),
+                                                         log_prob_ratios.data(), &it, &cv, soft_syndrome.data());
         if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return decoding; }
         iterations = it;
         converge = cv != 0;
@@ -110,11 +146,24 @@ private:
         }
         last_status = ldpc_hip_bp_set_params(h_, maximum_iterations, (int32_t)bp_method, ms_scaling_factor);
         if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+        if ((int)schedule != synced_schedule_ || serial_schedule_order != synced_order_) {
+            if (!serial_schedule_order.empty() && (int)serial_schedule_order.size() != bit_count) {
+                fail_(LDPC_HIP_ERR_INVALID, "serial_schedule_order must have n entries");
+                return false;
+            }
+            std::vector<int32_t> order(serial_schedule_order.begin(), serial_schedule_order.end());
+            last_status = ldpc_hip_bp_set_schedule(h_, (int32_t)schedule, order.empty() ? nullptr : order.data());
+            if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+            synced_schedule_ = (int)schedule;
+            synced_order_ = serial_schedule_order;
+        }
         return true;
     }
     void fail_(int code, const char *msg) { last_status = code; last_error = msg; }
     ldpc_hip_bp *h_ = nullptr;
     std::vector<double> synced_probs_;
+    int synced_schedule_ = (int)PARALLEL;
+    std::vector<int> synced_order_;
 };
 
 }  // namespace ldpc_hip
