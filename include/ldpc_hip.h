@@ -154,7 +154,8 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
  * -1 = automatic (max_iter / 8, default), 0 = off.  With repacking the call waits once for the device.
  * The streamed parallel schedule (codes too large for the on-chip kernels, batches of >= 32768 syndromes) repacks the
  * same way; there "automatic" prices both ways with the iteration histogram the previous decode on the handle left behind
- * and runs plain when that says so or says nothing yet -- no work is wasted where nothing converges. */
+ * and runs plain when that says so or says nothing yet -- no work is wasted where nothing converges.  (Reading that
+ * histogram means a streamed *_async decode first waits for the previous decode on the same handle.) */
 int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
 /* Serial schedule kernels: bits that share no check commute, so the schedule is cut into levels of mutually check-disjoint
  * bits (level = 1 + the highest level among the EARLIER bits sharing a check) and a workgroup runs a tile level by level
