@@ -50,5 +50,18 @@ def main():
         error_channel=chan, note="three one-wavefront kernels per CU at most: the workgroup kernel with H in LDS takes it")
 
 
+
+
+def bp_fixtures():
+    """BP alone on the [[1600,64]] matrix, log-ratios included: two wavefronts per CU, so bp_wave_kernel runs with the
+    log-ratios stored straight to HBM (WaveArgs.llr_direct) -- pinned here to the real reference, both methods."""
+    from make_golden import run_case
+    hx = hgp1600()
+    s = bsc_syndromes(hx, 31, 0.03, 0, 64)
+    run_case("hgp1600_ms20_p030", hx, s, error_rate=0.03, max_iter=20, bp_method="minimum_sum", ms_scaling_factor=0.625, full_llr=16)
+    run_case("hgp1600_ps12_p030", hx, s[:32], error_rate=0.03, max_iter=12, bp_method="product_sum", full_llr=8)
+
+
 if __name__ == "__main__":
     main()
+    bp_fixtures()
