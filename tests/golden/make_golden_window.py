@@ -60,6 +60,8 @@ def main():
     bb = codes.bivariate_bicycle_hx()
     run("window_bb144_d2_w3_c2", bb, 5, 0.004, 0.004, tuple(range(12)), decodings=2, window=3, commit=2, shots=48, seed=6, scale=2.0,
         max_iter=20, ms_scaling_factor=0.625)
+    run("window_bb144_d2_w6_c3", bb, 9, 0.004, 0.004, tuple(range(12)), decodings=2, window=6, commit=3, shots=40, seed=7, scale=2.5,
+        max_iter=12, ms_scaling_factor=0.625)  # 432-row windows: OSD-0 with a workgroup per syndrome on the device
 
 
 if __name__ == "__main__":
