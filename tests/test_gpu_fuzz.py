@@ -324,4 +324,10 @@ def test_streamed_parallel_schedule_repacks_from_the_previous_histogram(oracle_b
     want = o.decode_batch(s.cpu().numpy()[pick])
     assert np.array_equal(runs["steered"][0][pick], want[0]) and np.array_equal(runs["steered"][2][pick], want[2])
     assert np.array_equal(runs["steered"][3][pick].astype(bool), want[3].astype(bool)) and bits_equal(runs["steered"][1][pick], want[1])
+    # ordered-statistics post-processing on top of the repacked run (it consumes the scattered log-ratios and flags)
+    eng.set_osd(1, 0)
+    osd = eng.decode_batch(s, want_llr=False, osd=True)[0].cpu().numpy()
+    want_osd = o.bposd_decode_batch(s.cpu().numpy()[pick], 1, 0, want_llr=False)[0]
+    assert np.array_equal(osd[pick], want_osd)
+    assert np.array_equal(osd[conv], runs["first"][0][conv])
 
