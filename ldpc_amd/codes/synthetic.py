@@ -118,3 +118,19 @@ def bivariate_bicycle_hx(
     out = sp.csr_matrix(h, dtype=np.uint8)
     out.sort_indices()
     return out
+
+
+def hypergraph_product_hx(h1, h2=None) -> sp.csr_matrix:
+    """X-check matrix ``[H1 (x) I_n2 | I_m1 (x) H2^T]`` of the hypergraph product of two classical codes (H2 = H1 if omitted).
+
+    ``hypergraph_product_hx(regular_ldpc_code(n=32, dv=3, dc=4, seed=5))`` is the 768 x 1600 matrix of a [[1600, 64]] code
+    used by ``tools/bench_configs.py hgp1600`` and the ``*hgp1600*`` fixtures: the smallest of the usual BP+OSD benchmark
+    sizes whose ``[H | s]`` no longer fits LDS.
+    """
+    h1 = sp.csr_matrix(h1, dtype=np.uint8)
+    h2 = h1 if h2 is None else sp.csr_matrix(h2, dtype=np.uint8)
+    (m1, _), (_, n2) = h1.shape, h2.shape
+    hx = sp.hstack([sp.kron(h1, sp.identity(n2, dtype=np.uint8)), sp.kron(sp.identity(m1, dtype=np.uint8), h2.T)]).tocsr().astype(np.uint8)
+    hx.sort_indices()
+    return hx
+

@@ -26,11 +26,7 @@ from make_golden_osdw import run  # noqa: E402
 
 
 def hgp1600():
-    h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
-    m1, n1 = h1.shape
-    hx = sp.hstack([sp.kron(h1, sp.identity(n1, dtype=np.uint8)), sp.kron(sp.identity(m1, dtype=np.uint8), h1.T)]).tocsr().astype(np.uint8)
-    hx.sort_indices()
-    return hx
+    return codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))
 
 
 def main():

@@ -91,10 +91,7 @@ def hgp1600():
     bit-packed -- beyond LDS, so OSD runs through osd_big_kernel (H in an HBM scratch slot)."""
     import scipy.sparse as sp
     from ldpc_amd import codes
-    h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
-    m1, n1 = h1.shape
-    hx = sp.hstack([sp.kron(h1, sp.identity(n1, dtype=np.uint8)), sp.kron(sp.identity(m1, dtype=np.uint8), h1.T)]).tocsr().astype(np.uint8)
-    hx.sort_indices()
+    hx = codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))
     for p in (0.02, 0.04):
         run(f"hgp [[1600,64]] min_sum 30 it (BP only) p={p}", hx, p, 30, 1, 0.625, 65536, False)
         run(f"hgp [[1600,64]] min_sum 30 it + OSD-0 p={p}", hx, p, 30, 1, 0.625, 65536, True)

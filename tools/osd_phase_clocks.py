@@ -39,9 +39,7 @@ def main():
     import scipy.sparse as sp
     import torch
     if args.hgp1600:
-        h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
-        h = sp.hstack([sp.kron(h1, sp.identity(32, dtype=np.uint8)), sp.kron(sp.identity(24, dtype=np.uint8), h1.T)]).tocsr().astype(np.uint8)
-        h.sort_indices()
+        h = codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))
         p, it, method, alpha = 0.02, 30, 1, 0.625
     elif args.bb:
         h, p, it, method, alpha = codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0
