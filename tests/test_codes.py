@@ -1,0 +1,30 @@
+"""The matrix generators the benches, tests and fixture generators share: shapes, weights, and the algebra they promise."""
+import numpy as np
+import scipy.sparse as sp
+
+from ldpc_amd import codes
+from golden_util import load_case
+
+
+def test_baseline_matrices():
+    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    assert h.shape == (5000, 10000) and h.nnz == 30000
+    assert set(np.diff(h.indptr)) == {6} and set(np.diff(h.tocsc().indptr)) == {3}
+    s = codes.rotated_surface_code_x(21)
+    assert s.shape == (220, 441) and s.nnz == 840
+    b = codes.bivariate_bicycle_hx()
+    assert b.shape == (72, 144) and set(np.diff(b.indptr)) == {6} and set(np.diff(b.tocsc().indptr)) == {3}
+    assert codes.hamming_code(5).shape == (5, 31)
+
+
+def test_hypergraph_product():
+    h1 = codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)
+    m1, n1 = h1.shape
+    hx = codes.hypergraph_product_hx(h1)
+    assert hx.shape == (m1 * n1, n1 * n1 + m1 * m1) == (768, 1600)
+    # the partner Z-check matrix [I (x) H1 | H1^T (x) I] commutes with it: a CSS code
+    hz = sp.hstack([sp.kron(sp.identity(n1, dtype=np.uint8), h1), sp.kron(h1.T, sp.identity(m1, dtype=np.uint8))]).tocsr()
+    assert not ((hx.astype(np.int64) @ hz.T.astype(np.int64)).toarray() % 2).any()
+    assert (sp.csr_matrix(load_case("hgp1600_ms20_p030")["h"]) != hx).nnz == 0, "the committed fixtures were made on this matrix"
+    h2 = codes.hamming_code(3)
+    assert codes.hypergraph_product_hx(h1, h2).shape == (m1 * 7, n1 * 7 + m1 * 3)
