@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on BASELINE.json's config, one JSON line on rank 0.
 
-Workload (configs[1]): (3,6)-regular LDPC, n = 10 000 (m = 5 000, E = 30 000), code seed 1;
-product_sum flooding BP, max_iter = 50; batch = 65 536 syndromes PER GPU (weak scaling: N GPUs decode
-N x 65 536); iid BSC errors p = 0.09 from the counter-based stream (error seed 7), syndromes = H e,
-generated ON the device before the timed region, so inputs are resident in HBM when timing starts.
+Workload (configs[1] / configs[3]): (3,6)-regular LDPC, n = 10 000 (m = 5 000, E = 30 000), code seed 1;
+product_sum flooding BP, max_iter = 50; iid BSC errors p = 0.09 from the counter-based stream (error seed 7),
+syndromes = H e, generated ON the device before the timed region (inputs resident in HBM when timing starts).
 
-A "step" = one decode of the rank's whole batch through the C ABI (pack -> BP kernel -> unpack ->
-LLR transpose) plus, for N > 1, the single gather of decoded rows onto rank 0 (RCCL over xGMI).
+    N = 1   batch = 65 536 syndromes                      = configs[1]
+    N > 1   batch = 131 072 syndromes PER GPU (weak scaling; N = 8: 1 048 576 syndromes = configs[3]); rank r decodes
+            shots [r B, (r + 1) B) of the same stream.  Throughput per GPU does not depend on B at these sizes
+            (profiles/: 8 192 ... 65 536 within the box-to-box spread), so N = 1 is comparable with the rest.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch-per-gpu B] [--p P]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+A "step" = one decode of the rank's whole batch through the C ABI (pack -> BP kernels -> unpack -> LLR transpose)
+plus, when a process group exists, the single gather of decoded rows (bit-packed on the device) + flags onto rank 0
+(RCCL over xGMI).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1: spawns its N ranks itself (torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+After the headline, at N = 1, the two on-chip BASELINE configs are timed as well (`secondary`): configs[2] (rotated
+surface code d = 21, min-sum 30, B = 262 144) and configs[4] (BB [[144,12,12]] product-sum 50 + OSD-0, B = 8 192).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LDS_PEAK_GBPS = 150000.0  # ds_read_b64 / b128 aggregate at 2.4 GHz, same guide (LDS table)
+SIMDS = 1024             # 256 CUs x 4
+MAX_CLOCK_GHZ = 2.4
 
 
 def algorithmic_bytes(iters: np.ndarray, m: int, n: int, nnz: int) -> float:
@@ -34,17 +47,60 @@ def algorithmic_bytes(iters: np.ndarray, m: int, n: int, nnz: int) -> float:
     return float(np.sum(iters.astype(np.float64) * (4.0 * nnz * 8.0) + (m + n + 8.0 * n + 5.0)))
 
 
-def main() -> None:
+def physical_cores() -> int:
+    """Distinct (package, core) pairs of /proc/cpuinfo; falls back to the logical count."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n_ranks: int, argv: list[str], port: int | None = None) -> list[str]:
+    """The command the driver uses for N > 1, built here when bench.py is started bare (`python bench.py --gpus N`)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_ranks: int) -> int:
+    argv = [a for a in sys.argv[1:] if a != "--force-launch"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(launch_command(n_ranks, argv), env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536)
+    ap.add_argument("--batch-per-gpu", type=int, default=-1, help="-1: 65536 at N = 1 (configs[1]), 131072 at N > 1 (configs[3] at N = 8)")
     ap.add_argument("--p", type=float, default=0.09, help="BSC error rate (0.09: primary point, 0.05: early-exit point)")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--waves", type=int, default=0, help="waves per workgroup (0 = library default)")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="syndromes for the CPU baseline and parity gate (-1 = max(1024, 4 per host thread), 0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="syndromes for the CPU baseline and parity gate at N = 1 (-1 = 1024, 0 = skip)")
+    ap.add_argument("--rank-parity", type=int, default=128, help="rows of EVERY rank's shard checked against the CPU checker when N > 1 (0 = skip)")
     ap.add_argument("--math", default="libm_exact", choices=["libm_exact", "fast"], help="device tanh/log (include/ldpc_hip.h)")
     ap.add_argument("--bp-method", default="product_sum", choices=["product_sum", "minimum_sum"],
                     help="product_sum is the BASELINE workload; minimum_sum (alpha 0.625) is a diagnostic memory-only run")
@@ -52,7 +108,123 @@ def main() -> None:
     ap.add_argument("--ring", type=int, default=1, help="LDS-DMA ring: 0 = register-prefetch variant, 1 = default depth, 2/3 = depth (diagnostic)")
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     ap.add_argument("--repack", type=int, default=-1, help="first-pass iterations of the repacked schedule (-1 = steered by the previous decode, 0 = off; diagnostic)")
-    args = ap.parse_args()
+    ap.add_argument("--secondary", type=int, default=1, help="1: also time configs[2] and configs[4] (N = 1 only); 0: skip")
+    ap.add_argument("--dry-ranks", action="store_true", help="launcher self-test: every rank joins a gloo group, rank 0 prints the ranks it saw; no GPU work")
+    ap.add_argument("--force-launch", action="store_true", help="go through torch.distributed.run even for --gpus 1 (exercises the N > 1 code path on one GPU)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the real reference (oracle/_ref) or the C restatement, on a bounded sample of the batch
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(h, p, max_iter, method, alpha, s_host):
+    """Thread-count sweep on small slices, then the whole sample at the best count (whose outputs are the parity reference)."""
+    from oracle import cpu_bench  # checker / baseline only
+    logical, phys = os.cpu_count() or 1, physical_cores()
+    counts = sorted({c for c in (1, 8, 16, 32, 64, phys // 2, phys, logical) if 1 <= c <= logical})
+    sweep = []
+    for c in counts:
+        k = min(len(s_host), max(6, 2 * c))
+        r, _ = cpu_bench.run(h, p, max_iter, method, alpha, s_host[:k], cores=c)
+        sweep.append({"threads": r["cores"], "value": r["value"], "per_thread": r["per_core"], "syndromes": k})
+    best = max(sweep, key=lambda e: e["value"])
+    res, outs = cpu_bench.run(h, p, max_iter, method, alpha, s_host, cores=best["threads"])
+    res["host"] = {"logical_cpus": logical, "physical_cores": phys}
+    res["thread_sweep"] = sweep
+    res["single_thread"] = {"value": sweep[0]["value"], "unit": "syndromes/s"}
+    res["note"] = ("one decoder object per thread over disjoint slices (the reference object is single-threaded); `value` is the "
+                   "best thread count of the sweep -- the linked-list matrix of every decoder (1.7 MB) competes for cache, so "
+                   "per-thread speed falls as threads are added")
+    return res, outs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# secondary configs (SURVEY.md §8d C3 / C5): on-chip kernels, so the bound is LDS / FP64 VALU, not HBM
+# ------------------------------------------------------------------------------------------------------------------
+def secondary_configs(dev, steps):
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    import oracle  # checker only
+
+    out = []
+    valu = {}
+    try:
+        valu = json.load(open(os.path.join(ROOT, "profiles", "secondary_valu.json")))
+    except Exception:
+        valu = {}
+    specs = [
+        dict(key="c3", name="configs[2]: rotated surface code d=21 X checks (220 x 441, E=840), minimum_sum alpha=0.625, max_iter=30, "
+                            "batch=262144, BSC p=0.05", h=codes.rotated_surface_code_x(21), p=0.05, max_iter=30, method=1,
+             alpha=0.625, batch=262144, osd0=False, dr=4, dc=2),
+        dict(key="c5", name="configs[4]: BB [[144,12,12]] hx (72 x 144, E=432), product_sum max_iter=50 + OSD-0, batch=8192, BSC p=0.05",
+             h=codes.bivariate_bicycle_hx(), p=0.05, max_iter=50, method=0, alpha=1.0, batch=8192, osd0=True, dr=6, dc=3),
+    ]
+    for sp in specs:
+        h, p, B = sp["h"], sp["p"], sp["batch"]
+        m, n, nnz = h.shape[0], h.shape[1], h.nnz
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), sp["max_iter"], sp["method"], sp["alpha"], device=dev.index or 0)
+        s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+        res = eng.decode_batch(s, osd0=sp["osd0"])  # warm-up; also the outputs that are checked
+        torch.cuda.synchronize()
+        kms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.decode_batch(s, out=res, osd0=sp["osd0"], asynchronous=True)
+            kms.append(eng.last_kernel_ms())
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        it = res[2].cpu().numpy()
+        cv = res[3].cpu().numpy().astype(bool)
+        # parity: a sample of the timed batch against the CPU checker (bit-exact decisions / iterations / flags, LLR 1e-5)
+        rows = np.sort(np.random.default_rng(4321).choice(B, size=256, replace=False))
+        rt = torch.from_numpy(rows).to(dev)
+        s_host = s[rt].cpu().numpy()
+        orc = oracle.BpOracle(h, error_rate=p, max_iter=sp["max_iter"], bp_method=sp["method"], ms_scaling_factor=sp["alpha"])
+        od, ol, oi, oc = orc.bposd0_decode_batch(s_host) if sp["osd0"] else orc.decode_batch(s_host)
+        ok = bool(np.array_equal(res[0][rt].cpu().numpy(), od) and np.array_equal(it[rows], oi) and np.array_equal(cv[rows], oc)
+                  and oracle.llr_close(res[1][rt].cpu().numpy(), ol, rtol=1e-5))
+        iters_total = float(it.astype(np.float64).sum())
+        io_bytes = B * (m + n + 8.0 * n + 5.0)
+        entry = {"config": sp["name"], "key": sp["key"], "value": B / ms * 1e3, "unit": "syndromes/s", "ms": ms, "bp_kernel_ms": float(np.mean(kms)),
+                 "mean_iterations": float(it.mean()), "bp_converged_fraction": float(cv.mean()),
+                 "io_hbm_GBps": io_bytes / (ms * 1e-3) / 1e9, "parity_vs_oracle": ok,
+                 "algorithmic_message_bytes_per_s_GBps": iters_total * 4.0 * nnz * 8.0 / (ms * 1e-3) / 1e9}
+        if sp["method"] == 1:
+            # bp_wave_kernel keeps ONE message array per syndrome in LDS.  LDS bytes of one iteration, from the kernel's own
+            # geometry (bp_wave_kernel.h: rows padded to mp, columns to np, DR / DC template bounds):
+            #   check pass   mp * (DR * (8 + 8) + 2)           messages read + written, syndrome byte, degree
+            #   bit pass     np * (DC * (2 + 8 + 8) + 8 + 8)   position, message read + written, prior, posterior
+            #   syndrome     mp * (DR * (2 + 8) + 1)           column numbers, decision words, syndrome byte
+            mp, npad, dr, dc = (m + 63) // 64 * 64, (n + 63) // 64 * 64, sp["dr"], sp["dc"]
+            per_iter = mp * (dr * 16 + 2) + npad * (dc * 18 + 16) + mp * (dr * 10 + 1)
+            lds_gbps = iters_total * per_iter / (ms * 1e-3) / 1e9
+            entry.update({"bound": "lds", "frac": lds_gbps / LDS_PEAK_GBPS, "achieved": lds_gbps, "peak": LDS_PEAK_GBPS,
+                          "bound_unit": "GB/s", "lds_bytes_per_syndrome_iteration": per_iter,
+                          "bound_note": "LDS bytes the kernel moves (its padded geometry) / time vs the guide's ~150 TB/s ds_read_b64 aggregate"})
+        else:
+            # product-sum on chip: FP64 VALU issue.  Instructions per entry-iteration come from the committed PMC profile of
+            # this kernel (profiles/secondary_valu.json: SQ_INSTS_VALU / (entries x iterations)); a wave-instruction takes
+            # 4 cycles of its SIMD, and the chip has 1024 SIMDs at <= 2.4 GHz.
+            per = valu.get(sp["key"], {}).get("valu_insts_per_entry_iteration")
+            if per:
+                wave_insts = iters_total * nnz * per / 64.0
+                frac = wave_insts * 4.0 / (SIMDS * MAX_CLOCK_GHZ * 1e9 * float(np.mean(kms)) * 1e-3)
+                entry.update({"bound": "fp64_valu", "frac": frac, "valu_insts_per_entry_iteration": per,
+                              "bound_note": "VALU issue slots used by the BP kernel / slots of 1024 SIMDs at the 2.4 GHz maximum clock "
+                                            "(the real clock under this load is lower, so the true fraction is higher); counts from "
+                                            "profiles/secondary_valu.json"})
+            else:
+                entry.update({"bound": "fp64_valu", "frac": None, "bound_note": "profiles/secondary_valu.json absent"})
+        out.append(entry)
+        eng.close()
+    return out
+
+
+def main() -> None:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch):
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -60,14 +232,24 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    grouped = "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (the driver's command, or self_launch)
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_ranks:  # does `python bench.py --gpus N` really become N ranks that find each other?  (tests/test_bench_launch.py)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        if rank == 0:
+            print(json.dumps({"dry_ranks": seen, "world": dist.get_world_size(), "backend": dist.get_backend()}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -78,7 +260,7 @@ def main() -> None:
     n = args.n
     h = regular_ldpc_code(n, 3, 6, seed=1)
     m, nnz = h.shape[0], h.nnz
-    B = args.batch_per_gpu
+    B = args.batch_per_gpu if args.batch_per_gpu > 0 else (65536 if world == 1 else 131072)
     total = B * world
     method_id = 0 if args.bp_method == "product_sum" else 1
     alpha = 1.0 if method_id == 0 else 0.625
@@ -98,58 +280,101 @@ def main() -> None:
     cv = torch.empty((B,), dtype=torch.uint8, device=dev)
     out = (dec, llr, it, cv)
 
-    kernel_ms = []
-    phase_ms = []
+    kernel_ms, phase_ms, gather_ms = [], [], []
+    gathered = {}
 
     def step(record: bool):
         eng.decode_batch(synd, want_llr=llr is not None, out=out, asynchronous=True)
         if record:
             kernel_ms.append(eng.last_kernel_ms())  # HIP events around the BP kernels on the launch stream
             phase_ms.append(eng.last_phase_ms())
-        if world > 1:  # the only collective: gather decoded rows (bit-packed on the device first) + flags onto rank 0
-            gather_rows(eng.pack_b8(dec), total, 0)
-            gather_rows(cv, total, 0)
-            gather_rows(it, total, 0)
+        if grouped:  # the only collective: gather decoded rows (bit-packed on the device first) + flags onto rank 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gathered["dec_b8"] = gather_rows(eng.pack_b8(dec), total, 0)
+            gathered["conv"] = gather_rows(cv, total, 0)
+            gathered["iters"] = gather_rows(it, total, 0)
+            e1.record()
+            if record:
+                gather_ms.append((e0, e1))
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1 and args.warmup == 0:
+    if grouped and args.warmup == 0:
         # RCCL sets up its peer-to-peer connections at the first gather: keep that out of the timed region
         gather_rows(torch.zeros((8, 8), dtype=torch.uint8, device=dev), 8 * world, 0)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    iters = it.cpu().numpy()
+    conv = cv.cpu().numpy().astype(bool)
+    k_ms = float(np.mean(kernel_ms))
+    g_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ms])) if gather_ms else 0.0
+
+    # ---- every rank: parity of a sample of ITS shard against the CPU checker; per-rank timings to rank 0 -------------
+    rank_ok = 1
+    rank_rows = 0
+    if grouped and args.rank_parity > 0:
+        from oracle import cpu_bench, llr_close  # checker only
+        rank_rows = min(B, args.rank_parity)
+        rows = np.sort(np.random.default_rng(777 + rank).choice(B, size=rank_rows, replace=False))
+        rows_t = torch.from_numpy(rows).to(dev)
+        _, (cd, cl, ci, cc) = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, synd[rows_t].cpu().numpy(),
+                                            cores=max(1, min(32, physical_cores() // world)))
+        ok = np.array_equal(dec[rows_t].cpu().numpy(), cd) and np.array_equal(iters[rows], ci) and np.array_equal(conv[rows], cc)
+        if llr is not None:
+            ok = ok and llr_close(llr[rows_t].cpu().numpy(), cl, rtol=1e-5)
+        if rank == 0 and ok:  # what arrived through the gather is what this rank produced
+            own = eng.unpack_b8(gathered["dec_b8"][:B].contiguous(), n)
+            ok = bool(torch.equal(own, dec)) and bool(torch.equal(gathered["conv"][:B], cv)) and bool(torch.equal(gathered["iters"][:B], it))
+        rank_ok = int(bool(ok))
+    per_rank = None
+    if grouped:
+        mine = torch.tensor([k_ms, g_ms, float(rank_ok), float(iters.mean())], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(v) for v in t_.cpu()] for t_ in allr]
+
     if rank == 0:
-        iters = it.cpu().numpy()
-        conv = cv.cpu().numpy().astype(bool)
         alg = algorithmic_bytes(iters, m, n, nnz)
-        k_ms = float(np.mean(kernel_ms))
-        pers_ms = float(np.mean([p[0] for p in phase_ms]))
-        spread_ms = float(np.mean([p[1] for p in phase_ms]))
+        pers_ms = float(np.mean([p_[0] for p_ in phase_ms]))
+        spread_ms = float(np.mean([p_[1] for p_ in phase_ms]))
         achieved = alg / (k_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC run of this same workload (profiles/hbm_traffic.json,
-        # produced by tools/profile_bench.sh + tools/prof_parse.py); null when absent or for another workload
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tj) and world == 1 and method_id == 0:
+        # HBM bytes per launch and the VALU / clock picture from the committed PMC run of this same workload
+        # (profiles/hbm_traffic.json, profiles/valu_clock.json: tools/profile_bench.sh + tools/prof_parse.py); null when
+        # absent or measured on another workload
+        traffic, second = None, None
+        same = world == 1 and method_id == 0
+
+        def committed(name):
             try:
-                t = json.load(open(tj))
-                if t.get("batch_per_gpu") == B and t.get("p") == args.p and t.get("max_iter") == args.max_iter and t.get("n") == n:
-                    traffic = t["hbm_bytes_per_launch"]
+                t_ = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if t_.get("batch_per_gpu") == B and t_.get("p") == args.p and t_.get("max_iter") == args.max_iter and t_.get("n") == n \
+                        and t_.get("math", "libm_exact") == args.math:
+                    return t_
             except Exception:
-                traffic = None
+                pass
+            return None
+        if same:
+            tj = committed("hbm_traffic.json")
+            traffic = tj["hbm_bytes_per_launch"] if tj else None
+            vj = committed("valu_clock.json")
+            if vj:
+                second = {"kind": "fp64_valu", "issue_frac": vj.get("valu_issue_frac"), "clock_ghz": vj.get("clock_ghz"),
+                          "insts_per_edge_iter": vj.get("valu_insts_per_edge_iteration"),
+                          "source": "profiles/valu_clock.json (PMC passes of this workload: SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
         res = {
             "metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k" if method_id == 0 else "syndromes_per_sec_DIAGNOSTIC_min_sum",
             "value": total * args.steps / elapsed,
@@ -159,11 +384,12 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: (3,6)-regular LDPC n={n} (m={m}, E={nnz}), {args.bp_method} flooding BP, "
-                            f"max_iter={args.max_iter}, batch={B} syndromes per GPU, BSC p={args.p}, code seed 1, error seed 7",
+                "workload": (f"configs[1]: " if world == 1 else f"configs[3] geometry ({B} syndromes per GPU; N = 8 is configs[3] itself): ")
+                            + f"(3,6)-regular LDPC n={n} (m={m}, E={nnz}), {args.bp_method} flooding BP, "
+                              f"max_iter={args.max_iter}, batch={B} syndromes per GPU, BSC p={args.p}, code seed 1, error seed 7",
                 "batch_per_gpu": B, "global_batch": total, "p": args.p, "max_iter": args.max_iter,
                 "outputs": "decoding u8, log_prob_ratios f64, iterations i32, converge u8" if llr is not None else "no LLR",
-                "parallelism": f"batch-sharded x{world}, one gather of decoded rows" if world > 1 else "single GPU",
+                "parallelism": f"batch-sharded x{world}, one gather of bit-packed decoded rows + flags onto rank 0" if grouped else "single GPU, no process group",
                 "device_math": args.math, "mean_iterations": float(iters.mean()), "converged_fraction": float(conv.mean()),
             },
             "roofline": {
@@ -172,19 +398,33 @@ def main() -> None:
                 "kernel": "bp_decode_kernel (persistent, one workgroup per 64-syndrome tile) + bp_spread_* per-pass launches for the last tiles",
                 "kernel_ms": k_ms, "kernel_ms_persistent": pers_ms, "kernel_ms_per_pass": spread_ms,
                 "algorithmic_bytes_per_launch": alg,
-                "note": "one decode = the whole batch; algorithmic bytes = sum over syndromes of iters_run*4*E*8 + (m+n+8n+5); "
+                "second_bound": second,
+                "note": "one decode = the whole batch of this rank; algorithmic bytes = sum over syndromes of iters_run*4*E*8 + (m+n+8n+5); "
                         "kernel_ms = HIP events on the launch stream around all BP kernels of the decode (the persistent kernel "
                         "hands its last <= 256 tiles to per-pass launches: compare kernel_ms_persistent with rocprofv3's "
-                        "bp_decode_kernel average and kernel_ms_per_pass with the sum of the bp_spread_* kernels); traffic = "
-                        "PMC HBM bytes of the same kernels (profiles/hbm_traffic.json)",
+                        "bp_decode_kernel average and kernel_ms_per_pass with the sum of the bp_spread_* kernels); traffic and "
+                        "second_bound = PMC counters of the same kernels from the committed profile run (profiles/), not of this run",
             },
         }
+        if grouped:
+            res["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                           "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                           "devices": [torch.cuda.get_device_name(local_rank)], "launcher": "torch.distributed.run"}
+            res["per_rank"] = {"kernel_ms": [r[0] for r in per_rank], "gather_ms": [r[1] for r in per_rank],
+                               "mean_iterations": [r[3] for r in per_rank],
+                               "parity_ok": [bool(r[2]) for r in per_rank], "parity_rows_per_rank": rank_rows,
+                               "parity_all_ranks": bool(all(r[2] for r in per_rank)),
+                               "parity_note": "every rank: decisions, iterations, converge flags bit-exact and LLR <= 1e-5 vs the CPU checker on "
+                                              "random rows of its own shard; rank 0 also checks that its rows came back unchanged through the gather"}
+            res["gather"] = {"ms": g_ms, "bytes_to_rank0": (world - 1) * B * ((n + 7) // 8 + 5),
+                             "rows_on_rank0": int(gathered["dec_b8"].shape[0]) if gathered.get("dec_b8") is not None else 0}
+            if not res["per_rank"]["parity_all_ranks"]:
+                res["parity_failed"] = True
         # ---- CPU baseline + parity gate on a bounded sample of THIS batch (rank 0, N = 1 only) ----
         if world == 1 and args.cpu_sample != 0:
-            from oracle import cpu_bench  # checker / baseline only
+            from oracle import llr_close  # checker only
             from ldpc_amd.noise_models import generate_bsc_batch
-            cores = os.cpu_count() or 1
-            sample = args.cpu_sample if args.cpu_sample > 0 else min(B, max(1024, 4 * cores))
+            sample = args.cpu_sample if args.cpu_sample > 0 else min(B, 1024)
             # the device shot generator against its host twin on the first rows ...
             head = min(B, 64)
             err = generate_bsc_batch(n, args.p, 7, 0, head)
@@ -193,16 +433,11 @@ def main() -> None:
             # ... and the decoder against the CPU reference on a random subset of the timed batch
             rows = np.sort(np.random.default_rng(12345).choice(B, size=sample, replace=False))
             rows_t = torch.from_numpy(rows).to(dev)
-            s_host = synd[rows_t].cpu().numpy()
-            cpu, (cd, cl, ci, cc) = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, s_host, cores=cores)
-            one, _ = cpu_bench.run(h, args.p, args.max_iter, args.bp_method, alpha, s_host[:6], cores=1)  # (i) one thread alone
-            cpu["single_thread"] = {"value": one["value"], "unit": "syndromes/s", "sample": one["sample"]}
+            cpu, (cd, cl, ci, cc) = cpu_baseline(h, args.p, args.max_iter, args.bp_method, alpha, synd[rows_t].cpu().numpy())
             gd = dec[rows_t].cpu().numpy()
             ok = bool(np.array_equal(gd, cd) and np.array_equal(iters[rows], ci) and np.array_equal(conv[rows], cc))
             if llr is not None:
-                gl = llr[rows_t].cpu().numpy()
-                from oracle import llr_close
-                ok = ok and llr_close(gl, cl, rtol=1e-5)
+                ok = ok and llr_close(llr[rows_t].cpu().numpy(), cl, rtol=1e-5)
             cpu["parity_vs_gpu"] = {"syndromes": int(sample), "subset": "random rows of the timed batch (seed 12345)",
                                     "hard_decisions_iters_converge_exact_llr_1e-5": ok}
             res["cpu_baseline"] = cpu
@@ -210,8 +445,19 @@ def main() -> None:
                 res["parity_failed"] = True
         else:
             res["cpu_baseline"] = None
+        if world == 1 and args.secondary and method_id == 0:
+            eng.close()
+            del synd, dec, llr, out
+            torch.cuda.empty_cache()
+            try:
+                res["secondary"] = secondary_configs(dev, max(1, args.steps))
+                if not all(e["parity_vs_oracle"] for e in res["secondary"]):
+                    res["parity_failed"] = True
+            except Exception as exc:  # the headline line must not be lost to a secondary config
+                res["secondary"] = {"error": repr(exc)[:300]}
         print(json.dumps(res))
-    if world > 1:
+    if grouped:
+        dist.barrier()
         dist.destroy_process_group()
 
 

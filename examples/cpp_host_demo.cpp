@@ -62,6 +62,39 @@ int main() {
         }
         if (dec.soft_syndrome.size() != 4 || dec.soft_syndrome[1] < 8.16 || dec.soft_syndrome[1] > 8.17) { ++bad; std::printf("soft_syndrome member not filled\n"); }
     }
+    {   // one object over several GPUs (device_ids; here GPU 0 twice, so that a one-GPU machine runs the sharded path too,
+        // and every visible GPU when there are more): a batch of 300 rows gives what the single-GPU object gives
+        int ngpu = 0;
+        {
+            ldpc_hip_bp_multi *probe = nullptr;
+            ldpc_hip_bp_desc d{m, n, (int32_t)ci.size(), rp.data(), ci.data(), nullptr, n, 0, 1.0, -1};
+            std::vector<double> p(n, 0.1);
+            d.channel_probs = p.data();
+            int32_t ids[64];
+            for (ngpu = 0; ngpu < 64; ++ngpu) {  // how many devices does the library see?
+                ids[0] = ngpu;
+                if (ldpc_hip_bp_multi_create(&d, ids, 1, &probe) != LDPC_HIP_OK) break;
+                ldpc_hip_bp_multi_destroy(probe);
+            }
+        }
+        std::vector<uint8_t> flat;
+        for (int k = 0; k < 300; ++k) flat.insert(flat.end(), syndromes[(size_t)(k * 7 % 5)].begin(), syndromes[(size_t)(k * 7 % 5)].end());
+        ldpc_hip::BpDecoder one(m, n, rp, ci, std::vector<double>(n, 0.1), n, ldpc_hip::PRODUCT_SUM, 1.0);
+        if (!one.decode_batch(flat.data(), 300)) { std::printf("batch failed: %s\n", one.last_error.c_str()); return 2; }
+        std::vector<std::vector<int>> sets{{0, 0}, {0, 0, 0}};
+        if (ngpu > 1) { std::vector<int> all; for (int g = 0; g < ngpu; ++g) all.push_back(g); sets.push_back(all); }
+        for (auto &ids : sets) {
+            ldpc_hip::BpDecoder many(m, n, rp, ci, std::vector<double>(n, 0.1), n, ldpc_hip::PRODUCT_SUM, 1.0, -1, ids);
+            if (many.device_count() != (int)ids.size()) { ++bad; std::printf("device_count\n"); }
+            if (!many.decode_batch(flat.data(), 300)) { std::printf("multi-GPU batch failed: %s\n", many.last_error.c_str()); return 2; }
+            if (many.decoding_batch != one.decoding_batch || many.log_prob_ratios_batch != one.log_prob_ratios_batch ||
+                many.iterations_batch != one.iterations_batch || many.converge_batch != one.converge_batch) {
+                ++bad;
+                std::printf("device_ids of %zu entries: results differ from the single-GPU object\n", ids.size());
+            }
+        }
+        std::printf("multi-GPU object: %d GPU(s) visible, %zu device lists checked\n", ngpu, sets.size());
+    }
     std::printf(bad ? "FAIL (%d)\n" : "cpp_host_demo: all reference known answers reproduced (PASS)\n", bad);
     return bad ? 1 : 0;
 }

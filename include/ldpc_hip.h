@@ -17,7 +17,11 @@
  *   - the caller owns every buffer it passes; the library owns device memory, streams and events
  *     inside the handle.  Data pointers may be host or device pointers (detected per call).
  *   - a handle is single-consumer, like the reference object (its messages live inside H,
- *     bp.hpp:42-48); distinct handles are independent.  One handle lives on one GPU.
+ *     bp.hpp:42-48); distinct handles are independent.  An ldpc_hip_bp handle lives on one GPU; an
+ *     ldpc_hip_bp_multi handle (end of this file) shards a batch over several GPUs of the node.
+ *   - a handle owns ONE workspace and launches on ONE stream at a time (ldpc_hip_bp_set_stream).  The
+ *     *_async entry points only queue work; queue the next call on the same stream, or change the stream
+ *     first -- ldpc_hip_bp_set_stream orders the new stream after everything the handle has queued so far.
  */
 #ifndef LDPC_HIP_H
 #define LDPC_HIP_H
@@ -109,7 +113,12 @@ int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t b
                              uint8_t *decoding, double *llr, int32_t *iterations,
                              uint8_t *converge);
 
-/* Same, but only enqueues on the launch stream; all pointers must be device pointers. */
+/* Same, but only enqueues on the launch stream and returns without waiting for the device (no host synchronisation:
+ * the number of tiles the streaming kernel hands to the per-pass kernels stays on the device, and the per-pass rounds
+ * are queued for all of max_iter -- a host-mapped flag the device sets when nothing is left merely lets the host stop
+ * queueing early).  All pointers must be device pointers.  Exceptions: a batch that does not fit the workspace in one
+ * piece (> 2 097 152 syndromes, or device memory) waits between pieces; the repacked schedules (ldpc_hip_bp_set_repack)
+ * wait where noted there. */
 int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
                                    uint8_t *decoding, double *llr, int32_t *iterations,
                                    uint8_t *converge);
@@ -262,9 +271,7 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
  * refuse to converge, a tiny batch, or the reference's default max_iter = n) those tiles park their state and
  * their remaining iterations run as per-pass launches (check pass, bit pass, syndrome test, bookkeeping) spread
  * over the whole chip; a batch of no more than `threshold_tiles` tiles runs that way from the first iteration.
- * -1 = automatic (256 tiles, default), 0 = off.  Results are identical.  With the hand-off enabled
- * decode_batch_async waits once for the persistent kernel (it needs the number of parked tiles) when the batch
- * is larger than the threshold. */
+ * -1 = automatic (256 tiles, default), 0 = off.  Results are identical.  The hand-off costs no host synchronisation. */
 int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
 
 /* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)
@@ -282,6 +289,35 @@ int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);
 
 const char *ldpc_hip_last_error(void);
 const char *ldpc_hip_version(void);
+
+/*
+ * ---- several GPUs, one process --------------------------------------------------------------------------------
+ * "device_ids[ndev] ... the library owns device memory, streams and the inter-GPU traffic
+ * inside the handle".  ldpc_hip_bp_multi_create builds one ordinary handle per entry of device_ids (a device may be
+ * listed more than once: two handles then share that GPU); ldpc_hip_bp_multi_decode_batch cuts the batch into
+ * contiguous row ranges on 64-syndrome boundaries, decodes every range on its GPU concurrently (one host thread per
+ * GPU for the duration of the call) and returns when all results are in the caller's buffers -- row b of every output
+ * is what the single-GPU call gives for row b, bit for bit.  Buffers: all host memory (every GPU copies its own rows
+ * over its own PCIe link), or all on ONE GPU (the others receive their rows by peer copy over xGMI and send their hard
+ * decisions back bit-packed, 1/8 of the bytes, to be unpacked on that GPU when it is one of device_ids).
+ * with_osd: -1 = ldpc_hip_bp_decode_batch, 0 = ldpc_hip_bposd0_decode_batch, 1 = ldpc_hip_bposd_decode_batch.
+ * Settings (channel, parameters, schedule, OSD, math ...) are applied per GPU through ldpc_hip_bp_multi_handle(mh, i),
+ * i < ldpc_hip_bp_multi_devices(mh): the setters above, unchanged.  Multi-PROCESS sharding (one rank per GPU, RCCL
+ * gather of the packed rows) is ldpc_amd/sharding.py + bench.py; the reference has neither (bp.hpp:129-140).
+ */
+typedef struct ldpc_hip_bp_multi ldpc_hip_bp_multi;
+int ldpc_hip_bp_multi_create(const ldpc_hip_bp_desc *desc /* desc->device is ignored */, const int32_t *device_ids,
+                             int32_t ndev, ldpc_hip_bp_multi **out);
+void ldpc_hip_bp_multi_destroy(ldpc_hip_bp_multi *mh);
+int32_t ldpc_hip_bp_multi_devices(const ldpc_hip_bp_multi *mh);
+ldpc_hip_bp *ldpc_hip_bp_multi_handle(ldpc_hip_bp_multi *mh, int32_t i);
+int ldpc_hip_bp_multi_decode_batch(ldpc_hip_bp_multi *mh, int32_t with_osd, const uint8_t *syndromes, int64_t batch,
+                                   uint8_t *decoding, double *llr, int32_t *iterations, uint8_t *converge);
+/* BP kernel time of the last decode on every GPU (ldpc_hip_bp_last_kernel_ms per handle), ms_per_device[ndev] */
+int ldpc_hip_bp_multi_last_kernel_ms(ldpc_hip_bp_multi *mh, float *ms_per_device);
+/* Testing aid: force != 0 routes device buffers through the peer-copy / bit-packed path even on the GPU they live on
+ * (so that the path can be exercised on a one-GPU machine, e.g. with device_ids = {0, 0}). */
+int ldpc_hip_bp_multi_set_staging(ldpc_hip_bp_multi *mh, int32_t force);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,7 @@ public:
     // H as CSR with strictly ascending column indices per row (what insert_entry maintains, sparse_matrix_base.hpp:423-482)
     BpDecoder(int m, int n, const std::vector<int32_t> &csr_row_ptr, const std::vector<int32_t> &csr_col_idx,
               std::vector<double> channel_probs, int max_iter = 0, BpMethod method = PRODUCT_SUM,
-              double min_sum_scaling_factor = 0.625, int device = -1)
+              double min_sum_scaling_factor = 0.625, int device = -1, const std::vector<int> &device_ids = {})
         : channel_probabilities(std::move(channel_probs)), check_count(m), bit_count(n),
           maximum_iterations(max_iter > 0 ? max_iter : n), bp_method(method), ms_scaling_factor(min_sum_scaling_factor) {
         if ((int)channel_probabilities.size() != n)  // bp.hpp:103-106
@@ -64,14 +64,20 @@ public:
         d.channel_probs = channel_probabilities.data();
         d.max_iter = maximum_iterations; d.bp_method = (int32_t)bp_method; d.ms_scaling_factor = ms_scaling_factor;
         d.device = device;
-        if (ldpc_hip_bp_create(&d, &h_) != LDPC_HIP_OK) throw std::runtime_error(ldpc_hip_last_error());
+        if (!device_ids.empty()) {
+            // several GPUs behind one object: decode_batch shards the rows over them (ldpc_hip_bp_multi, ldpc_hip.h);
+            // single-vector calls and H r run on the first one
+            std::vector<int32_t> ids(device_ids.begin(), device_ids.end());
+            if (ldpc_hip_bp_multi_create(&d, ids.data(), (int32_t)ids.size(), &mh_) != LDPC_HIP_OK) throw std::runtime_error(ldpc_hip_last_error());
+            h_ = ldpc_hip_bp_multi_handle(mh_, 0);
+        } else if (ldpc_hip_bp_create(&d, &h_) != LDPC_HIP_OK) throw std::runtime_error(ldpc_hip_last_error());
         synced_probs_ = channel_probabilities;
         decoding.assign((size_t)n, 0);
         log_prob_ratios.assign((size_t)n, 0.0);
     }
     BpDecoder(const BpDecoder &) = delete;
     BpDecoder &operator=(const BpDecoder &) = delete;
-    ~BpDecoder() { ldpc_hip_bp_destroy(h_); }
+    ~BpDecoder() { if (mh_) ldpc_hip_bp_multi_destroy(mh_); else ldpc_hip_bp_destroy(h_); }
 
     // one input vector: ldpc::bp::BpDecoder::decode (bp.hpp:159-190).  A received vector r (bp_input_type
     // RECEIVED_VECTOR, or AUTO and n entries) is turned into the syndrome H r on the device, decoded, and XORed back in.
@@ -120,7 +126,7 @@ public:
     bool decode_batch(const uint8_t *syndromes, int64_t batch, bool want_llr = true, bool osd = false) {
         if (!sync_()) return false;
         if (osd) {
-            last_status = ldpc_hip_bp_set_osd(h_, osd_method, osd_order);
+            last_status = each_([&](ldpc_hip_bp *h) { return ldpc_hip_bp_set_osd(h, osd_method, osd_order); });
             if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
         }
         decoding_batch.assign((size_t)batch * bit_count, 0);
@@ -128,23 +134,27 @@ public:
         iterations_batch.assign((size_t)batch, 0);
         converge_batch.assign((size_t)batch, 0);
         auto fn = osd ? ldpc_hip_bposd_decode_batch : ldpc_hip_bp_decode_batch;
-        last_status = fn(h_, syndromes, batch, decoding_batch.data(), want_llr ? log_prob_ratios_batch.data() : nullptr,
-                         iterations_batch.data(), converge_batch.data());
+        double *llr_out = want_llr ? log_prob_ratios_batch.data() : nullptr;
+        last_status = mh_ ? ldpc_hip_bp_multi_decode_batch(mh_, osd ? 1 : -1, syndromes, batch, decoding_batch.data(), llr_out,
+                                                           iterations_batch.data(), converge_batch.data())
+                          : fn(h_, syndromes, batch, decoding_batch.data(), llr_out, iterations_batch.data(), converge_batch.data());
         if (last_status != LDPC_HIP_OK) last_error = ldpc_hip_last_error();
         return last_status == LDPC_HIP_OK;
     }
 
     ldpc_hip_bp *handle() { return h_; }
+    ldpc_hip_bp_multi *multi_handle() { return mh_; }  // null unless constructed with device_ids
+    int device_count() const { return mh_ ? (int)ldpc_hip_bp_multi_devices(mh_) : 1; }
 
 private:
     // the reference lets callers write the public members between decodes; push them to the device handle
     bool sync_() {
         if (channel_probabilities != synced_probs_) {
-            last_status = ldpc_hip_bp_set_channel(h_, channel_probabilities.data(), (int32_t)channel_probabilities.size());
+            last_status = each_([&](ldpc_hip_bp *h) { return ldpc_hip_bp_set_channel(h, channel_probabilities.data(), (int32_t)channel_probabilities.size()); });
             if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
             synced_probs_ = channel_probabilities;
         }
-        last_status = ldpc_hip_bp_set_params(h_, maximum_iterations, (int32_t)bp_method, ms_scaling_factor);
+        last_status = each_([&](ldpc_hip_bp *h) { return ldpc_hip_bp_set_params(h, maximum_iterations, (int32_t)bp_method, ms_scaling_factor); });
         if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
         if ((int)schedule != synced_schedule_ || serial_schedule_order != synced_order_) {
             if (!serial_schedule_order.empty() && (int)serial_schedule_order.size() != bit_count) {
@@ -152,7 +162,7 @@ private:
                 return false;
             }
             std::vector<int32_t> order(serial_schedule_order.begin(), serial_schedule_order.end());
-            last_status = ldpc_hip_bp_set_schedule(h_, (int32_t)schedule, order.empty() ? nullptr : order.data());
+            last_status = each_([&](ldpc_hip_bp *h) { return ldpc_hip_bp_set_schedule(h, (int32_t)schedule, order.empty() ? nullptr : order.data()); });
             if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
             synced_schedule_ = (int)schedule;
             synced_order_ = serial_schedule_order;
@@ -160,7 +170,17 @@ private:
         return true;
     }
     void fail_(int code, const char *msg) { last_status = code; last_error = msg; }
+    template <class F>
+    int each_(F f) {  // a setter on every GPU's handle
+        const int nd = device_count();
+        for (int i = 0; i < nd; ++i) {
+            const int rc = f(mh_ ? ldpc_hip_bp_multi_handle(mh_, i) : h_);
+            if (rc != LDPC_HIP_OK) return rc;
+        }
+        return LDPC_HIP_OK;
+    }
     ldpc_hip_bp *h_ = nullptr;
+    ldpc_hip_bp_multi *mh_ = nullptr;
     std::vector<double> synced_probs_;
     int synced_schedule_ = (int)PARALLEL;
     std::vector<int> synced_order_;

@@ -56,7 +56,9 @@ def _check_pcm_type(pcm):
 def _ingest(pcm) -> scipy.sparse.csr_matrix:
     """Py2BpSparse (pyx:9-49): validate and return canonical CSR (sorted columns, ones only)."""
     _check_pcm_type(pcm)
-    h = scipy.sparse.csr_matrix(convert_to_binary_sparse(pcm))
+    # (a copy: the normalisation below must not reach into the caller's arrays -- the reference only reads pcm.nonzero();
+    # like the reference's helper, convert_to_binary_sparse itself drops explicit zeros of a sparse input in place)
+    h = scipy.sparse.csr_matrix(convert_to_binary_sparse(pcm), copy=True)
     h.sum_duplicates()  # insert_entry returns the existing entry for a repeated coordinate
     h.data[:] = 1       # (sparse_matrix_base.hpp:437-440), so duplicates collapse to a single one
     h.sort_indices()
@@ -94,6 +96,12 @@ class BpDecoderBase:
         self._engine = None
         self._engine_key = None
         self._device = kwargs.get("_device", -1)
+        # additive: device_ids=[...] shards every decode_batch over those GPUs inside this process (ldpc_hip_bp_multi)
+        self._device_ids = kwargs.get("device_ids", None)
+        if self._device_ids is not None:
+            self._device_ids = [int(d) for d in self._device_ids]
+            if not self._device_ids or any(d < 0 for d in self._device_ids):
+                raise ValueError("device_ids must be a non-empty list of GPU ordinals")
         # "cython": NumPy inputs go through the Cython binding of the C++ host class (ldpc_amd/bp_decoder/_bp_core.pyx,
         # the reference's own binding style); "ctypes": everything through ldpc_amd/engine.py.  Same C ABI underneath.
         self._backend = kwargs.get("_backend", None)
@@ -325,11 +333,15 @@ class BpDecoderBase:
     # ---- device engine --------------------------------------------------------------------------
     def _get_engine(self):
         """Create / refresh the HIP handle lazily so that construction and validation need no GPU."""
-        from ldpc_amd.engine import HipBpEngine
+        from ldpc_amd.engine import HipBpEngine, HipBpMultiEngine
         if self._engine is None:
-            self._engine = HipBpEngine(self._h.indptr, self._h.indices, self.n, self._channel_probs,
-                                       self._max_iter, self._bp_method, self._ms_scaling_factor,
-                                       device=self._device)
+            if self._device_ids is not None:
+                self._engine = HipBpMultiEngine(self._h.indptr, self._h.indices, self.n, self._channel_probs,
+                                                self._max_iter, self._bp_method, self._ms_scaling_factor, self._device_ids)
+            else:
+                self._engine = HipBpEngine(self._h.indptr, self._h.indices, self.n, self._channel_probs,
+                                           self._max_iter, self._bp_method, self._ms_scaling_factor,
+                                           device=self._device)
             self._channel_dirty = False
             self._engine_key = (self._max_iter, self._bp_method, self._ms_scaling_factor)
         if self._channel_dirty:  # the reference re-reads channel_probabilities on every decode (bp.hpp:149-151)
@@ -350,7 +362,7 @@ class BpDecoderBase:
 
     def _get_cy(self):
         """The Cython-bound C++ host object (None if the extension is not built or the ctypes backend was requested)."""
-        if self._backend == "ctypes":
+        if self._backend == "ctypes" or self._device_ids is not None:
             return None
         if self._cy is None:
             try:
@@ -410,7 +422,7 @@ class BpDecoder(BpDecoderBase):
         (pinned by python_test/test_bp_decoder.py:121-136).
         """
         for key in kwargs.keys():  # pyx:625-627
-            if key not in ["channel_probs", "_device", "_backend"]:
+            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
                 raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,

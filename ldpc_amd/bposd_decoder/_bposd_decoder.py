@@ -23,7 +23,7 @@ class BpOsdDecoder(BpDecoderBase):
                  serial_schedule_order=_UNSET, osd_method=0, osd_order: int = 0, input_vector_type: str = "syndrome",
                  **kwargs):
         for key in kwargs.keys():  # pyx:60-62 (the reference's message says BpDecoder here too)
-            if key not in ["channel_probs", "_device", "_backend"]:
+            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
                 raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
@@ -114,17 +114,27 @@ class BpOsdDecoder(BpDecoderBase):
             return np.zeros(self.n, dtype=syndrome.dtype)
         self._require_supported()
         dec, llr, it, cv = self._decode_osd(vec[None, :])
-        self._log_prob_ratios = llr[0]
-        self._iterations = int(it[0])
-        self._converge = bool(cv[0])
-        if self._converge:
-            self._bp_decoding = dec[0].copy()
-            self._decoding = dec[0].copy()
-        else:
-            self._osdw_decoding = dec[0].copy()
-            self._osd0_decoding = None  # evaluated on demand (osd0_decoding) when the order is > 0
-            self._last_syndrome = vec.copy()
+        self._remember(vec, dec[0], llr[0], it[0], cv[0])
         return dec[0].astype(syndrome.dtype)
+
+    def _remember(self, synd_row, dec_row, llr_row, it, cv):
+        """Scalar state after a row that ran BP (bpd.decoding / log_prob_ratios / iterations / converge and the osdD results,
+        pyx:125-136, 236-299).  ``bp_decoding`` is BP's own hard decision whether or not it converged: the device hands back
+        the OSD solution for an unconverged row, BP's decision is ``llr <= 0`` (bp.hpp:290) of the log-ratios it returns."""
+        self._iterations = int(it)
+        self._converge = bool(cv)
+        if llr_row is not None:
+            self._log_prob_ratios = np.asarray(llr_row).copy()
+            self._bp_decoding = (self._log_prob_ratios <= 0).astype(np.uint8)
+        elif self._converge:
+            self._bp_decoding = np.asarray(dec_row, np.uint8).copy()
+        if self._converge:
+            self._bp_decoding = np.asarray(dec_row, np.uint8).copy()
+            self._decoding = self._bp_decoding.copy()
+        else:
+            self._osdw_decoding = np.asarray(dec_row, np.uint8).copy()
+            self._osd0_decoding = None  # evaluated on demand (osd0_decoding) when the order is > 0
+            self._last_syndrome = np.asarray(synd_row, np.uint8).copy()
 
     def decode_batch(self, syndromes, want_log_prob_ratios: bool = True):
         """Every row through BP (+ OSD-0 where BP does not converge) in one call; row b == ``decode(syndromes[b])``."""
@@ -155,6 +165,10 @@ class BpOsdDecoder(BpDecoderBase):
         if llr is not None:
             llr[zero] = 0.0
         self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv, it, llr
+        ran = np.flatnonzero(~zero)
+        if len(ran):  # scalar members describe the last row that ran BP, as after the reference's per-row loop
+            last = int(ran[-1])
+            self._remember(vec[last], dec[last], None if llr is None else llr[last], it[last], cv[last])
         if len(vec):
             self._converge = bool(cv[-1])
         return dec.astype(dtype)

@@ -30,6 +30,22 @@ class _WindowBpOsd:
         occupied = np.diff(round_dcm.tocsc().indptr) > 0
         self.cols = np.flatnonzero(occupied) if zero_order else np.arange(self.n)
         self.static_ones = np.flatnonzero(~occupied & (weights >= 0.5)) if zero_order else np.zeros(0, np.int64)
+        # options that depend on n are resolved against the FULL width the reference's decoder sees, then restricted:
+        # max_iter = 0 means n_full iterations (pyx:357); a serial_schedule_order lists all n_full bits, of which the
+        # occupied ones keep their relative order (an empty column has no entry to update, bp.hpp:451-545)
+        config = dict(config)
+        if len(self.cols) != self.n:
+            if int(config.get("max_iter", 0) or 0) == 0:
+                config["max_iter"] = int(self.n)
+            order = config.get("serial_schedule_order", None)
+            if order is not None:
+                order = np.asarray(order, dtype=np.int64)
+                if len(order) != self.n:
+                    raise ValueError("serial_schedule_order must have length equal to the block length of the code.")
+                new_index = np.full(self.n, -1, np.int64)
+                new_index[self.cols] = np.arange(len(self.cols))
+                kept = new_index[order]
+                config["serial_schedule_order"] = kept[kept >= 0]
         self.inner = BpOsdDecoder(round_dcm[:, self.cols], error_channel=list(weights[self.cols]), **config)
         self._cols_dev = None
 

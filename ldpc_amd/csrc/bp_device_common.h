@@ -41,7 +41,7 @@ struct BpArgs {
     uint8_t *conv;                      // [batch] or nullptr
     // hand-off of straggler tiles to the chip-wide per-pass kernels (see bp_spread_*): 0 = never
     struct TileState *state;            // [tiles]
-    unsigned *counters;                 // [0] tiles finished by the persistent kernel, [1] tiles handed off
+    unsigned *counters;                 // [0] tiles finished by the persistent kernel, [1] tiles handed off, [2] handed-off tiles still running
     int32_t *handoff_list;              // [tiles] ids of handed-off tiles
     int32_t total_tiles, handoff_threshold;
 };

@@ -39,6 +39,7 @@
 //   bp_serial_kernels.h  bp_serial_kernel, bp_softinfo_kernel   serial schedule, soft-syndrome serial min-sum
 //   osd_kernels.h        osd0[_reg]_kernel, osdw[_reg]_kernel, osd_big_kernel   OSD-0 / OSD-E / OSD-CS post-processing
 //   io_kernels.h         pack / unpack / transpose, H v, b8 shot data, synthetic BSC shots
+//   multi_device.h       ldpc_hip_bp_multi_*: a batch sharded over several GPUs inside one process (host code only)
 
 #include "bp_device_common.h"
 #include "bp_stream_kernel.h"
@@ -111,6 +112,11 @@ struct ldpc_hip_bp {
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
+    // Per-pass rounds are queued without waiting for the device.  The kernel that finalises the last running tile writes
+    // the decode's sequence number into this host-mapped word; the host merely LOOKS at it before queueing the next round
+    // (no synchronisation) and stops queueing once it matches -- rounds queued past that point find nothing to do.
+    unsigned *h_flag = nullptr, *d_flag = nullptr;
+    unsigned flag_seq = 0;
     int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial (fixed order), 1 parallel
     int32_t *d_csc_row = nullptr, *d_order = nullptr;
     bool custom_order = false;
@@ -127,6 +133,8 @@ struct ldpc_hip_bp {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: end of the persistent kernel, when one ran
+    hipEvent_t ev_done = nullptr;  // end of the last call that queued work on `stream` (orders a change of stream after it)
+    bool work_queued = false;
     bool timed = false, timed_mid = false;
     float accumulated_ms = 0.f, accumulated_persistent_ms = 0.f;
 
@@ -164,6 +172,23 @@ static int upload_priors(ldpc_hip_bp *h) {
     for (int j = 0; j < h->n; ++j) llr0[(size_t)j] = std::log(1 / h->channel_probs[(size_t)j]);  // osd.hpp:134
     HIPCHK(hipMemcpy(h->d_osd_wt, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
     return 0;
+}
+
+// grid of the one-dimensional element-wise kernels (io_kernels.h): they run grid-stride loops, so the grid is capped --
+// item counts like batch * n exceed what one launch dimension can carry for large batches of large codes
+static dim3 flat_grid(size_t items) {
+    size_t blocks = (items + 255) / 256;
+    if (blocks > (1u << 22)) blocks = 1u << 22;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+// end of a call that only queued work: remembered so that a later change of stream is ordered after it (set_stream)
+static int mark_queued(ldpc_hip_bp *h, int rc) {
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev_done, h->stream));
+    h->work_queued = true;
+    return LDPC_HIP_OK;
 }
 
 static bool is_device_ptr(const void *p) {
@@ -268,6 +293,9 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_mid);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_hist);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { h->h_flag[0] = 0; e = hipHostGetDevicePointer((void **)&h->d_flag, h->h_flag, 0); }
     if (e != hipSuccess) {
         ldpc_hip_bp_destroy(h);
         return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -299,6 +327,8 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->h_hist) (void)hipHostFree(h->h_hist);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -328,8 +358,16 @@ int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method, 
 
 int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *s) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (s == LDPC_HIP_STREAM_LEGACY_DEFAULT) h->stream = nullptr;  // hipStream_t 0: the device's legacy default stream
-    else h->stream = s ? (hipStream_t)s : h->own_stream;
+    hipStream_t ns;
+    if (s == LDPC_HIP_STREAM_LEGACY_DEFAULT) ns = nullptr;  // hipStream_t 0: the device's legacy default stream
+    else ns = s ? (hipStream_t)s : h->own_stream;
+    if (ns != h->stream && h->work_queued) {
+        // The handle has ONE workspace: work queued on the old stream (an *_async decode) may still be using it, so
+        // everything queued on the new stream from now on is ordered after it.
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamWaitEvent(ns, h->ev_done, 0));
+    }
+    h->stream = ns;
     return LDPC_HIP_OK;
 }
 
@@ -669,7 +707,7 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
         (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
     const int32_t *list = (const int32_t *)h->osd_list.p;
-    auto grid = [](size_t items) { return dim3((unsigned)((items + 255) / 256)); };
+    auto grid = [](size_t items) { return flat_grid(items); };
     if (h->m > 0)
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * h->m), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
     HIPCHK(hipGetLastError());
@@ -1198,15 +1236,20 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         HIPCHK(hipEventRecord(h->ev0, st));
         SpreadArgs sa = {};
         sa.bp = a;
-        unsigned parked = 0;
+        sa.host_flag = h->d_flag;
+        sa.seq = ++h->flag_seq ? h->flag_seq : ++h->flag_seq;  // never 0 (the word's initial value)
+        // per-pass rounds: `grid_tiles` workgroup rows; how many of them have a tile is known to the host only when the
+        // batch skips the persistent kernel (sa.n_tiles >= 0), otherwise the kernels read it from counters[1]
+        unsigned grid_tiles = 0;
         int first_round = 1;  // a tile parked by the persistent kernel has completed >= 1 iteration
         if (handoff > 0 && tiles <= handoff && h->max_iter > 1) {
             // so few tiles that they would each sit on one compute unit: per-pass launches from the start
-            parked = (unsigned)tiles;
-            sa.n_tiles = (int32_t)parked;
+            grid_tiles = (unsigned)tiles;
+            sa.n_tiles = (int32_t)tiles;
+            sa.nodes = tiles <= 8 ? 1 : 4;
             first_round = 0;
-            hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((parked + 255) / 256), dim3(256), 0, st, sa);
-            const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), parked);  // (a grid dimension must not be 0: empty matrices)
+            hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((grid_tiles + 255) / 256), dim3(256), 0, st, sa);
+            const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), grid_tiles);  // (a grid dimension must not be 0: empty matrices)
             if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
             else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), gi, dim3(256), 0, st, sa);
             else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
@@ -1217,37 +1260,33 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             HIPCHK(hipEventRecord(h->ev_mid, st));
             h->timed_mid = true;
             if (handoff > 0 && h->max_iter > 1) {
-                // tiles parked by the persistent kernel: the host needs their number (this is the one point where the
-                // otherwise asynchronous call waits for the device)
-                HIPCHK(hipMemcpyAsync(h->h_counters, h->counter.p, 16, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                parked = h->h_counters[1];
+                // the persistent kernel parks at most `handoff` tiles (it starts parking when that many are unfinished);
+                // how many it did park stays on the device
+                grid_tiles = (unsigned)(tiles < handoff ? tiles : handoff);
+                sa.n_tiles = -1;
+                sa.nodes = 4;
             }
         }
-        if (parked > 0) {
-            // finish the parked tiles with chip-wide per-pass launches: check, bit, syndrome test, bookkeeping
-            unsigned *live = (unsigned *)h->counter.p + 2;
-            h->h_counters[3] = parked;
-            HIPCHK(hipMemcpyAsync(live, &h->h_counters[3], sizeof(unsigned), hipMemcpyHostToDevice, st));
-            sa.n_tiles = (int32_t)parked;
-            sa.nodes = parked <= 8 ? 1 : 4;
+        if (grid_tiles > 0) {
+            // finish the parked tiles with chip-wide per-pass launches: check, bit, syndrome test, bookkeeping.  Every
+            // round is queued at once; the host never waits.  A tile that is final (or a workgroup row without a tile)
+            // leaves each kernel at its first instruction, and once the device has reported "nothing left" through
+            // the host-mapped flag the host stops queueing -- which only matters when max_iter is far larger than
+            // the iterations needed (the reference's default max_iter = n).
             spread_kernel_t kc, kb;
             pick_spread(h, kc, kb);
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
-            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), parked), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), parked);
-            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), parked), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), parked);
+            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
+            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
             const int rounds = h->max_iter - first_round;
+            const volatile unsigned *flag = h->h_flag;
             for (int round = 0; round < rounds; ++round) {
+                if (*flag == sa.seq) break;  // a look, not a wait
                 sa.round = round;
                 hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
                 hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
                 hipLaunchKernelGGL(bp_spread_synd_kernel, gs, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(bp_spread_finish_kernel, gf, dim3(256), 0, st, sa, live);
-                if ((round & 7) == 7 && round + 1 < rounds) {  // everything converged early?
-                    HIPCHK(hipMemcpyAsync(&h->h_counters[2], live, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-                    HIPCHK(hipStreamSynchronize(st));
-                    if (h->h_counters[2] == 0) break;
-                }
+                hipLaunchKernelGGL(bp_spread_finish_kernel, gf, dim3(256), 0, st, sa);
             }
             HIPCHK(hipGetLastError());
         }
@@ -1352,7 +1391,7 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
             (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
         const int32_t *list = (const int32_t *)h->osd_list.p;
-        auto grid = [](size_t items) { return dim3((unsigned)((items + 255) / 256)); };
+        auto grid = [](size_t items) { return flat_grid(items); };
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
         HIPCHK(hipGetLastError());
         if ((rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
@@ -1541,7 +1580,7 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int6
     if (batch == 0) return LDPC_HIP_OK;
     if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
     HIPCHK(hipSetDevice(h->device));
-    return bposd_device(h, 1, 0, synd, batch, decoding, llr, iters, conv);
+    return mark_queued(h, bposd_device(h, 1, 0, synd, batch, decoding, llr, iters, conv));
 }
 
 int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
@@ -1581,7 +1620,7 @@ int ldpc_hip_bposd_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64
     if (batch == 0) return LDPC_HIP_OK;
     if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
     HIPCHK(hipSetDevice(h->device));
-    return bposd_device(h, h->osd_method, h->osd_order, synd, batch, decoding, llr, iters, conv);
+    return mark_queued(h, bposd_device(h, h->osd_method, h->osd_order, synd, batch, decoding, llr, iters, conv));
 }
 
 int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch,
@@ -1592,7 +1631,7 @@ int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *synd, int64_t 
     if (!synd || !decoding) return fail(LDPC_HIP_ERR_INVALID, "syndromes and decoding must not be NULL");
     if (batch > (1ll << 40)) return fail(LDPC_HIP_ERR_INVALID, "batch too large");
     HIPCHK(hipSetDevice(h->device));
-    return decode_device(h, synd, batch, decoding, llr, iters, conv);
+    return mark_queued(h, decode_device(h, synd, batch, decoding, llr, iters, conv));
 }
 
 // osd: -1 BP only, 0 BP + OSD-0, 1 BP + the handle's osd_method / osd_order
@@ -1670,7 +1709,7 @@ int ldpc_hip_gf2_mulvec_batch(ldpc_hip_bp *h, const uint8_t *vectors, int64_t ba
     }
     if (h_out) { if ((rc = h->st_synd.ensure(B * m))) return rc; d_out = (uint8_t *)h->st_synd.p; }
     const int64_t total = batch * h->m;
-    hipLaunchKernelGGL(gf2_mulvec_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(gf2_mulvec_kernel, flat_grid((size_t)(total)), dim3(256), 0, h->stream,
                        h->d_row_ptr, h->d_col_idx, h->m, h->n, d_in, batch, d_out);
     HIPCHK(hipGetLastError());
     if (h_out) HIPCHK(hipMemcpyAsync(out, d_out, B * m, hipMemcpyDeviceToHost, h->stream));
@@ -1726,9 +1765,9 @@ int ldpc_hip_pack_b8(ldpc_hip_bp *h, const uint8_t *bytes, int64_t batch, int32_
     if (!is_device_ptr(bytes) || !is_device_ptr(packed)) return fail(LDPC_HIP_ERR_INVALID, "ldpc_hip_pack_b8 takes device pointers");
     HIPCHK(hipSetDevice(h->device));
     const size_t total = (size_t)batch * (size_t)((bits + 7) / 8);
-    hipLaunchKernelGGL(pack_b8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, bytes, batch, bits, packed);
+    hipLaunchKernelGGL(pack_b8_kernel, flat_grid((size_t)(total)), dim3(256), 0, h->stream, bytes, batch, bits, packed);
     HIPCHK(hipGetLastError());
-    return LDPC_HIP_OK;
+    return mark_queued(h, LDPC_HIP_OK);
 }
 
 int ldpc_hip_unpack_b8(ldpc_hip_bp *h, const uint8_t *packed, int64_t batch, int32_t bits, uint8_t *bytes) {
@@ -1739,9 +1778,9 @@ int ldpc_hip_unpack_b8(ldpc_hip_bp *h, const uint8_t *packed, int64_t batch, int
     if (!is_device_ptr(bytes) || !is_device_ptr(packed)) return fail(LDPC_HIP_ERR_INVALID, "ldpc_hip_unpack_b8 takes device pointers");
     HIPCHK(hipSetDevice(h->device));
     const size_t total = (size_t)batch * (size_t)bits;
-    hipLaunchKernelGGL(unpack_b8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, packed, batch, bits, bytes);
+    hipLaunchKernelGGL(unpack_b8_kernel, flat_grid((size_t)(total)), dim3(256), 0, h->stream, packed, batch, bits, bytes);
     HIPCHK(hipGetLastError());
-    return LDPC_HIP_OK;
+    return mark_queued(h, LDPC_HIP_OK);
 }
 
 int ldpc_hip_bp_set_observables(ldpc_hip_bp *h, int32_t k, const int32_t *csr_row_ptr, const int32_t *csr_col_idx) {
@@ -1786,7 +1825,7 @@ int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch,
     if ((rc = h->b8_synd.ensure(B * m ? B * m : 1))) return rc;
     if ((rc = h->b8_dec.ensure(B * n ? B * n : 1))) return rc;
     uint8_t *d_synd = (uint8_t *)h->b8_synd.p, *d_dec = (uint8_t *)h->b8_dec.p;
-    if (m) hipLaunchKernelGGL(unpack_b8_kernel, dim3((unsigned)((B * m + 255) / 256)), dim3(256), 0, h->stream, d_in, batch, h->m, d_synd);
+    if (m) hipLaunchKernelGGL(unpack_b8_kernel, flat_grid((size_t)(B * m)), dim3(256), 0, h->stream, d_in, batch, h->m, d_synd);
     HIPCHK(hipGetLastError());
     const bool h_it = iters && !is_device_ptr(iters), h_cv = conv && !is_device_ptr(conv);
     int32_t *d_it = iters;
@@ -1795,7 +1834,7 @@ int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch,
     if (h_cv) { if ((rc = h->st_conv.ensure(B))) return rc; d_cv = (uint8_t *)h->st_conv.p; }
     if ((rc = with_osd ? bposd_device(h, h->osd_method, h->osd_order, d_synd, batch, d_dec, nullptr, d_it, d_cv)
                        : decode_device(h, d_synd, batch, d_dec, nullptr, d_it, d_cv))) return rc;
-    hipLaunchKernelGGL(zero_shot_shortcut_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, d_in, batch, h->m, h->n,
+    hipLaunchKernelGGL(zero_shot_shortcut_kernel, flat_grid((size_t)(B)), dim3(256), 0, h->stream, d_in, batch, h->m, h->n,
                        d_dec, d_it, d_cv);
     size_t off = 0;
     if ((rc = h->b8_out.ensure(B * (kb + nb) ? B * (kb + nb) : 1))) return rc;
@@ -1804,10 +1843,10 @@ int ldpc_hip_bp_decode_b8(ldpc_hip_bp *h, const uint8_t *dets_b8, int64_t batch,
     if (h_obs) { d_obs = (uint8_t *)h->b8_out.p; off = B * kb; }
     if (h_dec8) d_dec8 = (uint8_t *)h->b8_out.p + off;
     if (obs_b8 && kb)
-        hipLaunchKernelGGL(observables_b8_kernel, dim3((unsigned)((B * kb + 255) / 256)), dim3(256), 0, h->stream,
+        hipLaunchKernelGGL(observables_b8_kernel, flat_grid((size_t)(B * kb)), dim3(256), 0, h->stream,
                            (const int32_t *)h->obs_row_ptr.p, (const int32_t *)h->obs_col_idx.p, h->obs_k, h->n, d_dec, batch, d_obs);
     if (decoding_b8 && nb)
-        hipLaunchKernelGGL(pack_b8_kernel, dim3((unsigned)((B * nb + 255) / 256)), dim3(256), 0, h->stream, d_dec, batch, h->n, d_dec8);
+        hipLaunchKernelGGL(pack_b8_kernel, flat_grid((size_t)(B * nb)), dim3(256), 0, h->stream, d_dec, batch, h->n, d_dec8);
     HIPCHK(hipGetLastError());
     if (h_obs && kb) HIPCHK(hipMemcpyAsync(obs_b8, d_obs, B * kb, hipMemcpyDeviceToHost, h->stream));
     if (h_dec8 && nb) HIPCHK(hipMemcpyAsync(decoding_b8, d_dec8, B * nb, hipMemcpyDeviceToHost, h->stream));
@@ -1832,13 +1871,13 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
     if (h_e) { if ((rc = h->st_misc.ensure(B * n ? B * n : 1))) return rc; d_e = (uint8_t *)h->st_misc.p; }
     if (h->m > 0) {
         const int64_t total = batch * h->m;
-        hipLaunchKernelGGL(gen_bsc_syndromes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL(gen_bsc_syndromes_kernel, flat_grid((size_t)(total)), dim3(256), 0,
                            h->stream, h->d_row_ptr, h->d_col_idx, h->m, h->n, seed, threshold, shot0,
                            batch, d_s);
     }
     if (errors && h->n > 0) {
         const int64_t total = batch * h->n;
-        hipLaunchKernelGGL(gen_bsc_errors_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+        hipLaunchKernelGGL(gen_bsc_errors_kernel, flat_grid((size_t)(total)), dim3(256), 0,
                            h->stream, h->n, seed, threshold, shot0, batch, d_e);
     }
     HIPCHK(hipGetLastError());
@@ -1849,6 +1888,8 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
 }
 
 }  // extern "C"
+
+#include "multi_device.h"  // ldpc_hip_bp_multi_*: one decoder over several GPUs in one process (host code over the entry points above)
 
 #ifdef LDPC_HIP_OSD_CLOCKS
 extern "C" int ldpc_hip_debug_osd_clocks(unsigned long long *out, int reset) {

@@ -10,13 +10,19 @@
 // chip would otherwise idle; each launch handles every parked tile that is still running.
 struct SpreadArgs {
     BpArgs bp;
-    int32_t n_tiles;  // entries of bp.handoff_list
+    int32_t n_tiles;  // entries of bp.handoff_list; < 0: only the device knows (bp.counters[1], left by the persistent kernel)
     int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4 otherwise: amortises the table load)
     int32_t round;    // 0-based per-pass round; a tile's iteration number is it0 + round + 1
+    unsigned *host_flag;  // host-mapped word: receives `seq` when the last parked tile becomes final (the host stops queueing rounds)
+    unsigned seq;
 };
 
 // tile handled by workgroup row `slot`, its iteration number and converged mask in this round; false: already final
 __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
+    // The host sizes the grid for the most tiles that can have been parked and queues every round without waiting for
+    // the device (the *_async entry points never synchronise): rows beyond the parked count and tiles that are final leave here.
+    const int n_tiles = a.n_tiles >= 0 ? a.n_tiles : (int)a.bp.counters[1];
+    if (slot >= n_tiles) return false;
     tile = a.bp.handoff_list[slot];
     st = a.bp.state + tile;
     it = st->it0 + a.round + 1;
@@ -28,14 +34,14 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
 template <int METHOD, int MATH, int DR>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
     __shared__ __attribute__((aligned(16))) double log_tab[256];
-    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
-        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
-    __syncthreads();
     int64_t tile;
     const TileState *st;
     int it;
     uint64_t done;
-    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;  // (uniform over the workgroup)
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
+        for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(256) bp_spread_state_init_kernel(const SpreadA
     st->end_round = INT32_MAX;
     for (int l = 0; l < 64; ++l) st->lane_iter[l] = 0;
     a.bp.handoff_list[t] = t;
+    if (t == 0) a.bp.counters[1] = a.bp.counters[2] = (unsigned)a.n_tiles;  // parked, live
 }
 
 template <int METHOD, int MATH>
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(256) bp_spread_init_kernel(const SpreadArgs a)
 // (decisions + posterior of THIS iteration), a tile whose lanes are all frozen or that reached max_iter gets its
 // outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
 // to freeze and every workgroup but the first leaves at once.
-__global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a, unsigned *live_tiles) {
+__global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a) {
     int64_t tile;
     const TileState *cst;
     int it;
@@ -210,7 +217,8 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
         st->unsat[par ^ 1] = 0ull;
         if (over) {
             st->end_round = a.round;
-            atomicSub(live_tiles, 1u);
+            if (atomicSub(&a.bp.counters[2], 1u) == 1u && a.host_flag)  // that was the last live tile
+                __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

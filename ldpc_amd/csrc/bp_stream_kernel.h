@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                     stt->end_round = INT32_MAX;
                     stt->unsat[0] = stt->unsat[1] = 0ull;
                     a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
+                    atomicAdd(&a.counters[2], 1u);  // live tiles of the per-pass rounds
                 }
                 return;
             }

@@ -4,6 +4,9 @@
 
 #include "bp_device_common.h"
 
+// One-dimensional element-wise kernels run grid-stride loops under a capped grid (flat_grid in bp_hip.hip): item counts
+// such as batch * n pass 2^32 for large batches of large codes.
+
 // syndromes [batch][m] u8  ->  par / nzm [tiles][m] u64, invalid [tiles] u64 (pre-zeroed)
 __global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch, int m,
                                       uint64_t *par, uint64_t *nzm, uint64_t *invalid) {
@@ -63,53 +66,53 @@ __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__rest
 __global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
                                   const int32_t *__restrict__ col_idx, int m, int n,
                                   const uint8_t *__restrict__ in, int64_t batch, uint8_t *out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * m) return;
-    const int64_t b = t / m;
-    const int i = (int)(t - b * m);
-    uint8_t s = 0;
-    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) s ^= in[b * n + col_idx[e]];
-    out[t] = s;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * m; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / m;
+        const int i = (int)(t - b * m);
+        uint8_t s = 0;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) s ^= in[b * n + col_idx[e]];
+        out[t] = s;
+    }
 }
 
 // ---- bit-packed shot data ("b8": bit i of a shot is bit i % 8 of its byte i / 8; every shot starts on a byte) --
 // the wire format of the reference's sinter decoders (sinter_decoders/sinter_bposd_decoder.py:57-130)
 __global__ void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * bits) return;
-    const int64_t b = t / bits;
-    const int i = (int)(t - b * bits);
-    out[t] = (in[b * ((bits + 7) >> 3) + (i >> 3)] >> (i & 7)) & 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * bits; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / bits;
+        const int i = (int)(t - b * bits);
+        out[t] = (in[b * ((bits + 7) >> 3) + (i >> 3)] >> (i & 7)) & 1;
+    }
 }
 
 __global__ void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
     const int nb = (bits + 7) >> 3;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * nb) return;
-    const int64_t b = t / nb;
-    const int byte = (int)(t - b * nb);
-    uint8_t v = 0;
-    for (int q = 0; q < 8 && byte * 8 + q < bits; ++q) v |= (uint8_t)((in[b * bits + byte * 8 + q] & 1) << q);
-    out[t] = v;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * nb; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / nb;
+        const int byte = (int)(t - b * nb);
+        uint8_t v = 0;
+        for (int q = 0; q < 8 && byte * 8 + q < bits; ++q) v |= (uint8_t)((in[b * bits + byte * 8 + q] & 1) << q);
+        out[t] = v;
+    }
 }
 
 // BpDecoder.decode / BpOsdDecoder.decode return the zero vector for an all-zero input without running BP
 // (_bp_decoder.pyx:679-681, _bposd_decoder.pyx:118-123): converge = True, iterations reported as 0 by the batch API
 __global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, int64_t batch, int m, int n, uint8_t *dec,
                                           int32_t *iters, uint8_t *conv) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
-    const int mb = (m + 7) >> 3;
-    uint8_t any = 0;
-    for (int q = 0; q < mb; ++q) {
-        uint8_t v = dets_b8[b * mb + q];
-        if (q == mb - 1 && (m & 7)) v &= (uint8_t)((1u << (m & 7)) - 1u);  // padding bits carry no data
-        any |= v;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
+        const int mb = (m + 7) >> 3;
+        uint8_t any = 0;
+        for (int q = 0; q < mb; ++q) {
+            uint8_t v = dets_b8[b * mb + q];
+            if (q == mb - 1 && (m & 7)) v &= (uint8_t)((1u << (m & 7)) - 1u);  // padding bits carry no data
+            any |= v;
+        }
+        if (any) continue;
+        for (int j = 0; j < n; ++j) dec[b * n + j] = 0;
+        if (iters) iters[b] = 0;
+        if (conv) conv[b] = 1;
     }
-    if (any) return;
-    for (int j = 0; j < n; ++j) dec[b * n + j] = 0;
-    if (iters) iters[b] = 0;
-    if (conv) conv[b] = 1;
 }
 
 // predicted observables L x (mod 2) of every decoding, bit-packed: one thread per (shot, output byte)
@@ -117,18 +120,18 @@ __global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, i
 __global__ void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx, int k, int n,
                                       const uint8_t *__restrict__ dec, int64_t batch, uint8_t *__restrict__ out) {
     const int nb = (k + 7) >> 3;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * nb) return;
-    const int64_t b = t / nb;
-    const int byte = (int)(t - b * nb);
-    uint8_t v = 0;
-    for (int q = 0; q < 8 && byte * 8 + q < k; ++q) {
-        const int o = byte * 8 + q;
-        uint8_t s = 0;
-        for (int e = row_ptr[o]; e < row_ptr[o + 1]; ++e) s ^= dec[b * n + col_idx[e]];
-        v |= (uint8_t)((s & 1) << q);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * nb; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / nb;
+        const int byte = (int)(t - b * nb);
+        uint8_t v = 0;
+        for (int q = 0; q < 8 && byte * 8 + q < k; ++q) {
+            const int o = byte * 8 + q;
+            uint8_t s = 0;
+            for (int e = row_ptr[o]; e < row_ptr[o + 1]; ++e) s ^= dec[b * n + col_idx[e]];
+            v |= (uint8_t)((s & 1) << q);
+        }
+        out[t] = v;
     }
-    out[t] = v;
 }
 
 // synthetic BSC shots: syndrome[b][i] = XOR_{j in row i} bernoulli(seed, (shot0+b)*n + j)
@@ -136,23 +139,23 @@ __global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
                                          const int32_t *__restrict__ col_idx, int m, int n,
                                          uint64_t seed, uint64_t threshold, int64_t shot0,
                                          int64_t batch, uint8_t *synd) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * m) return;
-    const int64_t b = t / m;
-    const int i = (int)(t - b * m);
-    const uint64_t base = (uint64_t)(shot0 + b) * (uint64_t)n;
-    uint8_t s = 0;
-    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
-        s ^= (uint8_t)((sm64(seed, base + (uint64_t)col_idx[e]) >> 11) < threshold);
-    synd[t] = s;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * m; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / m;
+        const int i = (int)(t - b * m);
+        const uint64_t base = (uint64_t)(shot0 + b) * (uint64_t)n;
+        uint8_t s = 0;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+            s ^= (uint8_t)((sm64(seed, base + (uint64_t)col_idx[e]) >> 11) < threshold);
+        synd[t] = s;
+    }
 }
 
 __global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, int64_t shot0,
                                       int64_t batch, uint8_t *err) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * n) return;
-    const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
-    err[t] = (uint8_t)((sm64(seed, idx) >> 11) < threshold);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * n; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
+        err[t] = (uint8_t)((sm64(seed, idx) >> 11) < threshold);
+    }
 }
 
 
@@ -160,18 +163,18 @@ __global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, 
 template <class T>
 __global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ list, int64_t count, int width,
                                    T *__restrict__ dst) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count * width) return;
-    const int64_t r = t / width;
-    dst[t] = src[(int64_t)list[r] * width + (t - r * width)];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count * width; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / width;
+        dst[t] = src[(int64_t)list[r] * width + (t - r * width)];
+    }
 }
 template <class T>
 __global__ void scatter_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ list, int64_t count, int width,
                                     T *__restrict__ dst) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count * width) return;
-    const int64_t r = t / width;
-    dst[(int64_t)list[r] * width + (t - r * width)] = src[t];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count * width; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / width;
+        dst[(int64_t)list[r] * width + (t - r * width)] = src[t];
+    }
 }
 
 // How many rows converged after exactly j iterations (bin j, j capped at 255) and how many did not converge (bin 0):

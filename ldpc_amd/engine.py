@@ -44,10 +44,21 @@ class HipBpEngine:
             ms_scaling_factor=float(ms_scaling_factor), device=int(device))
         _lib.check(self._lib.ldpc_hip_bp_create(C.byref(desc), C.byref(self._h)))
 
+    @classmethod
+    def _view(cls, handle, m, n, nnz, device):
+        """Non-owning engine over a handle that belongs to an ``ldpc_hip_bp_multi`` (``HipBpMultiEngine``)."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self.device, self.m, self.n, self.nnz = int(device), int(m), int(n), int(nnz)
+        return self
+
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.ldpc_hip_bp_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.ldpc_hip_bp_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -315,3 +326,121 @@ class HipBpEngine:
             _lib.check(self._lib.ldpc_hip_gen_bsc_syndromes(
                 self._h, seed, thr, shot0, shots, synd.ctypes.data, err.ctypes.data if want_errors else None))
         return (synd, err) if want_errors else synd
+
+
+class HipBpMultiEngine:
+    """One decoder over several GPUs of the node inside ONE process (``ldpc_hip_bp_multi``, include/ldpc_hip.h).
+
+    ``decode_batch`` cuts the batch into contiguous row ranges, one per entry of ``device_ids``, decodes them
+    concurrently and returns when every row is in place; results equal the single-GPU call's bit for bit.  Setters are
+    those of ``HipBpEngine`` and apply to every GPU.  NumPy in -> NumPy out (each GPU stages its own rows over PCIe);
+    torch CUDA tensors in -> torch CUDA tensors out on the same GPU (the others get their rows by peer copy over xGMI
+    and return their decisions bit-packed).  For one process PER GPU use ``ldpc_amd.sharding`` instead.
+    """
+
+    _BROADCAST = ("set_channel", "set_params", "set_schedule", "set_tuning", "set_math", "set_ring", "set_handoff", "set_osd",
+                  "set_repack", "set_serial_kernel", "set_osd_kernel", "set_small_code_kernel")
+
+    def __init__(self, row_ptr, col_idx, n, channel_probs, max_iter, bp_method, ms_scaling_factor, device_ids):
+        self._lib = _lib.load()
+        self._mh = C.c_void_p()
+        row_ptr = np.ascontiguousarray(row_ptr, np.int32)
+        col_idx = np.ascontiguousarray(col_idx, np.int32)
+        probs = np.ascontiguousarray(channel_probs, np.float64)
+        self.m, self.n, self.nnz = int(len(row_ptr) - 1), int(n), int(len(col_idx))
+        if probs.shape != (self.n,):
+            raise ValueError("Channel probabilities vector must have length equal to the number of bits")
+        self.device_ids = [int(d) for d in device_ids]
+        if not self.device_ids:
+            raise ValueError("device_ids must name at least one GPU")
+        ids = (C.c_int32 * len(self.device_ids))(*self.device_ids)
+        desc = _lib.BpDesc(m=self.m, n=self.n, nnz=self.nnz, csr_row_ptr=row_ptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                           csr_col_idx=col_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                           channel_probs=probs.ctypes.data_as(C.POINTER(C.c_double)), max_iter=int(max_iter),
+                           bp_method=int(bp_method), ms_scaling_factor=float(ms_scaling_factor), device=-1)
+        _lib.check(self._lib.ldpc_hip_bp_multi_create(C.byref(desc), ids, len(self.device_ids), C.byref(self._mh)))
+        self.subs = [HipBpEngine._view(self._lib.ldpc_hip_bp_multi_handle(self._mh, i), self.m, self.n, self.nnz, d)
+                     for i, d in enumerate(self.device_ids)]
+        for name in self._BROADCAST:
+            setattr(self, name, self._broadcast(name))
+
+    def _broadcast(self, name):
+        def apply(*a, **k):
+            for sub in self.subs:
+                getattr(sub, name)(*a, **k)
+        apply.__name__ = name
+        return apply
+
+    def close(self):
+        if getattr(self, "_mh", None) is not None and self._mh.value:
+            for sub in self.subs:
+                sub.close()
+            self._lib.ldpc_hip_bp_multi_destroy(self._mh)
+            self._mh = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_staging(self, force):
+        """Testing aid (``ldpc_hip_bp_multi_set_staging``): route device tensors through the peer-copy path on their own GPU too."""
+        _lib.check(self._lib.ldpc_hip_bp_multi_set_staging(self._mh, int(bool(force))))
+
+    def last_kernel_ms(self):
+        """BP kernel time of the last decode on every GPU."""
+        ms = (C.c_float * len(self.subs))()
+        _lib.check(self._lib.ldpc_hip_bp_multi_last_kernel_ms(self._mh, ms))
+        return [float(v) for v in ms]
+
+    def _sub_for(self, tensor=None):
+        if tensor is not None and _is_torch(tensor) and tensor.is_cuda:
+            for sub in self.subs:
+                if sub.device == tensor.device.index:
+                    return sub
+        return self.subs[0]
+
+    def mulvec_batch(self, vectors):
+        return self._sub_for(vectors).mulvec_batch(vectors)
+
+    def gen_bsc_syndromes(self, seed, error_rate, shot0, shots, device=None, want_errors=False):
+        sub = self.subs[0]
+        if device is not None:
+            import torch
+            idx = torch.device(device).index
+            sub = next((s_ for s_ in self.subs if s_.device == idx), sub)
+        return sub.gen_bsc_syndromes(seed, error_rate, shot0, shots, device=device, want_errors=want_errors)
+
+    def decode_batch(self, syndromes, want_llr=True, out=None, osd0=False, osd=False, asynchronous=False):
+        """As ``HipBpEngine.decode_batch`` (always synchronous: the call returns when every GPU has delivered its rows)."""
+        with_osd = 1 if osd else (0 if osd0 else -1)
+        if _is_torch(syndromes):
+            import torch
+            s = syndromes
+            if s.dtype != torch.uint8 or s.dim() != 2 or s.shape[1] != self.m or not s.is_cuda:
+                raise ValueError(f"syndromes must be a CUDA uint8 tensor of shape (B, {self.m})")
+            s = s.contiguous()
+            b = int(s.shape[0])
+            if out is not None:
+                dec, llr, it, cv = out
+            else:
+                dec = torch.empty((b, self.n), dtype=torch.uint8, device=s.device)
+                llr = torch.empty((b, self.n), dtype=torch.float64, device=s.device) if want_llr else None
+                it = torch.empty((b,), dtype=torch.int32, device=s.device)
+                cv = torch.empty((b,), dtype=torch.uint8, device=s.device)
+            torch.cuda.current_stream(s.device).synchronize()  # the GPUs read `s` on their own streams
+            _lib.check(self._lib.ldpc_hip_bp_multi_decode_batch(self._mh, with_osd, s.data_ptr(), b, dec.data_ptr(),
+                                                                llr.data_ptr() if llr is not None else None, it.data_ptr(), cv.data_ptr()))
+            return dec, llr, it, cv
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        if s.ndim != 2 or s.shape[1] != self.m:
+            raise ValueError(f"syndromes must have shape (B, {self.m})")
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64) if want_llr else None
+        it = np.zeros(b, np.int32)
+        cv = np.zeros(b, np.uint8)
+        _lib.check(self._lib.ldpc_hip_bp_multi_decode_batch(self._mh, with_osd, s.ctypes.data, b, dec.ctypes.data,
+                                                            llr.ctypes.data if want_llr else None, it.ctypes.data, cv.ctypes.data))
+        return dec, llr, it, cv.astype(bool)

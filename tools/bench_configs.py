@@ -67,6 +67,8 @@ def main():
         run("c5 BB144 product_sum 50 it + OSD_CS order 60 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, False, osd=(3, 60))
         run("c5 BB144 product_sum 50 it + OSD_E order 10 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, False, osd=(2, 10))
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05, B=262144", h, 0.05, 50, 0, 1.0, 262144, True)
+    if "c5bp" in args.which:  # the BP stage of config 5 alone, one workload (tools/profile_secondary.sh counts its VALU instructions)
+        run("c5 BB144 product_sum 50 it (BP only) p=0.05", codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0, 8192, False)
     if "c5" in args.which:
         h = codes.bivariate_bicycle_hx()
         run("c5 BB144 product_sum 50 it + OSD-0 p=0.05", h, 0.05, 50, 0, 1.0, 8192, True)

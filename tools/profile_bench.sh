@@ -8,7 +8,7 @@ TAG=${1:-r}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --cpu-sample 0 $*"
+ARGS="--steps 1 --warmup 1 --cpu-sample 0 --secondary 0 $*"
 echo "== stats: bench.py $ARGS" > "$OUT/log.txt"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python bench.py $ARGS >> "$OUT/log.txt" 2>&1
 i=0
@@ -20,5 +20,5 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   echo "== pmc $grp" >> "$OUT/log.txt"
   timeout 600 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" -o pmc -- python bench.py $ARGS >> "$OUT/log.txt" 2>&1
 done
-python tools/prof_parse.py "$OUT" bp_decode "$OUT/hbm_traffic.json" > "$OUT/summary.txt" 2>&1
+python tools/prof_parse.py "$OUT" bp_decode "$OUT" > "$OUT/summary.txt" 2>&1   # also writes hbm_traffic.json, valu_clock.json
 cat "$OUT/summary.txt"
