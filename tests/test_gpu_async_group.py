@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _assert_same(got, want):
+    """Outputs equal bit for bit (log-ratios may hold NaN -- inf - inf in the reference's arithmetic too --, so compare their bits)."""
+    import torch
+    for g, w in zip(got, want):
+        if g.dtype == torch.float64:
+            g, w = g.view(torch.int64), w.view(torch.int64)
+        assert bool(torch.equal(g, w))
+
+
 def _headline_engine(p=0.09, max_iter=50):
     from ldpc_amd.codes import regular_ldpc_code
     from ldpc_amd.engine import HipBpEngine
@@ -43,8 +52,7 @@ def test_decode_batch_async_returns_before_the_kernels_finish():
     assert t_call < 0.5 * t_all, f"call took {t_call * 1e3:.1f} ms of {t_all * 1e3:.1f} ms: it waited for the device"
     # the results of the asynchronous call are those of the synchronous one
     ref = eng.decode_batch(synd, want_llr=True)
-    for a, b in zip(out, ref):
-        assert bool((a == b).all())
+    _assert_same(out, ref)
     assert eng.last_kernel_ms() > 100.0
 
 
@@ -70,10 +78,8 @@ def test_change_of_stream_waits_for_the_previous_decode(oracle_built):
         with torch.cuda.stream(st_b):
             got_b = eng.decode_batch(sb, want_llr=True, asynchronous=True)
         torch.cuda.synchronize()
-        for g, w in zip(got_a, want_a):
-            assert bool((g == w).all())
-        for g, w in zip(got_b, want_b):
-            assert bool((g == w).all())
+        _assert_same(got_a, want_a)
+        _assert_same(got_b, want_b)
     o = oracle_built.BpOracle(h, error_rate=p, max_iter=40, bp_method="product_sum")
     chk = o.decode_batch(sa[:32].cpu().numpy())
     assert np.array_equal(want_a[0][:32].cpu().numpy(), chk[0])
@@ -90,7 +96,7 @@ def test_large_max_iter_stops_queueing_rounds():
     p = 0.03
     dev = torch.device("cuda", 0)
     short = HipBpEngine(h.indptr, h.indices, 2400, np.full(2400, p), 60, 0, 1.0)
-    long_ = HipBpEngine(h.indptr, h.indices, 2400, np.full(2400, p), 20000, 0, 1.0)
+    long_ = HipBpEngine(h.indptr, h.indices, 2400, np.full(2400, p), 200000, 0, 1.0)
     for e in (short, long_):
         e.set_small_code_kernel(0)
     s = short.gen_bsc_syndromes(7, p, shot0=0, shots=4096, device=dev)
@@ -100,9 +106,8 @@ def test_large_max_iter_stops_queueing_rounds():
     t0 = time.perf_counter()
     b = long_.decode_batch(s, want_llr=True)
     dt = time.perf_counter() - t0
-    for x, y in zip(a, b):
-        assert bool((x == y).all())
-    assert dt < 2.0, f"{dt:.2f} s: 20 000 rounds were queued although the batch converged within 60"
+    _assert_same(b, a)
+    assert dt < 2.0, f"{dt:.2f} s: 200 000 rounds were queued although the batch converged within 60"
 
 
 def _bench(args, timeout=900):
@@ -144,7 +149,7 @@ s = eng.gen_bsc_syndromes(7, 0.06, shot0=0, shots=1000, device=torch.device("cud
 t = torch.ones(1, device="cuda"); dist.all_reduce(t)   # a real collective on the RCCL communicator
 want = eng.decode_batch(s, want_llr=True)
 assert dec8.shape == (1000, 150) and bool((eng.unpack_b8(dec8, 1200) == want[0]).all())
-assert bool((cv == want[3]).all()) and bool((it == want[2]).all()) and bool((llr == want[1]).all())
+assert bool((cv == want[3]).all()) and bool((it == want[2]).all()) and bool(torch.equal(llr.view(torch.int64), want[1].view(torch.int64)))
 assert shard_range(1000, 0, 1) == (0, 1000) and float(t.item()) == 1.0
 dist.destroy_process_group()
 print("ok")
