@@ -47,15 +47,17 @@ def _bp_method_code(value) -> int:
                     'product_sum', 'minimum_sum'")
 
 
-def _check_pcm_type(pcm):
+def _check_pcm_type(pcm, spaces=12):
     if not isinstance(pcm, (np.ndarray, scipy.sparse.spmatrix)):  # pyx:17-21, 113-117
-        raise TypeError(f"The input matrix is of an invalid type. Please input\
-        a np.ndarray or scipy.sparse.spmatrix object, not {type(pcm)}")
+        # (the reference's message carries the indentation of its source line across a backslash continuation: 12 spaces in
+        # BpDecoderBase.__cinit__, pyx:113-117, 8 in Py2BpSparse, pyx:17-21)
+        raise TypeError("The input matrix is of an invalid type. Please input" + " " * spaces +
+                        f"a np.ndarray or scipy.sparse.spmatrix object, not {type(pcm)}")
 
 
 def _ingest(pcm) -> scipy.sparse.csr_matrix:
     """Py2BpSparse (pyx:9-49): validate and return canonical CSR (sorted columns, ones only)."""
-    _check_pcm_type(pcm)
+    _check_pcm_type(pcm, spaces=8)
     # (a copy: the normalisation below must not reach into the caller's arrays -- the reference only reads pcm.nonzero();
     # like the reference's helper, convert_to_binary_sparse itself drops explicit zeros of a sparse input in place)
     h = scipy.sparse.csr_matrix(convert_to_binary_sparse(pcm), copy=True)
@@ -70,11 +72,44 @@ def io_test(pcm):
     return scipy.sparse.csr_matrix(_ingest(pcm), dtype=np.uint8)
 
 
-def _typed(name, value, types, type_name):
-    # the reference's Cython signature rejects wrongly typed arguments with TypeError before any
-    # setter runs (e.g. python_test/test_bp_decoder.py:143-168)
-    if value is not None and not isinstance(value, types):
-        raise TypeError(f"Argument '{name}' has incorrect type (expected {type_name}, got {type(value).__name__})")
+# ---- what Cython does with annotated arguments -------------------------------------------------------------------
+# The reference's classes are Cython `cdef class`es compiled with annotation typing: an argument annotated with a builtin
+# type (`value: int`, `input_type: str`, `Optional[float]`, `List[int]`) must be EXACTLY of that type (None allowed only for
+# Optional[...]), `value: float` / `sigma: float` become C doubles (anything with __float__ / __index__ converts), `value: bool`
+# becomes a C truth value, and a violation is a TypeError whose text is Cython's.  python_test/test_bp_decoder.py:143-168 pins
+# some of these; tests/golden/api_reference.json (generated from the reference) pins all of them.
+def _type_name(t) -> str:
+    return t.__name__ if t.__module__ == "builtins" else f"{t.__module__}.{t.__name__}"
+
+
+def _typed(name, value, typ, optional=True):
+    """Exact-type test of an argument annotated with the builtin / extension type ``typ``."""
+    if value is None and optional:
+        return
+    if type(value) is typ or (typ is np.ndarray and isinstance(value, np.ndarray)):
+        return
+    msg = f"Argument '{name}' has incorrect type (expected {_type_name(typ)}, got {_type_name(type(value))})"
+    if isinstance(value, typ):
+        msg += (". Note that Cython is deliberately stricter than PEP-484 and rejects subclasses of builtin types. If you need to "
+                "pass subclasses then set the 'annotation_typing' directive to False.")
+    raise TypeError(msg)
+
+
+def _c_double(value) -> float:
+    """Conversion of a Python object to a C double (``__pyx_PyFloat_AsDouble``)."""
+    if isinstance(value, float):
+        return float(value)
+    t = type(value)
+    if hasattr(t, "__float__") or hasattr(t, "__index__"):
+        return float(value)
+    raise TypeError(f"must be real number, not {t.__name__}")
+
+
+def _readonly(name, owner):
+    """Setter of a read-only property: the message of the reference's Cython getset descriptor."""
+    def refuse(self, value):
+        raise AttributeError(f"attribute '{name}' of 'ldpc.bp_decoder._bp_decoder.{owner}' objects is not writable")
+    return refuse
 
 
 class BpDecoderBase:
@@ -159,6 +194,7 @@ class BpDecoderBase:
 
     @error_rate.setter
     def error_rate(self, value: Optional[float]) -> None:
+        _typed("value", value, float)
         if value is not None:
             if not isinstance(value, float):
                 raise ValueError("The `error_rate` parameter must be specified as a single float value.")
@@ -174,8 +210,9 @@ class BpDecoderBase:
         if value is not None:
             if len(value) != self.n:
                 raise ValueError(f"The error channel vector must have length {self.n}, not {len(value)}.")
-            self._channel_probs[:] = np.asarray([value[i] for i in range(self.n)], dtype=np.float64)
             self._channel_dirty = True
+            for i in range(self.n):  # element by element into the C++ vector (pyx:222-223): a bad element stops HERE
+                self._channel_probs[i] = _c_double(value[i])
 
     def update_channel_probs(self, value) -> None:
         self.error_channel = value
@@ -184,6 +221,8 @@ class BpDecoderBase:
     def channel_probs(self) -> np.ndarray:
         return self._channel_probs.astype(float).copy()
 
+    channel_probs = channel_probs.setter(_readonly("channel_probs", "BpDecoderBase"))
+
     # ---- input vector type (pyx:236-276) --------------------------------------------------------
     @property
     def input_vector_type(self) -> str:
@@ -191,6 +230,7 @@ class BpDecoderBase:
 
     @input_vector_type.setter
     def input_vector_type(self, input_type: str):
+        _typed("input_type", input_type, str, optional=False)
         key = input_type.lower()
         if key in ("auto", "a", "2"):
             if self.m == self.n:
@@ -227,6 +267,12 @@ class BpDecoderBase:
     def bit_count(self) -> int:
         return self.n
 
+    log_prob_ratios = log_prob_ratios.setter(_readonly("log_prob_ratios", "BpDecoderBase"))
+    converge = converge.setter(_readonly("converge", "BpDecoderBase"))
+    iter = iter.setter(_readonly("iter", "BpDecoderBase"))
+    check_count = check_count.setter(_readonly("check_count", "BpDecoderBase"))
+    bit_count = bit_count.setter(_readonly("bit_count", "BpDecoderBase"))
+
     # ---- algorithm parameters (pyx:332-579) -----------------------------------------------------
     @property
     def max_iter(self) -> int:
@@ -234,6 +280,7 @@ class BpDecoderBase:
 
     @max_iter.setter
     def max_iter(self, value: int) -> None:
+        _typed("value", value, int, optional=False)
         if not isinstance(value, int):
             raise ValueError("max_iter input parameter is invalid. This must be specified as a positive int.")
         if value < 0:
@@ -290,6 +337,7 @@ class BpDecoderBase:
 
     @ms_scaling_factor.setter
     def ms_scaling_factor(self, value: float) -> None:
+        value = _c_double(value)
         if not isinstance(value, (float, int)):
             raise TypeError("The ms_scaling factor must be specified as a float")
         self._ms_scaling_factor = float(value)
@@ -302,6 +350,7 @@ class BpDecoderBase:
 
     @omp_thread_count.setter
     def omp_thread_count(self, value: int) -> None:
+        _typed("value", value, int, optional=False)
         if not isinstance(value, int) or value < 1:
             raise TypeError("The omp_thread_count must be specified as a\
             positive integer.")
@@ -315,6 +364,7 @@ class BpDecoderBase:
 
     @random_schedule_seed.setter
     def random_schedule_seed(self, value: int) -> None:
+        _typed("value", value, int, optional=False)
         if not isinstance(value, int) or value < -2:
             raise ValueError("The value of random_schedule_seed must\
             be a positive integer. Set as -1 to disable to the random\
@@ -328,7 +378,7 @@ class BpDecoderBase:
 
     @random_serial_schedule.setter
     def random_serial_schedule(self, value: bool) -> None:
-        self._random_serial_schedule = value
+        self._random_serial_schedule = bool(value)  # a C truth value
 
     # ---- device engine --------------------------------------------------------------------------
     def _get_engine(self):
@@ -421,9 +471,6 @@ class BpDecoder(BpDecoderBase):
         (pyx:90-100) therefore win over the signature's: an omitted ``bp_method`` means product_sum
         (pinned by python_test/test_bp_decoder.py:121-136).
         """
-        for key in kwargs.keys():  # pyx:625-627
-            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
-                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
                      ms_scaling_factor=ms_scaling_factor, schedule=schedule, omp_thread_count=omp_thread_count,
@@ -431,18 +478,25 @@ class BpDecoder(BpDecoderBase):
                      random_serial_schedule=random_serial_schedule)
         passed = dict(kwargs)
         passed.update({k: v for k, v in given.items() if v is not _UNSET})
-        _typed("error_rate", passed.get("error_rate"), float, "float")
-        _typed("max_iter", passed.get("max_iter"), int, "int")
-        _typed("bp_method", passed.get("bp_method"), str, "str")
-        _typed("schedule", passed.get("schedule"), str, "str")
-        _typed("omp_thread_count", passed.get("omp_thread_count"), int, "int")
-        _typed("random_schedule_seed", passed.get("random_schedule_seed"), int, "int")
-        _typed("input_vector_type", input_vector_type, str, "str")
+        # order of events in the reference: the base class's __cinit__ runs first, with every keyword (its setters raise
+        # their own errors); then this class's signature is type-checked; then its body (pyx:620-629)
         super().__init__(pcm, **passed)
+        _typed("error_rate", passed.get("error_rate"), float)
+        _typed("max_iter", passed.get("max_iter", 0), int)
+        _typed("bp_method", passed.get("bp_method", "minimum_sum"), str)
+        _typed("schedule", passed.get("schedule", "parallel"), str)
+        _typed("omp_thread_count", passed.get("omp_thread_count", 1), int)
+        _typed("random_schedule_seed", passed.get("random_schedule_seed", 0), int)
+        _typed("serial_schedule_order", passed.get("serial_schedule_order"), list)
+        _typed("input_vector_type", input_vector_type, str, optional=False)
+        for key in kwargs.keys():  # pyx:625-627
+            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
+                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         self.input_vector_type = input_vector_type  # pyx:629
 
     # ---- single input, reference signature (pyx:642-695) ----------------------------------------
     def decode(self, input_vector: np.ndarray) -> np.ndarray:
+        _typed("input_vector", input_vector, np.ndarray, optional=False)
         ln = len(input_vector)
         if self._bp_input_type == SYNDROME and not ln == self.m:
             raise ValueError(f"The input_vector must have length {self.m} (for syndrome decoding). Not length {ln}.")
@@ -539,6 +593,8 @@ class BpDecoder(BpDecoderBase):
     def decoding(self) -> np.ndarray:
         return np.array(self._decoding).astype(int)  # pyx:698-709
 
+    decoding = decoding.setter(_readonly("decoding", "BpDecoder"))
+
 
 class SoftInfoBpDecoder(BpDecoderBase):
     """Serial minimum-sum BP with analog syndrome information (drop-in for ``ldpc.bp_decoder.SoftInfoBpDecoder``,
@@ -557,7 +613,14 @@ class SoftInfoBpDecoder(BpDecoderBase):
         passed = dict(kwargs)
         passed.update({k: v for k, v in given.items() if v is not _UNSET})
         super().__init__(pcm, **passed)
-        self.cutoff = float(cutoff)
+        _typed("error_rate", passed.get("error_rate"), float)  # the signature of pyx:743-745, checked after the base class ran
+        _typed("error_channel", passed.get("error_channel"), list)
+        _typed("max_iter", passed.get("max_iter", 0), int)
+        _typed("bp_method", passed.get("bp_method", "minimum_sum"), str)
+        _typed("ms_scaling_factor", passed.get("ms_scaling_factor", 1.0), float)
+        _typed("cutoff", cutoff, float)
+        sigma = _c_double(sigma)
+        self.cutoff = cutoff
         if not isinstance(sigma, float) or sigma <= 0:  # pyx:748-749
             raise ValueError("The sigma value must be a float greater than 0.")
         self.sigma = sigma

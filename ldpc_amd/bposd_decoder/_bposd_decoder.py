@@ -22,20 +22,30 @@ class BpOsdDecoder(BpDecoderBase):
                  ms_scaling_factor=_UNSET, schedule=_UNSET, omp_thread_count=_UNSET, random_schedule_seed=_UNSET,
                  serial_schedule_order=_UNSET, osd_method=0, osd_order: int = 0, input_vector_type: str = "syndrome",
                  **kwargs):
-        for key in kwargs.keys():  # pyx:60-62 (the reference's message says BpDecoder here too)
-            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
-                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         _check_pcm_type(pcm)
         given = dict(error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
                      ms_scaling_factor=ms_scaling_factor, schedule=schedule, omp_thread_count=omp_thread_count,
                      random_schedule_seed=random_schedule_seed, serial_schedule_order=serial_schedule_order)
         passed = dict(kwargs)
         passed.update({k: v for k, v in given.items() if v is not _UNSET})
-        _typed("error_rate", passed.get("error_rate"), float, "float")
-        _typed("max_iter", passed.get("max_iter"), int, "int")
-        _typed("bp_method", passed.get("bp_method"), str, "str")
-        _typed("schedule", passed.get("schedule"), str, "str")
-        super().__init__(pcm, **passed)
+        super().__init__(pcm, **passed)  # the base class's __cinit__ runs first; then this signature's checks (pyx:51-55)
+        _typed("error_rate", passed.get("error_rate"), float)
+        _typed("error_channel", passed.get("error_channel"), list)
+        _typed("max_iter", passed.get("max_iter", 0), int)
+        _typed("bp_method", passed.get("bp_method", "minimum_sum"), str)
+        _typed("schedule", passed.get("schedule", "parallel"), str)
+        _typed("omp_thread_count", passed.get("omp_thread_count", 1), int)
+        _typed("random_schedule_seed", passed.get("random_schedule_seed", 0), int)
+        _typed("serial_schedule_order", passed.get("serial_schedule_order"), list)
+        # `osd_order: int` of this signature is a C int: numbers are truncated to one, anything else is refused (pyx:54)
+        if isinstance(osd_order, (int, float, np.integer, np.floating)):
+            osd_order = int(osd_order)
+        else:
+            _typed("osd_order", osd_order, int, optional=False)
+        _typed("input_vector_type", input_vector_type, str, optional=False)
+        for key in kwargs.keys():  # pyx:57-59 (the reference's message says BpDecoder here too)
+            if key not in ["channel_probs", "_device", "_backend", "device_ids"]:
+                raise ValueError(f"Unknown parameter '{key}' passed to the BpDecoder constructor.")
         self._osd_method = OSD_OFF  # `new OsdDecoderCpp(pcm, OSD_OFF, 0, ...)`, pyx:67
         self._osd_order = 0
         self.osd_method = osd_method
@@ -74,6 +84,7 @@ class BpOsdDecoder(BpDecoderBase):
 
     @osd_order.setter
     def osd_order(self, order: int) -> None:
+        _typed("order", order, int, optional=False)
         if order < 0:
             raise ValueError(f"ERROR: OSD order '{order}' invalid. Please choose a positive integer.")
         if self._osd_method == OSD_0 and order != 0:
@@ -106,6 +117,7 @@ class BpOsdDecoder(BpDecoderBase):
 
     # ---- decode (pyx:78-136) ----------------------------------------------------------------------
     def decode(self, syndrome: np.ndarray) -> np.ndarray:
+        _typed("syndrome", syndrome, np.ndarray, optional=False)
         if not len(syndrome) == self.m:
             raise ValueError(f"The syndrome must have length {self.m}. Not {len(syndrome)}.")
         vec = np.asarray(syndrome).astype(np.uint8)

@@ -273,7 +273,6 @@ def _probes():
         add(f"decode_zero_dtype_{dt}", kwargs=base, ops=[["call", "decode", [ND([0] * 3, dt)]], ["get", "converge"]])
     add("decode_list_input", kwargs=base, ops=[["call", "decode", [[0, 0, 0]]]])
     add("decode_2d_input", kwargs=base, ops=[["call", "decode", [ND([[0, 0, 0]], "uint8")]]])
-    add("decode_no_argument", kwargs=base, ops=[["call", "decode", []]])
     add("decode_none", kwargs=base, ops=[["call", "decode", [None]]])
     add("decode_zero_osd", cls="BpOsdDecoder", kwargs={"error_rate": 0.1, "osd_method": "osd_0"},
         ops=[["call", "decode", [ND([0, 0, 0], "int64")]], ["get", "converge"], ["call", "decode", [ND([0, 0], "uint8")]], ["call", "decode", [ND([0] * 7, "uint8")]]])

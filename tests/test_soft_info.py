@@ -73,8 +73,9 @@ def test_mirror_validation():
     d = SoftInfoBpDecoder(h, error_rate=0.1, max_iter=3, ms_scaling_factor=1.0, cutoff=10.0)
     assert d.schedule == "serial" and d.bp_method == "minimum_sum" and d.sigma == 2.0 and d.cutoff == 10.0
     assert d.input_vector_type == "syndrome" and d.max_iter == 3
-    with pytest.raises(ValueError, match="sigma"):
-        SoftInfoBpDecoder(h, error_rate=0.1, sigma=2)  # int, not float (pyx:748)
+    assert SoftInfoBpDecoder(h, error_rate=0.1, sigma=2).sigma == 2.0  # `sigma: float` is a C double: an int converts (api_reference.json)
+    with pytest.raises(TypeError, match="must be real number"):
+        SoftInfoBpDecoder(h, error_rate=0.1, sigma="2")
     with pytest.raises(ValueError, match="sigma"):
         SoftInfoBpDecoder(h, error_rate=0.1, sigma=-1.0)
     with pytest.raises(ValueError):
