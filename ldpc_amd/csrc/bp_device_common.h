@@ -187,6 +187,99 @@ __device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs
     }
 }
 
+// ---- product-sum check row, libm-exact math: the fast path -------------------------------------------------------
+// The exact `log` has two evaluation branches (argument within ~6 % of 1, or not), and in a wavefront of 64 syndromes
+// both are almost always populated -- at the benchmark's operating point 5.7 % of the arguments are near 1, i.e. ~22 of
+// a row's 384 (lane, entry) pairs, yet every entry paid for both branches (42 + 37 VALU instructions).  Here
+//   * every lane evaluates the TABLE branch for each of its entries and stores the message,
+//   * lanes whose argument is near 1 park it in a wave-private LDS buffer, COMPACTED over the whole row (position =
+//     entries parked before + rank of the lane among this entry's parkers: one ballot, one mbcnt),
+//   * the near-1 branch then runs once per 64 parked arguments (usually once per row instead of six times), and
+//   * the owners fetch their results and overwrite the message they had stored.
+// The same operations reach the same operands, so every message keeps its bits.  The row-level preconditions (no NaN
+// and no +-1 among the row's tanh values in any LIVE lane) remove the per-entry 0 / inf / NaN patches of the generic
+// routine: then q = (1 + x) / (1 - x) is a normal number.  Lanes whose syndrome has converged keep computing (the
+// wavefront executes them anyway) but their values are dead, so they neither veto the fast path nor park anything;
+// a row that fails the precondition takes the generic path below.
+#define LDPC_NEAR_SLOTS 48  // parked arguments per wavefront (LDS doubles); a row with more evaluates the excess in place
+#define LDPC_NEAR_BYTES (LDPC_NEAR_SLOTS * 8)
+
+__device__ __forceinline__ int lane_rank(uint64_t mask) {  // number of set bits of `mask` below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <int DR>
+__device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR], int d, int rs, bool neg, const MsgBuf &Ct, int l8,
+                                                        const double *log_tab, uint64_t live, double *near_buf) {
+    if (d < 2) return false;  // a weight-1 row: x is the empty product 1.0, q = 2 / 0 (generic path: +inf)
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < DR; ++k)
+        if (k < d) bad = bad || !(__builtin_fabs(cur[k]) < 1.0);
+    if (__builtin_amdgcn_ballot_w64(bad) & live) return false;
+    const int lane = (int)(threadIdx.x & (LDPC_WAVE - 1));
+    const bool lane_live = (live >> lane) & 1ull;
+    double pre[DR];
+    double temp = 1.0;
+#pragma unroll
+    for (int k = 0; k < DR; ++k)
+        if (k < d) { pre[k] = temp; temp *= cur[k]; }
+    temp = 1.0;
+    uint64_t parked[DR];
+    int first[DR];
+    int total = 0;
+#pragma unroll
+    for (int k = DR - 1; k >= 0; --k) {
+        parked[k] = 0;
+        first[k] = 0;
+        if (k < d) {
+            const double x = pre[k] * temp;
+            temp *= cur[k];
+            const double q = ldpc_math::div_cr(1.0 + x, 1.0 - x);
+            const bool near = ldpc_math::log_near_one(q) && lane_live;
+            double y = ldpc_math::log_libm_general(q, log_tab);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(near);
+            if (mask) {
+                const int cnt = __builtin_popcountll(mask);
+                if (total + cnt <= LDPC_NEAR_SLOTS) {
+                    if (near) near_buf[total + lane_rank(mask)] = q;
+                    parked[k] = mask;
+                    first[k] = total;
+                    total += cnt;
+                } else if (near) {
+                    y = ldpc_math::log_libm_near_one(q);  // buffer full: in place, as the generic routine would
+                }
+            }
+            Ct.st(l8, rs + k, neg ? -y : y);
+            LDPC_EDGE_FENCE();
+        }
+    }
+    if (total) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of a wavefront execute in order; this only pins the compiler
+        for (int c = lane; c < total; c += LDPC_WAVE) near_buf[c] = ldpc_math::log_libm_near_one(near_buf[c]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = DR - 1; k >= 0; --k)
+            if (k < d && parked[k]) {
+                if ((parked[k] >> lane) & 1ull) {
+                    const double y = near_buf[first[k] + lane_rank(parked[k])];
+                    Ct.st(l8, rs + k, neg ? -y : y);
+                }
+            }
+    }
+    return true;
+}
+
+// product-sum rows of the streaming kernels: the fast path where it applies, else the generic row
+template <int METHOD, int MATH, int DR>
+__device__ __forceinline__ void check_row_live(const double (&cur)[DR], int d, int rs, bool neg, int parity0, double alpha,
+                                               const MsgBuf &Ct, int l8, const double *log_tab, uint64_t live, double *near_buf) {
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0) {
+        if (check_row_ps_exact_fast<DR>(cur, d, rs, neg, Ct, l8, log_tab, live, near_buf)) return;
+    }
+    check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity0, alpha, Ct, l8, log_tab);
+}
+
 // A row heavier than the register bound: two streaming sweeps, exactly the reference's loops.
 template <int METHOD, int MATH>
 __device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int parity, double alpha,

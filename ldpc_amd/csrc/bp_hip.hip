@@ -1217,7 +1217,9 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         }
         if (waves > 16) waves = 16;
         // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
-        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth;
+        // + the parking space of the exact product-sum check row (LDPC_NEAR_BYTES per wavefront, behind the rings)
+        const size_t near_bytes = (h->bp_method == LDPC_HIP_PRODUCT_SUM && h->math_mode == LDPC_HIP_MATH_LIBM_EXACT) ? LDPC_NEAR_BYTES : 0;
+        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth + near_bytes;
         while (lds_per_wave * (size_t)waves > 144u * 1024u) --waves;
         const size_t dyn_lds = lds_per_wave * (size_t)waves;
         if (dyn_lds > 48u * 1024u)

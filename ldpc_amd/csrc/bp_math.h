@@ -191,16 +191,20 @@ LDPC_HD double tanh_half_libm(double b) {
     const double Q1 = -3.33333333333331316428e-02, Q2 = 1.58730158725481460165e-03,
                  Q3 = -7.93650757867487942473e-05, Q4 = 4.00821782732936239552e-06,
                  Q5 = -2.01099218183624371326e-07;
-    const double xh = b * 0.5;  // == b / 2
-    const double ax = __builtin_fabs(xh);
-    const bool big = ax >= 1.0;
-    const double w2 = ax + ax;  // 2|x| exactly
-    const double w = big ? w2 : -w2;
+    // x = b / 2 and 2|x| = |b| exactly for every normal b (a subnormal b ends in the "tiny" patch below, which does
+    // its own b * 0.5), so the argument reduction works on |b| and never forms x.
+    const uint64_t bb = as_u64(b);
+    const uint32_t hb = (uint32_t)(bb >> 32) & 0x7fffffffu;  // high word of |b| = high word of 2|x|
+    const bool big = hb >= 0x40000000u;                      // |x| >= 1 (a NaN lands here too and is patched at the end)
+    const uint32_t sign_w = big ? 0u : 0x80000000u;          // w = 2|x| if |x| >= 1, else -2|x|
+    const double w = as_f64((bb & 0x7fffffffffffffffull) | ((uint64_t)sign_w << 32));
     // ---- __expm1(w): argument reduction (s_expm1.c) ----
-    const uint32_t hw = (uint32_t)(as_u64(w2) >> 32);  // high word of |w|
-    int k = (int)(invln2 * w + (big ? 0.5 : -0.5));
-    k = hw < 0x3ff0a2b2u ? -1 : k;  // 0.5 ln2 < |w| < 1.5 ln2 (only reachable for w < 0: big has |w| >= 2)
-    k = hw > 0x3fd62e42u ? k : 0;   // |w| <= 0.5 ln2: no reduction
+    //   |w| <= 0.5 ln2 (hw <= 0x3fd62e42): k = 0;  0.5 ln2 < |w| < 1.5 ln2: k = +-1;  else k = (int)(invln2 w +- 0.5).
+    //   The middle case needs no test of its own: there invln2 |w| + 0.5 lies in [1.0000003, 1.9999997] (the bounds are
+    //   the doubles next to the two high-word thresholds, 1.5 ln2 itself sits INSIDE the high word 0x3ff0a2b2 and so takes
+    //   the general formula in the original as well), which truncates to 1.
+    int k = (int)(invln2 * w + as_f64((uint64_t)(0x3fe00000u | sign_w) << 32));  // + copysign(0.5, w)
+    k = hb > 0x3fd62e42u ? k : 0;
     const double t_k = (double)k;
     const double hi = w - t_k * ln2_hi;  // k = 0: hi = w, lo = 0, c = 0 (identical to the unreduced path)
     const double lo = t_k * ln2_lo;
@@ -222,19 +226,23 @@ LDPC_HD double tanh_half_libm(double b) {
     const double a1 = k >= 2 ? as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ks)) << 32) : 1.0;  // 1 - 2^-k | 1
     const double y1 = add_exponent(a1 - emx, k);      // 2 <= k < 20: the result; k <= -2: result + 1
     double t = k >= 2 ? y1 : y1 - 1.0;
-    t = k == -1 ? -(0.5 * emx + 0.5) : t;
+    t = k == -1 ? -fma_(0.5, emx, 0.5) : t;           // -(0.5 * emx + 0.5): the product is exact, so the fused form rounds alike
     t = k == 0 ? -emx : t;
-    if (LDPC_ANY(big && w2 >= 13.0)) {  // superset of k >= 20 (w >= 13.5) phrased on a value that is never poison
+    // everything rare hangs off ONE test: |b| >= 13 (superset of k >= 20), |x| < 2^-55, |x| >= 22, inf, NaN
+    const bool rare = hb - 0x3c900000u >= 0x402a0000u - 0x3c900000u;
+    const bool any_rare = LDPC_ANY(rare);
+    if (any_rare) {
         const double two_mk = as_f64((uint64_t)((uint32_t)(0x3ff - k) << 20) << 32);  // 2^-k
         const double y2 = add_exponent((x - (e + two_mk)) + 1.0, k);
-        t = k >= 20 ? y2 : t;
+        t = (big && k >= 20) ? y2 : t;
     }
     // ---- tanh from expm1 ----
     const double quo = div_cr(big ? 2.0 : -t, t + 2.0);  // denominator in [1.1, 2^64]
     double z = big ? 1.0 - quo : quo;
-    z = __builtin_copysign(z, xh);
-    const uint32_t hx = (uint32_t)(as_u64(ax) >> 32);
-    if (LDPC_ANY(hx - 0x3c800000u >= 0x40360000u - 0x3c800000u)) {  // |x| < 2^-55, |x| >= 22, inf or NaN
+    z = __builtin_copysign(z, b);
+    if (any_rare) {
+        const double xh = b * 0.5;
+        const double ax = __builtin_fabs(xh);
         z = ax < 0x1p-55 ? xh * (1.0 + xh) : z;                      // tiny and +-0 (carries its own sign)
         z = ax >= 22.0 ? __builtin_copysign(1.0, xh) : z;            // also +-inf
         z = xh != xh ? xh + xh : z;                                   // NaN
@@ -299,6 +307,57 @@ LDPC_HD double log_libm(double q, const double *tab) {
     }
     return y;
 #endif
+}
+
+// ---- the same log, split for the check pass's fast path ----------------------------------------------------------
+// There q = (1 + x) / (1 - x) with 0 <= |x| < 1 (the row's tanh values all have magnitude below 1 and none is NaN:
+// tested once per row), so q is a normal number in [2^-54, 2^54]: no zero, infinity or NaN tail, and the two
+// evaluation branches can be driven separately (the near-1 branch on compacted lanes, bp_device_common.h).
+LDPC_HD bool log_near_one(double q) {  // glibc's `ix - LO < HI - LO` on the high word (LO and HI have zero low words)
+    return (uint32_t)(as_u64(q) >> 32) - 0x3fee0000u < 0x3ff10900u - 0x3fee0000u;
+}
+
+// the table branch, for q outside [1 - 2^-4, 1 + 0x1.09p-4)
+LDPC_HD double log_libm_general(double q, const double *tab) {
+#if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
+    return q;  // host pass of hipcc: never called
+#else
+    const double A[5] = LDPC_LOG_POLY;
+    const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    const uint64_t ix = as_u64(q);
+    const uint32_t hq = (uint32_t)(ix >> 32);
+    const uint32_t th = hq - 0x3fe60000u;                      // high word of tmp = ix - 0x3fe6000000000000
+    const uint32_t off = (th >> 9) & 0x7f0u;                   // ((tmp >> 45) & 127) * 16: byte offset of {1/c, log c}
+    const int k = (int32_t)th >> 20;                           // (int64_t)tmp >> 52
+    const double z = as_f64(((uint64_t)(hq - (th & 0xfff00000u)) << 32) | (uint32_t)ix);
+    const double *pair = reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + off);
+    const double invc = pair[0], logc = pair[1];
+    const double r = fma_(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = fma_(kd, Ln2hi, logc);
+    const double hi = w + r;
+    const double lo = fma_(kd, Ln2lo, w - hi + r);
+    const double r2 = r * r;
+    const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
+    return fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
+#endif
+}
+
+// the near-1 branch, for q in [1 - 2^-4, 1 + 0x1.09p-4).  q == 1 needs no patch: r = 0 makes every term +0.
+LDPC_HD double log_libm_near_one(double q) {
+    const double B[11] = LDPC_LOG_POLY1;
+    const double r = q - 1.0, r2 = r * r, r3 = r * r2;
+    const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_(r, B[8], B[7])));
+    const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_(r, B[5], B[4])));
+    const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_(r, B[2], B[1])));
+    double w = r * 0x1p27;
+    const double rhi = r + w - w;
+    const double rlo = r - rhi;
+    w = rhi * rhi * B[0];  // B[0] == -0.5
+    const double hi = r + w;
+    double lo = r - hi + w;
+    lo = fma_(B[0] * rlo, rhi + r, lo);
+    return fma_(r3, p1, lo) + hi;
 }
 
 // std::log((1 + x) / (1 - x)) with the host libm's bits; |x| <= 1 or NaN.  1 - x == 0 (x == 1) gives

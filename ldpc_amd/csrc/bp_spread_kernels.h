@@ -34,6 +34,7 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
 template <int METHOD, int MATH, int DR>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
     __shared__ __attribute__((aligned(16))) double log_tab[256];
+    __shared__ double near_bufs[4][LDPC_NEAR_SLOTS];
     int64_t tile;
     const TileState *st;
     int it;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
 #pragma unroll
             for (int k = 0; k < DR; ++k)
                 if (k < d) cur[k] = At.ld(l8, rs + k);
-            check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+            check_row_live<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab, ~done, near_bufs[wave]);
         } else {
             check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
         }

@@ -11,7 +11,7 @@
 //   RING    0: next row / bits prefetched into VGPRs;  2 or 3: slots of the per-wavefront LDS ring filled by
 //           `buffer_load_dwordx4 ... lds` (only for matrices with a single row weight DR and column weight DC)
 template <int METHOD, int MATH, int DR, int DC, int RING>
-__global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING ? 6 : 4))) bp_decode_kernel(const BpArgs a) {
     constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -48,6 +48,8 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
     constexpr int N_BIT = RING * (2 * DC + 2) + (RING - 1) * DC;
     const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
     const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
+    // parking space of the exact product-sum check row (check_row_ps_exact_fast): behind the rings, LDPC_NEAR_BYTES per wavefront
+    double *near_buf = reinterpret_cast<double *>(ldpc_dyn_lds + (size_t)nwaves * (RING * SLOT_BYTES) + (size_t)wave * LDPC_NEAR_BYTES);
     const unsigned l16 = (unsigned)lane * 16u;
 
     bool llr_each = false;  // tile-uniform: posteriors are stored by every bit pass (set at the first convergence event)
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 if (idx + RING < nsteps) issue_row(i + RING * nwaves, slot);
                 const bool neg = (sload(nzm + i) >> lane) & 1ull;         // syndrome[i] != 0 (bp.hpp:213)
                 const int parity = (int)((sload(par + i) >> lane) & 1ull);
-                check_row<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab);
+                check_row_live<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
                 slot = slot + 1 == RING ? 0 : slot + 1;
             }
         } else {
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(1024) bp_decode_kernel(const BpArgs a) {
                 }
                 const bool neg = (sload(nzm + i) >> lane) & 1ull;
                 const int parity = (int)((sload(par + i) >> lane) & 1ull);
-                if (d <= DR) check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab);
+                if (d <= DR) check_row_live<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
                 else check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
                 rs = rs_n;
                 d = d_n;

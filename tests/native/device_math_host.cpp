@@ -18,6 +18,11 @@ double dx_log_ratio(double x) { return ldpc_math::ps_log_ratio_libm(x, ldpc_math
 void dx_tanh_half_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::tanh_half_libm(in[i]); }
 void dx_log_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::log_libm(in[i], ldpc_math::k_log_tab); }
 void dx_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = ldpc_math::ps_log_ratio_libm(in[i], ldpc_math::k_log_tab); }
+// the split routines of the check pass's fast path, recombined: must equal log_libm wherever q is a normal number in [2^-54, 2^54]
+void dx_log_split_v(long n, const double *in, double *out) {
+    for (long i = 0; i < n; i++)
+        out[i] = ldpc_math::log_near_one(in[i]) ? ldpc_math::log_libm_near_one(in[i]) : ldpc_math::log_libm_general(in[i], ldpc_math::k_log_tab);
+}
 void libm_log_ratio_v(long n, const double *in, double *out) { for (long i = 0; i < n; i++) out[i] = std::log((1 + in[i]) / (1 - in[i])); }
 void *dx_tanh_half_ptr() { return (void *)&dx_tanh_half; }
 void *dx_log_ratio_ptr() { return (void *)&dx_log_ratio; }

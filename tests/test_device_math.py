@@ -30,7 +30,7 @@ def dm():
                        check=True)
     lib = C.CDLL(SO)
     for f in ("dm_tanh_half_v", "dm_log_pos_v", "dm_log_ratio_v", "libm_tanh_half_v", "libm_log_v",
-              "dx_tanh_half_v", "dx_log_v", "dx_log_ratio_v", "libm_log_ratio_v"):
+              "dx_tanh_half_v", "dx_log_v", "dx_log_ratio_v", "libm_log_ratio_v", "dx_log_split_v"):
         getattr(lib, f).argtypes = [C.c_long, _dp, _dp]
     for f in ("ref_tanh_half_v", "ref_log_v"):
         getattr(lib, f).argtypes = [C.c_long, _dp, _ldp]
@@ -110,9 +110,29 @@ def test_libm_twins_are_bit_identical_to_the_host_libm(dm):
                         [0.0, np.inf, np.nan, 1.0, 2.0 ** -54, 2.0 ** 54]])
     x = np.concatenate([rng.uniform(-1, 1, n), np.tanh(rng.uniform(-20, 20, n)), rng.uniform(-1e-3, 1e-3, n),
                         [1.0, -1.0, 0.0, -0.0, np.nan, 1 - 2.0 ** -53, -1 + 2.0 ** -53]])
+    # arguments around every threshold of the tanh twin's argument reduction and tails (high-word boundaries, k changes)
+    edges = []
+    for v in (0.5 * np.log(2) / 1, 1.5 * np.log(2), 2.0, 13.0, 13.5, 20 * np.log(2), 44.0, 2.0 ** -54, 2.0 ** -55, 2.0 ** -1022, 5e-324,
+              *(k * np.log(2) for k in range(1, 64)), *((k + 0.5) * np.log(2) for k in range(0, 64))):
+        e = np.float64(v)
+        around = [e]
+        for _ in range(40):
+            around.append(np.nextafter(around[-1], np.inf))
+        lo_ = e
+        for _ in range(40):
+            lo_ = np.nextafter(lo_, -np.inf)
+            around.append(lo_)
+        edges.extend(around)
+    hw = np.array([0x3fd62e42, 0x3fd62e43, 0x3ff0a2b1, 0x3ff0a2b2, 0x3ff0a2b3, 0x40000000, 0x3fffffff, 0x402a0000, 0x4029ffff, 0x3c900000, 0x3c8fffff,
+                   0x40460000, 0x4045ffff], dtype=np.uint64)
+    words = np.concatenate([(hw << np.uint64(32)) | np.uint64(lo32) for lo32 in (0, 1, 0xffffffff, 0x80000000)]).view(np.float64)
+    edges = np.concatenate([np.array(edges, dtype=np.float64), words])
+    b = np.concatenate([b, edges, -edges])
+    q_norm = np.concatenate([np.exp(rng.uniform(-37.4, 37.4, n)), rng.uniform(0.9, 1.1, n), [1.0, 2.0 ** -54, 2.0 ** 54, 0.9375, np.nextafter(0.9375, 0),
+                             1.064697265625, np.nextafter(1.064697265625, 0), np.nextafter(1.0, 0), np.nextafter(1.0, 2)]])
     ok = True
     for mine, libm, arg in (("dx_tanh_half_v", "libm_tanh_half_v", b), ("dx_log_v", "libm_log_v", q),
-                            ("dx_log_ratio_v", "libm_log_ratio_v", x)):
+                            ("dx_log_ratio_v", "libm_log_ratio_v", x), ("dx_log_split_v", "libm_log_v", q_norm)):
         got, want = np.empty(len(arg)), np.empty(len(arg))
         getattr(dm, mine)(len(arg), arg, got)
         getattr(dm, libm)(len(arg), arg, want)
