@@ -132,7 +132,7 @@ int ldpc_hip_bp_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes, int
  * decision for converged rows and the OSD-0 solution otherwise; llr / iterations / converge are BP's
  * (bpd.log_prob_ratios, bpd.iterations, bpd.converge), any of them may be NULL.
  * The bit-packed [H | s] of one syndrome must fit in LDS (m * ceil((n+1)/64) * 8 + 13 n + 4 m <= 150 KiB),
- * else LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H (any H e does).
+ * else LDPC_HIP_ERR_UNSUPPORTED.  Syndromes outside the image of H: see ldpc_hip_bposd_get_status.
  */
 int ldpc_hip_bposd0_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
                                  uint8_t *decoding, double *llr, int32_t *iterations,
@@ -154,9 +154,25 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes,
  * branch whatever the method (osd.hpp:114).  Outputs as for ldpc_hip_bposd0_decode_batch.
  * Limits: the LDS bound of OSD-0 (plus 8 m + 4 n bytes); OSD_E osd_order <= 24; OSD_CS osd_order <= 64 (pairs
  * whose second index reaches past the k = n - rank non-pivot columns are skipped -- undefined behaviour in the
- * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes must lie in the image of H.
+ * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes outside the image of H: see below.
  */
 int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
+/*
+ * Syndromes outside the image of H.  Every H e is inside; a rank-deficient H (toric-code checks, any H with dependent
+ * rows) fed with a syndrome that breaks a dependency is not, and then NO x satisfies H x = s.  The reference still
+ * returns a vector: RowReduce::fast_solve never reaches its early stop, eliminates every column, and lu_solve
+ * (gf2sparse_linalg.hpp:237-288) solves the equations of the PIVOT ROWS only -- which rows those are is decided by the
+ * sparsity heuristic of its linked-list elimination (fewest entries across L and U, ties by current row position,
+ * :327-340), i.e. by an implementation detail of that data structure.  The device kernels eliminate bit-packed rows and
+ * take the first candidate row; their output for such a row is the solution of THEIR pivot-row subsystem (deterministic,
+ * supported on the same pivot columns, generally a different vector than the reference's), and it is flagged:
+ * after any ldpc_hip_bposd*_decode_batch call, ldpc_hip_bposd_get_status fills status[batch] (host or device pointer) with
+ *   0  BP converged, OSD did not run            1  OSD ran and H x = s (bit-identical to the reference)
+ *   2  OSD ran, s is outside the image of H: x does not satisfy H x = s and is NOT the reference's vector.
+ * `batch` must be the batch size of that decode.  (tests/golden/osd_outside_image_*.npz hold the reference's outputs on
+ * such syndromes next to in-image ones.)
+ */
+int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
 /* Serial schedule: a 64-syndrome tile is decoded by one wavefront, which runs until its slowest syndrome is done.  With
  * repacking a first pass of `first_pass_iters` iterations runs over the whole batch and the rows it leaves unconverged are
  * packed into dense tiles and decoded again from the start with the full max_iter (deterministic: same results).

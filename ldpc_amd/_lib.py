@@ -10,13 +10,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libldpc_hip.so")
+# (LDPC_HIP_LIB: another build of the same library, for A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, "lib", "libldpc_hip.so")
 
 # every symbol include/ldpc_hip.h declares (tests/test_cabi_symbols.py checks header <-> library)
 SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
     "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
-    "ldpc_hip_bp_set_osd", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
+    "ldpc_hip_bp_set_osd", "ldpc_hip_bposd_get_status", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
     "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
@@ -75,6 +76,7 @@ def load():
     lib.ldpc_hip_bposd0_decode_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.ldpc_hip_bposd0_decode_batch_async.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.ldpc_hip_bp_set_osd.argtypes = [vp, i32, i32]
+    lib.ldpc_hip_bposd_get_status.argtypes = [vp, vp, i64]
     lib.ldpc_hip_bp_set_osd_kernel.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_repack.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_serial_kernel.argtypes = [vp, i32]

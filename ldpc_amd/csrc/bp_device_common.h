@@ -93,20 +93,29 @@ __device__ __forceinline__ uint64_t wave_or(uint64_t v) {
 // lane offset", so an access costs no per-lane 64-bit address arithmetic and no address VGPR pairs
 // (flat global_load needs a VGPR pair per distinct address; with ~30 addresses live that alone cost
 // an occupancy step).  One descriptor covers one tile's [nnz][64] doubles: nnz * 512 bytes < 4 GiB.
+// Cache policy of the message traffic (the `aux` operand of the buffer instructions: 0 = default, 2 = nt, non-temporal).
+// A large batch's messages are touched once per pass and come round again only after gigabytes of other tiles' traffic,
+// so no cache level can hold them; nt tells L2 / MALL not to try (measured on the headline workload: +2.4 % at 1024 tiles,
+// +3.8 % at 64).  A handful of tiles (<= ~250 MB of messages) DO live in the 256 MB MALL from one pass to the next and are
+// better off with the default policy (8 tiles: nt -3 %), so the policy is a template parameter of the buffer type.
 typedef unsigned int ldpc_v2u __attribute__((ext_vector_type(2)));
-struct MsgBuf {
+template <int AUX>
+struct MsgBufT {
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ double ld(int lane8, int edge) const {  // edge is wave-uniform
-        ldpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (int)((unsigned)edge << 9), 0);
+        ldpc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane8, (int)((unsigned)edge << 9), AUX);
         return __builtin_bit_cast(double, v);
     }
     __device__ __forceinline__ void st(int lane8, int edge, double x) const {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ldpc_v2u, x), rsrc, lane8,
-                                              (int)((unsigned)edge << 9), 0);
+                                              (int)((unsigned)edge << 9), AUX);
     }
 };
-__device__ __forceinline__ MsgBuf make_msgbuf(double *base, unsigned rows) {
-    MsgBuf b;
+typedef MsgBufT<0> MsgBuf;    // default policy
+typedef MsgBufT<2> MsgBufNT;  // non-temporal: streamed tiles
+template <class BUF = MsgBuf>
+__device__ __forceinline__ BUF make_msgbuf(double *base, unsigned rows) {
+    BUF b;
     b.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows << 9), 0x00020000);
     return b;
 }
@@ -143,9 +152,9 @@ __device__ __forceinline__ double edge_form(double b2c) {
 
 // One check row held in registers: cur[0..d) are the row's A values in ascending column order.
 // Computes the d check->bit messages (bp.hpp:201-219 / 220-273) and stores them to C[rs + k].
-template <int METHOD, int MATH, int DR>
+template <int METHOD, int MATH, int DR, class BUF>
 __device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs, bool neg, int parity0,
-                                          double alpha, const MsgBuf &Ct, int l8, const double *log_tab) {
+                                          double alpha, const BUF &Ct, int l8, const double *log_tab) {
     double pre[DR];
     if (METHOD == LDPC_HIP_PRODUCT_SUM) {
         double temp = 1.0;
@@ -191,11 +200,12 @@ __device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs
 // The exact `log` has two evaluation branches (argument within ~6 % of 1, or not), and in a wavefront of 64 syndromes
 // both are almost always populated -- at the benchmark's operating point 5.7 % of the arguments are near 1, i.e. ~22 of
 // a row's 384 (lane, entry) pairs, yet every entry paid for both branches (42 + 37 VALU instructions).  Here
-//   * every lane evaluates the TABLE branch for each of its entries and stores the message,
+//   * every lane evaluates the TABLE branch for each of its entries and keeps the result in a register (the one that
+//     held the entry's prefix product, which is dead by then),
 //   * lanes whose argument is near 1 park it in a wave-private LDS buffer, COMPACTED over the whole row (position =
 //     entries parked before + rank of the lane among this entry's parkers: one ballot, one mbcnt),
-//   * the near-1 branch then runs once per 64 parked arguments (usually once per row instead of six times), and
-//   * the owners fetch their results and overwrite the message they had stored.
+//   * the near-1 branch then runs once per 64 parked arguments (usually once per row instead of six times),
+//   * the owners fetch their results, and the row's messages are stored -- once each.
 // The same operations reach the same operands, so every message keeps its bits.  The row-level preconditions (no NaN
 // and no +-1 among the row's tanh values in any LIVE lane) remove the per-entry 0 / inf / NaN patches of the generic
 // routine: then q = (1 + x) / (1 - x) is a normal number.  Lanes whose syndrome has converged keep computing (the
@@ -208,8 +218,8 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) {  // number of set bits
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <int DR>
-__device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR], int d, int rs, bool neg, const MsgBuf &Ct, int l8,
+template <int DR, class BUF>
+__device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR], int d, int rs, bool neg, const BUF &Ct, int l8,
                                                         const double *log_tab, uint64_t live, double *near_buf) {
     if (d < 2) return false;  // a weight-1 row: x is the empty product 1.0, q = 2 / 0 (generic path: +inf)
     bool bad = false;
@@ -219,6 +229,7 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
     if (__builtin_amdgcn_ballot_w64(bad) & live) return false;
     const int lane = (int)(threadIdx.x & (LDPC_WAVE - 1));
     const bool lane_live = (live >> lane) & 1ull;
+    const uint64_t sign = neg ? 0x8000000000000000ull : 0ull;  // message_sign (bp.hpp:213) as a sign-bit flip
     double pre[DR];
     double temp = 1.0;
 #pragma unroll
@@ -227,6 +238,7 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
     temp = 1.0;
     uint64_t parked[DR];
     int first[DR];
+    double out[DR];
     int total = 0;
 #pragma unroll
     for (int k = DR - 1; k >= 0; --k) {
@@ -236,9 +248,10 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
             const double x = pre[k] * temp;
             temp *= cur[k];
             const double q = ldpc_math::div_cr(1.0 + x, 1.0 - x);
-            const bool near = ldpc_math::log_near_one(q) && lane_live;
+            const bool near_any = ldpc_math::log_near_one(q);
             double y = ldpc_math::log_libm_general(q, log_tab);
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(near);
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(near_any) & live;  // (scalar AND: dead lanes park nothing)
+            const bool near = near_any && lane_live;
             if (mask) {
                 const int cnt = __builtin_popcountll(mask);
                 if (total + cnt <= LDPC_NEAR_SLOTS) {
@@ -250,7 +263,7 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
                     y = ldpc_math::log_libm_near_one(q);  // buffer full: in place, as the generic routine would
                 }
             }
-            Ct.st(l8, rs + k, neg ? -y : y);
+            out[k] = y;
             LDPC_EDGE_FENCE();
         }
     }
@@ -261,29 +274,29 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
 #pragma unroll
         for (int k = DR - 1; k >= 0; --k)
             if (k < d && parked[k]) {
-                if ((parked[k] >> lane) & 1ull) {
-                    const double y = near_buf[first[k] + lane_rank(parked[k])];
-                    Ct.st(l8, rs + k, neg ? -y : y);
-                }
+                if ((parked[k] >> lane) & 1ull) out[k] = near_buf[first[k] + lane_rank(parked[k])];
             }
     }
+#pragma unroll
+    for (int k = 0; k < DR; ++k)
+        if (k < d) Ct.st(l8, rs + k, ldpc_math::as_f64(ldpc_math::as_u64(out[k]) ^ sign));
     return true;
 }
 
 // product-sum rows of the streaming kernels: the fast path where it applies, else the generic row
-template <int METHOD, int MATH, int DR>
+template <int METHOD, int MATH, int DR, class BUF>
 __device__ __forceinline__ void check_row_live(const double (&cur)[DR], int d, int rs, bool neg, int parity0, double alpha,
-                                               const MsgBuf &Ct, int l8, const double *log_tab, uint64_t live, double *near_buf) {
+                                               const BUF &Ct, int l8, const double *log_tab, uint64_t live, double *near_buf) {
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0) {
-        if (check_row_ps_exact_fast<DR>(cur, d, rs, neg, Ct, l8, log_tab, live, near_buf)) return;
+        if (check_row_ps_exact_fast<DR, BUF>(cur, d, rs, neg, Ct, l8, log_tab, live, near_buf)) return;
     }
-    check_row<METHOD, MATH, DR>(cur, d, rs, neg, parity0, alpha, Ct, l8, log_tab);
+    check_row<METHOD, MATH, DR, BUF>(cur, d, rs, neg, parity0, alpha, Ct, l8, log_tab);
 }
 
 // A row heavier than the register bound: two streaming sweeps, exactly the reference's loops.
-template <int METHOD, int MATH>
+template <int METHOD, int MATH, class BUF>
 __device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int parity, double alpha,
-                                                   const MsgBuf &At, const MsgBuf &Ct, int l8,
+                                                   const BUF &At, const BUF &Ct, int l8,
                                                    const double *log_tab) {
     if (METHOD == LDPC_HIP_PRODUCT_SUM) {
         double temp = 1.0;
@@ -321,9 +334,9 @@ __device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int 
 
 // One bit column held in registers: c[0..d) are its check->bit messages in ascending row order, e[] the
 // CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored.
-template <int METHOD, int MATH, int DC>
+template <int METHOD, int MATH, int DC, class BUF>
 __device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&e)[DC], int d, double prior,
-                                             const MsgBuf &At, int l8) {
+                                             const BUF &At, int l8) {
     double pre[DC];
     double temp = prior;
 #pragma unroll
@@ -354,7 +367,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ldpc_dyn_lds[];
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
     unsigned keep;  // M0 carries the LDS destination; it is compiler-reserved, so save/restore it in the same statement
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
 }
 template <int N>

@@ -144,6 +144,8 @@ struct ldpc_hip_bp {
     DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
+    DeviceBuf osd_status;                                           // [batch] of the last BP + OSD decode: 0 BP converged, 1 OSD solved, 2 s outside image(H)
+    int64_t osd_status_rows = 0;
     DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
     int32_t serial_kernel = -1;                                     // -1 auto, 0 one wavefront per tile, 1 level-parallel workgroup per tile
     bool order_visits_all = true;                                   // false: some bit is never updated (its outputs stay 0)
@@ -310,7 +312,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -486,9 +488,14 @@ typedef void (*bp_kernel_t)(const BpArgs);
 typedef void (*spread_kernel_t)(const SpreadArgs);
 
 template <int METHOD, int MATH>
-static void pick_spread_m(int max_row, int max_col, spread_kernel_t &kc, spread_kernel_t &kb) {
-    kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8> : bp_spread_check_kernel<METHOD, MATH, 16>;
-    kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4> : bp_spread_bit_kernel<METHOD, MATH, 8>;
+static void pick_spread_m(int max_row, int max_col, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
+    if (nt) {
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 1> : bp_spread_check_kernel<METHOD, MATH, 16, 1>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 1> : bp_spread_bit_kernel<METHOD, MATH, 8, 1>;
+    } else {
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 0> : bp_spread_check_kernel<METHOD, MATH, 16, 0>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 0> : bp_spread_bit_kernel<METHOD, MATH, 8, 0>;
+    }
 }
 
 struct KernelChoice {
@@ -1093,10 +1100,11 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     return LDPC_HIP_OK;
 }
 
-static void pick_spread(const ldpc_hip_bp *h, spread_kernel_t &kc, spread_kernel_t &kb) {
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, kc, kb);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, kc, kb);
-    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, kc, kb);
+// nt: non-temporal cache policy for the message traffic (tiles that outgrow the 256 MB MALL; see MsgBufT)
+static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
 }
 
 // Everything below runs on h->stream with device pointers only.
@@ -1276,7 +1284,8 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             // the host-mapped flag the host stops queueing -- which only matters when max_iter is far larger than
             // the iterations needed (the reference's default max_iter = n).
             spread_kernel_t kc, kb;
-            pick_spread(h, kc, kb);
+            // messages of the tiles in flight: 2 arrays x nnz x 512 B each; beyond ~the MALL they are streamed, not cached
+            pick_spread(h, (double)grid_tiles * 2.0 * (double)per_tile_msg > 384.0 * 1024.0 * 1024.0, kc, kb);
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
             const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
             const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
@@ -1295,6 +1304,20 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());
+        if (getenv("LDPC_HIP_DEBUG_HANDOFF")) {  // diagnostic only: waits for the device and reports what the persistent kernel parked
+            unsigned c[4] = {0, 0, 0, 0};
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(c, h->counter.p, 16, hipMemcpyDeviceToHost));
+            const TileState *ts = nullptr; (void)ts;
+            std::vector<TileState> states((size_t)tiles);
+            HIPCHK(hipMemcpy(states.data(), h->tile_state.p, sizeof(TileState) * (size_t)tiles, hipMemcpyDeviceToHost));
+            std::vector<int32_t> list((size_t)tiles);
+            HIPCHK(hipMemcpy(list.data(), h->handoff_list.p, sizeof(int32_t) * (size_t)tiles, hipMemcpyDeviceToHost));
+            long sum_it0 = 0; int min_it0 = 1 << 30, max_it0 = 0;
+            for (unsigned q = 0; q < c[1] && q < (unsigned)tiles; ++q) { const int it0 = states[(size_t)list[q]].it0; sum_it0 += it0; if (it0 < min_it0) min_it0 = it0; if (it0 > max_it0) max_it0 = it0; }
+            fprintf(stderr, "[ldpc_hip] tiles %lld: finished by the persistent kernel %u, parked %u (iterations done when parked: min %d mean %.1f max %d), live afterwards %u\n",
+                    (long long)tiles, c[0], c[1], c[1] ? min_it0 : 0, c[1] ? (double)sum_it0 / c[1] : 0.0, max_it0, c[2]);
+        }
 
         if (h->n > 0) {
             dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
@@ -1435,6 +1458,18 @@ static int osd_k(ldpc_hip_bp *h) {
     return h->osd_k_cached;
 }
 
+// After the OSD kernels: did every OSD output solve its syndrome?  (osd_status_kernel; read back with ldpc_hip_bposd_get_status)
+static int osd_status_pass(ldpc_hip_bp *h, const OsdArgs &a, int64_t batch) {
+    int rc;
+    if ((rc = h->osd_status.ensure((size_t)(batch ? batch : 1)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_status.p, 0, (size_t)batch, h->stream));
+    int64_t blocks = batch < 4096 ? batch : 4096;
+    hipLaunchKernelGGL(osd_status_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, h->stream, a, (uint8_t *)h->osd_status.p);
+    HIPCHK(hipGetLastError());
+    h->osd_status_rows = batch;
+    return LDPC_HIP_OK;
+}
+
 static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                         double *llr, int32_t *iters, uint8_t *conv) {
     if (osd_method == 0)  // OSD_OFF: BpOsdDecoder still calls OsdDecoder::decode, which then has no LU object -- refuse instead
@@ -1444,6 +1479,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     int rc;
     if (!llr) { if ((rc = h->osd_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; llr = (double *)h->osd_llr.p; }
     if (!conv) { if ((rc = h->osd_conv.ensure(B ? B : 1))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    h->osd_status_rows = 0;
     if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv))) return rc;
     if (h->m == 0 || h->n == 0) return LDPC_HIP_OK;
     OsdArgs a = {};
@@ -1558,7 +1594,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bk, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
         HIPCHK(hipGetLastError());
-        return LDPC_HIP_OK;
+        return osd_status_pass(h, a, batch);
     }
     int groups_per_cu = (int)((160u * 1024u) / dyn);
     if (groups_per_cu * waves > 32) groups_per_cu = 32 / waves;
@@ -1570,7 +1606,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     else if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());
-    return LDPC_HIP_OK;
+    return osd_status_pass(h, a, batch);
 }
 
 extern "C" {
@@ -1596,6 +1632,16 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_CS with osd_order > 64 is not available on the device");
     h->osd_method = osd_method;
     h->osd_order = osd_order;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch) {
+    if (!h || !status) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    if (batch != h->osd_status_rows) return fail(LDPC_HIP_ERR_INVALID, "the last BP + OSD decode on this handle had %lld rows, not %lld", (long long)h->osd_status_rows, (long long)batch);
+    if (batch == 0) return LDPC_HIP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(status, h->osd_status.p, (size_t)batch, is_device_ptr(status) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return LDPC_HIP_OK;
 }
 

@@ -35,6 +35,19 @@ namespace ldpc_math {
 
 LDPC_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// a * B + C for two CONSTANTS B and C.  A VOP3 instruction of gfx9 reads at most one scalar operand, so one constant sits in a
+// VGPR pair; left to itself the compiler then copies that pair into the destination and issues a two-address v_fmac (one extra
+// VALU instruction per Horner step whose addend is a constant).  Spelt out, the three-address form needs no copy.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_kk(double a, double B, double C) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(B), "v"(C));
+    return d;
+}
+#else
+LDPC_HD double fma_kk(double a, double B, double C) { return __builtin_fma(a, B, C); }
+#endif
+
 // 2^k as a double for k in [-1022, 1023] by exponent construction (no libm call)
 LDPC_HD double pow2i(int k) {
     const uint64_t bits = (uint64_t)(int64_t)(k + 1023) << 52;
@@ -222,8 +235,9 @@ LDPC_HD double tanh_half_libm(double b) {
     e -= hxs;
     const double emx = e - x;
     // ---- tails ----
-    const int ks = k < 0 ? 0 : (k > 31 ? 31 : k);                                    // shift guard only
-    const double a1 = k >= 2 ? as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ks)) << 32) : 1.0;  // 1 - 2^-k | 1
+    // a1 = 1 - 2^-k for 2 <= k < 20, 1 for k <= -2; not used otherwise (k is never 1; k in {0, -1} and k >= 20 have forms of
+    // their own).  A shift count is taken modulo 32, which turns k = -2, -3 into shifts by 30, 29: 0x200000 >> that = 0.
+    const double a1 = as_f64((uint64_t)(0x3ff00000u - (0x200000u >> ((unsigned)k & 31u))) << 32);
     const double y1 = add_exponent(a1 - emx, k);      // 2 <= k < 20: the result; k <= -2: result + 1
     double t = k >= 2 ? y1 : y1 - 1.0;
     t = k == -1 ? -fma_(0.5, emx, 0.5) : t;           // -(0.5 * emx + 0.5): the product is exact, so the fused form rounds alike
@@ -338,7 +352,7 @@ LDPC_HD double log_libm_general(double q, const double *tab) {
     const double hi = w + r;
     const double lo = fma_(kd, Ln2lo, w - hi + r);
     const double r2 = r * r;
-    const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
+    const double poly = fma_(r2, fma_kk(r, A[4], A[3]), fma_kk(r, A[2], A[1]));
     return fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
 #endif
 }
@@ -347,9 +361,9 @@ LDPC_HD double log_libm_general(double q, const double *tab) {
 LDPC_HD double log_libm_near_one(double q) {
     const double B[11] = LDPC_LOG_POLY1;
     const double r = q - 1.0, r2 = r * r, r3 = r * r2;
-    const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_(r, B[8], B[7])));
-    const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_(r, B[5], B[4])));
-    const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_(r, B[2], B[1])));
+    const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_kk(r, B[8], B[7])));
+    const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_kk(r, B[5], B[4])));
+    const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_kk(r, B[2], B[1])));
     double w = r * 0x1p27;
     const double rhi = r + w - w;
     const double rlo = r - rhi;

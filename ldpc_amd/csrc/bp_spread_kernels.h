@@ -31,8 +31,9 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
 }
 
 
-template <int METHOD, int MATH, int DR>
+template <int METHOD, int MATH, int DR, int NT>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
+    typedef MsgBufT<NT ? 2 : 0> Buf;  // cache policy of the message traffic: non-temporal once the tiles outgrow the caches
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     __shared__ double near_bufs[4][LDPC_NEAR_SLOTS];
     int64_t tile;
@@ -46,8 +47,8 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
-    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
     const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
     for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
@@ -66,8 +67,9 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     }
 }
 
-template <int METHOD, int MATH, int DC>
+template <int METHOD, int MATH, int DC, int NT>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
+    typedef MsgBufT<NT ? 2 : 0> Buf;
     int64_t tile;
     const TileState *st;
     int it;
@@ -76,10 +78,10 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
-    const MsgBuf At = make_msgbuf(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    const MsgBuf Ct = make_msgbuf(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const bool want_llr = a.bp.llr_t != nullptr;
-    const MsgBuf Lt = make_msgbuf(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+    const Buf Lt = make_msgbuf<Buf>(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
     const bool last = it == a.bp.max_iter;
     const bool lane_live = !((done >> lane) & 1ull);
     const int j0 = (blockIdx.x * 4 + wave) * a.nodes;

@@ -27,12 +27,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
     const uint64_t *__restrict__ par = a.par + tile * m;
     const uint64_t *__restrict__ nzm = a.nzm + tile * m;
 
-    const MsgBuf At = make_msgbuf(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-    const MsgBuf Ct = make_msgbuf(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    // (non-temporal policy: this kernel only runs batches of hundreds of tiles, whose messages no cache can hold)
+    const MsgBufNT At = make_msgbuf<MsgBufNT>(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const MsgBufNT Ct = make_msgbuf<MsgBufNT>(a.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     uint64_t *dec = a.dec + tile * n;    // frozen decisions of converged syndromes (zero-initialised)
     uint64_t *dcur = a.dcur + tile * n;  // this iteration's hard decisions, all lanes
     const bool want_llr = a.llr_t != nullptr;
-    const MsgBuf Lt = make_msgbuf(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
+    const MsgBufNT Lt = make_msgbuf<MsgBufNT>(want_llr ? a.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.A, want_llr ? (unsigned)n : 0u);
     const int l8 = lane * 8;
 
     __shared__ uint64_t red[2][16];

@@ -57,6 +57,34 @@ __global__ void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restr
     if (need) list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
 }
 
+// What became of every row that went through OSD: status[b] = 1 if the returned x satisfies H x = s, 2 if it does not.
+// The latter happens exactly when s lies outside the image of H (rank-deficient H with a syndrome that violates a
+// dependency among the checks, e.g. toric-code X checks with a measurement error): no x solves such a system.  The
+// reference then still returns a vector -- the solution of the subsystem formed by ITS pivot rows, and which rows those are
+// is decided by the sparsity heuristic of its linked-list elimination (fewest entries across L and U, ties by current
+// position; gf2sparse_linalg.hpp:327-340), which a bit-packed elimination does not re-enact.  The device returns the
+// solution of the subsystem of its own pivot rows (first candidate row in sorted-column order) and says so here.
+// One workgroup per listed row; the status array is zeroed beforehand (0 = BP converged, OSD not run).
+__global__ void __launch_bounds__(256) osd_status_kernel(const OsdArgs a, uint8_t *status) {
+    __shared__ int bad;
+    const unsigned count = a.counters[0];
+    for (unsigned r = blockIdx.x; r < count; r += gridDim.x) {
+        const int64_t b = a.list[r];
+        if (threadIdx.x == 0) bad = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+            unsigned par = a.synd[b * a.m + i] ? 1u : 0u;  // a non-zero byte is a one (gf2sparse_linalg.hpp:309)
+            for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) par ^= a.decoding[b * a.n + a.col_idx[e]] & 1u;
+            mine |= (int)par;
+        }
+        if (mine) atomicOr(&bad, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) status[b] = bad ? 2 : 1;
+        __syncthreads();
+    }
+}
+
 // next unconverged row for this wavefront, -1 when the list is exhausted
 __device__ __forceinline__ int64_t osd_next_row(const OsdArgs &a, int lane) {
     unsigned idx = 0;

@@ -116,6 +116,13 @@ class HipBpEngine:
         """OSD method / order for ``decode_batch(osd=True)``: 0 off, 1 OSD_0, 2 OSD_E, 3 OSD_CS (osd.hpp:18-23)."""
         _lib.check(self._lib.ldpc_hip_bp_set_osd(self._h, int(osd_method), int(osd_order)))
 
+    def osd_status(self, batch):
+        """Per row of the last BP + OSD decode: 0 BP converged, 1 OSD solved H x = s, 2 syndrome outside the image of H
+        (``ldpc_hip_bposd_get_status``)."""
+        out = np.zeros(int(batch), np.uint8)
+        _lib.check(self._lib.ldpc_hip_bposd_get_status(self._h, out.ctypes.data, int(batch)))
+        return out
+
     def set_repack(self, first_pass_iters):
         """Serial schedule: iterations of the first pass before unconverged rows are repacked (-1 auto, 0 off)."""
         _lib.check(self._lib.ldpc_hip_bp_set_repack(self._h, int(first_pass_iters)))
