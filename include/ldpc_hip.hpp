@@ -46,6 +46,8 @@ public:
     std::vector<double> log_prob_ratios_batch; // [batch][n]
     std::vector<int32_t> iterations_batch;     // [batch]
     std::vector<uint8_t> converge_batch;       // [batch]
+    std::vector<uint8_t> osd_status_batch;     // [batch] after decode_batch(..., osd = true): 0 BP converged, 1 OSD solved H x = s,
+                                               // 2 syndrome outside the image of H (ldpc_hip_bposd_get_status, ldpc_hip.h)
     int last_status = LDPC_HIP_OK;
     std::string last_error;
 
@@ -138,8 +140,14 @@ public:
         last_status = mh_ ? ldpc_hip_bp_multi_decode_batch(mh_, osd ? 1 : -1, syndromes, batch, decoding_batch.data(), llr_out,
                                                            iterations_batch.data(), converge_batch.data())
                           : fn(h_, syndromes, batch, decoding_batch.data(), llr_out, iterations_batch.data(), converge_batch.data());
-        if (last_status != LDPC_HIP_OK) last_error = ldpc_hip_last_error();
-        return last_status == LDPC_HIP_OK;
+        if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+        osd_status_batch.clear();
+        if (osd && !mh_) {  // (the sharded object keeps one status array per GPU; ask the handles for those)
+            osd_status_batch.assign((size_t)batch, 0);
+            last_status = ldpc_hip_bposd_get_status(h_, osd_status_batch.data(), batch);
+            if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
+        }
+        return true;
     }
 
     ldpc_hip_bp *handle() { return h_; }

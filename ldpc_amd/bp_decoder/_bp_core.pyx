@@ -37,6 +37,7 @@ cdef extern from "ldpc_hip.hpp" namespace "ldpc_hip":
         vector[double] log_prob_ratios_batch
         vector[int32_t] iterations_batch
         vector[uint8_t] converge_batch
+        vector[uint8_t] osd_status_batch
         int last_status
         string last_error
         int osd_method
@@ -48,6 +49,7 @@ cdef extern from "ldpc_hip.hpp" namespace "ldpc_hip":
 cdef class CyBpCore:
     cdef BpDecoderCpp *bpd
     cdef int m, n
+    cdef public object osd_status  # (B,) uint8 after decode_batch(..., osd0=True): see ldpc_hip_bposd_get_status
 
     def __cinit__(self, row_ptr, col_idx, int n, channel_probs, int max_iter, int bp_method, double ms_scaling_factor,
                   int device=-1):
@@ -178,4 +180,9 @@ cdef class CyBpCore:
         cv = np.empty(b, np.uint8)
         cv_view = <uint8_t[:b]> &self.bpd.converge_batch[0]
         cv[:] = cv_view
+        self.osd_status = None
+        if osd0 and self.bpd.osd_status_batch.size() == <size_t>b:
+            self.osd_status = np.empty(b, np.uint8)
+            cv_view = <uint8_t[:b]> &self.bpd.osd_status_batch[0]
+            self.osd_status[:] = cv_view
         return dec, llr, it, cv.astype(bool)

@@ -56,6 +56,9 @@ class BpOsdDecoder(BpDecoderBase):
         self._osdw_decoding = np.zeros(self.n, np.uint8)
         self._last_syndrome = np.zeros(self.m, np.uint8)
         self.bp_decoding_batch = None
+        # additive: per row of the last decode_batch, 0 = BP converged, 1 = OSD solved H x = s, 2 = the syndrome lies outside
+        # the image of H (no x solves it; the returned vector is flagged, see include/ldpc_hip.h: ldpc_hip_bposd_get_status)
+        self.osd_status_batch = None
 
     # ---- OSD parameters (pyx:139-234) -------------------------------------------------------------
     @property
@@ -110,10 +113,14 @@ class BpOsdDecoder(BpDecoderBase):
         cy = self._get_cy() if self._schedule == PARALLEL else None  # the schedule setters live on the ctypes engine
         if cy is not None:
             cy.osd_method, cy.osd_order = method, order
-            return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, True)
+            out = cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, True)
+            self._last_status = cy.osd_status
+            return out
         eng = self._get_engine()
         eng.set_osd(method, order)
-        return eng.decode_batch(synd2d, want_llr=want_llr, osd=True)
+        out = eng.decode_batch(synd2d, want_llr=want_llr, osd=True)
+        self._last_status = eng.osd_status(len(synd2d)) if hasattr(eng, "osd_status") else None
+        return out
 
     # ---- decode (pyx:78-136) ----------------------------------------------------------------------
     def decode(self, syndrome: np.ndarray) -> np.ndarray:
@@ -158,6 +165,7 @@ class BpOsdDecoder(BpDecoderBase):
             eng = self._get_engine()
             eng.set_osd(self._osd_method, self._osd_order)
             dec, llr, it, cv = eng.decode_batch(syndromes, want_llr=want_log_prob_ratios, osd=True)
+            self.osd_status_batch = eng.osd_status(int(syndromes.shape[0])) if hasattr(eng, "osd_status") else None
             zero = syndromes.any(dim=1).logical_not()
             if bool(zero.any()):
                 dec[zero] = 0
@@ -170,6 +178,7 @@ class BpOsdDecoder(BpDecoderBase):
         dtype = syndromes.dtype
         vec = np.ascontiguousarray(np.asarray(syndromes).astype(np.uint8))
         dec, llr, it, cv = self._decode_osd(vec, want_llr=want_log_prob_ratios)
+        self.osd_status_batch = self._last_status
         zero = ~vec.any(axis=1)
         dec[zero] = 0
         cv[zero] = True

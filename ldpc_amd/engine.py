@@ -401,6 +401,20 @@ class HipBpMultiEngine:
         _lib.check(self._lib.ldpc_hip_bp_multi_last_kernel_ms(self._mh, ms))
         return [float(v) for v in ms]
 
+    def osd_status(self, batch):
+        """Status of every row of the last BP + OSD decode, shard by shard (rows are cut on 64-row boundaries)."""
+        batch = int(batch)
+        nd, tiles = len(self.subs), (batch + 63) // 64
+        base, rem = divmod(tiles, nd)
+        parts = []
+        for d, sub in enumerate(self.subs):
+            t0 = d * base + min(d, rem)
+            t1 = t0 + base + (1 if d < rem else 0)
+            lo, hi = min(t0 * 64, batch), min(t1 * 64, batch)
+            if hi > lo:
+                parts.append(sub.osd_status(hi - lo))
+        return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
     def _sub_for(self, tensor=None):
         if tensor is not None and _is_torch(tensor) and tensor.is_cuda:
             for sub in self.subs:
