@@ -89,6 +89,10 @@ class _OracleLib:
             lib.bp_oracle_decode_serial_batch.argtypes = [
                 C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, C.c_void_p, _u8p, C.c_int64, _u8p,
                 C.c_void_p, _i32p, _u8p]
+            lib.bp_oracle_decode_serial_relative_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, _i32p, C.c_int, _u8p, C.c_int64, _u8p, _f64p, _i32p, _u8p]
+            lib.bp_oracle_decode_serial_orders_batch.argtypes = [
+                C.c_void_p, _f64p, C.c_int, C.c_int, C.c_double, _i32p, C.c_int, _u8p, C.c_int64, _u8p, _f64p, _i32p, _u8p]
             lib.osd0_oracle.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p, _u8p, _u8p]
             lib.bposd0_oracle_decode_batch.argtypes = lib.bp_oracle_decode_batch.argtypes
             lib.bp_oracle_soft_info_decode_batch.argtypes = [
@@ -151,6 +155,34 @@ class BpOracle:
         self.lib.bp_oracle_decode_serial_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha,
                                                od.ctypes.data if od is not None else None, s, b, dec,
                                                llr.ctypes.data if want_llr else None, it, conv)
+        return dec, llr, it, conv.astype(bool)
+
+    def decode_serial_relative_batch(self, syndromes, order_state=None, fresh=True):
+        """schedule='serial_relative' (bp.hpp:469-483).  ``fresh``: every row on a new decoder object (order 0..n-1 or
+        ``order_state``); else the rows run one after the other on one object.  Returns (..., final order)."""
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        st = np.arange(self.n, dtype=np.int32) if order_state is None else np.ascontiguousarray(order_state, np.int32).copy()
+        self.lib.bp_oracle_decode_serial_relative_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha, st,
+                                                        1 if fresh else 0, s, b, dec, llr, it, conv)
+        return dec, llr, it, conv.astype(bool), st
+
+    def decode_random_serial_batch(self, syndromes, seed):
+        """random_serial_schedule=True with random_schedule_seed=``seed`` (bp.hpp:467-468), a new decoder object per row:
+        iteration t of every row walks the order after t shuffles of 0..n-1 (std::shuffle on std::mt19937, shuffle_helper.cpp)."""
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        orders = shuffle_orders(seed, self.n, self.max_iter)[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        self.lib.bp_oracle_decode_serial_orders_batch(self._h, self.channel_probs, self.max_iter, self.method, self.alpha,
+                                                      np.ascontiguousarray(orders.reshape(-1)), self.max_iter, s, b, dec, llr, it, conv)
         return dec, llr, it, conv.astype(bool)
 
     def osd0(self, syndrome, llr):
@@ -219,6 +251,47 @@ class BpOracle:
             self.m, self.n, self.row_ptr, self.col_idx, seed, bernoulli_threshold(p), shot0, shots,
             synd, err.ctypes.data if want_errors else None)
         return (synd, err) if want_errors else synd
+
+
+def shuffle_orders(seed, n, count, order=None, state=b""):
+    """``count`` successive std::shuffle results of ``order`` (default 0..n-1) on std::mt19937(seed) -> (orders [count][n],
+    final order, generator state) through oracle/liboracle_shuffle.so (the host's own C++ standard library)."""
+    so = os.path.join(_HERE, "liboracle_shuffle.so")
+    if not os.path.exists(so):
+        build(ref=False)
+    lib = C.CDLL(so)
+    lib.oracle_shuffle_orders.argtypes = [C.c_uint32, C.c_int32, _i32p, C.c_int32, _i32p, C.c_char_p]
+    cur = np.arange(n, dtype=np.int32) if order is None else np.ascontiguousarray(order, np.int32).copy()
+    out = np.zeros((max(count, 1), n), np.int32)
+    buf = C.create_string_buffer(bytes(state), 16384)
+    lib.oracle_shuffle_orders(int(seed), int(n), cur, int(count), out.reshape(-1), buf)
+    return out[:count], cur, buf.value
+
+
+def ref_decode_stateful(h, syndromes, *, schedule, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum",
+                        ms_scaling_factor=1.0, random_serial=False, seed=0, fresh=True):
+    """The REAL reference with a schedule that keeps state in the decoder object: a new object per row (``fresh``) or one
+    object for all rows.  Returns (decoding, llr, iterations, converge, final order per row)."""
+    if not have_ref():
+        raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
+    lib = C.CDLL(REF_SO)
+    fn = lib.ref_bp_decode_fresh_batch if fresh else lib.ref_bp_decode_carried_batch
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                   _u8p, C.c_int64, _u8p, _f64p, _i32p, _u8p, _i32p]
+    m, n, row_ptr, col_idx = csr_arrays(h)
+    rows = np.ascontiguousarray(np.repeat(np.arange(m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32))
+    probs = _probs(n, error_rate, error_channel)
+    s = np.ascontiguousarray(syndromes, np.uint8)
+    b = s.shape[0]
+    dec = np.zeros((b, n), np.uint8)
+    llr = np.zeros((b, n), np.float64)
+    it = np.zeros(b, np.int32)
+    conv = np.zeros(b, np.uint8)
+    final = np.zeros((b, n), np.int32)
+    fn(m, n, len(col_idx), rows, col_idx, probs, int(max_iter) if max_iter else n, _method_id(bp_method),
+       RefBp.SCHEDULE[schedule], float(ms_scaling_factor), 1 if random_serial else 0, int(seed), s, b, dec, llr, it, conv,
+       final.reshape(-1))
+    return dec, llr, it, conv.astype(bool), final
 
 
 class RefBp:

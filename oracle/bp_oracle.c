@@ -457,9 +457,177 @@ void bposd0_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int m
  * the plain sequential product over the row's OTHER entries (bp.hpp:493-498), its sign is
  * pow(-1, syndrome byte) (bp.hpp:499), min-sum multiplies alpha * sign * magnitude (bp.hpp:519).
  * ============================================================================================== */
+/* ---- std::sort as libstdc++ implements it (bits/stl_algo.h: introsort = median-of-three quicksort down to runs of 16,
+ * heapsort when the recursion budget 2 floor(log2 n) runs out, one final insertion sort), restated on an int array with
+ * a comparator over keys.  serial_relative sorts its bit order with it every iteration (bp.hpp:470-483), the sort is not
+ * stable, and with equal keys (uniform priors in iteration 1: ALL keys equal) the outcome is whatever this exact sequence
+ * of swaps leaves -- so the sequence is part of the reference's observable behaviour.  libstdc++ is a third-party
+ * dependency of the reference (GCC 11, the toolchain of this image); tests/test_std_sort_port.py checks this restatement
+ * against the real std::sort on the host. ------------------------------------------------------------------------- */
+typedef struct { const double *key; } sort_ctx;
+static inline int sort_gt(const sort_ctx *c, int a, int b) { return c->key[a] > c->key[b]; }  /* comp(a, b): key[a] > key[b] */
+#define SS_SWAP(i, j) do { t = v[i]; v[i] = v[j]; v[j] = t; } while (0)
+
+static void ss_move_median_to_first(int *v, long result, long a, long b, long c, const sort_ctx *x) {
+    int t;
+    if (sort_gt(x, v[a], v[b])) {
+        if (sort_gt(x, v[b], v[c])) SS_SWAP(result, b);
+        else if (sort_gt(x, v[a], v[c])) SS_SWAP(result, c);
+        else SS_SWAP(result, a);
+    } else if (sort_gt(x, v[a], v[c])) SS_SWAP(result, a);
+    else if (sort_gt(x, v[b], v[c])) SS_SWAP(result, c);
+    else SS_SWAP(result, b);
+}
+static long ss_unguarded_partition(int *v, long first, long last, long pivot, const sort_ctx *x) {
+    int t;
+    for (;;) {
+        while (sort_gt(x, v[first], v[pivot])) ++first;
+        --last;
+        while (sort_gt(x, v[pivot], v[last])) --last;
+        if (!(first < last)) return first;
+        SS_SWAP(first, last);
+        ++first;
+    }
+}
+static void ss_push_heap(int *v, long first, long hole, long top, int value, const sort_ctx *x) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && sort_gt(x, v[first + parent], value)) {
+        v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v[first + hole] = value;
+}
+static void ss_adjust_heap(int *v, long first, long hole, long len, int value, const sort_ctx *x) {
+    const long top = hole;
+    long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (sort_gt(x, v[first + child], v[first + (child - 1)])) child--;
+        v[first + hole] = v[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v[first + hole] = v[first + (child - 1)];
+        hole = child - 1;
+    }
+    ss_push_heap(v, first, hole, top, value, x);
+}
+static void ss_heapsort(int *v, long first, long last, const sort_ctx *x) { /* __partial_sort(first, last, last) */
+    const long len = last - first;
+    if (len >= 2)
+        for (long parent = (len - 2) / 2;; parent--) {
+            ss_adjust_heap(v, first, parent, len, v[first + parent], x);
+            if (parent == 0) break;
+        }
+    while (last - first > 1) {
+        --last;
+        const int value = v[last];
+        v[last] = v[first];
+        ss_adjust_heap(v, first, 0, last - first, value, x);
+    }
+}
+static void ss_unguarded_linear_insert(int *v, long last, const sort_ctx *x) {
+    const int val = v[last];
+    long next = last - 1;
+    while (sort_gt(x, val, v[next])) {
+        v[last] = v[next];
+        last = next;
+        --next;
+    }
+    v[last] = val;
+}
+static void ss_insertion_sort(int *v, long first, long last, const sort_ctx *x) {
+    if (first == last) return;
+    for (long i = first + 1; i != last; ++i) {
+        if (sort_gt(x, v[i], v[first])) {
+            const int val = v[i];
+            memmove(v + first + 1, v + first, sizeof(int) * (size_t)(i - first));
+            v[first] = val;
+        } else ss_unguarded_linear_insert(v, i, x);
+    }
+}
+void oracle_std_sort_desc(int *v, long n, const double *key) { /* std::sort(v, v + n, [](a, b) { return key[a] > key[b]; }) */
+    if (n <= 0) return;
+    const sort_ctx ctx = {key}, *x = &ctx;
+    long depth = 0;
+    for (long q = n; q > 1; q >>= 1) depth++;
+    depth *= 2; /* std::__lg(n) * 2 */
+    /* __introsort_loop recurses into the right part and iterates on the left; the parts are disjoint ranges, so deferring
+     * the right part on an explicit stack of (first, last, depth) changes nothing observable */
+    long stack_first[128], stack_last[128], stack_depth[128];
+    int sp = 1;
+    stack_first[0] = 0; stack_last[0] = n; stack_depth[0] = depth;
+    while (sp > 0) {
+        --sp;
+        long first = stack_first[sp], last = stack_last[sp], d = stack_depth[sp];
+        while (last - first > 16) {
+            if (d == 0) { ss_heapsort(v, first, last, x); break; }
+            --d;
+            const long mid = first + (last - first) / 2;
+            ss_move_median_to_first(v, first, first + 1, mid, last - 1, x);
+            const long cut = ss_unguarded_partition(v, first + 1, last, first, x);
+            stack_first[sp] = cut; stack_last[sp] = last; stack_depth[sp] = d; ++sp;
+            last = cut;
+        }
+    }
+    if (n > 16) { /* __final_insertion_sort */
+        ss_insertion_sort(v, 0, 16, x);
+        for (long i = 16; i != n; ++i) ss_unguarded_linear_insert(v, i, x);
+    } else ss_insertion_sort(v, 0, n, x);
+}
+#undef SS_SWAP
+
+/* serial schedules whose order changes while decoding:
+ *   order_mode 0  the fixed `order` (NULL: 0 .. n-1), as bp_oracle_decode_serial always did;
+ *   order_mode 1  iteration it walks orders[min(it, n_orders) - 1][0 .. n): the random serial schedule (bp.hpp:467-468; the
+ *                 shuffles themselves are std::shuffle on std::mt19937, produced by oracle/shuffle_helper.cpp);
+ *   order_mode 2  serial_relative (bp.hpp:469-483): `order_state` [n] is re-sorted in place at the start of every iteration,
+ *                 by descending prior in iteration 1 and by descending log_prob_ratios of the previous iteration afterwards,
+ *                 and keeps its final arrangement (the reference keeps it in the decoder object from one decode to the next).
+ */
+static void decode_serial_dyn(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method, double ms_scaling_factor,
+                              int order_mode, const int32_t *order, const int32_t *orders, int n_orders, int32_t *order_state,
+                              const uint8_t *syndrome, uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge);
+
 void bp_oracle_decode_serial(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
                              double ms_scaling_factor, const int32_t *order, const uint8_t *syndrome,
                              uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge) {
+    decode_serial_dyn(o, channel_probs, max_iter, bp_method, ms_scaling_factor, 0, order, NULL, 0, NULL, syndrome, decoding,
+                      log_prob_ratios, iterations, converge);
+}
+
+/* `fresh` != 0: every row starts from the same order_state (a new decoder object per row); else rows are decoded one after
+ * the other on ONE decoder object, as a loop of BpDecoder.decode calls does.  order_state [n] ends as the last row left it. */
+void bp_oracle_decode_serial_relative_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                                            double ms_scaling_factor, int32_t *order_state, int fresh, const uint8_t *syndromes,
+                                            int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    int32_t *start = (int32_t *)malloc(sizeof(int32_t) * (size_t)(o->n ? o->n : 1));
+    memcpy(start, order_state, sizeof(int32_t) * (size_t)o->n);
+    for (int64_t b = 0; b < shots; b++) {
+        if (fresh) memcpy(order_state, start, sizeof(int32_t) * (size_t)o->n);
+        iterations[b] = 0;
+        decode_serial_dyn(o, channel_probs, max_iter, bp_method, ms_scaling_factor, 2, NULL, NULL, 0, order_state,
+                          syndromes + b * o->m, decodings + b * o->n, llr + b * o->n, iterations + b, converge + b);
+    }
+    free(start);
+}
+
+/* every row walks the same per-iteration orders (a new decoder object per row, freshly seeded) */
+void bp_oracle_decode_serial_orders_batch(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method,
+                                          double ms_scaling_factor, const int32_t *orders, int n_orders, const uint8_t *syndromes,
+                                          int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations, uint8_t *converge) {
+    for (int64_t b = 0; b < shots; b++) {
+        iterations[b] = 0;
+        decode_serial_dyn(o, channel_probs, max_iter, bp_method, ms_scaling_factor, 1, NULL, orders, n_orders, NULL,
+                          syndromes + b * o->m, decodings + b * o->n, llr + b * o->n, iterations + b, converge + b);
+    }
+}
+
+static void decode_serial_dyn(bp_oracle *o, const double *channel_probs, int max_iter, int bp_method, double ms_scaling_factor,
+                              int order_mode, const int32_t *order, const int32_t *orders, int n_orders, int32_t *order_state,
+                              const uint8_t *syndrome, uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge) {
     const int m = o->m, n = o->n;
     *converge = 0;
     for (int j = 0; j < n; j++) { /* initialise_log_domain_bp, bp.hpp:147-157 */
@@ -470,6 +638,11 @@ void bp_oracle_decode_serial(bp_oracle *o, const double *channel_probs, int max_
         double alpha;
         if (ms_scaling_factor == 0.0) alpha = 1.0 - pow(2.0, -1.0 * it);
         else alpha = ms_scaling_factor;
+        if (order_mode == 1) order = orders + (size_t)((it < n_orders ? it : n_orders) - 1) * (size_t)n;
+        if (order_mode == 2) { /* bp.hpp:469-483 */
+            oracle_std_sort_desc(order_state, n, it != 1 ? log_prob_ratios : o->llr0);
+            order = order_state;
+        }
         for (int t = 0; t < n; t++) {
             const int bit = order ? order[t] : t;
             log_prob_ratios[bit] = log((1 - channel_probs[bit]) / channel_probs[bit]);

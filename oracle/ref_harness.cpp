@@ -94,6 +94,50 @@ void ref_bp_soft_info_decode_batch(ref_bp *r, const double *soft_syndromes, int6
     }
 }
 
+/* A NEW decoder object per row (what "row b of a batch" means for the schedules that keep state in the object: the
+ * serial_relative order, the random schedule's order and generator): bp.hpp:77-132 constructor with the given schedule
+ * (0 serial, 2 serial_relative), random_serial_schedule and random_schedule_seed, then ONE decode. */
+void ref_bp_decode_fresh_batch(int m, int n, int nnz, const int32_t *rows, const int32_t *cols, const double *channel_probs,
+                               int max_iter, int bp_method, int schedule, double ms_scaling_factor, int random_serial,
+                               int random_seed, const uint8_t *inputs, int64_t shots, uint8_t *decodings, double *llr,
+                               int32_t *iterations, uint8_t *converge, int32_t *final_order) {
+    BpSparse pcm(m, n, nnz);
+    for (int k = 0; k < nnz; k++) pcm.insert_entry(rows[k], cols[k]);
+    std::vector<double> probs(channel_probs, channel_probs + n);
+    for (int64_t b = 0; b < shots; b++) {
+        BpDecoder dec(pcm, probs, max_iter, static_cast<ldpc::bp::BpMethod>(bp_method), static_cast<ldpc::bp::BpSchedule>(schedule),
+                      ms_scaling_factor, 1, ldpc::bp::NULL_INT_VECTOR, random_seed, random_serial != 0, ldpc::bp::SYNDROME);
+        std::vector<uint8_t> in(inputs + b * m, inputs + (b + 1) * m);
+        dec.decode(in);
+        std::memcpy(decodings + b * n, dec.decoding.data(), (size_t)n);
+        if (llr) std::memcpy(llr + b * n, dec.log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        iterations[b] = dec.iterations;
+        converge[b] = dec.converge ? 1 : 0;
+        if (final_order) for (int j = 0; j < n; j++) final_order[b * n + j] = dec.serial_schedule_order[(size_t)j];
+    }
+}
+
+/* ONE decoder object for all rows, as a loop of BpDecoder.decode calls on one Python object: the order (and generator) carry over */
+void ref_bp_decode_carried_batch(int m, int n, int nnz, const int32_t *rows, const int32_t *cols, const double *channel_probs,
+                                 int max_iter, int bp_method, int schedule, double ms_scaling_factor, int random_serial,
+                                 int random_seed, const uint8_t *inputs, int64_t shots, uint8_t *decodings, double *llr,
+                                 int32_t *iterations, uint8_t *converge, int32_t *final_order) {
+    BpSparse pcm(m, n, nnz);
+    for (int k = 0; k < nnz; k++) pcm.insert_entry(rows[k], cols[k]);
+    std::vector<double> probs(channel_probs, channel_probs + n);
+    BpDecoder dec(pcm, probs, max_iter, static_cast<ldpc::bp::BpMethod>(bp_method), static_cast<ldpc::bp::BpSchedule>(schedule),
+                  ms_scaling_factor, 1, ldpc::bp::NULL_INT_VECTOR, random_seed, random_serial != 0, ldpc::bp::SYNDROME);
+    for (int64_t b = 0; b < shots; b++) {
+        std::vector<uint8_t> in(inputs + b * m, inputs + (b + 1) * m);
+        dec.decode(in);
+        std::memcpy(decodings + b * n, dec.decoding.data(), (size_t)n);
+        if (llr) std::memcpy(llr + b * n, dec.log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        iterations[b] = dec.iterations;
+        converge[b] = dec.converge ? 1 : 0;
+        if (final_order) for (int j = 0; j < n; j++) final_order[b * n + j] = dec.serial_schedule_order[(size_t)j];
+    }
+}
+
 /* GF2Sparse::mulvec (gf2sparse.hpp:177-214) */
 void ref_bp_mulvec(ref_bp *r, const uint8_t *in, uint8_t *out) {
     std::vector<uint8_t> v(in, in + r->pcm->n);
