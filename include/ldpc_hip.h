@@ -80,11 +80,24 @@ int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method,
                            double ms_scaling_factor);
 
 /* replaces: the schedule / serial_schedule_order setters (_bp_decoder.pyx:415-483).  `schedule` uses
- * ldpc::bp::BpSchedule's values (bp.hpp:28-32): 1 = PARALLEL (flooding, default), 0 = SERIAL with a fixed
- * bit order (`serial_schedule_order`, n entries, or NULL for 0..n-1; bp.hpp:120-124, 451-545).
- * 2 = SERIAL_RELATIVE and the random serial order re-sort per syndrome and per iteration and are not
- * available on the device (LDPC_HIP_ERR_UNSUPPORTED). */
+ * ldpc::bp::BpSchedule's values (bp.hpp:28-32): 1 = PARALLEL (flooding, default), 0 = SERIAL, 2 = SERIAL_RELATIVE;
+ * `serial_schedule_order` (n entries, or NULL for 0..n-1; bp.hpp:110-124) is the order a serial sweep walks.
+ * SERIAL with a fixed order runs the tile-wide serial kernels.  Two variants keep STATE in the reference's decoder object
+ * and change the order while decoding (bp.hpp:467-483): SERIAL_RELATIVE re-sorts it at the start of every iteration
+ * (std::sort by descending prior, then by descending posterior of the previous iteration -- reproduced swap for swap,
+ * since ties make the unstable sort's arrangement observable), the random serial schedule (ldpc_hip_bp_set_random_serial)
+ * re-shuffles it (std::shuffle on a std::mt19937).  For these, every row of a call starts from the handle's current state
+ * (order, generator) and the call leaves the state of its LAST row: a one-row call is exactly one BpDecoder::decode, a
+ * sequence of one-row calls exactly a sequence of decodes on one reference object, and a batch on a fresh handle equals a
+ * new reference object per row.  Such calls return after the device has finished (the state comes back to the host).
+ * This call (re)sets the state to `serial_schedule_order`. */
 int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *serial_schedule_order);
+/* replaces: the random_serial_schedule / random_schedule_seed setters (_bp_decoder.pyx:527-579 -> bp.hpp:142-145): with
+ * `enable` the serial sweep shuffles the order before every iteration; `seed` re-seeds the generator (0 = from the clock, as
+ * rng.hpp:117-123 does).  Takes precedence over SERIAL_RELATIVE, as in bp.hpp:467-469. */
+int ldpc_hip_bp_set_random_serial(ldpc_hip_bp *h, int32_t enable, uint32_t seed);
+/* the handle's current serial_schedule_order (n entries): what bpd.serial_schedule_order holds after a decode */
+int ldpc_hip_bp_get_schedule_order(ldpc_hip_bp *h, int32_t *order);
 
 /* Launch stream (a hipStream_t) for decode calls; NULL selects the handle's own (non-blocking) stream,
  * LDPC_HIP_STREAM_LEGACY_DEFAULT the device's legacy default stream (hipStream_t 0, which is what

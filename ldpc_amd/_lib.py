@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LDPC_HIP_LIB") or os.path.join(_HERE, "lib", "libldpc
 # every symbol include/ldpc_hip.h declares (tests/test_cabi_symbols.py checks header <-> library)
 SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
-    "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
+    "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_set_random_serial", "ldpc_hip_bp_get_schedule_order", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
     "ldpc_hip_bp_set_osd", "ldpc_hip_bposd_get_status", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
     "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
@@ -71,6 +71,8 @@ def load():
     lib.ldpc_hip_bp_set_params.argtypes = [vp, i32, i32, dbl]
     lib.ldpc_hip_bp_set_stream.argtypes = [vp, vp]
     lib.ldpc_hip_bp_set_schedule.argtypes = [vp, i32, vp]
+    lib.ldpc_hip_bp_set_random_serial.argtypes = [vp, i32, C.c_uint32]
+    lib.ldpc_hip_bp_get_schedule_order.argtypes = [vp, vp]
     lib.ldpc_hip_bp_decode_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.ldpc_hip_bp_decode_batch_async.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.ldpc_hip_bposd0_decode_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]

@@ -155,6 +155,7 @@ class BpDecoderBase:
         self._omp_thread_count = 1
         self._serial_schedule_order = np.arange(self.n, dtype=np.int64)  # bp.hpp:120-124
         self._random_schedule_seed = 0
+        self._seed_epoch = 0
         self._random_serial_schedule = False
         self._bp_input_type = SYNDROME
         self._decoding = np.zeros(self.n, np.uint8)
@@ -371,6 +372,7 @@ class BpDecoderBase:
             schedule. Set as 0 to use the system clock.")
         self._random_serial_schedule = True  # pyx:551 (the constructor resets it right after, pyx:142)
         self._random_schedule_seed = value
+        self._seed_epoch = getattr(self, "_seed_epoch", 0) + 1  # every call re-seeds the generator (bp.hpp:142-145)
 
     @property
     def random_serial_schedule(self) -> bool:
@@ -405,9 +407,14 @@ class BpDecoderBase:
         if sched != getattr(self, "_engine_sched", (PARALLEL, None)):
             if self._schedule == PARALLEL:
                 self._engine.set_schedule("parallel")
-            else:
-                self._engine.set_schedule("serial", np.asarray(self._serial_schedule_order, np.int32))
+            else:  # (re)sets the object's serial_schedule_order, the state serial_relative / the random schedule work on
+                self._engine.set_schedule({SERIAL: "serial", SERIAL_RELATIVE: "serial_relative"}[self._schedule],
+                                          np.asarray(self._serial_schedule_order, np.int32))
             self._engine_sched = sched
+        rnd = (bool(self._random_serial_schedule), self._random_schedule_seed, self._seed_epoch)
+        if rnd != getattr(self, "_engine_random", (False, 0, 0)):
+            self._engine.set_random_serial(rnd[0], rnd[1])  # re-seeds, as bpd.set_random_schedule_seed does (pyx:553-554)
+            self._engine_random = rnd
         return self._engine
 
     def _get_cy(self):
@@ -443,14 +450,22 @@ class BpDecoderBase:
         return self._get_engine().decode_batch(synd2d, want_llr=want_llr, osd0=osd0)
 
     def _require_parallel(self):
-        """Schedules available on the device: 'parallel' (bp.hpp:192-325) and 'serial' with a FIXED bit order
-        (bp.hpp:451-545).  The per-syndrome orders (random serial, serial_relative) raise: no CPU fallback."""
-        if self._schedule == SERIAL_RELATIVE or (self._schedule == SERIAL and self._random_serial_schedule):
-            what = "schedule='serial_relative'" if self._schedule == SERIAL_RELATIVE else "random_serial_schedule=True"
-            raise NotImplementedError(
-                f"{what} re-sorts the bit order per syndrome and per iteration (bp.hpp:467-483) and is not available on "
-                "the MI355X path yet: use schedule='parallel' or 'serial' with a fixed serial_schedule_order; "
-                "there is no CPU fallback.")
+        """Every schedule of the reference runs on the device: 'parallel' (bp.hpp:192-325), 'serial' (bp.hpp:451-545) with a
+        fixed order, and the two that keep state in the decoder object -- 'serial_relative' and random_serial_schedule
+        (bp.hpp:467-483; include/ldpc_hip.h: ldpc_hip_bp_set_schedule).  For those, ``decode`` calls follow one another as on
+        a reference object (the order / generator carry over); the rows of a ``decode_batch`` each start from the state at the
+        time of the call."""
+        return None
+
+    def _schedule_keeps_state(self) -> bool:
+        return self._schedule != PARALLEL and (self._schedule == SERIAL_RELATIVE or bool(self._random_serial_schedule))
+
+    def _pull_schedule_state(self):
+        """After a decode with a schedule that rearranges ``serial_schedule_order`` (bp.hpp:467-483): read it back, as the
+        reference's property shows the decoder object's rearranged member."""
+        if self._schedule_keeps_state() and self._engine is not None and hasattr(self._engine, "schedule_order"):
+            self._serial_schedule_order = self._engine.schedule_order().astype(np.int64)
+            self._engine_sched = (self._schedule, tuple(int(v) for v in self._serial_schedule_order))
 
 
 class BpDecoder(BpDecoderBase):
@@ -522,6 +537,7 @@ class BpDecoder(BpDecoderBase):
         self._log_prob_ratios = llr[0]
         self._iterations = int(it[0])
         self._converge = bool(cv[0])
+        self._pull_schedule_state()
         return out.astype(dtype)
 
     # ---- batch (additive) -----------------------------------------------------------------------
@@ -564,6 +580,7 @@ class BpDecoder(BpDecoderBase):
                 if llr is not None:
                     llr[zero] = 0
             self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv.bool(), it, llr
+            self._pull_schedule_state()
             return dec
         dtype = input_vectors.dtype
         vec = np.ascontiguousarray(np.asarray(input_vectors).astype(np.uint8))
@@ -587,6 +604,7 @@ class BpDecoder(BpDecoderBase):
             self._iterations = int(it[last])
         if len(vec):
             self._converge = bool(cv[-1])
+        self._pull_schedule_state()
         return dec.astype(dtype)
 
     @property

@@ -45,10 +45,14 @@
 #include "bp_stream_kernel.h"
 #include "bp_spread_kernels.h"
 #include "bp_serial_kernels.h"
+#include "bp_relative_kernel.h"
 #include "bp_small_kernel.h"
 #include "bp_wave_kernel.h"
 #include "osd_kernels.h"
 #include "io_kernels.h"
+
+#include <chrono>
+#include <random>
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -117,7 +121,13 @@ struct ldpc_hip_bp {
     // (no synchronisation) and stops queueing once it matches -- rounds queued past that point find nothing to do.
     unsigned *h_flag = nullptr, *d_flag = nullptr;
     unsigned flag_seq = 0;
-    int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial (fixed order), 1 parallel
+    int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial, 1 parallel, 2 serial_relative
+    // What the reference keeps in the decoder OBJECT from one decode to the next (bp.hpp:67, 75): serial_schedule_order -- the
+    // arrangement serial_relative re-sorts and the random schedule re-shuffles every iteration -- and the generator of the shuffles.
+    std::vector<int32_t> sched_state;
+    std::mt19937 sched_rng;
+    bool random_serial = false;
+    DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
     int32_t *d_csc_row = nullptr, *d_order = nullptr;
     bool custom_order = false;
     DeviceBuf counter;
@@ -288,6 +298,8 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
 #undef ALLOC_COPY
     int rc = upload_priors(h);
     if (rc) { ldpc_hip_bp_destroy(h); return rc; }
+    h->sched_state.resize((size_t)d->n);
+    for (int j = 0; j < d->n; ++j) h->sched_state[(size_t)j] = j;  // bp.hpp:120-124
     h->h_row_ptr.assign(d->csr_row_ptr, d->csr_row_ptr + d->m + 1);  // kept for tables that are built on first use
     h->h_col_idx.assign(d->csr_col_idx, d->csr_col_idx + d->nnz);
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
@@ -312,7 +324,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -391,10 +403,13 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t enable) {
 
 int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *serial_schedule_order) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (schedule == 2)
-        return fail(LDPC_HIP_ERR_UNSUPPORTED, "serial_relative (per-syndrome LLR-sorted order, bp.hpp:470-483) is not available on the device");
-    if (schedule != 0 && schedule != 1) return fail(LDPC_HIP_ERR_INVALID, "Invalid BP schedule");  // bp.hpp:188
+    if (schedule != 0 && schedule != 1 && schedule != 2) return fail(LDPC_HIP_ERR_INVALID, "Invalid BP schedule");  // bp.hpp:188
     HIPCHK(hipSetDevice(h->device));
+    for (int j = 0; j < h->n; ++j) {  // the object's serial_schedule_order: the given order, else 0 .. n-1 (bp.hpp:110-124)
+        if (serial_schedule_order && (serial_schedule_order[j] < 0 || serial_schedule_order[j] >= h->n))
+            return fail(LDPC_HIP_ERR_INVALID, "serial_schedule_order[%d] is out of range", j);
+        h->sched_state[(size_t)j] = serial_schedule_order ? serial_schedule_order[j] : j;
+    }
     if (schedule == 0 && serial_schedule_order) {
         for (int j = 0; j < h->n; ++j)
             if (serial_schedule_order[j] < 0 || serial_schedule_order[j] >= h->n)
@@ -413,6 +428,21 @@ int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *se
     }
     h->schedule = schedule;
     h->levels_valid = false;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_random_serial(ldpc_hip_bp *h, int32_t enable, uint32_t seed) {
+    if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
+    h->random_serial = enable != 0;
+    if (seed == 0)  // rng.hpp:117-123: seed 0 = take the system clock
+        seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
+    h->sched_rng.seed(seed);  // BpDecoder::set_random_schedule_seed (bp.hpp:142-145)
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_get_schedule_order(ldpc_hip_bp *h, int32_t *order) {
+    if (!h || !order) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    for (int j = 0; j < h->n; ++j) order[j] = h->sched_state[(size_t)j];
     return LDPC_HIP_OK;
 }
 
@@ -577,7 +607,7 @@ static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
 }
 
 static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                              int32_t *iters, uint8_t *conv) {
+                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
@@ -607,7 +637,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
     void (*kern)(const SerialArgs);
     // level-parallel variant when the schedule has at least two bits per level on average (or when asked for)
     int level_waves = 0;
-    if (h->serial_kernel != 0 && h->n > 0) {
+    if (h->serial_kernel != 0 && h->n > 0 && !orders) {  // (a schedule that changes per iteration has no fixed levels)
         if ((rc = ensure_serial_levels(h))) return rc;
         const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
         if (h->serial_kernel == 1 || per_level >= 2.0) {
@@ -663,6 +693,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         }
         HIPCHK(hipEventRecord(h->ev0, st));
         a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+        a.orders = orders; a.n_orders = n_orders;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
@@ -688,8 +719,132 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
 // few iterations over everything, then the rows it left unconverged -- packed densely into new tiles -- are decoded
 // again from the start with the full iteration budget (BP is deterministic: restarting gives what continuing would),
 // and their results replace the first pass's.  Work ~ k1 + f * max_iter instead of max_iter (f = unconverged fraction).
+// ---- schedules whose order lives in the decoder object and changes while decoding (bp.hpp:467-483) ------------------------
+// The reference decodes one syndrome at a time and carries serial_schedule_order (and the shuffle generator) from decode to
+// decode.  A batch cannot do that across its rows (where row b starts would depend on how many iterations rows 0 .. b-1
+// took), so: EVERY ROW OF A CALL STARTS FROM THE HANDLE'S CURRENT STATE -- what the reference gives with a new decoder
+// object per syndrome when the state is the initial one -- and the call leaves the state its LAST row produced.  A batch
+// of one row is therefore exactly one BpDecoder::decode, and a sequence of one-row calls is exactly a sequence of decodes
+// on one reference object.  Both wait for the device at the end (the state comes back to the host).
+static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                int32_t *iters, uint8_t *conv) {
+    const int n = h->n, max_iter = h->max_iter;
+    // the arrangements of iterations 1 .. max_iter: std::shuffle on the object's std::mt19937, as RandomListShuffle does (rng.hpp:128-130)
+    std::vector<int32_t> orders((size_t)max_iter * (size_t)(n ? n : 1));
+    {
+        std::mt19937 g = h->sched_rng;
+        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+        for (int it = 0; it < max_iter; ++it) {
+            std::shuffle(v.begin(), v.end(), g);
+            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)n);
+        }
+    }
+    int rc;
+    if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t)))) return rc;
+    if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if ((rc = decode_serial_pass(h, max_iter, synd, batch, decoding, llr, iters, conv, (const int32_t *)h->sched_orders.p, max_iter))) return rc;
+    int32_t last = 0;
+    HIPCHK(hipMemcpyAsync(&last, iters + (batch - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+    for (int it = 0; it < last; ++it) std::shuffle(v.begin(), v.end(), h->sched_rng);  // the last row consumed `last` shuffles
+    std::copy(v.begin(), v.end(), h->sched_state.begin());
+    return LDPC_HIP_OK;
+}
+
+static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                  int32_t *iters, uint8_t *conv) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t n1 = (size_t)(h->n ? h->n : 1), m1 = (size_t)(h->m ? h->m : 1);
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap + h->rel_ord.cap + h->rel_dbit.cap;
+        const size_t per_tile = 2 * per_tile_msg + n1 * LDPC_WAVE * (8 + 4 + 1) + 24 * (m1 + n1);
+        int64_t fit = (int64_t)((double)(free_b + have) * 0.85 / (double)per_tile);
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk)) || (rc = h->msgC.ensure(per_tile_msg * (size_t)chunk)) ||
+        (rc = h->llr_t.ensure(n1 * LDPC_WAVE * 8 * (size_t)chunk)) || (rc = h->rel_ord.ensure(n1 * LDPC_WAVE * 4 * (size_t)chunk)) ||
+        (rc = h->rel_dbit.ensure(n1 * LDPC_WAVE * (size_t)chunk)) || (rc = h->par.ensure(sizeof(uint64_t) * m1 * (size_t)chunk)) ||
+        (rc = h->nzm.ensure(sizeof(uint64_t) * m1 * (size_t)chunk)) || (rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk)) ||
+        (rc = h->sched_order0.ensure(n1 * sizeof(int32_t)))) return rc;
+    hipStream_t st = h->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    void (*kern)(const RelArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_serial_relative_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_relative_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
+    else kern = bp_serial_relative_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = false;
+    h->timed_mid = false;
+    int64_t last_tiles = 0;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        RelArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row;
+        a.order0 = (const int32_t *)h->sched_order0.p;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.llr_t = (double *)h->llr_t.p;
+        a.ord = (int32_t *)h->rel_ord.p; a.dbit = (uint8_t *)h->rel_dbit.p;
+        a.par = (const uint64_t *)h->par.p; a.invalid = (const uint64_t *)h->invalid.p;
+        a.decoding = decoding + b0 * h->n;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (llr && h->n > 0) {
+            dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+            hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n);
+        }
+        HIPCHK(hipGetLastError());
+        last_tiles = tiles;
+    }
+    // the order the LAST row ended with becomes the object's serial_schedule_order: column (last lane) of the last tile's ord
+    if (h->n > 0) {
+        const int64_t lane = (batch - 1) % LDPC_WAVE;
+        const int32_t *src = (const int32_t *)h->rel_ord.p + (size_t)(last_tiles - 1) * n1 * LDPC_WAVE + (size_t)lane;
+        HIPCHK(hipMemcpy2DAsync(h->sched_state.data(), sizeof(int32_t), src, sizeof(int32_t) * LDPC_WAVE, sizeof(int32_t), (size_t)h->n,
+                                hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return LDPC_HIP_OK;
+}
+
 static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                          int32_t *iters, uint8_t *conv) {
+    if (h->random_serial) return decode_serial_random(h, synd, batch, decoding, llr, iters, conv);  // (takes precedence, bp.hpp:467-469)
+    if (h->schedule == 2) return decode_serial_relative(h, synd, batch, decoding, llr, iters, conv);
     int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
     if (h->repack_iters < 0 && k1 < 2) k1 = 2;
     if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
@@ -1114,7 +1269,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                          double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
-    if (h->schedule == 0) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
+    if (h->schedule == 0 || h->schedule == 2) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
     if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave

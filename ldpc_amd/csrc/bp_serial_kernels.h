@@ -31,6 +31,9 @@ struct SerialArgs {
     const int32_t *lvl_ptr;   // [n_levels + 1]
     const int32_t *lvl_bits;  // [n] bits in level-major order (schedule order inside a level)
     int32_t n_levels;
+    // random serial schedule (bp.hpp:467-468): iteration it walks orders[min(it, n_orders) - 1][0 .. n) instead of `order`
+    const int32_t *orders;
+    int32_t n_orders;
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the
@@ -161,8 +164,9 @@ __global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
     for (int it = 1; it <= a.max_iter; ++it) {
         const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
         const bool lane_live = !((done >> lane) & 1ull);
+        const int32_t *order = a.orders ? a.orders + (size_t)((it < a.n_orders ? it : a.n_orders) - 1) * (size_t)n : a.order;
         for (int t = 0; t < n; ++t) {
-            const int bit = a.order ? sload(a.order + t) : t;
+            const int bit = order ? sload(order + t) : t;
             serial_update_bit<METHOD, MATH, DCS, DRS>(a, bit, At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab, want_llr, lane_live);
         }
         // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)

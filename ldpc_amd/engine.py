@@ -86,6 +86,16 @@ class HipBpEngine:
                 raise ValueError("serial_schedule_order must have length n")
             _lib.check(self._lib.ldpc_hip_bp_set_schedule(self._h, code, order.ctypes.data))
 
+    def set_random_serial(self, enable, seed=0):
+        """Random serial schedule (``random_serial_schedule`` / ``random_schedule_seed``): shuffle the order before every iteration."""
+        _lib.check(self._lib.ldpc_hip_bp_set_random_serial(self._h, int(bool(enable)), int(seed) & 0xFFFFFFFF))
+
+    def schedule_order(self):
+        """The handle's current ``serial_schedule_order`` (what serial_relative / the random schedule left behind)."""
+        out = np.zeros(self.n, np.int32)
+        _lib.check(self._lib.ldpc_hip_bp_get_schedule_order(self._h, out.ctypes.data))
+        return out
+
     def set_stream(self, stream_ptr):
         """``None`` -> the handle's own stream; ``0`` -> the legacy default stream (torch's stream 0); else a hipStream_t."""
         if stream_ptr is None:
@@ -345,7 +355,7 @@ class HipBpMultiEngine:
     and return their decisions bit-packed).  For one process PER GPU use ``ldpc_amd.sharding`` instead.
     """
 
-    _BROADCAST = ("set_channel", "set_params", "set_schedule", "set_tuning", "set_math", "set_ring", "set_handoff", "set_osd",
+    _BROADCAST = ("set_channel", "set_params", "set_schedule", "set_random_serial", "set_tuning", "set_math", "set_ring", "set_handoff", "set_osd",
                   "set_repack", "set_serial_kernel", "set_osd_kernel", "set_small_code_kernel")
 
     def __init__(self, row_ptr, col_idx, n, channel_probs, max_iter, bp_method, ms_scaling_factor, device_ids):

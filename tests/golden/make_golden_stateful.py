@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the schedules that keep state in the decoder object (bp.hpp:467-483): schedule = serial_relative
+(the bit order is re-sorted by std::sort at the start of every iteration and stays rearranged) and the random serial
+schedule (std::shuffle on a std::mt19937 before every iteration), through the REAL reference (oracle/_ref/libref_bp.so).
+Build container only:   make -C oracle ref && python tests/golden/make_golden_stateful.py
+
+Two ways of running the same syndromes are recorded:
+  fresh    a NEW decoder object per syndrome  -- what row b of a decode_batch means on the device;
+  carried  ONE decoder object, syndromes one after the other -- what a loop of BpDecoder.decode calls does.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import oracle  # noqa: E402
+from oracle import csr_arrays  # noqa: E402
+from ldpc_amd import codes  # noqa: E402
+from make_golden import bsc_syndromes, h_crc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial=False, seed=0, varied=False):
+    h = sp.csr_matrix(h, dtype=np.uint8)
+    m, n, rp, ci = csr_arrays(h)
+    s = bsc_syndromes(h, 31, p, 0, rows)
+    probs = np.full(n, p)
+    if varied:
+        probs = np.clip(p * np.random.default_rng(9).uniform(0.5, 1.5, n), 1e-3, 0.4)
+    kw = dict(schedule=schedule, error_channel=probs, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=alpha,
+              random_serial=random_serial, seed=seed)
+    fd, fl, fi, fc, fo = oracle.ref_decode_stateful(h, s, fresh=True, **kw)
+    cd, cl, ci_, cc, co = oracle.ref_decode_stateful(h, s, fresh=False, **kw)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, name=name, m=m, n=n, h_crc=np.uint32(h_crc(h)), row_ptr=rp, col_idx=ci, channel_probs=probs,
+                        max_iter=np.int32(max_iter), bp_method=np.int32(0 if bp_method == "product_sum" else 1), ms_scaling_factor=np.float64(alpha),
+                        schedule=np.int32({"serial": 0, "serial_relative": 2}[schedule]), random_serial=np.bool_(random_serial), seed=np.int32(seed),
+                        syndromes=np.packbits(s, axis=1),
+                        fresh_decoding=np.packbits(fd, axis=1), fresh_llr=fl, fresh_iterations=fi, fresh_converge=fc, fresh_order_last=fo[-1],
+                        carried_decoding=np.packbits(cd, axis=1), carried_llr=cl, carried_iterations=ci_, carried_converge=cc,
+                        carried_orders=co.astype(np.int16 if n < 32768 else np.int32))
+    differ = int((fd != cd).any(axis=1).sum())
+    print(f"{name:34s} {m} x {n} rows={rows} converged={int(fc.sum())} rows where carried != fresh: {differ}  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    bb = codes.bivariate_bicycle_hx()
+    run("stateful_rel_bb144_ps", bb, 0.06, schedule="serial_relative", max_iter=12, bp_method="product_sum", alpha=1.0, rows=96)
+    run("stateful_rel_bb144_ms_varied", bb, 0.06, schedule="serial_relative", max_iter=12, bp_method="minimum_sum", alpha=0.8, rows=70, varied=True)
+    run("stateful_rel_ham4_ms", codes.hamming_code(4), 0.08, schedule="serial_relative", max_iter=9, bp_method="minimum_sum", alpha=0.0, rows=40)
+    run("stateful_rel_surf7_ps", codes.rotated_surface_code_x(7), 0.06, schedule="serial_relative", max_iter=10, bp_method="product_sum", alpha=1.0, rows=64)
+    run("stateful_rel_ldpc600_ms", codes.regular_ldpc_code(600, 3, 6, seed=3), 0.06, schedule="serial_relative", max_iter=8, bp_method="minimum_sum", alpha=0.75,
+        rows=48)
+    run("stateful_rnd_bb144_ps_s7", bb, 0.06, schedule="serial", max_iter=12, bp_method="product_sum", alpha=1.0, rows=96, random_serial=True, seed=7)
+    run("stateful_rnd_surf7_ms_s123", codes.rotated_surface_code_x(7), 0.06, schedule="serial", max_iter=10, bp_method="minimum_sum", alpha=0.625, rows=64,
+        random_serial=True, seed=123)
+    run("stateful_rnd_ldpc600_ps_s1", codes.regular_ldpc_code(600, 3, 6, seed=3), 0.06, schedule="serial", max_iter=8, bp_method="product_sum", alpha=1.0, rows=48,
+        random_serial=True, seed=1)
+    # the random flag wins over serial_relative (bp.hpp:467-469)
+    run("stateful_rnd_over_rel_ham4_s5", codes.hamming_code(4), 0.08, schedule="serial_relative", max_iter=9, bp_method="product_sum", alpha=1.0, rows=40,
+        random_serial=True, seed=5)
+
+
+if __name__ == "__main__":
+    main()

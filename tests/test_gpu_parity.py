@@ -359,10 +359,13 @@ def test_bpdecoder_decode_and_batch_semantics(oracle_built):
     assert np.array_equal(d.iter_batch[nz], c["iterations"][nz])
     with pytest.raises(ValueError):
         d.decode(np.zeros(7, np.uint8))
-    with pytest.raises(NotImplementedError):
-        BpDecoder(h, error_rate=0.1, schedule="serial_relative").decode(s)
-    with pytest.raises(NotImplementedError):
-        BpDecoder(h, error_rate=0.1, schedule="serial", random_serial_schedule=True).decode(s)
+    # the schedules that keep state in the decoder object run on the device too (tests/test_stateful_schedules.py pins their bits)
+    o = oracle_built.BpOracle(h, error_rate=0.1, max_iter=h.shape[1], bp_method="product_sum")
+    want = o.decode_serial_relative_batch(s[None, :])
+    d = BpDecoder(h, error_rate=0.1, schedule="serial_relative")
+    assert np.array_equal(d.decode(s), want[0][0]) and np.array_equal(d.serial_schedule_order, want[4])
+    want = o.decode_random_serial_batch(s[None, :], 11)
+    assert np.array_equal(BpDecoder(h, error_rate=0.1, schedule="serial", random_schedule_seed=11, random_serial_schedule=True).decode(s), want[0][0])
 
 
 # ---- BP + OSD-0 (BASELINE config 5) ---------------------------------------

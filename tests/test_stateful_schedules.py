@@ -1,0 +1,119 @@
+"""schedule = 'serial_relative' and random_serial_schedule (bp.hpp:467-483): the two schedules that keep state -- the bit order,
+the shuffle generator -- in the reference's decoder OBJECT.  tests/golden/stateful_*.npz hold the real reference's outputs for
+  fresh    a new decoder object per syndrome (= the rows of one decode_batch on a new handle),
+  carried  one decoder object for all syndromes (= a loop of decode calls on one object).
+CPU: the oracle reproduces both.  GPU: the C ABI and the BpDecoder mirror reproduce both -- decisions, iteration counts,
+converge flags, log-ratios bit for bit, and the rearranged serial_schedule_order."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from golden_util import GOLDEN_DIR, bits_equal
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stateful_*.npz")))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    m, n = int(z["m"]), int(z["n"])
+    h = sp.csr_matrix((np.ones(len(z["col_idx"]), np.uint8), z["col_idx"], z["row_ptr"]), shape=(m, n))
+    c = dict(h=h, m=m, n=n, probs=z["channel_probs"], max_iter=int(z["max_iter"]), bp_method=int(z["bp_method"]), alpha=float(z["ms_scaling_factor"]),
+             schedule=int(z["schedule"]), random=bool(z["random_serial"]), seed=int(z["seed"]), synd=np.unpackbits(z["syndromes"], axis=1, count=m))
+    for kind in ("fresh", "carried"):
+        c[kind] = (np.unpackbits(z[kind + "_decoding"], axis=1, count=n), z[kind + "_llr"], z[kind + "_iterations"].astype(np.int32),
+                   z[kind + "_converge"].astype(bool))
+    c["fresh_order_last"] = z["fresh_order_last"].astype(np.int32)
+    c["carried_orders"] = z["carried_orders"].astype(np.int32)
+    return c
+
+
+def same(got, want):
+    return (np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+            and np.array_equal(np.asarray(got[3], bool), want[3]))
+
+
+def test_cases_present():
+    assert len(CASES) >= 9 and any("_rel_" in c for c in CASES) and any("_rnd_" in c for c in CASES)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_reference(name, oracle_built):
+    c = load(name)
+    o = oracle_built.BpOracle(c["h"], error_channel=c["probs"], max_iter=c["max_iter"], bp_method=c["bp_method"], ms_scaling_factor=c["alpha"])
+    if c["random"]:
+        assert same(o.decode_random_serial_batch(c["synd"], c["seed"]), c["fresh"])
+    else:
+        g = o.decode_serial_relative_batch(c["synd"], fresh=True)
+        assert same(g, c["fresh"]) and np.array_equal(g[4], c["fresh_order_last"])
+        g = o.decode_serial_relative_batch(c["synd"], fresh=False)
+        assert same(g, c["carried"]) and np.array_equal(g[4], c["carried_orders"][-1])
+
+
+def _engine(c):
+    from ldpc_amd.engine import HipBpEngine
+    eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["probs"], c["max_iter"], c["bp_method"], c["alpha"])
+    eng.set_schedule(c["schedule"])
+    if c["random"]:
+        eng.set_random_serial(True, c["seed"])
+    return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_device_batch_is_a_new_decoder_per_row(name):
+    c = load(name)
+    eng = _engine(c)
+    got = eng.decode_batch(c["synd"])
+    assert same(got, c["fresh"])
+    if not c["random"]:
+        assert np.array_equal(eng.schedule_order(), c["fresh_order_last"])
+    import torch
+    eng2 = _engine(c)
+    t = eng2.decode_batch(torch.from_numpy(c["synd"]).cuda())
+    assert same(tuple(x.cpu().numpy() for x in t), c["fresh"])
+    eng3 = _engine(c)  # without log-ratios, and a ragged last tile
+    d = eng3.decode_batch(c["synd"][:37], want_llr=False)
+    assert d[1] is None and np.array_equal(d[0], c["fresh"][0][:37]) and np.array_equal(d[2], c["fresh"][2][:37])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_device_one_row_calls_follow_one_reference_object(name):
+    c = load(name)
+    eng = _engine(c)
+    rows = min(len(c["synd"]), 24)
+    for b in range(rows):
+        got = eng.decode_batch(c["synd"][b:b + 1])
+        want = tuple(x[b:b + 1] for x in c["carried"])
+        assert same(got, want), f"row {b}"
+        if not c["random"]:
+            assert np.array_equal(eng.schedule_order(), c["carried_orders"][b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stateful_rel_bb144_ps", "stateful_rnd_bb144_ps_s7", "stateful_rnd_over_rel_ham4_s5"])
+def test_mirror_decode_sequence_and_batch(name):
+    from ldpc_amd.bp_decoder import BpDecoder
+    c = load(name)
+    kw = dict(error_channel=list(c["probs"]), max_iter=c["max_iter"], bp_method="ps" if c["bp_method"] == 0 else "ms", ms_scaling_factor=c["alpha"],
+              schedule={0: "serial", 2: "serial_relative"}[c["schedule"]], input_vector_type="syndrome")
+    if c["random"]:
+        kw.update(random_schedule_seed=c["seed"], random_serial_schedule=True)
+    d = BpDecoder(c["h"], **kw)
+    for b in range(16):
+        s = c["synd"][b]
+        if not s.any():
+            break  # (the fixture ran the C++ decoder on every row; the Python layer's all-zero shortcut, pyx:679-681, would not)
+        out = d.decode(s)
+        assert np.array_equal(out, c["carried"][0][b]) and d.iter == c["carried"][2][b] and d.converge == c["carried"][3][b]
+        assert bits_equal(d.log_prob_ratios, c["carried"][1][b])
+        if not c["random"]:
+            assert np.array_equal(d.serial_schedule_order, c["carried_orders"][b])
+    d2 = BpDecoder(c["h"], **kw)
+    nz = c["synd"].any(axis=1)
+    out = d2.decode_batch(c["synd"])
+    assert np.array_equal(out[nz], c["fresh"][0][nz]) and np.array_equal(d2.iter_batch[nz], c["fresh"][2][nz])
+    assert bits_equal(d2.log_prob_ratios_batch[nz], c["fresh"][1][nz])
