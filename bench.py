@@ -226,6 +226,12 @@ def main() -> None:
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch):
         sys.exit(self_launch(args.gpus))
 
+    # ONE JSON line on stdout: libraries that greet on stdout (RCCL prints a version banner from its first communicator) are
+    # sent to stderr by pointing file descriptor 1 there for the duration of the run; the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -243,7 +249,7 @@ def main() -> None:
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
         if rank == 0:
-            print(json.dumps({"dry_ranks": seen, "world": dist.get_world_size(), "backend": dist.get_backend()}))
+            print(json.dumps({"dry_ranks": seen, "world": dist.get_world_size(), "backend": dist.get_backend()}), file=real_stdout, flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -455,7 +461,7 @@ def main() -> None:
                     res["parity_failed"] = True
             except Exception as exc:  # the headline line must not be lost to a secondary config
                 res["secondary"] = {"error": repr(exc)[:300]}
-        print(json.dumps(res))
+        print(json.dumps(res), file=real_stdout, flush=True)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
