@@ -1731,11 +1731,22 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         const size_t mat_bytes = (size_t)A.hwords * a.m * 8;
         const bool mat_lds = !h->osd_big && lds + mat_bytes <= 150u * 1024u;
         if (mat_lds) { A.mat_off = (int32_t)lds; lds += mat_bytes; }
+        // blocked elimination (osd_block_eliminate): four rows per thread in registers -> m <= 1024, and the combination table
+        // of the block's pivot rows in LDS; LDPC_HIP_OSD_UNBLOCKED=1 keeps the one-pivot-per-step loop (A/B measurements)
+        A.pbuf_off = -1;
+        const size_t pbuf_bytes = 16 * OSD_PIECE * 16 * 8;  // [group of four pivots][plane of the round][combination]
+        if (a.m <= 1024 && !getenv("LDPC_HIP_OSD_UNBLOCKED")) {
+            // higher orders: the candidates' plane staging area [4][m + 1] words is idle during the elimination -- reuse it when it is large enough
+            const size_t planes_off = ((size_t)A.extra_off + 4 * (size_t)a.n + 7) & ~(size_t)7;
+            if (higher && ((size_t)a.m + 1) * 32 >= pbuf_bytes) A.pbuf_off = (int32_t)planes_off;
+            else if (lds + pbuf_bytes <= 150u * 1024u) { A.pbuf_off = (int32_t)lds; lds += pbuf_bytes; }
+        }
         a.lds_per_wave = (int32_t)region0;
         A.slot_stride = (int64_t)((mat_lds ? 0 : A.hwords) + A.kwords) * a.m;
         if (A.slot_stride < 1) A.slot_stride = 1;
         int per_cu = (int)((160u * 1024u) / lds);
         if (per_cu > 4) per_cu = 4;
+        if (const char *e = getenv("LDPC_HIP_OSD_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }  // (measurements)
         if (per_cu < 1) per_cu = 1;
         int64_t slots = 256 * (int64_t)per_cu;
         if (slots > batch) slots = batch;

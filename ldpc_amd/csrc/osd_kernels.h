@@ -4,6 +4,9 @@
 
 #include "bp_device_common.h"
 
+#define OSD_PIECE 9  // blocked elimination of osd_big_kernel: planes per table round
+#define OSD_TRIP 16  // osd_big_kernel: columns per trip when a candidate is weighed
+
 #ifdef LDPC_HIP_OSD_CLOCKS  // profiling aid (tools/osd_phase_clocks.py): cycles per phase of osdw_reg_kernel, summed over wavefronts
 __device__ unsigned long long osd_phase_clocks[8];
 #define OSD_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -747,10 +750,97 @@ struct OsdBigArgs {
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
     int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i16, npcol [n] u16, (8-aligned) planes [4][m + 1] u64}
     int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
+    int32_t pbuf_off;       // blocked elimination (m <= 1024): byte offset in LDS of the 16 KiB combination table; -1: one pivot per step
 };
 
+// ---- blocked elimination: the 64 columns of a look-ahead block, rows in registers ----------------------------------------------
+// The one-pivot-per-step loop below pays, per pivot, two workgroup barriers around a read-modify-write of every hit row in
+// L2 / MALL (H in an HBM slot) -- ~800 dependent round trips for a 768 x 1600 matrix.  Blocked: the next 64 sorted columns
+// of every row are one word (`look`, gathered as before); the workgroup eliminates on those words alone, thread t holding rows
+// t, t + 256, ... in registers, and records for every row r a mask M_r over the block's pivots meaning
+//     row_r (after the block) = row_r (at block start) ^ XOR_{j in M_r} pivot_row_j (at block start)
+// (taking pivot p's row: M_r ^= M_p ^ {p}).  Per column: every wavefront offers its first unpivoted row with the bit (a ballot
+// per register row) together with that row's two words through LDS, ONE barrier, everybody takes the lowest offer.  Then every
+// row takes ONE combined update over all planes (osd_big_kernel below) -- one load and one store per row per block instead
+// of one per pivot, all loads independent -- and its syndrome bit parity(M_r & S), S_j = syndrome bit of pivot row j at block
+// start.  Same pivots (first unpivoted row with the bit, columns in sorted order), same reduced matrix:
+// tools/proto_blocked_elimination.py checks the algebra against the one-pivot-at-a-time form, the golden fixtures the kernel.
+__device__ __forceinline__ unsigned osd_bit_at(uint64_t x, int j) {  // j uniform: one 32-bit shift instead of a 64-bit one
+    const unsigned h = j < 32 ? (unsigned)x : (unsigned)(x >> 32);
+    return (h >> (j & 31)) & 1u;
+}
+
+template <int MQ>
+__device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, const uint16_t *ord_t, uint64_t *look, const int16_t *pivcol,
+                                                uint16_t *blk_row, uint16_t *blk_col, unsigned long long *xch, int rank, int max_rank) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint64_t L[MQ], M[MQ];
+    unsigned unp = 0;  // bit q: row q * 256 + tid exists and carries no pivot yet
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const int r = q * 256 + tid;
+        L[q] = r < m ? look[r] : 0ull;
+        M[q] = 0ull;
+        if (r < m && pivcol[r] < 0) unp |= 1u << q;
+    }
+    int np = 0;
+    for (int j = 0; j < ahead && rank < max_rank; ++j) {
+        // this wavefront's offer: its first unpivoted row with the bit -- rows ascend in (q, lane) within a wavefront
+        int qs = -1;
+        uint64_t cm = 0;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q)
+            if (qs < 0) {
+                cm = __builtin_amdgcn_ballot_w64(((unp >> q) & 1u) && osd_bit_at(L[q], j));
+                if (cm) qs = q;
+            }
+        // offers, two sets (step j + 1 writes the other one): words 0-1 = the four wavefronts' rows (u32 each, ~0: none),
+        // words 2 + 2 w, 3 + 2 w = wavefront w's row in the block's columns and its mask
+        unsigned long long *set = xch + (j & 1) * 10;
+        if (qs < 0) {
+            if (lane == 0) reinterpret_cast<unsigned *>(set)[wave] = ~0u;
+        } else if (lane == __builtin_ctzll(cm)) {
+            uint64_t lq = L[0], mq = M[0];
+#pragma unroll
+            for (int q = 1; q < MQ; ++q)
+                if (q == qs) { lq = L[q]; mq = M[q]; }
+            reinterpret_cast<unsigned *>(set)[wave] = (unsigned)(qs * 256 + tid);
+            set[2 + 2 * wave] = lq;
+            set[3 + 2 * wave] = mq;
+        }
+        __syncthreads();
+        const uint4 rows = *reinterpret_cast<const uint4 *>(set);
+        const unsigned long long l0 = set[2], m0 = set[3], l1 = set[4], m1 = set[5], l2 = set[6], m2 = set[7], l3 = set[8], m3 = set[9];
+        const unsigned r0 = __builtin_amdgcn_readfirstlane(rows.x), r1 = __builtin_amdgcn_readfirstlane(rows.y);
+        const unsigned r2 = __builtin_amdgcn_readfirstlane(rows.z), r3 = __builtin_amdgcn_readfirstlane(rows.w);
+        const unsigned r01 = r0 < r1 ? r0 : r1, r23 = r2 < r3 ? r2 : r3;
+        const int p = (int)(r01 < r23 ? r01 : r23);
+        if (p < 0) continue;  // (~0: nobody has the bit) not a pivot column
+        const int pw = (p >> 6) & 3;  // the wavefront that made the offer
+        const uint64_t lp = pw == 0 ? l0 : pw == 1 ? l1 : pw == 2 ? l2 : l3;
+        const uint64_t mp = pw == 0 ? m0 : pw == 1 ? m1 : pw == 2 ? m2 : m3;
+        const uint64_t take = mp ^ (1ull << np);
+        const int pq = p >> 8, pt = p & 255;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) {
+            const bool hit = osd_bit_at(L[q], j) && !(q == pq && tid == pt);
+            if (hit) { L[q] ^= lp; M[q] ^= take; }
+        }
+        if (tid == pt) unp &= ~(1u << pq);
+        if (tid == 0) { blk_row[np] = (uint16_t)p; blk_col[np] = ord_t[j]; }
+        ++np;
+        ++rank;
+    }
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+        const int r = q * 256 + tid;
+        if (r < m) look[r] = M[q];  // the look-ahead words are spent; the next block gathers its own
+    }
+    return np;
+}
+
 template <bool HIGHER, bool MAT_LDS>
-__global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) osd_big_kernel(const OsdBigArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const OsdArgs &a = A.o;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -765,9 +855,12 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
     uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m + 1]
     uint64_t *look = reinterpret_cast<uint64_t *>(osd_lds + ((5 * (size_t)m + 1 + 7) & ~(size_t)7));  // [m] bits of the next 64 columns, per row
     int16_t *colinfo = reinterpret_cast<int16_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
-    uint16_t *npcol = reinterpret_cast<uint16_t *>(colinfo + n);       // [n] non-pivot columns in sorted order
+    uint64_t *npm = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 2 * (size_t)n + 7) & ~(size_t)7));  // [HW] non-pivot positions of every plane, then [HW][6] the compress moves (< 2 n - 8 bytes: n >= 64)
     uint64_t *planes = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 4 * (size_t)n + 7) & ~(size_t)7));  // [4][m + 1] (entry m: the all-zero dummy row)
     __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
+    __shared__ uint16_t blk_row[64], blk_col[64];
+    __shared__ unsigned long long blk_sy;
+    __shared__ __attribute__((aligned(16))) unsigned long long blk_xch[20];
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
     // MAT_LDS: the working copy of H fits LDS next to everything else (mid-size matrices: a whole workgroup on one
@@ -786,11 +879,7 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         const int64_t b = sh_row;
         if (b < 0) return;
         OSD_CLK_START();
-        // working copy of H, word-plane major (a.packed is row-major with a.words words per row)
-        for (int64_t e = tid; e < (int64_t)HW * m; e += T) {
-            const int w = (int)(e / m), i = (int)(e - (int64_t)w * m);
-            mat[e] = a.packed[(size_t)i * a.words + w];
-        }
+        for (int64_t e = tid; e < (int64_t)HW * m; e += T) mat[e] = 0ull;  // (filled after the sort)
         for (int j = tid; j < n; j += T) keys[j] = osd_sort_key(a.llr[b * n + j]);
         for (int j = tid; j < P; j += T) ord[j] = (uint16_t)j;
         __syncthreads();
@@ -808,7 +897,24 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
                 }
                 __syncthreads();
             }
-        OSD_WG_CLK(1);  // copy + sort
+        // Working copy of H with its COLUMNS IN SORTED ORDER, word-plane major: bit (t & 63) of mat[(t >> 6) * m + i] = H[i][ord[t]].
+        // The 64 columns of an elimination block are then one plane (one coalesced read per row instead of 64 scattered ones: the
+        // copies of a batch's rows live in HBM / MALL, and bytes moved are what this kernel is bound by), and the non-pivot
+        // columns come out in candidate order.  Filled from the CSR form: nnz atomic ORs into the zeroed planes.
+        {
+            uint16_t *pos = reinterpret_cast<uint16_t *>(osd_lds);  // [n] sorted position of a column (in the keys' room, until the fill is done)
+            for (int t = tid; t < n; t += T) pos[ord[t]] = (uint16_t)t;
+            __threadfence();
+            __syncthreads();
+            for (int i = tid; i < m; i += T)
+                for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
+                    const int t = pos[a.col_idx[e]];
+                    atomicOr(reinterpret_cast<unsigned long long *>(&mat[(int64_t)(t >> 6) * m + i]), 1ull << (t & 63));
+                }
+            __threadfence();
+            __syncthreads();
+        }
+        OSD_WG_CLK(1);  // sort + working copy
         for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }  // (overwrites the keys)
         if (tid < 3) { sh_nhits[tid] = 0; sh_pivot[tid] = INT32_MAX; }
         __syncthreads();
@@ -821,19 +927,109 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         // the NEXT 64 columns into one word per row (64 independent loads in flight), and from then on the owner of a
         // row keeps that word current -- a row that takes the pivot row takes the pivot row's word as well.
         int rank = 0;
+        if (A.pbuf_off >= 0) {
+            // ---- blocked: 64 sorted columns per round (osd_block_eliminate above) ----
+            // tbl [16][8][16]: for the piece (8 planes) in hand, every XOR combination of each group of four pivot rows as they were at
+            // block start -- a row then takes ceil(pivots / 4) table entries whatever its mask, so the lanes of a wavefront do equal work
+            uint64_t *tbl = reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.pbuf_off);
+            for (int t = 0; t < n && rank < A.max_rank; t += 64) {
+                const int ahead = n - t < 64 ? n - t : 64;
+                int pending = 0;
+                for (int i = tid; i < m; i += T) {
+                    look[i] = mat[(int64_t)(t >> 6) * m + i];  // the block's columns: one plane of the sorted copy
+                    if (!HIGHER && pivcol[i] < 0 && sy[i]) pending = 1;
+                }
+                if (tid == 0) blk_sy = 0ull;
+                if (!HIGHER) {
+                    // OSD-0 stops once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383).  Tested per block:
+                    // pivots made past that point have a zero syndrome bit and change no other, so x is the same.
+                    if (!__syncthreads_or(pending)) break;
+                } else {
+                    __syncthreads();
+                }
+                OSD_WG_CLK(0);  // blocked: the block's plane
+                int npv;
+                if (m <= 256) npv = osd_block_eliminate<1>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 512) npv = osd_block_eliminate<2>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 768) npv = osd_block_eliminate<3>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else npv = osd_block_eliminate<4>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                __syncthreads();
+                OSD_WG_CLK(6);  // blocked: the block's pivots
+#ifdef LDPC_HIP_OSD_CLOCKS
+                if (tid == 0) atomicAdd(&osd_phase_clocks[2], 1000000ull * ahead + 1000000000ull * npv);  // (columns, pivots: read off the decimal digits)
+#endif
+                rank += npv;
+                if (npv == 0) continue;
+                if (tid < npv && sy[blk_row[tid]]) atomicOr(&blk_sy, 1ull << tid);
+                __syncthreads();
+                const unsigned long long blk_sy_now = blk_sy;  // S: the pivot rows' syndrome bits at block start
+                const int groups = (npv + 3) >> 2;
+                const unsigned long long smask = blk_sy_now;
+                for (int r = tid; r < m; r += T) {
+                    const uint64_t Mr = look[r];
+                    if (Mr) sy[r] ^= (uint8_t)(__builtin_popcountll(Mr & smask) & 1);
+                }
+                // OSD-0 never looks at a column again once its block is done: only the planes ahead follow the rows
+                const int wfirst = HIGHER ? 0 : (t >> 6) + 1, wspan = HW - wfirst;
+                const int rounds = (wspan + OSD_PIECE - 1) / OSD_PIECE, pw = rounds > 0 ? (wspan + rounds - 1) / rounds : 1;  // planes per round, <= OSD_PIECE
+                for (int w0 = wfirst; w0 < HW; w0 += pw) {
+                    // my rows' planes of this round: independent of the table, in flight while it is built
+                    uint64_t Mr[4], v[4][OSD_PIECE];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = k * 256 + tid;
+                        Mr[k] = r < m ? look[r] : 0ull;
+#pragma unroll
+                        for (int q = 0; q < OSD_PIECE; ++q) v[k][q] = 0ull;
+                        if (Mr[k]) {
+#pragma unroll
+                            for (int q = 0; q < OSD_PIECE; ++q)
+                                if (q < pw && w0 + q < HW) v[k][q] = mat[(int64_t)(w0 + q) * m + r];
+                        }
+                    }
+                    // table: thread (group g, plane q) reads the group's four pivot rows at that plane and writes their 16 combinations
+                    if (tid < groups * pw) {
+                        const int g = tid / pw, q = tid - g * pw;
+                        uint64_t x[4];
+#pragma unroll
+                        for (int bit = 0; bit < 4; ++bit) {
+                            const int j = 4 * g + bit;
+                            const uint64_t y = w0 + q < HW ? mat[(int64_t)(w0 + q < HW ? w0 + q : 0) * m + blk_row[j < npv ? j : 0]] : 0ull;
+                            x[bit] = j < npv ? y : 0ull;
+                        }
+                        uint64_t *e = tbl + (g * OSD_PIECE + q) * 16;
+                        const uint64_t x01 = x[0] ^ x[1], x23 = x[2] ^ x[3];
+                        e[0] = 0ull;        e[1] = x[0];         e[2] = x[1];         e[3] = x01;
+                        e[4] = x[2];        e[5] = x[2] ^ x[0];  e[6] = x[2] ^ x[1];  e[7] = x[2] ^ x01;
+                        e[8] = x[3];        e[9] = x[3] ^ x[0];  e[10] = x[3] ^ x[1]; e[11] = x[3] ^ x01;
+                        e[12] = x23;        e[13] = x23 ^ x[0];  e[14] = x23 ^ x[1];  e[15] = x23 ^ x01;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!Mr[k]) continue;
+                        const int r = k * 256 + tid;
+                        for (int g = 0; g < groups; ++g) {
+                            const uint64_t *e = tbl + g * (OSD_PIECE * 16) + ((Mr[k] >> (g << 2)) & 15ull);
+#pragma unroll
+                            for (int q = 0; q < OSD_PIECE; ++q)
+                                if (q < pw) v[k][q] ^= e[q * 16];
+                        }
+#pragma unroll
+                        for (int q = 0; q < OSD_PIECE; ++q)
+                            if (q < pw && w0 + q < HW) mat[(int64_t)(w0 + q) * m + r] = v[k][q];
+                    }
+                    __syncthreads();  // (the next round rewrites the table; pivcol is written after the last reader)
+                }
+                if (tid < npv) pivcol[blk_row[tid]] = (int16_t)blk_col[tid];
+                __syncthreads();
+                OSD_WG_CLK(7);  // blocked: the combination tables + the combined update of every row
+            }
+        } else
         for (int t = 0; t < n && rank < A.max_rank; ++t) {
             const int c = ord[t], cur = t % 3, kk = t & 63;
             if (kk == 0) {
-                const int ahead = n - t < 64 ? n - t : 64;
-                for (int i = tid; i < m; i += T) {
-                    uint64_t word = 0;
-#pragma unroll 8
-                    for (int q = 0; q < ahead; ++q) {
-                        const int cq = ord[t + q];
-                        word |= ((mat[(int64_t)(cq >> 6) * m + i] >> (cq & 63)) & 1ull) << q;
-                    }
-                    look[i] = word;
-                }
+                for (int i = tid; i < m; i += T) look[i] = mat[(int64_t)(t >> 6) * m + i];  // (columns in sorted order: a plane)
                 __syncthreads();
             }
             int pending = 0;
@@ -915,27 +1111,77 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             if (np) {
                 const int q = k + before + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
                 colinfo[c] = (int16_t)(-1 - q);
-                npcol[q] = (uint16_t)c;
             }
+            if (lane == 0 && (t0 >> 6) + wave < HW) npm[(t0 >> 6) + wave] = mask;  // this wavefront's 64 sorted positions are one plane
             k += total;
             __syncthreads();
         }
         const int KW = (k + 63) >> 6;  // <= A.kwords by the host's sizing
         OSD_WG_CLK(3);  // numbering
-        // T: the reduced rows on the non-pivot columns (bit q = the q-th of them), plane v = word v of every row
-        for (int r = tid; r < m; r += T) {
-            const bool pivoted = pivcol[r] >= 0;
-            for (int v = 0; v < KW; ++v) {
-                uint64_t word = 0;
-                if (pivoted) {
-                    const int cnt = k - 64 * v < 64 ? k - 64 * v : 64;
-#pragma unroll 8
-                    for (int qq = 0; qq < cnt; ++qq) {  // (unrolled: eight independent loads in flight)
-                        const int c = npcol[64 * v + qq];
-                        word |= ((mat[(int64_t)(c >> 6) * m + r] >> (c & 63)) & 1ull) << qq;
+        // T: the reduced rows on the non-pivot columns (bit q = the q-th of them), plane v = word v of every row.  With the
+        // columns in sorted order that is every plane squeezed to its non-pivot positions (a six-step parallel bit compress,
+        // the moves worked out once per plane) and the pieces laid end to end: one read of the matrix.
+        for (int w = tid; w < HW; w += T) {
+            uint64_t mm = npm[w], mk = ~mm << 1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                uint64_t mp = mk ^ (mk << 1);
+                mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16; mp ^= mp << 32;
+                const uint64_t mv = mp & mm;
+                npm[HW + w * 6 + i] = mv;
+                mm = (mm ^ mv) | (mv >> (1 << i));
+                mk &= ~mp;
+            }
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < m; r0 += 1024) {  // four rows per thread at a time
+            int rr[4];
+            bool piv[4];
+            uint64_t acc[4] = {0, 0, 0, 0}, x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rr[q] = r0 + q * 256 + tid < m ? r0 + q * 256 + tid : m - 1;
+                piv[q] = r0 + q * 256 + tid < m && pivcol[rr[q]] >= 0;
+                x[q] = r0 + q * 256 < m ? mat[rr[q]] : 0ull;
+            }
+            int fill = 0, v = 0;
+            for (int w = 0; w < HW; ++w) {
+                uint64_t cur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cur[q] = x[q]; x[q] = (w + 1 < HW && r0 + q * 256 < m) ? mat[(int64_t)(w + 1) * m + rr[q]] : 0ull; }  // (next plane in flight)
+                const uint64_t mask = npm[w];
+                const int cnt = __builtin_popcountll(mask);
+                if (cnt == 0) continue;
+                uint64_t mv[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) mv[i] = npm[HW + w * 6 + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint64_t y = cur[q] & mask;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const uint64_t tt = y & mv[i];
+                        y = (y ^ tt) | (tt >> (1 << i));
                     }
+                    cur[q] = y;
+                    acc[q] |= y << fill;
                 }
-                Tm[(int64_t)v * m + r] = word;
+                if (fill + cnt >= 64) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (r0 + q * 256 + tid < m) Tm[(int64_t)v * m + r0 + q * 256 + tid] = piv[q] ? acc[q] : 0ull;
+                        acc[q] = fill ? cur[q] >> (64 - fill) : 0ull;
+                    }
+                    ++v;
+                    fill += cnt - 64;
+                } else {
+                    fill += cnt;
+                }
+            }
+            if (fill > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + q * 256 + tid < m) Tm[(int64_t)v * m + r0 + q * 256 + tid] = piv[q] ? acc[q] : 0ull;
             }
         }
         __syncthreads();
@@ -943,23 +1189,25 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
         // Weights are added in column order (osd.hpp:171-176); `acc += bit ? w : 0.0` adds the same numbers.
         OSD_WG_CLK(4);  // gather
         const double *wt = a.wt;
-        // Branch-free, so that the loads of several columns are in flight together: a non-pivot column reads the all-zero
-        // dummy row m and adds its own term; for the one-column candidates S is folded into the staged plane.
-        // (four columns per trip, written out: the compiler does not unroll these loops on request)
+        // Branch-free: a non-pivot column reads the all-zero dummy row m and adds its own term; for the one-column candidates
+        // S is folded into the staged plane.
+        // OSD_TRIP columns per trip, written out (the compiler does not unroll these loops on request): a trip waits for an LDS
+        // read (column info), a dependent LDS read (plane words) and an L1 / L2 read (weights) in turn, and that wait is what a
+        // trip costs -- the more columns share it the better; the additions themselves stay a serial chain in column order.
         auto weigh_single = [&](const uint64_t *pl, int q, bool live) -> double {  // candidate: non-pivot column q alone; pl[r] = T plane q / 64 of row r, XOR all-ones if S_r
             double acc = 0;
             const int sh = q & 63;
             int i = 0;
-            for (; i + 4 <= n; i += 4) {
-                int ci[4], r[4];
-                uint64_t t[4];
-                double w[4];
+            for (; i + OSD_TRIP <= n; i += OSD_TRIP) {
+                int ci[OSD_TRIP];
+                uint64_t t[OSD_TRIP];
+                double w[OSD_TRIP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);  // the same for every lane
+                for (int u = 0; u < OSD_TRIP; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);  // the same for every lane
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { r[u] = ci[u] >= 0 ? ci[u] : m; t[u] = pl[r[u]]; w[u] = wt[i + u]; }
+                for (int u = 0; u < OSD_TRIP; ++u) { t[u] = pl[ci[u] >= 0 ? ci[u] : m]; w[u] = wt[i + u]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < OSD_TRIP; ++u) {
                     const bool bit = (((t[u] >> sh) & 1ull) != 0) || (live && -1 - ci[u] == q);
                     acc += bit ? w[u] : 0.0;
                 }
@@ -972,21 +1220,21 @@ __global__ void __launch_bounds__(256) osd_big_kernel(const OsdBigArgs A) {
             return acc;
         };
         auto weigh_mask = [&](const uint64_t *pl0, uint64_t mask) -> double {  // candidate: a set of the first 64 non-pivot columns; pl0 = T plane 0
-            // (bitwise, not `||`: with the short-circuit form and four columns per trip this compiler drops the weight of
+            // (bitwise, not `||`: with the short-circuit form and several columns per trip this compiler drops the weight of
             // the lanes whose bit comes from the second term)
             double acc = 0;
             int i = 0;
-            for (; i + 4 <= n; i += 4) {
-                int ci[4], r[4];
-                uint64_t t[4];
-                unsigned sv[4];
-                double w[4];
+            for (; i + OSD_TRIP <= n; i += OSD_TRIP) {
+                int ci[OSD_TRIP], r[OSD_TRIP];
+                uint64_t t[OSD_TRIP];
+                unsigned sv[OSD_TRIP];
+                double w[OSD_TRIP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);
+                for (int u = 0; u < OSD_TRIP; ++u) ci[u] = __builtin_amdgcn_readfirstlane(colinfo[i + u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { r[u] = ci[u] >= 0 ? ci[u] : m; t[u] = pl0[r[u]]; sv[u] = sy[r[u]]; w[u] = wt[i + u]; }
+                for (int u = 0; u < OSD_TRIP; ++u) { r[u] = ci[u] >= 0 ? ci[u] : m; t[u] = pl0[r[u]]; sv[u] = sy[r[u]]; w[u] = wt[i + u]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < OSD_TRIP; ++u) {
                     const int qn = ci[u] >= 0 ? 64 : -1 - ci[u];
                     const unsigned own = (unsigned)((mask >> (qn & 63)) & 1ull) & (qn < 64 ? 1u : 0u);
                     const unsigned bit = (((unsigned)__builtin_popcountll(t[u] & mask) + sv[u]) & 1u) | own;

@@ -62,8 +62,13 @@ def main():
     rows = int((out[3].cpu().numpy() == 0).sum())
     tot = sum(buf[:7])
     print(f"{rows} rows through OSD; cycles per row (s_memtime, 100 MHz-class counter units):")
-    for name, c in zip(PHASES, buf[:7]):
-        print(f"  {name:28s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
+    names = PHASES
+    if args.hgp1600:  # the workgroup kernel's slots (osd_big_kernel); 0 / 6 / 7 split its blocked elimination
+        names = ["elimination: gather look-ahead words", "copy + sort", "elimination: rest", "number non-pivot columns", "gather reduced rows",
+                 "weigh candidates", "elimination: block pivots (one wavefront)", "elimination: stage pivot rows + combined update"]
+        tot = sum(buf[:8])
+    for name, c in zip(names, buf[:8]):
+        print(f"  {name:52s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
 
 
 if __name__ == "__main__":

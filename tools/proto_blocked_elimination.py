@@ -85,3 +85,107 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def blocked_orig(mat, m, n, block=64):
+    """The form osd_big_kernel uses: every row carries a mask M_r over the block's pivots meaning
+    row_r (now) = row_r (at block start) ^ XOR_{j in M_r} pivot_row_j (at block start); taking pivot p's row means
+    M_r ^= M_p ^ {p} -- no sequential step 2, every row's update reads block-start rows only."""
+    mat = mat.copy()
+    pivcol = -np.ones(m, dtype=np.int64)
+    for c0 in range(0, n, block):
+        c1 = min(n, c0 + block)
+        plane = mat[:, c0:c1].copy()
+        orig = mat.copy()
+        M = np.zeros((m, block), dtype=np.uint8)
+        piv_rows = []
+        for lc in range(c1 - c0):
+            rows = np.flatnonzero(plane[:, lc] & (pivcol < 0))
+            if rows.size == 0:
+                continue
+            p = rows[0]
+            j = len(piv_rows)
+            piv_rows.append(p)
+            pivcol[p] = c0 + lc
+            unit = np.zeros(block, dtype=np.uint8)
+            unit[j] = 1
+            for r in np.flatnonzero(plane[:, lc]):
+                if r != p:
+                    plane[r] ^= plane[p]
+                    M[r] ^= M[p] ^ unit
+        for r in range(m):
+            for j in np.flatnonzero(M[r]):
+                mat[r] ^= orig[piv_rows[j]]
+        assert np.array_equal(mat[:, c0:c1], plane)
+    return mat, pivcol
+
+
+def check_orig_form():
+    rng = np.random.default_rng(1)
+    for trial in range(60):
+        m = int(rng.integers(1, 90))
+        n = int(rng.integers(1, 200))
+        mat = (rng.random((m, n + 1)) < rng.uniform(0.02, 0.5)).astype(np.uint8)  # last column: the syndrome rides along
+        if trial % 5 == 0 and m > 2:
+            mat[-1] = mat[0] ^ mat[1]
+        want, wp = plain(mat[:, :n].copy(), m, n)
+        # the syndrome column under the plain elimination
+        aug, _ = plain_aug(mat, m, n)
+        for block in (64, 8):
+            got, gp = blocked_orig_aug(mat, m, n, block)
+            assert np.array_equal(got[:, :n], want) and np.array_equal(gp, wp) and np.array_equal(got[:, n], aug[:, n]), (trial, block)
+    print("mask-over-block-start-rows form == one pivot at a time, syndrome column included")
+
+
+def plain_aug(mat, m, n):
+    mat = mat.copy()
+    pivcol = -np.ones(m, dtype=np.int64)
+    for c in range(n):
+        rows = np.flatnonzero(mat[:, c] & (pivcol < 0))
+        if rows.size == 0:
+            continue
+        p = rows[0]
+        hit = np.flatnonzero(mat[:, c])
+        hit = hit[hit != p]
+        mat[hit] ^= mat[p]
+        pivcol[p] = c
+    return mat, pivcol
+
+
+def blocked_orig_aug(mat, m, n, block):
+    """blocked_orig on [H | s]: the syndrome bit of row r takes parity(M_r & S) with S_j = syndrome bit of pivot row j at block start."""
+    h, pc = blocked_orig(mat[:, :n].copy(), m, n, block)
+    # redo with the syndrome riding along (same masks: recompute them)
+    full = mat.copy()
+    pivcol = -np.ones(m, dtype=np.int64)
+    for c0 in range(0, n, block):
+        c1 = min(n, c0 + block)
+        plane = full[:, c0:c1].copy()
+        orig = full.copy()
+        M = np.zeros((m, block), dtype=np.uint8)
+        piv_rows = []
+        for lc in range(c1 - c0):
+            rows = np.flatnonzero(plane[:, lc] & (pivcol < 0))
+            if rows.size == 0:
+                continue
+            p = rows[0]
+            j = len(piv_rows)
+            piv_rows.append(p)
+            pivcol[p] = c0 + lc
+            unit = np.zeros(block, dtype=np.uint8)
+            unit[j] = 1
+            for r in np.flatnonzero(plane[:, lc]):
+                if r != p:
+                    plane[r] ^= plane[p]
+                    M[r] ^= M[p] ^ unit
+        S = np.array([orig[p, n] for p in piv_rows] + [0] * (block - len(piv_rows)), dtype=np.uint8)
+        for r in range(m):
+            for j in np.flatnonzero(M[r]):
+                full[r, :n] ^= orig[piv_rows[j], :n]
+            full[r, n] ^= int((M[r] & S).sum() & 1)
+    assert np.array_equal(full[:, :n], h)
+    return full, pivcol
+
+
+if __name__ == "__main__":
+    check_orig_form()
