@@ -1712,18 +1712,26 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         A.max_rank = a.rank;
         A.kwords = !higher ? 0 : host_rank ? (a.n - a.rank + 63) / 64 : A.hwords;  // planes of T; rank unknown: room for every column
         if (higher && A.kwords < 1) A.kwords = 1;
-        // LDS: [keys 8 n | later: pivot columns 2 m, hit list 2 m, syndrome column m + 1, look-ahead words 8 m] [column order 2 pow2]
-        //      higher order: [column info 2 n] [non-pivot columns 2 n] [four T planes 32 (m + 1)];  [H: hwords planes of m words, if it fits]
+        // LDS: [pivot columns 2 m, hit list 2 m, syndrome column m + 1] [column order 2 pow2] and then, phase by phase in the SAME room:
+        //   sort: keys 8 n;  fill of the working copy: sorted positions 2 n;  elimination: look-ahead words 8 m, combination table;
+        //   higher order, once the elimination is over: column info 2 n, plane masks + compress moves 56 hwords, four T planes 32 (m + 1);
+        // last [H: hwords planes of m words, if it fits].  (An [[1600,64]] code: 38 KiB, four workgroups per CU.)
         if (a.m > 32767 || a.n > 32767)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: %d x %d is beyond the 16-bit row / column tables of the workgroup kernel", a.m, a.n);
-        size_t region0 = (size_t)a.n * 8;
-        const size_t after = (((size_t)a.m * 5 + 1 + 7) & ~(size_t)7) + (size_t)a.m * 8;
-        if (after > region0) region0 = after;
-        region0 = (region0 + 15) & ~(size_t)15;
-        size_t lds = region0 + (size_t)A.pow2 * 2;
-        lds = (lds + 7) & ~(size_t)7;
-        A.extra_off = (int32_t)lds;
-        if (higher) lds = ((lds + 4 * (size_t)a.n + 7) & ~(size_t)7) + ((size_t)a.m + 1) * 32;
+        const size_t fixed = ((size_t)a.m * 5 + 1 + 7) & ~(size_t)7;  // bytes before `ord`
+        const size_t phase = (fixed + (size_t)A.pow2 * 2 + 15) & ~(size_t)15;
+        // blocked elimination (osd_block_eliminate): four rows per thread in registers -> m <= 1024, and the combination table
+        // of the block's pivot rows in LDS; LDPC_HIP_OSD_UNBLOCKED=1 keeps the one-pivot-per-step loop (A/B measurements)
+        const bool blocked = a.m <= 1024 && !getenv("LDPC_HIP_OSD_UNBLOCKED");
+        const size_t pbuf_bytes = 16 * OSD_PIECE * 16 * 8;  // [group of four pivots][plane of the round][combination]
+        size_t room = (size_t)a.n * 8;
+        const size_t elim = (size_t)a.m * 8 + (blocked ? pbuf_bytes : 0);
+        if (elim > room) room = elim;
+        const size_t weigh = !higher ? 0 : (((size_t)a.n * 2 + 7) & ~(size_t)7) + 56 * (size_t)A.hwords + ((size_t)a.m + 1) * 32;
+        if (weigh > room) room = weigh;
+        size_t lds = phase + room;
+        A.extra_off = (int32_t)phase;
+        A.pbuf_off = blocked ? (int32_t)(phase + (size_t)a.m * 8) : -1;
         if (lds > 150u * 1024u)
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: the column order%s of a %d x %d matrix need%s %zu bytes of LDS, 150 KiB available",
                         higher ? " and the candidate tables" : "", a.m, a.n, higher ? "" : "s", lds);
@@ -1731,20 +1739,10 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         const size_t mat_bytes = (size_t)A.hwords * a.m * 8;
         const bool mat_lds = !h->osd_big && lds + mat_bytes <= 150u * 1024u;
         if (mat_lds) { A.mat_off = (int32_t)lds; lds += mat_bytes; }
-        // blocked elimination (osd_block_eliminate): four rows per thread in registers -> m <= 1024, and the combination table
-        // of the block's pivot rows in LDS; LDPC_HIP_OSD_UNBLOCKED=1 keeps the one-pivot-per-step loop (A/B measurements)
-        A.pbuf_off = -1;
-        const size_t pbuf_bytes = 16 * OSD_PIECE * 16 * 8;  // [group of four pivots][plane of the round][combination]
-        if (a.m <= 1024 && !getenv("LDPC_HIP_OSD_UNBLOCKED")) {
-            // higher orders: the candidates' plane staging area [4][m + 1] words is idle during the elimination -- reuse it when it is large enough
-            const size_t planes_off = ((size_t)A.extra_off + 4 * (size_t)a.n + 7) & ~(size_t)7;
-            if (higher && ((size_t)a.m + 1) * 32 >= pbuf_bytes) A.pbuf_off = (int32_t)planes_off;
-            else if (lds + pbuf_bytes <= 150u * 1024u) { A.pbuf_off = (int32_t)lds; lds += pbuf_bytes; }
-        }
-        a.lds_per_wave = (int32_t)region0;
+        a.lds_per_wave = (int32_t)fixed;
         A.slot_stride = (int64_t)((mat_lds ? 0 : A.hwords) + A.kwords) * a.m;
         if (A.slot_stride < 1) A.slot_stride = 1;
-        int per_cu = (int)((160u * 1024u) / lds);
+        int per_cu = (int)((160u * 1024u) / (lds + 1024));  // (+ the kernel's static LDS)
         if (per_cu > 4) per_cu = 4;
         if (const char *e = getenv("LDPC_HIP_OSD_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }  // (measurements)
         if (per_cu < 1) per_cu = 1;
@@ -2107,8 +2105,8 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
 
 #ifdef LDPC_HIP_OSD_CLOCKS
 extern "C" int ldpc_hip_debug_osd_clocks(unsigned long long *out, int reset) {
-    if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(osd_phase_clocks), sizeof(unsigned long long) * 8));
-    if (reset) { unsigned long long z[8] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(osd_phase_clocks), z, sizeof z)); }
+    if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(osd_phase_clocks), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(osd_phase_clocks), z, sizeof z)); }
     return LDPC_HIP_OK;
 }
 #endif

@@ -8,7 +8,7 @@
 #define OSD_TRIP 16  // osd_big_kernel: columns per trip when a candidate is weighed
 
 #ifdef LDPC_HIP_OSD_CLOCKS  // profiling aid (tools/osd_phase_clocks.py): cycles per phase of osdw_reg_kernel, summed over wavefronts
-__device__ unsigned long long osd_phase_clocks[8];
+__device__ unsigned long long osd_phase_clocks[16];
 #define OSD_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
                            if (lane == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
 #define OSD_CLK_START() unsigned long long clk_ = __builtin_readcyclecounter()
@@ -748,9 +748,9 @@ struct OsdBigArgs {
     int32_t pow2;           // bitonic size: smallest power of two >= n
     int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
-    int32_t extra_off;      // HIGHER: byte offset in LDS of {colinfo [n] i16, npcol [n] u16, (8-aligned) planes [4][m + 1] u64}
+    int32_t extra_off;      // byte offset in LDS of the room the phases share: keys [n] u64 | positions [n] u16 | look [m] u64 + table | {colinfo [n] i16, (8-aligned) plane masks and moves [7][hwords] u64, planes [4][m + 1] u64}
     int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
-    int32_t pbuf_off;       // blocked elimination (m <= 1024): byte offset in LDS of the 16 KiB combination table; -1: one pivot per step
+    int32_t pbuf_off;       // blocked elimination (m <= 1024): byte offset in LDS of the combination table (extra_off + 8 m); -1: one pivot per step
 };
 
 // ---- blocked elimination: the 64 columns of a look-ahead block, rows in registers ----------------------------------------------
@@ -840,23 +840,24 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
 }
 
 template <bool HIGHER, bool MAT_LDS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) osd_big_kernel(const OsdBigArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) osd_big_kernel(const OsdBigArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
     const OsdArgs &a = A.o;
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = a.m, n = a.n, HW = A.hwords, P = A.pow2;
-    // during the sort: keys [n] u64, then ord [P] i32.  Afterwards the keys' room is reused.
-    uint64_t *keys = reinterpret_cast<uint64_t *>(osd_lds);
+    // [pivcol, hits, sy | ord] stay; the room after them (extra_off) belongs to one phase at a time: the sort's keys, the fill's
+    // positions, the elimination's look-ahead words and table, the candidates' tables and planes (sized by the host, decode path of bp_hip.hip)
+    uint64_t *keys = reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.extra_off);
     // (16-bit tables: m, n < 32768 here -- the host checks --, and the LDS they save is a third resident workgroup)
     uint16_t *ord = reinterpret_cast<uint16_t *>(osd_lds + (size_t)a.lds_per_wave);  // lds_per_wave: bytes before `ord`
     int16_t *pivcol = reinterpret_cast<int16_t *>(osd_lds);            // [m]
     uint16_t *hits = reinterpret_cast<uint16_t *>(pivcol + m);         // [m]
     uint8_t *sy = reinterpret_cast<uint8_t *>(hits + m);               // [m + 1]
-    uint64_t *look = reinterpret_cast<uint64_t *>(osd_lds + ((5 * (size_t)m + 1 + 7) & ~(size_t)7));  // [m] bits of the next 64 columns, per row
+    uint64_t *look = reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.extra_off);  // [m] bits of the block's 64 columns, per row
     int16_t *colinfo = reinterpret_cast<int16_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
-    uint64_t *npm = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 2 * (size_t)n + 7) & ~(size_t)7));  // [HW] non-pivot positions of every plane, then [HW][6] the compress moves (< 2 n - 8 bytes: n >= 64)
-    uint64_t *planes = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 4 * (size_t)n + 7) & ~(size_t)7));  // [4][m + 1] (entry m: the all-zero dummy row)
+    uint64_t *npm = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 2 * (size_t)n + 7) & ~(size_t)7));  // [HW] non-pivot positions of every plane, then [HW][6] the compress moves
+    uint64_t *planes = npm + 7 * (size_t)HW;  // [4][m + 1] (entry m: the all-zero dummy row)
     __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
     __shared__ uint16_t blk_row[64], blk_col[64];
     __shared__ unsigned long long blk_sy;
@@ -902,7 +903,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
         // copies of a batch's rows live in HBM / MALL, and bytes moved are what this kernel is bound by), and the non-pivot
         // columns come out in candidate order.  Filled from the CSR form: nnz atomic ORs into the zeroed planes.
         {
-            uint16_t *pos = reinterpret_cast<uint16_t *>(osd_lds);  // [n] sorted position of a column (in the keys' room, until the fill is done)
+            uint16_t *pos = reinterpret_cast<uint16_t *>(osd_lds + (size_t)A.extra_off);  // [n] sorted position of a column (in the keys' room, until the fill is done)
             for (int t = tid; t < n; t += T) pos[ord[t]] = (uint16_t)t;
             __threadfence();
             __syncthreads();
@@ -915,7 +916,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
             __syncthreads();
         }
         OSD_WG_CLK(1);  // sort + working copy
-        for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }  // (overwrites the keys)
+        for (int i = tid; i < m; i += T) { pivcol[i] = -1; sy[i] = a.synd[b * m + i] ? 1 : 0; }
         if (tid < 3) { sh_nhits[tid] = 0; sh_pivot[tid] = INT32_MAX; }
         __syncthreads();
 
@@ -936,7 +937,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 const int ahead = n - t < 64 ? n - t : 64;
                 int pending = 0;
                 for (int i = tid; i < m; i += T) {
-                    look[i] = mat[(int64_t)(t >> 6) * m + i];  // the block's columns: one plane of the sorted copy
+                    look[i] = mat[(t >> 6) * m + i];  // the block's columns: one plane of the sorted copy
                     if (!HIGHER && pivcol[i] < 0 && sy[i]) pending = 1;
                 }
                 if (tid == 0) blk_sy = 0ull;
@@ -984,9 +985,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                         if (Mr[k]) {
 #pragma unroll
                             for (int q = 0; q < OSD_PIECE; ++q)
-                                if (q < pw && w0 + q < HW) v[k][q] = mat[(int64_t)(w0 + q) * m + r];
+                                if (q < pw && w0 + q < HW) v[k][q] = mat[(w0 + q) * m + r];  // (plane-major index < 2^24: m, n < 32768)
                         }
                     }
+                    OSD_WG_CLK(8);  // update: issue of my rows' loads
                     // table: thread (group g, plane q) reads the group's four pivot rows at that plane and writes their 16 combinations
                     if (tid < groups * pw) {
                         const int g = tid / pw, q = tid - g * pw;
@@ -994,7 +996,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
 #pragma unroll
                         for (int bit = 0; bit < 4; ++bit) {
                             const int j = 4 * g + bit;
-                            const uint64_t y = w0 + q < HW ? mat[(int64_t)(w0 + q < HW ? w0 + q : 0) * m + blk_row[j < npv ? j : 0]] : 0ull;
+                            const uint64_t y = w0 + q < HW ? mat[(w0 + q < HW ? w0 + q : 0) * m + blk_row[j < npv ? j : 0]] : 0ull;
                             x[bit] = j < npv ? y : 0ull;
                         }
                         uint64_t *e = tbl + (g * OSD_PIECE + q) * 16;
@@ -1004,22 +1006,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                         e[8] = x[3];        e[9] = x[3] ^ x[0];  e[10] = x[3] ^ x[1]; e[11] = x[3] ^ x01;
                         e[12] = x23;        e[13] = x23 ^ x[0];  e[14] = x23 ^ x[1];  e[15] = x23 ^ x01;
                     }
+                    OSD_WG_CLK(9);  // update: table build
                     __syncthreads();
+                    OSD_WG_CLK(10);  // update: barrier (loads land)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (!Mr[k]) continue;
-                        const int r = k * 256 + tid;
                         for (int g = 0; g < groups; ++g) {
-                            const uint64_t *e = tbl + g * (OSD_PIECE * 16) + ((Mr[k] >> (g << 2)) & 15ull);
+                            const unsigned nib = (unsigned)(Mr[k] >> (g << 2)) & 15u;
+                            if (!__builtin_amdgcn_ballot_w64(nib != 0)) continue;  // (early blocks: most rows take few pivots -- entry 0 is zero)
+                            const uint64_t *e = tbl + g * (OSD_PIECE * 16) + nib;
 #pragma unroll
                             for (int q = 0; q < OSD_PIECE; ++q)
                                 if (q < pw) v[k][q] ^= e[q * 16];
                         }
+                    }
+                    OSD_WG_CLK(13);  // update: lookups
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!Mr[k]) continue;
+                        const int r = k * 256 + tid;
 #pragma unroll
                         for (int q = 0; q < OSD_PIECE; ++q)
-                            if (q < pw && w0 + q < HW) mat[(int64_t)(w0 + q) * m + r] = v[k][q];
+                            if (q < pw && w0 + q < HW) mat[(w0 + q) * m + r] = v[k][q];
                     }
-                    __syncthreads();  // (the next round rewrites the table; pivcol is written after the last reader)
+                    OSD_WG_CLK(11);  // update: stores
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    OSD_WG_CLK(12);  // update: closing barrier
                 }
                 if (tid < npv) pivcol[blk_row[tid]] = (int16_t)blk_col[tid];
                 __syncthreads();
@@ -1148,7 +1161,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
             for (int w = 0; w < HW; ++w) {
                 uint64_t cur[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { cur[q] = x[q]; x[q] = (w + 1 < HW && r0 + q * 256 < m) ? mat[(int64_t)(w + 1) * m + rr[q]] : 0ull; }  // (next plane in flight)
+                for (int q = 0; q < 4; ++q) { cur[q] = x[q]; x[q] = (w + 1 < HW && r0 + q * 256 < m) ? mat[(w + 1) * m + rr[q]] : 0ull; }  // (next plane in flight)
                 const uint64_t mask = npm[w];
                 const int cnt = __builtin_popcountll(mask);
                 if (cnt == 0) continue;

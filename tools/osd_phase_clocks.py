@@ -54,7 +54,7 @@ def main():
     out = eng.decode_batch(s, osd=True)
     torch.cuda.synchronize()
     dll = lib.load()
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     dll.ldpc_hip_debug_osd_clocks(buf, 1)
     eng.decode_batch(s, out=out, osd=True)
     torch.cuda.synchronize()
@@ -64,10 +64,11 @@ def main():
     print(f"{rows} rows through OSD; cycles per row (s_memtime, 100 MHz-class counter units):")
     names = PHASES
     if args.hgp1600:  # the workgroup kernel's slots (osd_big_kernel); 0 / 6 / 7 split its blocked elimination
-        names = ["elimination: gather look-ahead words", "copy + sort", "elimination: rest", "number non-pivot columns", "gather reduced rows",
-                 "weigh candidates", "elimination: block pivots (one wavefront)", "elimination: stage pivot rows + combined update"]
-        tot = sum(buf[:8])
-    for name, c in zip(names, buf[:8]):
+        names = ["elimination: the block's plane", "sort + working copy", "(columns, pivots: 1e6, 1e9 digits)", "number non-pivot columns", "T planes",
+                 "weigh candidates", "elimination: block pivots", "elimination: rest of the update", "update: issue my rows' loads", "update: table build",
+                 "update: barrier (loads land)", "update: stores", "update: closing barrier", "update: lookups"]
+        tot = sum(buf[:16]) - buf[2]
+    for name, c in zip(names, buf[:16]):
         print(f"  {name:52s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
 
 
