@@ -5,6 +5,8 @@
 #include "bp_device_common.h"
 
 #define OSD_PIECE 9  // blocked elimination of osd_big_kernel: planes per table round
+// workgroup barrier that orders LDS traffic only: global loads and stores in flight stay in flight (__syncthreads() waits for them)
+#define OSD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define OSD_TRIP 16  // osd_big_kernel: columns per trip when a candidate is weighed
 
 #ifdef LDPC_HIP_OSD_CLOCKS  // profiling aid (tools/osd_phase_clocks.py): cycles per phase of osdw_reg_kernel, summed over wavefronts
@@ -783,8 +785,22 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
         M[q] = 0ull;
         if (r < m && pivcol[r] < 0) unp |= 1u << q;
     }
-    int np = 0;
+    // Columns no unpivoted row has a bit in NOW never become pivot columns in this block (a row only changes by taking rows that
+    // were unpivoted at block start, and those all have a zero there): they cost no step.  For the sparse matrices OSD meets that is
+    // most of the non-pivot columns -- the ones that depend on pivots of earlier blocks only.
+    uint64_t any = 0;
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) any |= ((unp >> q) & 1u) ? L[q] : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)any, off), hi = (unsigned)__shfl_xor((int)(unsigned)(any >> 32), off);
+        any |= ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0 && any) atomicOr(xch + 20, (unsigned long long)any);  // (zeroed by the caller before its last barrier)
+    __syncthreads();
+    const uint64_t live = __builtin_amdgcn_readfirstlane((unsigned)xch[20]) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xch[20] >> 32)) << 32);
+    int np = 0, step = 0;
     for (int j = 0; j < ahead && rank < max_rank; ++j) {
+        if (!((live >> j) & 1ull)) continue;
         // this wavefront's offer: its first unpivoted row with the bit -- rows ascend in (q, lane) within a wavefront
         int qs = -1;
         uint64_t cm = 0;
@@ -794,9 +810,10 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
                 cm = __builtin_amdgcn_ballot_w64(((unp >> q) & 1u) && osd_bit_at(L[q], j));
                 if (cm) qs = q;
             }
-        // offers, two sets (step j + 1 writes the other one): words 0-1 = the four wavefronts' rows (u32 each, ~0: none),
+        // offers, two sets (the next step writes the other one): words 0-1 = the four wavefronts' rows (u32 each, ~0: none),
         // words 2 + 2 w, 3 + 2 w = wavefront w's row in the block's columns and its mask
-        unsigned long long *set = xch + (j & 1) * 10;
+        unsigned long long *set = xch + (step & 1) * 10;
+        ++step;
         if (qs < 0) {
             if (lane == 0) reinterpret_cast<unsigned *>(set)[wave] = ~0u;
         } else if (lane == __builtin_ctzll(cm)) {
@@ -836,7 +853,7 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
         const int r = q * 256 + tid;
         if (r < m) look[r] = M[q];  // the look-ahead words are spent; the next block gathers its own
     }
-    return np;
+    return np | (step << 8);  // pivots made, columns that took a step
 }
 
 template <bool HIGHER, bool MAT_LDS>
@@ -858,10 +875,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     int16_t *colinfo = reinterpret_cast<int16_t *>(osd_lds + (size_t)A.extra_off);  // [n] pivot column: its row; q-th non-pivot column: -1 - q
     uint64_t *npm = reinterpret_cast<uint64_t *>(osd_lds + (((size_t)A.extra_off + 2 * (size_t)n + 7) & ~(size_t)7));  // [HW] non-pivot positions of every plane, then [HW][6] the compress moves
     uint64_t *planes = npm + 7 * (size_t)HW;  // [4][m + 1] (entry m: the all-zero dummy row)
-    __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4];
+    __shared__ int sh_row, sh_pivot[3], sh_nhits[3], sh_cnt[4], sh_nact;
     __shared__ uint16_t blk_row[64], blk_col[64];
     __shared__ unsigned long long blk_sy;
-    __shared__ __attribute__((aligned(16))) unsigned long long blk_xch[20];
+    __shared__ __attribute__((aligned(16))) unsigned long long blk_xch[21];  // [20]: OR of the unpivoted rows' look-ahead words
     __shared__ double sh_w[4];
     __shared__ long sh_c[4];
     // MAT_LDS: the working copy of H fits LDS next to everything else (mid-size matrices: a whole workgroup on one
@@ -940,7 +957,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     look[i] = mat[(t >> 6) * m + i];  // the block's columns: one plane of the sorted copy
                     if (!HIGHER && pivcol[i] < 0 && sy[i]) pending = 1;
                 }
-                if (tid == 0) blk_sy = 0ull;
+                if (tid == 0) { blk_sy = 0ull; sh_nact = 0; blk_xch[20] = 0ull; }
                 if (!HIGHER) {
                     // OSD-0 stops once the syndrome is in the span of the pivots (gf2sparse_linalg.hpp:373-383).  Tested per block:
                     // pivots made past that point have a zero syndrome bit and change no other, so x is the same.
@@ -949,57 +966,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     __syncthreads();
                 }
                 OSD_WG_CLK(0);  // blocked: the block's plane
-                int npv;
+                int npv;  // (pivots | steps << 8)
                 if (m <= 256) npv = osd_block_eliminate<1>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 else if (m <= 512) npv = osd_block_eliminate<2>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 else if (m <= 768) npv = osd_block_eliminate<3>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 else npv = osd_block_eliminate<4>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 __syncthreads();
                 OSD_WG_CLK(6);  // blocked: the block's pivots
+                const int nsteps = npv >> 8;
+                npv &= 255;
+                (void)nsteps;
 #ifdef LDPC_HIP_OSD_CLOCKS
-                if (tid == 0) atomicAdd(&osd_phase_clocks[2], 1000000ull * ahead + 1000000000ull * npv);  // (columns, pivots: read off the decimal digits)
+                if (tid == 0) atomicAdd(&osd_phase_clocks[2], 1000000ull * nsteps + 1000000000ull * npv);  // (columns, pivots: read off the decimal digits)
 #endif
                 rank += npv;
                 if (npv == 0) continue;
                 if (tid < npv && sy[blk_row[tid]]) atomicOr(&blk_sy, 1ull << tid);
-                __syncthreads();
-                const unsigned long long blk_sy_now = blk_sy;  // S: the pivot rows' syndrome bits at block start
                 const int groups = (npv + 3) >> 2;
-                const unsigned long long smask = blk_sy_now;
-                for (int r = tid; r < m; r += T) {
-                    const uint64_t Mr = look[r];
-                    if (Mr) sy[r] ^= (uint8_t)(__builtin_popcountll(Mr & smask) & 1);
-                }
                 // OSD-0 never looks at a column again once its block is done: only the planes ahead follow the rows
                 const int wfirst = HIGHER ? 0 : (t >> 6) + 1, wspan = HW - wfirst;
                 const int rounds = (wspan + OSD_PIECE - 1) / OSD_PIECE, pw = rounds > 0 ? (wspan + rounds - 1) / rounds : 1;  // planes per round, <= OSD_PIECE
-                for (int w0 = wfirst; w0 < HW; w0 += pw) {
-                    // my rows' planes of this round: independent of the table, in flight while it is built
-                    uint64_t Mr[4], v[4][OSD_PIECE];
+                // table of a round: thread (group g, plane q) reads the group's four pivot rows at that plane -- as they are at block
+                // start, and a round only changes its own planes: the reads for a round are issued a round ahead
+                const int tg = tid / pw, tq = tid - tg * pw;
+                uint64_t xt[4] = {0, 0, 0, 0};
+                auto table_rows = [&](int w0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int r = k * 256 + tid;
-                        Mr[k] = r < m ? look[r] : 0ull;
-#pragma unroll
-                        for (int q = 0; q < OSD_PIECE; ++q) v[k][q] = 0ull;
-                        if (Mr[k]) {
-#pragma unroll
-                            for (int q = 0; q < OSD_PIECE; ++q)
-                                if (q < pw && w0 + q < HW) v[k][q] = mat[(w0 + q) * m + r];  // (plane-major index < 2^24: m, n < 32768)
-                        }
+                    for (int bit = 0; bit < 4; ++bit) {
+                        const int j = 4 * tg + bit;
+                        xt[bit] = (tid < groups * pw && j < npv && w0 + tq < HW) ? mat[(w0 + tq) * m + blk_row[j]] : 0ull;
                     }
-                    OSD_WG_CLK(8);  // update: issue of my rows' loads
-                    // table: thread (group g, plane q) reads the group's four pivot rows at that plane and writes their 16 combinations
-                    if (tid < groups * pw) {
-                        const int g = tid / pw, q = tid - g * pw;
-                        uint64_t x[4];
+                };
+                if (wfirst < HW) table_rows(wfirst);
+                OSD_LDS_BARRIER();
+                const unsigned long long blk_sy_now = blk_sy;  // S: the pivot rows' syndrome bits at block start
+                const unsigned long long smask = blk_sy_now;
+                // The rows that take any of the block's pivots, listed: for sparse H they are a fraction of the rows, and a wavefront
+                // whose lanes each own fixed rows would run the whole update for the few lanes that have one.
 #pragma unroll
-                        for (int bit = 0; bit < 4; ++bit) {
-                            const int j = 4 * g + bit;
-                            const uint64_t y = w0 + q < HW ? mat[(w0 + q < HW ? w0 + q : 0) * m + blk_row[j < npv ? j : 0]] : 0ull;
-                            x[bit] = j < npv ? y : 0ull;
-                        }
-                        uint64_t *e = tbl + (g * OSD_PIECE + q) * 16;
+                for (int k = 0; k < 4; ++k) {
+                    const int r = k * 256 + tid;
+                    if (k * 256 >= m) break;
+                    const uint64_t Mr = r < m ? look[r] : 0ull;
+                    const uint64_t am = __builtin_amdgcn_ballot_w64(Mr != 0);
+                    if (!am) continue;
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&sh_nact, __builtin_popcountll(am));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (Mr) {
+                        hits[base + __builtin_popcountll(am & ((1ull << lane) - 1ull))] = (uint16_t)r;
+                        sy[r] ^= (uint8_t)(__builtin_popcountll(Mr & smask) & 1);
+                    }
+                }
+                OSD_LDS_BARRIER();
+                const int nact = sh_nact;
+                const float inv_nact = 1.0f / (float)(nact > 0 ? nact : 1);
+                OSD_WG_CLK(8);  // update: list of the rows
+                for (int w0 = wfirst; w0 < HW && nact > 0; w0 += pw) {
+                    if (tid < groups * pw) {  // the 16 combinations of the group's four rows
+                        const uint64_t *x = xt;
+                        uint64_t *e = tbl + (tg * OSD_PIECE + tq) * 16;
                         const uint64_t x01 = x[0] ^ x[1], x23 = x[2] ^ x[3];
                         e[0] = 0ull;        e[1] = x[0];         e[2] = x[1];         e[3] = x01;
                         e[4] = x[2];        e[5] = x[2] ^ x[0];  e[6] = x[2] ^ x[1];  e[7] = x[2] ^ x01;
@@ -1007,31 +1033,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                         e[12] = x23;        e[13] = x23 ^ x[0];  e[14] = x23 ^ x[1];  e[15] = x23 ^ x01;
                     }
                     OSD_WG_CLK(9);  // update: table build
-                    __syncthreads();
-                    OSD_WG_CLK(10);  // update: barrier (loads land)
+                    OSD_LDS_BARRIER();  // (the previous round's stores may still be in flight: other planes)
+                    OSD_WG_CLK(10);  // update: barrier
+                    if (w0 + pw < HW) table_rows(w0 + pw);
+                    // items (listed row, plane of the round), neighbouring lanes on neighbouring listed rows of one plane; eight at a time:
+                    // what each takes from the table first, then only the words that change are read and written back
+                    const int pwr = HW - w0 < pw ? HW - w0 : pw, items = nact * pwr;
+                    for (int i0 = tid; i0 < items; i0 += 8 * 256) {
+                        uint64_t d[8];
+                        int at[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (!Mr[k]) continue;
-                        for (int g = 0; g < groups; ++g) {
-                            const unsigned nib = (unsigned)(Mr[k] >> (g << 2)) & 15u;
-                            if (!__builtin_amdgcn_ballot_w64(nib != 0)) continue;  // (early blocks: most rows take few pivots -- entry 0 is zero)
-                            const uint64_t *e = tbl + g * (OSD_PIECE * 16) + nib;
-#pragma unroll
-                            for (int q = 0; q < OSD_PIECE; ++q)
-                                if (q < pw) v[k][q] ^= e[q * 16];
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * 256;
+                            d[u] = 0ull;
+                            at[u] = 0;
+                            if (i < items) {
+                                int q = (int)((float)i * inv_nact);  // i / nact, i < 2^14: the float quotient is off by one at most
+                                if (q * nact > i) --q;
+                                if ((q + 1) * nact <= i) ++q;
+                                const int r = hits[i - q * nact];
+                                const uint64_t Mr = look[r];
+                                const uint64_t *e = tbl + q * 16;
+                                uint64_t acc = 0ull;
+                                for (int g = 0; g < groups; ++g) acc ^= e[g * (OSD_PIECE * 16) + ((Mr >> (g << 2)) & 15ull)];
+                                d[u] = acc;
+                                at[u] = (w0 + q) * m + r;  // (plane-major index < 2^24: m, n < 32768)
+                            }
                         }
-                    }
-                    OSD_WG_CLK(13);  // update: lookups
+                        uint64_t x[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (!Mr[k]) continue;
-                        const int r = k * 256 + tid;
+                        for (int u = 0; u < 8; ++u) x[u] = d[u] ? mat[at[u]] : 0ull;
 #pragma unroll
-                        for (int q = 0; q < OSD_PIECE; ++q)
-                            if (q < pw && w0 + q < HW) mat[(w0 + q) * m + r] = v[k][q];
+                        for (int u = 0; u < 8; ++u)
+                            if (d[u]) mat[at[u]] = x[u] ^ d[u];
                     }
-                    OSD_WG_CLK(11);  // update: stores
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    OSD_WG_CLK(11);  // update: items
+                    // the next round rewrites the table: an LDS-only barrier -- the stores above need not have landed, nobody reads those
+                    // planes before the next full barrier (the next round's table is built from planes further on)
+                    OSD_LDS_BARRIER();
                     OSD_WG_CLK(12);  // update: closing barrier
                 }
                 if (tid < npv) pivcol[blk_row[tid]] = (int16_t)blk_col[tid];
@@ -1201,7 +1240,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // x_i of a candidate: pivot column with row r: S_r ^ parity(T_r & candidate); q-th non-pivot column: the candidate's bit q.
         // Weights are added in column order (osd.hpp:171-176); `acc += bit ? w : 0.0` adds the same numbers.
         OSD_WG_CLK(4);  // gather
-        const double *wt = a.wt;
+        // the weights are the same for every lane, wavefront and workgroup and nobody writes them: through the constant address
+        // space they come by scalar loads (a vector load would move 64 copies of each through L1)
+        const __attribute__((address_space(4))) double *wt = (const __attribute__((address_space(4))) double *)a.wt;
         // Branch-free: a non-pivot column reads the all-zero dummy row m and adds its own term; for the one-column candidates
         // S is folded into the staged plane.
         // OSD_TRIP columns per trip, written out (the compiler does not unroll these loops on request): a trip waits for an LDS

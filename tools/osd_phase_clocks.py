@@ -65,9 +65,9 @@ def main():
     names = PHASES
     if args.hgp1600:  # the workgroup kernel's slots (osd_big_kernel); 0 / 6 / 7 split its blocked elimination
         names = ["elimination: the block's plane", "sort + working copy", "(columns, pivots: 1e6, 1e9 digits)", "number non-pivot columns", "T planes",
-                 "weigh candidates", "elimination: block pivots", "elimination: rest of the update", "update: issue my rows' loads", "update: table build",
-                 "update: barrier (loads land)", "update: stores", "update: closing barrier", "update: lookups"]
-        tot = sum(buf[:16]) - buf[2]
+                 "weigh candidates", "elimination: block pivots", "elimination: rest of the update", "update: list of the rows", "update: table build",
+                 "update: barrier", "update: items", "update: closing barrier"]
+        tot = sum(buf[:14]) - buf[2]
     for name, c in zip(names, buf[:16]):
         print(f"  {name:52s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
 
