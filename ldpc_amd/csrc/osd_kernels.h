@@ -14,8 +14,11 @@ __device__ unsigned long long osd_phase_clocks[16];
 #define OSD_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
                            if (lane == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
 #define OSD_CLK_START() unsigned long long clk_ = __builtin_readcyclecounter()
-#define OSD_WG_CLK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-                              if (tid == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } while (0)
+#ifndef LDPC_HIP_OSD_CLOCK_MASK  // which osd_big_kernel probes are live (a probe serialises: few at a time perturb least); time goes to the next live probe
+#define LDPC_HIP_OSD_CLOCK_MASK 0xffff
+#endif
+#define OSD_WG_CLK(slot) do { if ((LDPC_HIP_OSD_CLOCK_MASK >> (slot)) & 1) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                              if (tid == 0) atomicAdd(&osd_phase_clocks[slot], now_ - clk_); clk_ = now_; } } while (0)
 #else
 #define OSD_CLK(slot) do { } while (0)
 #define OSD_CLK_START() do { } while (0)
@@ -1313,40 +1316,55 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         };
         const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
         const long npairs = (long)a.order * (a.order - 1) / 2;
-        // plane 0 for the mask candidates and the OSD-0 weight
-        for (int r = tid; r < m; r += T) planes[r] = KW > 0 ? Tm[r] : 0ull;
-        if (tid == 0) { planes[m] = 0; sy[m] = 0; }  // the dummy row of the non-pivot columns
+        // The winner is the lightest candidate, the earliest of the reference's list among equals, the OSD-0 solution before all of
+        // them (osd.hpp:131-136, 171-181: a candidate replaces the incumbent only if strictly lighter) -- a lexicographic minimum, so
+        // the candidates can be weighed in any order.  Tasks of 64 candidates, one per wavefront at a time, each wavefront staging the
+        // plane it needs in its own buffer and running at its own pace: first the sets of the first `order` non-pivot columns (entry 0
+        // = the empty set = the OSD-0 solution, index -1; then the pairs of OSD_CS, index k + pair, or the numbers of OSD_E), then
+        // for OSD_CS the single columns, plane by plane (index q).
+        const long nsets = (a.method == 3 ? npairs : (1L << a.order) - 1) + 1;  // (numbers 1 .. 2^order - 1, order <= 24, bits >= k dropped: util.hpp:12-38)
+        const long nchunk = (nsets + 63) >> 6, ntask = nchunk + (a.method == 3 ? KW : 0);
+        if (tid == 0) sy[m] = 0;  // the dummy row of the non-pivot columns
         __syncthreads();
-        double best_w = weigh_mask(planes, 0);  // the OSD-0 solution (osd.hpp:131-136)
-        long best_c = -1;                       // index in the reference's candidate list; -1: the OSD-0 solution
-        if (a.method == 3) {
-            for (long p0 = 0; p0 < npairs; p0 += T) {
-                const long pp = p0 + tid;
-                bool valid = false;
-                const uint64_t mask = pp < npairs ? pair_mask(pp, valid) : 0ull;
-                const double w = weigh_mask(planes, mask);
-                if (valid && (w < best_w || (w == best_w && best_c >= 0 && k + pp < best_c))) { best_w = w; best_c = k + pp; }
-            }
-            // one-column candidates come FIRST in the reference's list: an equal weight met here replaces a later pair
-            for (int v0 = 0; v0 < KW; v0 += 4) {
-                __syncthreads();
-                const int v = v0 + wave;
-                uint64_t *pl = planes + (size_t)wave * (m + 1);
-                if (v < KW)
-                    for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)v * m + r] ^ (sy[r] ? ~0ull : 0ull);
-                if (lane == 0) pl[m] = 0;
-                __syncthreads();
-                const int q = 64 * v + lane;
-                const bool live = v < KW && q < k;
-                const double w = weigh_single(pl, q, live);
-                if (live && (w < best_w || (w == best_w && best_c >= 0 && q < best_c))) { best_w = w; best_c = q; }
-            }
-        } else {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
-            const long total = (1L << a.order) - 1;
-            for (long c0 = 0; c0 < total; c0 += T) {
-                const long c = c0 + tid;
-                const double w = weigh_mask(planes, (uint64_t)(c + 1) & kmask);
-                if (c < total && w < best_w) { best_w = w; best_c = c; }
+        double best_w = __builtin_huge_val();
+        long best_c = LONG_MAX;  // index in the reference's candidate list; -1: the OSD-0 solution
+        auto offer = [&](double w, long c) { if (w < best_w || (w == best_w && c < best_c)) { best_w = w; best_c = c; } };
+        {
+            uint64_t *pl = planes + (size_t)wave * (m + 1);
+            int held = -2;  // what the buffer holds: -1 = T plane 0 as it is (sets), v >= 0 = plane v XOR all-ones where S_r (single columns)
+            for (long task0 = 0; task0 < ntask; task0 += 4) {
+                const long task = task0 + __builtin_amdgcn_readfirstlane(wave);
+                if (task >= ntask) break;
+                const int want = task < nchunk ? -1 : (int)(task - nchunk);
+                if (want != held) {
+                    if (want < 0) {
+                        for (int r = lane; r < m; r += 64) pl[r] = KW > 0 ? Tm[r] : 0ull;
+                    } else {
+                        for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)want * m + r] ^ (sy[r] ? ~0ull : 0ull);
+                    }
+                    if (lane == 0) pl[m] = 0;
+                    held = want;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of a wavefront execute in order; this only pins the compiler
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                if (want < 0) {
+                    const long e = task * 64 + lane;
+                    bool valid = e < nsets;
+                    uint64_t mask = 0;
+                    long idx = -1;
+                    if (valid && e >= 1) {
+                        if (a.method == 3) { mask = pair_mask(e - 1, valid); idx = k + e - 1; }
+                        else { mask = (uint64_t)e & kmask; idx = e - 1; }
+                    }
+                    const double w = weigh_mask(pl, mask);
+                    if (valid) offer(w, idx);
+                } else {
+                    const int q = 64 * want + lane;
+                    const bool live = q < k;
+                    const double w = weigh_single(pl, q, live);
+                    if (live) offer(w, q);
+                }
             }
         }
         OSD_WG_CLK(5);  // weighing
@@ -1354,18 +1372,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int off = 32; off > 0; off >>= 1) {
             const double ow = __shfl_xor(best_w, off);
             const long oc = ((long)__shfl_xor((int)(best_c >> 32), off) << 32) | (unsigned)__shfl_xor((int)(best_c & 0xffffffff), off);
-            const bool mine_set = best_c >= 0, other_set = oc >= 0;
-            if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
+            offer(ow, oc);
         }
         __syncthreads();
         if (lane == 0) { sh_w[wave] = best_w; sh_c[wave] = best_c; }
         __syncthreads();
         best_w = sh_w[0]; best_c = sh_c[0];
-        for (int w = 1; w < 4; ++w) {
-            const double ow = sh_w[w];
-            const long oc = sh_c[w];
-            if (oc >= 0 && (best_c < 0 || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
-        }
+        for (int w = 1; w < 4; ++w) offer(sh_w[w], sh_c[w]);
         const bool single = a.method == 3 && best_c >= 0 && best_c < k;
         uint64_t win = 0;
         if (best_c >= 0 && !single) {

@@ -25,12 +25,18 @@ def main():
     ap.add_argument("--bb", action="store_true")
     ap.add_argument("--hgp1600", action="store_true", help="the [[1600,64]] code of bench_configs.py: workgroup kernel, H in HBM")
     ap.add_argument("--order", type=int, default=10)
+    ap.add_argument("--mask", type=lambda v: int(v, 0), default=0xffff,
+                    help="workgroup kernel: the probes that are live (bit = slot); every probe serialises, so a few at a time perturb "
+                         "least -- the time between two live probes goes to the later one")
     args = ap.parse_args()
+    global DBG
+    if args.mask != 0xffff:
+        DBG = DBG[:-3] + "_%x.so" % args.mask
     if args.build:
         os.makedirs(os.path.dirname(DBG), exist_ok=True)
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "ldpc_amd", "csrc"), "OUT=" + DBG,
                                "FLAGS=-O3 -std=c++17 -ffp-contract=off -fPIC -shared --offload-arch=gfx950 -Wall "
-                               "-Wno-unused-function -DLDPC_HIP_OSD_CLOCKS"])
+                               "-Wno-unused-function -DLDPC_HIP_OSD_CLOCKS -DLDPC_HIP_OSD_CLOCK_MASK=0x%x" % args.mask])
         return
     import ldpc_amd._lib as lib
     lib.LIB_PATH = DBG
