@@ -737,14 +737,17 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
 }
 
 // ---- OSD with one WORKGROUP per syndrome: [H] in LDS (mid-size matrices) or in a global scratch slot (beyond LDS) ------
-// Same results as osd0_kernel / osdw_kernel.  The working copy of H lives in LDS or in HBM / L2, word-plane major -- plane w holds
-// word w of every row, so the test "which rows have a one in column c" is a coalesced read of one plane, and the XOR of
-// the pivot row into the rows that do walks the planes with neighbouring rows sharing cache lines.  LDS holds what is
-// touched all the time: the column order, the syndrome column, the pivot columns and the hit list.
-// The columns are sorted by a bitonic network over column numbers (comparing (key, number), hence stable).
-// HIGHER (OSD_E / OSD_CS): no early stop; afterwards the reduced rows are compressed to the non-pivot columns (T, again
-// plane-major, behind the matrix in the slot) and the candidates are weighed as in osdw_reg_kernel: thread = candidate,
-// 256 at a time, each wavefront with the T plane of its 64 one-column candidates staged in LDS.
+// Same results as osd0_kernel / osdw_kernel.  The columns are sorted first (a bitonic network over column numbers comparing
+// (key, number), hence stable), and the working copy of H is then built WITH ITS COLUMNS IN THAT ORDER, word-plane major, in LDS
+// or in an HBM / MALL slot: plane w holds the sorted columns 64 w .. 64 w + 63 of every row, so "which rows have a one in the next
+// 64 columns" is one coalesced read of one plane, and the non-pivot columns come out in candidate order.  LDS holds what is
+// touched all the time: the column order, the syndrome column, the pivot columns and -- phase by phase in the same room -- the
+// sort keys, the elimination's look-ahead words and combination table, the candidates' column info and staged planes.
+// The elimination is blocked (osd_block_eliminate): 64 columns at a time on the look-ahead words alone, then one combined
+// update of the rows that took a pivot.  Matrices with more than 1024 rows keep the one-pivot-per-step loop.
+// HIGHER (OSD_E / OSD_CS): no early stop; afterwards the reduced rows are squeezed to the non-pivot columns (T, again
+// plane-major, behind the matrix in the slot: one pass, a parallel bit compress per plane) and the candidates are weighed as in
+// osdw_reg_kernel: lane = candidate, a task of 64 per wavefront, each wavefront with the T plane it needs staged in LDS.
 struct OsdBigArgs {
     OsdArgs o;
     uint64_t *scratch;      // [slots][hwords + kwords][m]
@@ -761,14 +764,14 @@ struct OsdBigArgs {
 // ---- blocked elimination: the 64 columns of a look-ahead block, rows in registers ----------------------------------------------
 // The one-pivot-per-step loop below pays, per pivot, two workgroup barriers around a read-modify-write of every hit row in
 // L2 / MALL (H in an HBM slot) -- ~800 dependent round trips for a 768 x 1600 matrix.  Blocked: the next 64 sorted columns
-// of every row are one word (`look`, gathered as before); the workgroup eliminates on those words alone, thread t holding rows
+// of every row are one word (`look`: a plane of the working copy); the workgroup eliminates on those words alone, thread t holding rows
 // t, t + 256, ... in registers, and records for every row r a mask M_r over the block's pivots meaning
 //     row_r (after the block) = row_r (at block start) ^ XOR_{j in M_r} pivot_row_j (at block start)
 // (taking pivot p's row: M_r ^= M_p ^ {p}).  Per column: every wavefront offers its first unpivoted row with the bit (a ballot
 // per register row) together with that row's two words through LDS, ONE barrier, everybody takes the lowest offer.  Then every
-// row takes ONE combined update over all planes (osd_big_kernel below) -- one load and one store per row per block instead
-// of one per pivot, all loads independent -- and its syndrome bit parity(M_r & S), S_j = syndrome bit of pivot row j at block
-// start.  Same pivots (first unpivoted row with the bit, columns in sorted order), same reduced matrix:
+// row with a non-empty mask takes ONE combined update over all planes (osd_big_kernel below) -- per block instead of per pivot,
+// from a table of the XOR combinations of every four pivot rows -- and its syndrome bit parity(M_r & S), S_j = syndrome bit
+// of pivot row j at block start.  Same pivots (first unpivoted row with the bit, columns in sorted order), same reduced matrix:
 // tools/proto_blocked_elimination.py checks the algebra against the one-pivot-at-a-time form, the golden fixtures the kernel.
 __device__ __forceinline__ unsigned osd_bit_at(uint64_t x, int j) {  // j uniform: one 32-bit shift instead of a 64-bit one
     const unsigned h = j < 32 ? (unsigned)x : (unsigned)(x >> 32);
@@ -940,18 +943,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (tid < 3) { sh_nhits[tid] = 0; sh_pivot[tid] = INT32_MAX; }
         __syncthreads();
 
-        // One column per step, two barriers when it yields a pivot, one when not.  The hit counter and the pivot slot
-        // exist three times over: step t uses copy t % 3 and, once past its first barrier, re-arms copy (t + 2) % 3,
-        // which nobody has touched since step t - 1 and nobody will before step t + 2.
-        // Which rows have a one in the column of a step is not read from the planes step by step (a dependent round
-        // trip to L2 / MALL each time when H lives in HBM): every 64 steps each thread gathers, for its rows, the bits of
-        // the NEXT 64 columns into one word per row (64 independent loads in flight), and from then on the owner of a
-        // row keeps that word current -- a row that takes the pivot row takes the pivot row's word as well.
         int rank = 0;
         if (A.pbuf_off >= 0) {
             // ---- blocked: 64 sorted columns per round (osd_block_eliminate above) ----
-            // tbl [16][8][16]: for the piece (8 planes) in hand, every XOR combination of each group of four pivot rows as they were at
-            // block start -- a row then takes ceil(pivots / 4) table entries whatever its mask, so the lanes of a wavefront do equal work
+            // tbl [16][OSD_PIECE][16]: for the planes of the round in hand, every XOR combination of each group of four pivot rows as
+            // they were at block start -- a row then takes ceil(pivots / 4) table entries per plane whatever its mask
             uint64_t *tbl = reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.pbuf_off);
             for (int t = 0; t < n && rank < A.max_rank; t += 64) {
                 const int ahead = n - t < 64 ? n - t : 64;
@@ -1081,6 +1077,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 OSD_WG_CLK(7);  // blocked: the combination tables + the combined update of every row
             }
         } else
+        // One column per step, two barriers when it yields a pivot, one when not.  The hit counter and the pivot slot
+        // exist three times over: step t uses copy t % 3 and, once past its first barrier, re-arms copy (t + 2) % 3,
+        // which nobody has touched since step t - 1 and nobody will before step t + 2.
+        // Which rows have a one in the column of a step is not read from the planes step by step (a dependent round
+        // trip to L2 / MALL each time when H lives in HBM): every 64 steps the plane of the NEXT 64 columns is read into one
+        // word per row, and from then on the owner of a row keeps that word current -- a row that takes the pivot row
+        // takes the pivot row's word as well.
         for (int t = 0; t < n && rank < A.max_rank; ++t) {
             const int c = ord[t], cur = t % 3, kk = t & 63;
             if (kk == 0) {
@@ -1242,7 +1245,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         __syncthreads();
         // x_i of a candidate: pivot column with row r: S_r ^ parity(T_r & candidate); q-th non-pivot column: the candidate's bit q.
         // Weights are added in column order (osd.hpp:171-176); `acc += bit ? w : 0.0` adds the same numbers.
-        OSD_WG_CLK(4);  // gather
+        OSD_WG_CLK(4);  // T planes
         // the weights are the same for every lane, wavefront and workgroup and nobody writes them: through the constant address
         // space they come by scalar loads (a vector load would move 64 copies of each through L1)
         const __attribute__((address_space(4))) double *wt = (const __attribute__((address_space(4))) double *)a.wt;

@@ -455,6 +455,27 @@ def test_bposdw_golden_fixture(name):
     assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["decoding"])
 
 
+@pytest.mark.parametrize("name", ["osdw_cs10_hgp1600_ms12", "osdw_e6_hgp1600_ms12", "osdw_cs8_random400x900_ps6", "osdw_cs10_bb144_ps8",
+                                  "osdw_cs64_bb144_ms8", "osdw_e13_hamming4_ps2"])
+@pytest.mark.parametrize("unblocked", [False, True])
+def test_workgroup_osd_kernel_variants(name, unblocked, monkeypatch):
+    """osd_big_kernel in each of its forms -- working copy in an HBM slot (osd_kernel 2) or in LDS, blocked elimination or the
+    one-pivot-per-step loop matrices with more than 1024 rows take (LDPC_HIP_OSD_UNBLOCKED) -- against the reference's fixtures,
+    OSD-0 and the higher order.  (The default dispatch gives small matrices to the one-wavefront kernels.)"""
+    c = load_case(name)
+    eng = _engine(c)
+    if unblocked:
+        monkeypatch.setenv("LDPC_HIP_OSD_UNBLOCKED", "1")  # read by every decode call
+    for kernel in (2, -1):  # 2: workgroup kernel, H in HBM whatever the size; -1: the default dispatch (400 x 900: workgroup kernel, copy in LDS)
+        eng.set_osd_kernel(kernel)
+        eng.set_osd(c["osd_method"], c["osd_order"])
+        dec, _, it, cv = eng.decode_batch(c["syndromes"], want_llr=False, osd=True)
+        assert np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+        assert np.array_equal(dec, c["decoding"]), (kernel, unblocked)
+        eng.set_osd(1, 0)
+        assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"]), (kernel, unblocked)
+
+
 def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
     """Config-5 code, OSD_CS order 10 (the setting most BP+OSD papers use), B = 4096 device resident vs the CPU oracle."""
     from ldpc_amd.engine import HipBpEngine
