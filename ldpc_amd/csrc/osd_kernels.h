@@ -907,20 +907,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int j = tid; j < n; j += T) keys[j] = osd_sort_key(a.llr[b * n + j]);
         for (int j = tid; j < P; j += T) ord[j] = (uint16_t)j;
         __syncthreads();
-        // soft_decision_col_sort (sort.hpp:48-62): ascending key, ties by column number; numbers >= n pad the network
-        for (int k = 2; k <= P; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += T) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const int x = ord[i], y = ord[l];
-                        const uint64_t kx = x < n ? keys[x] : ~0ull, ky = y < n ? keys[y] : ~0ull;
-                        const bool y_first = ky < kx || (ky == kx && y < x);
-                        if (y_first == ((i & k) == 0)) { ord[i] = (uint16_t)y; ord[l] = (uint16_t)x; }
+        // soft_decision_col_sort (sort.hpp:48-62): ascending key, ties by column number; numbers >= n pad the network.
+        // A pass compares P / 2 disjoint pairs: pair p = the two positions whose numbers are p with a zero / one inserted at bit
+        // log2(j).  A wavefront owns P / 8 consecutive pairs -- for j < P / 4 those are the positions of its own quarter of the
+        // array, so such passes (all but six of a 2048-position sort's 66) need no workgroup barrier, only the in-order LDS queue of the
+        // wavefront; and a thread's pairs are fetched four at a time (order entries, then the keys they point at) instead of one
+        // dependent chain after the other.
+        {
+            const bool chunked = P >= 512;
+            const int per_lane = chunked ? P >> 9 : (P / 2 + T - 1) / T;  // pairs per thread
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int e0 = 0; e0 < per_lane; e0 += 4) {
+                        int pi[4], pl[4], x[4], y[4];
+                        uint64_t kx[4], ky[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = e0 + u;
+                            const int pr = chunked ? wave * (P >> 3) + lane + 64 * e : tid + T * e;
+                            const bool on = e < per_lane && pr < (P >> 1);
+                            pi[u] = on ? ((pr & ~(j - 1)) << 1) | (pr & (j - 1)) : -1;
+                            pl[u] = pi[u] | j;
+                            x[u] = on ? ord[pi[u]] : 0;
+                            y[u] = on ? ord[pl[u]] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            kx[u] = x[u] < n ? keys[x[u]] : ~0ull;
+                            ky[u] = y[u] < n ? keys[y[u]] : ~0ull;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool y_first = ky[u] < kx[u] || (ky[u] == kx[u] && y[u] < x[u]);
+                            if (pi[u] >= 0 && y_first == ((pi[u] & k) == 0)) { ord[pi[u]] = (uint16_t)y[u]; ord[pl[u]] = (uint16_t)x[u]; }
+                        }
+                    }
+                    const int jn = j > 1 ? j >> 1 : k;  // the next pass's distance (k: the next stage starts there)
+                    if (!chunked || j >= (P >> 2) || jn >= (P >> 2) || (k == P && j == 1)) {
+                        __syncthreads();
+                    } else {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of a wavefront execute in order; this only pins the compiler
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
                 }
-                __syncthreads();
-            }
+        }
         // Working copy of H with its COLUMNS IN SORTED ORDER, word-plane major: bit (t & 63) of mat[(t >> 6) * m + i] = H[i][ord[t]].
         // The 64 columns of an elimination block are then one plane (one coalesced read per row instead of 64 scattered ones: the
         // copies of a batch's rows live in HBM / MALL, and bytes moved are what this kernel is bound by), and the non-pivot
