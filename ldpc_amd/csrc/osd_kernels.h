@@ -779,43 +779,43 @@ __device__ __forceinline__ unsigned osd_bit_at(uint64_t x, int j) {  // j unifor
 }
 
 template <int MQ>
-__device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, const uint16_t *ord_t, uint64_t *look, const int16_t *pivcol,
+__device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, uint64_t *look, const int16_t *pivcol,
                                                 uint16_t *blk_row, uint16_t *blk_col, unsigned long long *xch, int rank, int max_rank) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t L[MQ], M[MQ];
-    unsigned unp = 0;  // bit q: row q * 256 + tid exists and carries no pivot yet
+    uint64_t unpm[MQ];  // per register row: the lanes whose row exists and carries no pivot yet (the same for the whole wavefront: scalar registers)
+    uint64_t any = 0;
 #pragma unroll
     for (int q = 0; q < MQ; ++q) {
         const int r = q * 256 + tid;
         L[q] = r < m ? look[r] : 0ull;
         M[q] = 0ull;
-        if (r < m && pivcol[r] < 0) unp |= 1u << q;
+        const bool unpivoted = r < m && pivcol[r] < 0;
+        unpm[q] = __builtin_amdgcn_ballot_w64(unpivoted);
+        any |= unpivoted ? L[q] : 0ull;
     }
     // Columns no unpivoted row has a bit in NOW never become pivot columns in this block (a row only changes by taking rows that
-    // were unpivoted at block start, and those all have a zero there): they cost no step.  For the sparse matrices OSD meets that is
-    // most of the non-pivot columns -- the ones that depend on pivots of earlier blocks only.
-    uint64_t any = 0;
-#pragma unroll
-    for (int q = 0; q < MQ; ++q) any |= ((unp >> q) & 1u) ? L[q] : 0ull;
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)any, off), hi = (unsigned)__shfl_xor((int)(unsigned)(any >> 32), off);
-        any |= ((uint64_t)hi << 32) | lo;
-    }
+    // were unpivoted at block start, and those all have a zero there): they cost no step.  (Keeping that OR current step by step
+    // would catch the other non-pivot columns as well, but costs more than the steps it saves: measured.)
+    any = (uint64_t)__reduce_or_sync(~0ull, (unsigned)any) | ((uint64_t)__reduce_or_sync(~0ull, (unsigned)(any >> 32)) << 32);
     if (lane == 0 && any) atomicOr(xch + 20, (unsigned long long)any);  // (zeroed by the caller before its last barrier)
     __syncthreads();
     const uint64_t live = __builtin_amdgcn_readfirstlane((unsigned)xch[20]) | ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xch[20] >> 32)) << 32);
     int np = 0, step = 0;
+    // A step is one dependent chain (~8 cycles an instruction, contention or not): every instruction off it counts.  The test
+    // "row has the bit" is made once per register row; who offers is then scalar arithmetic on its ballot.
     for (int j = 0; j < ahead && rank < max_rank; ++j) {
         if (!((live >> j) & 1ull)) continue;
-        // this wavefront's offer: its first unpivoted row with the bit -- rows ascend in (q, lane) within a wavefront
+        const uint64_t jb = 1ull << j;
+        bool h[MQ];
         int qs = -1;
         uint64_t cm = 0;
 #pragma unroll
-        for (int q = 0; q < MQ; ++q)
-            if (qs < 0) {
-                cm = __builtin_amdgcn_ballot_w64(((unp >> q) & 1u) && osd_bit_at(L[q], j));
-                if (cm) qs = q;
-            }
+        for (int q = 0; q < MQ; ++q) {
+            h[q] = (L[q] & jb) != 0;
+            const uint64_t c = __builtin_amdgcn_ballot_w64(h[q]) & unpm[q];
+            if (qs < 0 && c) { qs = q; cm = c; }  // this wavefront's offer: its first unpivoted row with the bit (rows ascend in (q, lane))
+        }
         // offers, two sets (the next step writes the other one): words 0-1 = the four wavefronts' rows (u32 each, ~0: none),
         // words 2 + 2 w, 3 + 2 w = wavefront w's row in the block's columns and its mask
         unsigned long long *set = xch + (step & 1) * 10;
@@ -823,13 +823,10 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
         if (qs < 0) {
             if (lane == 0) reinterpret_cast<unsigned *>(set)[wave] = ~0u;
         } else if (lane == __builtin_ctzll(cm)) {
-            uint64_t lq = L[0], mq = M[0];
-#pragma unroll
-            for (int q = 1; q < MQ; ++q)
-                if (q == qs) { lq = L[q]; mq = M[q]; }
             reinterpret_cast<unsigned *>(set)[wave] = (unsigned)(qs * 256 + tid);
-            set[2 + 2 * wave] = lq;
-            set[3 + 2 * wave] = mq;
+#pragma unroll
+            for (int q = 0; q < MQ; ++q)
+                if (q == qs) { set[2 + 2 * wave] = L[q]; set[3 + 2 * wave] = M[q]; }  // (qs is scalar: one of these runs)
         }
         __syncthreads();
         const uint4 rows = *reinterpret_cast<const uint4 *>(set);
@@ -844,13 +841,16 @@ __device__ __forceinline__ int osd_block_eliminate(int tid, int m, int ahead, co
         const uint64_t mp = pw == 0 ? m0 : pw == 1 ? m1 : pw == 2 ? m2 : m3;
         const uint64_t take = mp ^ (1ull << np);
         const int pq = p >> 8, pt = p & 255;
+        const bool mine = tid == pt;
 #pragma unroll
-        for (int q = 0; q < MQ; ++q) {
-            const bool hit = osd_bit_at(L[q], j) && !(q == pq && tid == pt);
-            if (hit) { L[q] ^= lp; M[q] ^= take; }
+        for (int q = 0; q < MQ; ++q)
+            if (h[q] && !(q == pq && mine)) { L[q] ^= lp; M[q] ^= take; }
+        if (wave == pw) {
+#pragma unroll
+            for (int q = 0; q < MQ; ++q)
+                if (q == pq) unpm[q] &= ~(1ull << (pt & 63));
         }
-        if (tid == pt) unp &= ~(1u << pq);
-        if (tid == 0) { blk_row[np] = (uint16_t)p; blk_col[np] = ord_t[j]; }
+        if (tid == 0) { blk_row[np] = (uint16_t)p; blk_col[np] = (uint16_t)j; }  // (the column number is looked up afterwards: no LDS read on this path)
         ++np;
         ++rank;
     }
@@ -997,10 +997,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 }
                 OSD_WG_CLK(0);  // blocked: the block's plane
                 int npv;  // (pivots | steps << 8)
-                if (m <= 256) npv = osd_block_eliminate<1>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
-                else if (m <= 512) npv = osd_block_eliminate<2>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
-                else if (m <= 768) npv = osd_block_eliminate<3>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
-                else npv = osd_block_eliminate<4>(tid, m, ahead, ord + t, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                if (m <= 256) npv = osd_block_eliminate<1>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 512) npv = osd_block_eliminate<2>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 768) npv = osd_block_eliminate<3>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else npv = osd_block_eliminate<4>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 __syncthreads();
                 OSD_WG_CLK(6);  // blocked: the block's pivots
                 const int nsteps = npv >> 8;
@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     OSD_LDS_BARRIER();
                     OSD_WG_CLK(12);  // update: closing barrier
                 }
-                if (tid < npv) pivcol[blk_row[tid]] = (int16_t)blk_col[tid];
+                if (tid < npv) pivcol[blk_row[tid]] = (int16_t)ord[t + blk_col[tid]];
                 __syncthreads();
                 OSD_WG_CLK(7);  // blocked: the combination tables + the combined update of every row
             }
