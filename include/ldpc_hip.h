@@ -94,7 +94,10 @@ int ldpc_hip_bp_set_params(ldpc_hip_bp *h, int32_t max_iter, int32_t bp_method,
 int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *serial_schedule_order);
 /* replaces: the random_serial_schedule / random_schedule_seed setters (_bp_decoder.pyx:527-579 -> bp.hpp:142-145): with
  * `enable` the serial sweep shuffles the order before every iteration; `seed` re-seeds the generator (0 = from the clock, as
- * rng.hpp:117-123 does).  Takes precedence over SERIAL_RELATIVE, as in bp.hpp:467-469. */
+ * rng.hpp:117-123 does).  Takes precedence over SERIAL_RELATIVE, as in bp.hpp:467-469.
+ * ldpc_hip_bp_soft_info_decode_batch honours the flag the way soft_info_decode_serial does (bp.hpp:573-577): at the top of every
+ * iteration that still runs the order is rearranged by std::shuffle with a NEW std::default_random_engine((int32_t)seed) -- the
+ * seed as given, 0 included --; rows and state as described above. */
 int ldpc_hip_bp_set_random_serial(ldpc_hip_bp *h, int32_t enable, uint32_t seed);
 /* the handle's current serial_schedule_order (n entries): what bpd.serial_schedule_order holds after a decode */
 int ldpc_hip_bp_get_schedule_order(ldpc_hip_bp *h, int32_t *order);

@@ -649,10 +649,12 @@ class SoftInfoBpDecoder(BpDecoderBase):
         self.soft_syndrome_batch = None
 
     def _soft_decode(self, soft2d):
-        if self._random_serial_schedule:
-            raise NotImplementedError("random_serial_schedule reshuffles a persistent order every iteration (bp.hpp:573-577) and is "
-                                      "not available on the MI355X path; there is no CPU fallback.")
-        return self._get_engine().soft_info_decode_batch(soft2d, self.cutoff, self.sigma)
+        """With random_serial_schedule the routine rearranges the order the object carries at the top of every iteration it runs
+        (bp.hpp:573-577: ``shuffle(order, std::default_random_engine(random_schedule_seed))``, a new engine each time); the engine
+        does the same draws, every row of a batch from the order at the time of the call, and leaves its last row's order."""
+        out = self._get_engine().soft_info_decode_batch(soft2d, self.cutoff, self.sigma)
+        self._pull_schedule_state()
+        return out
 
     def decode(self, soft_info_syndrome: np.ndarray) -> np.ndarray:
         """One analog syndrome (pyx:761-785); returns the decoding as uint8."""

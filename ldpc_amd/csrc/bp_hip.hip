@@ -126,6 +126,7 @@ struct ldpc_hip_bp {
     // arrangement serial_relative re-sorts and the random schedule re-shuffles every iteration -- and the generator of the shuffles.
     std::vector<int32_t> sched_state;
     std::mt19937 sched_rng;
+    int32_t sched_seed_raw = 0;  // random_schedule_seed as given (the soft-syndrome routine seeds its own engine with it)
     bool random_serial = false;
     DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
     int32_t *d_csc_row = nullptr, *d_order = nullptr;
@@ -434,6 +435,7 @@ int ldpc_hip_bp_set_schedule(ldpc_hip_bp *h, int32_t schedule, const int32_t *se
 int ldpc_hip_bp_set_random_serial(ldpc_hip_bp *h, int32_t enable, uint32_t seed) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
     h->random_serial = enable != 0;
+    h->sched_seed_raw = (int32_t)seed;  // soft_info_decode_serial seeds a std::default_random_engine with the member as it is (bp.hpp:576)
     if (seed == 0)  // rng.hpp:117-123: seed 0 = take the system clock
         seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
     h->sched_rng.seed(seed);  // BpDecoder::set_random_schedule_seed (bp.hpp:142-145)
@@ -929,6 +931,27 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
             if (level_waves < 1) level_waves = 1;
         }
     }
+    // random_serial_schedule in this routine (bp.hpp:573-577): at the top of every iteration that still runs the order the
+    // object carries is rearranged by std::shuffle with a NEW std::default_random_engine(random_schedule_seed) -- one fixed
+    // rearrangement applied again and again.  Every row of the batch starts from the handle's order; the call leaves the order
+    // of its last row (its iteration count many rearrangements on).
+    const bool shuffled = h->random_serial && h->n > 0;
+    std::vector<int32_t> orders;
+    int32_t *d_iters_last = nullptr;
+    if (shuffled) {
+        level_waves = 0;  // the levels belong to one fixed order
+        orders.resize((size_t)h->max_iter * (size_t)h->n);
+        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+        for (int it = 0; it < h->max_iter; ++it) {
+            std::shuffle(v.begin(), v.end(), std::default_random_engine(h->sched_seed_raw));
+            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)h->n);
+        }
+        if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;
+        if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+        d_iters_last = iters + (batch - 1);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     void (*soft_kern)(const SoftArgs);
     if (h->max_row_deg <= 4 && h->max_col_deg <= 2) soft_kern = level_waves ? bp_softinfo_level_kernel<2, 4> : bp_softinfo_kernel<2, 4>;
     else if (h->max_row_deg <= 6 && h->max_col_deg <= 3) soft_kern = level_waves ? bp_softinfo_level_kernel<3, 6> : bp_softinfo_kernel<3, 6>;
@@ -958,6 +981,7 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
         a.batch = nb;
         a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
         a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
+        if (shuffled && h->max_iter > 0) { a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; }
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.S = (double *)h->soft_S.p;
         a.syn = (const uint64_t *)h->par.p;
@@ -993,6 +1017,13 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
                                soft_out + (size_t)b0 * h->m);
         }
         HIPCHK(hipGetLastError());
+    }
+    if (shuffled && batch > 0) {  // the order the last row leaves behind
+        int32_t last = 0;
+        HIPCHK(hipMemcpyAsync(&last, d_iters_last, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (last > h->max_iter) last = h->max_iter;
+        if (last > 0) std::copy(orders.begin() + (size_t)(last - 1) * (size_t)h->n, orders.begin() + (size_t)last * (size_t)h->n, h->sched_state.begin());
     }
     return LDPC_HIP_OK;
 }

@@ -286,6 +286,8 @@ struct SoftArgs {
     double ms_scaling_factor, cutoff;
     int64_t batch;
     const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
+    const int32_t *orders;  // random serial schedule (bp.hpp:573-577): [n_orders][n], iteration it walks orders[min(it, n_orders) - 1]; else nullptr
+    int32_t n_orders;
     const double *llr0;
     double *A;        // [tiles][nnz][64] bit->check messages
     double *C;        // [tiles][nnz][64] check->bit messages of the bit being updated
@@ -486,8 +488,9 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
 
     for (int it = 1; it <= a.max_iter; ++it) {
         const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
+        const int32_t *order = a.orders ? a.orders + (size_t)((it < a.n_orders ? it : a.n_orders) - 1) * (size_t)n : a.order;
         for (int t = 0; t < n; ++t) {
-            const int bit = a.order ? sload(a.order + t) : t;
+            const int bit = order ? sload(order + t) : t;
             if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, bit, At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
             else soft_update_bit(a, bit, At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
         }

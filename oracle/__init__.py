@@ -185,6 +185,25 @@ class BpOracle:
                                                       np.ascontiguousarray(orders.reshape(-1)), self.max_iter, s, b, dec, llr, it, conv)
         return dec, llr, it, conv.astype(bool)
 
+    def soft_info_decode_random_batch(self, soft_syndromes, cutoff, sigma, seed, order=None):
+        """soft_info_decode_serial with random_serial_schedule (bp.hpp:573-577), every row from the same starting ``order``
+        (default 0..n-1: a new decoder object per row): iteration t walks the order after t reseeded shuffles."""
+        s = np.ascontiguousarray(soft_syndromes, np.float64)
+        b = s.shape[0]
+        orders = shuffle_orders_reseeded(seed, self.n, self.max_iter, order)[0]
+        dec = np.zeros((b, self.n), np.uint8)
+        llr = np.zeros((b, self.n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        soft = np.zeros((b, self.m), np.float64)
+        self.lib.bp_oracle_soft_info_decode_orders_batch.argtypes = [C.c_void_p, _f64p, C.c_int, C.c_double, _i32p, C.c_int, _f64p,
+                                                                     C.c_int64, C.c_double, C.c_double, _u8p, C.c_void_p, _i32p,
+                                                                     _u8p, C.c_void_p]
+        self.lib.bp_oracle_soft_info_decode_orders_batch(self._h, self.channel_probs, self.max_iter, self.alpha,
+                                                         np.ascontiguousarray(orders.reshape(-1)), self.max_iter, s, b,
+                                                         float(cutoff), float(sigma), dec, llr.ctypes.data, it, conv, soft.ctypes.data)
+        return dec, llr, it, conv.astype(bool), soft
+
     def osd0(self, syndrome, llr):
         """OSD-0 alone (osd.hpp:110-117 restated) on one syndrome and one vector of log-ratios."""
         out = np.zeros(self.n, np.uint8)
@@ -266,6 +285,47 @@ def shuffle_orders(seed, n, count, order=None, state=b""):
     buf = C.create_string_buffer(bytes(state), 16384)
     lib.oracle_shuffle_orders(int(seed), int(n), cur, int(count), out.reshape(-1), buf)
     return out[:count], cur, buf.value
+
+
+def shuffle_orders_reseeded(seed, n, count, order=None):
+    """The soft-syndrome routine's random schedule (bp.hpp:573-577): ``count`` successive
+    ``std::shuffle(order, std::default_random_engine(seed))`` -- a new engine from the same seed each time -> (orders [count][n],
+    final order).  Through oracle/liboracle_shuffle.so."""
+    so = os.path.join(_HERE, "liboracle_shuffle.so")
+    if not os.path.exists(so):
+        build(ref=False)
+    lib = C.CDLL(so)
+    lib.oracle_shuffle_orders_reseeded.argtypes = [C.c_int32, C.c_int32, _i32p, C.c_int32, _i32p]
+    cur = np.arange(n, dtype=np.int32) if order is None else np.ascontiguousarray(order, np.int32).copy()
+    out = np.zeros((max(count, 1), n), np.int32)
+    lib.oracle_shuffle_orders_reseeded(int(seed), int(n), cur, int(count), out.reshape(-1))
+    return out[:count], cur
+
+
+def ref_soft_random(h, soft_syndromes, cutoff, sigma, *, error_rate=None, error_channel=None, max_iter=0, ms_scaling_factor=1.0,
+                    seed=0, fresh=True):
+    """The REAL soft_info_decode_serial with random_serial_schedule: a new decoder object per row (``fresh``) or one for all
+    rows.  Returns (decoding, llr, iterations, converge, soft syndrome, final order per row)."""
+    if not have_ref():
+        raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
+    lib = C.CDLL(REF_SO)
+    fn = lib.ref_bp_soft_random_batch
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_double, C.c_int, C.c_int, _f64p, C.c_int64,
+                   C.c_double, C.c_double, _u8p, _f64p, _i32p, _u8p, _f64p, _i32p]
+    m, n, row_ptr, col_idx = csr_arrays(h)
+    rows = np.ascontiguousarray(np.repeat(np.arange(m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32))
+    probs = _probs(n, error_rate, error_channel)
+    s = np.ascontiguousarray(soft_syndromes, np.float64)
+    b = s.shape[0]
+    dec = np.zeros((b, n), np.uint8)
+    llr = np.zeros((b, n), np.float64)
+    it = np.zeros(b, np.int32)
+    conv = np.zeros(b, np.uint8)
+    soft = np.zeros((b, m), np.float64)
+    final = np.zeros((b, n), np.int32)
+    fn(m, n, len(col_idx), rows, col_idx, probs, int(max_iter) if max_iter else n, float(ms_scaling_factor), int(seed),
+       1 if fresh else 0, s, b, float(cutoff), float(sigma), dec, llr, it, conv, soft, final.reshape(-1))
+    return dec, llr, it, conv.astype(bool), soft, final
 
 
 def ref_decode_stateful(h, syndromes, *, schedule, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum",

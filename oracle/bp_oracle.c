@@ -697,10 +697,25 @@ static void decode_serial_dyn(bp_oracle *o, const double *channel_probs, int max
  * ms_scaling_factor is used as it is (no adaptive 1 - 2^-it here); the convergence test compares H x with
  * the CURRENT (possibly flipped) hard syndrome (:645-653).  `order` may be NULL (0 .. n-1).
  * ============================================================================================== */
+static void soft_info_decode_orders(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
+                                    const int32_t *order, const int32_t *orders, int n_orders, const double *soft_info_syndrome,
+                                    double cutoff, double sigma, uint8_t *decoding, double *log_prob_ratios, int32_t *iterations,
+                                    uint8_t *converge, double *soft_syndrome);
+
 void bp_oracle_soft_info_decode(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
                                 const int32_t *order, const double *soft_info_syndrome, double cutoff, double sigma,
                                 uint8_t *decoding, double *log_prob_ratios, int32_t *iterations, uint8_t *converge,
                                 double *soft_syndrome) {
+    soft_info_decode_orders(o, channel_probs, max_iter, ms_scaling_factor, order, NULL, 0, soft_info_syndrome, cutoff, sigma,
+                            decoding, log_prob_ratios, iterations, converge, soft_syndrome);
+}
+
+/* `orders` [n_orders][n], if given: the arrangement walked in iteration it is orders[min(it, n_orders) - 1] -- the random serial
+ * schedule of this routine (bp.hpp:573-577: the order is reshuffled at the top of every iteration that still runs) */
+static void soft_info_decode_orders(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
+                                    const int32_t *order, const int32_t *orders, int n_orders, const double *soft_info_syndrome,
+                                    double cutoff, double sigma, uint8_t *decoding, double *log_prob_ratios, int32_t *iterations,
+                                    uint8_t *converge, double *soft_syndrome) {
     const int m = o->m, n = o->n;
     uint8_t *syndrome = (uint8_t *)malloc((size_t)(m ? m : 1));
     for (int i = 0; i < m; i++) {
@@ -715,6 +730,7 @@ void bp_oracle_soft_info_decode(bp_oracle *o, const double *channel_probs, int m
     int converged = 0;
     for (int it = 1; it <= max_iter; it++) {
         if (converged) continue;
+        if (orders) order = orders + (size_t)((it < n_orders ? it : n_orders) - 1) * (size_t)n;
         for (int t = 0; t < n; t++) {
             const int bit = order ? order[t] : t;
             log_prob_ratios[bit] = log((1 - channel_probs[bit]) / channel_probs[bit]);
@@ -779,6 +795,21 @@ void bp_oracle_soft_info_decode_batch(bp_oracle *o, const double *channel_probs,
         bp_oracle_soft_info_decode(o, channel_probs, max_iter, ms_scaling_factor, order, soft_syndromes + b * o->m, cutoff, sigma,
                                    decodings + b * o->n, llr ? llr + b * o->n : tmp, iterations + b, converge + b,
                                    soft_syndromes_out ? soft_syndromes_out + b * o->m : tmp + o->n);
+    }
+    free(tmp);
+}
+
+/* every row walks the same per-iteration orders (a new decoder object per row) */
+void bp_oracle_soft_info_decode_orders_batch(bp_oracle *o, const double *channel_probs, int max_iter, double ms_scaling_factor,
+                                             const int32_t *orders, int n_orders, const double *soft_syndromes, int64_t shots,
+                                             double cutoff, double sigma, uint8_t *decodings, double *llr, int32_t *iterations,
+                                             uint8_t *converge, double *soft_syndromes_out) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)(o->n + o->m + 1));
+    for (int64_t b = 0; b < shots; b++) {
+        iterations[b] = 0;
+        soft_info_decode_orders(o, channel_probs, max_iter, ms_scaling_factor, NULL, orders, n_orders, soft_syndromes + b * o->m,
+                                cutoff, sigma, decodings + b * o->n, llr ? llr + b * o->n : tmp, iterations + b, converge + b,
+                                soft_syndromes_out ? soft_syndromes_out + b * o->m : tmp + o->n);
     }
     free(tmp);
 }

@@ -138,6 +138,34 @@ void ref_bp_decode_carried_batch(int m, int n, int nnz, const int32_t *rows, con
     }
 }
 
+/* soft_info_decode_serial with random_serial_schedule (bp.hpp:573-577): a new decoder object per row (`fresh`) or one object
+ * for all rows (the order carries over).  Schedule SERIAL, MINIMUM_SUM as SoftInfoBpDecoder sets them (pyx:751-752). */
+void ref_bp_soft_random_batch(int m, int n, int nnz, const int32_t *rows, const int32_t *cols, const double *channel_probs,
+                              int max_iter, double ms_scaling_factor, int random_seed, int fresh, const double *soft_syndromes,
+                              int64_t shots, double cutoff, double sigma, uint8_t *decodings, double *llr, int32_t *iterations,
+                              uint8_t *converge, double *soft_out, int32_t *final_order) {
+    BpSparse pcm(m, n, nnz);
+    for (int k = 0; k < nnz; k++) pcm.insert_entry(rows[k], cols[k]);
+    std::vector<double> probs(channel_probs, channel_probs + n);
+    BpDecoder *dec = nullptr;
+    for (int64_t b = 0; b < shots; b++) {
+        if (fresh || !dec) {
+            delete dec;
+            dec = new BpDecoder(pcm, probs, max_iter, ldpc::bp::MINIMUM_SUM, ldpc::bp::SERIAL, ms_scaling_factor, 1,
+                                ldpc::bp::NULL_INT_VECTOR, random_seed, true, ldpc::bp::SYNDROME);
+        }
+        std::vector<double> s(soft_syndromes + b * m, soft_syndromes + (b + 1) * m);
+        dec->soft_info_decode_serial(s, cutoff, sigma);
+        std::memcpy(decodings + b * n, dec->decoding.data(), (size_t)n);
+        if (llr) std::memcpy(llr + b * n, dec->log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        if (soft_out) std::memcpy(soft_out + b * m, dec->soft_syndrome.data(), sizeof(double) * (size_t)m);
+        iterations[b] = dec->iterations;
+        converge[b] = dec->converge ? 1 : 0;
+        if (final_order) for (int j = 0; j < n; j++) final_order[b * n + j] = dec->serial_schedule_order[(size_t)j];
+    }
+    delete dec;
+}
+
 /* GF2Sparse::mulvec (gf2sparse.hpp:177-214) */
 void ref_bp_mulvec(ref_bp *r, const uint8_t *in, uint8_t *out) {
     std::vector<uint8_t> v(in, in + r->pcm->n);

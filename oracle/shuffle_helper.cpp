@@ -30,4 +30,16 @@ void oracle_shuffle_orders(uint32_t seed, int32_t n, int32_t *order, int32_t cou
     if (state) { std::ostringstream os; os << g; const std::string s = os.str(); s.copy(state, s.size()); state[s.size()] = 0; }
 }
 
+/* soft_info_decode_serial's random schedule (bp.hpp:573-577) is a different draw: `shuffle(order, std::default_random_engine(
+ * random_schedule_seed))` -- a NEW engine from the same seed at the top of every iteration, i.e. one fixed rearrangement applied
+ * again and again to the order the object carries.  orders_out [count][n] as above; `order` is updated in place. */
+void oracle_shuffle_orders_reseeded(int32_t seed, int32_t n, int32_t *order, int32_t count, int32_t *orders_out) {
+    std::vector<int> v(order, order + n);
+    for (int c = 0; c < count; ++c) {
+        std::shuffle(v.begin(), v.end(), std::default_random_engine(seed));
+        if (orders_out) std::copy(v.begin(), v.end(), orders_out + (size_t)c * (size_t)n);
+    }
+    std::copy(v.begin(), v.end(), order);
+}
+
 }

@@ -51,6 +51,28 @@ def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial
     print(f"{name:34s} {m} x {n} rows={rows} converged={int(fc.sum())} rows where carried != fresh: {differ}  {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def run_soft(name, h, soft, p, *, max_iter, alpha, cutoff, sigma, seed):
+    """soft_info_decode_serial with random_serial_schedule (bp.hpp:573-577: the order is reshuffled by a NEW
+    std::default_random_engine(seed) at the top of every iteration that runs), fresh and carried as above."""
+    h = sp.csr_matrix(h, dtype=np.uint8)
+    m, n, rp, ci = csr_arrays(h)
+    soft = np.ascontiguousarray(soft, np.float64).reshape(-1, m)
+    kw = dict(error_rate=p, max_iter=max_iter, ms_scaling_factor=alpha, seed=seed)
+    fd, fl, fi, fc, fs, fo = oracle.ref_soft_random(h, soft, cutoff, sigma, fresh=True, **kw)
+    cd, cl, ci_, cc, cs, co = oracle.ref_soft_random(h, soft, cutoff, sigma, fresh=False, **kw)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, name=name, m=m, n=n, h_crc=np.uint32(h_crc(h)), row_ptr=rp, col_idx=ci, channel_probs=np.full(n, p),
+                        max_iter=np.int32(max_iter), ms_scaling_factor=np.float64(alpha), cutoff=np.float64(cutoff), sigma=np.float64(sigma),
+                        seed=np.int32(seed), soft_syndromes=soft,
+                        fresh_decoding=np.packbits(fd, axis=1), fresh_llr=fl, fresh_iterations=fi, fresh_converge=fc, fresh_soft_out=fs,
+                        fresh_order_last=fo[-1],
+                        carried_decoding=np.packbits(cd, axis=1), carried_llr=cl, carried_iterations=ci_, carried_converge=cc, carried_soft_out=cs,
+                        carried_orders=co.astype(np.int16 if n < 32768 else np.int32))
+    differ = int((fd != cd).any(axis=1).sum())
+    print(f"{name:34s} {m} x {n} rows={len(soft)} converged={int(fc.sum())} mean iterations {fi.mean():.2f} rows where carried != fresh: {differ}  "
+          f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def main():
     bb = codes.bivariate_bicycle_hx()
     run("stateful_rel_bb144_ps", bb, 0.06, schedule="serial_relative", max_iter=12, bp_method="product_sum", alpha=1.0, rows=96)
@@ -67,6 +89,14 @@ def main():
     # the random flag wins over serial_relative (bp.hpp:467-469)
     run("stateful_rnd_over_rel_ham4_s5", codes.hamming_code(4), 0.08, schedule="serial_relative", max_iter=9, bp_method="product_sum", alpha=1.0, rows=40,
         random_serial=True, seed=5)
+
+    # SoftInfoBpDecoder with random_serial_schedule
+    from make_golden_soft import noisy  # noqa: E402
+    run_soft("stateful_softrnd_bb144_s7", bb, noisy(bb, 21, 0.02, 64, 3.0), 0.02, max_iter=12, alpha=0.8, cutoff=4.0, sigma=1.5, seed=7)
+    hs = codes.rotated_surface_code_x(7)
+    run_soft("stateful_softrnd_surf7_s0", hs, noisy(hs, 23, 0.08, 48, 3.0), 0.08, max_iter=10, alpha=0.75, cutoff=2.0, sigma=1.0, seed=0)
+    hl = codes.regular_ldpc_code(120, 3, 6, seed=2)
+    run_soft("stateful_softrnd_ldpc120_sneg", hl, noisy(hl, 25, 0.03, 40, 4.0), 0.03, max_iter=15, alpha=0.75, cutoff=4.0, sigma=1.5, seed=-3)
 
 
 if __name__ == "__main__":

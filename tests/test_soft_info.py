@@ -121,6 +121,9 @@ def test_mirror_decode_and_batch_and_order(oracle_built):
     want = o.soft_info_decode_batch(c["soft"][:70], c["cutoff"], c["sigma"], order=order.astype(np.int32))
     got = d.decode_batch(c["soft"][:70])  # 70 rows: one full tile and a partial one
     assert np.array_equal(got, want[0]) and bits_equal(d.soft_syndrome_batch, want[4]) and np.array_equal(d.iter_batch, want[2])
+    # random_serial_schedule on top of it: the custom order is what the reshuffles start from (bp.hpp:573-577; seed 0 as constructed)
     d.random_serial_schedule = True
-    with pytest.raises(NotImplementedError):
-        d.decode(c["soft"][0])
+    want = o.soft_info_decode_random_batch(c["soft"][:5], c["cutoff"], c["sigma"], 0, order.astype(np.int32))
+    got = d.decode_batch(c["soft"][:5])
+    assert np.array_equal(got, want[0]) and bits_equal(d.soft_syndrome_batch, want[4]) and np.array_equal(d.iter_batch, want[2])
+    assert np.array_equal(d.serial_schedule_order, oracle_built.shuffle_orders_reseeded(0, c["n"], int(want[2][-1]), order.astype(np.int32))[1])

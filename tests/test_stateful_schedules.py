@@ -13,7 +13,8 @@ import scipy.sparse as sp
 
 from golden_util import GOLDEN_DIR, bits_equal
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stateful_*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stateful_*.npz")) if "_softrnd_" not in p)
+SOFT_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stateful_softrnd_*.npz")))
 
 
 def load(name):
@@ -117,3 +118,90 @@ def test_mirror_decode_sequence_and_batch(name):
     out = d2.decode_batch(c["synd"])
     assert np.array_equal(out[nz], c["fresh"][0][nz]) and np.array_equal(d2.iter_batch[nz], c["fresh"][2][nz])
     assert bits_equal(d2.log_prob_ratios_batch[nz], c["fresh"][1][nz])
+
+
+# ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of
+# every iteration that runs by std::shuffle with a NEW std::default_random_engine(random_schedule_seed) -----------------------------
+
+def load_soft(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    m, n = int(z["m"]), int(z["n"])
+    h = sp.csr_matrix((np.ones(len(z["col_idx"]), np.uint8), z["col_idx"], z["row_ptr"]), shape=(m, n))
+    c = dict(h=h, m=m, n=n, probs=z["channel_probs"], max_iter=int(z["max_iter"]), alpha=float(z["ms_scaling_factor"]), cutoff=float(z["cutoff"]),
+             sigma=float(z["sigma"]), seed=int(z["seed"]), soft=z["soft_syndromes"])
+    for kind in ("fresh", "carried"):
+        c[kind] = (np.unpackbits(z[kind + "_decoding"], axis=1, count=n), z[kind + "_llr"], z[kind + "_iterations"].astype(np.int32),
+                   z[kind + "_converge"].astype(bool), z[kind + "_soft_out"])
+    c["fresh_order_last"] = z["fresh_order_last"].astype(np.int32)
+    c["carried_orders"] = z["carried_orders"].astype(np.int32)
+    return c
+
+
+def same_soft(got, want):
+    return same(got, want) and bits_equal(got[4], want[4])
+
+
+def test_soft_cases_present():
+    assert len(SOFT_CASES) >= 3
+    its = np.concatenate([load_soft(n)["fresh"][2] for n in SOFT_CASES])
+    assert len(np.unique(its)) >= 5  # rows stop at different iterations: the order a row leaves differs from row to row
+
+
+@pytest.mark.parametrize("name", SOFT_CASES)
+def test_oracle_reproduces_the_reference_soft(name, oracle_built):
+    c = load_soft(name)
+    o = oracle_built.BpOracle(c["h"], error_channel=c["probs"], max_iter=c["max_iter"], bp_method="minimum_sum", ms_scaling_factor=c["alpha"])
+    assert same_soft(o.soft_info_decode_random_batch(c["soft"], c["cutoff"], c["sigma"], c["seed"]), c["fresh"])
+    orders, _ = oracle_built.shuffle_orders_reseeded(c["seed"], c["n"], c["max_iter"])
+    assert np.array_equal(orders[c["fresh"][2][-1] - 1], c["fresh_order_last"])
+    order = None  # one object: the order carries over
+    for b in range(len(c["soft"])):
+        g = o.soft_info_decode_random_batch(c["soft"][b:b + 1], c["cutoff"], c["sigma"], c["seed"], order)
+        assert same_soft(g, tuple(x[b:b + 1] for x in c["carried"])), f"row {b}"
+        order = oracle_built.shuffle_orders_reseeded(c["seed"], c["n"], int(g[2][0]), order)[1]
+        assert np.array_equal(order, c["carried_orders"][b])
+
+
+def _soft_engine(c):
+    from ldpc_amd.engine import HipBpEngine
+    eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["probs"], c["max_iter"], 1, c["alpha"])
+    eng.set_schedule("serial")
+    eng.set_random_serial(True, c["seed"] & 0xffffffff)
+    return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SOFT_CASES)
+def test_device_soft_batch_and_one_row_calls(name):
+    c = load_soft(name)
+    eng = _soft_engine(c)
+    assert same_soft(eng.soft_info_decode_batch(c["soft"], c["cutoff"], c["sigma"]), c["fresh"])
+    assert np.array_equal(eng.schedule_order(), c["fresh_order_last"])
+    import torch
+    eng2 = _soft_engine(c)
+    t = eng2.soft_info_decode_batch(torch.from_numpy(c["soft"]).cuda(), c["cutoff"], c["sigma"])
+    assert same_soft(tuple(x.cpu().numpy() for x in t), c["fresh"])
+    eng3 = _soft_engine(c)  # one object, one row after the other: the order carries over
+    for b in range(min(len(c["soft"]), 24)):
+        got = eng3.soft_info_decode_batch(c["soft"][b:b + 1], c["cutoff"], c["sigma"])
+        assert same_soft(got, tuple(x[b:b + 1] for x in c["carried"])), f"row {b}"
+        assert np.array_equal(eng3.schedule_order(), c["carried_orders"][b])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in SOFT_CASES if "_sneg" not in n])  # (the Python layer refuses seeds below -2, pyx:548)
+def test_soft_mirror_decode_sequence_and_batch(name):
+    from ldpc_amd.bp_decoder import SoftInfoBpDecoder
+    c = load_soft(name)
+    kw = dict(error_channel=list(c["probs"]), max_iter=c["max_iter"], ms_scaling_factor=c["alpha"], cutoff=c["cutoff"], sigma=c["sigma"],
+              random_schedule_seed=c["seed"], random_serial_schedule=True)
+    d = SoftInfoBpDecoder(c["h"], **kw)
+    for b in range(16):
+        out = d.decode(c["soft"][b])
+        assert np.array_equal(out, c["carried"][0][b]) and d.iter == c["carried"][2][b] and d.converge == c["carried"][3][b]
+        assert bits_equal(d.log_prob_ratios, c["carried"][1][b]) and bits_equal(d.soft_syndrome, c["carried"][4][b])
+        assert np.array_equal(d.serial_schedule_order, c["carried_orders"][b])
+    d2 = SoftInfoBpDecoder(c["h"], **kw)
+    out = d2.decode_batch(c["soft"])
+    assert np.array_equal(out, c["fresh"][0]) and np.array_equal(d2.iter_batch, c["fresh"][2])
+    assert bits_equal(d2.log_prob_ratios_batch, c["fresh"][1]) and bits_equal(d2.soft_syndrome_batch, c["fresh"][4])
