@@ -114,3 +114,23 @@ def test_config2_code_with_osd0(oracle_built):
     o = oracle_built.BpOracle(h, error_rate=0.09, max_iter=5, bp_method="product_sum")
     want = o.bposd_decode_batch(s[:2], 1, 0, want_llr=False)
     assert np.array_equal(dec[:2], want[0])
+
+
+def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built):
+    """OSD_CS / OSD_E on a 1200 x 2400 matrix: more rows than the blocked elimination keeps in registers, so the one-pivot-per-step
+    loop runs on the working copy with its columns in sorted order, and the T planes are squeezed out 1024 rows at a time."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(codes.regular_ldpc_code(2400, 3, 6, seed=4))
+    m, n = h.shape
+    assert m > 1024
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.08), 4, 1, 0.75)
+    s = eng.gen_bsc_syndromes(5, 0.08, shot0=0, shots=40, device="cuda:0").cpu().numpy()
+    o = oracle_built.BpOracle(h, error_rate=0.08, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.75)
+    for method, order in ((3, 7), (2, 5), (1, 0)):
+        eng.set_osd(method, order)
+        dec, _, it, cv = eng.decode_batch(s, want_llr=False, osd=True)
+        assert not cv.all()
+        assert not np.any((h @ dec.T % 2).T != s)
+        want = o.bposd_decode_batch(s[:6], method, order, want_llr=False)
+        assert np.array_equal(dec[:6], want[0]) and np.array_equal(cv[:6], want[3])
