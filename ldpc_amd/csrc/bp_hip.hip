@@ -1751,9 +1751,9 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
             return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD on the device: %d x %d is beyond the 16-bit row / column tables of the workgroup kernel", a.m, a.n);
         const size_t fixed = ((size_t)a.m * 5 + 1 + 7) & ~(size_t)7;  // bytes before `ord`
         const size_t phase = (fixed + (size_t)A.pow2 * 2 + 15) & ~(size_t)15;
-        // blocked elimination (osd_block_eliminate): four rows per thread in registers -> m <= 1024, and the combination table
+        // blocked elimination (osd_block_eliminate): up to eight rows per thread in registers -> m <= 2048, and the combination table
         // of the block's pivot rows in LDS; LDPC_HIP_OSD_UNBLOCKED=1 keeps the one-pivot-per-step loop (A/B measurements)
-        const bool blocked = a.m <= 1024 && !getenv("LDPC_HIP_OSD_UNBLOCKED");
+        const bool blocked = a.m <= OSD_BLOCK_ROWS && !getenv("LDPC_HIP_OSD_UNBLOCKED");
         const size_t pbuf_bytes = 16 * OSD_PIECE * 16 * 8;  // [group of four pivots][plane of the round][combination]
         size_t room = (size_t)a.n * 8;
         const size_t elim = (size_t)a.m * 8 + (blocked ? pbuf_bytes : 0);

@@ -7,6 +7,7 @@
 #define OSD_PIECE 9  // blocked elimination of osd_big_kernel: planes per table round
 // workgroup barrier that orders LDS traffic only: global loads and stores in flight stay in flight (__syncthreads() waits for them)
 #define OSD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define OSD_BLOCK_ROWS 2048  // blocked elimination: rows the workgroup keeps in registers (eight per thread)
 #define OSD_TRIP 16  // osd_big_kernel: columns per trip when a candidate is weighed
 
 #ifdef LDPC_HIP_OSD_CLOCKS  // profiling aid (tools/osd_phase_clocks.py): cycles per phase of osdw_reg_kernel, summed over wavefronts
@@ -744,7 +745,7 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
 // touched all the time: the column order, the syndrome column, the pivot columns and -- phase by phase in the same room -- the
 // sort keys, the elimination's look-ahead words and combination table, the candidates' column info and staged planes.
 // The elimination is blocked (osd_block_eliminate): 64 columns at a time on the look-ahead words alone, then one combined
-// update of the rows that took a pivot.  Matrices with more than 1024 rows keep the one-pivot-per-step loop.
+// update of the rows that took a pivot.  Matrices with more than OSD_BLOCK_ROWS rows keep the one-pivot-per-step loop.
 // HIGHER (OSD_E / OSD_CS): no early stop; afterwards the reduced rows are squeezed to the non-pivot columns (T, again
 // plane-major, behind the matrix in the slot: one pass, a parallel bit compress per plane) and the candidates are weighed as in
 // osdw_reg_kernel: lane = candidate, a task of 64 per wavefront, each wavefront with the T plane it needs staged in LDS.
@@ -758,7 +759,7 @@ struct OsdBigArgs {
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
     int32_t extra_off;      // byte offset in LDS of the room the phases share: keys [n] u64 | positions [n] u16 | look [m] u64 + table | {colinfo [n] i16, (8-aligned) plane masks and moves [7][hwords] u64, planes [4][m + 1] u64}
     int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
-    int32_t pbuf_off;       // blocked elimination (m <= 1024): byte offset in LDS of the combination table (extra_off + 8 m); -1: one pivot per step
+    int32_t pbuf_off;       // blocked elimination (m <= OSD_BLOCK_ROWS): byte offset in LDS of the combination table (extra_off + 8 m); -1: one pivot per step
 };
 
 // ---- blocked elimination: the 64 columns of a look-ahead block, rows in registers ----------------------------------------------
@@ -1000,7 +1001,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 if (m <= 256) npv = osd_block_eliminate<1>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 else if (m <= 512) npv = osd_block_eliminate<2>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 else if (m <= 768) npv = osd_block_eliminate<3>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
-                else npv = osd_block_eliminate<4>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 1024) npv = osd_block_eliminate<4>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else if (m <= 1536) npv = osd_block_eliminate<6>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
+                else npv = osd_block_eliminate<8>(tid, m, ahead, look, pivcol, blk_row, blk_col, blk_xch, rank, A.max_rank);
                 __syncthreads();
                 OSD_WG_CLK(6);  // blocked: the block's pivots
                 const int nsteps = npv >> 8;
@@ -1034,7 +1037,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 // The rows that take any of the block's pivots, listed: for sparse H they are a fraction of the rows, and a wavefront
                 // whose lanes each own fixed rows would run the whole update for the few lanes that have one.
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < OSD_BLOCK_ROWS / 256; ++k) {
                     const int r = k * 256 + tid;
                     if (k * 256 >= m) break;
                     const uint64_t Mr = r < m ? look[r] : 0ull;

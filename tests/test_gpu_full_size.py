@@ -116,13 +116,17 @@ def test_config2_code_with_osd0(oracle_built):
     assert np.array_equal(dec[:2], want[0])
 
 
-def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built):
-    """OSD_CS / OSD_E on a 1200 x 2400 matrix: more rows than the blocked elimination keeps in registers, so the one-pivot-per-step
-    loop runs on the working copy with its columns in sorted order, and the T planes are squeezed out 1024 rows at a time."""
+@pytest.mark.parametrize("n, unblocked", [(2400, False), (3600, False), (2400, True)])
+def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built, monkeypatch, n, unblocked):
+    """OSD_CS / OSD_E / OSD-0 on 1200 x 2400 and 1800 x 3600 matrices: six and eight rows per thread in the blocked elimination
+    (its limit is 2048 rows), and the one-pivot-per-step loop larger matrices take (forced here) -- both on the working copy with
+    its columns in sorted order, the T planes squeezed out 1024 rows at a time."""
     from ldpc_amd import codes
     from ldpc_amd.engine import HipBpEngine
-    h = sp.csr_matrix(codes.regular_ldpc_code(2400, 3, 6, seed=4))
-    m, n = h.shape
+    if unblocked:
+        monkeypatch.setenv("LDPC_HIP_OSD_UNBLOCKED", "1")
+    h = sp.csr_matrix(codes.regular_ldpc_code(n, 3, 6, seed=4))
+    m = h.shape[0]
     assert m > 1024
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.08), 4, 1, 0.75)
     s = eng.gen_bsc_syndromes(5, 0.08, shot0=0, shots=40, device="cuda:0").cpu().numpy()
@@ -132,5 +136,5 @@ def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built):
         dec, _, it, cv = eng.decode_batch(s, want_llr=False, osd=True)
         assert not cv.all()
         assert not np.any((h @ dec.T % 2).T != s)
-        want = o.bposd_decode_batch(s[:6], method, order, want_llr=False)
-        assert np.array_equal(dec[:6], want[0]) and np.array_equal(cv[:6], want[3])
+        want = o.bposd_decode_batch(s[:4], method, order, want_llr=False)
+        assert np.array_equal(dec[:4], want[0]) and np.array_equal(cv[:4], want[3])
