@@ -312,7 +312,10 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * and a workgroup that keeps up to four syndromes resident (any degrees).  mode -1 = automatic (default),
  * 0 = always use the streaming kernel, 1 = use an on-chip kernel whenever one syndrome fits in LDS,
  * 2 = as 1 but only the workgroup ("slot") variant, 3 = as 1 but only the lane = node wavefront variant (product-sum
- * otherwise prefers a lane = entry variant that keeps every lane busy with one transcendental).  Results are identical. */
+ * otherwise prefers a lane = entry variant that keeps every lane busy with one transcendental).  That variant gives a syndrome
+ * one wavefront, or -- where LDS leaves room for fewer than six syndromes per compute unit, e.g. a 768 x 1600 matrix -- all the
+ * wavefronts of a workgroup (its "team" form); 4 = as 3, one wavefront per syndrome, 5 = as 3, a workgroup per syndrome.
+ * Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 
 #define LDPC_HIP_MATH_LIBM_EXACT 0

@@ -464,8 +464,9 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
 
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 3)
-        return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits), 2 (slot kernel only) or 3 (lane = node wavefront kernel)");
+    if (mode < -1 || mode > 5)
+        return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits), 2 (slot kernel only), 3 (lane = node wavefront kernel), "
+                                          "4 (that kernel, one wavefront per syndrome) or 5 (that kernel, a workgroup per syndrome)");
     h->small_mode = mode;
     return LDPC_HIP_OK;
 }
@@ -1076,16 +1077,19 @@ struct WavePlan {
     int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, mp = 0, np = 0;
     size_t shared = 0, per_wave = 0;
     bool llr_direct = false;
-    void (*kern)(const WaveArgs) = nullptr;
+    bool team = false;  // the workgroup's wavefronts share ONE syndrome (bp_wave_kernel<..., TEAM>): `waves` = wavefronts of a team
+    void (*kern)(const WaveArgs) = nullptr, (*kern_team)(const WaveArgs) = nullptr;
 };
 
 template <int METHOD, int MATH>
 static void pick_wave(int max_row, int max_col, WavePlan &p) {
-    if (max_row <= 4 && max_col <= 2) { p.dr = 4; p.dc = 2; p.kern = bp_wave_kernel<METHOD, MATH, 4, 2>; return; }
-    if (max_row <= 4 && max_col <= 4) { p.dr = 4; p.dc = 4; p.kern = bp_wave_kernel<METHOD, MATH, 4, 4>; return; }
-    if (max_row <= 6 && max_col <= 3) { p.dr = 6; p.dc = 3; p.kern = bp_wave_kernel<METHOD, MATH, 6, 3>; return; }
-    if (max_col <= 4) { p.dr = 8; p.dc = 4; p.kern = bp_wave_kernel<METHOD, MATH, 8, 4>; return; }
-    p.dr = 8; p.dc = 8; p.kern = bp_wave_kernel<METHOD, MATH, 8, 8>;
+#define LDPC_PICK_WAVE(R, C) { p.dr = R; p.dc = C; p.kern = bp_wave_kernel<METHOD, MATH, R, C, false>; p.kern_team = bp_wave_kernel<METHOD, MATH, R, C, true>; return; }
+    if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE(4, 2)
+    if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE(4, 4)
+    if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE(6, 3)
+    if (max_col <= 4) LDPC_PICK_WAVE(8, 4)
+    LDPC_PICK_WAVE(8, 8)
+#undef LDPC_PICK_WAVE
 }
 
 static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
@@ -1120,6 +1124,23 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     // tile runs until its slowest of 64 has.  Measured on 432..864-row window matrices (tools/bench_window.py): min-sum
     // with 3 / 2 / 1 wavefronts per CU is 12x / 7x / 1.5x faster than streaming when most syndromes converge early and
     // 2.2x faster at 3 when most do not; product-sum 3x / 2.4x / 0.7x and about level.
+    // Where LDS leaves room for only a few syndromes per CU, one wavefront each leaves the CU idle: the wavefronts of a workgroup
+    // then share ONE syndrome (TEAM), as many as its bit pass has rounds of 64 U columns for (small_mode 5 forces, 4 forbids it).
+    const bool team = h->small_mode == 5 || (h->small_mode != 4 && w < 6);
+    if (team) {
+        const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
+        const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
+        int tw = (p.np + 64 * u - 1) / (64 * u);
+        if (tw < 2) tw = 2;
+        if (tw > 16) tw = 16;
+        p.team = true;
+        p.waves = tw;
+        p.kern = p.kern_team;
+        p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
+        if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;
+        if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+        return p;
+    }
     if (!forced && w < (h->bp_method == LDPC_HIP_MINIMUM_SUM ? 2 : 3)) return p;
     p.waves = (int)w;
     p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
@@ -1271,10 +1292,10 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     a.llr_direct = p.llr_direct ? 1 : 0;
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
-    const size_t dyn = p.shared + (size_t)p.waves * p.per_wave;
+    const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
     if (dyn > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    int64_t groups = (batch + p.waves - 1) / p.waves;
+    int64_t groups = p.team ? batch : (batch + p.waves - 1) / p.waves;
     const int64_t resident = 256 * (int64_t)p.groups_per_cu;
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
@@ -1305,12 +1326,12 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
-        if (h->small_mode != 2 && h->small_mode != 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
+        if (h->small_mode != 2 && h->small_mode < 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
             const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode == 3, llr != nullptr);
+            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr);
             if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
         }
         int slots = 0;

@@ -54,7 +54,11 @@ __host__ __device__ inline size_t wave_lds_private(int mp, int np, int DR, bool 
     return (b + 15) & ~(size_t)15;
 }
 
-template <int METHOD, int MATH, int DR, int DC>
+// TEAM: the whole workgroup decodes ONE syndrome at a time (its wavefronts share the rows of the check pass and the columns of
+// the bit pass; workgroup barriers between the passes, the syndrome test reduced through an LDS flag).  For the codes whose
+// message array leaves room for two or three wavefronts per compute unit (e.g. a 768 x 1600 hypergraph product: 49 KiB a
+// syndrome) a lone wavefront per syndrome leaves the CU almost idle; eight or sixteen on one syndrome cut its latency instead.
+template <int METHOD, int MATH, int DR, int DC, bool TEAM = false>
 __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     // nodes per lane in flight: min-sum has few live values per node, the transcendental chains of product-sum many
     constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : 2) : (DR <= 6 ? 2 : 1);
@@ -63,6 +67,11 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = TEAM ? tid : lane, TS = TEAM ? T : 64;    // this thread within the team that shares a syndrome, the team's size
+    const int wt = TEAM ? wave : 0, W = TEAM ? T >> 6 : 1;   // this wavefront within the team, wavefronts of a team
+    __shared__ int team_unsat[2];
+    __shared__ long long team_b;
+    auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     const int m = a.m, n = a.n, mp = a.mp, np = a.np, rm = DR * mp, cn = DC * np;
     const bool want_llr = a.llr != nullptr && !a.llr_direct, llr_direct = a.llr != nullptr && a.llr_direct;
     // Every LDS pointer is typed in the LDS address space from the start: generic ("flat") pointers into LDS make this
@@ -98,26 +107,33 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     }
 
     // wave-private: [M DR*mp][dummy][+0.0][posteriors np, if asked for][hard decisions np/64 + 1 words, the last one zero][syndrome bytes mp]
-    lds_u8 *mine = base + a.lds_shared + wave * a.lds_per_wave;
+    lds_u8 *mine = base + a.lds_shared + (TEAM ? 0 : wave) * a.lds_per_wave;
     lds_f64 *M = (lds_f64 *)mine;
     lds_f64 *L = M + rm + 2;
     volatile lds_u64 *hardw = (volatile lds_u64 *)(L + (want_llr ? np : 0));
     volatile lds_u8 *sy = (volatile lds_u8 *)(hardw + np / 64 + 1);
     const int DUMMY = rm, ZERO = rm + 1;
-    if (lane == 0) { M[ZERO] = 0.0; hardw[np / 64] = 0; }
-    for (int q = lane; q < mp; q += 64) sy[q] = 0;
-    __builtin_amdgcn_wave_barrier();
+    if (tl == 0) { M[ZERO] = 0.0; hardw[np / 64] = 0; team_unsat[0] = 0; team_unsat[1] = 0; }
+    for (int q = tl; q < mp; q += TS) sy[q] = 0;
+    team_sync();
 
     for (;;) {
-        unsigned long long pulled = 0;
-        if (lane == 0) pulled = atomicAdd(a.next, 1ull);
-        const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        int64_t b;
+        if (TEAM) {
+            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
+            __syncthreads();
+            b = team_b;
+        } else {
+            unsigned long long pulled = 0;
+            if (lane == 0) pulled = atomicAdd(a.next, 1ull);
+            b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        }
         if (b >= a.batch) break;
         // initialise_log_domain_bp (bp.hpp:147-157) + this syndrome's bytes; phantom entries get the neutral element
-        for (int i = lane; i < m; i += 64) sy[i] = a.synd[b * m + i];
-        for (int q = lane; q < rm; q += 64) M[q] = pform[col[q]];
-        __builtin_amdgcn_wave_barrier();
+        for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
+        for (int q = tl; q < rm; q += TS) M[q] = pform[col[q]];
+        team_sync();
 
         int it = 0;
         bool unsat_any = true;
@@ -125,7 +141,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
             ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
             // ---- check pass (bp.hpp:201-273), in place, U rows per lane in flight: loads, arithmetic, stores ----
-            for (int i0 = 0; i0 < mp; i0 += 64 * U) {
+            for (int i0 = wt * 64 * U; i0 < mp; i0 += 64 * U * W) {
                 uint8_t sb[U];
                 int d[U];
                 double cur[U][DR], out[U][DR];
@@ -183,9 +199,9 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                         for (int k = 0; k < DR; ++k) M[k < d[u] ? k * mp + i : DUMMY] = out[u][k];  // phantom entries keep their neutral value
                     }
             }
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
             // ---- bit pass (bp.hpp:276-298, 311-318), in place through the position table, U bits per lane in flight ----
-            for (int j0 = 0; j0 < np; j0 += 64 * U) {
+            for (int j0 = wt * 64 * U; j0 < np; j0 += 64 * U * W) {
                 int d[U], pos[U][DC];
                 double c[U][DC], pre[U][DC], pr[U];
 #pragma unroll
@@ -226,10 +242,10 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                         for (int k = 0; k < DC; ++k) M[pos[u][k] == ZERO ? DUMMY : pos[u][k]] = pre[u][k];
                     }
             }
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
             // ---- syndrome test (bp.hpp:292-294, 300-302): candidate parity of every check vs its syndrome BYTE ----
             bool unsat = false;
-            for (int i0 = 0; i0 < mp; i0 += 64) {
+            for (int i0 = wt * 64; i0 < mp; i0 += 64 * W) {
                 const int i = i0 + lane;
                 unsigned par = 0;
 #pragma unroll
@@ -240,18 +256,24 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                 unsat |= par != (unsigned)sy[i];
             }
             unsat_any = __ballot(unsat) != 0;
+            if (TEAM) {  // (two flags: iteration it + 1 raises the other one, which nobody has read since iteration it - 1)
+                if (unsat_any && lane == 0) team_unsat[it & 1] = 1;
+                if (tid == 0) team_unsat[(it + 1) & 1] = 0;
+                __syncthreads();
+                unsat_any = team_unsat[it & 1] != 0;
+            }
         } while (unsat_any && it < a.max_iter);
 
         // ---- outputs (bp.hpp:62,65,69,71) ----
-        for (int j = lane; j < n; j += 64) {
+        for (int j = tl; j < n; j += TS) {
             a.decoding[b * n + j] = (uint8_t)((hardw[j >> 6] >> (j & 63)) & 1ull);
             if (want_llr) a.llr[b * n + j] = L[j];
         }
-        if (lane == 0) {
+        if (tl == 0) {
             if (a.iters) a.iters[b] = it;
             if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
         }
-        __builtin_amdgcn_wave_barrier();
+        team_sync();
     }
 }
 

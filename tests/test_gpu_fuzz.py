@@ -63,7 +63,7 @@ def test_parallel_schedule_random_codes(seed, kind, oracle_built):
         o = oracle_built.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
         want = o.decode_batch(s)
         eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 0 if method == "product_sum" else 1, alpha)
-        for small, handoff in ((-1, -1), (0, 0), (0, 100000), (1, -1), (2, -1), (3, -1)):
+        for small, handoff in ((-1, -1), (0, 0), (0, 100000), (1, -1), (2, -1), (3, -1), (4, -1), (5, -1)):
             eng.set_small_code_kernel(small)
             eng.set_handoff(handoff)
             got = eng.decode_batch(s)
@@ -247,7 +247,7 @@ def test_one_handle_through_a_random_sequence_of_settings(seed, oracle_built):
                 st["order"] = rng.permutation(n).astype(np.int32) if rng.random() < 0.6 else None
                 eng.set_schedule("serial", st["order"])
         elif op == 3:
-            eng.set_small_code_kernel(int(rng.choice([-1, 0, 1, 2, 3])))
+            eng.set_small_code_kernel(int(rng.choice([-1, 0, 1, 2, 3, 4, 5])))
             eng.set_handoff(int(rng.choice([-1, 0, 2, 100000])))
         elif op == 4:
             eng.set_serial_kernel(int(rng.choice([-1, 0, 1])))

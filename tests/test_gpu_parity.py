@@ -495,6 +495,21 @@ def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
         eng.set_osd(1, 2)
 
 
+@pytest.mark.parametrize("name", ["hgp1600_ms20_p030", "hgp1600_ps12_p030"])
+@pytest.mark.parametrize("small", [-1, 4, 5, 0])
+def test_mid_size_code_one_wavefront_or_a_workgroup_per_syndrome(name, small):
+    """768 x 1600: the message array of a syndrome is 49 KiB of LDS, two fit a compute unit.  Automatic = a workgroup per
+    syndrome (bp_wave_kernel's TEAM form), 4 = one wavefront per syndrome, 0 = streamed: the reference's bits from each."""
+    c = load_case(name)
+    eng = _engine(c)
+    eng.set_small_code_kernel(small)
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert bits_equal(llr[: len(c["llr"])], c["llr"])
+    d2 = eng.decode_batch(c["syndromes"], want_llr=False)
+    assert np.array_equal(d2[0], c["decoding"]) and np.array_equal(d2[2], c["iterations"])
+
+
 @pytest.mark.parametrize("backend", ["cython", "ctypes"])
 def test_bposd_decoder_api_higher_order(backend):
     from ldpc_amd.bposd_decoder import BpOsdDecoder
@@ -520,7 +535,7 @@ def test_bposd_decoder_api_higher_order(backend):
 @pytest.mark.parametrize("name", ["c5_bb144_ps50_p050", "c5_bb144_ms50_p050", "c3_surface21_ms30_p050", "surface5_ps30",
                                   "edge_extreme_priors_ps", "edge_syndrome_bytes_gt1_ms", "edge_degree1_empty_ps",
                                   "c1_hamming5_ps20", "ldpc36_n600_ps50_p070"])
-@pytest.mark.parametrize("small", [0, 1, 2, 3])
+@pytest.mark.parametrize("small", [0, 1, 2, 3, 4, 5])  # 4 / 5: the lane = node kernel with one wavefront / a whole workgroup per syndrome
 def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
     """Small codes are decoded by the LDS-resident kernel (auto); forcing either kernel gives the reference's bits."""
     c = load_case(name)
