@@ -1125,12 +1125,17 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     // with 3 / 2 / 1 wavefronts per CU is 12x / 7x / 1.5x faster than streaming when most syndromes converge early and
     // 2.2x faster at 3 when most do not; product-sum 3x / 2.4x / 0.7x and about level.
     // Where LDS leaves room for only a few syndromes per CU, one wavefront each leaves the CU idle: the wavefronts of a workgroup
-    // then share ONE syndrome (TEAM), as many as its bit pass has rounds of 64 U columns for (small_mode 5 forces, 4 forbids it).
-    const bool team = h->small_mode == 5 || (h->small_mode != 4 && w < 6);
+    // then share ONE syndrome (TEAM), as many as its bit pass has rounds of 64 U columns for (small_mode 5 forces, 4 forbids it);
+    // and a code whose bit pass takes one wavefront several rounds is quicker that way whatever the room.
+    // Measured (round 2, min-sum / product-sum, large batches): 768 x 1600 15.5 -> 4.9 ms / 50 -> 16 ms, 1200 x 2400 21 -> 3.5 ms,
+    // surface d = 41 / 31 / 21 25 -> 11 / 24 -> 12.6 / 11.0 -> 10.0 ms, 300 x 600 1.03 -> 0.79 ms; d = 13, 17 (the bit pass of one
+    // wavefront is a single round of 64 U columns already) 7 % slower -- hence the second condition.
+    const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
+    const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
+    const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u));
     if (team) {
-        const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
-        const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
         int tw = (p.np + 64 * u - 1) / (64 * u);
+        if (const char *e = getenv("LDPC_HIP_TEAM_WAVES")) { const int v = atoi(e); if (v >= 1) tw = v; }  // (measurements)
         if (tw < 2) tw = 2;
         if (tw > 16) tw = 16;
         p.team = true;

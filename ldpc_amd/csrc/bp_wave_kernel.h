@@ -62,6 +62,9 @@ template <int METHOD, int MATH, int DR, int DC, bool TEAM = false>
 __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     // nodes per lane in flight: min-sum has few live values per node, the transcendental chains of product-sum many
     constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : 2) : (DR <= 6 ? 2 : 1);
+    // (a team has more wavefronts than the check pass has rounds of 64 U rows -- there are half as many rows as columns --: one row
+    // per lane there, so that twice as many wavefronts take part)
+    constexpr int UC = TEAM ? 1 : U;
     constexpr bool PS = METHOD == LDPC_HIP_PRODUCT_SUM;
     extern __shared__ __attribute__((aligned(16))) unsigned char wv_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
@@ -141,12 +144,12 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
             ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
             // ---- check pass (bp.hpp:201-273), in place, U rows per lane in flight: loads, arithmetic, stores ----
-            for (int i0 = wt * 64 * U; i0 < mp; i0 += 64 * U * W) {
-                uint8_t sb[U];
-                int d[U];
-                double cur[U][DR], out[U][DR];
+            for (int i0 = wt * 64 * UC; i0 < mp; i0 += 64 * UC * W) {
+                uint8_t sb[UC];
+                int d[UC];
+                double cur[UC][DR], out[UC][DR];
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int u = 0; u < UC; ++u)
                     if (i0 + u * 64 < mp) {  // wave-uniform
                         const int i = i0 + u * 64 + lane;
                         sb[u] = sy[i];
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                         for (int k = 0; k < DR; ++k) cur[u][k] = M[k * mp + i];
                     }
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int u = 0; u < UC; ++u)
                     if (i0 + u * 64 < mp) {
                         if (PS) {
                             const bool neg = sb[u] != 0;  // bp.hpp:213
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                         }
                     }
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int u = 0; u < UC; ++u)
                     if (i0 + u * 64 < mp) {
                         const int i = i0 + u * 64 + lane;
 #pragma unroll
