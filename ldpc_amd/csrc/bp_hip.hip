@@ -112,7 +112,7 @@ struct ldpc_hip_bp {
     int wave_dr = 0, wave_dc = 0;  // template bounds the uploaded SoA position tables of bp_wave_kernel were built for (0: none)
     int wave_ps_dr = 0, wave_ps_dc = 0;  // likewise for bp_wave_ps_kernel
     DeviceBuf wp_rdeg, wp_col, wp_epos;
-    DeviceBuf w_rdeg, w_cdeg, w_col, w_apos;
+    DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
@@ -325,7 +325,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1073,10 +1073,17 @@ static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint
 }
 
 // bp_wave_kernel: template bounds, launch shape and LDS split; waves == 0: not applicable (degrees, table range, LDS)
+// the priors as bp_wave_kernel's LDS copy would hold them: llr0, 1.0 for the padding columns, DBL_MAX at np (a row's phantom entries)
+__global__ void wave_prior_pad_kernel(const double *llr0, int n, int np, double *out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < np + 2) out[q] = q < n ? llr0[q] : q == np ? DBL_MAX : 1.0;
+}
+
 struct WavePlan {
     int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, mp = 0, np = 0;
     size_t shared = 0, per_wave = 0;
     bool llr_direct = false;
+    bool prior_global = false;  // min-sum: the priors are read from a padded device array instead of an LDS copy (WaveArgs.prior_g)
     bool team = false;  // the workgroup's wavefronts share ONE syndrome (bp_wave_kernel<..., TEAM>): `waves` = wavefronts of a team
     void (*kern)(const WaveArgs) = nullptr, (*kern_team)(const WaveArgs) = nullptr;
 };
@@ -1141,8 +1148,14 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
         p.team = true;
         p.waves = tw;
         p.kern = p.kern_team;
+        if (ms) {  // the LDS copy of the priors, 8 (np + 2) bytes: worth reading them from memory where that fits another workgroup
+            const size_t lean_shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc, false, false);
+            if (lds / (lean_shared + p.per_wave) > lds / (p.shared + p.per_wave) && !getenv("LDPC_HIP_TEAM_PRIOR_LDS")) { p.shared = lean_shared; p.prior_global = true; }
+        }
+        // (the kernel's ~100 VGPRs allow 16 wavefronts per CU: two teams of eight beat one of thirteen -- 768 x 1600: 4.0 vs 4.8 ms)
         p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
-        if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;
+        if (p.groups_per_cu >= 2 && p.waves > 8 && !getenv("LDPC_HIP_TEAM_WAVES")) p.waves = 8;
+        if (p.groups_per_cu * p.waves > 16) p.groups_per_cu = 16 / p.waves;
         if (p.groups_per_cu < 1) p.groups_per_cu = 1;
         return p;
     }
@@ -1293,6 +1306,11 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     a.rdeg = (const uint8_t *)h->w_rdeg.p; a.cdeg = (const uint8_t *)h->w_cdeg.p;
     a.col = (const uint16_t *)h->w_col.p; a.apos = (const uint16_t *)h->w_apos.p;
     a.llr0 = h->d_llr0;
+    if (p.prior_global) {
+        if ((rc = h->w_prior.ensure(sizeof(double) * (size_t)(p.np + 2)))) return rc;
+        hipLaunchKernelGGL(wave_prior_pad_kernel, dim3((unsigned)((p.np + 2 + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, h->n, p.np, (double *)h->w_prior.p);
+        a.prior_g = (const double *)h->w_prior.p;
+    }
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.llr_direct = p.llr_direct ? 1 : 0;
     a.next = (unsigned long long *)h->counter.p;

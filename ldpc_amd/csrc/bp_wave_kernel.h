@@ -33,6 +33,8 @@ struct WaveArgs {
     const uint16_t *col;         // [DR * mp] column of the k-th entry of row i at [k * mp + i]; phantom: np
     const uint16_t *apos;        // [DC * np] position in M of the k-th entry of column j at [k * np + j]; phantom: DR * mp + 1
     const double *llr0;          // [n]
+    const double *prior_g;       // min-sum, optional: [np + 2] the priors padded as the LDS copy would be (1.0 beyond n, DBL_MAX at np) --
+                                 // read from here instead of an LDS copy where those 8 (np + 2) bytes buy another resident workgroup
     const uint8_t *synd;         // [batch][m]
     uint8_t *decoding;           // [batch][n]
     double *llr;                 // [batch][n] or nullptr
@@ -43,8 +45,8 @@ struct WaveArgs {
 };
 
 // LDS bytes: shared tables of a workgroup / private region of one wavefront (host and device agree through these)
-__host__ __device__ inline size_t wave_lds_shared(int mp, int np, int DR, int DC, bool product_sum) {
-    size_t b = (size_t)(np + 2) * 8 + (size_t)DR * mp * 2 + (size_t)DC * np * 2 + (size_t)mp + (size_t)np;
+__host__ __device__ inline size_t wave_lds_shared(int mp, int np, int DR, int DC, bool product_sum, bool prior_in_lds = true) {
+    size_t b = (prior_in_lds ? (size_t)(np + 2) * 8 : 0) + (size_t)DR * mp * 2 + (size_t)DC * np * 2 + (size_t)mp + (size_t)np;
     b = (b + 15) & ~(size_t)15;
     if (product_sum) b += (size_t)(np + 2) * 8 + 256 * 8;  // edge form of the priors, log table
     return (b + 15) & ~(size_t)15;
@@ -86,22 +88,23 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     lds_u8 *base = (lds_u8 *)wv_lds;
     // shared, read-only after the barriers below: [llr0, np + 2][col][apos][rdeg][cdeg] and for product-sum
     // [edge form of llr0, np + 2][log table].  Entry np of llr0 / its edge form = what a phantom entry of a row holds.
+    const bool PG = !PS && a.prior_g != nullptr;  // priors read from global memory (min-sum only)
     lds_f64 *prior = (lds_f64 *)base;
-    lds_u16 *col = (lds_u16 *)(prior + np + 2);
+    lds_u16 *col = (lds_u16 *)(prior + (PG ? 0 : np + 2));
     lds_u16 *apos = col + rm;
     lds_u8 *rdeg = (lds_u8 *)(apos + cn);
     lds_u8 *cdeg = rdeg + mp;
-    const int ps_off = (int)((((size_t)(np + 2) * 8 + (size_t)rm * 2 + (size_t)cn * 2 + (size_t)mp + (size_t)np) + 15) & ~(size_t)15);
+    const int ps_off = (int)((((PG ? 0 : (size_t)(np + 2) * 8) + (size_t)rm * 2 + (size_t)cn * 2 + (size_t)mp + (size_t)np) + 15) & ~(size_t)15);
     lds_f64 *pform = PS ? (lds_f64 *)(base + ps_off) : prior;
     lds_f64 *log_tab_l = pform + np + 2;
     const double *log_tab = reinterpret_cast<const double *>(wv_lds + ps_off) + np + 2;  // same place, for the math routines' signature
     if (PS)
         for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
-    for (int q = tid; q < np; q += T) { prior[q] = q < n ? a.llr0[q] : 1.0; cdeg[q] = a.cdeg[q]; }
+    for (int q = tid; q < np; q += T) { if (!PG) prior[q] = q < n ? a.llr0[q] : 1.0; cdeg[q] = a.cdeg[q]; }
     for (int q = tid; q < mp; q += T) rdeg[q] = a.rdeg[q];
     for (int q = tid; q < rm; q += T) col[q] = a.col[q];
     for (int q = tid; q < cn; q += T) apos[q] = a.apos[q];
-    if (tid == 0) prior[np] = DBL_MAX;
+    if (tid == 0 && !PG) prior[np] = DBL_MAX;
     __syncthreads();
     if (PS) {
         for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
@@ -135,7 +138,8 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
         if (b >= a.batch) break;
         // initialise_log_domain_bp (bp.hpp:147-157) + this syndrome's bytes; phantom entries get the neutral element
         for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
-        for (int q = tl; q < rm; q += TS) M[q] = pform[col[q]];
+        if (PG) { for (int q = tl; q < rm; q += TS) M[q] = a.prior_g[col[q]]; }
+        else { for (int q = tl; q < rm; q += TS) M[q] = pform[col[q]]; }
         team_sync();
 
         int it = 0;
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
                 for (int u = 0; u < U; ++u)
                     if (j0 + u * 64 < np) {
                         const int j = j0 + u * 64 + lane;
-                        pr[u] = prior[j];
+                        pr[u] = PG ? a.prior_g[j] : prior[j];
                         if (PS) d[u] = cdeg[j];
 #pragma unroll
                         for (int k = 0; k < DC; ++k) { pos[u][k] = apos[k * np + j]; c[u][k] = M[pos[u][k]]; }  // phantom: the +0.0 slot
