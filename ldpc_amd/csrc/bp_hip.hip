@@ -1202,18 +1202,21 @@ static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
 struct WavePsPlan {
     int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, np = 0;
     size_t shared = 0, per_wave = 0;
-    void (*kern)(const WavePsArgs) = nullptr;
+    bool team = false;  // a workgroup per syndrome (bp_wave_ps_kernel<..., TEAM>): `waves` = wavefronts of a team
+    void (*kern)(const WavePsArgs) = nullptr, (*kern_team)(const WavePsArgs) = nullptr;
 };
 
 template <int MATH>
 static void pick_wave_ps(int max_row, int max_col, WavePsPlan &p) {
-    if (max_row <= 4 && max_col <= 2) { p.dr = 4; p.dc = 2; p.kern = bp_wave_ps_kernel<MATH, 4, 2>; return; }
-    if (max_row <= 4 && max_col <= 4) { p.dr = 4; p.dc = 4; p.kern = bp_wave_ps_kernel<MATH, 4, 4>; return; }
-    if (max_row <= 6 && max_col <= 3) { p.dr = 6; p.dc = 3; p.kern = bp_wave_ps_kernel<MATH, 6, 3>; return; }
-    p.dr = 8; p.dc = 4; p.kern = bp_wave_ps_kernel<MATH, 8, 4>;
+#define LDPC_PICK_WAVE_PS(R, C) { p.dr = R; p.dc = C; p.kern = bp_wave_ps_kernel<MATH, R, C, false>; p.kern_team = bp_wave_ps_kernel<MATH, R, C, true>; return; }
+    if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE_PS(4, 2)
+    if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE_PS(4, 4)
+    if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE_PS(6, 3)
+    LDPC_PICK_WAVE_PS(8, 4)
+#undef LDPC_PICK_WAVE_PS
 }
 
-static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr) {
+static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
     WavePsPlan p;
     if (h->bp_method != LDPC_HIP_PRODUCT_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 4) return p;
     if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave_ps<1>(h->max_row_deg, h->max_col_deg, p);
@@ -1229,6 +1232,21 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr)
     size_t w = (lds - p.shared) / p.per_wave;
     if (w > 16) w = 16;
     if (!forced && w < 8) return p;
+    // A batch so small that every wavefront decodes only a few syndromes takes as long as its slowest syndrome: then the
+    // workgroup's wavefronts share one (TEAM), one round of 64 entries each per pass.  LDPC_HIP_PS_TEAM=0 / 1 overrides (measurements).
+    bool team = batch <= 256 * (int64_t)w * 4;
+    if (const char *e = getenv("LDPC_HIP_PS_TEAM")) team = atoi(e) != 0;
+    if (team) {
+        const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
+        int tw = (int)(rounds < 2 ? 2 : rounds > 8 ? 8 : rounds);
+        p.team = true;
+        p.waves = tw;
+        p.kern = p.kern_team;
+        p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
+        if (p.groups_per_cu * p.waves > 16) p.groups_per_cu = 16 / p.waves;
+        if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+        return p;
+    }
     p.waves = (int)w;
     p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
     if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;
@@ -1277,10 +1295,10 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
-    const size_t dyn = p.shared + (size_t)p.waves * p.per_wave;
+    const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
     if (dyn > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    int64_t groups = (batch + p.waves - 1) / p.waves;
+    int64_t groups = p.team ? batch : (batch + p.waves - 1) / p.waves;
     const int64_t resident = 256 * (int64_t)p.groups_per_cu;
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
@@ -1350,7 +1368,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
         if (h->small_mode != 2 && h->small_mode < 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
-            const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr);
+            const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {

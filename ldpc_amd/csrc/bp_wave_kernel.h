@@ -319,13 +319,21 @@ __host__ __device__ inline size_t wave_ps_lds_private(int m, int np, int DR, boo
     return (b + 15) & ~(size_t)15;
 }
 
-template <int MATH, int DR, int DC>
+// TEAM: as for bp_wave_kernel -- the workgroup's wavefronts share one syndrome, each taking rounds of 64 entries of a pass.  For
+// batches so small that a wavefront decodes only a few syndromes the time is the 50 iterations of the slowest one: a team cuts
+// exactly that.
+template <int MATH, int DR, int DC, bool TEAM = false>
 __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     constexpr int METHOD = LDPC_HIP_PRODUCT_SUM;
     extern __shared__ __attribute__((aligned(16))) unsigned char wv_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = TEAM ? tid : lane, TS = TEAM ? T : 64;
+    const int wt = TEAM ? wave : 0, W = TEAM ? T >> 6 : 1;
+    __shared__ int team_unsat[2];
+    __shared__ long long team_b;
+    auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     const int m = a.m, n = a.n, np = a.np, rm = m * DR, cn = n * DC;
     const bool want_llr = a.llr != nullptr;
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -351,32 +359,39 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     __syncthreads();
 
     // wave-private: [A rm + 2][C rm + 2 (entry rm = the +0.0 slot)][posteriors np, if asked for][hard decisions np + 16 bytes][syndrome bytes m]
-    lds_u8 *mine = base + a.lds_shared + wave * a.lds_per_wave;
+    lds_u8 *mine = base + a.lds_shared + (TEAM ? 0 : wave) * a.lds_per_wave;
     lds_f64 *A = (lds_f64 *)mine;
     lds_f64 *C = A + rm + 2;
     lds_f64 *L = C + rm + 2;
     volatile lds_u8 *hard = (volatile lds_u8 *)(L + (want_llr ? np : 0));
     volatile lds_u8 *sy = hard + np + 16;
     const int ZERO = rm;
-    if (lane == 0) { C[ZERO] = 0.0; hard[np] = 0; }
-    __builtin_amdgcn_wave_barrier();
+    if (tl == 0) { C[ZERO] = 0.0; hard[np] = 0; team_unsat[0] = 0; team_unsat[1] = 0; }
+    team_sync();
 
     for (;;) {
-        unsigned long long pulled = 0;
-        if (lane == 0) pulled = atomicAdd(a.next, 1ull);
-        const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        int64_t b;
+        if (TEAM) {
+            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
+            __syncthreads();
+            b = team_b;
+        } else {
+            unsigned long long pulled = 0;
+            if (lane == 0) pulled = atomicAdd(a.next, 1ull);
+            b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        }
         if (b >= a.batch) break;
-        for (int i = lane; i < m; i += 64) sy[i] = a.synd[b * m + i];
-        for (int q = lane; q < rm; q += 64) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
-        __builtin_amdgcn_wave_barrier();
+        for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
+        for (int q = tl; q < rm; q += TS) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
+        team_sync();
 
         int it = 0;
         bool unsat_any = true;
         do {
             ++it;
             // ---- check pass (bp.hpp:201-219): lane = entry (i, k) ----
-            for (int s0 = 0; s0 < rm; s0 += 64) {
+            for (int s0 = wt * 64; s0 < rm; s0 += 64 * W) {
                 const int slot = s0 + lane;
                 const int sc = slot < rm ? slot : rm - 1;
                 const int i = sc / DR, k = sc - i * DR;
@@ -397,9 +412,9 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
                 }
                 if (valid) C[slot] = ps_message<MATH>(mine_pre * mine_suf, sy[i] != 0, log_tab);
             }
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
             // ---- bit pass (bp.hpp:276-298, 311-318): lane = entry (j, k) of the column ----
-            for (int s0 = 0; s0 < cn; s0 += 64) {
+            for (int s0 = wt * 64; s0 < cn; s0 += 64 * W) {
                 const int slot = s0 + lane;
                 const int sc = slot < cn ? slot : cn - 1;
                 const int j = sc / DC, k = sc - j * DC;
@@ -425,26 +440,32 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
                 }
                 if (slot < cn && mine_pos != ZERO) A[mine_pos] = edge_form<METHOD, MATH>(mine_pre + mine_sfx);
             }
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
             // ---- syndrome test (bp.hpp:292-294, 300-302) ----
             bool unsat = false;
-            for (int i = lane; i < m; i += 64) {
+            for (int i = tl; i < m; i += TS) {
                 unsigned par = 0;
 #pragma unroll
                 for (int kk = 0; kk < DR; ++kk) par ^= hard[col[i * DR + kk]];  // phantom: byte np, always zero
                 unsat |= par != (unsigned)sy[i];
             }
             unsat_any = __ballot(unsat) != 0;
+            if (TEAM) {  // (two flags: iteration it + 1 raises the other one, which nobody has read since iteration it - 1)
+                if (unsat_any && lane == 0) team_unsat[it & 1] = 1;
+                if (tid == 0) team_unsat[(it + 1) & 1] = 0;
+                __syncthreads();
+                unsat_any = team_unsat[it & 1] != 0;
+            }
         } while (unsat_any && it < a.max_iter);
 
-        for (int j = lane; j < n; j += 64) {
+        for (int j = tl; j < n; j += TS) {
             a.decoding[b * n + j] = hard[j];
             if (want_llr) a.llr[b * n + j] = L[j];
         }
-        if (lane == 0) {
+        if (tl == 0) {
             if (a.iters) a.iters[b] = it;
             if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
         }
-        __builtin_amdgcn_wave_barrier();
+        team_sync();
     }
 }
