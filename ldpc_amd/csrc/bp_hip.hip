@@ -1820,7 +1820,27 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         size_t room = (size_t)a.n * 8;
         const size_t elim = (size_t)a.m * 8 + (blocked ? pbuf_bytes : 0);
         if (elim > room) room = elim;
-        const size_t weigh = !higher ? 0 : (((size_t)a.n * 2 + 7) & ~(size_t)7) + 56 * (size_t)A.hwords + ((size_t)a.m + 1) * 32;
+        // the staged T planes, one buffer of 8 (m + 1) bytes per wavefront that weighs candidates: four, unless fewer let more
+        // workgroups stay resident (tall matrices: at 1728 rows four buffers are 55 KiB and leave ONE workgroup per CU) -- weighing is
+        // about a quarter of an OSD row, so halving its wavefronts costs ~ 25 %, a second resident workgroup gains ~ 70 %
+        // -- IF there are more rows than resident workgroups; a handful of rows is about latency and wants all four.  How many rows the
+        // previous OSD call on this handle listed is the guide (copied back asynchronously, never waited for; first call: an eighth of the batch).
+        A.nplanes = 4;
+        size_t weigh = 0;
+        if (higher) {
+            const unsigned seen = h->h_flag ? ((volatile unsigned *)h->h_flag)[8] : 0u;
+            const double rows = seen ? (double)seen : (double)batch / 8.0 + 1.0;
+            double best = 1e300;
+            for (int nb = 4; nb >= 1; nb >>= 1) {
+                const size_t wb = (((size_t)a.n * 2 + 7) & ~(size_t)7) + 56 * (size_t)A.hwords + ((size_t)a.m + 1) * 8 * (size_t)nb;
+                const size_t tot = phase + (wb > room ? wb : room);
+                int pc = (int)((160u * 1024u) / (tot + 1024));
+                if (pc > 4) pc = 4;
+                if (pc < 1) pc = 1;
+                const double cost = std::ceil(rows / (256.0 * pc)) * (1.0 + 0.25 * (4.0 / nb - 1.0));  // rounds of resident workgroups x time of a row
+                if (cost < best - 1e-9) { best = cost; A.nplanes = nb; weigh = wb; }
+            }
+        }
         if (weigh > room) room = weigh;
         size_t lds = phase + room;
         A.extra_off = (int32_t)phase;
@@ -1851,6 +1871,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bk, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
         HIPCHK(hipGetLastError());
+        if (h->h_flag) HIPCHK(hipMemcpyAsync(&h->h_flag[8], a.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));  // rows listed: the next call's guide
         return osd_status_pass(h, a, batch);
     }
     int groups_per_cu = (int)((160u * 1024u) / dyn);

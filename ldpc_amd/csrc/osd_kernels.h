@@ -757,8 +757,9 @@ struct OsdBigArgs {
     int32_t pow2;           // bitonic size: smallest power of two >= n
     int32_t max_rank;       // rank of H if the host worked it out, else min(m, n)
     int32_t kwords;         // HIGHER: planes of T the slot has room for (>= ceil((n - rank) / 64))
-    int32_t extra_off;      // byte offset in LDS of the room the phases share: keys [n] u64 | positions [n] u16 | look [m] u64 + table | {colinfo [n] i16, (8-aligned) plane masks and moves [7][hwords] u64, planes [4][m + 1] u64}
+    int32_t extra_off;      // byte offset in LDS of the room the phases share: keys [n] u64 | positions [n] u16 | look [m] u64 + table | {colinfo [n] i16, (8-aligned) plane masks and moves [7][hwords] u64, planes [nplanes][m + 1] u64}
     int32_t mat_off;        // MAT_LDS: byte offset in LDS of the working copy [hwords][m]
+    int32_t nplanes;        // HIGHER: wavefronts that weigh candidates, each with its own staged plane [m + 1] u64 in LDS (4, 2 or 1)
     int32_t pbuf_off;       // blocked elimination (m <= OSD_BLOCK_ROWS): byte offset in LDS of the combination table (extra_off + 8 m); -1: one pivot per step
 };
 
@@ -1369,9 +1370,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         {
             uint64_t *pl = planes + (size_t)wave * (m + 1);
             int held = -2;  // what the buffer holds: -1 = T plane 0 as it is (sets), v >= 0 = plane v XOR all-ones where S_r (single columns)
-            for (long task0 = 0; task0 < ntask; task0 += 4) {
+            for (long task0 = 0; task0 < ntask; task0 += A.nplanes) {
                 const long task = task0 + __builtin_amdgcn_readfirstlane(wave);
-                if (task >= ntask) break;
+                if (wave >= A.nplanes || task >= ntask) break;  // (fewer buffers than wavefronts where LDS is short: the others wait below)
                 const int want = task < nchunk ? -1 : (int)(task - nchunk);
                 if (want != held) {
                     if (want < 0) {
