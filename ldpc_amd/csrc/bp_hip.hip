@@ -1099,7 +1099,7 @@ static void pick_wave(int max_row, int max_col, WavePlan &p) {
 #undef LDPC_PICK_WAVE
 }
 
-static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
+static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
     WavePlan p;
     if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 8) return p;
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_wave<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
@@ -1139,7 +1139,9 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr) {
     // wavefront is a single round of 64 U columns already) 7 % slower -- hence the second condition.
     const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
     const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
-    const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u));
+    // A batch of no more than one syndrome per wavefront slot is about latency: a team (two wavefronts at least) then too --
+    // surface d = 9 .. 17, BB144 at 512 / 4 096 syndromes: 1.25 - 1.6x / 1.0 - 1.3x faster, at 65 536 up to 16 % slower.
+    const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u || batch <= 256 * (int64_t)w));
     if (team) {
         int tw = (p.np + 64 * u - 1) / (64 * u);
         if (const char *e = getenv("LDPC_HIP_TEAM_WAVES")) { const int v = atoi(e); if (v >= 1) tw = v; }  // (measurements)
@@ -1372,7 +1374,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr);
+            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr, batch);
             if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
         }
         int slots = 0;
