@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--bb", action="store_true")
     ap.add_argument("--hgp1600", action="store_true", help="the [[1600,64]] code of bench_configs.py: workgroup kernel, H in HBM")
     ap.add_argument("--order", type=int, default=10)
+    ap.add_argument("--shots", type=int, default=65536, help="batch size (few rows through OSD = the latency regime: little contention between wavefronts)")
     ap.add_argument("--mask", type=lambda v: int(v, 0), default=0xffff,
                     help="workgroup kernel: the probes that are live (bit = slot); every probe serialises, so a few at a time perturb "
                          "least -- the time between two live probes goes to the later one")
@@ -55,7 +56,7 @@ def main():
         p, it, method, alpha = 0.02, 30, 1, 0.625
     n = h.shape[1]
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), it, method, alpha)
-    s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=65536, device="cuda:0")
+    s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=args.shots, device="cuda:0")
     eng.set_osd(3, args.order)
     out = eng.decode_batch(s, osd=True)
     torch.cuda.synchronize()
