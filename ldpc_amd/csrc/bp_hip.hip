@@ -1115,7 +1115,7 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int6
     (void)cn;
     // one workgroup per compute unit with as many wavefronts as LDS (160 KiB) and the 16-wave workgroup limit allow;
     // small codes fit several such workgroups
-    const size_t lds = 160u * 1024u;
+    const size_t lds = 160u * 1024u - 64u;  // (the kernels' few bytes of static LDS come on top of the dynamic part)
     if (want_llr) {
         // the LDS copy of the log-ratios is a convenience (the store of every iteration stays on chip); where it costs a
         // resident wavefront and few are resident, every bit pass stores them straight to HBM instead
@@ -1229,7 +1229,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
     if (!forced && (rm > 2 * (size_t)h->nnz || (size_t)p.dc * h->n > 2 * (size_t)h->nnz)) return p;  // padding would dominate
     p.shared = wave_ps_lds_shared(h->m, p.np, p.dr, p.dc);
     p.per_wave = wave_ps_lds_private(h->m, p.np, p.dr, want_llr);
-    const size_t lds = 160u * 1024u;
+    const size_t lds = 160u * 1024u - 64u;  // (the kernels' few bytes of static LDS come on top of the dynamic part)
     if (p.shared + p.per_wave > lds) return p;
     size_t w = (lds - p.shared) / p.per_wave;
     if (w > 16) w = 16;
