@@ -1842,6 +1842,10 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
                 const double cost = std::ceil(rows / (256.0 * pc)) * (1.0 + 0.25 * (4.0 / nb - 1.0));  // rounds of resident workgroups x time of a row
                 if (cost < best - 1e-9) { best = cost; A.nplanes = nb; weigh = wb; }
             }
+            if (const char *e = getenv("LDPC_HIP_OSD_PLANES")) {  // (tests, measurements)
+                const int nb = atoi(e);
+                if (nb == 1 || nb == 2 || nb == 4) { A.nplanes = nb; weigh = (((size_t)a.n * 2 + 7) & ~(size_t)7) + 56 * (size_t)A.hwords + ((size_t)a.m + 1) * 8 * (size_t)nb; }
+            }
         }
         if (weigh > room) room = weigh;
         size_t lds = phase + room;

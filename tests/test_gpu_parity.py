@@ -476,6 +476,20 @@ def test_workgroup_osd_kernel_variants(name, unblocked, monkeypatch):
         assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0], c["osd0_decoding"]), (kernel, unblocked)
 
 
+@pytest.mark.parametrize("planes", ["1", "2", "4"])
+@pytest.mark.parametrize("name", ["osdw_cs10_hgp1600_ms12", "osdw_e6_hgp1600_ms12", "osdw_cs8_random400x900_ps6"])
+def test_workgroup_osd_kernel_staged_planes(name, planes, monkeypatch):
+    """The workgroup kernel weighs candidates with one, two or four wavefronts (one staged T plane each; fewer where LDS would
+    otherwise cost resident workgroups and many rows wait): the same solutions whichever it picks."""
+    c = load_case(name)
+    eng = _engine(c)
+    monkeypatch.setenv("LDPC_HIP_OSD_PLANES", planes)
+    eng.set_osd_kernel(2)
+    eng.set_osd(c["osd_method"], c["osd_order"])
+    dec = eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0]
+    assert np.array_equal(dec, c["decoding"])
+
+
 def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
     """Config-5 code, OSD_CS order 10 (the setting most BP+OSD papers use), B = 4096 device resident vs the CPU oracle."""
     from ldpc_amd.engine import HipBpEngine
