@@ -550,7 +550,7 @@ def test_bposd_decoder_api_higher_order(backend):
                                   "edge_extreme_priors_ps", "edge_syndrome_bytes_gt1_ms", "edge_degree1_empty_ps",
                                   "c1_hamming5_ps20", "ldpc36_n600_ps50_p070"])
 @pytest.mark.parametrize("small", [0, 1, 2, 3, 4, 5])  # 4 / 5: the lane = node kernel with one wavefront / a whole workgroup per syndrome
-def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
+def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small, monkeypatch):
     """Small codes are decoded by the LDS-resident kernel (auto); forcing either kernel gives the reference's bits."""
     c = load_case(name)
     eng = _engine(c)
@@ -564,6 +564,11 @@ def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small):
     d2, l2, i2, c2 = eng.decode_batch(big)
     for r in range(0, 3001 - k, k):
         assert np.array_equal(d2[r:r + k], c["decoding"]) and np.array_equal(i2[r:r + k], c["iterations"])
+    if small == 1 and c["bp_method"] == "product_sum":  # the lane = entry kernel in both of its forms, whatever the batch size would pick
+        for form in ("0", "1"):
+            monkeypatch.setenv("LDPC_HIP_PS_TEAM", form)
+            d3, l3, i3, c3 = eng.decode_batch(c["syndromes"])
+            assert np.array_equal(d3, c["decoding"]) and np.array_equal(i3, c["iterations"]) and bits_equal(l3[: len(c["llr"])], c["llr"]), form
 
 
 @pytest.mark.parametrize("backend", ["cython", "ctypes"])
