@@ -1236,7 +1236,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
     if (!forced && w < 8) return p;
     // A batch so small that every wavefront decodes only a few syndromes takes as long as its slowest syndrome: then the
     // workgroup's wavefronts share one (TEAM), one round of 64 entries each per pass.  LDPC_HIP_PS_TEAM=0 / 1 overrides (measurements).
-    bool team = batch <= 256 * (int64_t)w * 4;
+    bool team = batch <= 256 * (int64_t)w * 8;  // (BB144, w = 16: 0.96 -> 0.57 ms at 8 192 syndromes, 1.52 -> 1.37 ms at 32 768, 4.2 -> 4.5 ms at 131 072)
     if (const char *e = getenv("LDPC_HIP_PS_TEAM")) team = atoi(e) != 0;
     if (team) {
         const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
@@ -1245,7 +1245,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
         p.waves = tw;
         p.kern = p.kern_team;
         p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
-        if (p.groups_per_cu * p.waves > 16) p.groups_per_cu = 16 / p.waves;
+        if (p.groups_per_cu * p.waves > 28) p.groups_per_cu = 28 / p.waves;  // (this kernel's 59 VGPRs allow 7 wavefronts per SIMD)
         if (p.groups_per_cu < 1) p.groups_per_cu = 1;
         return p;
     }
