@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
         for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
         if (PG) { for (int q = tl; q < rm; q += TS) M[q] = a.prior_g[col[q]]; }
         else { for (int q = tl; q < rm; q += TS) M[q] = pform[col[q]]; }
+        if (TEAM && tid == 0) { team_unsat[0] = 0; team_unsat[1] = 0; }  // (a syndrome that ran out of iterations leaves its last flag raised)
         team_sync();
 
         int it = 0;
@@ -384,6 +385,7 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
         if (b >= a.batch) break;
         for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
         for (int q = tl; q < rm; q += TS) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
+        if (TEAM && tid == 0) { team_unsat[0] = 0; team_unsat[1] = 0; }  // (a syndrome that ran out of iterations leaves its last flag raised)
         team_sync();
 
         int it = 0;

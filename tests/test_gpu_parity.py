@@ -509,6 +509,34 @@ def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
         eng.set_osd(1, 2)
 
 
+@pytest.mark.parametrize("method", ["minimum_sum", "product_sum"])
+def test_team_form_after_a_syndrome_that_ran_out_of_iterations(method, oracle_built):
+    """A team decodes one syndrome after another: one that stops at an ODD iteration limit without converging leaves its
+    'unsatisfied' flag raised, and the next one may converge in its very first iteration -- many such pairs through few teams."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    m, n = h.shape
+    rng = np.random.default_rng(11)
+    rows = 40000
+    s = np.zeros((rows, m), np.uint8)
+    s[0::2] = 2  # a syndrome byte above 1 can never be matched (bp.hpp:300): every other row runs out of iterations
+    one = np.zeros((rows // 2, n), np.uint8)
+    one[np.arange(rows // 2), rng.integers(0, n, rows // 2)] = 1
+    s[1::2] = (one @ h.T.toarray()) % 2  # a single error: converges at once
+    for max_iter in (3, 4):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.01), max_iter, 0 if method == "product_sum" else 1, 0.9)
+        o = oracle_built.BpOracle(h, error_rate=0.01, max_iter=max_iter, bp_method=method, ms_scaling_factor=0.9)
+        want = o.decode_batch(s[:64])
+        for small in (5, 1):  # the lane = node kernel as a team; whatever mode 1 picks (product-sum: the lane = entry kernel, a team at this batch size)
+            eng.set_small_code_kernel(small)
+            dec, llr, it, cv = eng.decode_batch(s, want_llr=False)
+            assert np.array_equal(it[0::2], np.full(rows // 2, max_iter)) and not cv[0::2].any()
+            assert cv[1::2].all()
+            assert int(it[1::2].max()) == int(want[2][1::2].max()) == 1, (small, max_iter)
+            assert np.array_equal(dec[:64], want[0])
+
+
 @pytest.mark.parametrize("name", ["hgp1600_ms20_p030", "hgp1600_ps12_p030"])
 @pytest.mark.parametrize("small", [-1, 4, 5, 0])
 def test_mid_size_code_one_wavefront_or_a_workgroup_per_syndrome(name, small):
