@@ -733,6 +733,8 @@ static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
                                 int32_t *iters, uint8_t *conv) {
     const int n = h->n, max_iter = h->max_iter;
     // the arrangements of iterations 1 .. max_iter: std::shuffle on the object's std::mt19937, as RandomListShuffle does (rng.hpp:128-130)
+    if ((size_t)max_iter * (size_t)(n ? n : 1) > ((size_t)1 << 28))
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", max_iter, n);
     std::vector<int32_t> orders((size_t)max_iter * (size_t)(n ? n : 1));
     {
         std::mt19937 g = h->sched_rng;
@@ -941,6 +943,8 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     int32_t *d_iters_last = nullptr;
     if (shuffled) {
         level_waves = 0;  // the levels belong to one fixed order
+        if ((size_t)h->max_iter * (size_t)h->n > ((size_t)1 << 28))
+            return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", h->max_iter, h->n);
         orders.resize((size_t)h->max_iter * (size_t)h->n);
         std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
         for (int it = 0; it < h->max_iter; ++it) {
