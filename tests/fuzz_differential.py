@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Extended differential run (a tool, not part of the test suite): random regular codes of 96 .. 1300 bits, random priors /
+"""Extended differential run (run by hand; not collected by pytest): random regular codes of 96 .. 1300 bits, random priors /
 methods / iteration limits / batch sizes, through every form of the on-chip BP kernels (one wavefront or a workgroup per syndrome,
 lane = node or lane = entry) and through the workgroup OSD kernel (blocked, one pivot per step, one staged plane), against the CPU
-checker bit for bit.      python tools/fuzz_differential.py <seconds> <seed>
+checker bit for bit.      python tests/fuzz_differential.py <seconds> <seed>
 End of round 2: 3 242 cases over two seeds, no mismatch (gpurun, 7 minutes)."""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
