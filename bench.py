@@ -81,12 +81,24 @@ def launch_command(n_ranks: int, argv: list[str], port: int | None = None) -> li
             "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
 
 
+RANK_ENV_DEFAULTS = {
+    "HSA_ENABLE_IPC_MODE_LEGACY": "0",  # dmabuf IPC: without it RCCL fails with `hipIpcGetMemHandle: invalid argument` on this pool
+    "OMP_NUM_THREADS": "1",
+}
+
+
+def apply_rank_env_defaults(env=None) -> dict:
+    """Environment every rank needs BEFORE `import torch` / the first HIP call -- set in main() itself, so it holds under the
+    driver's own `python -m torch.distributed.run ... bench.py --gpus N` as well as under self_launch()."""
+    env = os.environ if env is None else env
+    for k, v in RANK_ENV_DEFAULTS.items():
+        env.setdefault(k, v)
+    return env
+
+
 def self_launch(n_ranks: int) -> int:
     argv = [a for a in sys.argv[1:] if a != "--force-launch"]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this pool)
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(launch_command(n_ranks, argv), env=env)
+    return subprocess.call(launch_command(n_ranks, argv), env=apply_rank_env_defaults(dict(os.environ)))
 
 
 def parse_args():
@@ -222,17 +234,54 @@ def secondary_configs(dev, steps):
     return out
 
 
+def error_line(args, exc, stage: str) -> dict:
+    """What rank 0 prints instead of the result line when the run fails: still ONE parseable JSON line, never a bare traceback."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    info = {"ranks": world, "backend": "nccl" if "WORLD_SIZE" in os.environ else None, "launcher": "torch.distributed.run" if "WORLD_SIZE" in os.environ else None,
+            "env": {k: os.environ.get(k) for k in (*RANK_ENV_DEFAULTS, "MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE")}}
+    return {"metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k", "value": None, "unit": "syndromes/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "error": f"{type(exc).__name__}: {exc}"[:600], "stage": stage,
+            "rank": int(os.environ.get("RANK", "0")), "rccl": info}
+
+
 def main() -> None:
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch):
         sys.exit(self_launch(args.gpus))
+    apply_rank_env_defaults()  # before `import torch`: the driver's own torch.distributed.run command does not pass through self_launch
 
     # ONE JSON line on stdout: libraries that greet on stdout (RCCL prints a version banner from its first communicator) are
     # sent to stderr by pointing file descriptor 1 there for the duration of the run; the line goes to the saved descriptor.
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    stage = ["start"]
+    rank = int(os.environ.get("RANK", "0"))
 
+    def terminated(signum, _frame):  # the launcher stops the surviving ranks when one of them dies: rank 0 still leaves a line
+        if rank == 0 and not stage[0] == "done":
+            print(json.dumps(error_line(args, RuntimeError(f"signal {signum} from the launcher (another rank failed?)"), stage[0])),
+                  file=real_stdout, flush=True)
+        os._exit(1)
+
+    if "WORLD_SIZE" in os.environ:
+        import signal
+        signal.signal(signal.SIGTERM, terminated)
+    try:
+        run(args, real_stdout, stage)
+        stage[0] = "done"
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001 -- RCCL / HIP failures surface as RuntimeError, DistBackendError, ...
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        line = json.dumps(error_line(args, exc, stage[0]))
+        # rank 0 owns stdout's one line; another rank's failure goes to stderr (rank 0 then reports the launcher's signal)
+        print(line, file=real_stdout if rank == 0 else sys.stderr, flush=True)
+        sys.exit(1)
+
+
+def run(args, real_stdout, stage) -> None:
     import torch
     import torch.distributed as dist
 
@@ -246,9 +295,13 @@ def main() -> None:
         sys.exit(2)
     if args.dry_ranks:  # does `python bench.py --gpus N` really become N ranks that find each other?  (tests/test_bench_launch.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage[0] = "init_process_group(gloo)"
         dist.init_process_group("gloo")
+        if os.environ.get("BENCH_DRY_FAIL_RANK") == str(rank):  # test hook: what a rank's failure leaves on stdout
+            raise RuntimeError("injected failure (BENCH_DRY_FAIL_RANK)")
         seen = [None] * world
-        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+                                      "env": {k: os.environ.get(k) for k in RANK_ENV_DEFAULTS}})
         if rank == 0:
             print(json.dumps({"dry_ranks": seen, "world": dist.get_world_size(), "backend": dist.get_backend()}), file=real_stdout, flush=True)
         dist.barrier()
@@ -258,7 +311,9 @@ def main() -> None:
     dev = torch.device("cuda", local_rank)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        stage[0] = "init_process_group(nccl)"
         dist.init_process_group("nccl", device_id=dev)
+    stage[0] = "engine"
 
     from ldpc_amd.codes import regular_ldpc_code
     from ldpc_amd.engine import HipBpEngine
@@ -305,6 +360,7 @@ def main() -> None:
             if record:
                 gather_ms.append((e0, e1))
 
+    stage[0] = "warmup (first decode + first gather)"
     for _ in range(args.warmup):
         step(False)
     if grouped and args.warmup == 0:
@@ -313,6 +369,7 @@ def main() -> None:
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
+    stage[0] = "timed steps"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -325,6 +382,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    stage[0] = "parity + report"
     iters = it.cpu().numpy()
     conv = cv.cpu().numpy().astype(bool)
     k_ms = float(np.mean(kernel_ms))
@@ -451,7 +509,9 @@ def main() -> None:
             if not ok:
                 res["parity_failed"] = True
         else:
-            res["cpu_baseline"] = None
+            res["cpu_baseline"] = "N = 1 only" if world > 1 else None  # (None: --cpu-sample 0 asked for no CPU leg)
+            if world > 1:
+                res["roofline"]["traffic_note"] = "PMC traffic is collected at N = 1 only (profiles/hbm_traffic.json)"
         if world == 1 and args.secondary and method_id == 0:
             eng.close()
             del synd, dec, llr, out

@@ -42,3 +42,47 @@ def test_bare_invocation_spawns_its_ranks():
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "3", "--dry-ranks"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2
+
+
+def _torchrun(args, env=None, nproc=2):
+    """The DRIVER's route: torch.distributed.run around bench.py (bench.self_launch is not involved)."""
+    import bench
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", *bench.RANK_ENV_DEFAULTS):
+        e.pop(k, None)
+    e.update(env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_drivers_own_torchrun_command_gets_the_rank_environment():
+    """The RCCL environment defaults must hold when the driver starts the ranks itself (missing 1)."""
+    import bench
+    r = _torchrun(["--dry-ranks"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got["world"] == 2 and sorted(d["rank"] for d in got["dry_ranks"]) == [0, 1]
+    for d in got["dry_ranks"]:
+        assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == bench.RANK_ENV_DEFAULTS["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert d["env"]["OMP_NUM_THREADS"] is not None
+
+
+def test_rank_environment_respects_what_the_caller_set():
+    r = _torchrun(["--dry-ranks"], env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert all(d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "1" for d in got["dry_ranks"])
+
+
+def test_a_failing_rank_leaves_one_json_error_line():
+    for bad in ("0", "1"):
+        r = _torchrun(["--dry-ranks"], env={"BENCH_DRY_FAIL_RANK": bad})
+        assert r.returncode != 0
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (bad, r.stdout, r.stderr[-1500:])
+        got = json.loads(lines[0])
+        assert got["value"] is None and "error" in got and got["n_gpus"] == 2
+        assert got["rccl"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and got["rccl"]["ranks"] == 2
