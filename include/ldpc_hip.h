@@ -337,7 +337,11 @@ const char *ldpc_hip_version(void);
  * decisions back bit-packed, 1/8 of the bytes, to be unpacked on that GPU when it is one of device_ids).
  * with_osd: -1 = ldpc_hip_bp_decode_batch, 0 = ldpc_hip_bposd0_decode_batch, 1 = ldpc_hip_bposd_decode_batch.
  * Settings (channel, parameters, schedule, OSD, math ...) are applied per GPU through ldpc_hip_bp_multi_handle(mh, i),
- * i < ldpc_hip_bp_multi_devices(mh): the setters above, unchanged.  Multi-PROCESS sharding (one rank per GPU, RCCL
+ * i < ldpc_hip_bp_multi_devices(mh): the setters above, unchanged.  The schedules that keep state in the decoder object
+ * (serial_relative, the random serial schedule) have ONE state per multi handle: a call starts every row from the state of
+ * handle 0 (copied to the others first -- which also settles random_schedule_seed = 0, the clock) and leaves the state of the
+ * batch's last row on EVERY handle, so that sequences of calls equal the single-GPU sequences bit for bit.  Soft-syndrome
+ * decoding (ldpc_hip_bp_soft_info_decode_batch) is a per-handle call: use ldpc_hip_bp_multi_handle(mh, 0).  Multi-PROCESS sharding (one rank per GPU, RCCL
  * gather of the packed rows) is ldpc_amd/sharding.py + bench.py; the reference has neither (bp.hpp:129-140).
  */
 typedef struct ldpc_hip_bp_multi ldpc_hip_bp_multi;

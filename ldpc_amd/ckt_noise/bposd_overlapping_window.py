@@ -45,7 +45,7 @@ class _WindowBpOsd:
                 new_index = np.full(self.n, -1, np.int64)
                 new_index[self.cols] = np.arange(len(self.cols))
                 kept = new_index[order]
-                config["serial_schedule_order"] = kept[kept >= 0]
+                config["serial_schedule_order"] = [int(v) for v in kept[kept >= 0]]  # (the decoder takes a list, pyx:620-623)
         self.inner = BpOsdDecoder(round_dcm[:, self.cols], error_channel=list(weights[self.cols]), **config)
         self._cols_dev = None
 

@@ -310,7 +310,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev_hist);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
-    if (e == hipSuccess) { h->h_flag[0] = 0; e = hipHostGetDevicePointer((void **)&h->d_flag, h->h_flag, 0); }
+    if (e == hipSuccess) { std::memset(h->h_flag, 0, 64); e = hipHostGetDevicePointer((void **)&h->d_flag, h->h_flag, 0); }
     if (e != hipSuccess) {
         ldpc_hip_bp_destroy(h);
         return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -745,10 +745,10 @@ static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
         }
     }
     int rc;
-    if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t)))) return rc;
+    if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
     if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = decode_serial_pass(h, max_iter, synd, batch, decoding, llr, iters, conv, (const int32_t *)h->sched_orders.p, max_iter))) return rc;
     int32_t last = 0;
     HIPCHK(hipMemcpyAsync(&last, iters + (batch - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));

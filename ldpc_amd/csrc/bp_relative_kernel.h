@@ -59,12 +59,17 @@ __device__ inline void move_median_to_first(const Ctx &x, long result, long a, l
     else if (x.gt(vb, vc)) x.swap(result, c);
     else x.swap(result, b);
 }
+// The "unguarded" loops of libstdc++ rely on a strict weak order (a sentinel stops them).  With NaN keys (product-sum with
+// priors 0 or 1: inf - inf) the comparison is none and the reference's own behaviour is undefined; on the device a walk off
+// the lane's range would read another lane's order entry and use it as an index -- so the loops are also bounded by the
+// range [lo, hi) they work in.  For keys that ARE ordered the bounds are never reached: nothing observable changes.
 __device__ inline long unguarded_partition(const Ctx &x, long first, long last, long pivot) {
+    const long lo = first, hi = last;
     for (;;) {
         const int vp = x.get(pivot);  // (the pivot position holds the same element throughout: swaps happen in (pivot, last))
-        while (x.gt(x.get(first), vp)) ++first;
+        while (first < hi - 1 && x.gt(x.get(first), vp)) ++first;
         --last;
-        while (x.gt(vp, x.get(last))) --last;
+        while (last > lo && x.gt(vp, x.get(last))) --last;
         if (!(first < last)) return first;
         x.swap(first, last);
         ++first;
@@ -112,7 +117,7 @@ __device__ inline void heapsort(const Ctx &x, long first, long last) {  // __par
 __device__ inline void unguarded_linear_insert(const Ctx &x, long last) {
     const int val = x.get(last);
     long next = last - 1;
-    while (x.gt(val, x.get(next))) {
+    while (next >= 0 && x.gt(val, x.get(next))) {  // (next >= 0: see unguarded_partition)
         x.set(last, x.get(next));
         last = next;
         --next;

@@ -171,6 +171,23 @@ static int multi_decode_shard(ldpc_hip_bp_multi *mh, MultiDev &md, int osd, cons
     return ldpc_hip_bp_last_kernel_ms(h, &md.kernel_ms);
 }
 
+// The schedules that keep state in the decoder object (serial_relative's re-sorted order, the random schedule's order and
+// generator: bp.hpp:467-483) promise "every row starts from the state at the time of the call, the call leaves the state
+// of its LAST row" (decode_serial_random above).  With one handle per GPU that state has to be ONE state: handle 0 is the
+// authority before a call (which also settles random_schedule_seed = 0, where every handle read the clock on its own),
+// the handle that decoded the batch's last row is the authority after it.
+static bool multi_schedule_has_state(const ldpc_hip_bp *h) { return h->random_serial || h->schedule == 2; }
+static void multi_copy_schedule_state(ldpc_hip_bp_multi *mh, int from) {
+    const ldpc_hip_bp *src = mh->devs[(size_t)from].h;
+    for (size_t d = 0; d < mh->devs.size(); ++d) {
+        ldpc_hip_bp *dst = mh->devs[d].h;
+        if (dst == src) continue;
+        dst->sched_state = src->sched_state;
+        dst->sched_rng = src->sched_rng;
+        dst->sched_seed_raw = src->sched_seed_raw;
+    }
+}
+
 extern "C" int ldpc_hip_bp_multi_decode_batch(ldpc_hip_bp_multi *mh, int32_t with_osd, const uint8_t *synd, int64_t batch,
                                               uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
     if (!mh) return fail(LDPC_HIP_ERR_INVALID, "null handle");
@@ -211,6 +228,8 @@ extern "C" int ldpc_hip_bp_multi_decode_batch(ldpc_hip_bp_multi *mh, int32_t wit
         HIPCHK(hipSetDevice(pd));
         if (root >= 0) HIPCHK(hipStreamSynchronize(mh->devs[(size_t)root].h->stream));
     }
+    const bool stateful = multi_schedule_has_state(mh->devs[0].h);
+    if (stateful) multi_copy_schedule_state(mh, 0);
     std::vector<std::thread> threads;
     for (int d = 0; d < ndev; ++d) {
         threads.emplace_back([=, &packed]() {
@@ -228,6 +247,12 @@ extern "C" int ldpc_hip_bp_multi_decode_batch(ldpc_hip_bp_multi *mh, int32_t wit
         if (mh->devs[(size_t)d].rc) {
             g_last_error = "device " + std::to_string(mh->devs[(size_t)d].device) + ": " + mh->devs[(size_t)d].err;
             return mh->devs[(size_t)d].rc;
+        }
+    if (stateful)  // the state the batch's last row left (shards without rows decoded nothing and keep the old state until now)
+        for (int d = ndev - 1; d >= 0; --d) {
+            int64_t lo, hi;
+            multi_range(batch, ndev, d, lo, hi);
+            if (hi > lo) { multi_copy_schedule_state(mh, d); break; }
         }
     // packed decisions that arrived on the root: unpack them into the caller's array there
     bool any = false;

@@ -401,6 +401,18 @@ class HipBpMultiEngine:
         except Exception:
             pass
 
+    def schedule_order(self):
+        """The order serial_relative / the random schedule left behind (one state for all GPUs: every call ends by copying the
+        state of the batch's last row to every handle, ``multi_device.h``)."""
+        return self.subs[0].schedule_order()
+
+    def soft_info_decode_batch(self, soft_syndromes, cutoff, sigma, want_llr=True):
+        """Soft-syndrome decoding is a per-handle call in the C ABI (include/ldpc_hip.h): it runs on the first GPU of
+        ``device_ids``, unsharded -- same results as the single-GPU engine."""
+        if _is_torch(soft_syndromes) and soft_syndromes.is_cuda and soft_syndromes.device.index != self.subs[0].device:
+            raise ValueError(f"soft_syndromes must live on cuda:{self.subs[0].device} (the first of device_ids)")
+        return self.subs[0].soft_info_decode_batch(soft_syndromes, cutoff, sigma, want_llr=want_llr)
+
     def set_staging(self, force):
         """Testing aid (``ldpc_hip_bp_multi_set_staging``): route device tensors through the peer-copy path on their own GPU too."""
         _lib.check(self._lib.ldpc_hip_bp_multi_set_staging(self._mh, int(bool(force))))

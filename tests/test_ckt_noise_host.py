@@ -209,3 +209,20 @@ def test_reader_against_an_independent_flattening_of_random_programs(seed):
     got = parse_dem_text(text)
     assert [(e.probability, e.detectors, e.observables) for e in got.errors] == want["errors"], text
     assert (got.num_detectors, got.num_observables) == (want["nd"], want["no"]), text
+
+
+def test_window_decoder_restricts_a_serial_order_to_the_occupied_columns():
+    """A window matrix with empty columns + schedule='serial' with an explicit order: the order handed to the inner decoder
+    is a list (the decoder's own type check, pyx:620-623) of the occupied columns in their old relative order."""
+    import scipy.sparse as sp
+    from ldpc_amd.ckt_noise.bposd_overlapping_window import _WindowBpOsd
+    h = sp.csr_matrix(np.array([[1, 0, 1, 0, 0, 1], [0, 0, 1, 0, 1, 1]], dtype=np.uint8))  # columns 1 and 3 are empty
+    w = np.array([0.1, 0.6, 0.1, 0.2, 0.1, 0.1])
+    dec = _WindowBpOsd(h, w, dict(schedule="serial", serial_schedule_order=[5, 4, 3, 2, 1, 0], osd_method="osd_0", osd_order=0,
+                                 bp_method="minimum_sum", max_iter=0))
+    assert list(dec.cols) == [0, 2, 4, 5] and list(dec.static_ones) == [1]
+    order = dec.inner.serial_schedule_order
+    assert [int(v) for v in order] == [3, 2, 1, 0]  # old columns 5, 4, 2, 0
+    assert dec.inner.max_iter == 6  # max_iter = 0 means the FULL width's n
+    with pytest.raises(ValueError):
+        _WindowBpOsd(h, w, dict(schedule="serial", serial_schedule_order=[0, 1, 2], osd_method="osd_0", osd_order=0))

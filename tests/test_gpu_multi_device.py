@@ -129,3 +129,41 @@ def test_bad_device_lists_are_errors():
     h = _code()
     with pytest.raises(_lib.LdpcHipError, match="device"):
         HipBpMultiEngine(h.indptr, h.indices, 1200, np.full(1200, 0.05), 10, 0, 1.0, [0, 99])
+
+
+@pytest.mark.parametrize("kind", ["serial_relative", "random", "random_clock_seed"])
+def test_stateful_schedules_keep_one_state_over_all_handles(kind):
+    """serial_relative / the random serial schedule carry their order (and generator) from call to call (bp.hpp:467-483):
+    a SEQUENCE of sharded calls must equal the same sequence on one GPU -- including batches that leave shards without rows."""
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    p = 0.06
+    one, many = _engines(h, p, 12, 0, 1.0, [0, 0, 0])
+    for e in (one, many):
+        if kind == "serial_relative":
+            e.set_schedule("serial_relative")
+        else:
+            e.set_schedule("serial")
+            e.set_random_serial(True, 1234)
+    if kind == "random_clock_seed":  # seed 0 = every handle reads the clock on its own: the first call must still use ONE generator
+        many.set_random_serial(True, 0)
+        s = one.gen_bsc_syndromes(7, p, shot0=0, shots=64 * 3 + 5)
+        got = many.decode_batch(s)
+        orders = [sub.schedule_order() for sub in many.subs]
+        assert all(np.array_equal(orders[0], o) for o in orders[1:])
+        assert got[3].any()
+        return
+    for shot0, B in ((0, 200), (300, 1), (400, 64 * 3 + 9), (900, 70)):  # B = 1 and 70: shards without rows
+        s = one.gen_bsc_syndromes(7, p, shot0=shot0, shots=B)
+        _same(one.decode_batch(s), many.decode_batch(s))
+        assert np.array_equal(one.schedule_order(), many.schedule_order())
+        assert all(np.array_equal(one.schedule_order(), sub.schedule_order()) for sub in many.subs)
+
+
+def test_soft_info_on_a_multi_engine_runs_on_its_first_gpu():
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    one, many = _engines(h, 0.05, 20, 1, 0.9, [0, 0])
+    rng = np.random.default_rng(5)
+    soft = rng.normal(1.0, 0.8, size=(100, h.shape[0]))
+    _same(one.soft_info_decode_batch(soft, 2.0, 0.7), many.soft_info_decode_batch(soft, 2.0, 0.7))
