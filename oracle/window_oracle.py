@@ -5,10 +5,15 @@ Restates ``BaseOverlappingWindowDecoder._corr_multiple_rounds`` / ``decode`` / `
 ``BpOsdOverlappingWindowDecoder`` hooks (bposd_overlapping_window.py:38-58: weights = the priors array itself, minimum
 weight 0.0, one ``BpOsdDecoder(round_dcm, error_channel=list(weights), **config)`` per window, built on first use).
 
-PARITY UNPINNED for the loop itself: the reference module starts with ``import stim`` (absent from this image), so it
-cannot be imported here, and no test of the reference exercises it.  The window decodes inside the loop ARE pinned: they
-go through ``oracle.RefBpOsd`` (the real reference BP + OSD, oracle/_ref) when that library exists, else through
-``oracle.BpOracle`` (itself pinned to the reference by tests/golden/).  ``BpOsdDecoder.decode``'s shortcut for an
+PINNED (round 3): tests/golden/window_*.npz are produced by the reference's OWN modules -- tests/golden/make_golden_window.py
+imports base_overlapping_window_decoder.py and bposd_overlapping_window.py byte-identical from a scratch build of the
+reference (behind a ``stim`` placeholder that raises on any use; the constructor's stim conversion is the only part bypassed)
+and runs ``_corr_multiple_rounds_batch`` / ``decode_batch`` / ``decode`` around the reference's own ``BpOsdDecoder``.  This
+restatement reproduces those fixtures byte for byte (tests/test_ckt_noise_host.py), and
+tests/test_golden_generators.py re-runs the generator in --check mode wherever /root/reference is present.  The window
+decodes inside the loop go through ``oracle.RefBpOsd`` (the real reference BP + OSD, oracle/_ref) when that library
+exists, else through ``oracle.BpOracle`` (itself pinned to the reference by tests/golden/).
+``BpOsdDecoder.decode``'s shortcut for an
 all-zero syndrome (bposd_decoder.pyx:118-123) is part of the restatement.
 """
 from __future__ import annotations

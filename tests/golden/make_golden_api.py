@@ -19,28 +19,9 @@ TESTS = os.path.dirname(HERE)
 REF = "/root/reference"
 scratch = sys.argv[1] if len(sys.argv) > 1 else "/tmp/ldpc_ref_py"
 
-SETUP = '''
-import numpy as np
-from setuptools import setup, Extension
-from Cython.Build import cythonize
-exts = [Extension(f"ldpc.{m}._{m}", [f"src_python/ldpc/{m}/_{m}.pyx"], include_dirs=[np.get_include(), "src_cpp", "include/robin_map"],
-                  extra_compile_args=["-std=c++2a", "-O3"], language="c++") for m in ("bp_decoder", "bposd_decoder")]
-setup(name="ldpc_probe", ext_modules=cythonize(exts, include_path=["src_python"], language_level=3), package_dir={"": "src_python"}, packages=[])
-'''
-
-if not os.path.exists(os.path.join(scratch, "src_python", "ldpc", "bp_decoder")) or not any(
-        f.endswith(".so") for f in os.listdir(os.path.join(scratch, "src_python", "ldpc", "bp_decoder"))):
-    os.makedirs(scratch, exist_ok=True)
-    for d in ("src_python", "src_cpp", "include"):
-        shutil.rmtree(os.path.join(scratch, d), ignore_errors=True)
-        shutil.copytree(os.path.join(REF, d), os.path.join(scratch, d))
-    subprocess.run(["chmod", "-R", "u+w", scratch], check=True)
-    open(os.path.join(scratch, "setup_probe.py"), "w").write(SETUP)
-    subprocess.run([sys.executable, "setup_probe.py", "build_ext", "--inplace"], cwd=scratch, check=True, capture_output=True)
-open(os.path.join(scratch, "src_python", "ldpc", "__init__.py"), "w").write(
-    "from ldpc.bp_decoder import BpDecoder, SoftInfoBpDecoder\nfrom ldpc.bposd_decoder import BpOsdDecoder\n")
-
-sys.path.insert(0, os.path.join(scratch, "src_python"))
+sys.path.insert(0, HERE)
+import ref_python  # noqa: E402  (the scratch build of the reference: tests/golden/ref_python.py)
+ref_python.use(scratch)
 sys.path.insert(0, TESTS)
 import ldpc  # noqa: E402  (the reference)
 from ldpc.bp_decoder import io_test  # noqa: E402

@@ -1,48 +1,125 @@
 #!/usr/bin/env python3
-"""Golden fixtures for the overlapping-window decoders (ckt_noise/base_overlapping_window_decoder.py:96-214,
-bposd_overlapping_window.py).  Build container only:
+"""Golden fixtures for the overlapping-window decoders, produced by the REFERENCE'S OWN window loop and decoders.
 
-    make -C oracle ref && python tests/golden/make_golden_window.py
+Build container only:
 
-What is pinned and what is not: every window decode inside a fixture was done by the REAL reference BP + OSD
-(oracle/_ref/libref_bp.so).  The window loop around them is the restatement in oracle/window_oracle.py -- the
-reference's own module cannot be imported here (it starts with ``import stim``, which this image lacks), and the
-reference has no test of it.  Models are phenomenological detector error models written as DEM text
-(tests/window_util.py); shots are sampled from the model's own priors with numpy's PCG64.
+    python tests/golden/make_golden_window.py [--check]
+
+tests/golden/ref_python.py builds the reference's Python package in a scratch directory.  The two
+modules under test -- ``ldpc/ckt_noise/base_overlapping_window_decoder.py`` (the loop: ``decode_batch`` :139-175,
+``_corr_multiple_rounds_batch`` :177-226, ``_get_decoder`` :238-261, ``current_round_inds`` :279-334) and
+``ldpc/ckt_noise/bposd_overlapping_window.py`` (the BP+OSD hooks :29-58) -- are imported byte-identical to /root/reference's
+files and run around the reference's own ``BpOsdDecoder``.
+
+Both start with ``import stim``, which this image lacks.  What they need from it at import time is only the NAME
+``stim.DetectorErrorModel`` inside two signature annotations; so a placeholder module named ``stim`` is registered whose
+attributes are inert tokens: evaluating an annotation keeps one, but calling it, instantiating it, or reading anything
+from it RAISES -- if the code path exercised here ever touched stim's functionality, this script would fail instead of
+producing a fixture.  The constructor (:8-53) is the one place that does (it converts a ``stim.DetectorErrorModel`` to
+matrices and reads ``model.num_detectors``), so the object is made with ``__new__`` and given the attributes that
+constructor would set, with the matrices of tests/window_util.py (the same model the DEM text in the fixture describes).
+
+``--check`` regenerates in memory and compares with the committed files instead of writing.  Models are phenomenological
+detector error models; shots are sampled from the model's own priors with numpy's PCG64.
 """
 from __future__ import annotations
 
 import os
 import sys
+import types
 
 import numpy as np
+import scipy.sparse as sp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import ref_python  # noqa: E402
+
+
+class _StimToken:
+    """What ``stim.<name>`` evaluates to: good for sitting in an annotation, fatal for anything else."""
+
+    def __init__(self, name):
+        object.__setattr__(self, "_name", name)
+
+    def _refuse(self, *a, **k):
+        raise RuntimeError(f"the code under test USED {object.__getattribute__(self, '_name')}: stim is not in this image, "
+                           "the window loop is NOT pinned by this run")
+
+    __call__ = __getattr__ = __getitem__ = __iter__ = __len__ = __bool__ = _refuse
+
+
+class _StimPlaceholder(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _StimToken("stim." + name)
+
+
+assert "stim" not in sys.modules
+sys.modules["stim"] = _StimPlaceholder("stim")
+
+ldpc = ref_python.use()
+from ldpc.ckt_noise import base_overlapping_window_decoder as ref_base  # noqa: E402  (the reference's modules)
+from ldpc.ckt_noise import bposd_overlapping_window as ref_bposd  # noqa: E402
+from ldpc.ckt_noise import config as ref_config  # noqa: E402
+
+for mod in (ref_base, ref_bposd, ref_config):
+    ref_python.assert_untouched(mod)
+
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import oracle  # noqa: E402
-from oracle.window_oracle import WindowOracle  # noqa: E402
-from ldpc_amd import codes  # noqa: E402
+from ldpc_amd import codes  # noqa: E402  (our own code constructions)
 from window_util import phenomenological_dem, phenomenological_matrices, ring_code, sample_shots  # noqa: E402
 
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE
+CHECK = "--check" in sys.argv
+
+
+def reference_window_decoder(check, obs, pri, *, decodings, window, commit, num_checks, decoder_config):
+    """``BpOsdOverlappingWindowDecoder`` as its constructors would leave it (bposd_overlapping_window.py:13-21 and
+    base_overlapping_window_decoder.py:30-53), minus the stim conversion."""
+    w = ref_bposd.BpOsdOverlappingWindowDecoder.__new__(ref_bposd.BpOsdOverlappingWindowDecoder)
+    w.decoder_config = ref_config.DEFAULT_BPOSD_DECODER_ARGS | decoder_config          # bposd_overlapping_window.py:14-16
+    w.decodings, w.window, w.commit, w.num_checks = decodings, window, commit, num_checks  # base:30-33
+    w.dem_matrices = types.SimpleNamespace(check_matrix=sp.csc_matrix(check), observables_matrix=sp.csc_matrix(obs),
+                                           priors=np.array(pri, dtype=np.float64))      # base:35-37 (dem_matrices.py's DemMatrices fields)
+    w.num_detectors = check.shape[0]                                                     # base:38
+    rounds = (window - commit) + decodings * commit                                      # base:41-42
+    assert w.num_detectors % rounds == 0
+    w.dcm = w._get_dcm()                                                                 # base:51
+    w.logical_observables_matrix = w._get_logical_observables_matrix()                   # base:52
+    return w
 
 
 def run(name, h, rounds, p_data, p_meas, logical, *, decodings, window, commit, shots, seed, scale=1.0, **cfg):
-    assert oracle.have_ref(), "make -C oracle ref first"
     assert (window - commit) + decodings * commit == rounds
     text = phenomenological_dem(h, rounds, p_data, p_meas, logical)
     check, obs, pri = phenomenological_matrices(h, rounds, p_data, p_meas, logical)
     synd, _ = sample_shots(check, np.minimum(pri * scale, 0.5), shots, seed)
     synd[0] = 0  # the all-zero shot takes BpOsdDecoder.decode's shortcut in every window
-    w = WindowOracle(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], inner="ref", **cfg)
-    preds, corrs, after = w.decode_batch(synd)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), name=name, dem_text=text, num_checks=h.shape[0], decodings=decodings,
-                        window=window, commit=commit, config_keys=np.array(sorted(cfg)), config_vals=np.array([str(cfg[k]) for k in sorted(cfg)]),
-                        shots=np.packbits(synd, axis=1, bitorder="little"), num_detectors=synd.shape[1],
-                        predictions=preds, corrections=corrs, shots_after=np.packbits(after, axis=1, bitorder="little"),
-                        priors_after=w.weights)
+    w = reference_window_decoder(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], decoder_config=cfg)
+    after = synd.copy()
+    corrs = w._corr_multiple_rounds_batch(after)   # base:177-226 (updates `after` in place, as the reference does with the caller's shots)
+    w2 = reference_window_decoder(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], decoder_config=cfg)
+    preds = w2.decode_batch(synd.copy())           # base:139-175: the public entry, on a fresh object
+    assert np.array_equal(preds, np.stack([(sp.csr_matrix(obs) @ c) % 2 for c in corrs]).astype(bool))
+    one = reference_window_decoder(check, obs, pri, decodings=decodings, window=window, commit=commit, num_checks=h.shape[0], decoder_config=cfg)
+    assert np.array_equal(one.decode(synd[shots // 2].copy()), preds[shots // 2].astype(np.uint8))  # base:68-94 + 96-137: the per-shot route agrees
+    out = dict(name=name, dem_text=text, num_checks=h.shape[0], decodings=decodings, window=window, commit=commit,
+               config_keys=np.array(sorted(cfg)), config_vals=np.array([str(cfg[k]) for k in sorted(cfg)]),
+               shots=np.packbits(synd, axis=1, bitorder="little"), num_detectors=synd.shape[1], predictions=preds, corrections=corrs,
+               shots_after=np.packbits(after, axis=1, bitorder="little"), priors_after=w.dem_matrices.priors)
+    path = os.path.join(OUT, name + ".npz")
+    if CHECK:
+        g = np.load(path)
+        bad = [k for k in ("shots", "predictions", "corrections", "shots_after", "priors_after", "dem_text") if not np.array_equal(g[k], out[k])]
+        print(f"{name}: {'== committed fixture' if not bad else 'DIFFERS from the committed fixture in ' + str(bad)}")
+        assert not bad
+        return
+    np.savez_compressed(path, generated_by="the reference's BaseOverlappingWindowDecoder._corr_multiple_rounds_batch / decode_batch "
+                                           "(base_overlapping_window_decoder.py:139-226) around the reference's own BpOsdDecoder", **out)
     print(f"{name}: {shots} shots, {check.shape[0]} detectors x {check.shape[1]} errors, corrections with weight "
           f"{corrs.sum(axis=1).mean():.2f} on average, {int(preds.sum())} flipped observables")
 
