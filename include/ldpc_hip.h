@@ -315,6 +315,9 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * otherwise prefers a lane = entry variant that keeps every lane busy with one transcendental).  That variant gives a syndrome
  * one wavefront, or -- where LDS leaves room for fewer than six syndromes per compute unit, e.g. a 768 x 1600 matrix -- all the
  * wavefronts of a workgroup (its "team" form); 4 = as 3, one wavefront per syndrome, 5 = as 3, a workgroup per syndrome.
+ * Min-sum on matrices with rows of weight <= 4 and columns of weight 1 .. 2 (rotated / toric surface codes, ring codes; m <= 256)
+ * takes a third variant in modes -1, 1 and 6: lane = EDGE, a row's entries in four neighbouring lanes, every message in a
+ * register for the whole decode (bp_edge_kernel.h); 6 = that variant where it applies, else as -1.
  * Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 

@@ -1,0 +1,195 @@
+// bp_edge_kernel.h -- bp_edge_kernel: min-sum with LANE = EDGE and the messages in REGISTERS (BASELINE config 3)
+// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+#pragma once
+
+#include "bp_device_common.h"
+
+// For the codes of the surface-code family -- rows of weight <= 4, columns of weight <= 2 (rotated / toric surface codes,
+// ring codes) -- the node-per-lane kernel (bp_wave_kernel.h) spends ~745 wave-instructions per syndrome-iteration on 840
+// edges: address arithmetic, position-table reads, a separate syndrome sweep, every message through LDS twice per pass.
+// Here a wavefront still owns one syndrome, but
+//   * a LANE owns one EDGE per round (slot s = 64 r + lane, r < R rounds), and a row's (up to) four edges sit in four
+//     neighbouring lanes (slot = 4 i + k): the check update (bp.hpp:220-273) needs the other entries of the row -- two
+//     DPP quad permutations -- and the row's sign parity -- one ballot and scalar bit tricks on the 64-bit lane mask;
+//   * the edge's message lives in a REGISTER for the whole decode (R of them per lane); the bit update (bp.hpp:276-318)
+//     needs the one other entry of the column, which sits in some other lane and round: every lane stores its
+//     check-to-bit message at its own slot of a wave-private LDS array and reads its partner's (2 LDS operations per edge
+//     and iteration instead of 8, and no index tables: the partner's address is a register);
+//   * hard decisions never leave the scalar unit: ballots of (log-ratio <= 0), nibble parities, XOR with the syndrome mask.
+// Arithmetic, per edge and in the reference's association:
+//   check pass   magnitude = min over the OTHER entries of |bit_to_check| (DBL_MAX if there is none) -- min is exact and
+//                order-free, NaNs are skipped as `abs < temp` skips them (bp.hpp:241-247, :257-259, :268-270; v_min_f64
+//                returns the other operand for a quiet NaN); sign = parity(syndrome byte + #{entries <= 0}) + own
+//                (bp.hpp:236-262); message = magnitude * (+-alpha) (bp.hpp:264-266).
+//   bit pass     column entries c0 (lower row), c1:  log-ratio = (prior + c0) + c1 (bp.hpp:278-281);
+//                bit_to_check_0 = prior + (0.0 + c1), bit_to_check_1 = (prior + c0) + 0.0 (bp.hpp:279, :313-316).
+//                Both equal prior + (the other entry) EXACTLY: x + 0.0 differs from x only for x = -0.0, and neither
+//                0.0 + c1 feeding a sum with the prior nor prior + c0 can be a -0.0 that matters -- the prior is
+//                log((1 - p) / p), never -0.0, and a sum is -0.0 only if both terms are.  A column of weight one reads
+//                a slot that holds +0.0 for good: prior + 0.0.
+// The reference's minimum starts from DBL_MAX and replaces it only by something SMALLER (bp.hpp:240-247): an infinite
+// |bit_to_check| never enters it.  Hence the clamp min(., DBL_MAX) after the butterfly -- and hence phantom lanes (a row
+// lighter than four, the padding behind the last row) may hold +inf for good (prior +inf, partner = the +0.0 slot): clamped
+// to DBL_MAX in the minimum, positive in the sign ballot, and their "log-ratio" is +inf or, at worst, inf - inf = NaN:
+// never <= 0, so they drop out of the decision ballots by themselves.
+// Results are bit-identical to bp_wave_kernel and to the reference (tests/test_gpu_parity.py, test_gpu_fuzz.py).
+struct EdgeArgs {
+    int32_t m, n, max_iter;
+    double ms_scaling_factor;
+    int64_t batch;
+    const double *prior_s;     // [R * 64] prior of the slot's column; phantom: +inf
+    const uint16_t *partner;   // [R * 64] slot of the other entry of the slot's column; none / phantom: R * 64 (the +0.0 slot)
+    const uint8_t *kind;       // [R * 64] 0 phantom, 1 first entry of its column (lower row), 2 second entry
+    const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
+    const uint8_t *synd;       // [batch][m]
+    uint8_t *decoding;         // [batch][n]
+    double *llr;               // [batch][n] or nullptr
+    int32_t *iters;            // [batch] or nullptr
+    uint8_t *conv;             // [batch] or nullptr
+    unsigned long long *next;  // device-wide work counter (zeroed before launch)
+};
+
+__host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }
+
+namespace edge_detail {
+// quad permutations of a double (two 32-bit DPP moves: 64-bit DPP allows row_newbcast only)
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// min(|a|, |b|) as ONE v_min_f64 with source modifiers (fmin() would first canonicalise both operands: two more instructions);
+// a quiet NaN operand yields the other operand, which is how `if (abs < temp) temp = abs` treats it
+__device__ __forceinline__ double min_abs(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double fmin_pos(double a, double b) {  // both >= +0 or NaN
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// per lane: bit `lane` of the wave-uniform mask selects b, else a -- one v_cndmask_b32 reading the mask from an SGPR pair
+__device__ __forceinline__ int select_by_mask(int a, int b, uint64_t mask) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+// every bit of a nibble := XOR of the nibble's four bits (a row's four lanes)
+__device__ __forceinline__ uint64_t nibble_parity_low(uint64_t x) {  // result in bit 0 of every nibble; the other bits are garbage
+    x ^= x >> 1;
+    x ^= x >> 2;
+    return x;
+}
+__device__ __forceinline__ uint64_t spread_nibble(uint64_t low) {  // bit 0 of every nibble -> all four bits
+    const uint32_t a = ((uint32_t)low & 0x11111111u) * 15u, b = ((uint32_t)(low >> 32) & 0x11111111u) * 15u;
+    return ((uint64_t)b << 32) | a;
+}
+}  // namespace edge_detail
+
+template <int R>
+__global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
+    using namespace edge_detail;
+    extern __shared__ __attribute__((aligned(16))) unsigned char edge_lds[];
+    typedef __attribute__((address_space(3))) double lds_f64;
+    lds_f64 *X = (lds_f64 *)edge_lds;  // [R * 64] check_to_bit of every slot, [R * 64] = +0.0 for good
+    const int lane = threadIdx.x;
+    const int m = a.m, n = a.n;
+    constexpr int ZERO = R * 64;
+    constexpr uint64_t LOW = 0x1111111111111111ull;
+
+    // per lane and round, for the whole kernel: prior, partner address; per round: which lanes are first / second entries
+    double pr[R], msg[R];
+    int paddr[R];
+    uint64_t k0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int s = r * 64 + lane;
+        pr[r] = a.prior_s[s];
+        paddr[r] = (int)a.partner[s];
+        k0[r] = __ballot(a.kind[s] == 1);
+    }
+    const double dbl_max = DBL_MAX;
+    if (lane == 0) X[ZERO] = 0.0;
+
+    for (;;) {
+        unsigned long long pulled = 0;
+        if (lane == 0) pulled = atomicAdd(a.next, 1ull);
+        const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        if (b >= a.batch) break;
+        // this syndrome's bytes as lane masks: bit l of sy[r] = (byte & 1) of the row lane l serves in round r (the same in the
+        // row's four lanes); a byte above 1 can never be matched (bp.hpp:300)
+        uint64_t sy[R];
+        bool never = false;
+        const uint8_t *sb = a.synd + b * m;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = r * 16 + (lane >> 2);
+            const int byte = row < m ? (int)sb[row] : 0;
+            sy[r] = __ballot((byte & 1) != 0);
+            never = never || __ballot(byte > 1) != 0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) msg[r] = pr[r];  // initialise_log_domain_bp (bp.hpp:147-157)
+
+        int it = 0;
+        bool unsat = true;
+        do {
+            ++it;
+            const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+            const int alo = __double2loint(alpha), ahi = __double2hiint(alpha), nhi = ahi ^ (int)0x80000000;
+            // ---- check pass: msg[r] (bit_to_check) -> msg[r] (check_to_bit), stored at the slot ----
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double cur = msg[r];
+                const uint64_t neg = __ballot(cur <= 0.0);
+                const double x1 = quad_perm<0xB1>(cur);               // lane ^ 1
+                const double pairmin = min_abs(cur, x1);
+                const double other = quad_perm<0x4E>(pairmin);        // the other pair's minimum (lane ^ 2)
+                const double mag = fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
+                const uint64_t flip = spread_nibble(nibble_parity_low(neg ^ (sy[r] & LOW))) ^ neg;  // row parity incl. the syndrome, own sign out
+                const double c = mag * __hiloint2double(select_by_mask(ahi, nhi, flip), alo);
+                msg[r] = c;
+                X[r * 64 + lane] = c;
+            }
+            // ---- bit pass: the partner's message; log-ratio, decision, new bit_to_check ----
+            uint64_t bad = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double cp = X[paddr[r]];
+                const double c = msg[r];
+                const double b2c = pr[r] + cp;
+                const double l1 = b2c + c;          // second entry of its column: (prior + c0) + c1 with c0 = the partner's
+                const double l0 = (pr[r] + c) + cp; // first entry: c0 = its own
+                const uint64_t d1 = __ballot(l1 <= 0.0);
+                const uint64_t d = d1 ^ ((__ballot(l0 <= 0.0) ^ d1) & k0[r]);  // (phantom lanes: neither)
+                bad |= nibble_parity_low(d) ^ sy[r];  // candidate syndrome vs syndrome (bp.hpp:292-302), bit 0 of every nibble
+                msg[r] = b2c;
+            }
+            unsat = never || (bad & LOW) != 0;
+        } while (unsat && it < a.max_iter);
+
+        // ---- outputs (bp.hpp:62,65,69,71): by the lanes that own the first entry of a column, from the last iteration's messages ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = r * 64 + lane;
+            if (a.kind[s] == 1) {
+                const double l0 = (pr[r] + X[s]) + X[paddr[r]];
+                const int j = a.scol[s];
+                a.decoding[b * n + j] = l0 <= 0.0 ? 1 : 0;
+                if (a.llr) a.llr[b * n + j] = l0;
+            }
+        }
+        if (lane == 0) {
+            if (a.iters) a.iters[b] = it;
+            if (a.conv) a.conv[b] = unsat ? 0 : 1;
+        }
+        // The wavefront must be whole again before lane 0 pulls the next syndrome: without this (convergent) barrier the
+        // compiler threads this `lane == 0` block into the one at the top of the loop and the readfirstlane there runs with
+        // lane 0 masked off -- every other lane's `pulled` is 0, i.e. syndrome 0 for ever (seen with R = 1).
+        __builtin_amdgcn_wave_barrier();
+    }
+}

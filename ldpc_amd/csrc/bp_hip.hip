@@ -35,6 +35,7 @@
 //   bp_spread_kernels.h  bp_spread_*_kernel      one launch per pass, a tile spread over the chip (small batches, stragglers)
 //   bp_small_kernel.h    bp_small_kernel         messages resident in LDS (surface / bivariate-bicycle sized codes), slots per workgroup
 //   bp_wave_kernel.h     bp_wave_kernel, bp_wave_ps_kernel   same regime, bounded degrees: one wavefront per syndrome, no workgroup barriers
+//   bp_edge_kernel.h     bp_edge_kernel                      min-sum, rows <= 4 / columns <= 2 (surface-code family): lane = edge, messages in registers
 //                        (lane = node; for product-sum lane = entry)
 //   bp_serial_kernels.h  bp_serial_kernel, bp_softinfo_kernel   serial schedule, soft-syndrome serial min-sum
 //   osd_kernels.h        osd0[_reg]_kernel, osdw[_reg]_kernel, osd_big_kernel   OSD-0 / OSD-E / OSD-CS post-processing
@@ -48,6 +49,7 @@
 #include "bp_relative_kernel.h"
 #include "bp_small_kernel.h"
 #include "bp_wave_kernel.h"
+#include "bp_edge_kernel.h"
 #include "osd_kernels.h"
 #include "io_kernels.h"
 
@@ -113,6 +115,8 @@ struct ldpc_hip_bp {
     int wave_ps_dr = 0, wave_ps_dc = 0;  // likewise for bp_wave_ps_kernel
     DeviceBuf wp_rdeg, wp_col, wp_epos;
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
+    int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
+    DeviceBuf e_partner, e_kind, e_scol, e_prior;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
     DeviceBuf tile_state, handoff_list;
     unsigned *h_counters = nullptr;  // pinned host copy of the device counters
@@ -325,7 +329,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -464,9 +468,9 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
 
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 5)
+    if (mode < -1 || mode > 6)
         return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (auto), 0 (off), 1 (whenever one fits), 2 (slot kernel only), 3 (lane = node wavefront kernel), "
-                                          "4 (that kernel, one wavefront per syndrome) or 5 (that kernel, a workgroup per syndrome)");
+                                          "4 (that kernel, one wavefront per syndrome), 5 (that kernel, a workgroup per syndrome) or 6 (lane = edge kernel where it applies)");
     h->small_mode = mode;
     return LDPC_HIP_OK;
 }
@@ -1354,6 +1358,91 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     return LDPC_HIP_OK;
 }
 
+// ---- bp_edge_kernel (min-sum, lane = edge, messages in registers): rows <= 4, columns 1 .. 2 entries, 4 m <= 1024 slots ----
+struct EdgePlan {
+    int rounds = 0;  // 0: not applicable
+    void (*kern)(const EdgeArgs) = nullptr;
+};
+
+static EdgePlan plan_edge(const ldpc_hip_bp *h) {
+    EdgePlan p;
+    if (h->bp_method != LDPC_HIP_MINIMUM_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0) return p;
+    if (h->max_row_deg > 4 || h->max_col_deg > 2 || h->n > 65535) return p;
+    const int rounds = (4 * h->m + 63) / 64;
+    if (rounds > 16) return p;
+    std::vector<char> seen((size_t)h->n, 0);  // a column without entries has no lane to write its outputs
+    for (int32_t j : h->h_col_idx) seen[(size_t)j] = 1;
+    for (char c : seen) if (!c) return p;
+    static void (*const kerns[17])(const EdgeArgs) = {nullptr, bp_edge_kernel<1>, bp_edge_kernel<2>, bp_edge_kernel<3>, bp_edge_kernel<4>,
+        bp_edge_kernel<5>, bp_edge_kernel<6>, bp_edge_kernel<7>, bp_edge_kernel<8>, bp_edge_kernel<9>, bp_edge_kernel<10>, bp_edge_kernel<11>,
+        bp_edge_kernel<12>, bp_edge_kernel<13>, bp_edge_kernel<14>, bp_edge_kernel<15>, bp_edge_kernel<16>};
+    p.rounds = rounds;
+    p.kern = kerns[rounds];
+    return p;
+}
+
+__global__ void edge_prior_kernel(const double *llr0, const int32_t *scol, const uint8_t *kind, int slots, double *out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < slots) out[s] = kind[s] ? llr0[scol[s]] : __builtin_inf();  // phantom lanes: +inf (bp_edge_kernel.h)
+}
+
+// slot tables of bp_edge_kernel: entry k of row i sits in slot 4 i + k (see bp_edge_kernel.h)
+static int ensure_edge_tables(ldpc_hip_bp *h, const EdgePlan &p) {
+    if (h->edge_rounds == p.rounds) return LDPC_HIP_OK;
+    const int slots = p.rounds * 64;
+    std::vector<uint16_t> partner((size_t)slots, (uint16_t)slots);
+    std::vector<uint8_t> kind((size_t)slots, 0);
+    std::vector<int32_t> scol((size_t)slots, 0), first((size_t)h->n, -1);
+    for (int i = 0; i < h->m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int s = 4 * i + (e - h->h_row_ptr[(size_t)i]), j = h->h_col_idx[(size_t)e];
+            scol[(size_t)s] = j;
+            if (first[(size_t)j] < 0) { first[(size_t)j] = s; kind[(size_t)s] = 1; }  // rows ascend: the column's first entry (bp.hpp:278)
+            else { kind[(size_t)s] = 2; partner[(size_t)s] = (uint16_t)first[(size_t)j]; partner[(size_t)first[(size_t)j]] = (uint16_t)s; }
+        }
+    int rc;
+    if ((rc = h->e_partner.ensure((size_t)slots * 2)) || (rc = h->e_kind.ensure((size_t)slots)) || (rc = h->e_scol.ensure((size_t)slots * 4)) ||
+        (rc = h->e_prior.ensure((size_t)slots * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
+    HIPCHK(hipMemcpy(h->e_partner.p, partner.data(), (size_t)slots * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_kind.p, kind.data(), (size_t)slots, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_scol.p, scol.data(), (size_t)slots * 4, hipMemcpyHostToDevice));
+    h->edge_rounds = p.rounds;
+    return LDPC_HIP_OK;
+}
+
+static int decode_edge(ldpc_hip_bp *h, const EdgePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                       int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_edge_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    const int slots = p.rounds * 64;
+    // (the priors may have changed since the last call: ldpc_hip_bp_set_channel)
+    hipLaunchKernelGGL(edge_prior_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, (const int32_t *)h->e_scol.p,
+                       (const uint8_t *)h->e_kind.p, slots, (double *)h->e_prior.p);
+    EdgeArgs a = {};
+    a.m = h->m; a.n = h->n; a.max_iter = h->max_iter;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.prior_s = (const double *)h->e_prior.p; a.partner = (const uint16_t *)h->e_partner.p;
+    a.kind = (const uint8_t *)h->e_kind.p; a.scol = (const int32_t *)h->e_scol.p;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    const size_t dyn = edge_lds_bytes(p.rounds);
+    // one wavefront per workgroup, as many resident as registers (4 per SIMD) and LDS allow
+    int64_t per_cu = (int64_t)((160u * 1024u) / (dyn + 64));
+    if (per_cu > 16) per_cu = 16;
+    int64_t groups = batch < 256 * per_cu ? batch : 256 * per_cu;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3(64), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
 // nt: non-temporal cache policy for the message traffic (tiles that outgrow the 256 MB MALL; see MsgBufT)
 static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
@@ -1376,6 +1465,10 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         if (h->small_mode != 2 && h->small_mode < 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
             const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
+        }
+        if (h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) {  // min-sum on the surface-code family: lane = edge
+            const EdgePlan ep = plan_edge(h);
+            if (ep.rounds) return decode_edge(h, ep, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {
             const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr, batch);

@@ -146,7 +146,7 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_set_osd_kernel(self._h, int(mode)))
 
     def set_small_code_kernel(self, mode):
-        """On-chip kernels for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS, 2 slot kernel only, 3 lane = node wavefront kernel only."""
+        """On-chip kernels for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS, 2 slot kernel only, 3 lane = node wavefront kernel only (4 / 5: one wavefront / a workgroup per syndrome), 6 lane = edge kernel where it applies."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))
 
     def workspace_bytes(self, batch):
