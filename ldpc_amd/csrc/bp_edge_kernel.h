@@ -29,7 +29,7 @@
 //                a slot that holds +0.0 for good: prior + 0.0.
 // The reference's minimum starts from DBL_MAX and replaces it only by something SMALLER (bp.hpp:240-247): an infinite
 // |bit_to_check| never enters it.  Hence the clamp min(., DBL_MAX) after the butterfly -- and hence phantom lanes (a row
-// lighter than four, the padding behind the last row) may hold +inf for good (prior +inf, partner = the +0.0 slot): clamped
+// lighter than four, the padding behind the last row) may hold +inf for good (prior +inf, partner = a slot that holds +inf): clamped
 // to DBL_MAX in the minimum, positive in the sign ballot, and their "log-ratio" is +inf or, at worst, inf - inf = NaN:
 // never <= 0, so they drop out of the decision ballots by themselves.
 // Results are bit-identical to bp_wave_kernel and to the reference (tests/test_gpu_parity.py, test_gpu_fuzz.py).
@@ -37,8 +37,11 @@ struct EdgeArgs {
     int32_t m, n, max_iter;
     double ms_scaling_factor;
     int64_t batch;
-    const double *prior_s;     // [R * 64] prior of the slot's column; phantom: +inf
-    const uint16_t *partner;   // [R * 64] slot of the other entry of the slot's column; none / phantom: R * 64 (the +0.0 slot)
+    const double *prior_s;     // [R * 64] prior of the slot's column; phantom: +inf          (general form)
+    double prior_u;            // the one prior of every column                              (UNIFORM form: no prior registers)
+    const uint16_t *partner;   // [R * 64] slot of the other entry of the slot's column; none: R * 64 (the +0.0 slot); a phantom lane:
+                               // R * 64 + 1 (a slot that holds +inf for good)
+    int32_t chunk;             // syndromes pulled per visit to the work counter
     const uint8_t *kind;       // [R * 64] 0 phantom, 1 first entry of its column (lower row), 2 second entry
     const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
     const uint8_t *synd;       // [batch][m]
@@ -49,7 +52,7 @@ struct EdgeArgs {
     unsigned long long *next;  // device-wide work counter (zeroed before launch)
 };
 
-__host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }
+__host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }  // slots, +0.0, +inf
 
 namespace edge_detail {
 // quad permutations of a double (two 32-bit DPP moves: 64-bit DPP allows row_newbcast only)
@@ -66,9 +69,9 @@ __device__ __forceinline__ double min_abs(double a, double b) {
     asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ double fmin_pos(double a, double b) {  // both >= +0 or NaN
+__device__ __forceinline__ double fmin_pos(double a, double uniform_b) {  // both >= +0 or NaN; the second from an SGPR pair
     double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(uniform_b));
     return r;
 }
 // per lane: bit `lane` of the wave-uniform mask selects b, else a -- one v_cndmask_b32 reading the mask from an SGPR pair
@@ -76,6 +79,9 @@ __device__ __forceinline__ int select_by_mask(int a, int b, uint64_t mask) {
     int r;
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
     return r;
+}
+__device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value -> SGPR pair
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 // every bit of a nibble := XOR of the nibble's four bits (a row's four lanes)
 __device__ __forceinline__ uint64_t nibble_parity_low(uint64_t x) {  // result in bit 0 of every nibble; the other bits are garbage
@@ -89,8 +95,10 @@ __device__ __forceinline__ uint64_t spread_nibble(uint64_t low) {  // bit 0 of e
 }
 }  // namespace edge_detail
 
-template <int R>
-__global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
+// UNIFORM: all columns have the same prior (a decoder built from `error_rate`): it is a scalar, which frees 2 R registers per
+// lane -- a fifth resident wavefront per SIMD; the phantom lanes' +inf then comes from their partner slot instead of their prior.
+template <int R, bool UNIFORM>
+__global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const EdgeArgs a) {
     using namespace edge_detail;
     extern __shared__ __attribute__((aligned(16))) unsigned char edge_lds[];
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -101,27 +109,32 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
     constexpr uint64_t LOW = 0x1111111111111111ull;
 
     // per lane and round, for the whole kernel: prior, partner address; per round: which lanes are first / second entries
-    double pr[R], msg[R];
+    double prv[UNIFORM ? 1 : R], msg[R];
     int paddr[R];
     uint64_t k0[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int s = r * 64 + lane;
-        pr[r] = a.prior_s[s];
+        if (!UNIFORM) prv[r] = a.prior_s[s];
         paddr[r] = (int)a.partner[s];
         k0[r] = __ballot(a.kind[s] == 1);
     }
-    const double dbl_max = DBL_MAX;
-    if (lane == 0) X[ZERO] = 0.0;
+    const double pu = uniform_f64(a.prior_u);
+#define LDPC_EDGE_PRIOR(r) (UNIFORM ? pu : prv[UNIFORM ? 0 : (r)])
+    const double dbl_max = uniform_f64(DBL_MAX);
+    if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
+    const int64_t chunk = a.chunk;
 
     for (;;) {
         unsigned long long pulled = 0;
-        if (lane == 0) pulled = atomicAdd(a.next, 1ull);
-        const int64_t b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
-        if (b >= a.batch) break;
-        // this syndrome's bytes as lane masks: bit l of sy[r] = (byte & 1) of the row lane l serves in round r (the same in the
-        // row's four lanes); a byte above 1 can never be matched (bp.hpp:300)
+        if (lane == 0) pulled = atomicAdd(a.next, (unsigned long long)chunk);
+        const int64_t b0 = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+        if (b0 >= a.batch) break;
+        const int64_t b1 = b0 + chunk < a.batch ? b0 + chunk : a.batch;
+      for (int64_t b = b0; b < b1; ++b) {
+        // this syndrome's bytes as lane masks: bit 4 q of sy[r] = (byte & 1) of the row that lanes 4 q .. 4 q + 3 serve in round r;
+        // a byte above 1 can never be matched (bp.hpp:300)
         uint64_t sy[R];
         bool never = false;
         const uint8_t *sb = a.synd + b * m;
@@ -129,11 +142,11 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
         for (int r = 0; r < R; ++r) {
             const int row = r * 16 + (lane >> 2);
             const int byte = row < m ? (int)sb[row] : 0;
-            sy[r] = __ballot((byte & 1) != 0);
+            sy[r] = __ballot((byte & 1) != 0) & LOW;  // (kept in bit 0 of every nibble only: one set of masks for both passes)
             never = never || __ballot(byte > 1) != 0;
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r) msg[r] = pr[r];  // initialise_log_domain_bp (bp.hpp:147-157)
+        for (int r = 0; r < R; ++r) msg[r] = UNIFORM ? (paddr[r] == ZERO + 1 ? __builtin_inf() : pu) : prv[r];  // initialise_log_domain_bp (bp.hpp:147-157)
 
         int it = 0;
         bool unsat = true;
@@ -150,7 +163,7 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
                 const double pairmin = min_abs(cur, x1);
                 const double other = quad_perm<0x4E>(pairmin);        // the other pair's minimum (lane ^ 2)
                 const double mag = fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
-                const uint64_t flip = spread_nibble(nibble_parity_low(neg ^ (sy[r] & LOW))) ^ neg;  // row parity incl. the syndrome, own sign out
+                const uint64_t flip = spread_nibble(nibble_parity_low(neg ^ sy[r])) ^ neg;  // row parity incl. the syndrome, own sign out
                 const double c = mag * __hiloint2double(select_by_mask(ahi, nhi, flip), alo);
                 msg[r] = c;
                 X[r * 64 + lane] = c;
@@ -161,9 +174,9 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
             for (int r = 0; r < R; ++r) {
                 const double cp = X[paddr[r]];
                 const double c = msg[r];
-                const double b2c = pr[r] + cp;
-                const double l1 = b2c + c;          // second entry of its column: (prior + c0) + c1 with c0 = the partner's
-                const double l0 = (pr[r] + c) + cp; // first entry: c0 = its own
+                const double b2c = LDPC_EDGE_PRIOR(r) + cp;
+                const double l1 = b2c + c;                       // second entry of its column: (prior + c0) + c1 with c0 = the partner's
+                const double l0 = (LDPC_EDGE_PRIOR(r) + c) + cp; // first entry: c0 = its own
                 const uint64_t d1 = __ballot(l1 <= 0.0);
                 const uint64_t d = d1 ^ ((__ballot(l0 <= 0.0) ^ d1) & k0[r]);  // (phantom lanes: neither)
                 bad |= nibble_parity_low(d) ^ sy[r];  // candidate syndrome vs syndrome (bp.hpp:292-302), bit 0 of every nibble
@@ -177,7 +190,7 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
         for (int r = 0; r < R; ++r) {
             const int s = r * 64 + lane;
             if (a.kind[s] == 1) {
-                const double l0 = (pr[r] + X[s]) + X[paddr[r]];
+                const double l0 = (LDPC_EDGE_PRIOR(r) + X[s]) + X[paddr[r]];
                 const int j = a.scol[s];
                 a.decoding[b * n + j] = l0 <= 0.0 ? 1 : 0;
                 if (a.llr) a.llr[b * n + j] = l0;
@@ -191,5 +204,7 @@ __global__ void __launch_bounds__(64) bp_edge_kernel(const EdgeArgs a) {
         // compiler threads this `lane == 0` block into the one at the top of the loop and the readfirstlane there runs with
         // lane 0 masked off -- every other lane's `pulled` is 0, i.e. syndrome 0 for ever (seen with R = 1).
         __builtin_amdgcn_wave_barrier();
+      }
     }
+#undef LDPC_EDGE_PRIOR
 }

@@ -1361,6 +1361,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
 // ---- bp_edge_kernel (min-sum, lane = edge, messages in registers): rows <= 4, columns 1 .. 2 entries, 4 m <= 1024 slots ----
 struct EdgePlan {
     int rounds = 0;  // 0: not applicable
+    bool uniform = false;  // every column has the same prior: the form without prior registers (bp_edge_kernel<R, true>)
     void (*kern)(const EdgeArgs) = nullptr;
 };
 
@@ -1373,11 +1374,16 @@ static EdgePlan plan_edge(const ldpc_hip_bp *h) {
     std::vector<char> seen((size_t)h->n, 0);  // a column without entries has no lane to write its outputs
     for (int32_t j : h->h_col_idx) seen[(size_t)j] = 1;
     for (char c : seen) if (!c) return p;
-    static void (*const kerns[17])(const EdgeArgs) = {nullptr, bp_edge_kernel<1>, bp_edge_kernel<2>, bp_edge_kernel<3>, bp_edge_kernel<4>,
-        bp_edge_kernel<5>, bp_edge_kernel<6>, bp_edge_kernel<7>, bp_edge_kernel<8>, bp_edge_kernel<9>, bp_edge_kernel<10>, bp_edge_kernel<11>,
-        bp_edge_kernel<12>, bp_edge_kernel<13>, bp_edge_kernel<14>, bp_edge_kernel<15>, bp_edge_kernel<16>};
+#define LDPC_EDGE_ROW(U) {nullptr, bp_edge_kernel<1, U>, bp_edge_kernel<2, U>, bp_edge_kernel<3, U>, bp_edge_kernel<4, U>, bp_edge_kernel<5, U>, \
+        bp_edge_kernel<6, U>, bp_edge_kernel<7, U>, bp_edge_kernel<8, U>, bp_edge_kernel<9, U>, bp_edge_kernel<10, U>, bp_edge_kernel<11, U>, \
+        bp_edge_kernel<12, U>, bp_edge_kernel<13, U>, bp_edge_kernel<14, U>, bp_edge_kernel<15, U>, bp_edge_kernel<16, U>}
+    static void (*const kerns[2][17])(const EdgeArgs) = {LDPC_EDGE_ROW(false), LDPC_EDGE_ROW(true)};
+#undef LDPC_EDGE_ROW
+    p.uniform = true;
+    for (int j = 1; j < h->n && p.uniform; ++j)
+        p.uniform = std::memcmp(&h->channel_probs[(size_t)j], &h->channel_probs[0], sizeof(double)) == 0;
     p.rounds = rounds;
-    p.kern = kerns[rounds];
+    p.kern = kerns[p.uniform ? 1 : 0][rounds];
     return p;
 }
 
@@ -1390,14 +1396,14 @@ __global__ void edge_prior_kernel(const double *llr0, const int32_t *scol, const
 static int ensure_edge_tables(ldpc_hip_bp *h, const EdgePlan &p) {
     if (h->edge_rounds == p.rounds) return LDPC_HIP_OK;
     const int slots = p.rounds * 64;
-    std::vector<uint16_t> partner((size_t)slots, (uint16_t)slots);
+    std::vector<uint16_t> partner((size_t)slots, (uint16_t)(slots + 1));  // phantom lanes read the slot that holds +inf
     std::vector<uint8_t> kind((size_t)slots, 0);
     std::vector<int32_t> scol((size_t)slots, 0), first((size_t)h->n, -1);
     for (int i = 0; i < h->m; ++i)
         for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
             const int s = 4 * i + (e - h->h_row_ptr[(size_t)i]), j = h->h_col_idx[(size_t)e];
             scol[(size_t)s] = j;
-            if (first[(size_t)j] < 0) { first[(size_t)j] = s; kind[(size_t)s] = 1; }  // rows ascend: the column's first entry (bp.hpp:278)
+            if (first[(size_t)j] < 0) { first[(size_t)j] = s; kind[(size_t)s] = 1; partner[(size_t)s] = (uint16_t)slots; }  // rows ascend: the column's first entry (bp.hpp:278); alone so far: the +0.0 slot
             else { kind[(size_t)s] = 2; partner[(size_t)s] = (uint16_t)first[(size_t)j]; partner[(size_t)first[(size_t)j]] = (uint16_t)s; }
         }
     int rc;
@@ -1426,14 +1432,20 @@ static int decode_edge(ldpc_hip_bp *h, const EdgePlan &p, const uint8_t *synd, i
     a.ms_scaling_factor = h->ms_scaling_factor;
     a.batch = batch;
     a.prior_s = (const double *)h->e_prior.p; a.partner = (const uint16_t *)h->e_partner.p;
+    a.prior_u = std::log((1 - h->channel_probs[0]) / h->channel_probs[0]);  // as upload_priors (bp.hpp:150-151); read by the uniform form only
     a.kind = (const uint8_t *)h->e_kind.p; a.scol = (const int32_t *)h->e_scol.p;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.next = (unsigned long long *)h->counter.p;
     const size_t dyn = edge_lds_bytes(p.rounds);
-    // one wavefront per workgroup, as many resident as registers (4 per SIMD) and LDS allow
+    // one wavefront per workgroup, as many resident as registers (4 or 5 per SIMD) and LDS allow
     int64_t per_cu = (int64_t)((160u * 1024u) / (dyn + 64));
-    if (per_cu > 16) per_cu = 16;
+    const int64_t by_regs = p.uniform ? 20 : 16;
+    if (per_cu > by_regs) per_cu = by_regs;
     int64_t groups = batch < 256 * per_cu ? batch : 256 * per_cu;
+    // a visit to the work counter costs ~1 us under load and one word serves ~88 of them per us: pull several syndromes at a
+    // time once there are many per wavefront (the tail then is at most `chunk` syndromes of one wavefront)
+    int64_t chunk = batch / (groups * 16);
+    a.chunk = (int32_t)(chunk < 1 ? 1 : chunk > 8 ? 8 : chunk);
     h->accumulated_ms = 0.f;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3(64), (unsigned)dyn, h->stream, a);
