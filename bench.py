@@ -204,17 +204,32 @@ def secondary_configs(dev, steps):
                  "io_hbm_GBps": io_bytes / (ms * 1e-3) / 1e9, "parity_vs_oracle": ok,
                  "algorithmic_message_bytes_per_s_GBps": iters_total * 4.0 * nnz * 8.0 / (ms * 1e-3) / 1e9}
         if sp["method"] == 1:
-            # bp_wave_kernel keeps ONE message array per syndrome in LDS.  LDS bytes of one iteration, from the kernel's own
-            # geometry (bp_wave_kernel.h: rows padded to mp, columns to np, DR / DC template bounds):
-            #   check pass   mp * (DR * (8 + 8) + 2)           messages read + written, syndrome byte, degree
-            #   bit pass     np * (DC * (2 + 8 + 8) + 8 + 8)   position, message read + written, prior, posterior
-            #   syndrome     mp * (DR * (2 + 8) + 1)           column numbers, decision words, syndrome byte
-            mp, npad, dr, dc = (m + 63) // 64 * 64, (n + 63) // 64 * 64, sp["dr"], sp["dc"]
-            per_iter = mp * (dr * 16 + 2) + npad * (dc * 18 + 16) + mp * (dr * 10 + 1)
-            lds_gbps = iters_total * per_iter / (ms * 1e-3) / 1e9
-            entry.update({"bound": "lds", "frac": lds_gbps / LDS_PEAK_GBPS, "achieved": lds_gbps, "peak": LDS_PEAK_GBPS,
-                          "bound_unit": "GB/s", "lds_bytes_per_syndrome_iteration": per_iter,
-                          "bound_note": "LDS bytes the kernel moves (its padded geometry) / time vs the guide's ~150 TB/s ds_read_b64 aggregate"})
+            # min-sum on chip (bp_edge_kernel: lane = edge, messages in registers).  The kernel is bound by instruction ISSUE: a SIMD
+            # issues one vector and one scalar instruction per 4-cycle turn, and the lane-mask parities make the scalar stream as
+            # long as the vector one.  Instructions per syndrome-iteration come from the committed PMC profile of this kernel
+            # (profiles/secondary_c3.json: SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_LDS_IDX_ACTIVE, GRBM_GUI_ACTIVE -> clock); the
+            # fractions below use THIS run's kernel time.  The larger one is the bound.
+            c3 = valu.get("c3") or {}
+            try:
+                c3 = json.load(open(os.path.join(ROOT, "profiles", "secondary_c3.json")))["c3"]
+            except Exception:
+                c3 = {}
+            k_s = float(np.median(kms)) * 1e-3
+            if c3.get("valu_insts_per_syndrome_iteration") and c3.get("batch") == B:
+                clock = float(c3.get("clock_ghz") or MAX_CLOCK_GHZ) * 1e9
+                slots = SIMDS * clock * k_s / 4.0  # issue turns on offer while the kernel ran, at the clock measured under this load
+                fv = iters_total * c3["valu_insts_per_syndrome_iteration"] / slots
+                fs = iters_total * c3["salu_insts_per_syndrome_iteration"] / slots
+                bounds = {"valu_issue": fv, "salu_issue": fs, "lds_array_busy": c3.get("lds_array_busy_frac_measured")}
+                which = "valu_issue" if fv >= fs else "salu_issue"
+                entry.update({"bound": which, "frac": bounds[which], "bounds": bounds, "kernel": c3.get("kernel"), "clock_ghz": c3.get("clock_ghz"),
+                              "valu_insts_per_syndrome_iteration": c3["valu_insts_per_syndrome_iteration"],
+                              "salu_insts_per_syndrome_iteration": c3["salu_insts_per_syndrome_iteration"],
+                              "lds_bank_conflict_share": c3.get("lds_bank_conflict_share"),
+                              "bound_note": "issue turns used / turns on offer (1024 SIMDs x measured clock x kernel time / 4 cycles); instruction counts and clock "
+                                            "from profiles/secondary_c3.json (tools/profile_c3.sh), time from this run; LDS array busy and conflict share from the same profile"})
+            else:
+                entry.update({"bound": "valu_issue", "frac": None, "bound_note": "profiles/secondary_c3.json absent or for another batch"})
         else:
             # product-sum on chip: FP64 VALU issue.  Instructions per entry-iteration come from the committed PMC profile of
             # this kernel (profiles/secondary_valu.json: SQ_INSTS_VALU / (entries x iterations)); a wave-instruction takes

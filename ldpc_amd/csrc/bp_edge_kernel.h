@@ -54,6 +54,18 @@ struct EdgeArgs {
 
 __host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }  // slots, +0.0, +inf
 
+// How many of the R rounds let the vector unit do what the scalar unit would (both issue one instruction per SIMD turn, and the
+// kernel's scalar work -- lane-mask parities -- outweighs its vector work): measured on BASELINE config 3, tools/bench_edge.py
+// (C3, M syndromes/s: none 60.9; V2 all rounds 64.3; V1 all rounds 62.0; both 66.1; V1 = 2 rounds + V2 all 66.8)
+#ifndef EDGE_V1
+#define EDGE_V1 2
+#endif
+#ifndef EDGE_V2
+#define EDGE_V2 16
+#endif
+#ifndef EDGE_G
+#define EDGE_G 4
+#endif
 namespace edge_detail {
 // quad permutations of a double (two 32-bit DPP moves: 64-bit DPP allows row_newbcast only)
 template <int CTRL>
@@ -163,24 +175,53 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
                 const double pairmin = min_abs(cur, x1);
                 const double other = quad_perm<0x4E>(pairmin);        // the other pair's minimum (lane ^ 2)
                 const double mag = fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
-                const uint64_t flip = spread_nibble(nibble_parity_low(neg ^ sy[r])) ^ neg;  // row parity incl. the syndrome, own sign out
-                const double c = mag * __hiloint2double(select_by_mask(ahi, nhi, flip), alo);
+                int shi;  // high word of +-alpha: sign = row parity (syndrome included) + own
+                if (r < EDGE_V1) {
+                    // the vector unit spreads the row's parity: lane 0 of the quad picks it up from the (unspread) scalar mask, a DPP
+                    // broadcast inside the quad XORs it onto everyone's own sign -- 2 vector instructions more, 5 scalar ones fewer
+                    const uint64_t par = nibble_parity_low(neg ^ sy[r]);
+                    const int own = select_by_mask(ahi, nhi, neg);
+                    const int rowbit = select_by_mask(0, (int)0x80000000, par);
+                    shi = own ^ __builtin_amdgcn_mov_dpp(rowbit, 0x00, 0xf, 0xf, true);  // quad_perm [0, 0, 0, 0]
+                } else {
+                    const uint64_t flip = spread_nibble(nibble_parity_low(neg ^ sy[r])) ^ neg;  // row parity incl. the syndrome, own sign out
+                    shi = select_by_mask(ahi, nhi, flip);
+                }
+                const double c = mag * __hiloint2double(shi, alo);
                 msg[r] = c;
                 X[r * 64 + lane] = c;
             }
             // ---- bit pass: the partner's message; log-ratio, decision, new bit_to_check ----
             uint64_t bad = 0;
+            // (groups of EDGE_G rounds: their LDS reads are issued together, then consumed -- one round trip per group, not per round)
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double cp = X[paddr[r]];
-                const double c = msg[r];
-                const double b2c = LDPC_EDGE_PRIOR(r) + cp;
-                const double l1 = b2c + c;                       // second entry of its column: (prior + c0) + c1 with c0 = the partner's
-                const double l0 = (LDPC_EDGE_PRIOR(r) + c) + cp; // first entry: c0 = its own
-                const uint64_t d1 = __ballot(l1 <= 0.0);
-                const uint64_t d = d1 ^ ((__ballot(l0 <= 0.0) ^ d1) & k0[r]);  // (phantom lanes: neither)
-                bad |= nibble_parity_low(d) ^ sy[r];  // candidate syndrome vs syndrome (bp.hpp:292-302), bit 0 of every nibble
-                msg[r] = b2c;
+            for (int r0 = 0; r0 < R; r0 += EDGE_G) {
+                double cpv[EDGE_G];
+#pragma unroll
+                for (int g = 0; g < EDGE_G; ++g)
+                    if (r0 + g < R) cpv[g] = X[paddr[r0 + g]];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < EDGE_G; ++g) {
+                    const int r = r0 + g;
+                    if (r >= R) break;
+                    const double cp = cpv[g];
+                    const double c = msg[r];
+                    const double b2c = LDPC_EDGE_PRIOR(r) + cp;
+                    const double l1 = b2c + c;                       // second entry of its column: (prior + c0) + c1 with c0 = the partner's
+                    const double l0 = (LDPC_EDGE_PRIOR(r) + c) + cp; // first entry: c0 = its own
+                    uint64_t d;
+                    if (r < EDGE_V2) {  // the vector unit picks the lane's own log-ratio: 1 vector instruction more, 3 scalar ones fewer
+                        const double l = __hiloint2double(select_by_mask(__double2hiint(l1), __double2hiint(l0), k0[r]),
+                                                          select_by_mask(__double2loint(l1), __double2loint(l0), k0[r]));
+                        d = __ballot(l <= 0.0);
+                    } else {
+                        const uint64_t d1 = __ballot(l1 <= 0.0);
+                        d = d1 ^ ((__ballot(l0 <= 0.0) ^ d1) & k0[r]);  // (phantom lanes: neither)
+                    }
+                    bad |= nibble_parity_low(d) ^ sy[r];  // candidate syndrome vs syndrome (bp.hpp:292-302), bit 0 of every nibble
+                    msg[r] = b2c;
+                }
             }
             unsat = never || (bad & LOW) != 0;
         } while (unsat && it < a.max_iter);

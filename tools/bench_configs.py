@@ -15,13 +15,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel", osd=None):
+def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel", osd=None, random_serial=None):
     import torch
     from ldpc_amd.engine import HipBpEngine
     m, n = h.shape
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
     eng.set_math(math)
     eng.set_schedule(schedule)
+    if random_serial is not None:
+        eng.set_random_serial(True, random_serial)
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
     if osd is not None:  # (osd_method, osd_order): 2 = OSD_E, 3 = OSD_CS
         eng.set_osd(*osd)
@@ -50,10 +52,14 @@ def main():
         h = codes.rotated_surface_code_x(21)
         run("c3 surface d=21 min_sum 30 it p=0.05", h, 0.05, 30, 1, 0.625, 262144, False)
         run("c3 surface d=21 min_sum 30 it p=0.01", h, 0.01, 30, 1, 0.625, 262144, False)
+    if "c3p05" in args.which:  # config 3 at its primary operating point alone (tools/profile_c3.sh counts its instructions)
+        run("c3 surface d=21 min_sum 30 it p=0.05", codes.rotated_surface_code_x(21), 0.05, 30, 1, 0.625, 262144, False)
     if "serial" in args.which:
         serial()
     if "serial_big" in args.which:
         serial_big()
+    if "stateful" in args.which:
+        stateful()
     if "soft" in args.which:
         soft()
     if "hgp" in args.which:
@@ -125,6 +131,18 @@ def soft():
             print(json.dumps({"config": f"soft-info: {name} serial min_sum {max_iter} it, cutoff 2, sigma 0.7, B={batch}", "batch": batch,
                               "syndromes_per_s": batch / ms * 1e3, "ms_per_decode": ms, "mean_iterations": float(out[2].float().mean()),
                               "bp_converged": float(out[3].float().mean())}), flush=True)
+
+
+def stateful():
+    """The two schedules that keep state in the decoder object (bp.hpp:467-483): serial_relative (every lane re-sorts its own bit
+    order before every iteration) and the random serial order (one shuffled order per iteration for the whole call), next to
+    the fixed-order serial schedule on the same workload."""
+    from ldpc_amd import codes
+    for name, h, p, it, method, alpha in (("BB144 product_sum 50 it", codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0),
+                                          ("surface d=21 min_sum 30 it", codes.rotated_surface_code_x(21), 0.05, 30, 1, 0.625)):
+        run(f"serial (fixed order): {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial")
+        run(f"serial, random order per iteration: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial", random_serial=1234)
+        run(f"serial_relative: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial_relative")
 
 
 def serial_big():
