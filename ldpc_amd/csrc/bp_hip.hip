@@ -1305,6 +1305,8 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+    a.min_rdeg = h->m;
+    for (int i = 0; i < h->m; ++i) a.min_rdeg = std::min(a.min_rdeg, h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i]);
     const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
     if (dyn > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));

@@ -285,16 +285,21 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     }
 }
 
-// ---- product-sum, lane = ENTRY ---------------------------------------------------------------------------------
-// For product-sum the cost of a pass is its transcendentals -- one log per entry in the check pass, one tanh per
-// entry in the bit pass -- and with lane = node a code like BB [[144,12,12]] (m = 72, n = 144) leaves a third of the
-// lanes idle in the last round of each pass while the busy ones evaluate 6 resp. 3 of them in sequence.  Here a lane
-// owns ONE entry: it reads its whole row (column), forms the reference's sequential prefix and suffix products (sums)
-// exactly as the node-owning lane would -- a dozen cheap operations, redundantly -- and evaluates one transcendental.
-// 432 entries fill 7 rounds of 64 lanes at 96 %, instead of 12 + 9 transcendental slots per iteration there are 7 + 7.
-// Entries live row-padded, entry k of row i at i * DR + k (phantoms hold 1.0), in TWO arrays (a lane overwriting its
-// entry in place would pull the inputs away from the other lanes of its row); the bit pass reaches the k-th entry of
-// column j through epos[j * DC + k] (phantom: a slot that holds +0.0 for good).
+// ---- product-sum: node-per-lane bookkeeping, ENTRY-per-lane transcendentals ----------------------------------------
+// For product-sum the cost of a pass is its transcendentals -- one log per entry in the check pass, one tanh per entry in
+// the bit pass.  With lane = node a code like BB [[144,12,12]] (m = 72, n = 144) leaves a third of the lanes idle in the last
+// round of each pass while the busy ones evaluate 6 resp. 3 of them in sequence; with lane = entry throughout (round 1 - 2)
+// every lane re-did its row's prefix / suffix products and picked its own by selects: ~70 of a round's ~165 vector
+// instructions were that bookkeeping (profiles/r3_*c5*).  Now each pass has two phases:
+//   check A  lane = row     the reference's two sweeps of the row (bp.hpp:205-218), x_k = prefix_k * suffix_k stored at entry k
+//   check B  lane = entry   C[slot] = sign * log((1 + x) / (1 - x)), in place: ONE LDS read, one transcendental, one LDS write
+//   bit A    lane = column  the reference's two sweeps of the column (bp.hpp:276-281, 311-318): log-ratio, decision, the new
+//                           bit_to_check values stored at their entries
+//   bit B    lane = entry   A[slot] = tanh(A[slot] / 2), in place; the syndrome test rides in the same phase (lane = row)
+// 432 entries fill 7 rounds of 64 lanes at 96 %; the node phases are 2 and 3 short rounds.  Entries live row-padded, entry k
+// of row i at i * DR + k (phantoms hold 1.0 for good), in TWO arrays; the bit pass reaches the k-th entry of column j through
+// epos[j * DC + k] (phantom: slot m * DR -- +0.0 for good in C, a dummy in A).  Per node the arithmetic is the node-owning
+// lane's of every other kernel here: same operations, same order, same bits.
 struct WavePsArgs {
     int32_t m, n, np, max_iter;
     int64_t batch;
@@ -309,18 +314,21 @@ struct WavePsArgs {
     uint8_t *conv;
     unsigned long long *next;
     int32_t lds_shared, lds_per_wave;
+    int32_t min_rdeg;        // lightest row (a row of weight 1 has x = the empty product 1: q = 2 / 0, generic path only)
 };
+
+#define LDPC_PS_NEAR_SLOTS 64  // entries whose log argument is near 1, listed per wavefront and iteration (see check B)
 
 __host__ __device__ inline size_t wave_ps_lds_shared(int m, int np, int DR, int DC) {
     size_t b = 256 * 8 + (size_t)(np + 2) * 16 + (size_t)m * DR * 2 + (size_t)np * DC * 2 + (size_t)m;
     return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t wave_ps_lds_private(int m, int np, int DR, bool want_llr) {
-    size_t b = 2 * ((size_t)m * DR + 2) * 8 + (want_llr ? (size_t)np * 8 : 0) + (size_t)(np + 16) + (size_t)m;
+    size_t b = 2 * ((size_t)m * DR + 2) * 8 + (want_llr ? (size_t)np * 8 : 0) + LDPC_PS_NEAR_SLOTS * 4 + (size_t)(np + 16) + (size_t)m + (size_t)m * DR;
     return (b + 15) & ~(size_t)15;
 }
 
-// TEAM: as for bp_wave_kernel -- the workgroup's wavefronts share one syndrome, each taking rounds of 64 entries of a pass.  For
+// TEAM: as for bp_wave_kernel -- the workgroup's wavefronts share one syndrome, each taking rounds of 64 lanes of a phase.  For
 // batches so small that a wavefront decodes only a few syndromes the time is the 50 iterations of the slowest one: a team cuts
 // exactly that.
 template <int MATH, int DR, int DC, bool TEAM = false>
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     __shared__ int team_unsat[2];
     __shared__ long long team_b;
     auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
-    const int m = a.m, n = a.n, np = a.np, rm = m * DR, cn = n * DC;
+    const int m = a.m, n = a.n, np = a.np, rm = m * DR;
     const bool want_llr = a.llr != nullptr;
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -359,16 +367,34 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     if (tid == 0) pform[np] = 1.0;  // phantom entries of a row: neutral for the products
     __syncthreads();
 
-    // wave-private: [A rm + 2][C rm + 2 (entry rm = the +0.0 slot)][posteriors np, if asked for][hard decisions np + 16 bytes][syndrome bytes m]
+    // wave-private: [A rm + 2 (entry rm = a dummy)][C rm + 2 (entry rm = the +0.0 slot)][posteriors np, if asked for][hard decisions np + 16 bytes]
+    // [syndrome bytes m][per entry: 0 phantom, 1 real, 2 real in a row whose syndrome byte is not 0 (the message's sign, bp.hpp:213) rm]
     lds_u8 *mine = base + a.lds_shared + (TEAM ? 0 : wave) * a.lds_per_wave;
     lds_f64 *A = (lds_f64 *)mine;
     lds_f64 *C = A + rm + 2;
     lds_f64 *L = C + rm + 2;
-    volatile lds_u8 *hard = (volatile lds_u8 *)(L + (want_llr ? np : 0));
+    typedef __attribute__((address_space(3))) int lds_i32;
+    lds_i32 *near_list = (lds_i32 *)(L + (want_llr ? np : 0));
+    volatile lds_u8 *hard = (volatile lds_u8 *)(near_list + LDPC_PS_NEAR_SLOTS);
     volatile lds_u8 *sy = hard + np + 16;
+    volatile lds_u8 *flag = sy + m;
     const int ZERO = rm;
     if (tl == 0) { C[ZERO] = 0.0; hard[np] = 0; team_unsat[0] = 0; team_unsat[1] = 0; }
     team_sync();
+    // The exact log has two evaluation branches (argument within ~6 % of 1, or not) and a round of 64 entries nearly always
+    // holds both kinds, so every round paid for both (37 + 42 instructions).  One wavefront per syndrome: every entry takes the
+    // table branch; the few with an argument near 1 are LISTED (compacted over all rounds of the pass: ballot + mbcnt) and
+    // the near-1 branch runs once over the list -- usually one round instead of seven.  Precondition, tested where the tanh
+    // values are made: every |tanh| < 1 (then q = (1 + x) / (1 - x) is a normal number: no 0 / inf / NaN tails), and no row
+    // of weight 1.  Same operations on the same operands as ps_log_ratio_libm: same bits (check_row_ps_exact_fast is the
+    // streamed kernels' form of this).
+    constexpr bool LISTED = !TEAM && MATH == 0;
+    bool prior_tame = true;  // every |tanh(prior / 2)| < 1
+    if (LISTED) {
+        bool wild = false;
+        for (int q = lane; q < n; q += 64) wild = wild || !(__builtin_fabs(pform[q]) < 1.0);
+        prior_tame = __ballot(wild) == 0 && a.min_rdeg >= 2;
+    }
 
     for (;;) {
         int64_t b;
@@ -387,63 +413,100 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
         for (int q = tl; q < rm; q += TS) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
         if (TEAM && tid == 0) { team_unsat[0] = 0; team_unsat[1] = 0; }  // (a syndrome that ran out of iterations leaves its last flag raised)
         team_sync();
+        for (int q = tl; q < rm; q += TS) {
+            const int i = q / DR, k = q - i * DR;
+            flag[q] = k < (int)rdeg[i] ? (sy[i] != 0 ? 2 : 1) : 0;
+        }
+        team_sync();
 
         int it = 0;
         bool unsat_any = true;
+        bool tame = prior_tame;  // wave-uniform: the tanh values of this iteration's check pass all lie inside (-1, 1)
         do {
             ++it;
-            // ---- check pass (bp.hpp:201-219): lane = entry (i, k) ----
-            for (int s0 = wt * 64; s0 < rm; s0 += 64 * W) {
-                const int slot = s0 + lane;
-                const int sc = slot < rm ? slot : rm - 1;
-                const int i = sc / DR, k = sc - i * DR;
-                const bool valid = slot < rm && k < rdeg[i];
-                double av[DR], pre[DR];
+            // ---- check A (bp.hpp:205-209, 211-212, 217): lane = row, both sweeps; x_k = prefix_k * suffix_k parked at entry k ----
+            for (int i0 = wt * 64; i0 < m; i0 += 64 * W) {
+                const int i = i0 + lane;
+                if (i < m) {
+                    double av[DR], pre[DR];
 #pragma unroll
-                for (int kk = 0; kk < DR; ++kk) av[kk] = A[i * DR + kk];
-                double temp = 1.0;
+                    for (int kk = 0; kk < DR; ++kk) av[kk] = A[i * DR + kk];  // phantoms: 1.0, behind the real entries
+                    double temp = 1.0;
 #pragma unroll
-                for (int kk = 0; kk < DR; ++kk) { pre[kk] = temp; temp *= av[kk]; }  // the reference's forward sweep
-                double mine_pre = pre[0], mine_suf = 1.0;
-                temp = 1.0;
+                    for (int kk = 0; kk < DR; ++kk) { pre[kk] = temp; temp *= av[kk]; }
+                    temp = 1.0;
 #pragma unroll
-                for (int kk = DR - 1; kk >= 0; --kk) {  // and its backward sweep; keep what belongs to entry k
-                    mine_pre = kk == k ? pre[kk] : mine_pre;
-                    mine_suf = kk == k ? temp : mine_suf;
-                    temp *= av[kk];
+                    for (int kk = DR - 1; kk >= 0; --kk) { C[i * DR + kk] = pre[kk] * temp; temp *= av[kk]; }
                 }
-                if (valid) C[slot] = ps_message<MATH>(mine_pre * mine_suf, sy[i] != 0, log_tab);
             }
             team_sync();
-            // ---- bit pass (bp.hpp:276-298, 311-318): lane = entry (j, k) of the column ----
-            for (int s0 = wt * 64; s0 < cn; s0 += 64 * W) {
-                const int slot = s0 + lane;
-                const int sc = slot < cn ? slot : cn - 1;
-                const int j = sc / DC, k = sc - j * DC;
-                int pos[DC];
-                double cv[DC], pre[DC];
+            // ---- check B (bp.hpp:213-216): lane = entry, one log each, in place ----
+            if (LISTED && tame) {
+                int total = 0;
+                for (int s0 = 0; s0 < rm; s0 += 64) {
+                    const int slot = s0 + lane;
+                    const int f = slot < rm ? (int)flag[slot] : 0;
+                    const double x = f ? C[slot] : 0.0;
+                    const double q = ldpc_math::div_cr(1.0 + x, 1.0 - x);
+                    const bool near = f != 0 && ldpc_math::log_near_one(q);
+                    const double y = ldpc_math::log_libm_general(q, log_tab);
+                    const uint64_t mask = __ballot(near);
+                    bool in_place = false;
+                    if (mask) {
+                        const int cnt = __builtin_popcountll(mask);
+                        if (total + cnt <= LDPC_PS_NEAR_SLOTS) {
+                            if (near) near_list[total + lane_rank(mask)] = slot;  // (its x stays in C[slot] for the second visit)
+                            total += cnt;
+                        } else in_place = near;  // list full: as the generic routine would
+                    }
+                    if (f && !near) C[slot] = f == 2 ? -y : y;
+                    if (in_place) { const double yn = ldpc_math::log_libm_near_one(q); C[slot] = f == 2 ? -yn : yn; }
+                }
+                for (int c = lane; c < total; c += 64) {
+                    const int slot = near_list[c];
+                    const double x = C[slot];
+                    const double yn = ldpc_math::log_libm_near_one(ldpc_math::div_cr(1.0 + x, 1.0 - x));
+                    C[slot] = flag[slot] == 2 ? -yn : yn;
+                }
+            } else {
+                for (int s0 = wt * 64; s0 < rm; s0 += 64 * W) {
+                    const int slot = s0 + lane;
+                    const int f = slot < rm ? (int)flag[slot] : 0;
+                    if (f) C[slot] = ps_message<MATH>(C[slot], f == 2, log_tab);
+                }
+            }
+            team_sync();
+            // ---- bit A (bp.hpp:276-298, 311-318): lane = column, both sweeps; the new bit_to_check values parked at their entries ----
+            for (int j0 = wt * 64; j0 < n; j0 += 64 * W) {
+                const int j = j0 + lane;
+                if (j < n) {
+                    int pos[DC];
+                    double cv[DC], pre[DC];
 #pragma unroll
-                for (int kk = 0; kk < DC; ++kk) { pos[kk] = epos[j * DC + kk]; cv[kk] = C[pos[kk]]; }  // phantom: the +0.0 slot
-                double temp = prior[j];
+                    for (int kk = 0; kk < DC; ++kk) { pos[kk] = epos[j * DC + kk]; cv[kk] = C[pos[kk]]; }  // phantom: the +0.0 slot, behind the real entries
+                    double temp = prior[j];
 #pragma unroll
-                for (int kk = 0; kk < DC; ++kk) { pre[kk] = temp; temp += cv[kk]; }
-                if (slot < cn && k == 0) {
+                    for (int kk = 0; kk < DC; ++kk) { pre[kk] = temp; temp += cv[kk]; }
                     hard[j] = temp <= 0 ? 1 : 0;
                     if (want_llr) L[j] = temp;
-                }
-                double mine_pre = pre[0], mine_sfx = 0.0, sfx = 0.0;
-                int mine_pos = pos[0];
+                    double sfx = 0.0;
 #pragma unroll
-                for (int kk = DC - 1; kk >= 0; --kk) {
-                    mine_pre = kk == k ? pre[kk] : mine_pre;
-                    mine_sfx = kk == k ? sfx : mine_sfx;
-                    mine_pos = kk == k ? pos[kk] : mine_pos;
-                    sfx += cv[kk];
+                    for (int kk = DC - 1; kk >= 0; --kk) { A[pos[kk]] = pre[kk] + sfx; sfx += cv[kk]; }  // (phantom: A's dummy slot)
                 }
-                if (slot < cn && mine_pos != ZERO) A[mine_pos] = edge_form<METHOD, MATH>(mine_pre + mine_sfx);
             }
             team_sync();
-            // ---- syndrome test (bp.hpp:292-294, 300-302) ----
+            // ---- bit B: lane = entry, one tanh each, in place (A holds tanh(bit_to_check / 2), bp.hpp:208) ----
+            bool wild = false;
+            for (int s0 = wt * 64; s0 < rm; s0 += 64 * W) {
+                const int slot = s0 + lane;
+                if (slot < rm && flag[slot]) {
+                    const double z = edge_form<METHOD, MATH>(A[slot]);
+                    A[slot] = z;
+                    if (LISTED) wild = wild || !(__builtin_fabs(z) < 1.0);
+                }
+            }
+            if (LISTED) tame = __ballot(wild) == 0 && a.min_rdeg >= 2;
+            // ---- syndrome test (bp.hpp:292-294, 300-302), same phase: it reads the decisions only ----
             bool unsat = false;
             for (int i = tl; i < m; i += TS) {
                 unsigned par = 0;
