@@ -248,6 +248,102 @@ void bp_oracle_decode_batch(bp_oracle *o, const double *channel_probs, int max_i
  * NaN log-ratios make the reference's column order implementation-defined (non-total comparator);
  * here NaN sorts after every number.
  * ============================================================================================== */
+/* ============================================================================================== *
+ * Syndromes OUTSIDE the image of H (rank-deficient H, e.g. toric-code checks with a measurement error).
+ * No x solves H x = s; what the reference returns is the solution of the subsystem of ITS pivot rows, and which rows
+ * those are is decided by the sparsity heuristic of its linked-list elimination: among the unpivoted rows with an entry in
+ * the pivot column, the FIRST IN THE COLUMN'S LINKED LIST of minimal weight(U row) + weight(L row)
+ * (gf2sparse_linalg.hpp:149-163 in rref, :318-333 in fast_solve).  The list order is history: swap_rows relabels rows
+ * without moving their entries (sparse_matrix_base.hpp:284-299), insert_entry walks a column from the bottom to the first
+ * entry with a smaller row label (:449-460), add_rows inserts / removes entry by entry (gf2sparse.hpp:277-305).  This
+ * routine re-enacts exactly that -- U as bit rows per row OBJECT, labels, per-column object lists with the reference's
+ * insert and remove, L only as row degrees -- over the whole column order (an out-of-image syndrome never triggers
+ * fast_solve's early stop, so fast_solve and rref + lu_solve make the same choices), and returns the syndrome s' that
+ * agrees with s on the chosen pivot rows and lies in the image of H: s'_i = s_i ^ (what is left of s in row i after the
+ * elimination).  H x = s' has the same solutions as (pivot rows of H) x = (pivot rows of s), so every ordinary OSD routine
+ * run on s' returns the reference's vector -- OSD-0 and the higher orders alike (osd.hpp:119-187 solves every candidate
+ * on those rows).  Checked against the real reference: tests/test_osd_outside_image.py.
+ * ============================================================================================== */
+void osd_reference_pivot_rows_syndrome(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const int *order,
+                                       const uint8_t *syndrome, uint8_t *corrected) {
+    const int hw = (n + 63) / 64;
+    uint64_t *U = (uint64_t *)calloc((size_t)(m ? m : 1) * (size_t)(hw ? hw : 1), sizeof(uint64_t));
+    int *deg = (int *)calloc((size_t)(m ? m : 1), sizeof(int)), *ldeg = (int *)calloc((size_t)(m ? m : 1), sizeof(int));
+    int *label = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1)), *obj_at = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    int *len = (int *)calloc((size_t)(n ? n : 1), sizeof(int));
+    int *lst = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1) * (size_t)(m ? m : 1));  /* column c: lst[c * m ..], top to bottom */
+    int *targets = (int *)malloc(sizeof(int) * (size_t)(m ? m : 1));
+    uint8_t *yb = (uint8_t *)malloc((size_t)(m ? m : 1));
+    for (int i = 0; i < m; i++) {
+        label[i] = obj_at[i] = i;
+        yb[i] = syndrome[i] ? 1 : 0;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+            const int c = col_idx[e];
+            if ((U[(size_t)i * hw + c / 64] >> (c % 64)) & 1) continue;
+            U[(size_t)i * hw + c / 64] |= 1ull << (c % 64);
+            deg[i]++;
+            lst[(size_t)c * m + len[c]++] = i;  /* rows ascend: the initial lists are sorted */
+        }
+    }
+    int rank = 0;
+    const int max_rank = m < n ? m : n;
+    for (int t = 0; t < n && rank < max_rank; t++) {
+        const int pc = order[t];
+        int best = -1, bw = 0;
+        for (int q = 0; q < len[pc]; q++) {
+            const int o = lst[(size_t)pc * m + q];
+            if (label[o] < rank) continue;
+            const int w = deg[o] + ldeg[o];
+            if (best < 0 || w < bw) { best = o; bw = w; }
+        }
+        if (best < 0) continue;
+        const int sw = label[best];
+        if (sw != rank) {
+            const int other = obj_at[rank];
+            label[best] = rank; label[other] = sw;
+            obj_at[rank] = best; obj_at[sw] = other;
+        }
+        ldeg[best]++;  /* L.insert_entry(rank, rank) */
+        int nt = 0;
+        for (int q = 0; q < len[pc]; q++) {
+            const int o = lst[(size_t)pc * m + q];
+            if (label[o] > rank) targets[nt++] = o;
+        }
+        for (int k = 0; k < nt; k++) {
+            const int tg = targets[k], tl = label[tg];
+            for (int w = 0; w < hw; w++) {
+                uint64_t bits = U[(size_t)best * hw + w];
+                while (bits) {
+                    const int c = w * 64 + __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    int *L = lst + (size_t)c * m;
+                    if ((U[(size_t)tg * hw + w] >> (c % 64)) & 1) {  /* remove */
+                        int q = 0;
+                        while (L[q] != tg) q++;
+                        for (; q + 1 < len[c]; q++) L[q] = L[q + 1];
+                        len[c]--;
+                        deg[tg]--;
+                    } else {  /* insert below the first entry, from the bottom, whose label is smaller */
+                        int pos = 0;
+                        for (int q = len[c] - 1; q >= 0; q--)
+                            if (label[L[q]] < tl) { pos = q + 1; break; }
+                        for (int q = len[c]; q > pos; q--) L[q] = L[q - 1];
+                        L[pos] = tg;
+                        len[c]++;
+                        deg[tg]++;
+                    }
+                }
+            }
+            for (int w = 0; w < hw; w++) U[(size_t)tg * hw + w] ^= U[(size_t)best * hw + w];
+            ldeg[tg]++;  /* L.insert_entry(row, rank) */
+            yb[tg] ^= yb[best];
+        }
+        rank++;
+    }
+    for (int i = 0; i < m; i++) corrected[i] = (uint8_t)((syndrome[i] ? 1 : 0) ^ (label[i] >= rank ? yb[i] : 0));
+    free(U); free(deg); free(ldeg); free(label); free(obj_at); free(len); free(lst); free(targets); free(yb);
+}
+
 static int osd_less(double a, int ia, double b, int ib) {
     const int na = a != a, nb = b != b;
     if (na || nb) return na == nb ? ia < ib : nb; /* numbers before NaNs */
@@ -256,8 +352,66 @@ static int osd_less(double a, int ia, double b, int ib) {
     return ia < ib;
 }
 
+/* 1 if H x = syndrome has a solution (plain bit-packed elimination of [H | s]) */
+static int osd_syndrome_in_image(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const uint8_t *syndrome) {
+    const int words = (n + 1 + 63) / 64;
+    uint64_t *a = (uint64_t *)calloc((size_t)(m ? m : 1) * (size_t)words, sizeof(uint64_t));
+    for (int i = 0; i < m; i++) {
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) a[(size_t)i * words + col_idx[e] / 64] |= 1ull << (col_idx[e] % 64);
+        if (syndrome[i]) a[(size_t)i * words + n / 64] |= 1ull << (n % 64);
+    }
+    int rank = 0;
+    for (int c = 0; c < n && rank < m; c++) {
+        int p = -1;
+        for (int i = rank; i < m; i++)
+            if ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1) { p = i; break; }
+        if (p < 0) continue;
+        for (int w = 0; w < words; w++) { const uint64_t t = a[(size_t)p * words + w]; a[(size_t)p * words + w] = a[(size_t)rank * words + w]; a[(size_t)rank * words + w] = t; }
+        for (int i = rank + 1; i < m; i++)
+            if ((a[(size_t)i * words + c / 64] >> (c % 64)) & 1)
+                for (int w = 0; w < words; w++) a[(size_t)i * words + w] ^= a[(size_t)rank * words + w];
+        rank++;
+    }
+    int ok = 1;
+    for (int i = rank; i < m; i++)
+        if ((a[(size_t)i * words + n / 64] >> (n % 64)) & 1) ok = 0;
+    free(a);
+    return ok;
+}
+
+/* the syndrome the ordinary routines below are run on: the caller's, or -- outside the image of H -- the one that keeps
+ * the reference's pivot rows (osd_reference_pivot_rows_syndrome); returns a malloc'ed copy */
+static uint8_t *osd_effective_syndrome(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                                       const uint8_t *syndrome) {
+    uint8_t *eff = (uint8_t *)malloc((size_t)(m ? m : 1));
+    for (int i = 0; i < m; i++) eff[i] = syndrome[i] ? 1 : 0;
+    if (osd_syndrome_in_image(m, n, row_ptr, col_idx, syndrome)) return eff;
+    int *order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int r = 0;
+        for (int j = 0; j < n; j++) {
+            const double a = llr[j], b = llr[i];
+            const int na = a != a, nb = b != b;
+            r += (na || nb) ? (na == nb ? j < i : nb) : (a < b ? 1 : a > b ? 0 : j < i);
+        }
+        order[r] = i;
+    }
+    osd_reference_pivot_rows_syndrome(m, n, row_ptr, col_idx, order, syndrome, eff);
+    free(order);
+    return eff;
+}
+
+static void osd0_oracle_in_image(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                                 const uint8_t *syndrome, uint8_t *decoding);
 void osd0_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
                  const uint8_t *syndrome, uint8_t *decoding) {
+    uint8_t *eff = osd_effective_syndrome(m, n, row_ptr, col_idx, llr, syndrome);
+    osd0_oracle_in_image(m, n, row_ptr, col_idx, llr, eff, decoding);
+    free(eff);
+}
+
+static void osd0_oracle_in_image(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                                 const uint8_t *syndrome, uint8_t *decoding) {
     const int words = (n + 1 + 63) / 64; /* n matrix bits + 1 augmented syndrome bit per row */
     uint64_t *a = (uint64_t *)calloc((size_t)(m ? m : 1) * (size_t)words, sizeof(uint64_t));
     int *order = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
@@ -314,11 +468,22 @@ void osd0_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, c
  * OSD_CS with osd_order > k writes past the candidate string in the reference (osd.hpp:92-96, undefined
  * behaviour); here such pairs are skipped.
  * ============================================================================================== */
+static void osdw_oracle_in_image(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                                 const uint8_t *syndrome, const double *channel_probs, int osd_method, int osd_order,
+                                 uint8_t *decoding, uint8_t *osd0_decoding);
 void osdw_oracle(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
                  const uint8_t *syndrome, const double *channel_probs, int osd_method, int osd_order,
                  uint8_t *decoding, uint8_t *osd0_decoding) {
+    uint8_t *eff = osd_effective_syndrome(m, n, row_ptr, col_idx, llr, syndrome);
+    osdw_oracle_in_image(m, n, row_ptr, col_idx, llr, eff, channel_probs, osd_method, osd_order, decoding, osd0_decoding);
+    free(eff);
+}
+
+static void osdw_oracle_in_image(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *llr,
+                                 const uint8_t *syndrome, const double *channel_probs, int osd_method, int osd_order,
+                                 uint8_t *decoding, uint8_t *osd0_decoding) {
     if (osd_order <= 0 || osd_method < 2) {
-        osd0_oracle(m, n, row_ptr, col_idx, llr, syndrome, decoding);
+        osd0_oracle_in_image(m, n, row_ptr, col_idx, llr, syndrome, decoding);
         if (osd0_decoding) memcpy(osd0_decoding, decoding, (size_t)n);
         return;
     }

@@ -39,12 +39,53 @@ def test_fixtures_present_and_consistent():
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_oracle_matches_reference_inside_the_image(name, oracle_built):
+def test_oracle_matches_reference_on_every_row(name, oracle_built):
+    """Inside AND outside the image: the restatement re-enacts the reference's pivot-row choice (oracle/bp_oracle.c,
+    osd_reference_pivot_rows_syndrome), so it lands on the reference's vector for the unsolvable rows too."""
     c = load(name)
     o = oracle_built.BpOracle(c["h"], error_rate=c["p"], max_iter=c["max_iter"], bp_method=c["bp_method"], ms_scaling_factor=c["alpha"])
     dec, llr, it, cv = o.bposd_decode_batch(c["synd"], c["osd_method"], c["osd_order"])
     assert np.array_equal(cv, c["conv"]) and np.array_equal(it, c["it"]) and bits_equal(llr, c["llr"])
-    assert np.array_equal(dec[c["inside"]], c["dec"][c["inside"]])
+    assert np.array_equal(dec, c["dec"])
+
+
+def _toric(L):
+    rows, cols = [], []
+    for r in range(L):
+        for q in range(L):
+            for e in (r * L + q, r * L + (q - 1) % L, L * L + r * L + q, L * L + ((r - 1) % L) * L + q):
+                rows.append(r * L + q)
+                cols.append(e)
+    return sp.csr_matrix((np.ones(len(rows), np.uint8), (rows, cols)), shape=(L * L, 2 * L * L))
+
+
+def _cases_outside(rng, h, count):
+    m, n = h.shape
+    for trial in range(count):
+        e = (rng.random(n) < 0.08).astype(np.uint8)
+        y = (h @ e % 2).astype(np.uint8)
+        for _ in range(1 if trial % 3 else 3):
+            y[rng.integers(m)] ^= 1  # odd number of flips: outside the image of the torus' checks
+        llr = rng.normal(2.0, 1.5, size=n)
+        if trial % 4 == 3:
+            llr = np.round(llr)  # ties in the column order
+        yield y, llr
+
+
+@pytest.mark.parametrize("L", [3, 4, 5, 7])
+def test_oracle_pivot_rows_against_the_real_reference(L, oracle_built):
+    """Randomised: OSD alone (no BP), syndromes outside the image, log-ratios with and without ties; rank-deficient H with
+    redundant rows of several kinds (a torus, and a torus with a duplicated and an all-zero row)."""
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(100 + L)
+    h0 = _toric(L)
+    h1 = sp.vstack([h0, h0[1], sp.csr_matrix((1, h0.shape[1]), dtype=np.uint8), h0[0]]).tocsr()
+    for h in (h0, h1):
+        ref = oracle_built.RefBpOsd(h, error_rate=0.05, max_iter=1, bp_method="minimum_sum")
+        orc = oracle_built.BpOracle(h, error_rate=0.05, max_iter=1, bp_method="minimum_sum")
+        for y, llr in _cases_outside(rng, h, 24):
+            assert np.array_equal(orc.osd0(y, llr), ref.osd0(y, llr))
 
 
 @pytest.mark.gpu
