@@ -178,15 +178,21 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
  * rows) fed with a syndrome that breaks a dependency is not, and then NO x satisfies H x = s.  The reference still
  * returns a vector: RowReduce::fast_solve never reaches its early stop, eliminates every column, and lu_solve
  * (gf2sparse_linalg.hpp:237-288) solves the equations of the PIVOT ROWS only -- which rows those are is decided by the
- * sparsity heuristic of its linked-list elimination (fewest entries across L and U, ties by current row position,
- * :327-340), i.e. by an implementation detail of that data structure.  The device kernels eliminate bit-packed rows and
- * take the first candidate row; their output for such a row is the solution of THEIR pivot-row subsystem (deterministic,
- * supported on the same pivot columns, generally a different vector than the reference's), and it is flagged:
- * after any ldpc_hip_bposd*_decode_batch call, ldpc_hip_bposd_get_status fills status[batch] (host or device pointer) with
- *   0  BP converged, OSD did not run            1  OSD ran and H x = s (bit-identical to the reference)
- *   2  OSD ran, s is outside the image of H: x does not satisfy H x = s and is NOT the reference's vector.
- * `batch` must be the batch size of that decode.  (tests/golden/osd_outside_image_*.npz hold the reference's outputs on
- * such syndromes next to in-image ones.)
+ * sparsity heuristic of its linked-list elimination (fewest entries across L and U, ties by the position in the pivot
+ * column's linked list, :149-163 / :318-333 -- a position that swap_rows, insert_entry and add_rows leave history-dependent).
+ * The bit-packed device eliminations take the first candidate row, which for a syndrome inside the image cannot change the
+ * solution.  Rows outside the image are detected (H x != s after the first pass) and go through a second pass: one workgroup
+ * per such row re-enacts the reference's elimination on that data structure (csrc/osd_exact_kernel.h) to learn ITS pivot
+ * rows, writes the syndrome that agrees with s on those rows and lies in the image, and the same OSD kernels run again on it
+ * -- OSD-0, OSD_E and OSD_CS alike.  The output is then the reference's vector, bit for bit (tests/golden/outimage_*.npz,
+ * every row), and the row stays flagged: after any ldpc_hip_bposd*_decode_batch call, ldpc_hip_bposd_get_status fills
+ * status[batch] (host or device pointer) with
+ *   0  BP converged, OSD did not run            1  OSD ran and H x = s
+ *   2  OSD ran, s is outside the image of H: x does not (cannot) satisfy H x = s; it solves the reference's pivot rows.
+ * `batch` must be the batch size of that decode.  The second pass needs rank H (worked out on the host for m * m * n / 64 < 4e9)
+ * and m <= 8192; beyond that a flagged row keeps the solution of the device's own pivot rows.  Both extra launches size
+ * themselves from device-side counters: no host round trip, a few microseconds when no row is flagged, nothing at all for
+ * a full-rank H.
  */
 int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
 /* Serial schedule: a 64-syndrome tile is decoded by one wavefront, which runs until its slowest syndrome is done.  With

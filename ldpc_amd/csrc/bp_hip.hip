@@ -51,6 +51,7 @@
 #include "bp_wave_kernel.h"
 #include "bp_edge_kernel.h"
 #include "osd_kernels.h"
+#include "osd_exact_kernel.h"
 #include "io_kernels.h"
 
 #include <chrono>
@@ -160,6 +161,7 @@ struct ldpc_hip_bp {
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf osd_status;                                           // [batch] of the last BP + OSD decode: 0 BP converged, 1 OSD solved, 2 s outside image(H)
+    DeviceBuf osd_fix_synd, osd_fix_list, osd_fix_counters, osd_fix_scratch;  // second OSD pass over the rows outside the image (osd_exact_kernel.h)
     int64_t osd_status_rows = 0;
     DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
     int32_t serial_kernel = -1;                                     // -1 auto, 0 one wavefront per tile, 1 level-parallel workgroup per tile
@@ -329,7 +331,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1910,6 +1912,9 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.counters = (unsigned *)h->osd_counters.p;
     hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
                        (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    // the OSD kernels proper, over the rows of a.list: run once on the caller's syndromes and -- for a rank-deficient H -- once more
+    // on the corrected syndromes of the rows that turned out to lie outside the image (osd_exact_kernel.h)
+    auto run_osd = [&](OsdArgs a) -> int {
     if (big0) {
         OsdBigArgs A = {};
         A.hwords = (a.n + 63) / 64;
@@ -1988,8 +1993,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if (lds > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bk, dim3((unsigned)slots), dim3(256), (unsigned)lds, h->stream, A);
         HIPCHK(hipGetLastError());
-        if (h->h_flag) HIPCHK(hipMemcpyAsync(&h->h_flag[8], a.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));  // rows listed: the next call's guide
-        return osd_status_pass(h, a, batch);
+        return LDPC_HIP_OK;
     }
     int groups_per_cu = (int)((160u * 1024u) / dyn);
     if (groups_per_cu * waves > 32) groups_per_cu = 32 / waves;
@@ -2001,7 +2005,47 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     else if (higher) hipLaunchKernelGGL(osdw_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     else hipLaunchKernelGGL(osd0_kernel, dim3((unsigned)blocks), dim3((unsigned)(waves * 64)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());
-    return osd_status_pass(h, a, batch);
+    return LDPC_HIP_OK;
+    };
+    if ((rc = run_osd(a))) return rc;
+    if (big0 && h->h_flag) HIPCHK(hipMemcpyAsync(&h->h_flag[8], a.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));  // rows listed: the next call's guide
+    if ((rc = osd_status_pass(h, a, batch))) return rc;
+    // Rows whose syndrome lies outside the image of H (status 2; only a rank-deficient H has any): the reference's answer depends on
+    // which rows its linked-list elimination made pivot rows.  One workgroup per such row re-enacts that choice and writes the syndrome
+    // that keeps exactly those rows (osd_exact_kernel.h); the same OSD kernels then run once more over these rows.  No host round trip:
+    // both launches size themselves from device-side counters and cost a few microseconds when there is nothing to do.
+    const bool rank_known = (double)a.m * a.m * a.words < 4e9;
+    if (rank_known && a.n - osd_k(h) < a.m && a.m <= 8192 && !getenv("LDPC_HIP_OSD_NO_EXACT")) {
+        const size_t slot_words = osd_exact_slot_words(a.m, a.n);
+        int64_t slots = 512;
+        if (slots > batch) slots = batch;
+        const int64_t cap = (int64_t)((2ull << 30) / (slot_words * 8));  // at most 2 GiB of working copies
+        if (cap >= 1) {
+            if (slots > cap) slots = cap;
+            if ((rc = h->osd_fix_synd.ensure(B * (size_t)a.m)) || (rc = h->osd_fix_list.ensure(B * sizeof(int32_t))) ||
+                (rc = h->osd_fix_counters.ensure(2 * sizeof(unsigned))) || (rc = h->osd_fix_scratch.ensure((size_t)slots * slot_words * 8))) return rc;
+            HIPCHK(hipMemsetAsync(h->osd_fix_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+            OsdExactArgs X = {};
+            X.o = a;
+            X.status = (const uint8_t *)h->osd_status.p;
+            X.corrected = (uint8_t *)h->osd_fix_synd.p;
+            X.list2 = (int32_t *)h->osd_fix_list.p;
+            X.counters2 = (unsigned *)h->osd_fix_counters.p;
+            X.scratch = (uint64_t *)h->osd_fix_scratch.p;
+            X.slot_words = (int64_t)slot_words;
+            X.hw = (a.n + 63) / 64;
+            const size_t xl = osd_exact_lds_bytes(a.m);
+            if (xl > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)osd_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xl));
+            hipLaunchKernelGGL(osd_exact_kernel, dim3((unsigned)slots), dim3(256), (unsigned)xl, h->stream, X);
+            HIPCHK(hipGetLastError());
+            OsdArgs a2 = a;
+            a2.synd = (const uint8_t *)h->osd_fix_synd.p;
+            a2.list = (const int32_t *)h->osd_fix_list.p;
+            a2.counters = (unsigned *)h->osd_fix_counters.p;
+            if ((rc = run_osd(a2))) return rc;
+        }
+    }
+    return LDPC_HIP_OK;
 }
 
 extern "C" {

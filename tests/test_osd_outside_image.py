@@ -2,9 +2,11 @@
 
 tests/golden/outimage_*.npz hold the REAL reference's outputs (tests/golden/make_golden_outimage.py) for rows inside and
 outside the image.  Inside, the OSD output is unique given the column order and the device must reproduce it bit for bit;
-outside, no x solves H x = s, the reference returns the solution of the subsystem of ITS pivot rows (a by-product of its
-linked-list elimination's sparsity heuristic), and the device flags the row instead (ldpc_hip_bposd_get_status == 2,
-include/ldpc_hip.h) -- for every OSD kernel family: registers, LDS, workgroup (H in LDS / HBM scratch).
+outside, no x solves H x = s and the reference returns the solution of the subsystem of ITS pivot rows (a by-product of its
+linked-list elimination's sparsity heuristic).  The device flags such rows (ldpc_hip_bposd_get_status == 2, include/ldpc_hip.h)
+AND returns the reference's vector for them: a workgroup per flagged row re-enacts the reference's pivot-row choice
+(ldpc_amd/csrc/osd_exact_kernel.h) and the ordinary OSD kernels run once more on the syndrome that keeps those rows -- for every
+OSD kernel family: registers, LDS, workgroup (H in LDS / HBM scratch).
 """
 import glob
 import os
@@ -91,7 +93,7 @@ def test_oracle_pivot_rows_against_the_real_reference(L, oracle_built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", [-1, 0, 2])
 @pytest.mark.parametrize("name", CASES)
-def test_device_flags_rows_outside_the_image(name, kernel):
+def test_device_flags_rows_outside_the_image_and_returns_the_reference_vector(name, kernel):
     from ldpc_amd.engine import HipBpEngine
     c = load(name)
     eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], np.full(c["n"], c["p"]), c["max_iter"], c["bp_method"], c["alpha"])
@@ -105,7 +107,7 @@ def test_device_flags_rows_outside_the_image(name, kernel):
     assert np.array_equal(status == 1, ~c["conv"] & c["inside"])
     ok = status < 2
     assert np.array_equal(dec[ok], c["dec"][ok]), "rows inside the image: the reference's OSD output, bit for bit"
-    # rows outside: deterministic, and a solution of as many checks as a rank-deficient system allows (all but the dependent one)
+    assert np.array_equal(dec, c["dec"]), "rows outside the image: the solution on the reference's own pivot rows, bit for bit"
     again = eng.decode_batch(c["synd"], osd=True)[0]
     assert np.array_equal(again, dec)
     resid = (((c["h"].astype(np.int64) @ dec.T.astype(np.int64)).T % 2) != c["synd"]).sum(axis=1)
@@ -127,4 +129,28 @@ def test_bposd_decoder_reports_status():
     d = BpOsdDecoder(c["h"], error_rate=c["p"], max_iter=c["max_iter"], bp_method="ms", ms_scaling_factor=c["alpha"], osd_method="osd_0")
     out = d.decode_batch(c["synd"])
     assert np.array_equal(d.osd_status_batch == 2, ~c["conv"] & ~c["inside"])
-    assert np.array_equal(out[d.osd_status_batch < 2], c["dec"][d.osd_status_batch < 2])
+    assert np.array_equal(out, c["dec"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [3, 5, 8])
+@pytest.mark.parametrize("osd", [(1, 0), (3, 4), (2, 3)])
+def test_device_against_the_oracle_on_random_rank_deficient_systems(L, osd, oracle_built):
+    """A torus with a duplicated, an all-zero and a repeated first row; syndromes with 1 .. 3 faulty bits; BP given one iteration so
+    that nearly every row goes to OSD.  Decisions of every row against the CPU restatement (itself pinned to the real reference above)."""
+    from ldpc_amd.engine import HipBpEngine
+    rng = np.random.default_rng(7 * L + osd[0])
+    h0 = _toric(L)
+    h = sp.vstack([h0, h0[1], sp.csr_matrix((1, h0.shape[1]), dtype=np.uint8), h0[0]]).tocsr()
+    m, n = h.shape
+    probs = rng.uniform(0.02, 0.2, size=n)
+    synd = np.stack([y for y, _ in _cases_outside(rng, h, 150)])
+    synd[::5] = (h @ (rng.random((n, 30)) < 0.1).astype(np.uint8) % 2).T  # some rows inside the image
+    eng = HipBpEngine(h.indptr, h.indices, n, probs, 1, 1, 0.75)
+    eng.set_osd(*osd)
+    dec, llr, it, cv = eng.decode_batch(synd, osd=True)
+    o = oracle_built.BpOracle(h, error_channel=probs, max_iter=1, bp_method="minimum_sum", ms_scaling_factor=0.75)
+    want = o.bposd_decode_batch(synd, osd[0], osd[1])
+    assert np.array_equal(cv, want[3]) and bits_equal(llr, want[1])
+    assert np.array_equal(dec, want[0])
+    assert (eng.osd_status(len(synd)) == 2).sum() > 50
