@@ -116,6 +116,7 @@ struct ldpc_hip_bp {
     int wave_ps_dr = 0, wave_ps_dc = 0;  // likewise for bp_wave_ps_kernel
     DeviceBuf wp_rdeg, wp_col, wp_epos;
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
+    DeviceBuf d_edge0;       // [n] initial edge values of the streamed kernel (BpArgs::edge0)
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
     DeviceBuf e_partner, e_kind, e_scol, e_prior;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
@@ -331,7 +332,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->d_edge0, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1628,6 +1629,14 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
             HIPCHK(hipGetLastError());
         } else {
+            if (kern.ring_depth && h->n > 0 && !getenv("LDPC_HIP_EXPLICIT_INIT")) {  // the first check pass reads this table instead of initial messages
+                if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
+                const dim3 ge((unsigned)((h->n + 255) / 256));
+                if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                a.edge0 = (const double *)h->d_edge0.p;
+            }
             hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(h->ev_mid, st));

@@ -164,6 +164,13 @@ __global__ void __launch_bounds__(256) bp_spread_init_kernel(const SpreadArgs a)
         At.st(l8, e, edge_form<METHOD, MATH>(sload(a.bp.llr0 + sload(a.bp.col_idx + e))));
 }
 
+// [n] initial edge values for BpArgs::edge0
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) bp_edge0_kernel(const double *llr0, int n, double *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = edge_form<METHOD, MATH>(llr0[j]);
+}
+
 // convergence bookkeeping of a round (bp.hpp:296-311, 320-322): lanes whose candidate syndrome matched are frozen
 // (decisions + posterior of THIS iteration), a tile whose lanes are all frozen or that reached max_iter gets its
 // outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing

@@ -60,9 +60,13 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
     const uint64_t never = a.invalid[tile];
     int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
 
-    // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j]
-    for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
-    __syncthreads();
+    // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j] -- written out, or (ring variant, a.edge0)
+    // left implicit: the first check pass reads the table of initial values instead of the message array
+    const bool implicit_init = RING != 0 && a.edge0 != nullptr;
+    if (!implicit_init) {
+        for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
+        __syncthreads();
+    }
 
     for (int it = 1; it <= a.max_iter; ++it) {
         // ---------------- check pass (bp.hpp:201-273) ----------------
@@ -70,7 +74,16 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
         if (METHOD == LDPC_HIP_MINIMUM_SUM)
             alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
 
-        if (RING) {
+        if (RING && implicit_init && it == 1) {
+            for (int i = wave; i < m; i += nwaves) {
+                double cur[DR];
+#pragma unroll
+                for (int k = 0; k < DR; ++k) cur[k] = sload(a.edge0 + sload(col_idx + i * DR + k));  // (the same in all 64 lanes)
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
+                check_row_live<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
+            }
+        } else if (RING) {
             // every row has exactly DR entries: row i starts at edge i * DR
             const int nsteps = wave < m ? (m - wave + nwaves - 1) / nwaves : 0;
             auto issue_row = [&](int i, int slot) {
