@@ -294,7 +294,8 @@ def early_exit_point(eng, h, dev, B, args, out, alpha, p=0.05):
             "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "bound_unit": "GB/s",
             "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": alg,
             "bound_note": "algorithmic bytes = sum over syndromes of iters_run * 4 * E * 8 + (m + 9 n + 5); a 64-syndrome tile runs until its "
-                          "slowest syndrome has converged and moves all 64 lanes' messages until then"}
+                          "slowest syndrome has converged and moves all 64 lanes' messages until then -- so, steered by the previous decode's "
+                          "iteration histogram, the live lanes' message state is compacted into dense tiles once mid-decode (DESIGN.md section 4)"}
 
 
 def main() -> None:

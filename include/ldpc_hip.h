@@ -199,10 +199,14 @@ int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
  * repacking a first pass of `first_pass_iters` iterations runs over the whole batch and the rows it leaves unconverged are
  * packed into dense tiles and decoded again from the start with the full max_iter (deterministic: same results).
  * -1 = automatic (max_iter / 8, default), 0 = off.  With repacking the call waits once for the device.
- * The streamed parallel schedule (codes too large for the on-chip kernels, batches of >= 32768 syndromes) repacks the
- * same way; there "automatic" prices both ways with the iteration histogram the previous decode on the handle left behind
- * and runs plain when that says so or says nothing yet -- no work is wasted where nothing converges.  (Reading that
- * histogram means a streamed *_async decode first waits for the previous decode on the same handle.) */
+ * The streamed parallel schedule (codes too large for the on-chip kernels, batches of >= 32768 syndromes) cuts a decode in two
+ * as well, but CARRIES ON instead of starting again: after the first pass the message state of the unconverged rows is
+ * gathered, lane by lane, out of the first pass's 64-syndrome tiles into dense tiles and the second pass continues from
+ * iteration first_pass_iters + 1 (a tile moves all 64 lanes' messages until its slowest syndrome is done; after the
+ * compaction the tiles hold live lanes only).  There "automatic" prices a cut at every iteration against the plain run with
+ * the iteration histogram the previous decode on the handle left behind, and runs plain when that says so or says nothing
+ * yet -- no work is wasted where nothing converges.  (Reading that histogram means a streamed *_async decode first waits for
+ * the previous decode on the same handle; a batch decoded in several chunks falls back to starting the second pass afresh.) */
 int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
 /* Serial schedule kernels: bits that share no check commute, so the schedule is cut into levels of mutually check-disjoint
  * bits (level = 1 + the highest level among the EARLIER bits sharing a check) and a workgroup runs a tile level by level

@@ -49,6 +49,9 @@ struct BpArgs {
     // pass takes its inputs from this table through the scalar cache -- one array write and one array read less per decode
     // (0.5 of 50 iterations on the headline, 0.5 of ~9 where everything converges early).
     const double *edge0;
+    // > 0: the message array A already holds the bit_to_check state after `it_start` iterations (lanes compacted out of the tiles
+    // of a first pass, decode_stream_repacked): no initialisation, iterations count on from it_start + 1
+    int32_t it_start;
 };
 
 // What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in

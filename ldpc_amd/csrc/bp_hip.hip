@@ -117,6 +117,11 @@ struct ldpc_hip_bp {
     DeviceBuf wp_rdeg, wp_col, wp_epos;
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
     DeviceBuf d_edge0;       // [n] initial edge values of the streamed kernel (BpArgs::edge0)
+    // continuation of a first pass (decode_stream_repacked): decode_device takes its message state from here and counts on from cont_it_start
+    double *cont_A = nullptr;
+    int32_t cont_it_start = 0;
+    int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
+    DeviceBuf rp_msg;
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
     DeviceBuf e_partner, e_kind, e_scol, e_prior;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
@@ -332,7 +337,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->d_edge0, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->d_edge0, &h->rp_msg, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -1527,6 +1532,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
     const int handoff = h->handoff < 0 ? 256 : h->handoff;
+    h->last_chunk_tiles = chunk;
     if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
     if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
     if ((rc = h->counter.ensure(16))) return rc;
@@ -1563,6 +1569,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
+        if (h->cont_A) { a.A = h->cont_A + (size_t)t0 * (size_t)h->nnz * LDPC_WAVE; a.it_start = h->cont_it_start; }
         a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
         a.invalid = (const uint64_t *)h->invalid.p;
         a.dec = (uint64_t *)h->dec.p;
@@ -1616,7 +1623,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // batch skips the persistent kernel (sa.n_tiles >= 0), otherwise the kernels read it from counters[1]
         unsigned grid_tiles = 0;
         int first_round = 1;  // a tile parked by the persistent kernel has completed >= 1 iteration
-        if (handoff > 0 && tiles <= handoff && h->max_iter > 1) {
+        if (handoff > 0 && tiles <= handoff && h->max_iter - a.it_start > 1) {
             // so few tiles that they would each sit on one compute unit: per-pass launches from the start
             grid_tiles = (unsigned)tiles;
             sa.n_tiles = (int32_t)tiles;
@@ -1624,7 +1631,8 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             first_round = 0;
             hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((grid_tiles + 255) / 256), dim3(256), 0, st, sa);
             const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), grid_tiles);  // (a grid dimension must not be 0: empty matrices)
-            if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
+            if (a.it_start > 0) { /* the message state is there already */ }
+            else if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
             else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), gi, dim3(256), 0, st, sa);
             else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
             HIPCHK(hipGetLastError());
@@ -1661,7 +1669,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
             const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
             const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
-            const int rounds = h->max_iter - first_round;
+            const int rounds = h->max_iter - (first_round ? first_round : a.it_start);  // (a tile parked by the persistent kernel knows its own it0)
             const volatile unsigned *flag = h->h_flag;
             for (int round = 0; round < rounds; ++round) {
                 if (*flag == sa.seq) break;  // a look, not a wait
@@ -1708,16 +1716,20 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 
 
 // Two passes of the streamed parallel schedule: k1 iterations for everyone, then the rows that have not converged are
-// gathered into a dense batch and decoded again from the start with the full budget (BP is deterministic: the second
-// pass repeats the first k1 iterations of those rows and carries on; its results replace the first pass's).  Whether
-// that pays depends on the noise, which the host cannot see -- so every streamed decode leaves a histogram of its
-// iteration counts behind (one tiny kernel, copied asynchronously), and the next decode on the handle prices both
-// ways with it: a tile costs as many iterations as its slowest syndrome, i.e. sum_j (1 - F(j-1)^64) for the plain run
-// (F = fraction converged within j iterations) against the same sum up to k1 plus (1 - F(k1)) max_iter for the
-// repacked one, minimised over k1.  No work is wasted when nothing converges (the first call and every call whose
-// predecessor says "plain" run plain), and results do not depend on any of this.
+// COMPACTED: their message state is gathered, lane by lane, out of the first pass's tiles into dense tiles, and the decode
+// carries on from iteration k1 + 1 on those (same operations on the same values: same results).  A 64-syndrome tile runs until
+// its slowest syndrome is done and moves all 64 lanes' messages until then; after the compaction the tiles hold live lanes
+// only.  (Rounds 1 - 2 restarted the gathered rows from scratch, which only pays when almost everything has converged by k1.)
+// Whether and where to cut depends on the noise, which the host cannot see -- so every streamed decode leaves a histogram of
+// its iteration counts behind (one tiny kernel, copied asynchronously) and the next decode on the handle prices the
+// alternatives with it, in tile-iterations per tile of the batch: F(j) = fraction converged within j iterations,
+//     plain        sum_j (1 - F(j-1)^64)
+//     cut at k     sum_{j<=k} (1 - F(j-1)^64)  +  gather  +  (1 - F(k)) sum_{j>k} (1 - G_k(j-1)^64),  G_k = F conditioned on > k,
+// gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) / 4 of an iteration (an
+// iteration moves four arrays), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
+// converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
 static int stream_first_pass_length(ldpc_hip_bp *h) {
-    if (h->repack_iters > 0) return h->repack_iters;
+    if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
     if (!h->hist_pending || h->hist_max_iter != h->max_iter) return 0;
     if (hipEventSynchronize(h->ev_hist) != hipSuccess) return 0;
     const int full = h->max_iter, top = full < 255 ? full : 255;
@@ -1727,18 +1739,27 @@ static int stream_first_pass_length(ldpc_hip_bp *h) {
     std::vector<double> F((size_t)top + 1, 0.0);  // F[j]: converged within j iterations
     double acc = 0;
     for (int j = 1; j <= top; ++j) { acc += h->h_hist[j]; F[(size_t)j] = acc / total; }
-    auto tile_runs = [&](int j) { return 1.0 - std::pow(F[(size_t)(j - 1 < top ? j - 1 : top)], 64.0); };  // still going at iteration j
+    auto Fj = [&](int j) { return F[(size_t)(j < top ? j : top)]; };
+    auto tile_runs = [&](int j) { return 1.0 - std::pow(Fj(j - 1), 64.0); };  // still going at iteration j
     double plain = 0;
     for (int j = 1; j <= full; ++j) plain += tile_runs(j);
     double best = plain, prefix = 0;
     int best_k = 0;
-    for (int k = 1; k <= full / 2 && k <= top; ++k) {
+    for (int k = 1; k < full && k <= top; ++k) {
         prefix += tile_runs(k);
-        if (k < 2) continue;
-        const double cost = prefix + (1.0 - F[(size_t)k]) * full + 0.5;  // + gather / scatter / a second launch, in iterations
+        const double live = 1.0 - Fj(k);
+        if (k < 2 || live <= 0.0 || live > 0.6) continue;
+        double rest = 0;
+        for (int j = k + 1; j <= full; ++j) {
+            const double g = (Fj(j - 1) - Fj(k)) / live;  // of the rows alive after k: done within j - 1
+            const double r = 1.0 - std::pow(g < 0 ? 0 : g, 64.0);
+            rest += r;
+            if (r < 1e-9 && j > top) break;
+        }
+        const double cost = prefix + 0.25 * (1.0 + live) + 0.1 + live * rest;
         if (cost < best) { best = cost; best_k = k; }
     }
-    return best < 0.85 * plain ? best_k : 0;
+    return best < 0.97 * plain ? best_k : 0;
 }
 
 static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
@@ -1791,8 +1812,31 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         auto grid = [](size_t items) { return flat_grid(items); };
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
         HIPCHK(hipGetLastError());
-        if ((rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
-                                (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, false))) return rc;
+        // the listed rows' message state after k1 iterations, lane by lane, into dense tiles -- possible when the first pass kept the
+        // whole batch's messages resident (one chunk) and ran the streamed kernels (they leave bit_to_check in msgA)
+        const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE, tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
+        const size_t per_tile = sizeof(double) * (size_t)h->nnz * LDPC_WAVE;
+        bool carry_on = h->last_chunk_tiles >= tiles1 && h->nnz > 0 && !getenv("LDPC_HIP_REPACK_RESTART");
+        if (carry_on && h->rp_msg.ensure(per_tile * (size_t)tiles2)) { carry_on = false; (void)hipGetLastError(); }
+        if (carry_on) {
+            const int epw = 16;
+            const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)tiles2);
+            HIPCHK(hipEventRecord(h->ev0, h->stream));  // (the compaction belongs to this decode's kernel time)
+            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, h->stream, (const double *)h->msgA.p, list, cnt, h->nnz, epw, (double *)h->rp_msg.p);
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventSynchronize(h->ev1));
+            float gms = 0.f;
+            HIPCHK(hipEventElapsedTime(&gms, h->ev0, h->ev1));
+            ms1 += gms;
+            h->cont_A = (double *)h->rp_msg.p;
+            h->cont_it_start = k1;
+        }
+        rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
+                           (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, false);
+        h->cont_A = nullptr;
+        h->cont_it_start = 0;
+        if (rc) return rc;
         h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
         hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * n1), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
         if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * n1), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) bp_spread_state_init_kernel(const SpreadA
     const int64_t valid = a.bp.batch - (int64_t)t * LDPC_WAVE;
     st->done[0] = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
     st->unsat[0] = st->unsat[1] = 0ull;
-    st->it0 = 0;
+    st->it0 = a.bp.it_start;
     st->end_round = INT32_MAX;
     for (int l = 0; l < 64; ++l) st->lane_iter[l] = 0;
     a.bp.handoff_list[t] = t;

@@ -63,12 +63,12 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
     // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j] -- written out, or (ring variant, a.edge0)
     // left implicit: the first check pass reads the table of initial values instead of the message array
     const bool implicit_init = RING != 0 && a.edge0 != nullptr;
-    if (!implicit_init) {
+    if (!implicit_init && a.it_start == 0) {
         for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
         __syncthreads();
     }
 
-    for (int it = 1; it <= a.max_iter; ++it) {
+    for (int it = a.it_start + 1; it <= a.max_iter; ++it) {
         // ---------------- check pass (bp.hpp:201-273) ----------------
         double alpha = 0.0;
         if (METHOD == LDPC_HIP_MINIMUM_SUM)

@@ -168,6 +168,21 @@ __global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__r
         dst[t] = src[(int64_t)list[r] * width + (t - r * width)];
     }
 }
+// message state of listed syndromes, lane by lane, out of the 64-syndrome tiles of a first pass into dense tiles: syndrome
+// list[r] (tile list[r] / 64, lane list[r] % 64) becomes lane r % 64 of tile r / 64; src, dst: [tiles][nnz][64] doubles.
+// One wavefront per (destination tile, edge): 64 gathered 8-byte loads (the live lanes of a source row share sectors), one 512-byte store.
+__global__ void __launch_bounds__(256) gather_lane_state_kernel(const double *__restrict__ src, const int32_t *__restrict__ list, int64_t count,
+                                                                int nnz, int edges_per_wave, double *__restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.y, r = tile * 64 + lane;
+    const bool live = r < count;
+    const int64_t b = live ? (int64_t)list[r] : 0;
+    const double *from = src + ((b >> 6) * (int64_t)nnz) * 64 + (b & 63);
+    double *to = dst + (tile * (int64_t)nnz) * 64 + lane;
+    const int e0 = (blockIdx.x * 4 + wave) * edges_per_wave;
+    for (int e = e0; e < e0 + edges_per_wave && e < nnz; ++e) to[(int64_t)e * 64] = live ? from[(int64_t)e * 64] : 0.0;
+}
+
 template <class T>
 __global__ void scatter_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ list, int64_t count, int width,
                                     T *__restrict__ dst) {
