@@ -162,6 +162,10 @@ struct ldpc_hip_bp {
 
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
     DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
+    // small calls with host buffers (a single decode()): one host-mapped, coherent block that the kernels read and write in place --
+    // no copy commands at all, one launch sequence and one wait
+    unsigned char *pin_host = nullptr, *pin_dev = nullptr;
+    static constexpr size_t PIN_BYTES = 512u * 1024u;
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
@@ -356,6 +360,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->pin_host) (void)hipHostFree(h->pin_host);
     if (h->h_hist) (void)hipHostFree(h->h_hist);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -2210,6 +2215,37 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
     const bool h_synd = !is_device_ptr(synd), h_dec = !is_device_ptr(decoding);
     const bool h_llr = llr && !is_device_ptr(llr), h_it = iters && !is_device_ptr(iters);
     const bool h_cv = conv && !is_device_ptr(conv);
+    // A small call whose buffers are all on the host (the reference's only mode: one syndrome per decode()): five copy commands
+    // and their completion cost more than the kernels.  The kernels work in a host-mapped block instead.
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_dec = up16(B * m), o_llr = o_dec + up16(B * n), o_it = o_llr + up16(B * n * 8), o_cv = o_it + up16(B * 4), pin_need = o_cv + up16(B);
+    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && pin_need <= ldpc_hip_bp::PIN_BYTES && !getenv("LDPC_HIP_NO_PINNED_PATH")) {
+        if (!h->pin_host) {
+            if (hipHostMalloc((void **)&h->pin_host, ldpc_hip_bp::PIN_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                hipHostGetDevicePointer((void **)&h->pin_dev, h->pin_host, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (h->pin_host) (void)hipHostFree(h->pin_host);
+                h->pin_host = h->pin_dev = nullptr;
+            }
+        }
+        if (h->pin_host) {
+            HIPCHK(hipStreamSynchronize(h->stream));  // (a previous asynchronous call may still use the block's neighbours -- and its results)
+            std::memcpy(h->pin_host, synd, B * m);
+            unsigned char *dv = h->pin_dev;
+            // BP + OSD needs log-ratios and flags whether the caller asks for them or not: the block has room for them
+            double *p_llr = (llr || osd >= 0) ? (double *)(dv + o_llr) : nullptr;
+            uint8_t *p_cv = (conv || osd >= 0) ? (uint8_t *)(dv + o_cv) : nullptr;
+            int32_t *p_it = iters ? (int32_t *)(dv + o_it) : nullptr;
+            if ((rc = osd >= 0 ? bposd_device(h, osd ? h->osd_method : 1, osd ? h->osd_order : 0, dv, batch, dv + o_dec, p_llr, p_it, p_cv)
+                               : decode_device(h, dv, batch, dv + o_dec, p_llr, p_it, p_cv))) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));
+            std::memcpy(decoding, h->pin_host + o_dec, B * n);
+            if (llr) std::memcpy(llr, h->pin_host + o_llr, B * n * 8);
+            if (iters) std::memcpy(iters, h->pin_host + o_it, B * 4);
+            if (conv) std::memcpy(conv, h->pin_host + o_cv, B);
+            return LDPC_HIP_OK;
+        }
+    }
     if (h_synd) {
         if ((rc = h->st_synd.ensure(B * m ? B * m : 1))) return rc;
         HIPCHK(hipMemcpyAsync(h->st_synd.p, synd, B * m, hipMemcpyHostToDevice, h->stream));
