@@ -330,6 +330,10 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * register for the whole decode (bp_edge_kernel.h); 6 = that variant where it applies, else as -1.
  * Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
+/* Measurement / test switches: kernel-shape choices that never change a result (profiles/README.md lists them: "PS_TEAM",
+ * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", ...).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
+ * created; afterwards only this call changes a switch (value < 0: back to "not set").  Unknown names are an error. */
+int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value);
 
 #define LDPC_HIP_MATH_LIBM_EXACT 0
 #define LDPC_HIP_MATH_FAST 1

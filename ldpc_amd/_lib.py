@@ -21,7 +21,7 @@ SYMBOLS = (
     "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
-    "ldpc_hip_bp_multi_create", "ldpc_hip_bp_multi_destroy", "ldpc_hip_bp_multi_devices", "ldpc_hip_bp_multi_handle",
+    "ldpc_hip_bp_set_debug_switch", "ldpc_hip_bp_multi_create", "ldpc_hip_bp_multi_destroy", "ldpc_hip_bp_multi_devices", "ldpc_hip_bp_multi_handle",
     "ldpc_hip_bp_multi_decode_batch", "ldpc_hip_bp_multi_last_kernel_ms", "ldpc_hip_bp_multi_set_staging",
 )
 
@@ -99,6 +99,7 @@ def load():
     lib.ldpc_hip_bp_set_math.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_ring.argtypes = [vp, i32]
     lib.ldpc_hip_bp_set_small_code_kernel.argtypes = [vp, i32]
+    lib.ldpc_hip_bp_set_debug_switch.argtypes = [vp, C.c_char_p, i32]
     lib.ldpc_hip_bp_set_handoff.argtypes = [vp, i32]
     lib.ldpc_hip_bp_multi_create.argtypes = [C.POINTER(BpDesc), C.POINTER(i32), i32, C.POINTER(vp)]
     lib.ldpc_hip_bp_multi_destroy.argtypes = [vp]

@@ -100,7 +100,21 @@ struct DeviceBuf {  // grow-only device allocation
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Measurement / test switches (none changes a result; profiles/README.md lists them).  They live in the handle: seeded ONCE, at
+// creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
+// getenv on the decode path, and nothing a test can change under a live handle by accident.
+static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF", "REPACK_RESTART",
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH"};
+constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
+
 struct ldpc_hip_bp {
+    int32_t switches[k_n_switches];  // -1 = not set
+    int sw(const char *name) const {  // value of a switch, -1 when it is not set
+        for (int i = 0; i < k_n_switches; ++i)
+            if (!std::strcmp(name, k_switch_names[i])) return switches[i];
+        return -1;
+    }
+    bool on(const char *name) const { return sw(name) > 0; }
     int device = 0;
     int32_t m = 0, n = 0, nnz = 0;
     int32_t max_iter = 1, bp_method = 0;
@@ -265,6 +279,11 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     HIPCHK(hipSetDevice(device));
 
     auto *h = new ldpc_hip_bp;
+    for (int i = 0; i < k_n_switches; ++i) {
+        const std::string var = std::string("LDPC_HIP_") + k_switch_names[i];
+        const char *e = getenv(var.c_str());
+        h->switches[i] = e ? (*e ? atoi(e) : 1) : -1;
+    }
     h->device = device;
     h->m = d->m; h->n = d->n; h->nnz = d->nnz;
     h->max_iter = d->max_iter; h->bp_method = d->bp_method;
@@ -477,6 +496,13 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles) {
     if (threshold_tiles < -1) return fail(LDPC_HIP_ERR_INVALID, "threshold must be -1 (auto), 0 (off) or a tile count");
     h->handoff = threshold_tiles > 32768 ? 32768 : threshold_tiles;
     return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value) {
+    if (!h || !name) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    for (int i = 0; i < k_n_switches; ++i)
+        if (!std::strcmp(name, k_switch_names[i])) { h->switches[i] = value < 0 ? -1 : value; return LDPC_HIP_OK; }
+    return fail(LDPC_HIP_ERR_INVALID, "unknown switch '%s'", name);
 }
 
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode) {
@@ -1165,7 +1191,7 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int6
     const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u || batch <= 256 * (int64_t)w));
     if (team) {
         int tw = (p.np + 64 * u - 1) / (64 * u);
-        if (const char *e = getenv("LDPC_HIP_TEAM_WAVES")) { const int v = atoi(e); if (v >= 1) tw = v; }  // (measurements)
+        if (h->sw("TEAM_WAVES") >= 1) tw = h->sw("TEAM_WAVES");  // (measurements)
         if (tw < 2) tw = 2;
         if (tw > 16) tw = 16;
         p.team = true;
@@ -1173,11 +1199,11 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int6
         p.kern = p.kern_team;
         if (ms) {  // the LDS copy of the priors, 8 (np + 2) bytes: worth reading them from memory where that fits another workgroup
             const size_t lean_shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc, false, false);
-            if (lds / (lean_shared + p.per_wave) > lds / (p.shared + p.per_wave) && !getenv("LDPC_HIP_TEAM_PRIOR_LDS")) { p.shared = lean_shared; p.prior_global = true; }
+            if (lds / (lean_shared + p.per_wave) > lds / (p.shared + p.per_wave) && !h->on("TEAM_PRIOR_LDS")) { p.shared = lean_shared; p.prior_global = true; }
         }
         // (the kernel's ~100 VGPRs allow 16 wavefronts per CU: two teams of eight beat one of thirteen -- 768 x 1600: 4.0 vs 4.8 ms)
         p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
-        if (p.groups_per_cu >= 2 && p.waves > 8 && !getenv("LDPC_HIP_TEAM_WAVES")) p.waves = 8;
+        if (p.groups_per_cu >= 2 && p.waves > 8 && h->sw("TEAM_WAVES") < 1) p.waves = 8;
         if (p.groups_per_cu * p.waves > 16) p.groups_per_cu = 16 / p.waves;
         if (p.groups_per_cu < 1) p.groups_per_cu = 1;
         return p;
@@ -1258,7 +1284,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
     // A batch so small that every wavefront decodes only a few syndromes takes as long as its slowest syndrome: then the
     // workgroup's wavefronts share one (TEAM), one round of 64 entries each per pass.  LDPC_HIP_PS_TEAM=0 / 1 overrides (measurements).
     bool team = batch <= 256 * (int64_t)w * 8;  // (BB144, w = 16: 0.96 -> 0.57 ms at 8 192 syndromes, 1.52 -> 1.37 ms at 32 768, 4.2 -> 4.5 ms at 131 072)
-    if (const char *e = getenv("LDPC_HIP_PS_TEAM")) team = atoi(e) != 0;
+    if (h->sw("PS_TEAM") >= 0) team = h->sw("PS_TEAM") != 0;
     if (team) {
         const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
         int tw = (int)(rounds < 2 ? 2 : rounds > 8 ? 8 : rounds);
@@ -1642,7 +1668,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
             HIPCHK(hipGetLastError());
         } else {
-            if (kern.ring_depth && h->n > 0 && !getenv("LDPC_HIP_EXPLICIT_INIT")) {  // the first check pass reads this table instead of initial messages
+            if (kern.ring_depth && h->n > 0 && !h->on("EXPLICIT_INIT")) {  // the first check pass reads this table instead of initial messages
                 if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
                 const dim3 ge((unsigned)((h->n + 255) / 256));
                 if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
@@ -1689,7 +1715,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
         HIPCHK(hipGetLastError());
-        if (getenv("LDPC_HIP_DEBUG_HANDOFF")) {  // diagnostic only: waits for the device and reports what the persistent kernel parked
+        if (h->on("DEBUG_HANDOFF")) {  // diagnostic only: waits for the device and reports what the persistent kernel parked
             unsigned c[4] = {0, 0, 0, 0};
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipMemcpy(c, h->counter.p, 16, hipMemcpyDeviceToHost));
@@ -1821,7 +1847,7 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         // whole batch's messages resident (one chunk) and ran the streamed kernels (they leave bit_to_check in msgA)
         const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE, tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
         const size_t per_tile = sizeof(double) * (size_t)h->nnz * LDPC_WAVE;
-        bool carry_on = h->last_chunk_tiles >= tiles1 && h->nnz > 0 && !getenv("LDPC_HIP_REPACK_RESTART");
+        bool carry_on = h->last_chunk_tiles >= tiles1 && h->nnz > 0 && !h->on("REPACK_RESTART");
         if (carry_on && h->rp_msg.ensure(per_tile * (size_t)tiles2)) { carry_on = false; (void)hipGetLastError(); }
         if (carry_on) {
             const int epw = 16;
@@ -1991,7 +2017,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         const size_t phase = (fixed + (size_t)A.pow2 * 2 + 15) & ~(size_t)15;
         // blocked elimination (osd_block_eliminate): up to eight rows per thread in registers -> m <= 2048, and the combination table
         // of the block's pivot rows in LDS; LDPC_HIP_OSD_UNBLOCKED=1 keeps the one-pivot-per-step loop (A/B measurements)
-        const bool blocked = a.m <= OSD_BLOCK_ROWS && !getenv("LDPC_HIP_OSD_UNBLOCKED");
+        const bool blocked = a.m <= OSD_BLOCK_ROWS && !h->on("OSD_UNBLOCKED");
         const size_t pbuf_bytes = 16 * OSD_PIECE * 16 * 8;  // [group of four pivots][plane of the round][combination]
         size_t room = (size_t)a.n * 8;
         const size_t elim = (size_t)a.m * 8 + (blocked ? pbuf_bytes : 0);
@@ -2016,8 +2042,8 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
                 const double cost = std::ceil(rows / (256.0 * pc)) * (1.0 + 0.25 * (4.0 / nb - 1.0));  // rounds of resident workgroups x time of a row
                 if (cost < best - 1e-9) { best = cost; A.nplanes = nb; weigh = wb; }
             }
-            if (const char *e = getenv("LDPC_HIP_OSD_PLANES")) {  // (tests, measurements)
-                const int nb = atoi(e);
+            if (h->sw("OSD_PLANES") > 0) {  // (tests, measurements)
+                const int nb = h->sw("OSD_PLANES");
                 if (nb == 1 || nb == 2 || nb == 4) { A.nplanes = nb; weigh = (((size_t)a.n * 2 + 7) & ~(size_t)7) + 56 * (size_t)A.hwords + ((size_t)a.m + 1) * 8 * (size_t)nb; }
             }
         }
@@ -2037,7 +2063,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
         if (A.slot_stride < 1) A.slot_stride = 1;
         int per_cu = (int)((160u * 1024u) / (lds + 1024));  // (+ the kernel's static LDS)
         if (per_cu > 4) per_cu = 4;
-        if (const char *e = getenv("LDPC_HIP_OSD_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }  // (measurements)
+        if (h->sw("OSD_PER_CU") >= 1 && h->sw("OSD_PER_CU") < per_cu) per_cu = h->sw("OSD_PER_CU");  // (measurements)
         if (per_cu < 1) per_cu = 1;
         int64_t slots = 256 * (int64_t)per_cu;
         if (slots > batch) slots = batch;
@@ -2073,7 +2099,7 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     // that keeps exactly those rows (osd_exact_kernel.h); the same OSD kernels then run once more over these rows.  No host round trip:
     // both launches size themselves from device-side counters and cost a few microseconds when there is nothing to do.
     const bool rank_known = (double)a.m * a.m * a.words < 4e9;
-    if (rank_known && a.n - osd_k(h) < a.m && a.m <= 8192 && !getenv("LDPC_HIP_OSD_NO_EXACT")) {
+    if (rank_known && a.n - osd_k(h) < a.m && a.m <= 8192 && !h->on("OSD_NO_EXACT")) {
         const size_t slot_words = osd_exact_slot_words(a.m, a.n);
         int64_t slots = 512;
         if (slots > batch) slots = batch;
@@ -2219,7 +2245,7 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
     // and their completion cost more than the kernels.  The kernels work in a host-mapped block instead.
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_dec = up16(B * m), o_llr = o_dec + up16(B * n), o_it = o_llr + up16(B * n * 8), o_cv = o_it + up16(B * 4), pin_need = o_cv + up16(B);
-    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && pin_need <= ldpc_hip_bp::PIN_BYTES && !getenv("LDPC_HIP_NO_PINNED_PATH")) {
+    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && pin_need <= ldpc_hip_bp::PIN_BYTES && !h->on("NO_PINNED_PATH")) {
         if (!h->pin_host) {
             if (hipHostMalloc((void **)&h->pin_host, ldpc_hip_bp::PIN_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&h->pin_dev, h->pin_host, 0) != hipSuccess) {

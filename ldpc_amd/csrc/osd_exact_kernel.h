@@ -18,8 +18,8 @@
 // rref + lu_solve make the same choices) and writes the syndrome s' that agrees with s on the chosen pivot rows and lies in
 // the image of H: s'_i = s_i ^ (what the elimination leaves of s in row i).  H x = s' has the solutions of
 // (pivot rows of H) x = (pivot rows of s), so the ordinary OSD kernels, run again on s', return the reference's vector --
-// OSD-0 and the higher orders alike (osd.hpp:119-187 solves every candidate on those rows).  CPU twin:
-// oracle/bp_oracle.c, osd_reference_pivot_rows_syndrome; both pinned to the real reference (tests/test_osd_outside_image.py).
+// OSD-0 and the higher orders alike (osd.hpp:119-187 solves every candidate on those rows).  Pinned to the real reference,
+// directly and through the CPU checker's twin of this routine (tests/test_osd_outside_image.py).
 struct OsdExactArgs {
     OsdArgs o;                 // m, n, CSR, synd, llr, list / counters of the first pass
     const uint8_t *status;     // [batch] of the first pass: 2 = outside the image

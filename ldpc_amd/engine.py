@@ -149,6 +149,10 @@ class HipBpEngine:
         """On-chip kernels for small codes: -1 automatic (default), 0 never, 1 whenever a syndrome fits in LDS, 2 slot kernel only, 3 lane = node wavefront kernel only (4 / 5: one wavefront / a workgroup per syndrome), 6 lane = edge kernel where it applies."""
         _lib.check(self._lib.ldpc_hip_bp_set_small_code_kernel(self._h, int(mode)))
 
+    def set_debug_switch(self, name, value=1):
+        """Measurement / test switch of the handle (``ldpc_hip_bp_set_debug_switch``; never changes a result).  ``value < 0`` unsets."""
+        _lib.check(self._lib.ldpc_hip_bp_set_debug_switch(self._h, str(name).encode(), int(value)))
+
     def workspace_bytes(self, batch):
         return int(self._lib.ldpc_hip_bp_workspace_bytes(self._h, int(batch)))
 
@@ -355,7 +359,7 @@ class HipBpMultiEngine:
     and return their decisions bit-packed).  For one process PER GPU use ``ldpc_amd.sharding`` instead.
     """
 
-    _BROADCAST = ("set_channel", "set_params", "set_schedule", "set_random_serial", "set_tuning", "set_math", "set_ring", "set_handoff", "set_osd",
+    _BROADCAST = ("set_debug_switch", "set_channel", "set_params", "set_schedule", "set_random_serial", "set_tuning", "set_math", "set_ring", "set_handoff", "set_osd",
                   "set_repack", "set_serial_kernel", "set_osd_kernel", "set_small_code_kernel")
 
     def __init__(self, row_ptr, col_idx, n, channel_probs, max_iter, bp_method, ms_scaling_factor, device_ids):

@@ -168,3 +168,24 @@ def test_codes_outside_the_family_take_the_other_kernels(oracle_built):
     hempty = np.array([[1, 1, 0, 0], [0, 1, 1, 0]], np.uint8)
     for h in (h3, hempty):
         _check(h, np.full(4, 0.1), 5, 1.0, _syndromes(h, 0.2, 40, 1), oracle_built)
+
+
+def test_debug_switches_live_in_the_handle(monkeypatch):
+    """Environment variables seed the switches when the handle is created; afterwards only set_debug_switch changes them."""
+    from ldpc_amd import _lib
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(bivariate_bicycle_hx())
+    n = h.shape[1]
+    monkeypatch.setenv("LDPC_HIP_PS_TEAM", "1")
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.05), 20, 0, 1.0)
+    monkeypatch.setenv("LDPC_HIP_PS_TEAM", "0")  # too late for this handle: not read again
+    synd = _syndromes(h, 0.05, 300, 1)
+    a = eng.decode_batch(synd)
+    eng.set_debug_switch("PS_TEAM", 0)
+    b = eng.decode_batch(synd)
+    eng.set_debug_switch("PS_TEAM", -1)
+    for x, y in zip(a, b):
+        assert np.array_equal(_bits(x), _bits(y))
+    with pytest.raises(_lib.LdpcHipError, match="unknown switch"):
+        eng.set_debug_switch("NO_SUCH_SWITCH", 1)

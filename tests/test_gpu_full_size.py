@@ -123,12 +123,12 @@ def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built, monkeypatch, 
     its columns in sorted order, the T planes squeezed out 1024 rows at a time."""
     from ldpc_amd import codes
     from ldpc_amd.engine import HipBpEngine
-    if unblocked:
-        monkeypatch.setenv("LDPC_HIP_OSD_UNBLOCKED", "1")
     h = sp.csr_matrix(codes.regular_ldpc_code(n, 3, 6, seed=4))
     m = h.shape[0]
     assert m > 1024
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.08), 4, 1, 0.75)
+    if unblocked:
+        eng.set_debug_switch("OSD_UNBLOCKED", 1)
     s = eng.gen_bsc_syndromes(5, 0.08, shot0=0, shots=40, device="cuda:0").cpu().numpy()
     o = oracle_built.BpOracle(h, error_rate=0.08, max_iter=4, bp_method="minimum_sum", ms_scaling_factor=0.75)
     for method, order in ((3, 7), (2, 5), (1, 0)):

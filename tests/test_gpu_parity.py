@@ -465,7 +465,7 @@ def test_workgroup_osd_kernel_variants(name, unblocked, monkeypatch):
     c = load_case(name)
     eng = _engine(c)
     if unblocked:
-        monkeypatch.setenv("LDPC_HIP_OSD_UNBLOCKED", "1")  # read by every decode call
+        eng.set_debug_switch("OSD_UNBLOCKED", 1)
     for kernel in (2, -1):  # 2: workgroup kernel, H in HBM whatever the size; -1: the default dispatch (400 x 900: workgroup kernel, copy in LDS)
         eng.set_osd_kernel(kernel)
         eng.set_osd(c["osd_method"], c["osd_order"])
@@ -483,7 +483,7 @@ def test_workgroup_osd_kernel_staged_planes(name, planes, monkeypatch):
     otherwise cost resident workgroups and many rows wait): the same solutions whichever it picks."""
     c = load_case(name)
     eng = _engine(c)
-    monkeypatch.setenv("LDPC_HIP_OSD_PLANES", planes)
+    eng.set_debug_switch("OSD_PLANES", int(planes))
     eng.set_osd_kernel(2)
     eng.set_osd(c["osd_method"], c["osd_order"])
     dec = eng.decode_batch(c["syndromes"], want_llr=False, osd=True)[0]
@@ -594,7 +594,7 @@ def test_on_chip_and_streaming_kernels_agree_with_the_reference(name, small, mon
         assert np.array_equal(d2[r:r + k], c["decoding"]) and np.array_equal(i2[r:r + k], c["iterations"])
     if small == 1 and c["bp_method"] == "product_sum":  # the lane = entry kernel in both of its forms, whatever the batch size would pick
         for form in ("0", "1"):
-            monkeypatch.setenv("LDPC_HIP_PS_TEAM", form)
+            eng.set_debug_switch("PS_TEAM", int(form))
             d3, l3, i3, c3 = eng.decode_batch(c["syndromes"])
             assert np.array_equal(d3, c["decoding"]) and np.array_equal(i3, c["iterations"]) and bits_equal(l3[: len(c["llr"])], c["llr"]), form
 
