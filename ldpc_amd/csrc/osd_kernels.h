@@ -94,14 +94,27 @@ __global__ void __launch_bounds__(256) osd_status_kernel(const OsdArgs a, uint8_
     }
 }
 
+// Rows for the persistent workers (wavefronts, or workgroups in osd_big_kernel).  Worker g of W starts with entry g of the list --
+// no atomic: a visit to the work counter costs ~1 us under load and one word serves ~88 of them per us, which for the few
+// hundred listed rows of a small batch was most of the kernel (8 192 idle wavefronts queueing for one word: ~100 us) -- and
+// workers beyond the list leave at once.  Entries W, W + 1, ... are handed out through the counter; none exist when W >= count.
+__device__ __forceinline__ unsigned osd_list_count(const OsdArgs &a) {
+    return __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int64_t osd_first_row(const OsdArgs &a, unsigned worker) {
+    return worker < osd_list_count(a) ? (int64_t)a.list[worker] : -1;
+}
 // next unconverged row for this wavefront, -1 when the list is exhausted
-__device__ __forceinline__ int64_t osd_next_row(const OsdArgs &a, int lane) {
+__device__ __forceinline__ int64_t osd_next_row(const OsdArgs &a, int lane, unsigned workers) {
+    const unsigned count = osd_list_count(a);
+    if (workers >= count) return -1;  // (wave-uniform)
     unsigned idx = 0;
     if (lane == 0) idx = atomicAdd(&a.counters[1], 1u);
-    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
-    const unsigned count = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    idx = workers + (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
     return idx < count ? (int64_t)a.list[idx] : -1;
 }
+#define OSD_WAVE_WORKER() (blockIdx.x * (blockDim.x >> 6) + (unsigned)wave)
+#define OSD_WAVE_WORKERS() (gridDim.x * (blockDim.x >> 6))
 
 __device__ __forceinline__ bool osd_less(double a, int ia, double b, int ib) {
     const bool na = a != a, nb = b != b;
@@ -125,7 +138,7 @@ __global__ void __launch_bounds__(256) osd0_kernel(const OsdArgs a) {
 
     const int sw = n >> 6;
     const uint64_t sbit = 1ull << (n & 63);
-    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+    for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
     for (int i = lane; i < m; i += 64) {
         for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
         for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
@@ -354,7 +367,7 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = a.n;
     volatile lds_i32 *order = (volatile lds_i32 *)((__attribute__((address_space(3))) unsigned char *)osd_lds + wave * a.lds_per_wave);  // [n]
-    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+    for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
         osd_sort_columns<W>(a.llr + b * n, n, lane, order);
@@ -420,7 +433,7 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
 
     const int sw = n >> 6;
     const uint64_t sbit = 1ull << (n & 63);
-    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+    for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
     for (int i = lane; i < m; i += 64) {
         for (int w = 0; w < W; ++w) mat[(size_t)i * W + w] = 0;
         for (int e = a.row_ptr[i]; e < a.row_ptr[i + 1]; ++e) {
@@ -579,7 +592,7 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
     volatile lds_i32 *order = (volatile lds_i32 *)(rec + (size_t)n * RS);  // [n]
     volatile lds_i32 *colQ = order + n;                            // [n] -2: unseen, -1: pivot column, q >= 0: the q-th non-pivot column
     volatile lds_i32 *npcol = colQ + n;                            // [64 KW]
-    for (int64_t b = osd_next_row(a, lane); b >= 0; b = osd_next_row(a, lane)) {
+    for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
         OSD_CLK_START();
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
@@ -895,10 +908,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     uint64_t *mat = MAT_LDS ? reinterpret_cast<uint64_t *>(osd_lds + (size_t)A.mat_off) : slot;
     uint64_t *Tm = MAT_LDS ? slot : slot + (int64_t)HW * m;  // [kwords][m]
 
-    for (;;) {
-        if (tid == 0) {
-            const unsigned idx = atomicAdd(&a.counters[1], 1u);
-            const unsigned count = __hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (bool first = true;; first = false) {
+        if (tid == 0) {  // (the first row without a visit to the work counter: see osd_first_row)
+            const unsigned count = osd_list_count(a);
+            unsigned idx = blockIdx.x;
+            if (!first) idx = gridDim.x >= count ? count : gridDim.x + atomicAdd(&a.counters[1], 1u);
             sh_row = idx < count ? a.list[idx] : -1;
         }
         __syncthreads();
