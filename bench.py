@@ -236,12 +236,13 @@ def secondary_configs(dev, steps):
             # 4 cycles of its SIMD, and the chip has 1024 SIMDs at <= 2.4 GHz.
             per = valu.get(sp["key"], {}).get("valu_insts_per_entry_iteration")
             if per:
+                clock = float(valu[sp["key"]].get("clock_ghz") or MAX_CLOCK_GHZ)  # measured under this load in the profile run
                 wave_insts = iters_total * nnz * per / 64.0
-                frac = wave_insts * 4.0 / (SIMDS * MAX_CLOCK_GHZ * 1e9 * float(np.median(kms)) * 1e-3)
-                entry.update({"bound": "fp64_valu", "frac": frac, "valu_insts_per_entry_iteration": per,
-                              "bound_note": "VALU issue slots used by the BP kernel / slots of 1024 SIMDs at the 2.4 GHz maximum clock "
-                                            "(the real clock under this load is lower, so the true fraction is higher); counts from "
-                                            "profiles/secondary_valu.json"})
+                frac = wave_insts * 4.0 / (SIMDS * clock * 1e9 * float(np.median(kms)) * 1e-3)
+                entry.update({"bound": "fp64_valu", "frac": frac, "valu_insts_per_entry_iteration": per, "clock_ghz": clock,
+                              "bound_note": "VALU issue turns used by the BP kernel (instructions per entry-iteration from profiles/secondary_valu.json x this "
+                                            "run's iterations) / turns of 1024 SIMDs at the clock measured under this load in that profile, over this run's "
+                                            "BP kernel time; at 8 192 syndromes the rest is latency: the 50 iterations of the slowest syndromes, four barriers each"})
             else:
                 entry.update({"bound": "fp64_valu", "frac": None, "bound_note": "profiles/secondary_valu.json absent"})
         out.append(entry)
