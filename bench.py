@@ -47,6 +47,18 @@ def algorithmic_bytes(iters: np.ndarray, m: int, n: int, nnz: int) -> float:
     return float(np.sum(iters.astype(np.float64) * (4.0 * nnz * 8.0) + (m + n + 8.0 * n + 5.0)))
 
 
+def kernel_sources_sha16() -> str:
+    """Fingerprint of the kernel sources (ldpc_amd/csrc): the committed PMC files under profiles/ carry the fingerprint of the build
+    they were measured on, so a line can say whether its copied counters belong to THIS build."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "ldpc_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "ldpc_amd", "csrc", "*.hip"))):
+        hsh.update(os.path.basename(path).encode())
+        hsh.update(open(path, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def physical_cores() -> int:
     """Distinct (package, core) pairs of /proc/cpuinfo; falls back to the logical count."""
     try:
@@ -245,6 +257,9 @@ def secondary_configs(dev, steps):
                                             "BP kernel time; at 8 192 syndromes the rest is latency: the 50 iterations of the slowest syndromes, four barriers each"})
             else:
                 entry.update({"bound": "fp64_valu", "frac": None, "bound_note": "profiles/secondary_valu.json absent"})
+        src = (c3 if sp["method"] == 1 else valu.get(sp["key"], {})) or {}
+        if src.get("kernel_sources_sha16"):
+            entry["counters_match_this_build"] = src["kernel_sources_sha16"] == kernel_sources_sha16()
         out.append(entry)
         eng.close()
     return out
@@ -487,9 +502,12 @@ def run(args, real_stdout, stage) -> None:
             except Exception:
                 pass
             return None
+        build_tag = kernel_sources_sha16()
+        profile_tag = None
         if same:
             tj = committed("hbm_traffic.json")
             traffic = tj["hbm_bytes_per_launch"] if tj else None
+            profile_tag = (tj or {}).get("kernel_sources_sha16")
             vj = committed("valu_clock.json")
             if vj:
                 second = {"kind": "fp64_valu", "issue_frac": vj.get("valu_issue_frac"), "clock_ghz": vj.get("clock_ghz"),
@@ -519,6 +537,8 @@ def run(args, real_stdout, stage) -> None:
                 "kernel_ms": k_ms, "kernel_ms_persistent": pers_ms, "kernel_ms_per_pass": spread_ms,
                 "algorithmic_bytes_per_launch": alg,
                 "second_bound": second,
+                "counters_from_build": profile_tag, "this_build": build_tag,
+                "counters_match_this_build": (profile_tag == build_tag) if profile_tag else None,
                 "note": "one decode = the whole batch of this rank; algorithmic bytes = sum over syndromes of iters_run*4*E*8 + (m+n+8n+5); "
                         "kernel_ms = HIP events on the launch stream around all BP kernels of the decode (the persistent kernel "
                         "hands its last <= 256 tiles to per-pass launches: compare kernel_ms_persistent with rocprofv3's "

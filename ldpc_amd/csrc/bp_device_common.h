@@ -52,6 +52,9 @@ struct BpArgs {
     // > 0: the message array A already holds the bit_to_check state after `it_start` iterations (lanes compacted out of the tiles
     // of a first pass, decode_stream_repacked): no initialisation, iterations count on from it_start + 1
     int32_t it_start;
+    // 1: the bit pass of iteration max_iter still writes the bit_to_check messages (a first pass whose state a second pass carries
+    // on, decode_stream_repacked).  0: nobody reads them -- the last bit pass only forms the log-ratios (no tanh, no message stores)
+    int32_t keep_state;
 };
 
 // What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in
@@ -344,13 +347,14 @@ __device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int 
 // CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored.
 template <int METHOD, int MATH, int DC, class BUF>
 __device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&e)[DC], int d, double prior,
-                                             const BUF &At, int l8) {
+                                             const BUF &At, int l8, bool messages = true) {
     double pre[DC];
     double temp = prior;
 #pragma unroll
     for (int k = 0; k < DC; ++k)
         if (k < d) { pre[k] = temp; temp += c[k]; }
     const double llr = temp;
+    if (!messages) return llr;  // (wave-uniform) the decode's last bit pass: the messages it would send are never read
     double s = 0.0;
 #pragma unroll
     for (int k = DC - 1; k >= 0; --k)

@@ -104,7 +104,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF", "REPACK_RESTART",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -134,6 +134,7 @@ struct ldpc_hip_bp {
     // continuation of a first pass (decode_stream_repacked): decode_device takes its message state from here and counts on from cont_it_start
     double *cont_A = nullptr;
     int32_t cont_it_start = 0;
+    bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
     int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
     DeviceBuf rp_msg;
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
@@ -1601,6 +1602,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
         if (h->cont_A) { a.A = h->cont_A + (size_t)t0 * (size_t)h->nnz * LDPC_WAVE; a.it_start = h->cont_it_start; }
+        a.keep_state = (h->keep_state || h->on("KEEP_LAST_MESSAGES")) ? 1 : 0;
         a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
         a.invalid = (const uint64_t *)h->invalid.p;
         a.dec = (uint64_t *)h->dec.p;
@@ -1822,7 +1824,9 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     }
     if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
     h->max_iter = k1;
+    h->keep_state = true;
     rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+    h->keep_state = false;
     h->max_iter = full;
     if (rc) return rc;
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
 #pragma unroll
             for (int k = 0; k < DC; ++k)
                 if (k < d) { e[k] = sload(a.bp.csc_edge + cs + k); c[k] = Ct.ld(l8, e[k]); }
-            llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8);
+            llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8, !last || a.bp.keep_state != 0);
         } else {  // the reference's two sweeps (bp.hpp:278-281, 313-316) through memory
             double temp = prior;
             for (int k = 0; k < d; ++k) {

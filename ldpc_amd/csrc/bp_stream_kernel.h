@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
     constexpr int SLOT_BYTES = (ROW_DMAS > DC ? ROW_DMAS : DC) * 1024;
     constexpr int N_CHECK = RING * DR + (RING - 1) * ROW_DMAS;
     constexpr int N_BIT = RING * (2 * DC + 2) + (RING - 1) * DC;
+    constexpr int N_BIT_QUIET = RING * 2 + (RING - 1) * DC;  // the decode's last bit pass sends no messages: only the two decision words per step are stored
     const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
     const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
     // parking space of the exact product-sum check row (check_row_ps_exact_fast): behind the rings, LDPC_NEAR_BYTES per wavefront
@@ -171,7 +172,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
             int slot = 0;
             for (int idx = 0; idx < nsteps; ++idx) {
                 const int g = wave + idx * nwaves;
-                if (idx >= RING && idx + RING - 1 < nsteps) wait_vmcnt<N_BIT>();
+                // (the counted wait must not exceed what was really issued behind the wanted loads, or it proves nothing: a pass without
+                // message stores counts fewer -- getting this wrong reads a ring slot before its data has landed)
+                const bool sends = !last || a.keep_state != 0;
+                if (idx >= RING && idx + RING - 1 < nsteps) { if (sends) wait_vmcnt<N_BIT>(); else wait_vmcnt<N_BIT_QUIET>(); }
                 else wait_vmcnt<0>();
                 double c[2][DC];
 #pragma unroll
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
                         int e[DC];
 #pragma unroll
                         for (int k = 0; k < DC; ++k) e[k] = sload(csc_edge + j * DC + k);
-                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, sload(llr0 + j), At, l8);
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u], e, DC, sload(llr0 + j), At, l8, sends);
                         const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
                         if (lane == 0) dcur[j] = hard;
                         if ((last || llr_each) && want_llr && lane_live) Lt.st(l8, j, llr);
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
                     const double prior = sload(llr0 + j);
                     double llr;
                     if (dg[u] <= DC) {
-                        llr = bit_column<METHOD, MATH, DC>(c[u], e[u], dg[u], prior, At, l8);
+                        llr = bit_column<METHOD, MATH, DC>(c[u], e[u], dg[u], prior, At, l8, !last || a.keep_state != 0);
                     } else {  // heavy column: two streaming sweeps like the reference's
                         double temp = prior;
                         for (int k = 0; k < dg[u]; ++k) {

@@ -20,6 +20,12 @@ python tools/prof_parse.py "$OUT" bp_ > "$OUT/summary.txt" 2>&1
 python - "$OUT" <<'PY' >> "$OUT/summary.txt" 2>&1
 import glob, json, os, sqlite3, sys
 out = sys.argv[1]
+sys.path.insert(0, os.getcwd())
+try:
+    import bench
+    build_tag = bench.kernel_sources_sha16()
+except Exception:
+    build_tag = None
 cfg = None
 for line in open(os.path.join(out, "log.txt")):
     if line.startswith('{"config"'):
@@ -35,7 +41,7 @@ for p in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*.db"), recursive=Tru
 if cfg and "SQ_INSTS_VALU" in res and "GRBM_GUI_ACTIVE" in res:
     synd_iters = cfg["mean_iterations"] * cfg["batch"]
     cyc = res["GRBM_GUI_ACTIVE"]["per_dispatch"] / 8.0  # per XCD
-    d = {"c3": {"kernel": kern, "batch": cfg["batch"], "mean_iterations": cfg["mean_iterations"],
+    d = {"c3": {"kernel": kern, "kernel_sources_sha16": build_tag, "batch": cfg["batch"], "mean_iterations": cfg["mean_iterations"],
                 "valu_insts_per_syndrome_iteration": res["SQ_INSTS_VALU"]["per_dispatch"] / synd_iters,
                 "salu_insts_per_syndrome_iteration": res["SQ_INSTS_SALU"]["per_dispatch"] / synd_iters,
                 "lds_insts_per_syndrome_iteration": res["SQ_INSTS_LDS"]["per_dispatch"] / synd_iters,

@@ -13,6 +13,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d "$OUT/pmc2" -o pmc
 python - "$OUT" <<'PY'
 import glob, json, os, sqlite3, sys
 out = sys.argv[1]
+sys.path.insert(0, os.getcwd())
+try:
+    import bench
+    build_tag = bench.kernel_sources_sha16()
+except Exception:
+    build_tag = None
 cfg = None
 for line in open(os.path.join(out, "log.txt")):
     if line.startswith('{"config"'):
@@ -28,7 +34,7 @@ print(json.dumps(res, indent=1))
 if cfg and "SQ_INSTS_VALU" in res:
     entries_iters = 432.0 * cfg["mean_iterations"] * cfg["batch"]
     per = res["SQ_INSTS_VALU"]["per_dispatch"] * 64.0 / entries_iters
-    d = {"c5": {"kernel": "bp_wave_ps_kernel<0, 6, 3>", "valu_insts_per_entry_iteration": per,
+    d = {"c5": {"kernel": "bp_wave_ps_kernel<0, 6, 3>", "kernel_sources_sha16": build_tag, "valu_insts_per_entry_iteration": per,
                 "sq_insts_valu_per_dispatch": res["SQ_INSTS_VALU"]["per_dispatch"], "batch": cfg["batch"], "mean_iterations": cfg["mean_iterations"],
                 "note": "SQ_INSTS_VALU (wave-instructions) x 64 lanes / (432 entries x iterations executed x batch): padding lanes and the "
                         "prefix/suffix recomputation of the lane = entry layout are included, i.e. this is issue work per useful entry-iteration"}}
