@@ -1,0 +1,195 @@
+// host_handle.h -- the handle (struct ldpc_hip_bp), error reporting, device buffers, measurement switches
+// Part of libldpc_hip.so: included by bp_hip.hip (one translation unit), in the order given there.
+#pragma once
+
+#include <chrono>
+#include <random>
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(_e == hipErrorOutOfMemory ? LDPC_HIP_ERR_NOMEM : LDPC_HIP_ERR_DEVICE, \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,      \
+                        __LINE__);                                                            \
+    } while (0)
+
+struct DeviceBuf {  // grow-only device allocation
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(LDPC_HIP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes,
+                        hipGetErrorString(e));
+        }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// Measurement / test switches (none changes a result; profiles/README.md lists them).  They live in the handle: seeded ONCE, at
+// creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
+// getenv on the decode path, and nothing a test can change under a live handle by accident.
+static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF", "REPACK_RESTART",
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES"};
+constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
+
+struct ldpc_hip_bp {
+    int32_t switches[k_n_switches];  // -1 = not set
+    int sw(const char *name) const {  // value of a switch, -1 when it is not set
+        for (int i = 0; i < k_n_switches; ++i)
+            if (!std::strcmp(name, k_switch_names[i])) return switches[i];
+        return -1;
+    }
+    bool on(const char *name) const { return sw(name) > 0; }
+    int device = 0;
+    int32_t m = 0, n = 0, nnz = 0;
+    int32_t max_iter = 1, bp_method = 0;
+    double ms_scaling_factor = 1.0;
+    int32_t max_row_deg = 0, max_col_deg = 0;
+    int32_t waves_per_wg = 0;  // 0 = auto
+    int32_t math_mode = LDPC_HIP_MATH_LIBM_EXACT;
+    bool regular = false;   // every row has the same weight and every column has the same weight
+    int32_t ring_depth = 2; // LDS-DMA ring slots per wavefront for regular matrices (0 = register variant)
+    int32_t small_mode = -1; // on-chip kernels for small codes: -1 auto, 0 never, 1 whenever one fits, 2 the slot kernel only
+    std::vector<int32_t> h_row_ptr, h_col_idx;  // host copy of the CSR arrays
+    int wave_dr = 0, wave_dc = 0;  // template bounds the uploaded SoA position tables of bp_wave_kernel were built for (0: none)
+    int wave_ps_dr = 0, wave_ps_dc = 0;  // likewise for bp_wave_ps_kernel
+    DeviceBuf wp_rdeg, wp_col, wp_epos;
+    DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
+    DeviceBuf d_edge0;       // [n] initial edge values of the streamed kernel (BpArgs::edge0)
+    // continuation of a first pass (decode_stream_repacked): decode_device takes its message state from here and counts on from cont_it_start
+    double *cont_A = nullptr;
+    int32_t cont_it_start = 0;
+    bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
+    int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
+    DeviceBuf rp_msg;
+    int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
+    DeviceBuf e_partner, e_kind, e_scol, e_prior;
+    int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
+    DeviceBuf tile_state, handoff_list;
+    unsigned *h_counters = nullptr;  // pinned host copy of the device counters
+    // Per-pass rounds are queued without waiting for the device.  The kernel that finalises the last running tile writes
+    // the decode's sequence number into this host-mapped word; the host merely LOOKS at it before queueing the next round
+    // (no synchronisation) and stops queueing once it matches -- rounds queued past that point find nothing to do.
+    unsigned *h_flag = nullptr, *d_flag = nullptr;
+    unsigned flag_seq = 0;
+    int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial, 1 parallel, 2 serial_relative
+    // What the reference keeps in the decoder OBJECT from one decode to the next (bp.hpp:67, 75): serial_schedule_order -- the
+    // arrangement serial_relative re-sorts and the random schedule re-shuffles every iteration -- and the generator of the shuffles.
+    std::vector<int32_t> sched_state;
+    std::mt19937 sched_rng;
+    int32_t sched_seed_raw = 0;  // random_schedule_seed as given (the soft-syndrome routine seeds its own engine with it)
+    bool random_serial = false;
+    DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
+    int32_t *d_csc_row = nullptr, *d_order = nullptr;
+    bool custom_order = false;
+    DeviceBuf counter;
+    std::vector<double> channel_probs;
+
+    int32_t *d_row_ptr = nullptr, *d_col_idx = nullptr, *d_col_ptr = nullptr, *d_csc_edge = nullptr;
+    double *d_llr0 = nullptr;
+    double *d_osd_wt = nullptr;  // [n] log(1 / p_j), the candidate weights of higher-order OSD
+    bool osd_reg = true;  // register-resident elimination for small matrices (ldpc_hip_bp_set_osd_kernel)
+    bool osd_big = false; // OSD-0 through osd0_big_kernel whatever the size (testing)
+    int osd_k_cached = -1;  // n - rank(H), computed on first use
+    int32_t osd_method = 1, osd_order = 0;  // ldpc::osd::OsdMethod (osd.hpp:18-23) used by ldpc_hip_bposd_decode_batch
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: end of the persistent kernel, when one ran
+    hipEvent_t ev_done = nullptr;  // end of the last call that queued work on `stream` (orders a change of stream after it)
+    bool work_queued = false;
+    bool timed = false, timed_mid = false;
+    float accumulated_ms = 0.f, accumulated_persistent_ms = 0.f;
+
+    DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace
+    DeviceBuf st_synd, st_dec, st_llr, st_iters, st_conv, st_misc;  // staging for host pointers
+    // small calls with host buffers (a single decode()): one host-mapped, coherent block that the kernels read and write in place --
+    // no copy commands at all, one launch sequence and one wait
+    unsigned char *pin_host = nullptr, *pin_dev = nullptr;
+    static constexpr size_t PIN_BYTES = 512u * 1024u;
+    DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
+    DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
+    DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
+    DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
+    DeviceBuf osd_status;                                           // [batch] of the last BP + OSD decode: 0 BP converged, 1 OSD solved, 2 s outside image(H)
+    DeviceBuf osd_fix_synd, osd_fix_list, osd_fix_counters, osd_fix_scratch;  // second OSD pass over the rows outside the image (osd_exact_kernel.h)
+    int64_t osd_status_rows = 0;
+    DeviceBuf rp_synd, rp_dec, rp_llr, rp_iters, rp_conv;           // repacked second pass of the serial schedule
+    int32_t serial_kernel = -1;                                     // -1 auto, 0 one wavefront per tile, 1 level-parallel workgroup per tile
+    bool order_visits_all = true;                                   // false: some bit is never updated (its outputs stay 0)
+    bool levels_valid = false;                                      // lvl_* describe the current schedule order
+    int32_t n_levels = 0;
+    DeviceBuf lvl_ptr, lvl_bits;
+    // repacking of the streamed parallel schedule (decode_stream_repacked), steered by what the previous decode looked like
+    DeviceBuf sp_hist, sp_iters;     // iteration histogram of the last streamed decode (256 bins) / iteration counts when the caller wants none
+    unsigned *h_hist = nullptr;      // pinned copy of the histogram
+    hipEvent_t ev_hist = nullptr;    // the copy has landed
+    bool hist_pending = false;
+    int32_t hist_max_iter = 0;
+    int32_t repack_iters = -1;                                      // first-pass iterations: -1 auto (max_iter / 8), 0 = no repacking
+    DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
+    DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix
+    int32_t obs_k = -1;                                              // rows of the observables matrix (-1: not set)
+    int64_t max_chunk_tiles = 0;                                     // 0 = decide from free memory
+};
+
+static int upload_priors(ldpc_hip_bp *h) {
+    // bp.hpp:150-151, evaluated by the host libm so that priors are bit-identical to the reference's
+    std::vector<double> llr0((size_t)h->n);
+    for (int j = 0; j < h->n; ++j)
+        llr0[(size_t)j] = std::log((1 - h->channel_probs[(size_t)j]) / h->channel_probs[(size_t)j]);
+    HIPCHK(hipMemcpy(h->d_llr0, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
+    for (int j = 0; j < h->n; ++j) llr0[(size_t)j] = std::log(1 / h->channel_probs[(size_t)j]);  // osd.hpp:134
+    HIPCHK(hipMemcpy(h->d_osd_wt, llr0.data(), sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// grid of the one-dimensional element-wise kernels (io_kernels.h): they run grid-stride loops, so the grid is capped --
+// item counts like batch * n exceed what one launch dimension can carry for large batches of large codes
+static dim3 flat_grid(size_t items) {
+    size_t blocks = (items + 255) / 256;
+    if (blocks > (1u << 22)) blocks = 1u << 22;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+// end of a call that only queued work: remembered so that a later change of stream is ordered after it (set_stream)
+static int mark_queued(ldpc_hip_bp *h, int rc) {
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev_done, h->stream));
+    h->work_queued = true;
+    return LDPC_HIP_OK;
+}
+
+static bool is_device_ptr(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory reports an error: clear it
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}

@@ -1,0 +1,424 @@
+// host_onchip.h -- host side of the on-chip kernels: plans (LDS / occupancy), tables and launches of bp_small / bp_wave / bp_wave_ps / bp_edge
+// Part of libldpc_hip.so: included by bp_hip.hip (one translation unit), in the order given there.
+#pragma once
+
+
+// LDS bytes of the on-chip kernel for `slots` resident syndromes; 0 if the code is too large for it
+static size_t small_lds_bytes(const ldpc_hip_bp *h, int slots) {
+    size_t fixed = 256 * 8 + (size_t)h->n * 8 + ((size_t)h->m + 1 + h->nnz + h->n + 1 + h->nnz) * 4;
+    fixed = (fixed + 15) & ~(size_t)15;
+    const size_t per_slot = ((size_t)h->nnz * 16 + (size_t)h->n * 9 + (size_t)h->m + 15) & ~(size_t)15;
+    return fixed + per_slot * (size_t)slots;
+}
+
+// On-chip variant (bp_small_kernel): chosen automatically when four resident syndromes per workgroup still
+// leave room for four workgroups per CU.  Device pointers, on h->stream.
+static int decode_small(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                        int32_t *iters, uint8_t *conv, int slots) {
+    int rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    SmallArgs a = {};
+    a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.slots = slots;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    void (*kern)(const SmallArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_small_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_small_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
+    else kern = bp_small_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    const size_t dyn = small_lds_bytes(h, slots);
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    // persistent workgroups: enough to fill the chip, never more than there are syndromes to hand out
+    int64_t groups = (batch + slots - 1) / slots;
+    const int64_t resident = 256 * (int64_t)((150u * 1024u) / dyn > 8 ? 8 : (150u * 1024u) / dyn);
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(256), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// bp_wave_kernel: template bounds, launch shape and LDS split; waves == 0: not applicable (degrees, table range, LDS)
+// the priors as bp_wave_kernel's LDS copy would hold them: llr0, 1.0 for the padding columns, DBL_MAX at np (a row's phantom entries)
+__global__ void wave_prior_pad_kernel(const double *llr0, int n, int np, double *out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < np + 2) out[q] = q < n ? llr0[q] : q == np ? DBL_MAX : 1.0;
+}
+
+struct WavePlan {
+    int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, mp = 0, np = 0;
+    size_t shared = 0, per_wave = 0;
+    bool llr_direct = false;
+    bool prior_global = false;  // min-sum: the priors are read from a padded device array instead of an LDS copy (WaveArgs.prior_g)
+    bool team = false;  // the workgroup's wavefronts share ONE syndrome (bp_wave_kernel<..., TEAM>): `waves` = wavefronts of a team
+    void (*kern)(const WaveArgs) = nullptr, (*kern_team)(const WaveArgs) = nullptr;
+};
+
+template <int METHOD, int MATH>
+static void pick_wave(int max_row, int max_col, WavePlan &p) {
+#define LDPC_PICK_WAVE(R, C) { p.dr = R; p.dc = C; p.kern = bp_wave_kernel<METHOD, MATH, R, C, false>; p.kern_team = bp_wave_kernel<METHOD, MATH, R, C, true>; return; }
+    if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE(4, 2)
+    if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE(4, 4)
+    if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE(6, 3)
+    if (max_col <= 4) LDPC_PICK_WAVE(8, 4)
+    LDPC_PICK_WAVE(8, 8)
+#undef LDPC_PICK_WAVE
+}
+
+static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
+    WavePlan p;
+    if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 8) return p;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_wave<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, p);
+    else pick_wave<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
+    p.mp = (h->m + 63) / 64 * 64;
+    p.np = (h->n + 63) / 64 * 64;
+    const size_t rm = (size_t)p.dr * p.mp, cn = (size_t)p.dc * p.np;
+    if (rm + 2 >= 65536 || p.np + 1 >= 65536) return p;               // positions and column numbers are 16 bits
+    if (!forced && rm > 2 * (size_t)h->nnz + 1024) return p;          // a few heavy rows would pad every row
+    p.shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc, h->bp_method == LDPC_HIP_PRODUCT_SUM);
+    p.per_wave = wave_lds_private(p.mp, p.np, p.dr, want_llr);
+    (void)cn;
+    // one workgroup per compute unit with as many wavefronts as LDS (160 KiB) and the 16-wave workgroup limit allow;
+    // small codes fit several such workgroups
+    const size_t lds = 160u * 1024u - 64u;  // (the kernels' few bytes of static LDS come on top of the dynamic part)
+    if (want_llr) {
+        // the LDS copy of the log-ratios is a convenience (the store of every iteration stays on chip); where it costs a
+        // resident wavefront and few are resident, every bit pass stores them straight to HBM instead
+        const size_t lean = wave_lds_private(p.mp, p.np, p.dr, false);
+        const size_t w_copy = p.shared + p.per_wave > lds ? 0 : (lds - p.shared) / p.per_wave;
+        const size_t w_lean = p.shared + lean > lds ? 0 : (lds - p.shared) / lean;
+        if (w_copy < 4 && w_lean > w_copy) { p.per_wave = lean; p.llr_direct = true; }
+    }
+    if (p.shared + p.per_wave > lds) return p;
+    size_t w = (lds - p.shared) / p.per_wave;
+    if (w > 16) w = 16;
+    // Few resident wavefronts hide little latency, but a wavefront stops when ITS syndrome has converged while a streamed
+    // tile runs until its slowest of 64 has.  Measured on 432..864-row window matrices (tools/bench_window.py): min-sum
+    // with 3 / 2 / 1 wavefronts per CU is 12x / 7x / 1.5x faster than streaming when most syndromes converge early and
+    // 2.2x faster at 3 when most do not; product-sum 3x / 2.4x / 0.7x and about level.
+    // Where LDS leaves room for only a few syndromes per CU, one wavefront each leaves the CU idle: the wavefronts of a workgroup
+    // then share ONE syndrome (TEAM), as many as its bit pass has rounds of 64 U columns for (small_mode 5 forces, 4 forbids it);
+    // and a code whose bit pass takes one wavefront several rounds is quicker that way whatever the room.
+    // Measured (round 2, min-sum / product-sum, large batches): 768 x 1600 15.5 -> 4.9 ms / 50 -> 16 ms, 1200 x 2400 21 -> 3.5 ms,
+    // surface d = 41 / 31 / 21 25 -> 11 / 24 -> 12.6 / 11.0 -> 10.0 ms, 300 x 600 1.03 -> 0.79 ms; d = 13, 17 (the bit pass of one
+    // wavefront is a single round of 64 U columns already) 7 % slower -- hence the second condition.
+    const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
+    const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
+    // A batch of no more than one syndrome per wavefront slot is about latency: a team (two wavefronts at least) then too --
+    // surface d = 9 .. 17, BB144 at 512 / 4 096 syndromes: 1.25 - 1.6x / 1.0 - 1.3x faster, at 65 536 up to 16 % slower.
+    const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u || batch <= 256 * (int64_t)w));
+    if (team) {
+        int tw = (p.np + 64 * u - 1) / (64 * u);
+        if (h->sw("TEAM_WAVES") >= 1) tw = h->sw("TEAM_WAVES");  // (measurements)
+        if (tw < 2) tw = 2;
+        if (tw > 16) tw = 16;
+        p.team = true;
+        p.waves = tw;
+        p.kern = p.kern_team;
+        if (ms) {  // the LDS copy of the priors, 8 (np + 2) bytes: worth reading them from memory where that fits another workgroup
+            const size_t lean_shared = wave_lds_shared(p.mp, p.np, p.dr, p.dc, false, false);
+            if (lds / (lean_shared + p.per_wave) > lds / (p.shared + p.per_wave) && !h->on("TEAM_PRIOR_LDS")) { p.shared = lean_shared; p.prior_global = true; }
+        }
+        // (the kernel's ~100 VGPRs allow 16 wavefronts per CU: two teams of eight beat one of thirteen -- 768 x 1600: 4.0 vs 4.8 ms)
+        p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
+        if (p.groups_per_cu >= 2 && p.waves > 8 && h->sw("TEAM_WAVES") < 1) p.waves = 8;
+        if (p.groups_per_cu * p.waves > 16) p.groups_per_cu = 16 / p.waves;
+        if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+        return p;
+    }
+    if (!forced && w < (h->bp_method == LDPC_HIP_MINIMUM_SUM ? 2 : 3)) return p;
+    p.waves = (int)w;
+    p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
+    if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;  // 32 wavefronts per compute unit
+    if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+    return p;
+}
+
+// structure-of-arrays position tables of bp_wave_kernel for the bounds (dr, dc): see bp_wave_kernel.h
+static int ensure_wave_tables(ldpc_hip_bp *h, const WavePlan &p) {
+    if (h->wave_dr == p.dr && h->wave_dc == p.dc) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n, mp = p.mp, np = p.np;
+    const size_t rm = (size_t)p.dr * mp, cn = (size_t)p.dc * np;
+    std::vector<uint8_t> rdeg((size_t)mp, 0), cdeg((size_t)np, 0);
+    std::vector<uint16_t> wcol(rm, (uint16_t)np), wapos(cn, (uint16_t)(rm + 1));  // phantom defaults
+    std::vector<int32_t> seen((size_t)n, 0);  // entries of column j met so far = rank of the next one inside the column
+    for (int i = 0; i < m; ++i) {
+        const int lo = h->h_row_ptr[(size_t)i];
+        rdeg[(size_t)i] = (uint8_t)(h->h_row_ptr[(size_t)i + 1] - lo);
+        for (int e = lo; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int k = e - lo, j = h->h_col_idx[(size_t)e], kc = seen[(size_t)j]++;  // rows ascend: kc is the CSC order
+            wcol[(size_t)k * mp + i] = (uint16_t)j;
+            wapos[(size_t)kc * np + j] = (uint16_t)((size_t)k * mp + i);
+        }
+    }
+    for (int j = 0; j < n; ++j) cdeg[(size_t)j] = (uint8_t)seen[(size_t)j];
+    int rc;
+    if ((rc = h->w_rdeg.ensure(rdeg.size())) || (rc = h->w_cdeg.ensure(cdeg.size())) || (rc = h->w_col.ensure(rm * 2)) ||
+        (rc = h->w_apos.ensure(cn * 2))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
+    HIPCHK(hipMemcpy(h->w_rdeg.p, rdeg.data(), rdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_cdeg.p, cdeg.data(), cdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_col.p, wcol.data(), rm * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->w_apos.p, wapos.data(), cn * 2, hipMemcpyHostToDevice));
+    h->wave_dr = p.dr;
+    h->wave_dc = p.dc;
+    return LDPC_HIP_OK;
+}
+
+// bp_wave_ps_kernel (product-sum, lane = entry): bounds, launch shape, LDS split; waves == 0: not applicable
+struct WavePsPlan {
+    int dr = 0, dc = 0, waves = 0, groups_per_cu = 0, np = 0;
+    size_t shared = 0, per_wave = 0;
+    bool team = false;  // a workgroup per syndrome (bp_wave_ps_kernel<..., TEAM>): `waves` = wavefronts of a team
+    void (*kern)(const WavePsArgs) = nullptr, (*kern_team)(const WavePsArgs) = nullptr;
+};
+
+template <int MATH>
+static void pick_wave_ps(int max_row, int max_col, WavePsPlan &p) {
+#define LDPC_PICK_WAVE_PS(R, C) { p.dr = R; p.dc = C; p.kern = bp_wave_ps_kernel<MATH, R, C, false>; p.kern_team = bp_wave_ps_kernel<MATH, R, C, true>; return; }
+    if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE_PS(4, 2)
+    if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE_PS(4, 4)
+    if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE_PS(6, 3)
+    LDPC_PICK_WAVE_PS(8, 4)
+#undef LDPC_PICK_WAVE_PS
+}
+
+static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
+    WavePsPlan p;
+    if (h->bp_method != LDPC_HIP_PRODUCT_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 4) return p;
+    if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave_ps<1>(h->max_row_deg, h->max_col_deg, p);
+    else pick_wave_ps<0>(h->max_row_deg, h->max_col_deg, p);
+    p.np = (h->n + 63) / 64 * 64;
+    const size_t rm = (size_t)p.dr * h->m;
+    if (rm + 2 >= 65536 || (size_t)p.np + 1 >= 65536) return p;
+    if (!forced && (rm > 2 * (size_t)h->nnz || (size_t)p.dc * h->n > 2 * (size_t)h->nnz)) return p;  // padding would dominate
+    p.shared = wave_ps_lds_shared(h->m, p.np, p.dr, p.dc);
+    p.per_wave = wave_ps_lds_private(h->m, p.np, p.dr, want_llr);
+    const size_t lds = 160u * 1024u - 64u;  // (the kernels' few bytes of static LDS come on top of the dynamic part)
+    if (p.shared + p.per_wave > lds) return p;
+    size_t w = (lds - p.shared) / p.per_wave;
+    if (w > 16) w = 16;
+    if (!forced && w < 8) return p;
+    // A batch so small that every wavefront decodes only a few syndromes takes as long as its slowest syndrome: then the
+    // workgroup's wavefronts share one (TEAM), one round of 64 entries each per pass.  LDPC_HIP_PS_TEAM=0 / 1 overrides (measurements).
+    bool team = batch <= 256 * (int64_t)w * 8;  // (BB144, w = 16: 0.96 -> 0.57 ms at 8 192 syndromes, 1.52 -> 1.37 ms at 32 768, 4.2 -> 4.5 ms at 131 072)
+    if (h->sw("PS_TEAM") >= 0) team = h->sw("PS_TEAM") != 0;
+    if (team) {
+        const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
+        int tw = (int)(rounds < 2 ? 2 : rounds > 8 ? 8 : rounds);
+        p.team = true;
+        p.waves = tw;
+        p.kern = p.kern_team;
+        p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
+        if (p.groups_per_cu * p.waves > 28) p.groups_per_cu = 28 / p.waves;  // (this kernel's 59 VGPRs allow 7 wavefronts per SIMD)
+        if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+        return p;
+    }
+    p.waves = (int)w;
+    p.groups_per_cu = (int)(lds / (p.shared + (size_t)p.waves * p.per_wave));
+    if (p.groups_per_cu * p.waves > 32) p.groups_per_cu = 32 / p.waves;
+    if (p.groups_per_cu < 1) p.groups_per_cu = 1;
+    return p;
+}
+
+static int ensure_wave_ps_tables(ldpc_hip_bp *h, const WavePsPlan &p) {
+    if (h->wave_ps_dr == p.dr && h->wave_ps_dc == p.dc) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n, np = p.np;
+    const size_t rm = (size_t)p.dr * m, cn = (size_t)p.dc * np;
+    std::vector<uint8_t> rdeg((size_t)m, 0);
+    std::vector<uint16_t> wcol(rm, (uint16_t)np), wepos(cn, (uint16_t)rm);  // phantom defaults
+    std::vector<int32_t> seen((size_t)n, 0);
+    for (int i = 0; i < m; ++i) {
+        const int lo = h->h_row_ptr[(size_t)i];
+        rdeg[(size_t)i] = (uint8_t)(h->h_row_ptr[(size_t)i + 1] - lo);
+        for (int e = lo; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int k = e - lo, j = h->h_col_idx[(size_t)e], kc = seen[(size_t)j]++;
+            wcol[(size_t)i * p.dr + k] = (uint16_t)j;
+            wepos[(size_t)j * p.dc + kc] = (uint16_t)((size_t)i * p.dr + k);
+        }
+    }
+    int rc;
+    if ((rc = h->wp_rdeg.ensure(rdeg.size())) || (rc = h->wp_col.ensure(rm * 2)) || (rc = h->wp_epos.ensure(cn * 2))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->wp_rdeg.p, rdeg.data(), rdeg.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wp_col.p, wcol.data(), rm * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wp_epos.p, wepos.data(), cn * 2, hipMemcpyHostToDevice));
+    h->wave_ps_dr = p.dr;
+    h->wave_ps_dc = p.dc;
+    return LDPC_HIP_OK;
+}
+
+static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                          int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_wave_ps_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    WavePsArgs a = {};
+    a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
+    a.batch = batch;
+    a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+    a.min_rdeg = h->m;
+    for (int i = 0; i < h->m; ++i) a.min_rdeg = std::min(a.min_rdeg, h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i]);
+    const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int64_t groups = p.team ? batch : (batch + p.waves - 1) / p.waves;
+    const int64_t resident = 256 * (int64_t)p.groups_per_cu;
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// Wavefront-per-syndrome on-chip variant (bp_wave_kernel).  Device pointers, on h->stream.
+static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                       int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_wave_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    WaveArgs a = {};
+    a.m = h->m; a.n = h->n; a.mp = p.mp; a.np = p.np; a.max_iter = h->max_iter;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.rdeg = (const uint8_t *)h->w_rdeg.p; a.cdeg = (const uint8_t *)h->w_cdeg.p;
+    a.col = (const uint16_t *)h->w_col.p; a.apos = (const uint16_t *)h->w_apos.p;
+    a.llr0 = h->d_llr0;
+    if (p.prior_global) {
+        if ((rc = h->w_prior.ensure(sizeof(double) * (size_t)(p.np + 2)))) return rc;
+        hipLaunchKernelGGL(wave_prior_pad_kernel, dim3((unsigned)((p.np + 2 + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, h->n, p.np, (double *)h->w_prior.p);
+        a.prior_g = (const double *)h->w_prior.p;
+    }
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.llr_direct = p.llr_direct ? 1 : 0;
+    a.next = (unsigned long long *)h->counter.p;
+    a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+    const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
+    if (dyn > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int64_t groups = p.team ? batch : (batch + p.waves - 1) / p.waves;
+    const int64_t resident = 256 * (int64_t)p.groups_per_cu;
+    if (groups > resident) groups = resident;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// ---- bp_edge_kernel (min-sum, lane = edge, messages in registers): rows <= 4, columns 1 .. 2 entries, 4 m <= 1024 slots ----
+struct EdgePlan {
+    int rounds = 0;  // 0: not applicable
+    bool uniform = false;  // every column has the same prior: the form without prior registers (bp_edge_kernel<R, true>)
+    void (*kern)(const EdgeArgs) = nullptr;
+};
+
+static EdgePlan plan_edge(const ldpc_hip_bp *h) {
+    EdgePlan p;
+    if (h->bp_method != LDPC_HIP_MINIMUM_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0) return p;
+    if (h->max_row_deg > 4 || h->max_col_deg > 2 || h->n > 65535) return p;
+    const int rounds = (4 * h->m + 63) / 64;
+    if (rounds > 16) return p;
+    std::vector<char> seen((size_t)h->n, 0);  // a column without entries has no lane to write its outputs
+    for (int32_t j : h->h_col_idx) seen[(size_t)j] = 1;
+    for (char c : seen) if (!c) return p;
+#define LDPC_EDGE_ROW(U) {nullptr, bp_edge_kernel<1, U>, bp_edge_kernel<2, U>, bp_edge_kernel<3, U>, bp_edge_kernel<4, U>, bp_edge_kernel<5, U>, \
+        bp_edge_kernel<6, U>, bp_edge_kernel<7, U>, bp_edge_kernel<8, U>, bp_edge_kernel<9, U>, bp_edge_kernel<10, U>, bp_edge_kernel<11, U>, \
+        bp_edge_kernel<12, U>, bp_edge_kernel<13, U>, bp_edge_kernel<14, U>, bp_edge_kernel<15, U>, bp_edge_kernel<16, U>}
+    static void (*const kerns[2][17])(const EdgeArgs) = {LDPC_EDGE_ROW(false), LDPC_EDGE_ROW(true)};
+#undef LDPC_EDGE_ROW
+    p.uniform = true;
+    for (int j = 1; j < h->n && p.uniform; ++j)
+        p.uniform = std::memcmp(&h->channel_probs[(size_t)j], &h->channel_probs[0], sizeof(double)) == 0;
+    p.rounds = rounds;
+    p.kern = kerns[p.uniform ? 1 : 0][rounds];
+    return p;
+}
+
+__global__ void edge_prior_kernel(const double *llr0, const int32_t *scol, const uint8_t *kind, int slots, double *out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < slots) out[s] = kind[s] ? llr0[scol[s]] : __builtin_inf();  // phantom lanes: +inf (bp_edge_kernel.h)
+}
+
+// slot tables of bp_edge_kernel: entry k of row i sits in slot 4 i + k (see bp_edge_kernel.h)
+static int ensure_edge_tables(ldpc_hip_bp *h, const EdgePlan &p) {
+    if (h->edge_rounds == p.rounds) return LDPC_HIP_OK;
+    const int slots = p.rounds * 64;
+    std::vector<uint16_t> partner((size_t)slots, (uint16_t)(slots + 1));  // phantom lanes read the slot that holds +inf
+    std::vector<uint8_t> kind((size_t)slots, 0);
+    std::vector<int32_t> scol((size_t)slots, 0), first((size_t)h->n, -1);
+    for (int i = 0; i < h->m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int s = 4 * i + (e - h->h_row_ptr[(size_t)i]), j = h->h_col_idx[(size_t)e];
+            scol[(size_t)s] = j;
+            if (first[(size_t)j] < 0) { first[(size_t)j] = s; kind[(size_t)s] = 1; partner[(size_t)s] = (uint16_t)slots; }  // rows ascend: the column's first entry (bp.hpp:278); alone so far: the +0.0 slot
+            else { kind[(size_t)s] = 2; partner[(size_t)s] = (uint16_t)first[(size_t)j]; partner[(size_t)first[(size_t)j]] = (uint16_t)s; }
+        }
+    int rc;
+    if ((rc = h->e_partner.ensure((size_t)slots * 2)) || (rc = h->e_kind.ensure((size_t)slots)) || (rc = h->e_scol.ensure((size_t)slots * 4)) ||
+        (rc = h->e_prior.ensure((size_t)slots * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
+    HIPCHK(hipMemcpy(h->e_partner.p, partner.data(), (size_t)slots * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_kind.p, kind.data(), (size_t)slots, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_scol.p, scol.data(), (size_t)slots * 4, hipMemcpyHostToDevice));
+    h->edge_rounds = p.rounds;
+    return LDPC_HIP_OK;
+}
+
+static int decode_edge(ldpc_hip_bp *h, const EdgePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                       int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_edge_tables(h, p))) return rc;
+    if ((rc = h->counter.ensure(8))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    const int slots = p.rounds * 64;
+    // (the priors may have changed since the last call: ldpc_hip_bp_set_channel)
+    hipLaunchKernelGGL(edge_prior_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, (const int32_t *)h->e_scol.p,
+                       (const uint8_t *)h->e_kind.p, slots, (double *)h->e_prior.p);
+    EdgeArgs a = {};
+    a.m = h->m; a.n = h->n; a.max_iter = h->max_iter;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.prior_s = (const double *)h->e_prior.p; a.partner = (const uint16_t *)h->e_partner.p;
+    a.prior_u = std::log((1 - h->channel_probs[0]) / h->channel_probs[0]);  // as upload_priors (bp.hpp:150-151); read by the uniform form only
+    a.kind = (const uint8_t *)h->e_kind.p; a.scol = (const int32_t *)h->e_scol.p;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.next = (unsigned long long *)h->counter.p;
+    const size_t dyn = edge_lds_bytes(p.rounds);
+    // one wavefront per workgroup, as many resident as registers (4 or 5 per SIMD) and LDS allow
+    int64_t per_cu = (int64_t)((160u * 1024u) / (dyn + 64));
+    const int64_t by_regs = p.uniform ? 20 : 16;
+    if (per_cu > by_regs) per_cu = by_regs;
+    int64_t groups = batch < 256 * per_cu ? batch : 256 * per_cu;
+    // a visit to the work counter costs ~1 us under load and one word serves ~88 of them per us: pull several syndromes at a
+    // time once there are many per wavefront (the tail then is at most `chunk` syndromes of one wavefront)
+    int64_t chunk = batch / (groups * 16);
+    a.chunk = (int32_t)(chunk < 1 ? 1 : chunk > 8 ? 8 : chunk);
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3(64), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}

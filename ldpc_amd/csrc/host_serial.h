@@ -1,0 +1,479 @@
+// host_serial.h -- host side of the serial schedules (fixed order, random order, serial_relative) and of soft-syndrome decoding
+// Part of libldpc_hip.so: included by bp_hip.hip (one translation unit), in the order given there.
+#pragma once
+
+// levels of the serial schedule: see bp_serial_level_kernel
+static int ensure_serial_levels(ldpc_hip_bp *h) {
+    if (h->levels_valid) return LDPC_HIP_OK;
+    const int m = h->m, n = h->n;
+    std::vector<int32_t> order((size_t)n);
+    if (h->custom_order) HIPCHK(hipMemcpy(order.data(), h->d_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    else for (int j = 0; j < n; ++j) order[(size_t)j] = j;
+    std::vector<std::vector<int32_t>> checks_of((size_t)n);
+    for (int i = 0; i < m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) checks_of[(size_t)h->h_col_idx[(size_t)e]].push_back(i);
+    // (the order need not be a permutation -- the reference accepts any n bit numbers -- so levels belong to POSITIONS)
+    std::vector<int32_t> check_level((size_t)(m ? m : 1), 0), level((size_t)(n ? n : 1), 1);
+    int32_t n_levels = n ? 1 : 0;
+    for (int t = 0; t < n; ++t) {
+        const int j = order[(size_t)t];
+        int32_t l = 1;
+        for (int i : checks_of[(size_t)j]) l = std::max(l, check_level[(size_t)i] + 1);
+        for (int i : checks_of[(size_t)j]) check_level[(size_t)i] = l;
+        level[(size_t)t] = l;
+        n_levels = std::max(n_levels, l);
+    }
+    std::vector<int32_t> ptr((size_t)n_levels + 1, 0), bits((size_t)(n ? n : 1));
+    for (int t = 0; t < n; ++t) ptr[(size_t)level[(size_t)t]]++;
+    for (int l = 0; l < n_levels; ++l) ptr[(size_t)l + 1] += ptr[(size_t)l];
+    {
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int t = 0; t < n; ++t) bits[(size_t)fill[(size_t)level[(size_t)t] - 1]++] = order[(size_t)t];  // schedule order inside a level
+    }
+    int rc;
+    if ((rc = h->lvl_ptr.ensure(sizeof(int32_t) * ((size_t)n_levels + 1))) || (rc = h->lvl_bits.ensure(sizeof(int32_t) * (size_t)(n ? n : 1)))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->lvl_ptr.p, ptr.data(), sizeof(int32_t) * ((size_t)n_levels + 1), hipMemcpyHostToDevice));
+    if (n) HIPCHK(hipMemcpy(h->lvl_bits.p, bits.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    h->n_levels = n_levels;
+    h->levels_valid = true;
+    return LDPC_HIP_OK;
+}
+
+template <int METHOD, int MATH>
+static void (*pick_serial_level(int max_row, int max_col))(const SerialArgs) {
+    if (max_row <= 4 && max_col <= 2) return bp_serial_level_kernel<METHOD, MATH, 2, 4>;
+    if (max_row <= 6 && max_col <= 3) return bp_serial_level_kernel<METHOD, MATH, 3, 6>;
+    return bp_serial_level_kernel<METHOD, MATH, 4, 8>;
+}
+
+template <int METHOD, int MATH>
+static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
+    if (max_row <= 4 && max_col <= 2) return bp_serial_kernel<METHOD, MATH, 2, 4>;
+    if (max_row <= 6 && max_col <= 3) return bp_serial_kernel<METHOD, MATH, 3, 6>;
+    return bp_serial_kernel<METHOD, MATH, 4, 8>;  // also the variant that streams heavier nodes (SerialArgs::fast == 0)
+}
+
+static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
+    const bool fast = h->max_col_deg <= 4 && h->max_row_deg <= 8;
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = (fast ? 1 : 2) * per_tile_msg + per_tile_llr + 24 * (size_t)(h->m + h->n + 1);
+        int64_t fit = (int64_t)(budget / (per_tile ? per_tile : 1));
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(fast ? 16 : per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    void (*kern)(const SerialArgs);
+    // level-parallel variant when the schedule has at least two bits per level on average (or when asked for)
+    int level_waves = 0;
+    if (h->serial_kernel != 0 && h->n > 0 && !orders) {  // (a schedule that changes per iteration has no fixed levels)
+        if ((rc = ensure_serial_levels(h))) return rc;
+        const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+        if (h->serial_kernel == 1 || per_level >= 2.0) {
+            level_waves = (int)(per_level + 0.999);
+            if (level_waves > 8) level_waves = 8;
+            if (level_waves < 1) level_waves = 1;
+        }
+    }
+    if (level_waves) {
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_level<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
+        else kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    } else if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
+    else kern = pick_serial<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = false;
+    h->timed_mid = false;
+    hipStream_t st = h->stream;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        if (llr && !h->order_visits_all)  // bits the order never visits report 0 (the reference leaves them stale)
+            HIPCHK(hipMemsetAsync(h->llr_t.p, 0, per_tile_llr * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        SerialArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = max_iter; a.fast = fast ? 1 : 0;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
+        a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
+        a.par = (const uint64_t *)h->par.p; a.invalid = (const uint64_t *)h->invalid.p;
+        a.dec = (uint64_t *)h->dec.p; a.dcur = (uint64_t *)h->dcur.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+        a.orders = orders; a.n_orders = n_orders;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st, (const uint64_t *)h->dec.p, nb, h->n,
+                               decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n,
+                                   llr + (size_t)b0 * h->n);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LDPC_HIP_OK;
+}
+
+
+// The serial kernel decodes a 64-syndrome tile with one wavefront, which runs until its slowest lane is done: one
+// syndrome that never converges keeps 63 finished ones waiting for max_iter iterations.  Repacking: a first pass with
+// few iterations over everything, then the rows it left unconverged -- packed densely into new tiles -- are decoded
+// again from the start with the full iteration budget (BP is deterministic: restarting gives what continuing would),
+// and their results replace the first pass's.  Work ~ k1 + f * max_iter instead of max_iter (f = unconverged fraction).
+// ---- schedules whose order lives in the decoder object and changes while decoding (bp.hpp:467-483) ------------------------
+// The reference decodes one syndrome at a time and carries serial_schedule_order (and the shuffle generator) from decode to
+// decode.  A batch cannot do that across its rows (where row b starts would depend on how many iterations rows 0 .. b-1
+// took), so: EVERY ROW OF A CALL STARTS FROM THE HANDLE'S CURRENT STATE -- what the reference gives with a new decoder
+// object per syndrome when the state is the initial one -- and the call leaves the state its LAST row produced.  A batch
+// of one row is therefore exactly one BpDecoder::decode, and a sequence of one-row calls is exactly a sequence of decodes
+// on one reference object.  Both wait for the device at the end (the state comes back to the host).
+static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                int32_t *iters, uint8_t *conv) {
+    const int n = h->n, max_iter = h->max_iter;
+    // the arrangements of iterations 1 .. max_iter: std::shuffle on the object's std::mt19937, as RandomListShuffle does (rng.hpp:128-130)
+    if ((size_t)max_iter * (size_t)(n ? n : 1) > ((size_t)1 << 28))
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", max_iter, n);
+    std::vector<int32_t> orders((size_t)max_iter * (size_t)(n ? n : 1));
+    {
+        std::mt19937 g = h->sched_rng;
+        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+        for (int it = 0; it < max_iter; ++it) {
+            std::shuffle(v.begin(), v.end(), g);
+            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)n);
+        }
+    }
+    int rc;
+    if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
+    if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if ((rc = decode_serial_pass(h, max_iter, synd, batch, decoding, llr, iters, conv, (const int32_t *)h->sched_orders.p, max_iter))) return rc;
+    int32_t last = 0;
+    HIPCHK(hipMemcpyAsync(&last, iters + (batch - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+    for (int it = 0; it < last; ++it) std::shuffle(v.begin(), v.end(), h->sched_rng);  // the last row consumed `last` shuffles
+    std::copy(v.begin(), v.end(), h->sched_state.begin());
+    return LDPC_HIP_OK;
+}
+
+static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                  int32_t *iters, uint8_t *conv) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t n1 = (size_t)(h->n ? h->n : 1), m1 = (size_t)(h->m ? h->m : 1);
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap + h->rel_ord.cap + h->rel_dbit.cap;
+        const size_t per_tile = 2 * per_tile_msg + n1 * LDPC_WAVE * (8 + 4 + 1) + 24 * (m1 + n1);
+        int64_t fit = (int64_t)((double)(free_b + have) * 0.85 / (double)per_tile);
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk)) || (rc = h->msgC.ensure(per_tile_msg * (size_t)chunk)) ||
+        (rc = h->llr_t.ensure(n1 * LDPC_WAVE * 8 * (size_t)chunk)) || (rc = h->rel_ord.ensure(n1 * LDPC_WAVE * 4 * (size_t)chunk)) ||
+        (rc = h->rel_dbit.ensure(n1 * LDPC_WAVE * (size_t)chunk)) || (rc = h->par.ensure(sizeof(uint64_t) * m1 * (size_t)chunk)) ||
+        (rc = h->nzm.ensure(sizeof(uint64_t) * m1 * (size_t)chunk)) || (rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk)) ||
+        (rc = h->sched_order0.ensure(n1 * sizeof(int32_t)))) return rc;
+    hipStream_t st = h->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    void (*kern)(const RelArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_serial_relative_kernel<LDPC_HIP_MINIMUM_SUM, 0>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_relative_kernel<LDPC_HIP_PRODUCT_SUM, 1>;
+    else kern = bp_serial_relative_kernel<LDPC_HIP_PRODUCT_SUM, 0>;
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = false;
+    h->timed_mid = false;
+    int64_t last_tiles = 0;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        RelArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row;
+        a.order0 = (const int32_t *)h->sched_order0.p;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.llr_t = (double *)h->llr_t.p;
+        a.ord = (int32_t *)h->rel_ord.p; a.dbit = (uint8_t *)h->rel_dbit.p;
+        a.par = (const uint64_t *)h->par.p; a.invalid = (const uint64_t *)h->invalid.p;
+        a.decoding = decoding + b0 * h->n;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (llr && h->n > 0) {
+            dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+            hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n);
+        }
+        HIPCHK(hipGetLastError());
+        last_tiles = tiles;
+    }
+    // the order the LAST row ended with becomes the object's serial_schedule_order: column (last lane) of the last tile's ord
+    if (h->n > 0) {
+        const int64_t lane = (batch - 1) % LDPC_WAVE;
+        const int32_t *src = (const int32_t *)h->rel_ord.p + (size_t)(last_tiles - 1) * n1 * LDPC_WAVE + (size_t)lane;
+        HIPCHK(hipMemcpy2DAsync(h->sched_state.data(), sizeof(int32_t), src, sizeof(int32_t) * LDPC_WAVE, sizeof(int32_t), (size_t)h->n,
+                                hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return LDPC_HIP_OK;
+}
+
+static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                         int32_t *iters, uint8_t *conv) {
+    if (h->random_serial) return decode_serial_random(h, synd, batch, decoding, llr, iters, conv);  // (takes precedence, bp.hpp:467-469)
+    if (h->schedule == 2) return decode_serial_relative(h, synd, batch, decoding, llr, iters, conv);
+    int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
+    if (h->repack_iters < 0 && k1 < 2) k1 = 2;
+    if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
+        return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
+    const size_t B = (size_t)batch, m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
+    int rc;
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+    if ((rc = decode_serial_pass(h, k1, synd, batch, decoding, llr, iters, conv))) return rc;
+    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
+    const int64_t cnt = (int64_t)h->h_counters[2];
+    if (cnt == 0) return LDPC_HIP_OK;
+    float ms1 = 0.f;
+    (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
+    const size_t C = (size_t)cnt;
+    if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
+        (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
+    const int32_t *list = (const int32_t *)h->osd_list.p;
+    auto grid = [](size_t items) { return flat_grid(items); };
+    if (h->m > 0)
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * h->m), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
+    HIPCHK(hipGetLastError());
+    if ((rc = decode_serial_pass(h, h->max_iter, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p,
+                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
+    h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
+    if (h->n > 0) {
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * h->n), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
+        if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * h->n), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);
+    }
+    if (iters) hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
+    hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// soft_info_decode_serial over a batch (bp_softinfo_kernel).  Device pointers, on h->stream.
+static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, double cutoff, double sigma, uint8_t *decoding,
+                            double *llr, int32_t *iters, uint8_t *conv, double *soft_out) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    if (tiles_total == 0) return LDPC_HIP_OK;
+    const size_t m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * n1 * LDPC_WAVE : 0;
+    const size_t per_tile_soft = sizeof(double) * m1 * LDPC_WAVE;
+    const size_t lds = sizeof(uint64_t) * (m1 + 32);  // hard-syndrome words + the level kernel's reduction slots
+    if (lds > 150u * 1024u)
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "soft-syndrome decoding keeps one hard-syndrome word per check in LDS: m <= 19200");
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap + h->soft_S.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = 2 * per_tile_msg + per_tile_llr + per_tile_soft + 24 * (m1 + n1);
+        int64_t fit = (int64_t)(budget / per_tile);
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-shot tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->soft_S.ensure(per_tile_soft * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * m1 * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * n1 * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    int level_waves = 0;  // level-parallel variant: as for the serial schedule
+    if (h->serial_kernel != 0 && h->n > 0) {
+        if ((rc = ensure_serial_levels(h))) return rc;
+        const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+        if (h->serial_kernel == 1 || per_level >= 2.0) {
+            level_waves = (int)(per_level + 0.999);
+            if (level_waves > 8) level_waves = 8;
+            if (level_waves < 1) level_waves = 1;
+        }
+    }
+    // random_serial_schedule in this routine (bp.hpp:573-577): at the top of every iteration that still runs the order the
+    // object carries is rearranged by std::shuffle with a NEW std::default_random_engine(random_schedule_seed) -- one fixed
+    // rearrangement applied again and again.  Every row of the batch starts from the handle's order; the call leaves the order
+    // of its last row (its iteration count many rearrangements on).
+    const bool shuffled = h->random_serial && h->n > 0;
+    std::vector<int32_t> orders;
+    int32_t *d_iters_last = nullptr;
+    if (shuffled) {
+        level_waves = 0;  // the levels belong to one fixed order
+        if ((size_t)h->max_iter * (size_t)h->n > ((size_t)1 << 28))
+            return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", h->max_iter, h->n);
+        orders.resize((size_t)h->max_iter * (size_t)h->n);
+        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+        for (int it = 0; it < h->max_iter; ++it) {
+            std::shuffle(v.begin(), v.end(), std::default_random_engine(h->sched_seed_raw));
+            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)h->n);
+        }
+        if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;
+        if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+        d_iters_last = iters + (batch - 1);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    void (*soft_kern)(const SoftArgs);
+    if (h->max_row_deg <= 4 && h->max_col_deg <= 2) soft_kern = level_waves ? bp_softinfo_level_kernel<2, 4> : bp_softinfo_kernel<2, 4>;
+    else if (h->max_row_deg <= 6 && h->max_col_deg <= 3) soft_kern = level_waves ? bp_softinfo_level_kernel<3, 6> : bp_softinfo_kernel<3, 6>;
+    else if (h->max_row_deg <= 8 && h->max_col_deg <= 4) soft_kern = level_waves ? bp_softinfo_level_kernel<4, 8> : bp_softinfo_kernel<4, 8>;
+    else soft_kern = level_waves ? bp_softinfo_level_kernel<0, 0> : bp_softinfo_kernel<0, 0>;
+    if (lds > 48u * 1024u)
+        HIPCHK(hipFuncSetAttribute((const void *)soft_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = false;
+    h->timed_mid = false;
+    hipStream_t st = h->stream;
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 3) / 4), (unsigned)tiles);
+            hipLaunchKernelGGL(softinfo_prepare_kernel, g, dim3(256), 0, st, soft + (size_t)b0 * h->m, nb, h->m, sigma,
+                               (double *)h->soft_S.p, (uint64_t *)h->par.p);
+        }
+        SoftArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor; a.cutoff = cutoff;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
+        a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
+        if (shuffled && h->max_iter > 0) { a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; }
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.S = (double *)h->soft_S.p;
+        a.syn = (const uint64_t *)h->par.p;
+        a.dec = (uint64_t *)h->dec.p; a.dcur = (uint64_t *)h->dcur.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        if (h->timed) {
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+        }
+        HIPCHK(hipEventRecord(h->ev0, st));
+        a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+        hipLaunchKernelGGL(soft_kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), (unsigned)lds, st, a);
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st, (const uint64_t *)h->dec.p, nb, h->n,
+                               decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->llr_t.p, nb, h->n,
+                                   llr + (size_t)b0 * h->n);
+            }
+        }
+        if (soft_out && h->m > 0) {
+            dim3 gt((unsigned)((h->m + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+            hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st, (const double *)h->soft_S.p, nb, h->m,
+                               soft_out + (size_t)b0 * h->m);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (shuffled && batch > 0) {  // the order the last row leaves behind
+        int32_t last = 0;
+        HIPCHK(hipMemcpyAsync(&last, d_iters_last, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (last > h->max_iter) last = h->max_iter;
+        if (last > 0) std::copy(orders.begin() + (size_t)(last - 1) * (size_t)h->n, orders.begin() + (size_t)last * (size_t)h->n, h->sched_state.begin());
+    }
+    return LDPC_HIP_OK;
+}

@@ -1,0 +1,389 @@
+// host_stream.h -- host side of the streamed kernels: dispatch (decode_device), persistent + per-pass launches, two-pass decode with lane compaction
+// Part of libldpc_hip.so: included by bp_hip.hip (one translation unit), in the order given there.
+#pragma once
+
+
+// nt: non-temporal cache policy for the message traffic (tiles that outgrow the 256 MB MALL; see MsgBufT)
+static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+}
+
+// Everything below runs on h->stream with device pointers only.
+static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                  double *llr, int32_t *iters, uint8_t *conv);
+static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                         double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    if (tiles_total == 0) return LDPC_HIP_OK;
+    if (h->schedule == 0 || h->schedule == 2) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
+    if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
+        // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
+        // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
+        // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
+        if (h->small_mode != 2 && h->small_mode < 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
+            const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
+            if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
+        }
+        if (h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) {  // min-sum on the surface-code family: lane = edge
+            const EdgePlan ep = plan_edge(h);
+            if (ep.rounds) return decode_edge(h, ep, synd, batch, decoding, llr, iters, conv);
+        }
+        if (h->small_mode != 2) {
+            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr, batch);
+            if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
+        }
+        int slots = 0;
+        const size_t budget = (h->small_mode == 1 || h->small_mode == 2) ? 150u * 1024u : 39u * 1024u + 512u;
+        for (int sl = 4; sl >= 1 && !slots; --sl)
+            if (small_lds_bytes(h, sl) <= budget) slots = sl;
+        if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);
+    }
+    // streamed tiles: a tile runs until the slowest of its 64 syndromes is done.  Where most syndromes converge early
+    // a short first pass + a second pass over the compacted rest does the same work in a fraction of the tile-iterations
+    if (may_repack && h->repack_iters != 0 && h->max_iter >= 8 && tiles_total >= 512 && h->m > 0 && h->n > 0)
+        return decode_stream_repacked(h, synd, batch, decoding, llr, iters, conv);
+    const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
+    const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
+
+    int64_t chunk = tiles_total;
+    if (h->max_chunk_tiles > 0 && chunk > h->max_chunk_tiles) chunk = h->max_chunk_tiles;
+    if (chunk > 32768) chunk = 32768;  // grid.y of the pack/unpack launches stays below 65536
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        const size_t budget = (size_t)((double)(free_b + have) * 0.85);
+        const size_t per_tile = 2 * per_tile_msg + per_tile_llr + 16 * (size_t)(h->m + h->n + 1);
+        int64_t fit = (int64_t)(budget / (per_tile ? per_tile : 1));
+        if (fit < 1) return fail(LDPC_HIP_ERR_NOMEM, "not enough device memory for one 64-syndrome tile");
+        if (chunk > fit) chunk = fit;
+    }
+    int rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgC.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)chunk))) return rc;
+    if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
+    if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
+    const int handoff = h->handoff < 0 ? 256 : h->handoff;
+    h->last_chunk_tiles = chunk;
+    if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
+    if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
+    if ((rc = h->counter.ensure(16))) return rc;
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+
+    const int ring = h->regular ? h->ring_depth : 0;
+    KernelChoice kern;
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, ring);
+    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = false;
+    h->timed_mid = false;
+    hipStream_t st = h->stream;
+
+    for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
+        const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
+        const int64_t b0 = t0 * LDPC_WAVE;
+        const int64_t nb = (batch - b0 < tiles * LDPC_WAVE) ? batch - b0 : tiles * LDPC_WAVE;
+
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        if (h->m > 0) {
+            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+        }
+        BpArgs a = {};
+        a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
+        a.ms_scaling_factor = h->ms_scaling_factor;
+        a.batch = nb;
+        a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
+        a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
+        a.llr0 = h->d_llr0;
+        a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
+        if (h->cont_A) { a.A = h->cont_A + (size_t)t0 * (size_t)h->nnz * LDPC_WAVE; a.it_start = h->cont_it_start; }
+        a.keep_state = (h->keep_state || h->on("KEEP_LAST_MESSAGES")) ? 1 : 0;
+        a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
+        a.invalid = (const uint64_t *)h->invalid.p;
+        a.dec = (uint64_t *)h->dec.p;
+        a.dcur = (uint64_t *)h->dcur.p;
+        a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+        a.iters = iters ? iters + b0 : nullptr;
+        a.conv = conv ? conv + b0 : nullptr;
+        a.state = (TileState *)h->tile_state.p;
+        a.counters = (unsigned *)h->counter.p;
+        a.handoff_list = (int32_t *)h->handoff_list.p;
+        a.total_tiles = (int32_t)tiles;
+        a.handoff_threshold = handoff;
+        HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
+
+        // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,
+        // 16 wavefronts per CU -> 4-wave workgroups once there are >= 4 tiles per CU.  Ring variant:
+        // ~70 VGPRs and 6 KiB of LDS per wavefront -> 24 wavefronts per CU as two 12-wave workgroups
+        // (3 wavefronts on each SIMD; measured best on MI355X, profiles/; 6-wave workgroups place
+        // unevenly on the 4 SIMDs and 8-wave ones leave a ragged last round at 1024 tiles).
+        int waves = h->waves_per_wg;
+        if (waves <= 0) {
+            if (kern.ring_depth) waves = tiles >= 512 ? 12 : 16;
+            else waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+        }
+        if (waves > 16) waves = 16;
+        // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
+        // + the parking space of the exact product-sum check row (LDPC_NEAR_BYTES per wavefront, behind the rings)
+        const size_t near_bytes = (h->bp_method == LDPC_HIP_PRODUCT_SUM && h->math_mode == LDPC_HIP_MATH_LIBM_EXACT) ? LDPC_NEAR_BYTES : 0;
+        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth + near_bytes;
+        while (lds_per_wave * (size_t)waves > 144u * 1024u) --waves;
+        const size_t dyn_lds = lds_per_wave * (size_t)waves;
+        if (dyn_lds > 48u * 1024u)
+            HIPCHK(hipFuncSetAttribute((const void *)kern.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        if (h->timed) {  // fold the previous chunk's time before the events are re-recorded
+            float prev = 0.f;
+            HIPCHK(hipEventSynchronize(h->ev1));
+            HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
+            h->accumulated_ms += prev;
+            if (h->timed_mid) {
+                HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev_mid));
+                h->accumulated_persistent_ms += prev;
+            }
+        }
+        h->timed_mid = false;
+        HIPCHK(hipEventRecord(h->ev0, st));
+        SpreadArgs sa = {};
+        sa.bp = a;
+        sa.host_flag = h->d_flag;
+        sa.seq = ++h->flag_seq ? h->flag_seq : ++h->flag_seq;  // never 0 (the word's initial value)
+        // per-pass rounds: `grid_tiles` workgroup rows; how many of them have a tile is known to the host only when the
+        // batch skips the persistent kernel (sa.n_tiles >= 0), otherwise the kernels read it from counters[1]
+        unsigned grid_tiles = 0;
+        int first_round = 1;  // a tile parked by the persistent kernel has completed >= 1 iteration
+        if (handoff > 0 && tiles <= handoff && h->max_iter - a.it_start > 1) {
+            // so few tiles that they would each sit on one compute unit: per-pass launches from the start
+            grid_tiles = (unsigned)tiles;
+            sa.n_tiles = (int32_t)tiles;
+            sa.nodes = tiles <= 8 ? 1 : 4;
+            first_round = 0;
+            hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((grid_tiles + 255) / 256), dim3(256), 0, st, sa);
+            const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), grid_tiles);  // (a grid dimension must not be 0: empty matrices)
+            if (a.it_start > 0) { /* the message state is there already */ }
+            else if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), gi, dim3(256), 0, st, sa);
+            else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), gi, dim3(256), 0, st, sa);
+            else hipLaunchKernelGGL((bp_spread_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), gi, dim3(256), 0, st, sa);
+            HIPCHK(hipGetLastError());
+        } else {
+            if (kern.ring_depth && h->n > 0 && !h->on("EXPLICIT_INIT")) {  // the first check pass reads this table instead of initial messages
+                if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
+                const dim3 ge((unsigned)((h->n + 255) / 256));
+                if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else hipLaunchKernelGGL((bp_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                a.edge0 = (const double *)h->d_edge0.p;
+            }
+            hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(h->ev_mid, st));
+            h->timed_mid = true;
+            if (handoff > 0 && h->max_iter > 1) {
+                // the persistent kernel parks at most `handoff` tiles (it starts parking when that many are unfinished);
+                // how many it did park stays on the device
+                grid_tiles = (unsigned)(tiles < handoff ? tiles : handoff);
+                sa.n_tiles = -1;
+                sa.nodes = 4;
+            }
+        }
+        if (grid_tiles > 0) {
+            // finish the parked tiles with chip-wide per-pass launches: check, bit, syndrome test, bookkeeping.  Every
+            // round is queued at once; the host never waits.  A tile that is final (or a workgroup row without a tile)
+            // leaves each kernel at its first instruction, and once the device has reported "nothing left" through
+            // the host-mapped flag the host stops queueing -- which only matters when max_iter is far larger than
+            // the iterations needed (the reference's default max_iter = n).
+            spread_kernel_t kc, kb;
+            // messages of the tiles in flight: 2 arrays x nnz x 512 B each; beyond ~the MALL they are streamed, not cached
+            pick_spread(h, (double)grid_tiles * 2.0 * (double)per_tile_msg > 384.0 * 1024.0 * 1024.0, kc, kb);
+            const unsigned per_wg = 4u * (unsigned)sa.nodes;
+            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
+            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
+            const int rounds = h->max_iter - (first_round ? first_round : a.it_start);  // (a tile parked by the persistent kernel knows its own it0)
+            const volatile unsigned *flag = h->h_flag;
+            for (int round = 0; round < rounds; ++round) {
+                if (*flag == sa.seq) break;  // a look, not a wait
+                sa.round = round;
+                hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_synd_kernel, gs, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_finish_kernel, gf, dim3(256), 0, st, sa);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        if (h->on("DEBUG_HANDOFF")) {  // diagnostic only: waits for the device and reports what the persistent kernel parked
+            unsigned c[4] = {0, 0, 0, 0};
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpy(c, h->counter.p, 16, hipMemcpyDeviceToHost));
+            const TileState *ts = nullptr; (void)ts;
+            std::vector<TileState> states((size_t)tiles);
+            HIPCHK(hipMemcpy(states.data(), h->tile_state.p, sizeof(TileState) * (size_t)tiles, hipMemcpyDeviceToHost));
+            std::vector<int32_t> list((size_t)tiles);
+            HIPCHK(hipMemcpy(list.data(), h->handoff_list.p, sizeof(int32_t) * (size_t)tiles, hipMemcpyDeviceToHost));
+            long sum_it0 = 0; int min_it0 = 1 << 30, max_it0 = 0;
+            for (unsigned q = 0; q < c[1] && q < (unsigned)tiles; ++q) { const int it0 = states[(size_t)list[q]].it0; sum_it0 += it0; if (it0 < min_it0) min_it0 = it0; if (it0 > max_it0) max_it0 = it0; }
+            fprintf(stderr, "[ldpc_hip] tiles %lld: finished by the persistent kernel %u, parked %u (iterations done when parked: min %d mean %.1f max %d), live afterwards %u\n",
+                    (long long)tiles, c[0], c[1], c[1] ? min_it0 : 0, c[1] ? (double)sum_it0 / c[1] : 0.0, max_it0, c[2]);
+        }
+
+        if (h->n > 0) {
+            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st,
+                               (const uint64_t *)h->dec.p, nb, h->n, decoding + b0 * h->n);
+            if (llr) {
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st,
+                                   (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return LDPC_HIP_OK;
+}
+
+
+// Two passes of the streamed parallel schedule: k1 iterations for everyone, then the rows that have not converged are
+// COMPACTED: their message state is gathered, lane by lane, out of the first pass's tiles into dense tiles, and the decode
+// carries on from iteration k1 + 1 on those (same operations on the same values: same results).  A 64-syndrome tile runs until
+// its slowest syndrome is done and moves all 64 lanes' messages until then; after the compaction the tiles hold live lanes
+// only.  (Rounds 1 - 2 restarted the gathered rows from scratch, which only pays when almost everything has converged by k1.)
+// Whether and where to cut depends on the noise, which the host cannot see -- so every streamed decode leaves a histogram of
+// its iteration counts behind (one tiny kernel, copied asynchronously) and the next decode on the handle prices the
+// alternatives with it, in tile-iterations per tile of the batch: F(j) = fraction converged within j iterations,
+//     plain        sum_j (1 - F(j-1)^64)
+//     cut at k     sum_{j<=k} (1 - F(j-1)^64)  +  gather  +  (1 - F(k)) sum_{j>k} (1 - G_k(j-1)^64),  G_k = F conditioned on > k,
+// gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) / 4 of an iteration (an
+// iteration moves four arrays), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
+// converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
+static int stream_first_pass_length(ldpc_hip_bp *h) {
+    if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
+    if (!h->hist_pending || h->hist_max_iter != h->max_iter) return 0;
+    if (hipEventSynchronize(h->ev_hist) != hipSuccess) return 0;
+    const int full = h->max_iter, top = full < 255 ? full : 255;
+    double total = 0;
+    for (int j = 0; j < 256; ++j) total += h->h_hist[j];
+    if (total <= 0) return 0;
+    std::vector<double> F((size_t)top + 1, 0.0);  // F[j]: converged within j iterations
+    double acc = 0;
+    for (int j = 1; j <= top; ++j) { acc += h->h_hist[j]; F[(size_t)j] = acc / total; }
+    auto Fj = [&](int j) { return F[(size_t)(j < top ? j : top)]; };
+    auto tile_runs = [&](int j) { return 1.0 - std::pow(Fj(j - 1), 64.0); };  // still going at iteration j
+    double plain = 0;
+    for (int j = 1; j <= full; ++j) plain += tile_runs(j);
+    double best = plain, prefix = 0;
+    int best_k = 0;
+    for (int k = 1; k < full && k <= top; ++k) {
+        prefix += tile_runs(k);
+        const double live = 1.0 - Fj(k);
+        if (k < 2 || live <= 0.0 || live > 0.6) continue;
+        double rest = 0;
+        for (int j = k + 1; j <= full; ++j) {
+            const double g = (Fj(j - 1) - Fj(k)) / live;  // of the rows alive after k: done within j - 1
+            const double r = 1.0 - std::pow(g < 0 ? 0 : g, 64.0);
+            rest += r;
+            if (r < 1e-9 && j > top) break;
+        }
+        const double cost = prefix + 0.25 * (1.0 + live) + 0.1 + live * rest;
+        if (cost < best) { best = cost; best_k = k; }
+    }
+    return best < 0.97 * plain ? best_k : 0;
+}
+
+static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
+    int rc;
+    if ((rc = h->sp_hist.ensure(256 * sizeof(unsigned)))) return rc;
+    if (!h->h_hist) HIPCHK(hipHostMalloc((void **)&h->h_hist, 256 * sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(h->sp_hist.p, 0, 256 * sizeof(unsigned), h->stream));
+    int64_t blocks = (batch + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(iteration_histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, iters, conv, batch, (unsigned *)h->sp_hist.p);
+    HIPCHK(hipMemcpyAsync(h->h_hist, h->sp_hist.p, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_hist, h->stream));
+    h->hist_pending = true;
+    h->hist_max_iter = h->max_iter;
+    return LDPC_HIP_OK;
+}
+
+static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                  double *llr, int32_t *iters, uint8_t *conv) {
+    const int full = h->max_iter;
+    const size_t B = (size_t)batch, m1 = (size_t)h->m, n1 = (size_t)h->n;
+    int rc;
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+    const int k1 = stream_first_pass_length(h);
+    if (k1 < 2 || k1 >= full) {
+        if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false))) return rc;
+        return stream_leave_histogram(h, iters, conv, batch);
+    }
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+    h->max_iter = k1;
+    h->keep_state = true;
+    rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+    h->keep_state = false;
+    h->max_iter = full;
+    if (rc) return rc;
+    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
+    const int64_t cnt = (int64_t)h->h_counters[2];
+    if (cnt > 0) {
+        float ms1 = 0.f;
+        (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
+        const size_t C = (size_t)cnt;
+        if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
+            (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
+        const int32_t *list = (const int32_t *)h->osd_list.p;
+        auto grid = [](size_t items) { return flat_grid(items); };
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
+        HIPCHK(hipGetLastError());
+        // the listed rows' message state after k1 iterations, lane by lane, into dense tiles -- possible when the first pass kept the
+        // whole batch's messages resident (one chunk) and ran the streamed kernels (they leave bit_to_check in msgA)
+        const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE, tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
+        const size_t per_tile = sizeof(double) * (size_t)h->nnz * LDPC_WAVE;
+        bool carry_on = h->last_chunk_tiles >= tiles1 && h->nnz > 0 && !h->on("REPACK_RESTART");
+        if (carry_on && h->rp_msg.ensure(per_tile * (size_t)tiles2)) { carry_on = false; (void)hipGetLastError(); }
+        if (carry_on) {
+            const int epw = 16;
+            const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)tiles2);
+            HIPCHK(hipEventRecord(h->ev0, h->stream));  // (the compaction belongs to this decode's kernel time)
+            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, h->stream, (const double *)h->msgA.p, list, cnt, h->nnz, epw, (double *)h->rp_msg.p);
+            HIPCHK(hipEventRecord(h->ev1, h->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventSynchronize(h->ev1));
+            float gms = 0.f;
+            HIPCHK(hipEventElapsedTime(&gms, h->ev0, h->ev1));
+            ms1 += gms;
+            h->cont_A = (double *)h->rp_msg.p;
+            h->cont_it_start = k1;
+        }
+        rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
+                           (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, false);
+        h->cont_A = nullptr;
+        h->cont_it_start = 0;
+        if (rc) return rc;
+        h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * n1), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
+        if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * n1), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);
+        hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
+        HIPCHK(hipGetLastError());
+    }
+    return stream_leave_histogram(h, iters, conv, batch);
+}
