@@ -215,11 +215,12 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
     if (team) {
         const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
         int tw = (int)(rounds < 2 ? 2 : rounds > 8 ? 8 : rounds);
+        if (h->sw("PS_TEAM_WAVES") >= 1 && h->sw("PS_TEAM_WAVES") <= 16) tw = h->sw("PS_TEAM_WAVES");  // (measurements)
         p.team = true;
         p.waves = tw;
         p.kern = p.kern_team;
         p.groups_per_cu = (int)(lds / (p.shared + p.per_wave));
-        if (p.groups_per_cu * p.waves > 28) p.groups_per_cu = 28 / p.waves;  // (this kernel's 59 VGPRs allow 7 wavefronts per SIMD)
+        if (p.groups_per_cu * p.waves > 28) p.groups_per_cu = 28 / p.waves;  // (this kernel's 65 VGPRs allow 7 wavefronts per SIMD)
         if (p.groups_per_cu < 1) p.groups_per_cu = 1;
         return p;
     }

@@ -331,3 +331,40 @@ def test_streamed_parallel_schedule_repacks_from_the_previous_histogram(oracle_b
     assert np.array_equal(osd[pick], want_osd)
     assert np.array_equal(osd[conv], runs["first"][0][conv])
 
+
+
+@pytest.mark.parametrize("method,alpha", [(0, 1.0), (1, 0.0)])
+def test_lane_compaction_carries_the_decode_on_at_any_cut(method, alpha, oracle_built):
+    """The streamed two-pass decode (ldpc_hip_bp_set_repack(k)): k iterations for all, then the unconverged rows' message state is
+    compacted lane by lane into dense tiles and iterations k + 1 ... follow on those.  Any cut must give the arrays of the plain
+    run -- including a cut after which nothing is left, one that leaves almost everything, the last possible one, the adaptive
+    scaling factor (which depends on the absolute iteration number) and a second pass small enough for the per-pass kernels."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = sp.csr_matrix(codes.regular_ldpc_code(n=600, dv=3, dc=6, seed=9))
+    n = h.shape[1]
+    max_iter = 14
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.04), max_iter, method, alpha)
+    eng.set_small_code_kernel(0)
+    s = torch.cat([eng.gen_bsc_syndromes(5, 0.03, shot0=0, shots=33000, device="cuda:0"),
+                   eng.gen_bsc_syndromes(6, 0.09, shot0=0, shots=900, device="cuda:0")])
+    s = s[torch.randperm(len(s), generator=torch.Generator().manual_seed(2)).to(s.device)].contiguous()
+    eng.set_repack(0)
+    plain = [t.cpu().numpy() for t in eng.decode_batch(s)]
+    it = plain[2]
+    assert 2 < np.median(it) < 9 and (it == max_iter).sum() > 100
+    for k in (1, 2, int(np.median(it)), int(np.median(it)) + 2, max_iter - 1):
+        eng.set_repack(k)
+        got = [t.cpu().numpy() for t in eng.decode_batch(s)]
+        for a, b in zip(plain, got):
+            assert bits_equal(a, b) if a.dtype == np.float64 else np.array_equal(a, b), k
+        lean = eng.decode_batch(s, want_llr=False)
+        assert lean[1] is None and np.array_equal(lean[0].cpu().numpy(), plain[0]) and np.array_equal(lean[2].cpu().numpy(), plain[2]), k
+    eng.set_debug_switch("REPACK_RESTART", 1)  # rounds 1 - 2: the second pass starts afresh
+    eng.set_repack(4)
+    got = [t.cpu().numpy() for t in eng.decode_batch(s)]
+    assert np.array_equal(got[0], plain[0]) and np.array_equal(got[2], plain[2]) and bits_equal(got[1], plain[1])
+    rows = np.r_[0:48, np.flatnonzero(it == max_iter)[:48]]
+    want = oracle_built.BpOracle(h, error_rate=0.04, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha).decode_batch(s.cpu().numpy()[rows])
+    assert np.array_equal(plain[0][rows], want[0]) and np.array_equal(plain[2][rows], want[2]) and bits_equal(plain[1][rows], want[1])
