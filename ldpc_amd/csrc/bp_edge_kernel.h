@@ -41,7 +41,8 @@ struct EdgeArgs {
     double prior_u;            // the one prior of every column                              (UNIFORM form: no prior registers)
     const uint16_t *partner;   // [R * 64] slot of the other entry of the slot's column; none: R * 64 (the +0.0 slot); a phantom lane:
                                // R * 64 + 1 (a slot that holds +inf for good)
-    int32_t chunk;             // syndromes pulled per visit to the work counter
+    int32_t chunk;             // syndromes pulled per visit to a work counter
+    int32_t static_per, dyn_base, pool_per;  // edge_next_chunk: static share per wavefront, where the pools start, syndromes per pool (batch < 2^30)
     const uint8_t *kind;       // [R * 64] 0 phantom, 1 first entry of its column (lower row), 2 second entry
     const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
     const uint8_t *synd;       // [batch][m]
@@ -49,10 +50,52 @@ struct EdgeArgs {
     double *llr;               // [batch][n] or nullptr
     int32_t *iters;            // [batch] or nullptr
     uint8_t *conv;             // [batch] or nullptr
-    unsigned long long *next;  // device-wide work counter (zeroed before launch)
+    unsigned long long *next;  // EDGE_POOLS work counters, EDGE_POOL_STRIDE words apart (zeroed before launch)
 };
 
 __host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }  // slots, +0.0, +inf
+
+// ---- work distribution of the lane = edge kernels ------------------------------------------------------------------------------
+// A wavefront's syndromes take 3 .. 100 us and the wavefronts do not run at one speed (equal static shares finish 20 % apart on
+// BASELINE config 3: tools/sweep_edge_split.py), so the batch is handed out syndrome by syndrome.  ONE counter word serves ~88
+// atomic visits per microsecond device-wide -- 5 120 resident wavefronts outrun that on every code below d = 21 -- hence
+// EDGE_POOLS counters, each in its own 4 KiB of memory (another channel), each owning a contiguous slice of the batch.  A
+// wavefront starts with its static share (static_per syndromes, no counter), then draws from pool blockIdx mod EDGE_POOLS
+// (workgroups go round the 8 XCDs: a pool is served by one XCD) and, when that runs dry, reads all counters in one vector load
+// and moves to the next pool that still has work: the faster XCDs finish the slower ones' slices.
+constexpr int EDGE_POOLS = 32;
+constexpr int EDGE_POOL_STRIDE = 512;  // 64-bit words between counters
+__host__ __device__ inline size_t edge_counter_bytes() { return (size_t)EDGE_POOLS * EDGE_POOL_STRIDE * 8; }
+
+// The next syndromes [b0, b1) of this wavefront (q: its current pool); false: the batch is done.  Wave-uniform results.
+template <typename ARGS>
+__device__ __forceinline__ bool edge_next_chunk(const ARGS &a, int lane, int &q, int &b0, int &b1) {
+    const int batch = (int)a.batch;
+    for (;;) {
+        unsigned pulled = 0;
+        if (lane == 0) pulled = (unsigned)atomicAdd(a.next + (size_t)q * EDGE_POOL_STRIDE, (unsigned long long)a.chunk);
+        const int got = __builtin_amdgcn_readfirstlane((int)pulled);
+        const int lo = a.dyn_base + q * a.pool_per;
+        const int end = lo + a.pool_per < batch ? lo + a.pool_per : batch;
+        if (got < end - lo) {
+            b0 = lo + got;
+            b1 = b0 + a.chunk < end ? b0 + a.chunk : end;
+            return true;
+        }
+        // this pool is dry: which ones are not?  (one load per lane; a counter only grows, so a pool seen dry stays dry)
+        bool has = false;
+        if (lane < EDGE_POOLS) {
+            const unsigned long long c = __hip_atomic_load(a.next + (size_t)lane * EDGE_POOL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long plo = (long long)a.dyn_base + (long long)lane * a.pool_per;
+            const long long pend = plo + a.pool_per < batch ? plo + a.pool_per : batch;
+            has = plo + (long long)c < pend;
+        }
+        const uint64_t mask = __ballot(has);
+        if (!mask) return false;
+        const uint64_t at_or_after = mask & (~0ull << q);
+        q = at_or_after ? __builtin_ctzll(at_or_after) : __builtin_ctzll(mask);
+    }
+}
 
 // How many of the R rounds let the vector unit do what the scalar unit would (both issue one instruction per SIMD turn, and the
 // kernel's scalar work -- lane-mask parities -- outweighs its vector work): measured on BASELINE config 3, tools/bench_edge.py
@@ -135,21 +178,17 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
 #define LDPC_EDGE_PRIOR(r) (UNIFORM ? pu : prv[UNIFORM ? 0 : (r)])
     const double dbl_max = uniform_f64(DBL_MAX);
     if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
-    const int64_t chunk = a.chunk;
 
+    // Work: the static share, then chunks from the pooled work counters (edge_next_chunk)
+    int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
+    int pool = (int)(blockIdx.x & (EDGE_POOLS - 1));
     for (;;) {
-        unsigned long long pulled = 0;
-        if (lane == 0) pulled = atomicAdd(a.next, (unsigned long long)chunk);
-        const int64_t b0 = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
-        if (b0 >= a.batch) break;
-        const int64_t b1 = b0 + chunk < a.batch ? b0 + chunk : a.batch;
-      for (int64_t b = b0; b < b1; ++b) {
+      for (int b = b0; b < b1; ++b) {
         // this syndrome's bytes as lane masks: bit 4 q of sy[r] = (byte & 1) of the row that lanes 4 q .. 4 q + 3 serve in round r;
         // a byte above 1 can never be matched (bp.hpp:300)
         uint64_t sy[R];
         bool never = false;
-        const uint8_t *sb = a.synd + b * m;
+        const uint8_t *sb = a.synd + (int64_t)b * m;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = r * 16 + (lane >> 2);
@@ -233,8 +272,8 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
             if (a.kind[s] == 1) {
                 const double l0 = (LDPC_EDGE_PRIOR(r) + X[s]) + X[paddr[r]];
                 const int j = a.scol[s];
-                a.decoding[b * n + j] = l0 <= 0.0 ? 1 : 0;
-                if (a.llr) a.llr[b * n + j] = l0;
+                a.decoding[(int64_t)b * n + j] = l0 <= 0.0 ? 1 : 0;
+                if (a.llr) a.llr[(int64_t)b * n + j] = l0;
             }
         }
         if (lane == 0) {
@@ -246,6 +285,190 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
         // lane 0 masked off -- every other lane's `pulled` is 0, i.e. syndrome 0 for ever (seen with R = 1).
         __builtin_amdgcn_wave_barrier();
       }
+        if (!edge_next_chunk(a, lane, pool, b0, b1)) break;
+    }
+#undef LDPC_EDGE_PRIOR
+}
+
+// ---- the same idea for heavier nodes: rows of weight <= 8 in EIGHT neighbouring lanes, columns of weight <= DC (<= 4) ----------
+// Bivariate-bicycle codes (rows of 6, columns of 3: BB [[72,12,6]] ... [[144,12,12]]), small hypergraph products.  Differences to
+// bp_edge_kernel:
+//   * the butterfly over the other entries of a row has a third step across the two quads of the 8-lane group (row_shl:4 / row_shr:4
+//     DPP moves, each writing the banks it is meant for), the sign parity is a BYTE parity of the lane mask;
+//   * a column has up to DC entries, so a lane reads ALL of them from the wave-private LDS array in column order (its own
+//     included; lighter columns: the +0.0 slot behind their entries) and forms the reference's sums with them:
+//         log-ratio            (((prior + c0) + c1) + c2) + c3                                   (bp.hpp:278-281), the same in every lane of a column,
+//         bit_to_check of k    ((prior + c0) + ... + c_{k-1})  +  (((0 + c_{DC-1}) + ...) + c_{k+1})  (bp.hpp:279, 311-318)
+//     (0.0 + x and x + 0.0 are dropped where x + a prior follows or the sum contains the prior: they can only turn -0.0 into +0.0,
+//     which a sum with a prior log((1-p)/p) -- never -0.0 -- does not see); the lane's own k picks its bit_to_check by two or three
+//     v_cndmask pairs reading per-round lane masks from SGPRs.
+struct Edge8Args {
+    int32_t m, n, max_iter;
+    double ms_scaling_factor;
+    int64_t batch;
+    const double *prior_s;     // [R * 64] prior of the slot's column; phantom: +inf          (general form)
+    double prior_u;            // the one prior of every column                              (UNIFORM form)
+    const uint16_t *cpos;      // [DC][R * 64] slot of the j-th entry of the slot's column, j < DC; beyond the column's weight: R * 64 (the +0.0
+                               // slot); a phantom lane: R * 64 + 1 everywhere (a slot that holds +inf for good)
+    const uint8_t *kind;       // [R * 64] 0 phantom, 1 + k for the k-th entry of its column
+    const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
+    int32_t chunk;
+    int32_t static_per, dyn_base, pool_per;  // (as EdgeArgs)
+    const uint8_t *synd;
+    uint8_t *decoding;
+    double *llr;
+    int32_t *iters;
+    uint8_t *conv;
+    unsigned long long *next;
+};
+
+namespace edge_detail {
+// lane ^ 4 inside an 8-lane group: two DPP moves per dword, each writing only the banks (groups of 4 lanes) it is right for
+__device__ __forceinline__ double xor4(double x) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11)
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(x), 0x114, 0xf, 0xa, false);      // row_shr:4 -> banks 1, 3
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x104, 0xf, 0x5, false);
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(x), 0x114, 0xf, 0xa, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t byte_parity_low(uint64_t x) {  // result in bit 0 of every byte; the other bits are garbage
+    x ^= x >> 1;
+    x ^= x >> 2;
+    x ^= x >> 4;
+    return x;
+}
+__device__ __forceinline__ uint64_t spread_byte(uint64_t low) {  // bit 0 of every byte -> all eight bits
+    const uint32_t a = ((uint32_t)low & 0x01010101u) * 255u, b = ((uint32_t)(low >> 32) & 0x01010101u) * 255u;
+    return ((uint64_t)b << 32) | a;
+}
+__device__ __forceinline__ double select_f64(double a, double b, uint64_t mask) {  // per lane: bit `lane` of mask ? b : a
+    return __hiloint2double(select_by_mask(__double2hiint(a), __double2hiint(b), mask), select_by_mask(__double2loint(a), __double2loint(b), mask));
+}
+}  // namespace edge_detail
+
+template <int R, int DC, bool UNIFORM>
+__global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edge8Args a) {
+    using namespace edge_detail;
+    static_assert(DC >= 2 && DC <= 4, "columns of 2 .. 4 entries");
+    extern __shared__ __attribute__((aligned(16))) unsigned char edge_lds[];
+    typedef __attribute__((address_space(3))) double lds_f64;
+    lds_f64 *X = (lds_f64 *)edge_lds;
+    const int lane = threadIdx.x;
+    const int m = a.m, n = a.n;
+    constexpr int ZERO = R * 64;
+    constexpr uint64_t LOW = 0x0101010101010101ull;
+
+    double prv[UNIFORM ? 1 : R], msg[R];
+    int caddr[R][DC];
+    uint64_t kmask[R][DC - 1];  // lanes whose entry is the (j + 1)-th of its column, j < DC - 1
+    bool phantom_lane[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int s = r * 64 + lane;
+        if (!UNIFORM) prv[r] = a.prior_s[s];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) caddr[r][j] = (int)a.cpos[(size_t)j * (R * 64) + s];
+        const int kd = a.kind[s];
+        phantom_lane[r] = kd == 0;
+#pragma unroll
+        for (int j = 0; j < DC - 1; ++j) kmask[r][j] = __ballot(kd == j + 2);
+    }
+    const double pu = uniform_f64(a.prior_u);
+#define LDPC_EDGE_PRIOR(r) (UNIFORM ? pu : prv[UNIFORM ? 0 : (r)])
+    const double dbl_max = uniform_f64(DBL_MAX);
+    if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
+
+    // Work: the static share, then chunks from the pooled work counters (edge_next_chunk)
+    int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
+    int pool = (int)(blockIdx.x & (EDGE_POOLS - 1));
+    for (;;) {
+      for (int b = b0; b < b1; ++b) {
+        uint64_t sy[R];
+        bool never = false;
+        const uint8_t *sb = a.synd + (int64_t)b * m;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = r * 8 + (lane >> 3);
+            const int byte = row < m ? (int)sb[row] : 0;
+            sy[r] = __ballot((byte & 1) != 0) & LOW;
+            never = never || __ballot(byte > 1) != 0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) msg[r] = phantom_lane[r] ? __builtin_inf() : LDPC_EDGE_PRIOR(r);  // initialise_log_domain_bp (bp.hpp:147-157)
+
+        int it = 0;
+        bool unsat = true;
+        do {
+            ++it;
+            const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
+            const int alo = __double2loint(alpha), ahi = __double2hiint(alpha), nhi = ahi ^ (int)0x80000000;
+            // ---- check pass (bp.hpp:220-273): minimum over the seven other lanes of the group, sign by the group's parity ----
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double cur = msg[r];
+                const uint64_t neg = __ballot(cur <= 0.0);
+                const double x1 = quad_perm<0xB1>(cur);                // lane ^ 1
+                const double pairmin = min_abs(cur, x1);
+                const double otherpair = quad_perm<0x4E>(pairmin);     // lane ^ 2: the other pair of the quad
+                const double inquad = min_abs(x1, otherpair);          // the three others of the quad
+                const double quadmin = min_abs(pairmin, otherpair);    // ... and the whole quad, for the other quad (values >= 0: |.| is idle)
+                const double otherquad = xor4(quadmin);
+                const double mag = fmin_pos(min_abs(inquad, otherquad), dbl_max);  // the seven other entries, from DBL_MAX down
+                const uint64_t flip = spread_byte(byte_parity_low(neg ^ sy[r])) ^ neg;
+                const double c = mag * __hiloint2double(select_by_mask(ahi, nhi, flip), alo);
+                msg[r] = c;
+                X[r * 64 + lane] = c;
+            }
+            // ---- bit pass (bp.hpp:276-318): the column's entries in order; log-ratio, decision, the lane's own bit_to_check ----
+            uint64_t bad = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double c[DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) c[j] = X[caddr[r][j]];
+                const double pr = LDPC_EDGE_PRIOR(r);
+                double pre[DC];  // pre[k] = prior + c0 + ... + c_{k-1}
+                double t = pr;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) { pre[j] = t; t += c[j]; }
+                const uint64_t d = __ballot(t <= 0.0);  // (phantom lanes: +inf or NaN, never <= 0)
+                bad |= byte_parity_low(d) ^ sy[r];
+                // the lane's own bit_to_check: cand[k] = pre[k] + (((0 + c_{DC-1}) + ...) + c_{k+1}), accumulated downwards as the reference
+                // does (bp.hpp:311-318); the k-th entry of its column takes cand[k]
+                double cand[DC];
+                double sfx = c[DC - 1];
+                cand[DC - 1] = pre[DC - 1];
+                cand[DC - 2] = pre[DC - 2] + sfx;
+#pragma unroll
+                for (int k = DC - 3; k >= 0; --k) { sfx += c[k + 1]; cand[k] = pre[k] + sfx; }
+                double b2c = cand[0];
+#pragma unroll
+                for (int k = 1; k < DC; ++k) b2c = select_f64(b2c, cand[k], kmask[r][k - 1]);
+                msg[r] = b2c;
+            }
+            unsat = never || (bad & LOW) != 0;
+        } while (unsat && it < a.max_iter);
+
+        // ---- outputs: by the lanes that own the first entry of a column ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = r * 64 + lane;
+            if (a.kind[s] == 1) {
+                double t = LDPC_EDGE_PRIOR(r);
+#pragma unroll
+                for (int j = 0; j < DC; ++j) t += X[caddr[r][j]];
+                const int j = a.scol[s];
+                a.decoding[(int64_t)b * n + j] = t <= 0.0 ? 1 : 0;
+                if (a.llr) a.llr[(int64_t)b * n + j] = t;
+            }
+        }
+        if (lane == 0) {
+            if (a.iters) a.iters[b] = it;
+            if (a.conv) a.conv[b] = unsat ? 0 : 1;
+        }
+        __builtin_amdgcn_wave_barrier();  // (see bp_edge_kernel)
+      }
+        if (!edge_next_chunk(a, lane, pool, b0, b1)) break;
     }
 #undef LDPC_EDGE_PRIOR
 }

@@ -386,12 +386,30 @@ static int ensure_edge_tables(ldpc_hip_bp *h, const EdgePlan &p) {
     return LDPC_HIP_OK;
 }
 
+// How the lane = edge kernels share a batch among their wavefronts (edge_next_chunk, bp_edge_kernel.h): one syndrome each to
+// start with, the rest in EDGE_POOLS slices behind a work counter each.  Syndromes per visit: 1, except for the smallest codes
+// (one round: a syndrome takes a few microseconds) on large batches.  EDGE_STATIC_PCT / EDGE_CHUNK: measurement overrides.
+template <typename ARGS>
+static int edge_work_split(ldpc_hip_bp *h, int rounds, int64_t batch, int64_t groups, ARGS &a) {
+    int rc;
+    if ((rc = h->counter.ensure(edge_counter_bytes()))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, edge_counter_bytes(), h->stream));
+    a.next = (unsigned long long *)h->counter.p;
+    int64_t static_per = 1;
+    if (h->sw("EDGE_STATIC_PCT") >= 0) static_per = (batch * (h->sw("EDGE_STATIC_PCT") > 100 ? 100 : h->sw("EDGE_STATIC_PCT")) / 100) / groups;
+    a.static_per = (int32_t)static_per;
+    a.dyn_base = (int32_t)(static_per * groups);
+    a.pool_per = (int32_t)((batch - a.dyn_base + EDGE_POOLS - 1) / EDGE_POOLS);
+    int64_t c = rounds >= 2 ? 1 : batch / (groups * 16);
+    if (h->sw("EDGE_CHUNK") > 0) c = h->sw("EDGE_CHUNK");
+    a.chunk = (int32_t)(c < 1 ? 1 : c > 8 ? 8 : c);
+    return LDPC_HIP_OK;
+}
+
 static int decode_edge(ldpc_hip_bp *h, const EdgePlan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                        int32_t *iters, uint8_t *conv) {
     int rc;
     if ((rc = ensure_edge_tables(h, p))) return rc;
-    if ((rc = h->counter.ensure(8))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
     const int slots = p.rounds * 64;
     // (the priors may have changed since the last call: ldpc_hip_bp_set_channel)
     hipLaunchKernelGGL(edge_prior_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, (const int32_t *)h->e_scol.p,
@@ -404,17 +422,107 @@ static int decode_edge(ldpc_hip_bp *h, const EdgePlan &p, const uint8_t *synd, i
     a.prior_u = std::log((1 - h->channel_probs[0]) / h->channel_probs[0]);  // as upload_priors (bp.hpp:150-151); read by the uniform form only
     a.kind = (const uint8_t *)h->e_kind.p; a.scol = (const int32_t *)h->e_scol.p;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
-    a.next = (unsigned long long *)h->counter.p;
     const size_t dyn = edge_lds_bytes(p.rounds);
     // one wavefront per workgroup, as many resident as registers (4 or 5 per SIMD) and LDS allow
     int64_t per_cu = (int64_t)((160u * 1024u) / (dyn + 64));
     const int64_t by_regs = p.uniform ? 20 : 16;
     if (per_cu > by_regs) per_cu = by_regs;
     int64_t groups = batch < 256 * per_cu ? batch : 256 * per_cu;
-    // a visit to the work counter costs ~1 us under load and one word serves ~88 of them per us: pull several syndromes at a
-    // time once there are many per wavefront (the tail then is at most `chunk` syndromes of one wavefront)
-    int64_t chunk = batch / (groups * 16);
-    a.chunk = (int32_t)(chunk < 1 ? 1 : chunk > 8 ? 8 : chunk);
+    if ((rc = edge_work_split(h, p.rounds, batch, groups, a))) return rc;
+    h->accumulated_ms = 0.f;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3(64), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// ---- bp_edge8_kernel (min-sum, lane = edge, rows in 8-lane groups): rows <= 8, columns 1 .. 4 entries, 8 m <= 64 R slots ----
+struct Edge8Plan {
+    int rounds = 0, dc = 0;  // rounds == 0: not applicable
+    bool uniform = false;
+    void (*kern)(const Edge8Args) = nullptr;
+};
+
+static Edge8Plan plan_edge8(const ldpc_hip_bp *h) {
+    Edge8Plan p;
+    if (h->bp_method != LDPC_HIP_MINIMUM_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0) return p;
+    if (h->max_row_deg > 8 || h->max_col_deg > 4 || h->n > 65535) return p;
+    const int dc = h->max_col_deg <= 3 ? 3 : 4;
+    const int need = (8 * h->m + 63) / 64;
+    static const int r3[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12}, r4[] = {2, 3, 4, 5, 6, 7, 8, 9};
+    int rounds = 0;
+    for (int v : r3) if (dc == 3 && !rounds && v >= need) rounds = v;
+    for (int v : r4) if (dc == 4 && !rounds && v >= need) rounds = v;
+    if (!rounds) return p;
+    std::vector<char> seen((size_t)h->n, 0);  // a column without entries has no lane to write its outputs
+    for (int32_t j : h->h_col_idx) seen[(size_t)j] = 1;
+    for (char c : seen) if (!c) return p;
+    p.uniform = true;
+    for (int j = 1; j < h->n && p.uniform; ++j)
+        p.uniform = std::memcmp(&h->channel_probs[(size_t)j], &h->channel_probs[0], sizeof(double)) == 0;
+#define LDPC_E8(R, C) if (rounds == R && dc == C) p.kern = p.uniform ? bp_edge8_kernel<R, C, true> : bp_edge8_kernel<R, C, false>;
+    LDPC_E8(2, 3) LDPC_E8(3, 3) LDPC_E8(4, 3) LDPC_E8(5, 3) LDPC_E8(6, 3) LDPC_E8(7, 3) LDPC_E8(8, 3) LDPC_E8(9, 3) LDPC_E8(10, 3) LDPC_E8(12, 3)
+    LDPC_E8(2, 4) LDPC_E8(3, 4) LDPC_E8(4, 4) LDPC_E8(5, 4) LDPC_E8(6, 4) LDPC_E8(7, 4) LDPC_E8(8, 4) LDPC_E8(9, 4)
+#undef LDPC_E8
+    p.rounds = rounds;
+    p.dc = dc;
+    return p;
+}
+
+// slot tables of bp_edge8_kernel: entry k of row i sits in slot 8 i + k (see bp_edge_kernel.h)
+static int ensure_edge8_tables(ldpc_hip_bp *h, const Edge8Plan &p) {
+    const int key = 1000 + p.rounds * 8 + p.dc;
+    if (h->edge_rounds == key) return LDPC_HIP_OK;
+    const int slots = p.rounds * 64, dc = p.dc;
+    std::vector<uint16_t> cpos((size_t)dc * slots, (uint16_t)(slots + 1));  // phantom lanes read the slot that holds +inf
+    std::vector<uint8_t> kind((size_t)slots, 0);
+    std::vector<int32_t> scol((size_t)slots, 0);
+    std::vector<std::vector<int>> col_slots((size_t)h->n);
+    for (int i = 0; i < h->m; ++i)
+        for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+            const int s = 8 * i + (e - h->h_row_ptr[(size_t)i]), j = h->h_col_idx[(size_t)e];
+            scol[(size_t)s] = j;
+            kind[(size_t)s] = (uint8_t)(1 + col_slots[(size_t)j].size());  // rows ascend: the column's order (bp.hpp:278)
+            col_slots[(size_t)j].push_back(s);
+        }
+    for (int j = 0; j < h->n; ++j)
+        for (int s : col_slots[(size_t)j])
+            for (int q = 0; q < dc; ++q)
+                cpos[(size_t)q * slots + s] = (uint16_t)(q < (int)col_slots[(size_t)j].size() ? col_slots[(size_t)j][(size_t)q] : slots);  // beyond the column: +0.0
+    int rc;
+    if ((rc = h->e_partner.ensure(cpos.size() * 2)) || (rc = h->e_kind.ensure((size_t)slots)) || (rc = h->e_scol.ensure((size_t)slots * 4)) ||
+        (rc = h->e_prior.ensure((size_t)slots * 8))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the old tables
+    HIPCHK(hipMemcpy(h->e_partner.p, cpos.data(), cpos.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_kind.p, kind.data(), (size_t)slots, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->e_scol.p, scol.data(), (size_t)slots * 4, hipMemcpyHostToDevice));
+    h->edge_rounds = key;
+    return LDPC_HIP_OK;
+}
+
+static int decode_edge8(ldpc_hip_bp *h, const Edge8Plan &p, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                        int32_t *iters, uint8_t *conv) {
+    int rc;
+    if ((rc = ensure_edge8_tables(h, p))) return rc;
+    const int slots = p.rounds * 64;
+    hipLaunchKernelGGL(edge_prior_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, h->stream, h->d_llr0, (const int32_t *)h->e_scol.p,
+                       (const uint8_t *)h->e_kind.p, slots, (double *)h->e_prior.p);
+    Edge8Args a = {};
+    a.m = h->m; a.n = h->n; a.max_iter = h->max_iter;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.prior_s = (const double *)h->e_prior.p; a.cpos = (const uint16_t *)h->e_partner.p;
+    a.prior_u = std::log((1 - h->channel_probs[0]) / h->channel_probs[0]);
+    a.kind = (const uint8_t *)h->e_kind.p; a.scol = (const int32_t *)h->e_scol.p;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    const size_t dyn = edge_lds_bytes(p.rounds);
+    int64_t per_cu = (int64_t)((160u * 1024u) / (dyn + 64));
+    const int64_t by_regs = p.uniform ? 20 : 16;
+    if (per_cu > by_regs) per_cu = by_regs;
+    int64_t groups = batch < 256 * per_cu ? batch : 256 * per_cu;
+    if ((rc = edge_work_split(h, p.rounds, batch, groups, a))) return rc;
     h->accumulated_ms = 0.f;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3(64), (unsigned)dyn, h->stream, a);

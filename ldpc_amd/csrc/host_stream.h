@@ -26,9 +26,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
-        if (h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) {  // min-sum on the surface-code family: lane = edge
+        if ((h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) && batch < (1ll << 30)) {  // min-sum on the surface-code family: lane = edge (32-bit syndrome indices)
             const EdgePlan ep = plan_edge(h);
             if (ep.rounds) return decode_edge(h, ep, synd, batch, decoding, llr, iters, conv);
+            const Edge8Plan e8 = plan_edge8(h);  // heavier nodes (rows <= 8, columns <= 4): rows in 8-lane groups
+            if (e8.rounds) return decode_edge8(h, e8, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {
             const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr, batch);

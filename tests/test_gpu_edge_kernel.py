@@ -189,3 +189,71 @@ def test_debug_switches_live_in_the_handle(monkeypatch):
         assert np.array_equal(_bits(x), _bits(y))
     with pytest.raises(_lib.LdpcHipError, match="unknown switch"):
         eng.set_debug_switch("NO_SUCH_SWITCH", 1)
+
+
+# ---- bp_edge8_kernel: rows of weight <= 8 in eight neighbouring lanes, columns of weight <= 4 --------------------------------
+def _random_wide_member(rng, max_col):
+    """Random matrix with rows of weight 1 .. 8, columns of weight 1 .. max_col, every column present, m small enough for the kernel."""
+    n = int(rng.integers(6, 120))
+    deg = rng.integers(1, max_col + 1, size=n)
+    sockets = np.repeat(np.arange(n), deg)
+    rng.shuffle(sockets)
+    rows, cur = [], []
+    limit = int(rng.integers(1, 9))
+    for j in sockets:
+        if int(j) in cur or len(cur) == limit:
+            if cur:
+                rows.append(cur)
+            cur, limit = [], int(rng.integers(1, 9))
+        cur.append(int(j))
+    if cur:
+        rows.append(cur)
+    h = np.zeros((len(rows), n), np.uint8)
+    for i, r in enumerate(rows):
+        h[i, r] = 1
+    return sp.csr_matrix(h)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_wide_kernel_random_members(seed, oracle_built):
+    rng = np.random.default_rng(900 + seed)
+    max_col = 3 if seed % 2 else 4
+    for _ in range(50):
+        h = _random_wide_member(rng, max_col)
+        if h.shape[0] <= (96 if max_col == 3 else 72) and h.sum(axis=1).max() > 4:
+            break
+    assert h.sum(axis=1).max() <= 8 and 1 <= h.sum(axis=0).min() and h.sum(axis=0).max() <= max_col
+    n = h.shape[1]
+    probs = np.full(n, float(rng.uniform(0.02, 0.2))) if seed % 3 else rng.uniform(0.01, 0.3, size=n)
+    if seed % 4 == 0:
+        probs[rng.integers(n)] = 0.5
+        probs[rng.integers(n)] = 0.7
+    synd = _syndromes(h, 0.1, 131, seed)
+    if seed % 4 == 1:
+        synd[5, rng.integers(h.shape[0])] = 3
+        synd[6, rng.integers(h.shape[0])] = 2
+    _check(h, probs, int(rng.integers(1, 20)), float(rng.choice([0.0, 0.625, 1.0])), synd, oracle_built, want_llr=bool(seed % 5))
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_wide_kernel_bivariate_bicycle(uniform, oracle_built):
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    n = h.shape[1]
+    probs = np.full(n, 0.05) if uniform else np.random.default_rng(3).uniform(0.01, 0.1, size=n)
+    synd = _syndromes(h, 0.05, 777, 5)
+    synd[0] = 0
+    got = _check(h, probs, 50, 0.625, synd, oracle_built)
+    assert got[3].any() and not got[3].all()
+    _check(h, probs, 7, 0.0, synd[:100], oracle_built)
+
+
+def test_wide_kernel_infinite_priors(oracle_built):
+    from ldpc_amd.codes import bivariate_bicycle_hx
+    h = bivariate_bicycle_hx()
+    n = h.shape[1]
+    for where, value in (([0], 0.0), (list(range(0, n, 3)), 1.0), (list(range(n)), 0.0)):
+        probs = np.full(n, 0.1)
+        probs[where] = value
+        with np.errstate(all="ignore"):
+            _check(h, probs, 6, 0.75, _syndromes(h, 0.15, 64, len(where)), oracle_built)

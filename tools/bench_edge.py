@@ -60,6 +60,8 @@ def main():
             ok &= run("surface d=21 small batch", codes.rotated_surface_code_x(21), 0.05, 30, 0.625, batch, reps=9)
         ok &= run("surface d=21 adaptive alpha", codes.rotated_surface_code_x(21), 0.08, 30, 0.0, 65536)
         ok &= run("ring 200", codes.ring_code(200), 0.1, 40, 0.9, 65536)
+        for batch in (512, 8192, 65536, 262144):  # bp_edge8_kernel: rows in 8-lane groups
+            ok &= run("BB144 min-sum 50", codes.bivariate_bicycle_hx(), 0.05, 50, 0.625, batch)
     print("ALL IDENTICAL" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
 
