@@ -385,3 +385,48 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N < 63 ? N : 63) : "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// ---- work distribution of the one-syndrome-per-wavefront kernels ----------------------------------------------------------------
+// A wavefront's syndromes take 3 .. 100 us and the wavefronts do not run at one speed (equal static shares finish 20 % apart on
+// BASELINE config 3: tools/sweep_edge_split.py), so the batch is handed out syndrome by syndrome.  ONE counter word serves ~88
+// atomic visits per microsecond device-wide -- 5 120 resident wavefronts outrun that on every code below d = 21 -- hence
+// WORK_POOLS counters, each in its own 4 KiB of memory (another channel), each owning a contiguous slice of the batch.  A
+// wavefront starts with its static share (if any: no counter), then draws from pool blockIdx mod WORK_POOLS (workgroups go round
+// the 8 XCDs: a pool is served by one XCD) and, when that runs dry, reads all counters in one vector load and moves to the next
+// pool that still has work: the faster XCDs finish the slower ones' slices.
+constexpr int WORK_POOLS = 32;
+constexpr int WORK_POOL_STRIDE = 512;  // 64-bit words between counters
+__host__ __device__ inline size_t work_pool_bytes() { return (size_t)WORK_POOLS * WORK_POOL_STRIDE * 8; }
+__host__ __device__ inline int32_t work_pool_share(int64_t batch, int64_t dyn_base) { return (int32_t)((batch - dyn_base + WORK_POOLS - 1) / WORK_POOLS); }
+
+// The next syndromes [b0, b1) of this wavefront (q: its current pool); false: the batch is done.  Called by a whole wavefront;
+// wave-uniform results.  batch < 2^30.
+__device__ __forceinline__ bool work_pool_next(unsigned long long *next, int dyn_base, int pool_per, int chunk, int batch, int lane, int &q, int &b0, int &b1) {
+    // (the wavefront must be whole when lane 0 pulls: without a convergent operation between a caller's `lane == 0` block and the one
+    // below, the compiler threads the two and the readfirstlane runs with lane 0 masked off -- seen in bp_edge_kernel<1>)
+    __builtin_amdgcn_wave_barrier();
+    for (;;) {
+        unsigned pulled = 0;
+        if (lane == 0) pulled = (unsigned)atomicAdd(next + (size_t)q * WORK_POOL_STRIDE, (unsigned long long)chunk);
+        const int got = __builtin_amdgcn_readfirstlane((int)pulled);
+        const int lo = dyn_base + q * pool_per;
+        const int end = lo + pool_per < batch ? lo + pool_per : batch;
+        if (got < end - lo) {
+            b0 = lo + got;
+            b1 = b0 + chunk < end ? b0 + chunk : end;
+            return true;
+        }
+        // this pool is dry: which ones are not?  (one load per lane; a counter only grows, so a pool seen dry stays dry)
+        bool has = false;
+        if (lane < WORK_POOLS) {
+            const unsigned long long c = __hip_atomic_load(next + (size_t)lane * WORK_POOL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long plo = (long long)dyn_base + (long long)lane * pool_per;
+            const long long pend = plo + pool_per < batch ? plo + pool_per : batch;
+            has = plo + (long long)c < pend;
+        }
+        const uint64_t mask = __ballot(has);
+        if (!mask) return false;
+        const uint64_t at_or_after = mask & (~0ull << q);
+        q = at_or_after ? __builtin_ctzll(at_or_after) : __builtin_ctzll(mask);
+    }
+}

@@ -42,7 +42,7 @@ struct EdgeArgs {
     const uint16_t *partner;   // [R * 64] slot of the other entry of the slot's column; none: R * 64 (the +0.0 slot); a phantom lane:
                                // R * 64 + 1 (a slot that holds +inf for good)
     int32_t chunk;             // syndromes pulled per visit to a work counter
-    int32_t static_per, dyn_base, pool_per;  // edge_next_chunk: static share per wavefront, where the pools start, syndromes per pool (batch < 2^30)
+    int32_t static_per, dyn_base, pool_per;  // work_pool_next: static share per wavefront, where the pools start, syndromes per pool (batch < 2^30)
     const uint8_t *kind;       // [R * 64] 0 phantom, 1 first entry of its column (lower row), 2 second entry
     const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
     const uint8_t *synd;       // [batch][m]
@@ -50,52 +50,10 @@ struct EdgeArgs {
     double *llr;               // [batch][n] or nullptr
     int32_t *iters;            // [batch] or nullptr
     uint8_t *conv;             // [batch] or nullptr
-    unsigned long long *next;  // EDGE_POOLS work counters, EDGE_POOL_STRIDE words apart (zeroed before launch)
+    unsigned long long *next;  // WORK_POOLS work counters, WORK_POOL_STRIDE words apart (work_pool_next, bp_device_common.h) (zeroed before launch)
 };
 
 __host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }  // slots, +0.0, +inf
-
-// ---- work distribution of the lane = edge kernels ------------------------------------------------------------------------------
-// A wavefront's syndromes take 3 .. 100 us and the wavefronts do not run at one speed (equal static shares finish 20 % apart on
-// BASELINE config 3: tools/sweep_edge_split.py), so the batch is handed out syndrome by syndrome.  ONE counter word serves ~88
-// atomic visits per microsecond device-wide -- 5 120 resident wavefronts outrun that on every code below d = 21 -- hence
-// EDGE_POOLS counters, each in its own 4 KiB of memory (another channel), each owning a contiguous slice of the batch.  A
-// wavefront starts with its static share (static_per syndromes, no counter), then draws from pool blockIdx mod EDGE_POOLS
-// (workgroups go round the 8 XCDs: a pool is served by one XCD) and, when that runs dry, reads all counters in one vector load
-// and moves to the next pool that still has work: the faster XCDs finish the slower ones' slices.
-constexpr int EDGE_POOLS = 32;
-constexpr int EDGE_POOL_STRIDE = 512;  // 64-bit words between counters
-__host__ __device__ inline size_t edge_counter_bytes() { return (size_t)EDGE_POOLS * EDGE_POOL_STRIDE * 8; }
-
-// The next syndromes [b0, b1) of this wavefront (q: its current pool); false: the batch is done.  Wave-uniform results.
-template <typename ARGS>
-__device__ __forceinline__ bool edge_next_chunk(const ARGS &a, int lane, int &q, int &b0, int &b1) {
-    const int batch = (int)a.batch;
-    for (;;) {
-        unsigned pulled = 0;
-        if (lane == 0) pulled = (unsigned)atomicAdd(a.next + (size_t)q * EDGE_POOL_STRIDE, (unsigned long long)a.chunk);
-        const int got = __builtin_amdgcn_readfirstlane((int)pulled);
-        const int lo = a.dyn_base + q * a.pool_per;
-        const int end = lo + a.pool_per < batch ? lo + a.pool_per : batch;
-        if (got < end - lo) {
-            b0 = lo + got;
-            b1 = b0 + a.chunk < end ? b0 + a.chunk : end;
-            return true;
-        }
-        // this pool is dry: which ones are not?  (one load per lane; a counter only grows, so a pool seen dry stays dry)
-        bool has = false;
-        if (lane < EDGE_POOLS) {
-            const unsigned long long c = __hip_atomic_load(a.next + (size_t)lane * EDGE_POOL_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long plo = (long long)a.dyn_base + (long long)lane * a.pool_per;
-            const long long pend = plo + a.pool_per < batch ? plo + a.pool_per : batch;
-            has = plo + (long long)c < pend;
-        }
-        const uint64_t mask = __ballot(has);
-        if (!mask) return false;
-        const uint64_t at_or_after = mask & (~0ull << q);
-        q = at_or_after ? __builtin_ctzll(at_or_after) : __builtin_ctzll(mask);
-    }
-}
 
 // How many of the R rounds let the vector unit do what the scalar unit would (both issue one instruction per SIMD turn, and the
 // kernel's scalar work -- lane-mask parities -- outweighs its vector work): measured on BASELINE config 3, tools/bench_edge.py
@@ -179,9 +137,9 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
     const double dbl_max = uniform_f64(DBL_MAX);
     if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
 
-    // Work: the static share, then chunks from the pooled work counters (edge_next_chunk)
+    // Work: the static share, then chunks from the pooled work counters (work_pool_next, bp_device_common.h)
     int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
-    int pool = (int)(blockIdx.x & (EDGE_POOLS - 1));
+    int pool = (int)(blockIdx.x & (WORK_POOLS - 1));
     for (;;) {
       for (int b = b0; b < b1; ++b) {
         // this syndrome's bytes as lane masks: bit 4 q of sy[r] = (byte & 1) of the row that lanes 4 q .. 4 q + 3 serve in round r;
@@ -285,7 +243,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
         // lane 0 masked off -- every other lane's `pulled` is 0, i.e. syndrome 0 for ever (seen with R = 1).
         __builtin_amdgcn_wave_barrier();
       }
-        if (!edge_next_chunk(a, lane, pool, b0, b1)) break;
+        if (!work_pool_next(a.next, a.dyn_base, a.pool_per, a.chunk, (int)a.batch, lane, pool, b0, b1)) break;
     }
 #undef LDPC_EDGE_PRIOR
 }
@@ -378,9 +336,9 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
     const double dbl_max = uniform_f64(DBL_MAX);
     if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
 
-    // Work: the static share, then chunks from the pooled work counters (edge_next_chunk)
+    // Work: the static share, then chunks from the pooled work counters (work_pool_next, bp_device_common.h)
     int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
-    int pool = (int)(blockIdx.x & (EDGE_POOLS - 1));
+    int pool = (int)(blockIdx.x & (WORK_POOLS - 1));
     for (;;) {
       for (int b = b0; b < b1; ++b) {
         uint64_t sy[R];
@@ -468,7 +426,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
         }
         __builtin_amdgcn_wave_barrier();  // (see bp_edge_kernel)
       }
-        if (!edge_next_chunk(a, lane, pool, b0, b1)) break;
+        if (!work_pool_next(a.next, a.dyn_base, a.pool_per, a.chunk, (int)a.batch, lane, pool, b0, b1)) break;
     }
 #undef LDPC_EDGE_PRIOR
 }

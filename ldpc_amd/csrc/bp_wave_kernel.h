@@ -40,7 +40,8 @@ struct WaveArgs {
     double *llr;                 // [batch][n] or nullptr
     int32_t *iters;              // [batch] or nullptr
     uint8_t *conv;               // [batch] or nullptr
-    unsigned long long *next;    // device-wide work counter (zeroed before launch)
+    unsigned long long *next;    // WORK_POOLS work counters (work_pool_next, bp_device_common.h; zeroed before launch)
+    int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;  // bytes
 };
 
@@ -123,17 +124,20 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     for (int q = tl; q < mp; q += TS) sy[q] = 0;
     team_sync();
 
+    int pool = (int)((TEAM ? blockIdx.x : blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
     for (;;) {
         int64_t b;
         if (TEAM) {
-            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
+            if (wave == 0) {
+                int b0 = 0, b1 = 0;
+                const bool more = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1);
+                if (lane == 0) team_b = more ? (long long)b0 : (long long)a.batch;
+            }
             __syncthreads();
             b = team_b;
         } else {
-            unsigned long long pulled = 0;
-            if (lane == 0) pulled = atomicAdd(a.next, 1ull);
-            b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+            int b0 = 0, b1 = 0;
+            b = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1) ? (int64_t)b0 : a.batch;
         }
         if (b >= a.batch) break;
         // initialise_log_domain_bp (bp.hpp:147-157) + this syndrome's bytes; phantom entries get the neutral element
@@ -312,7 +316,8 @@ struct WavePsArgs {
     double *llr;
     int32_t *iters;
     uint8_t *conv;
-    unsigned long long *next;
+    unsigned long long *next;    // WORK_POOLS work counters (work_pool_next; zeroed before launch)
+    int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;
     int32_t min_rdeg;        // lightest row (a row of weight 1 has x = the empty product 1: q = 2 / 0, generic path only)
 };
@@ -396,17 +401,20 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
         prior_tame = __ballot(wild) == 0 && a.min_rdeg >= 2;
     }
 
+    int pool = (int)((TEAM ? blockIdx.x : blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
     for (;;) {
         int64_t b;
         if (TEAM) {
-            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
+            if (wave == 0) {
+                int b0 = 0, b1 = 0;
+                const bool more = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1);
+                if (lane == 0) team_b = more ? (long long)b0 : (long long)a.batch;
+            }
             __syncthreads();
             b = team_b;
         } else {
-            unsigned long long pulled = 0;
-            if (lane == 0) pulled = atomicAdd(a.next, 1ull);
-            b = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) |
-                          (unsigned)__builtin_amdgcn_readfirstlane((int)(pulled & 0xffffffffu)));
+            int b0 = 0, b1 = 0;
+            b = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1) ? (int64_t)b0 : a.batch;
         }
         if (b >= a.batch) break;
         for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];

@@ -262,9 +262,10 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
                           int32_t *iters, uint8_t *conv) {
     int rc;
     if ((rc = ensure_wave_ps_tables(h, p))) return rc;
-    if ((rc = h->counter.ensure(8))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     WavePsArgs a = {};
+    a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
     a.batch = batch;
     a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
@@ -294,9 +295,10 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
                        int32_t *iters, uint8_t *conv) {
     int rc;
     if ((rc = ensure_wave_tables(h, p))) return rc;
-    if ((rc = h->counter.ensure(8))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, 8, h->stream));
+    if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     WaveArgs a = {};
+    a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.mp = p.mp; a.np = p.np; a.max_iter = h->max_iter;
     a.ms_scaling_factor = h->ms_scaling_factor;
     a.batch = batch;
@@ -386,20 +388,20 @@ static int ensure_edge_tables(ldpc_hip_bp *h, const EdgePlan &p) {
     return LDPC_HIP_OK;
 }
 
-// How the lane = edge kernels share a batch among their wavefronts (edge_next_chunk, bp_edge_kernel.h): one syndrome each to
-// start with, the rest in EDGE_POOLS slices behind a work counter each.  Syndromes per visit: 1, except for the smallest codes
+// How the lane = edge kernels share a batch among their wavefronts (work_pool_next, bp_device_common.h): one syndrome each to
+// start with, the rest in WORK_POOLS slices behind a work counter each.  Syndromes per visit: 1, except for the smallest codes
 // (one round: a syndrome takes a few microseconds) on large batches.  EDGE_STATIC_PCT / EDGE_CHUNK: measurement overrides.
 template <typename ARGS>
 static int edge_work_split(ldpc_hip_bp *h, int rounds, int64_t batch, int64_t groups, ARGS &a) {
     int rc;
-    if ((rc = h->counter.ensure(edge_counter_bytes()))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, edge_counter_bytes(), h->stream));
+    if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     a.next = (unsigned long long *)h->counter.p;
     int64_t static_per = 1;
     if (h->sw("EDGE_STATIC_PCT") >= 0) static_per = (batch * (h->sw("EDGE_STATIC_PCT") > 100 ? 100 : h->sw("EDGE_STATIC_PCT")) / 100) / groups;
     a.static_per = (int32_t)static_per;
     a.dyn_base = (int32_t)(static_per * groups);
-    a.pool_per = (int32_t)((batch - a.dyn_base + EDGE_POOLS - 1) / EDGE_POOLS);
+    a.pool_per = work_pool_share(batch, a.dyn_base);
     int64_t c = rounds >= 2 ? 1 : batch / (groups * 16);
     if (h->sw("EDGE_CHUNK") > 0) c = h->sw("EDGE_CHUNK");
     a.chunk = (int32_t)(c < 1 ? 1 : c > 8 ? 8 : c);

@@ -18,7 +18,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
     if (h->schedule == 0 || h->schedule == 2) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
-    if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22)) {
+    if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22) && batch < (1ll << 30)) {  // (32-bit syndrome indices in the work pools)
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
@@ -26,7 +26,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
-        if ((h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) && batch < (1ll << 30)) {  // min-sum on the surface-code family: lane = edge (32-bit syndrome indices)
+        if (h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) {  // min-sum on the surface-code family: lane = edge
             const EdgePlan ep = plan_edge(h);
             if (ep.rounds) return decode_edge(h, ep, synd, batch, decoding, llr, iters, conv);
             const Edge8Plan e8 = plan_edge8(h);  // heavier nodes (rows <= 8, columns <= 4): rows in 8-lane groups
