@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <cstddef>
 
 #include "../../include/ldpc_hip.h"
 #include "bp_math.h"
@@ -386,6 +387,35 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N < 63 ? N : 63) : "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// ---- kernel arguments read on demand ---------------------------------------------------------------------------------------------
+// A kernel whose inner loop fills the scalar register file (bp_edge_kernel: 56 lane masks) cannot also keep a dozen pointers it
+// needs once per syndrome: the compiler loads every argument at entry, parks the block in VGPR lanes and fetches it back
+// (v_readlane, a vector instruction each) wherever a field is used -- 16 per output round.  Such "cold" fields are instead read
+// from the kernel-argument segment with a scalar load at the point of use: LDPC_KERNARG(ARGS, field) -- no vector instruction,
+// nothing live across the loop.  (A field read this way must not ALSO be read as a.field, or the entry load comes back.)
+template <typename T, int OFF>
+__device__ __forceinline__ T kernarg_load() {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two dwords");
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long v;
+        asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(kp), "n"(OFF) : "memory");
+        T out;
+        __builtin_memcpy(&out, &v, 8);
+        return out;
+    } else {
+        unsigned v;
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(kp), "n"(OFF) : "memory");
+        T out;
+        __builtin_memcpy(&out, &v, 4);
+        return out;
+    }
+}
+#define LDPC_KERNARG(ARGS, field) kernarg_load<decltype(ARGS::field), (int)offsetof(ARGS, field)>()
+// (a pointer fetched this way is a plain number to the compiler: say that it points to global memory, or every access becomes a flat_ one)
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *global_ptr(T *p) { return (__attribute__((address_space(1))) T *)p; }
+
 // ---- work distribution of the one-syndrome-per-wavefront kernels ----------------------------------------------------------------
 // A wavefront's syndromes take 3 .. 100 us and the wavefronts do not run at one speed (equal static shares finish 20 % apart on
 // BASELINE config 3: tools/sweep_edge_split.py), so the batch is handed out syndrome by syndrome.  ONE counter word serves ~88
@@ -401,13 +431,14 @@ __host__ __device__ inline int32_t work_pool_share(int64_t batch, int64_t dyn_ba
 
 // The next syndromes [b0, b1) of this wavefront (q: its current pool); false: the batch is done.  Called by a whole wavefront;
 // wave-uniform results.  batch < 2^30.
-__device__ __forceinline__ bool work_pool_next(unsigned long long *next, int dyn_base, int pool_per, int chunk, int batch, int lane, int &q, int &b0, int &b1) {
+__device__ __forceinline__ bool work_pool_next(unsigned long long *next_generic, int dyn_base, int pool_per, int chunk, int batch, int lane, int &q, int &b0, int &b1) {
     // (the wavefront must be whole when lane 0 pulls: without a convergent operation between a caller's `lane == 0` block and the one
     // below, the compiler threads the two and the readfirstlane runs with lane 0 masked off -- seen in bp_edge_kernel<1>)
     __builtin_amdgcn_wave_barrier();
+    const auto next = global_ptr(next_generic);
     for (;;) {
         unsigned pulled = 0;
-        if (lane == 0) pulled = (unsigned)atomicAdd(next + (size_t)q * WORK_POOL_STRIDE, (unsigned long long)chunk);
+        if (lane == 0) pulled = (unsigned)__hip_atomic_fetch_add(next + (size_t)q * WORK_POOL_STRIDE, (unsigned long long)chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int got = __builtin_amdgcn_readfirstlane((int)pulled);
         const int lo = dyn_base + q * pool_per;
         const int end = lo + pool_per < batch ? lo + pool_per : batch;

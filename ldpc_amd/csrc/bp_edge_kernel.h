@@ -53,7 +53,7 @@ struct EdgeArgs {
     unsigned long long *next;  // WORK_POOLS work counters, WORK_POOL_STRIDE words apart (work_pool_next, bp_device_common.h) (zeroed before launch)
 };
 
-__host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 2) * 8; }  // slots, +0.0, +inf
+__host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 3) * 8; }  // slots, +0.0, +inf, a dummy (bp_edge8_kernel's phantom lanes park their output there)
 
 // How many of the R rounds let the vector unit do what the scalar unit would (both issue one instruction per SIMD turn, and the
 // kernel's scalar work -- lane-mask parities -- outweighs its vector work): measured on BASELINE config 3, tools/bench_edge.py
@@ -113,6 +113,7 @@ __device__ __forceinline__ uint64_t spread_nibble(uint64_t low) {  // bit 0 of e
 template <int R, bool UNIFORM>
 __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const EdgeArgs a) {
     using namespace edge_detail;
+    typedef EdgeArgs ARGS_T;  // (cold fields: LDPC_KERNARG, bp_device_common.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char edge_lds[];
     typedef __attribute__((address_space(3))) double lds_f64;
     lds_f64 *X = (lds_f64 *)edge_lds;  // [R * 64] check_to_bit of every slot, [R * 64] = +0.0 for good
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
     if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
 
     // Work: the static share, then chunks from the pooled work counters (work_pool_next, bp_device_common.h)
-    int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
+    int b0 = (int)blockIdx.x * LDPC_KERNARG(ARGS_T, static_per), b1 = b0 + LDPC_KERNARG(ARGS_T, static_per);
     int pool = (int)(blockIdx.x & (WORK_POOLS - 1));
     for (;;) {
       for (int b = b0; b < b1; ++b) {
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
         // a byte above 1 can never be matched (bp.hpp:300)
         uint64_t sy[R];
         bool never = false;
-        const uint8_t *sb = a.synd + (int64_t)b * m;
+        const auto sb = global_ptr(LDPC_KERNARG(ARGS_T, synd)) + (int64_t)b * m;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = r * 16 + (lane >> 2);
@@ -223,27 +224,42 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
             unsat = never || (bad & LOW) != 0;
         } while (unsat && it < a.max_iter);
 
-        // ---- outputs (bp.hpp:62,65,69,71): by the lanes that own the first entry of a column, from the last iteration's messages ----
+        // ---- outputs (bp.hpp:62,65,69,71): the log-ratios, formed from the last iteration's messages by the lanes that own the first entry
+        //      of a column, change places with the messages (X[j] = log-ratio of column j; n <= R * 64: every column has an entry, and
+        //      the next syndrome's first check pass rewrites every slot), then leave in whole 512- / 64-byte rows ----
+#pragma unroll
+        for (int r = 0; r < R; ++r) msg[r] = (LDPC_EDGE_PRIOR(r) + X[r * 64 + lane]) + X[paddr[r]];
+        const auto scol_t = global_ptr(LDPC_KERNARG(ARGS_T, scol));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int s = r * 64 + lane;
-            if (a.kind[s] == 1) {
-                const double l0 = (LDPC_EDGE_PRIOR(r) + X[s]) + X[paddr[r]];
-                const int j = a.scol[s];
-                a.decoding[(int64_t)b * n + j] = l0 <= 0.0 ? 1 : 0;
-                if (a.llr) a.llr[(int64_t)b * n + j] = l0;
+            const int j = scol_t[r * 64 + lane];
+            if ((k0[r] >> lane) & 1ull) X[j] = msg[r];
+        }
+        {
+            const auto dp = global_ptr(LDPC_KERNARG(ARGS_T, decoding)) + (int64_t)b * n;
+            auto lp = global_ptr(LDPC_KERNARG(ARGS_T, llr));
+            if (lp) lp += (int64_t)b * n;
+            for (int j = lane; j < n; j += 64) {
+                const double l0 = X[j];
+                dp[j] = l0 <= 0.0 ? 1 : 0;
+                if (lp) lp[j] = l0;
             }
         }
-        if (lane == 0) {
-            if (a.iters) a.iters[b] = it;
-            if (a.conv) a.conv[b] = unsat ? 0 : 1;
+        {
+            const auto ip = global_ptr(LDPC_KERNARG(ARGS_T, iters));
+            const auto cp = global_ptr(LDPC_KERNARG(ARGS_T, conv));
+            if (lane == 0) {
+                if (ip) ip[b] = it;
+                if (cp) cp[b] = unsat ? 0 : 1;
+            }
         }
         // The wavefront must be whole again before lane 0 pulls the next syndrome: without this (convergent) barrier the
         // compiler threads this `lane == 0` block into the one at the top of the loop and the readfirstlane there runs with
         // lane 0 masked off -- every other lane's `pulled` is 0, i.e. syndrome 0 for ever (seen with R = 1).
         __builtin_amdgcn_wave_barrier();
       }
-        if (!work_pool_next(a.next, a.dyn_base, a.pool_per, a.chunk, (int)a.batch, lane, pool, b0, b1)) break;
+        if (!work_pool_next(LDPC_KERNARG(ARGS_T, next), LDPC_KERNARG(ARGS_T, dyn_base), LDPC_KERNARG(ARGS_T, pool_per), LDPC_KERNARG(ARGS_T, chunk),
+                            (int)LDPC_KERNARG(ARGS_T, batch), lane, pool, b0, b1)) break;
     }
 #undef LDPC_EDGE_PRIOR
 }
@@ -269,7 +285,7 @@ struct Edge8Args {
     const uint16_t *cpos;      // [DC][R * 64] slot of the j-th entry of the slot's column, j < DC; beyond the column's weight: R * 64 (the +0.0
                                // slot); a phantom lane: R * 64 + 1 everywhere (a slot that holds +inf for good)
     const uint8_t *kind;       // [R * 64] 0 phantom, 1 + k for the k-th entry of its column
-    const int32_t *scol;       // [R * 64] column of the slot (outputs are written by the kind-1 lanes)
+    const int32_t *scol;       // [R * 64] column of the slot; a phantom lane: R * 64 + 2 (the dummy slot)
     int32_t chunk;
     int32_t static_per, dyn_base, pool_per;  // (as EdgeArgs)
     const uint8_t *synd;
@@ -307,6 +323,7 @@ __device__ __forceinline__ double select_f64(double a, double b, uint64_t mask) 
 template <int R, int DC, bool UNIFORM>
 __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edge8Args a) {
     using namespace edge_detail;
+    typedef Edge8Args ARGS_T;  // (cold fields: LDPC_KERNARG, bp_device_common.h)
     static_assert(DC >= 2 && DC <= 4, "columns of 2 .. 4 entries");
     extern __shared__ __attribute__((aligned(16))) unsigned char edge_lds[];
     typedef __attribute__((address_space(3))) double lds_f64;
@@ -337,13 +354,13 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
     if (lane == 0) { X[ZERO] = 0.0; X[ZERO + 1] = __builtin_inf(); }
 
     // Work: the static share, then chunks from the pooled work counters (work_pool_next, bp_device_common.h)
-    int b0 = (int)blockIdx.x * a.static_per, b1 = b0 + a.static_per;
+    int b0 = (int)blockIdx.x * LDPC_KERNARG(ARGS_T, static_per), b1 = b0 + LDPC_KERNARG(ARGS_T, static_per);
     int pool = (int)(blockIdx.x & (WORK_POOLS - 1));
     for (;;) {
       for (int b = b0; b < b1; ++b) {
         uint64_t sy[R];
         bool never = false;
-        const uint8_t *sb = a.synd + (int64_t)b * m;
+        const auto sb = global_ptr(LDPC_KERNARG(ARGS_T, synd)) + (int64_t)b * m;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = r * 8 + (lane >> 3);
@@ -407,26 +424,40 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
             unsat = never || (bad & LOW) != 0;
         } while (unsat && it < a.max_iter);
 
-        // ---- outputs: by the lanes that own the first entry of a column ----
+        // ---- outputs: as bp_edge_kernel -- every lane of a column holds the column's log-ratio (the same bits) and parks it at X[column]
+        //      (phantom lanes: at the dummy slot behind +inf), then whole rows leave ----
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int s = r * 64 + lane;
-            if (a.kind[s] == 1) {
-                double t = LDPC_EDGE_PRIOR(r);
+            double t = LDPC_EDGE_PRIOR(r);
 #pragma unroll
-                for (int j = 0; j < DC; ++j) t += X[caddr[r][j]];
-                const int j = a.scol[s];
-                a.decoding[(int64_t)b * n + j] = t <= 0.0 ? 1 : 0;
-                if (a.llr) a.llr[(int64_t)b * n + j] = t;
+            for (int j = 0; j < DC; ++j) t += X[caddr[r][j]];
+            msg[r] = t;
+        }
+        const auto scol_t = global_ptr(LDPC_KERNARG(ARGS_T, scol));
+#pragma unroll
+        for (int r = 0; r < R; ++r) X[scol_t[r * 64 + lane]] = msg[r];
+        {
+            const auto dp = global_ptr(LDPC_KERNARG(ARGS_T, decoding)) + (int64_t)b * n;
+            auto lp = global_ptr(LDPC_KERNARG(ARGS_T, llr));
+            if (lp) lp += (int64_t)b * n;
+            for (int j = lane; j < n; j += 64) {
+                const double t = X[j];
+                dp[j] = t <= 0.0 ? 1 : 0;
+                if (lp) lp[j] = t;
             }
         }
-        if (lane == 0) {
-            if (a.iters) a.iters[b] = it;
-            if (a.conv) a.conv[b] = unsat ? 0 : 1;
+        {
+            const auto ip = global_ptr(LDPC_KERNARG(ARGS_T, iters));
+            const auto cp = global_ptr(LDPC_KERNARG(ARGS_T, conv));
+            if (lane == 0) {
+                if (ip) ip[b] = it;
+                if (cp) cp[b] = unsat ? 0 : 1;
+            }
         }
         __builtin_amdgcn_wave_barrier();  // (see bp_edge_kernel)
       }
-        if (!work_pool_next(a.next, a.dyn_base, a.pool_per, a.chunk, (int)a.batch, lane, pool, b0, b1)) break;
+        if (!work_pool_next(LDPC_KERNARG(ARGS_T, next), LDPC_KERNARG(ARGS_T, dyn_base), LDPC_KERNARG(ARGS_T, pool_per), LDPC_KERNARG(ARGS_T, chunk),
+                            (int)LDPC_KERNARG(ARGS_T, batch), lane, pool, b0, b1)) break;
     }
 #undef LDPC_EDGE_PRIOR
 }

@@ -124,15 +124,11 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     for (int q = tl; q < mp; q += TS) sy[q] = 0;
     team_sync();
 
-    int pool = (int)((TEAM ? blockIdx.x : blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
+    int pool = (int)((blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
     for (;;) {
         int64_t b;
-        if (TEAM) {
-            if (wave == 0) {
-                int b0 = 0, b1 = 0;
-                const bool more = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1);
-                if (lane == 0) team_b = more ? (long long)b0 : (long long)a.batch;
-            }
+        if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
+            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
             __syncthreads();
             b = team_b;
         } else {
@@ -401,15 +397,11 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
         prior_tame = __ballot(wild) == 0 && a.min_rdeg >= 2;
     }
 
-    int pool = (int)((TEAM ? blockIdx.x : blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
+    int pool = (int)((blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
     for (;;) {
         int64_t b;
-        if (TEAM) {
-            if (wave == 0) {
-                int b0 = 0, b1 = 0;
-                const bool more = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1);
-                if (lane == 0) team_b = more ? (long long)b0 : (long long)a.batch;
-            }
+        if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
+            if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
             __syncthreads();
             b = team_b;
         } else {

@@ -480,7 +480,7 @@ static int ensure_edge8_tables(ldpc_hip_bp *h, const Edge8Plan &p) {
     const int slots = p.rounds * 64, dc = p.dc;
     std::vector<uint16_t> cpos((size_t)dc * slots, (uint16_t)(slots + 1));  // phantom lanes read the slot that holds +inf
     std::vector<uint8_t> kind((size_t)slots, 0);
-    std::vector<int32_t> scol((size_t)slots, 0);
+    std::vector<int32_t> scol((size_t)slots, slots + 2);  // phantom lanes: the dummy slot
     std::vector<std::vector<int>> col_slots((size_t)h->n);
     for (int i = 0; i < h->m; ++i)
         for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
