@@ -33,7 +33,7 @@ struct SerialArgs {
     int32_t n_levels;
     // random serial schedule (bp.hpp:467-468): iteration it walks orders[min(it, n_orders) - 1][0 .. n) instead of `order`
     const int32_t *orders;
-    int32_t n_orders;
+    int32_t n_orders, orders_first;  // (the table is a ring: its first row sits at orders_first)
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64) bp_serial_kernel(const SerialArgs a) {
     for (int it = 1; it <= a.max_iter; ++it) {
         const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
         const bool lane_live = !((done >> lane) & 1ull);
-        const int32_t *order = a.orders ? a.orders + (size_t)((it < a.n_orders ? it : a.n_orders) - 1) * (size_t)n : a.order;
+        const int32_t *order = a.orders ? a.orders + (size_t)(((it < a.n_orders ? it : a.n_orders) - 1 + a.orders_first) % a.n_orders) * (size_t)n : a.order;
         for (int t = 0; t < n; ++t) {
             const int bit = order ? sload(order + t) : t;
             serial_update_bit<METHOD, MATH, DCS, DRS>(a, bit, At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab, want_llr, lane_live);
@@ -287,7 +287,7 @@ struct SoftArgs {
     int64_t batch;
     const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
     const int32_t *orders;  // random serial schedule (bp.hpp:573-577): [n_orders][n], iteration it walks orders[min(it, n_orders) - 1]; else nullptr
-    int32_t n_orders;
+    int32_t n_orders, orders_first;  // (a ring: its first row sits at orders_first)
     const double *llr0;
     double *A;        // [tiles][nnz][64] bit->check messages
     double *C;        // [tiles][nnz][64] check->bit messages of the bit being updated
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(64) bp_softinfo_kernel(const SoftArgs a) {
 
     for (int it = 1; it <= a.max_iter; ++it) {
         const bool lane_live = !((done >> lane) & 1ull);  // a converged shot keeps its outputs (bp.hpp:570-572)
-        const int32_t *order = a.orders ? a.orders + (size_t)((it < a.n_orders ? it : a.n_orders) - 1) * (size_t)n : a.order;
+        const int32_t *order = a.orders ? a.orders + (size_t)(((it < a.n_orders ? it : a.n_orders) - 1 + a.orders_first) % a.n_orders) * (size_t)n : a.order;
         for (int t = 0; t < n; ++t) {
             const int bit = order ? sload(order + t) : t;
             if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, bit, At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);

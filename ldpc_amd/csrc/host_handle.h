@@ -103,6 +103,17 @@ struct ldpc_hip_bp {
     int32_t sched_seed_raw = 0;  // random_schedule_seed as given (the soft-syndrome routine seeds its own engine with it)
     bool random_serial = false;
     DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
+    // The random schedule's table of per-iteration orders (host_serial.h: random_orders_*), kept on the device between calls as a
+    // ring of max_iter rows: a call consumes as many rows as its LAST row ran iterations, and only those are generated anew.
+    struct RandomOrders {
+        bool valid = false;
+        int kind = 0, rows = 0, n = 0, first = 0;   // kind 0: one std::mt19937 stream (bp.hpp:467-469); 1: a new default_random_engine(seed) per shuffle (bp.hpp:573-577)
+        int32_t seed_raw = 0;
+        std::mt19937 rng_end;                       // generator behind the table's last row (kind 0)
+        std::vector<int> row_end;                   // the table's last row
+        std::vector<int32_t> expect_state;          // what the handle's order / generator must be for the table to be current
+        std::mt19937 expect_rng;
+    } rnd;
     int32_t *d_csc_row = nullptr, *d_order = nullptr;
     bool custom_order = false;
     DeviceBuf counter;

@@ -55,7 +55,7 @@ static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
 }
 
 static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0) {
+                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0, int orders_first = 0) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
@@ -141,7 +141,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         }
         HIPCHK(hipEventRecord(h->ev0, st));
         a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
-        a.orders = orders; a.n_orders = n_orders;
+        a.orders = orders; a.n_orders = n_orders; a.orders_first = orders_first;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
@@ -174,34 +174,94 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
 // object per syndrome when the state is the initial one -- and the call leaves the state its LAST row produced.  A batch
 // of one row is therefore exactly one BpDecoder::decode, and a sequence of one-row calls is exactly a sequence of decodes
 // on one reference object.  Both wait for the device at the end (the state comes back to the host).
+// ---- the random schedule's table of per-iteration orders ---------------------------------------------------------------------
+// Iteration it of EVERY row of a call walks the handle's order after it rearrangements (std::shuffle on the object's generator,
+// rng.hpp:128-130; the soft-syndrome routine applies one fixed rearrangement again and again, bp.hpp:573-577), and the call leaves
+// the order and generator of its LAST row.  The table [max_iter][n] lives on the device as a ring: the next call's table is this
+// one minus the rows the last row consumed plus as many new ones behind its end, so a call costs as many shuffles as iterations
+// actually ran (as in the reference) instead of max_iter of them -- at the reference's default max_iter = n that was n^2 draws and
+// a 4 n^2-byte upload per decode.  Any change of the order, generator, seed, max_iter or n from outside rebuilds it.
+static void random_orders_shuffle(ldpc_hip_bp *h, int kind, std::vector<int> &v, std::mt19937 &g) {
+    if (kind == 0) std::shuffle(v.begin(), v.end(), g);
+    else std::shuffle(v.begin(), v.end(), std::default_random_engine(h->sched_seed_raw));
+}
+
+// rows [pos, pos + count) of the ring <- `count` further rearrangements of r.row_end (host staging in blocks)
+static int random_orders_append(ldpc_hip_bp *h, int pos, int count) {
+    auto &r = h->rnd;
+    const size_t n = (size_t)r.n;
+    const int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)1 << 22) / (n ? n : 1)));
+    std::vector<int32_t> stage((size_t)block * n);
+    for (int done = 0; done < count;) {
+        const int now = std::min(block, count - done);
+        for (int q = 0; q < now; ++q) {
+            random_orders_shuffle(h, r.kind, r.row_end, r.rng_end);
+            std::copy(r.row_end.begin(), r.row_end.end(), stage.begin() + (size_t)q * n);
+        }
+        for (int q = 0; q < now;) {  // (the ring may wrap inside a block)
+            const int at = (pos + done + q) % r.rows;
+            const int run = std::min(now - q, r.rows - at);
+            HIPCHK(hipMemcpy((int32_t *)h->sched_orders.p + (size_t)at * n, stage.data() + (size_t)q * n, (size_t)run * n * sizeof(int32_t), hipMemcpyHostToDevice));
+            q += run;
+        }
+        done += now;
+    }
+    return LDPC_HIP_OK;
+}
+
+// the table of this call, current on the device (h->stream is idle afterwards)
+static int random_orders_prepare(ldpc_hip_bp *h, int kind) {
+    auto &r = h->rnd;
+    const int n = h->n, rows = h->max_iter;
+    if ((size_t)rows * (size_t)(n ? n : 1) > ((size_t)1 << 28))
+        return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", rows, n);
+    int rc;
+    if ((rc = h->sched_orders.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
+    HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the table
+    const bool current = r.valid && r.kind == kind && r.rows == rows && r.n == n && r.expect_state == h->sched_state &&
+                         (kind == 0 ? r.expect_rng == h->sched_rng : r.seed_raw == h->sched_seed_raw);
+    if (current || rows == 0 || n == 0) return LDPC_HIP_OK;
+    r.valid = false;
+    r.kind = kind; r.rows = rows; r.n = n; r.first = 0; r.seed_raw = h->sched_seed_raw;
+    r.row_end.assign(h->sched_state.begin(), h->sched_state.end());
+    r.rng_end = h->sched_rng;
+    if ((rc = random_orders_append(h, 0, rows))) return rc;
+    r.expect_state = h->sched_state;
+    r.expect_rng = h->sched_rng;
+    r.valid = true;
+    return LDPC_HIP_OK;
+}
+
+// after the call: its last row ran `last` iterations -- the handle's order and generator move on by as many rearrangements, the
+// ring drops those rows and grows as many behind its end
+static int random_orders_consume(ldpc_hip_bp *h, int kind, int last) {
+    auto &r = h->rnd;
+    if (last > h->max_iter) last = h->max_iter;
+    if (last <= 0 || h->n == 0) return LDPC_HIP_OK;
+    std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
+    for (int it = 0; it < last; ++it) random_orders_shuffle(h, kind, v, h->sched_rng);
+    std::copy(v.begin(), v.end(), h->sched_state.begin());
+    if (!r.valid) return LDPC_HIP_OK;
+    r.valid = false;
+    int rc;
+    if ((rc = random_orders_append(h, r.first, last))) return rc;
+    r.first = (r.first + last) % r.rows;
+    r.expect_state = h->sched_state;
+    r.expect_rng = h->sched_rng;
+    r.valid = true;
+    return LDPC_HIP_OK;
+}
+
 static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                                 int32_t *iters, uint8_t *conv) {
-    const int n = h->n, max_iter = h->max_iter;
-    // the arrangements of iterations 1 .. max_iter: std::shuffle on the object's std::mt19937, as RandomListShuffle does (rng.hpp:128-130)
-    if ((size_t)max_iter * (size_t)(n ? n : 1) > ((size_t)1 << 28))
-        return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", max_iter, n);
-    std::vector<int32_t> orders((size_t)max_iter * (size_t)(n ? n : 1));
-    {
-        std::mt19937 g = h->sched_rng;
-        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
-        for (int it = 0; it < max_iter; ++it) {
-            std::shuffle(v.begin(), v.end(), g);
-            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)n);
-        }
-    }
     int rc;
-    if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
+    if ((rc = random_orders_prepare(h, 0))) return rc;
     if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if ((rc = decode_serial_pass(h, max_iter, synd, batch, decoding, llr, iters, conv, (const int32_t *)h->sched_orders.p, max_iter))) return rc;
+    if ((rc = decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv, (const int32_t *)h->sched_orders.p, h->max_iter, h->rnd.first))) return rc;
     int32_t last = 0;
     HIPCHK(hipMemcpyAsync(&last, iters + (batch - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
-    for (int it = 0; it < last; ++it) std::shuffle(v.begin(), v.end(), h->sched_rng);  // the last row consumed `last` shuffles
-    std::copy(v.begin(), v.end(), h->sched_state.begin());
-    return LDPC_HIP_OK;
+    return random_orders_consume(h, 0, last);  // the last row consumed `last` shuffles
 }
 
 static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
@@ -384,23 +444,12 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     // rearrangement applied again and again.  Every row of the batch starts from the handle's order; the call leaves the order
     // of its last row (its iteration count many rearrangements on).
     const bool shuffled = h->random_serial && h->n > 0;
-    std::vector<int32_t> orders;
     int32_t *d_iters_last = nullptr;
     if (shuffled) {
         level_waves = 0;  // the levels belong to one fixed order
-        if ((size_t)h->max_iter * (size_t)h->n > ((size_t)1 << 28))
-            return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", h->max_iter, h->n);
-        orders.resize((size_t)h->max_iter * (size_t)h->n);
-        std::vector<int> v(h->sched_state.begin(), h->sched_state.end());
-        for (int it = 0; it < h->max_iter; ++it) {
-            std::shuffle(v.begin(), v.end(), std::default_random_engine(h->sched_seed_raw));
-            std::copy(v.begin(), v.end(), orders.begin() + (size_t)it * (size_t)h->n);
-        }
-        if ((rc = h->sched_orders.ensure(orders.size() * sizeof(int32_t) + 16))) return rc;
+        if ((rc = random_orders_prepare(h, 1))) return rc;  // (random_orders_*, above)
         if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
         d_iters_last = iters + (batch - 1);
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (!orders.empty()) HIPCHK(hipMemcpy(h->sched_orders.p, orders.data(), orders.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     void (*soft_kern)(const SoftArgs);
     if (h->max_row_deg <= 4 && h->max_col_deg <= 2) soft_kern = level_waves ? bp_softinfo_level_kernel<2, 4> : bp_softinfo_kernel<2, 4>;
@@ -431,7 +480,7 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
         a.batch = nb;
         a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
         a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
-        if (shuffled && h->max_iter > 0) { a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; }
+        if (shuffled && h->max_iter > 0) { a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; a.orders_first = h->rnd.first; }
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.S = (double *)h->soft_S.p;
         a.syn = (const uint64_t *)h->par.p;
@@ -472,8 +521,7 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
         int32_t last = 0;
         HIPCHK(hipMemcpyAsync(&last, d_iters_last, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (last > h->max_iter) last = h->max_iter;
-        if (last > 0) std::copy(orders.begin() + (size_t)(last - 1) * (size_t)h->n, orders.begin() + (size_t)last * (size_t)h->n, h->sched_state.begin());
+        if ((rc = random_orders_consume(h, 1, last))) return rc;
     }
     return LDPC_HIP_OK;
 }
