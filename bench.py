@@ -234,12 +234,16 @@ def secondary_configs(dev, steps):
                 fs = iters_total * c3["salu_insts_per_syndrome_iteration"] / slots
                 bounds = {"valu_issue": fv, "salu_issue": fs, "lds_array_busy": c3.get("lds_array_busy_frac_measured")}
                 which = "valu_issue" if fv >= fs else "salu_issue"
-                entry.update({"bound": which, "frac": bounds[which], "bounds": bounds, "kernel": c3.get("kernel"), "clock_ghz": c3.get("clock_ghz"),
+                # the chip does not hold one clock (2.08 - 2.3 GHz seen on this kernel): a run faster than the profile's clock allows shows
+                # as a fraction above 1 -- then the true fraction lies between the value at the 2.4 GHz maximum and 1
+                at_max = bounds[which] * clock / (MAX_CLOCK_GHZ * 1e9)
+                entry.update({"bound": which, "frac": min(bounds[which], 1.0), "frac_at_max_clock": at_max, "frac_measured_in_profile": c3.get(which + "_frac_measured"), "bounds": bounds, "kernel": c3.get("kernel"), "clock_ghz": c3.get("clock_ghz"),
                               "valu_insts_per_syndrome_iteration": c3["valu_insts_per_syndrome_iteration"],
                               "salu_insts_per_syndrome_iteration": c3["salu_insts_per_syndrome_iteration"],
                               "lds_bank_conflict_share": c3.get("lds_bank_conflict_share"),
-                              "bound_note": "issue turns used / turns on offer (1024 SIMDs x measured clock x kernel time / 4 cycles); instruction counts and clock "
-                                            "from profiles/secondary_c3.json (tools/profile_c3.sh), time from this run; LDS array busy and conflict share from the same profile"})
+                              "bound_note": "issue turns used / turns on offer (1024 SIMDs x the profile's clock x this run's kernel time / 4 cycles), capped at 1; "
+                                            "frac_at_max_clock = the same at 2.4 GHz (a lower bound), frac_measured_in_profile = counters and time of ONE run; instruction counts "
+                                            "and clock from profiles/secondary_c3.json (tools/profile_c3.sh); LDS array busy and conflict share from the same profile"})
             else:
                 entry.update({"bound": "valu_issue", "frac": None, "bound_note": "profiles/secondary_c3.json absent or for another batch"})
         else:
