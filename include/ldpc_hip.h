@@ -327,11 +327,13 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * wavefronts of a workgroup (its "team" form); 4 = as 3, one wavefront per syndrome, 5 = as 3, a workgroup per syndrome.
  * Min-sum on matrices with rows of weight <= 4 and columns of weight 1 .. 2 (rotated / toric surface codes, ring codes; m <= 256)
  * takes a third variant in modes -1, 1 and 6: lane = EDGE, a row's entries in four neighbouring lanes, every message in a
- * register for the whole decode (bp_edge_kernel.h); 6 = that variant where it applies, else as -1.
- * Results are identical. */
+ * register for the whole decode (bp_edge_kernel.h: bp_edge_kernel); with rows of weight <= 8 and columns of weight <= 4
+ * (8 m <= 768: the bivariate-bicycle family) the same idea with a row in EIGHT neighbouring lanes (bp_edge8_kernel).
+ * 6 = those variants where they apply, else as -1.  The on-chip kernels take batches below 2^30 syndromes (larger ones
+ * are streamed).  Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Measurement / test switches: kernel-shape choices that never change a result (profiles/README.md lists them: "PS_TEAM",
- * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", ...).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
+ * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", ...).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
  * created; afterwards only this call changes a switch (value < 0: back to "not set").  Unknown names are an error. */
 int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value);
 
