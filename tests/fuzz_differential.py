@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Extended differential run (run by hand; not collected by pytest): random regular codes of 96 .. 1300 bits, random priors /
 methods / iteration limits / batch sizes, through every form of the on-chip BP kernels (one wavefront or a workgroup per syndrome,
-lane = node or lane = entry) and through the workgroup OSD kernel (blocked, one pivot per step, one staged plane), against the CPU
-checker bit for bit.      python tests/fuzz_differential.py <seconds> <seed>
-End of round 2: 3 242 cases over two seeds, no mismatch (gpurun, 7 minutes)."""
+lane = node, lane = entry or lane = edge) and through the workgroup OSD kernel (blocked, one pivot per step, one staged plane; rows
+outside the image included since round 3), against the CPU checker bit for bit.      python tests/fuzz_differential.py <seconds> <seed>
+End of round 2: 3 242 cases over two seeds, no mismatch (gpurun, 7 minutes).  Round 3: the kernel-shape choices are handle switches
+(ldpc_hip_bp_set_debug_switch), mode 6 (the lane = edge kernels) joins wherever it applies, sizes 48 .. 1300."""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, scipy.sparse as sp
@@ -15,7 +16,7 @@ t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() +
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 n_ok = 0
 while time.time() < t_end:
-    n = int(rng.choice([96, 200, 330, 520, 800, 1300]))
+    n = int(rng.choice([48, 96, 200, 330, 520, 800, 1300]))
     dv, dc = (3, 6) if rng.random() < 0.6 else (4, 8) if rng.random() < 0.5 else (2, 4)
     n -= n % dc
     h = sp.csr_matrix(codes.regular_ldpc_code(n, dv, dc, seed=int(rng.integers(1, 1000))))
@@ -24,7 +25,7 @@ while time.time() < t_end:
     alpha = float(rng.choice([0.0, 0.7, 1.0]))
     max_iter = int(rng.integers(1, 14))
     p = float(rng.choice([0.02, 0.05, 0.09]))
-    B = int(rng.choice([1, 7, 64, 200, 513, 3000]))
+    B = int(rng.choice([1, 7, 64, 200, 513, 3000, 9000]))
     probs = np.full(n, p)
     e = (rng.random((B, n)) < p).astype(np.uint8)
     s = np.asarray((h @ e.T % 2).T, dtype=np.uint8)
@@ -32,26 +33,30 @@ while time.time() < t_end:
     o = oracle.BpOracle(h, error_channel=probs, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
     want = o.decode_batch(s)
     eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 0 if method == "product_sum" else 1, alpha)
-    for mode in (4, 5, 1, -1):
+    for mode in (4, 5, 1, 6, -1):
         eng.set_small_code_kernel(mode)
-        for env in ((), (("LDPC_HIP_PS_TEAM", "0"),), (("LDPC_HIP_PS_TEAM", "1"),)) if mode == 1 and method == "product_sum" else ((),):
-            for k, v in env: os.environ[k] = v
+        if mode == 1 and method == "product_sum": variants = ((), (("PS_TEAM", 0),), (("PS_TEAM", 1),))
+        elif mode == 6: variants = ((), (("EDGE_STATIC_PCT", 50), ("EDGE_CHUNK", 3)))
+        else: variants = ((),)
+        for sw in variants:
+            for k, v in sw: eng.set_debug_switch(k, v)
             got = eng.decode_batch(s)
-            for k, v in env: os.environ.pop(k)
-            tag = f"n={n} dv={dv} {method} a={alpha} it={max_iter} B={B} mode={mode} env={env}"
+            for k, v in sw: eng.set_debug_switch(k, -1)
+            tag = f"n={n} dv={dv} {method} a={alpha} it={max_iter} B={B} mode={mode} switches={sw}"
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), tag
             assert oracle.bits_equal(got[1], want[1]), "llr " + tag
-    # OSD through the workgroup kernel (in-image syndromes only)
-    s2 = np.asarray((h @ e.T % 2).T, dtype=np.uint8)[:min(B, 24)]
+    # OSD through the workgroup kernel and the automatic choice (rows outside the image included: the exact second pass)
+    s2 = np.asarray((h @ e.T % 2).T, dtype=np.uint8)[:min(B, 24)].copy()
+    s2[0, int(rng.integers(0, m))] ^= 1  # (outside the image where H is rank-deficient: every (2,4) and (4,8) code)
     meth, order = [(1, 0), (3, int(rng.integers(1, 12))), (2, int(rng.integers(1, 8)))][int(rng.integers(0, 3))]
     wo = o.bposd_decode_batch(s2, meth, order, want_llr=False)
     eng.set_small_code_kernel(-1)
     eng.set_osd(meth, order)
-    for kern, env in ((2, ()), (2, (("LDPC_HIP_OSD_UNBLOCKED", "1"),)), (2, (("LDPC_HIP_OSD_PLANES", "1"),)), (-1, ())):
+    for kern, sw in ((2, ()), (2, (("OSD_UNBLOCKED", 1),)), (2, (("OSD_PLANES", 1),)), (-1, ())):
         eng.set_osd_kernel(kern)
-        for k, v in env: os.environ[k] = v
+        for k, v in sw: eng.set_debug_switch(k, v)
         g = eng.decode_batch(s2, want_llr=False, osd=True)
-        for k, v in env: os.environ.pop(k)
-        assert np.array_equal(g[0], wo[0]), f"osd n={n} dv={dv} {method} method={meth} order={order} kern={kern} env={env}"
+        for k, v in sw: eng.set_debug_switch(k, -1)
+        assert np.array_equal(g[0], wo[0]), f"osd n={n} dv={dv} {method} method={meth} order={order} kern={kern} switches={sw}"
     n_ok += 1
 print("cases passed:", n_ok)
