@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Latency of ONE decode() call through the Python mirror (Cython and ctypes back ends): hamming(5), BB144, the n = 10 000 code.
+Run on an MI355X:   python tools/decode_latency.py   (profiles/r3_single_decode_latency.txt)"""
 import time, numpy as np, sys
 sys.path.insert(0, '.')
 from ldpc_amd.bp_decoder import BpDecoder
