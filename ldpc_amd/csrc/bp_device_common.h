@@ -67,6 +67,8 @@ struct TileState {
     int32_t it0;                 // iterations completed before round 0
     int32_t end_round;           // round in which the tile's outputs became final (INT32_MAX while it runs)
     int32_t lane_iter[64];       // iteration at which each lane converged
+    int32_t llr_each[2];         // [round & 1]: the bit pass stores the live lanes' posteriors every iteration (set at the tile's first convergence
+                                 // event, or from the start where convergence is imminent: the second pass of a compacted decode)
 };
 
 __device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {  // twin of ldpc_amd/prng.py

@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
     const Buf Lt = make_msgbuf<Buf>(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
     const bool last = it == a.bp.max_iter;
     const bool lane_live = !((done >> lane) & 1ull);
+    const bool each = st->llr_each[a.round & 1] != 0;  // (as the persistent kernel's llr_each)
     const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
     for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
         const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
         }
         const uint64_t hard = __ballot(llr <= 0);
         if (lane == 0) a.bp.dcur[tile * n + j] = hard;
-        if (last && want_llr && lane_live) Lt.st(l8, j, llr);
+        if ((last || each) && want_llr && lane_live) Lt.st(l8, j, llr);
     }
 }
 
@@ -147,6 +148,9 @@ __global__ void __launch_bounds__(256) bp_spread_state_init_kernel(const SpreadA
     st->unsat[0] = st->unsat[1] = 0ull;
     st->it0 = a.bp.it_start;
     st->end_round = INT32_MAX;
+    // lanes compacted out of a first pass (it_start > 0) are the ones about to converge: store their posteriors in every bit pass from
+    // the start instead of paying a sweep over C per convergence event (1.3 ms per round on the headline code at p = 0.05)
+    st->llr_each[0] = a.bp.it_start > 0 ? 1 : 0;
     for (int l = 0; l < 64; ++l) st->lane_iter[l] = 0;
     a.bp.handoff_list[t] = t;
     if (t == 0) a.bp.counters[1] = a.bp.counters[2] = (unsigned)a.n_tiles;  // parked, live
@@ -191,6 +195,7 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
     const uint64_t ndone = done | newly;
     const bool over = ndone == ~0ull || last;
     const bool mine = (newly >> lane) & 1ull;
+    const bool each = cst->llr_each[par] != 0;
     if (newly || (over && ndone != ~0ull)) {
         uint64_t *dec = a.bp.dec + tile * n;
         const uint64_t *dcur = a.bp.dcur + tile * n;
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
                 if (over) d = (d & ndone) | (cur & ~ndone);  // never converged: the last iteration's decisions
                 dec[j] = d;
             }
-            if (newly && !last && want_llr) {  // at the last iteration the bit pass has stored the posterior already
+            if (newly && !last && want_llr && !each) {  // (at the last iteration, or under llr_each, the bit pass has stored the posterior already)
                 double temp = a.bp.llr0[j];
                 for (int p = a.bp.col_ptr[j]; p < a.bp.col_ptr[j + 1]; ++p) temp += Ct.ld(l8, a.bp.csc_edge[p]);
                 if (mine) Lt.st(l8, j, temp);
@@ -225,6 +230,7 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
     if (threadIdx.x == 0) {
         st->done[par ^ 1] = ndone;
         st->unsat[par ^ 1] = 0ull;
+        st->llr_each[par ^ 1] = (each || newly) ? 1 : 0;  // after the first event: every bit pass stores the live lanes' posteriors
         if (over) {
             st->end_round = a.round;
             if (atomicSub(&a.bp.counters[2], 1u) == 1u && a.host_flag)  // that was the last live tile

@@ -308,6 +308,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
                     stt->it0 = it;
                     stt->end_round = INT32_MAX;
                     stt->unsat[0] = stt->unsat[1] = 0ull;
+                    stt->llr_each[0] = llr_each ? 1 : 0;  // (the per-pass kernels carry the policy on)
                     a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
                     atomicAdd(&a.counters[2], 1u);  // live tiles of the per-pass rounds
                 }
