@@ -156,3 +156,18 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_two_ranks_share_the_one_gpu():
+    """world_size 2 on hardware: two processes, each with its own HipBpEngine on cuda:0 (RCCL refuses two ranks on one device, so the
+    group is gloo and the rows travel as host tensors): shards of one shot stream decoded concurrently, gathered on rank 0, equal -- bits
+    of the log-ratios included -- to one decode of all rows (tests/two_rank_gpu_worker.py)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "tests", "two_rank_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "two ranks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
