@@ -135,6 +135,8 @@ def parse_args():
     ap.add_argument("--secondary", type=int, default=1, help="1: also time configs[2] and configs[4] (N = 1 only); 0: skip")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher self-test: every rank joins a gloo group, rank 0 prints the ranks it saw; no GPU work")
     ap.add_argument("--force-launch", action="store_true", help="go through torch.distributed.run even for --gpus 1 (exercises the N > 1 code path on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="diagnostic for a one-GPU box: the N ranks all use cuda:0 and form a gloo group (RCCL refuses two ranks on "
+                    "one device), collectives carry host tensors -- exercises the N > 1 bookkeeping on hardware; the rate means nothing")
     return ap.parse_args()
 
 
@@ -381,12 +383,19 @@ def run(args, real_stdout, stage) -> None:
         dist.barrier()
         dist.destroy_process_group()
         return
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll = torch.device("cpu") if args.share_gpu else dev  # where the tensors of a collective live (gloo: host)
     if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        stage[0] = "init_process_group(nccl)"
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            stage[0] = "init_process_group(gloo)"
+            dist.init_process_group("gloo")
+        else:
+            stage[0] = "init_process_group(nccl)"
+            dist.init_process_group("nccl", device_id=dev)
     stage[0] = "engine"
 
     from ldpc_amd.codes import regular_ldpc_code
@@ -427,9 +436,9 @@ def run(args, real_stdout, stage) -> None:
         if grouped:  # the only collective: gather decoded rows (bit-packed on the device first) + flags onto rank 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            gathered["dec_b8"] = gather_rows(eng.pack_b8(dec), total, 0)
-            gathered["conv"] = gather_rows(cv, total, 0)
-            gathered["iters"] = gather_rows(it, total, 0)
+            gathered["dec_b8"] = gather_rows(eng.pack_b8(dec).to(coll), total, 0)
+            gathered["conv"] = gather_rows(cv.to(coll), total, 0)
+            gathered["iters"] = gather_rows(it.to(coll), total, 0)
             e1.record()
             if record:
                 gather_ms.append((e0, e1))
@@ -439,7 +448,7 @@ def run(args, real_stdout, stage) -> None:
         step(False)
     if grouped and args.warmup == 0:
         # RCCL sets up its peer-to-peer connections at the first gather: keep that out of the timed region
-        gather_rows(torch.zeros((8, 8), dtype=torch.uint8, device=dev), 8 * world, 0)
+        gather_rows(torch.zeros((8, 8), dtype=torch.uint8, device=coll), 8 * world, 0)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -452,7 +461,7 @@ def run(args, real_stdout, stage) -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -476,12 +485,12 @@ def run(args, real_stdout, stage) -> None:
         if llr is not None:
             ok = ok and llr_close(llr[rows_t].cpu().numpy(), cl, rtol=1e-5)
         if rank == 0 and ok:  # what arrived through the gather is what this rank produced
-            own = eng.unpack_b8(gathered["dec_b8"][:B].contiguous(), n)
-            ok = bool(torch.equal(own, dec)) and bool(torch.equal(gathered["conv"][:B], cv)) and bool(torch.equal(gathered["iters"][:B], it))
+            own = eng.unpack_b8(gathered["dec_b8"][:B].contiguous().to(dev), n)
+            ok = bool(torch.equal(own, dec)) and bool(torch.equal(gathered["conv"][:B].to(dev), cv)) and bool(torch.equal(gathered["iters"][:B].to(dev), it))
         rank_ok = int(bool(ok))
     per_rank = None
     if grouped:
-        mine = torch.tensor([k_ms, g_ms, float(rank_ok), float(iters.mean())], dtype=torch.float64, device=dev)
+        mine = torch.tensor([k_ms, g_ms, float(rank_ok), float(iters.mean())], dtype=torch.float64, device=coll)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[float(v) for v in t_.cpu()] for t_ in allr]
@@ -554,6 +563,9 @@ def run(args, real_stdout, stage) -> None:
             res["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                            "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
                            "devices": [torch.cuda.get_device_name(local_rank)], "launcher": "torch.distributed.run"}
+            if args.share_gpu:
+                res["rccl"]["note"] = "--share-gpu diagnostic: every rank on cuda:0, gloo group, collectives on host tensors; the rate means nothing"
+
             res["per_rank"] = {"kernel_ms": [r[0] for r in per_rank], "gather_ms": [r[1] for r in per_rank],
                                "mean_iterations": [r[3] for r in per_rank],
                                "parity_ok": [bool(r[2]) for r in per_rank], "parity_rows_per_rank": rank_rows,

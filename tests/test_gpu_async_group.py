@@ -171,3 +171,16 @@ def test_two_ranks_share_the_one_gpu():
            os.path.join(ROOT, "tests", "two_rank_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "two ranks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_bench_with_two_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2 --share-gpu`: the N > 1 bookkeeping of the bench on hardware -- two shards of the shot stream, barrier,
+    max over ranks, gather onto rank 0, per-rank parity and timings -- with both ranks on cuda:0 under a gloo group (a diagnostic: RCCL
+    refuses two ranks on one device, and the rate of two processes sharing a GPU means nothing)."""
+    got = _bench(["--gpus", "2", "--share-gpu", "--batch-per-gpu", "4096", "--steps", "2", "--warmup", "1", "--rank-parity", "48"])
+    assert got["n_gpus"] == 2 and got["rccl"]["ranks"] == 2 and got["rccl"]["backend"] == "gloo"
+    assert got["config"]["global_batch"] == 8192 and got["gather"]["rows_on_rank0"] == 8192
+    assert got["per_rank"]["parity_ok"] == [True, True] and got["per_rank"]["parity_all_ranks"] is True
+    assert len(got["per_rank"]["kernel_ms"]) == 2 and min(got["per_rank"]["kernel_ms"]) > 0
+    assert got["cpu_baseline"] == "N = 1 only" and "secondary" not in got and "parity_failed" not in got
+    assert abs(got["value"] - 8192 / (got["ms_per_step"] * 1e-3)) < 1e-6 * got["value"]
