@@ -192,7 +192,11 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
  * `batch` must be the batch size of that decode.  The second pass needs rank H (worked out on the host for m * m * n / 64 < 4e9)
  * and m <= 8192; beyond that a flagged row keeps the solution of the device's own pivot rows.  Both extra launches size
  * themselves from device-side counters: no host round trip, a few microseconds when no row is flagged, nothing at all for
- * a full-rank H.
+ * a full-rank H.  Device memory of the second pass (per handle, allocated on the first BP + OSD call on a rank-deficient H and
+ * kept): the working copies of at most 64 workgroups, (m * ceil(n / 64) + n * m / 4) 64-bit words each, capped at 256 MiB in
+ * total, plus batch * (m + 4) bytes for the corrected syndromes and their list; the first such call also pays the host
+ * elimination that finds rank H.  If that memory cannot be had the pass is skipped: the decode still succeeds and flagged rows
+ * keep the device's own pivot-row solution (status 2).
  */
 int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
 /* Serial schedule: a 64-syndrome tile is decoded by one wavefront, which runs until its slowest syndrome is done.  With

@@ -225,14 +225,24 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     // both launches size themselves from device-side counters and cost a few microseconds when there is nothing to do.
     const bool rank_known = (double)a.m * a.m * a.words < 4e9;
     if (rank_known && a.n - osd_k(h) < a.m && a.m <= 8192 && !h->on("OSD_NO_EXACT")) {
+        // Footprint (documented in ldpc_hip.h): at most 64 workgroups' working copies, capped at 256 MiB, plus one corrected syndrome and
+        // one list entry per row of the batch.  If the device cannot spare that, the second pass is skipped -- the first-pass solutions
+        // stand and the affected rows keep status 2 -- rather than failing a decode whose outputs are already complete.
         const size_t slot_words = osd_exact_slot_words(a.m, a.n);
-        int64_t slots = 512;
+        int64_t slots = 64;
         if (slots > batch) slots = batch;
-        const int64_t cap = (int64_t)((2ull << 30) / (slot_words * 8));  // at most 2 GiB of working copies
-        if (cap >= 1) {
+        const int64_t cap = (int64_t)((256ull << 20) / (slot_words * 8));
+        bool room = cap >= 1;
+        if (room) {
             if (slots > cap) slots = cap;
-            if ((rc = h->osd_fix_synd.ensure(B * (size_t)a.m)) || (rc = h->osd_fix_list.ensure(B * sizeof(int32_t))) ||
-                (rc = h->osd_fix_counters.ensure(2 * sizeof(unsigned))) || (rc = h->osd_fix_scratch.ensure((size_t)slots * slot_words * 8))) return rc;
+            if (h->osd_fix_synd.ensure(B * (size_t)a.m) || h->osd_fix_list.ensure(B * sizeof(int32_t)) ||
+                h->osd_fix_counters.ensure(2 * sizeof(unsigned)) || h->osd_fix_scratch.ensure((size_t)slots * slot_words * 8)) {
+                (void)hipGetLastError();  // out of memory: not an error of this decode
+                g_last_error.clear();
+                room = false;
+            }
+        }
+        if (room) {
             HIPCHK(hipMemsetAsync(h->osd_fix_counters.p, 0, 2 * sizeof(unsigned), h->stream));
             OsdExactArgs X = {};
             X.o = a;

@@ -22,7 +22,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
         // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
         // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
-        if (h->small_mode != 2 && h->small_mode < 3) {  // product-sum: one lane per entry keeps the lanes busy with transcendentals
+        if (h->small_mode < 2 || h->small_mode == 6) {  // (mode 6: as -1 wherever the lane = edge variants do not apply) product-sum: one lane per entry keeps the lanes busy with transcendentals
             const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
             if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
         }
@@ -33,7 +33,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             if (e8.rounds) return decode_edge8(h, e8, synd, batch, decoding, llr, iters, conv);
         }
         if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1 || h->small_mode >= 3, llr != nullptr, batch);
+            const WavePlan wp = plan_wave(h, h->small_mode == 1 || (h->small_mode >= 3 && h->small_mode != 6), llr != nullptr, batch);
             if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
         }
         int slots = 0;

@@ -178,13 +178,32 @@ static int multi_decode_shard(ldpc_hip_bp_multi *mh, MultiDev &md, int osd, cons
 // the handle that decoded the batch's last row is the authority after it.
 static bool multi_schedule_has_state(const ldpc_hip_bp *h) { return h->random_serial || h->schedule == 2; }
 static void multi_copy_schedule_state(ldpc_hip_bp_multi *mh, int from) {
-    const ldpc_hip_bp *src = mh->devs[(size_t)from].h;
+    ldpc_hip_bp *src = mh->devs[(size_t)from].h;
+    int entry_device = -1;
+    (void)hipGetDevice(&entry_device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{entry_device};
     for (size_t d = 0; d < mh->devs.size(); ++d) {
         ldpc_hip_bp *dst = mh->devs[d].h;
         if (dst == src) continue;
+        const bool same = dst->sched_state == src->sched_state && dst->sched_rng == src->sched_rng && dst->sched_seed_raw == src->sched_seed_raw;
         dst->sched_state = src->sched_state;
         dst->sched_rng = src->sched_rng;
         dst->sched_seed_raw = src->sched_seed_raw;
+        if (same) continue;
+        // The random schedule's ring of per-iteration orders (host_serial.h: random_orders_*) belongs to that state: without it the
+        // receiving handle finds its ring stale at the next call and regenerates max_iter x n orders (n^2 shuffles and a 4 n^2-byte
+        // upload at the default max_iter = n).  The source's ring is current, so the receiver takes it over: bookkeeping + one
+        // device-to-device copy of the table.  Any failure just leaves the receiver's ring invalid (it is then rebuilt as before).
+        dst->rnd.valid = false;
+        const auto &r = src->rnd;
+        if (!r.valid || r.rows <= 0 || r.n <= 0 || !src->sched_orders.p) continue;
+        const size_t bytes = (size_t)r.rows * (size_t)r.n * sizeof(int32_t);
+        if (hipSetDevice(dst->device) != hipSuccess || hipStreamSynchronize(dst->stream) != hipSuccess || dst->sched_orders.ensure(bytes + 16) ||
+            hipMemcpyPeer(dst->sched_orders.p, dst->device, src->sched_orders.p, src->device, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        dst->rnd = r;
     }
 }
 

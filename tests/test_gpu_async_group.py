@@ -167,7 +167,8 @@ def test_two_ranks_share_the_one_gpu():
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+    import bench  # (free_port: a fixed port can collide on a shared box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(bench.free_port()),
            os.path.join(ROOT, "tests", "two_rank_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "two ranks ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

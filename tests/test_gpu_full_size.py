@@ -55,6 +55,54 @@ def test_config2_full_batch(p, oracle_built):
     assert bool((d2 == dec[:16384]).all()) and bool((i2 == it[:16384]).all()) and bool((c2 == cv[:16384]).all())
 
 
+@pytest.mark.parametrize("p", [0.09, 0.05])
+def test_config4_per_gpu_share(p, oracle_built):
+    """BASELINE configs[3] at the size ONE GPU of its eight decodes: (3,6)-regular n = 10 000, product_sum, 50 iterations, B = 131 072
+    (1 048 576 / 8; messages 63 GB).  flag <=> H x == s on every row, an oracle subset, and every row -- log-ratio bits included --
+    equal to what two 65 536-row decodes of the same shot stream (shots [0, 65 536) and [65 536, 131 072), the shards two ranks of a
+    16-GPU job would hold) give: a rank's results do not depend on how the stream is cut into shards."""
+    import torch
+    from ldpc_amd.codes import regular_ldpc_code
+    from ldpc_amd.engine import HipBpEngine
+    dev = torch.device("cuda", 0)
+    h = regular_ldpc_code(10000, 3, 6, seed=1)
+    eng = HipBpEngine(h.indptr, h.indices, 10000, np.full(10000, p), 50, 0, 1.0)
+    B, half = 131072, 65536
+    synd = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+    dec, llr, it, cv = eng.decode_batch(synd, want_llr=True)
+    cvb = _check_flags_against_syndromes(eng, synd, dec, cv, it, 50)
+    if p == 0.05:
+        assert cvb.float().mean().item() > 0.999 and 6.0 < it.float().mean().item() < 8.0
+    else:
+        assert cvb.float().mean().item() < 0.05
+    rows = torch.from_numpy(np.sort(np.random.default_rng(4).choice(B, 24 if p == 0.09 else 96, replace=False))).to(dev)
+    _subset_vs_oracle(oracle_built, h, p, 50, "product_sum", 1.0, synd, dec, it, cv, llr, rows)
+    for k in range(2):
+        part = eng.gen_bsc_syndromes(7, p, shot0=k * half, shots=half, device=dev)
+        assert bool(torch.equal(part, synd[k * half:(k + 1) * half])), "the shot stream is counter-based: a shard is a slice of it"
+        d2, l2, i2, c2 = eng.decode_batch(part, want_llr=True)
+        sl = slice(k * half, (k + 1) * half)
+        assert bool(torch.equal(d2, dec[sl])) and bool(torch.equal(i2, it[sl])) and bool(torch.equal(c2, cv[sl]))
+        assert bool(torch.equal(l2.view(torch.int64), llr[sl].view(torch.int64))), "log-ratio bits differ between shard sizes"
+        del part, d2, l2, i2, c2
+    eng.close()
+
+
+def test_bench_config4_geometry_under_a_process_group_of_one():
+    """`python bench.py --gpus 1 --force-launch --batch-per-gpu 131072`: the line the driver's `--gpus 8` run prints, for the one rank
+    this box can hold -- torch.distributed.run, an RCCL group, a 131 072-syndrome shard, the gather of bit-packed rows, per-rank parity."""
+    from test_gpu_async_group import _bench
+    got = _bench(["--gpus", "1", "--force-launch", "--batch-per-gpu", "131072", "--steps", "2", "--warmup", "1", "--rank-parity", "64",
+                  "--secondary", "0"], timeout=1200)
+    assert got["n_gpus"] == 1 and got["rccl"]["ranks"] == 1 and got["rccl"]["backend"] == "nccl"
+    assert got["config"]["batch_per_gpu"] == 131072 and got["config"]["global_batch"] == 131072
+    assert got["gather"]["rows_on_rank0"] == 131072
+    assert got["per_rank"]["parity_all_ranks"] is True and got["per_rank"]["parity_rows_per_rank"] == 64
+    assert "parity_failed" not in got and got["value"] > 0
+    assert 0.2 < got["roofline"]["frac"] <= 1.0
+    assert abs(got["value"] - 131072 / (got["ms_per_step"] * 1e-3)) < 1e-6 * got["value"]
+
+
 def test_config3_full_batch(oracle_built):
     """Rotated surface code d = 21, minimum_sum 0.625, 30 iterations, B = 262 144."""
     import torch

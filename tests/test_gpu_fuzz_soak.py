@@ -1,0 +1,21 @@
+"""A bounded slice of the two differential soaks (tests/fuzz_differential.py, tests/fuzz_streamed.py) with FIXED seeds, so the driver's
+`-m gpu` run exercises them: random regular codes through every on-chip kernel form and four OSD variants, and through the streamed
+kernels (hand-off thresholds, chunked workspaces, ring depths, the two-pass decode) -- decisions, iterations, flags and log-ratio BITS of
+every row against the CPU checker.  The same files run for minutes by hand (`python tests/fuzz_differential.py <seconds> <seed>`)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_differential_soak_slice(seed, oracle_built):
+    import fuzz_differential
+    cases = fuzz_differential.run(seconds=20.0, seed=seed, max_cases=40)
+    assert cases >= 5, f"only {cases} cases in 20 s"
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_streamed_soak_slice(seed, oracle_built):
+    import fuzz_streamed
+    cases = fuzz_streamed.run(seconds=20.0, seed=seed, max_cases=16)
+    assert cases >= 3, f"only {cases} cases in 20 s"
