@@ -39,7 +39,6 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 LDS_PEAK_GBPS = 150000.0  # ds_read_b64 / b128 aggregate at 2.4 GHz, same guide (LDS table)
 SIMDS = 1024             # 256 CUs x 4
-MAX_CLOCK_GHZ = 2.4
 
 
 def algorithmic_bytes(iters: np.ndarray, m: int, n: int, nnz: int) -> float:
@@ -77,6 +76,41 @@ def physical_cores() -> int:
     except OSError:
         pass
     return os.cpu_count() or 1
+
+
+class SclkSampler:
+    """Corroboration for the device-side clock probe: the driver's own reading of the shader clock (hwmon freq1_input, Hz), sampled by a
+    host thread every 20 ms while a timed region runs.  Absent file -> no samples -> None."""
+
+    def __init__(self, device_index: int = 0):
+        import glob
+        self.paths = sorted(glob.glob(f"/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.path = self.paths[min(device_index, len(self.paths) - 1)] if self.paths else None
+        self.samples, self._stop, self._thread = [], False, None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append(float(open(self.path).read().strip()))
+            except Exception:
+                pass
+            time.sleep(0.02)
+
+    def __enter__(self):
+        if self.path:
+            import threading
+            self._stop = False
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread:
+            self._thread.join(timeout=1.0)
+
+    def ghz(self):
+        return float(np.mean(self.samples)) / 1e9 if self.samples else None
 
 
 def free_port() -> int:
@@ -194,12 +228,15 @@ def secondary_configs(dev, steps):
         res = eng.decode_batch(s, osd0=sp["osd0"])  # warm-up; also the outputs that are checked
         torch.cuda.synchronize()
         kms, step_ms = [], []
-        for _ in range(steps):  # each decode timed on its own, the MEDIAN reported: these are sub-millisecond .. 10 ms calls, and one
-            t0 = time.perf_counter()  # hiccup of the box (seen once: a 0.75 ms kernel taking 7.5 ms) would otherwise be the result
-            eng.decode_batch(s, out=res, osd0=sp["osd0"], asynchronous=True)
-            kms.append(eng.last_kernel_ms())
-            torch.cuda.synchronize()
-            step_ms.append((time.perf_counter() - t0) * 1e3)
+        probe0 = eng.clock_probe()
+        with SclkSampler(dev.index or 0) as sclk:
+            for _ in range(steps):  # each decode timed on its own, the MEDIAN reported: these are sub-millisecond .. 10 ms calls, and one
+                t0 = time.perf_counter()  # hiccup of the box (seen once: a 0.75 ms kernel taking 7.5 ms) would otherwise be the result
+                eng.decode_batch(s, out=res, osd0=sp["osd0"], asynchronous=True)
+                kms.append(eng.last_kernel_ms())
+                torch.cuda.synchronize()
+                step_ms.append((time.perf_counter() - t0) * 1e3)
+        clock_run = eng.clock_ghz(probe0, eng.clock_probe())  # shader clock of the BP kernel's workgroups over these steps (device counters)
         ms = float(np.median(step_ms))
         it = res[2].cpu().numpy()
         cv = res[3].cpu().numpy().astype(bool)
@@ -221,48 +258,46 @@ def secondary_configs(dev, steps):
             # min-sum on chip (bp_edge_kernel: lane = edge, messages in registers).  The kernel is bound by instruction ISSUE: a SIMD
             # issues one vector and one scalar instruction per 4-cycle turn, and the lane-mask parities make the scalar stream as
             # long as the vector one.  Instructions per syndrome-iteration come from the committed PMC profile of this kernel
-            # (profiles/secondary_c3.json: SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_LDS_IDX_ACTIVE, GRBM_GUI_ACTIVE -> clock); the
-            # fractions below use THIS run's kernel time.  The larger one is the bound.
-            c3 = valu.get("c3") or {}
+            # (profiles/secondary_c3.json: SQ_INSTS_VALU, SQ_INSTS_SALU, SQ_LDS_IDX_ACTIVE); the
+            # fractions below use THIS run's kernel time and THIS run's clock.  The larger one is the bound.
             try:
                 c3 = json.load(open(os.path.join(ROOT, "profiles", "secondary_c3.json")))["c3"]
             except Exception:
                 c3 = {}
             k_s = float(np.median(kms)) * 1e-3
-            if c3.get("valu_insts_per_syndrome_iteration") and c3.get("batch") == B:
-                clock = float(c3.get("clock_ghz") or MAX_CLOCK_GHZ) * 1e9
-                slots = SIMDS * clock * k_s / 4.0  # issue turns on offer while the kernel ran, at the clock measured under this load
+            if c3.get("valu_insts_per_syndrome_iteration") and c3.get("batch") == B and clock_run:
+                slots = SIMDS * clock_run * 1e9 * k_s / 4.0  # issue turns on offer while the kernel ran, at the clock its workgroups measured in THIS run
                 fv = iters_total * c3["valu_insts_per_syndrome_iteration"] / slots
                 fs = iters_total * c3["salu_insts_per_syndrome_iteration"] / slots
                 bounds = {"valu_issue": fv, "salu_issue": fs, "lds_array_busy": c3.get("lds_array_busy_frac_measured")}
                 which = "valu_issue" if fv >= fs else "salu_issue"
-                # the chip does not hold one clock (2.08 - 2.3 GHz seen on this kernel): a run faster than the profile's clock allows shows
-                # as a fraction above 1 -- then the true fraction lies between the value at the 2.4 GHz maximum and 1
-                at_max = bounds[which] * clock / (MAX_CLOCK_GHZ * 1e9)
-                entry.update({"bound": which, "frac": min(bounds[which], 1.0), "frac_at_max_clock": at_max, "frac_measured_in_profile": c3.get(which + "_frac_measured"), "bounds": bounds, "kernel": c3.get("kernel"), "clock_ghz": c3.get("clock_ghz"),
+                entry.update({"bound": which, "frac": bounds[which], "frac_measured_in_profile": c3.get(which + "_frac_measured"), "bounds": bounds, "kernel": c3.get("kernel"),
+                              "clock_ghz_this_run": clock_run, "clock_ghz_in_profile": c3.get("clock_ghz"), "sclk_sysfs_ghz": sclk.ghz(),
                               "valu_insts_per_syndrome_iteration": c3["valu_insts_per_syndrome_iteration"],
                               "salu_insts_per_syndrome_iteration": c3["salu_insts_per_syndrome_iteration"],
                               "lds_bank_conflict_share": c3.get("lds_bank_conflict_share"),
-                              "bound_note": "issue turns used / turns on offer (1024 SIMDs x the profile's clock x this run's kernel time / 4 cycles), capped at 1; "
-                                            "frac_at_max_clock = the same at 2.4 GHz (a lower bound), frac_measured_in_profile = counters and time of ONE run; instruction counts "
-                                            "and clock from profiles/secondary_c3.json (tools/profile_c3.sh); LDS array busy and conflict share from the same profile"})
+                              "bound_note": "issue turns used / turns on offer = instructions per syndrome-iteration (profiles/secondary_c3.json, valid for this build when "
+                                            "counters_match_this_build) x this run's iterations / (1024 SIMDs x clock_ghz_this_run x this run's kernel time / 4 cycles); "
+                                            "clock_ghz_this_run = shader cycles / constant-rate ticks summed over the kernel's workgroups in this run "
+                                            "(ldpc_hip_bp_clock_probe); not capped"})
             else:
-                entry.update({"bound": "valu_issue", "frac": None, "bound_note": "profiles/secondary_c3.json absent or for another batch"})
+                entry.update({"bound": "valu_issue", "frac": None, "clock_ghz_this_run": clock_run,
+                              "bound_note": "profiles/secondary_c3.json absent or for another batch, or no clock reading"})
         else:
             # product-sum on chip: FP64 VALU issue.  Instructions per entry-iteration come from the committed PMC profile of
             # this kernel (profiles/secondary_valu.json: SQ_INSTS_VALU / (entries x iterations)); a wave-instruction takes
-            # 4 cycles of its SIMD, and the chip has 1024 SIMDs at <= 2.4 GHz.
+            # 4 cycles of its SIMD, and the chip has 1024 SIMDs at the clock this run's workgroups measured.
             per = valu.get(sp["key"], {}).get("valu_insts_per_entry_iteration")
-            if per:
-                clock = float(valu[sp["key"]].get("clock_ghz") or MAX_CLOCK_GHZ)  # measured under this load in the profile run
+            if per and clock_run:
                 wave_insts = iters_total * nnz * per / 64.0
-                frac = wave_insts * 4.0 / (SIMDS * clock * 1e9 * float(np.median(kms)) * 1e-3)
-                entry.update({"bound": "fp64_valu", "frac": frac, "valu_insts_per_entry_iteration": per, "clock_ghz": clock,
+                frac = wave_insts * 4.0 / (SIMDS * clock_run * 1e9 * float(np.median(kms)) * 1e-3)
+                entry.update({"bound": "fp64_valu", "frac": frac, "valu_insts_per_entry_iteration": per, "clock_ghz_this_run": clock_run,
+                              "clock_ghz_in_profile": valu[sp["key"]].get("clock_ghz"), "sclk_sysfs_ghz": sclk.ghz(),
                               "bound_note": "VALU issue turns used by the BP kernel (instructions per entry-iteration from profiles/secondary_valu.json x this "
-                                            "run's iterations) / turns of 1024 SIMDs at the clock measured under this load in that profile, over this run's "
+                                            "run's iterations) / turns of 1024 SIMDs at clock_ghz_this_run (device counters of this run) over this run's "
                                             "BP kernel time; at 8 192 syndromes the rest is latency: the 50 iterations of the slowest syndromes, four barriers each"})
             else:
-                entry.update({"bound": "fp64_valu", "frac": None, "bound_note": "profiles/secondary_valu.json absent"})
+                entry.update({"bound": "fp64_valu", "frac": None, "clock_ghz_this_run": clock_run, "bound_note": "profiles/secondary_valu.json absent, or no clock reading"})
         src = (c3 if sp["method"] == 1 else valu.get(sp["key"], {})) or {}
         if src.get("kernel_sources_sha16"):
             entry["counters_match_this_build"] = src["kernel_sources_sha16"] == kernel_sources_sha16()
@@ -453,6 +488,9 @@ def run(args, real_stdout, stage) -> None:
     if grouped:
         dist.barrier()
     stage[0] = "timed steps"
+    probe0 = eng.clock_probe()  # (waits for the stream: outside the timed region)
+    sclk = SclkSampler(local_rank)
+    sclk.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -460,6 +498,8 @@ def run(args, real_stdout, stage) -> None:
     if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    sclk.__exit__()
+    clock_run = eng.clock_ghz(probe0, eng.clock_probe())  # shader clock of the persistent kernel's workgroups over the timed steps
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -522,10 +562,19 @@ def run(args, real_stdout, stage) -> None:
             traffic = tj["hbm_bytes_per_launch"] if tj else None
             profile_tag = (tj or {}).get("kernel_sources_sha16")
             vj = committed("valu_clock.json")
-            if vj:
-                second = {"kind": "fp64_valu", "issue_frac": vj.get("valu_issue_frac"), "clock_ghz": vj.get("clock_ghz"),
-                          "insts_per_edge_iter": vj.get("valu_insts_per_edge_iteration"),
-                          "source": "profiles/valu_clock.json (PMC passes of this workload: SQ_INSTS_VALU, GRBM_GUI_ACTIVE)"}
+            if vj and vj.get("valu_insts_per_edge_iteration") and clock_run:
+                # VALU issue: instructions per edge-iteration (PMC profile of this workload; belongs to this build when the fingerprints
+                # match) x this run's edge-iterations, against the issue turns of 1024 SIMDs at THIS run's clock over THIS run's kernel time
+                per = float(vj["valu_insts_per_edge_iteration"])
+                wave_insts = float(iters.astype(np.float64).sum()) * nnz * per / 64.0
+                second = {"kind": "fp64_valu", "issue_frac": wave_insts * 4.0 / (SIMDS * clock_run * 1e9 * k_ms * 1e-3),
+                          "clock_ghz_this_run": clock_run, "sclk_sysfs_ghz": sclk.ghz(), "insts_per_edge_iter": per,
+                          "issue_frac_in_profile": vj.get("valu_issue_frac"), "clock_ghz_in_profile": vj.get("clock_ghz"),
+                          "source": "instructions per edge-iteration: profiles/valu_clock.json (SQ_INSTS_VALU of this workload); clock: shader cycles / "
+                                    "constant-rate ticks summed over the persistent kernel's workgroups during the timed steps (ldpc_hip_bp_clock_probe); "
+                                    "kernel time: HIP events of this run"}
+            elif clock_run:
+                second = {"kind": "fp64_valu", "issue_frac": None, "clock_ghz_this_run": clock_run, "sclk_sysfs_ghz": sclk.ghz()}
         res = {
             "metric": "syndromes_per_sec_batched_bp50_product_sum_ldpc36_n10k" if method_id == 0 else "syndromes_per_sec_DIAGNOSTIC_min_sum",
             "value": total * args.steps / elapsed,
@@ -548,6 +597,7 @@ def run(args, real_stdout, stage) -> None:
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "kernel": "bp_decode_kernel (persistent, one workgroup per 64-syndrome tile) + bp_spread_* per-pass launches for the last tiles",
                 "kernel_ms": k_ms, "kernel_ms_persistent": pers_ms, "kernel_ms_per_pass": spread_ms,
+                "clock_ghz_this_run": clock_run,
                 "algorithmic_bytes_per_launch": alg,
                 "second_bound": second,
                 "counters_from_build": profile_tag, "this_build": build_tag,
@@ -555,8 +605,9 @@ def run(args, real_stdout, stage) -> None:
                 "note": "one decode = the whole batch of this rank; algorithmic bytes = sum over syndromes of iters_run*4*E*8 + (m+n+8n+5); "
                         "kernel_ms = HIP events on the launch stream around all BP kernels of the decode (the persistent kernel "
                         "hands its last <= 256 tiles to per-pass launches: compare kernel_ms_persistent with rocprofv3's "
-                        "bp_decode_kernel average and kernel_ms_per_pass with the sum of the bp_spread_* kernels); traffic and "
-                        "second_bound = PMC counters of the same kernels from the committed profile run (profiles/), not of this run",
+                        "bp_decode_kernel average and kernel_ms_per_pass with the sum of the bp_spread_* kernels); traffic = PMC "
+                        "counters of the same kernels from the committed profile run (profiles/); second_bound = that profile's instruction count per "
+                        "edge-iteration with THIS run's clock (clock_ghz_this_run: device cycle / tick counters), iterations and kernel time",
             },
         }
         if grouped:

@@ -345,6 +345,14 @@ int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value
 #define LDPC_HIP_MATH_FAST 1
 int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);
 
+/* The shader clock the BP kernels actually ran at (a measurement aid; no counterpart in the reference).  Every workgroup of the
+ * long-running BP kernels (bp_decode_kernel, bp_wave_kernel, bp_wave_ps_kernel, bp_edge_kernel, bp_edge8_kernel) adds the shader cycles
+ * (s_memtime) and the constant-rate ticks (s_memrealtime) of its lifetime to two 64-bit words of the handle; the words only grow.
+ * This call waits for the handle's stream and returns them together with the tick rate (hipDeviceAttributeWallClockRate).
+ * Clock over an interval = (cycles_after - cycles_before) / (ticks_after - ticks_before) * tick_hz, averaged over the kernels'
+ * workgroups and weighted by their lifetime. */
+int ldpc_hip_bp_clock_probe(ldpc_hip_bp *h, uint64_t *cycles, uint64_t *ticks, double *tick_hz);
+
 const char *ldpc_hip_last_error(void);
 const char *ldpc_hip_version(void);
 

@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
     "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_set_random_serial", "ldpc_hip_bp_get_schedule_order", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
     "ldpc_hip_bp_set_osd", "ldpc_hip_bposd_get_status", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
-    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms",
+    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms", "ldpc_hip_bp_clock_probe",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
     "ldpc_hip_bp_set_debug_switch", "ldpc_hip_bp_multi_create", "ldpc_hip_bp_multi_destroy", "ldpc_hip_bp_multi_devices", "ldpc_hip_bp_multi_handle",
@@ -93,6 +93,7 @@ def load():
     lib.ldpc_hip_gen_bsc_syndromes.argtypes = [vp, u64, u64, i64, i64, vp, vp]
     lib.ldpc_hip_bp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldpc_hip_bp_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.ldpc_hip_bp_clock_probe.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
     lib.ldpc_hip_bp_workspace_bytes.argtypes = [vp, i64]
     lib.ldpc_hip_bp_workspace_bytes.restype = i64
     lib.ldpc_hip_bp_set_tuning.argtypes = [vp, i32, i32]

@@ -56,6 +56,8 @@ struct BpArgs {
     // 1: the bit pass of iteration max_iter still writes the bit_to_check messages (a first pass whose state a second pass carries
     // on, decode_stream_repacked).  0: nobody reads them -- the last bit pass only forms the log-ratios (no tanh, no message stores)
     int32_t keep_state;
+    // shader-clock probe (clock_probe_*, below): {cycles, constant-rate ticks} summed over this kernel's workgroups, or nullptr
+    unsigned long long *clk;
 };
 
 // What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in
@@ -417,6 +419,25 @@ __device__ __forceinline__ T kernarg_load() {
 // (a pointer fetched this way is a plain number to the compiler: say that it points to global memory, or every access becomes a flat_ one)
 template <typename T>
 __device__ __forceinline__ __attribute__((address_space(1))) T *global_ptr(T *p) { return (__attribute__((address_space(1))) T *)p; }
+
+// ---- the shader clock a kernel actually ran at --------------------------------------------------------------------------------------
+// The chip does not hold one clock under load (1.7 GHz on the FP64-heavy streamed kernel, 2.1 - 2.3 GHz on the on-chip ones, and it
+// differs from box to box), so any "fraction of the issue slots" needs the clock of THE RUN.  Every workgroup of the long-running BP
+// kernels reads the shader-cycle counter (s_memtime) and the constant-rate counter (s_memrealtime) when it starts and when it ends and
+// adds both differences to two 64-bit words of the handle: sum(cycles) / sum(ticks) x the tick rate = the clock, averaged over
+// the kernels' lifetime and weighted by it.  Two scalar reads and two atomics per workgroup LIFETIME (the kernels are persistent).
+// The words only ever grow; ldpc_hip_bp_clock_probe reads them, and the caller takes differences around what it times.
+__device__ __forceinline__ void clock_probe_begin(unsigned long long *stamp) {  // ONE thread of the workgroup; stamp: two words (LDS)
+    stamp[0] = (unsigned long long)__builtin_readcyclecounter();
+    stamp[1] = (unsigned long long)__builtin_readsteadycounter();
+}
+__device__ __forceinline__ void clock_probe_end(unsigned long long *clk, const unsigned long long *stamp) {  // the same thread, once
+    if (!clk) return;
+    const unsigned long long c = (unsigned long long)__builtin_readcyclecounter() - stamp[0];
+    const unsigned long long t = (unsigned long long)__builtin_readsteadycounter() - stamp[1];
+    __hip_atomic_fetch_add(clk, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(clk + 1, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- work distribution of the one-syndrome-per-wavefront kernels ----------------------------------------------------------------
 // A wavefront's syndromes take 3 .. 100 us and the wavefronts do not run at one speed (equal static shares finish 20 % apart on

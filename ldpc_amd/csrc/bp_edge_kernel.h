@@ -51,6 +51,7 @@ struct EdgeArgs {
     int32_t *iters;            // [batch] or nullptr
     uint8_t *conv;             // [batch] or nullptr
     unsigned long long *next;  // WORK_POOLS work counters, WORK_POOL_STRIDE words apart (work_pool_next, bp_device_common.h) (zeroed before launch)
+    unsigned long long *clk;   // shader-clock probe (clock_probe_*, bp_device_common.h) or nullptr
 };
 
 __host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)rounds * 64 + 3) * 8; }  // slots, +0.0, +inf, a dummy (bp_edge8_kernel's phantom lanes park their output there)
@@ -118,6 +119,8 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
     typedef __attribute__((address_space(3))) double lds_f64;
     lds_f64 *X = (lds_f64 *)edge_lds;  // [R * 64] check_to_bit of every slot, [R * 64] = +0.0 for good
     const int lane = threadIdx.x;
+    __shared__ unsigned long long clk_stamp[2];
+    if (lane == 0) clock_probe_begin(clk_stamp);
     const int m = a.m, n = a.n;
     constexpr int ZERO = R * 64;
     constexpr uint64_t LOW = 0x1111111111111111ull;
@@ -261,6 +264,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
         if (!work_pool_next(LDPC_KERNARG(ARGS_T, next), LDPC_KERNARG(ARGS_T, dyn_base), LDPC_KERNARG(ARGS_T, pool_per), LDPC_KERNARG(ARGS_T, chunk),
                             (int)LDPC_KERNARG(ARGS_T, batch), lane, pool, b0, b1)) break;
     }
+    if (lane == 0) clock_probe_end(LDPC_KERNARG(ARGS_T, clk), clk_stamp);
 #undef LDPC_EDGE_PRIOR
 }
 
@@ -294,6 +298,7 @@ struct Edge8Args {
     int32_t *iters;
     uint8_t *conv;
     unsigned long long *next;
+    unsigned long long *clk;   // shader-clock probe (clock_probe_*, bp_device_common.h) or nullptr
 };
 
 namespace edge_detail {
@@ -329,6 +334,8 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
     typedef __attribute__((address_space(3))) double lds_f64;
     lds_f64 *X = (lds_f64 *)edge_lds;
     const int lane = threadIdx.x;
+    __shared__ unsigned long long clk_stamp[2];
+    if (lane == 0) clock_probe_begin(clk_stamp);
     const int m = a.m, n = a.n;
     constexpr int ZERO = R * 64;
     constexpr uint64_t LOW = 0x0101010101010101ull;
@@ -459,5 +466,6 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge8_kernel(const Edg
         if (!work_pool_next(LDPC_KERNARG(ARGS_T, next), LDPC_KERNARG(ARGS_T, dyn_base), LDPC_KERNARG(ARGS_T, pool_per), LDPC_KERNARG(ARGS_T, chunk),
                             (int)LDPC_KERNARG(ARGS_T, batch), lane, pool, b0, b1)) break;
     }
+    if (lane == 0) clock_probe_end(LDPC_KERNARG(ARGS_T, clk), clk_stamp);
 #undef LDPC_EDGE_PRIOR
 }

@@ -38,6 +38,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
 
     __shared__ uint64_t red[2][16];
     __shared__ int red_i;
+    __shared__ unsigned long long clk_stamp[2];
+    if (threadIdx.x == 0) clock_probe_begin(clk_stamp);
     __shared__ __attribute__((aligned(16))) double log_tab[256];  // glibc log's {1/c, log c} table, LDS-resident
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
                     stt->llr_each[0] = llr_each ? 1 : 0;  // (the per-pass kernels carry the policy on)
                     a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
                     atomicAdd(&a.counters[2], 1u);  // live tiles of the per-pass rounds
+                    clock_probe_end(a.clk, clk_stamp);
                 }
                 return;
             }
@@ -331,4 +334,5 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
         }
     }
     if (threadIdx.x == 0 && a.counters) atomicAdd(&a.counters[0], 1u);
+    if (threadIdx.x == 0) clock_probe_end(a.clk, clk_stamp);
 }

@@ -43,6 +43,7 @@ struct WaveArgs {
     unsigned long long *next;    // WORK_POOLS work counters (work_pool_next, bp_device_common.h; zeroed before launch)
     int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;  // bytes
+    unsigned long long *clk;     // shader-clock probe (clock_probe_*, bp_device_common.h) or nullptr
 };
 
 // LDS bytes: shared tables of a workgroup / private region of one wavefront (host and device agree through these)
@@ -77,6 +78,8 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     const int wt = TEAM ? wave : 0, W = TEAM ? T >> 6 : 1;   // this wavefront within the team, wavefronts of a team
     __shared__ int team_unsat[2];
     __shared__ long long team_b;
+    __shared__ unsigned long long clk_stamp[2];
+    if (threadIdx.x == 0) clock_probe_begin(clk_stamp);
     auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     const int m = a.m, n = a.n, mp = a.mp, np = a.np, rm = DR * mp, cn = DC * np;
     const bool want_llr = a.llr != nullptr && !a.llr_direct, llr_direct = a.llr != nullptr && a.llr_direct;
@@ -283,6 +286,7 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
         }
         team_sync();
     }
+    if (threadIdx.x == 0) clock_probe_end(a.clk, clk_stamp);
 }
 
 // ---- product-sum: node-per-lane bookkeeping, ENTRY-per-lane transcendentals ----------------------------------------
@@ -316,6 +320,7 @@ struct WavePsArgs {
     int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;
     int32_t min_rdeg;        // lightest row (a row of weight 1 has x = the empty product 1: q = 2 / 0, generic path only)
+    unsigned long long *clk; // shader-clock probe (clock_probe_*, bp_device_common.h) or nullptr
 };
 
 #define LDPC_PS_NEAR_SLOTS 64  // entries whose log argument is near 1, listed per wavefront and iteration (see check B)
@@ -343,6 +348,8 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     const int wt = TEAM ? wave : 0, W = TEAM ? T >> 6 : 1;
     __shared__ int team_unsat[2];
     __shared__ long long team_b;
+    __shared__ unsigned long long clk_stamp[2];
+    if (threadIdx.x == 0) clock_probe_begin(clk_stamp);
     auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     const int m = a.m, n = a.n, np = a.np, rm = m * DR;
     const bool want_llr = a.llr != nullptr;
@@ -533,4 +540,5 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
         }
         team_sync();
     }
+    if (threadIdx.x == 0) clock_probe_end(a.clk, clk_stamp);
 }

@@ -95,6 +95,7 @@ struct ldpc_hip_bp {
     // (no synchronisation) and stops queueing once it matches -- rounds queued past that point find nothing to do.
     unsigned *h_flag = nullptr, *d_flag = nullptr;
     unsigned flag_seq = 0;
+    unsigned long long *d_clk = nullptr;  // {shader cycles, constant-rate ticks} summed over the workgroups of the long-running BP kernels (clock_probe_*)
     int32_t schedule = 1;    // ldpc::bp::BpSchedule (bp.hpp:28-32): 0 serial, 1 parallel, 2 serial_relative
     // What the reference keeps in the decoder OBJECT from one decode to the next (bp.hpp:67, 75): serial_schedule_order -- the
     // arrangement serial_relative re-sorts and the random schedule re-shuffles every iteration -- and the generator of the shuffles.

@@ -272,6 +272,7 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     a.llr0 = h->d_llr0;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.next = (unsigned long long *)h->counter.p;
+    a.clk = h->d_clk;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
     a.min_rdeg = h->m;
     for (int i = 0; i < h->m; ++i) a.min_rdeg = std::min(a.min_rdeg, h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i]);
@@ -313,6 +314,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.llr_direct = p.llr_direct ? 1 : 0;
     a.next = (unsigned long long *)h->counter.p;
+    a.clk = h->d_clk;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
     const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
     if (dyn > 48u * 1024u)
@@ -397,6 +399,7 @@ static int edge_work_split(ldpc_hip_bp *h, int rounds, int64_t batch, int64_t gr
     if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
     HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     a.next = (unsigned long long *)h->counter.p;
+    a.clk = h->d_clk;
     int64_t static_per = 1;
     if (h->sw("EDGE_STATIC_PCT") >= 0) static_per = (batch * (h->sw("EDGE_STATIC_PCT") > 100 ? 100 : h->sw("EDGE_STATIC_PCT")) / 100) / groups;
     a.static_per = (int32_t)static_per;

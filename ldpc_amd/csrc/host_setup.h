@@ -103,6 +103,8 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) { std::memset(h->h_flag, 0, 64); e = hipHostGetDevicePointer((void **)&h->d_flag, h->h_flag, 0); }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_clk, 16);
+    if (e == hipSuccess) e = hipMemset(h->d_clk, 0, 16);
     if (e != hipSuccess) {
         ldpc_hip_bp_destroy(h);
         return fail(LDPC_HIP_ERR_DEVICE, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -136,6 +138,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->pin_host) (void)hipHostFree(h->pin_host);
     if (h->h_hist) (void)hipHostFree(h->h_hist);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -295,6 +298,20 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
     float last = 0.f;
     HIPCHK(hipEventElapsedTime(&last, h->ev0, h->ev1));
     *ms = h->accumulated_ms + last;
+    return LDPC_HIP_OK;
+}
+
+int ldpc_hip_bp_clock_probe(ldpc_hip_bp *h, uint64_t *cycles, uint64_t *ticks, double *tick_hz) {
+    if (!h || !cycles || !ticks || !tick_hz) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(hipMemcpy(v, h->d_clk, 16, hipMemcpyDeviceToHost));
+    int khz = 0;
+    HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+    *cycles = v[0];
+    *ticks = v[1];
+    *tick_hz = (double)khz * 1e3;
     return LDPC_HIP_OK;
 }
 

@@ -123,6 +123,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.handoff_list = (int32_t *)h->handoff_list.p;
         a.total_tiles = (int32_t)tiles;
         a.handoff_threshold = handoff;
+        a.clk = h->d_clk;
         HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
 
         // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,

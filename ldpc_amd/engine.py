@@ -167,6 +167,19 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_last_phase_ms(self._h, C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
+    def clock_probe(self):
+        """(shader cycles, constant-rate ticks, tick rate in Hz) accumulated by the workgroups of this handle's long-running BP kernels
+        so far (``ldpc_hip_bp_clock_probe``; waits for the stream).  Take differences around a timed region: see ``clock_ghz``."""
+        c, t, hz = C.c_uint64(0), C.c_uint64(0), C.c_double(0.0)
+        _lib.check(self._lib.ldpc_hip_bp_clock_probe(self._h, C.byref(c), C.byref(t), C.byref(hz)))
+        return int(c.value), int(t.value), float(hz.value)
+
+    @staticmethod
+    def clock_ghz(before, after):
+        """Average shader clock (GHz) of the BP kernels that ran between two ``clock_probe()`` readings, or None if none did."""
+        dc, dt = after[0] - before[0], after[1] - before[1]
+        return dc / dt * after[2] / 1e9 if dt > 0 and dc > 0 else None
+
     # -- data path --------------------------------------------------------------------------------
     def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False, osd=False):
         """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
