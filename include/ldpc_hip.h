@@ -209,8 +209,13 @@ int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
  * iteration first_pass_iters + 1 (a tile moves all 64 lanes' messages until its slowest syndrome is done; after the
  * compaction the tiles hold live lanes only).  There "automatic" prices a cut at every iteration against the plain run with
  * the iteration histogram the previous decode on the handle left behind, and runs plain when that says so or says nothing
- * yet -- no work is wasted where nothing converges.  (Reading that histogram means a streamed *_async decode first waits for
- * the previous decode on the same handle; a batch decoded in several chunks falls back to starting the second pass afresh.) */
+ * yet -- no work is wasted where nothing converges.  Nothing of this waits for the device (the *_async entry points stay
+ * asynchronous): the histogram is used only once its copy is SEEN to have landed (a look at an event, never a wait -- decodes
+ * queued back to back are steered by the last one that did land), and the second pass is queued at once for the most rows
+ * there can be: the device lists the unconverged rows, counts them, and every kernel of the second pass reads that count and
+ * reaches the caller's arrays through the list (no rows are copied out and back; no extra message memory: the compacted state
+ * is gathered into the first pass's check_to_bit array, which is dead by then).  A batch that does not fit in one chunk of
+ * device memory runs plain. */
 int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
 /* Serial schedule kernels: bits that share no check commute, so the schedule is cut into levels of mutually check-disjoint
  * bits (level = 1 + the highest level among the EARLIER bits sharing a check) and a workgroup runs a tile level by level

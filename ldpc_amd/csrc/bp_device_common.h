@@ -56,6 +56,12 @@ struct BpArgs {
     // 1: the bit pass of iteration max_iter still writes the bit_to_check messages (a first pass whose state a second pass carries
     // on, decode_stream_repacked).  0: nobody reads them -- the last bit pass only forms the log-ratios (no tanh, no message stores)
     int32_t keep_state;
+    // Rows known to the device only (second pass of a compacted decode, host_stream.h: decode_stream_repacked).  rows_dev (if not null):
+    // [0] the number of rows of this launch, [1] its number of 64-row tiles -- they override `batch` and `total_tiles`, and workgroups
+    // beyond the last tile leave at once (the grid is sized for the most rows there can be).  row_map (if not null): row r of the launch
+    // is row row_map[r] of the caller's `iters` / `conv`.
+    const unsigned *rows_dev;
+    const int32_t *row_map;
     // shader-clock probe (clock_probe_*, below): {cycles, constant-rate ticks} summed over this kernel's workgroups, or nullptr
     unsigned long long *clk;
 };

@@ -221,10 +221,11 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
     if (wave == 0) {
         if (mine) st->lane_iter[lane] = it;
         const int64_t b = tile * LDPC_WAVE + lane;
-        if (over && b < a.bp.batch) {
+        if (over && b < (a.bp.rows_dev ? (int64_t)a.bp.rows_dev[0] : a.bp.batch)) {
+            const int64_t row = a.bp.row_map ? (int64_t)a.bp.row_map[b] : b;
             const bool cv = ((ndone >> lane) & 1ull) != 0;
-            if (a.bp.iters) a.bp.iters[b] = cv ? (mine ? it : st->lane_iter[lane]) : a.bp.max_iter;  // bp.hpp:304
-            if (a.bp.conv) a.bp.conv[b] = cv ? 1 : 0;
+            if (a.bp.iters) a.bp.iters[row] = cv ? (mine ? it : st->lane_iter[lane]) : a.bp.max_iter;  // bp.hpp:304
+            if (a.bp.conv) a.bp.conv[row] = cv ? 1 : 0;
         }
     }
     if (threadIdx.x == 0) {

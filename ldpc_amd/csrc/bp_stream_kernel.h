@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
     const int nwaves = (int)(blockDim.x >> 6);
     const int64_t tile = blockIdx.x;
     const int m = a.m, n = a.n, nnz = a.nnz;
+    if (a.rows_dev && tile >= (int64_t)sload(a.rows_dev + 1)) return;  // (rows known to the device only: this tile does not exist)
 
     const int32_t *__restrict__ row_ptr = a.row_ptr;
     const int32_t *__restrict__ col_idx = a.col_idx;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
 
     bool llr_each = false;  // tile-uniform: posteriors are stored by every bit pass (set at the first convergence event)
     // lanes beyond the batch (partial last tile) are born "done"
-    const int64_t valid = a.batch - tile * LDPC_WAVE;
+    const int64_t valid = (a.rows_dev ? (int64_t)sload(a.rows_dev) : a.batch) - tile * LDPC_WAVE;
     uint64_t done = valid >= LDPC_WAVE ? 0ull : ~((1ull << valid) - 1ull);
     const uint64_t never = a.invalid[tile];
     int my_iter = 0;  // meaningful in wave 0: iteration at which this lane's syndrome converged
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
         // kernels below spread its remaining iterations over the whole chip.
         if (a.handoff_threshold > 0 && it < a.max_iter) {
             if (threadIdx.x == 0)
-                red_i = a.total_tiles - (int)__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                red_i = (a.rows_dev ? (int)a.rows_dev[1] : a.total_tiles) - (int)__hip_atomic_load(&a.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (red_i <= a.handoff_threshold) {
                 TileState *stt = a.state + tile;
@@ -327,10 +328,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
 
     if (wave == 0) {
         const int64_t b = tile * LDPC_WAVE + lane;
-        if (b < a.batch) {
+        if (b < (a.rows_dev ? (int64_t)a.rows_dev[0] : a.batch)) {
+            const int64_t row = a.row_map ? (int64_t)a.row_map[b] : b;
             const bool cv = ((done >> lane) & 1ull) != 0;
-            if (a.iters) a.iters[b] = cv ? my_iter : a.max_iter;  // bp.hpp:304
-            if (a.conv) a.conv[b] = cv ? 1 : 0;
+            if (a.iters) a.iters[row] = cv ? my_iter : a.max_iter;  // bp.hpp:304
+            if (a.conv) a.conv[row] = cv ? 1 : 0;
         }
     }
     if (threadIdx.x == 0 && a.counters) atomicAdd(&a.counters[0], 1u);

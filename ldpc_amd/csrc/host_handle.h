@@ -51,7 +51,7 @@ struct DeviceBuf {  // grow-only device allocation
 // Measurement / test switches (none changes a result; profiles/README.md lists them).  They live in the handle: seeded ONCE, at
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
-static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF", "REPACK_RESTART",
+static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
                                              "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
@@ -80,11 +80,13 @@ struct ldpc_hip_bp {
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
     DeviceBuf d_edge0;       // [n] initial edge values of the streamed kernel (BpArgs::edge0)
     // continuation of a first pass (decode_stream_repacked): decode_device takes its message state from here and counts on from cont_it_start
-    double *cont_A = nullptr;
+    double *cont_A = nullptr, *cont_C = nullptr;  // its bit_to_check (compacted) / check_to_bit arrays
     int32_t cont_it_start = 0;
+    const int32_t *cont_row_map = nullptr;        // its rows in the caller's arrays (BpArgs::row_map)
+    const unsigned *cont_rows_dev = nullptr;      // {rows, tiles} on the device (BpArgs::rows_dev)
+    int64_t cont_grid_tiles = 0;                  // grid.y of its tile-looping kernels (an estimate; they loop)
     bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
     int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
-    DeviceBuf rp_msg;
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
     DeviceBuf e_partner, e_kind, e_scol, e_prior;
     int32_t handoff = -1;    // straggler hand-off threshold in tiles: -1 auto (256), 0 off
@@ -130,6 +132,8 @@ struct ldpc_hip_bp {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;  // ev_mid: end of the persistent kernel, when one ran
+    hipEvent_t evp0 = nullptr, evp1 = nullptr, evp_mid = nullptr;  // the same of the first pass of a two-pass decode (decode_stream_repacked)
+    bool timed_prev = false, timed_prev_mid = false;
     hipEvent_t ev_done = nullptr;  // end of the last call that queued work on `stream` (orders a change of stream after it)
     bool work_queued = false;
     bool timed = false, timed_mid = false;
@@ -160,6 +164,9 @@ struct ldpc_hip_bp {
     hipEvent_t ev_hist = nullptr;    // the copy has landed
     bool hist_pending = false;
     int32_t hist_max_iter = 0;
+    unsigned hist_landed[256] = {};  // the last histogram whose copy was SEEN complete (never waited for)
+    bool hist_landed_valid = false;
+    int32_t hist_landed_max_iter = 0;
     int32_t repack_iters = -1;                                      // first-pass iterations: -1 auto (max_iter / 8), 0 = no repacking
     DeviceBuf soft_S, soft_in, soft_out;                             // soft-syndrome decoding: scaled analog syndromes, staging
     DeviceBuf b8_in, b8_out, b8_synd, b8_dec, obs_row_ptr, obs_col_idx;  // bit-packed shot I/O and the observables matrix

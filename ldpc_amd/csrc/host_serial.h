@@ -458,6 +458,7 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     else soft_kern = level_waves ? bp_softinfo_level_kernel<0, 0> : bp_softinfo_kernel<0, 0>;
     if (lds > 48u * 1024u)
         HIPCHK(hipFuncSetAttribute((const void *)soft_kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->timed_prev = h->timed_prev_mid = false;
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed = false;

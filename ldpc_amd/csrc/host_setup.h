@@ -99,6 +99,9 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_mid);
+    if (e == hipSuccess) e = hipEventCreate(&h->evp0);
+    if (e == hipSuccess) e = hipEventCreate(&h->evp1);
+    if (e == hipSuccess) e = hipEventCreate(&h->evp_mid);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_hist);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
@@ -119,7 +122,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->msgA, &h->msgC, &h->par, &h->nzm, &h->invalid, &h->dec, &h->dcur, &h->llr_t,
-                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->d_edge0, &h->rp_msg, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
+                         &h->st_synd, &h->st_dec, &h->st_llr, &h->st_iters, &h->st_conv, &h->st_misc, &h->osd_llr, &h->osd_conv, &h->osd_packed, &h->osd_scratch, &h->sp_hist, &h->sp_iters, &h->osd_list, &h->osd_counters, &h->osd_status, &h->osd_fix_synd, &h->osd_fix_list, &h->osd_fix_counters, &h->osd_fix_scratch, &h->rel_ord, &h->rel_dbit, &h->sched_orders, &h->sched_order0, &h->lvl_ptr, &h->lvl_bits, &h->rp_synd, &h->rp_dec, &h->rp_llr, &h->rp_iters, &h->rp_conv, &h->counter, &h->w_rdeg, &h->w_cdeg, &h->w_col, &h->w_apos, &h->w_prior, &h->d_edge0, &h->e_partner, &h->e_kind, &h->e_scol, &h->e_prior, &h->wp_rdeg, &h->wp_col, &h->wp_epos,
                          &h->soft_S, &h->soft_in, &h->soft_out, &h->b8_in, &h->b8_out, &h->b8_synd, &h->b8_dec, &h->obs_row_ptr, &h->obs_col_idx,
                          &h->tile_state, &h->handoff_list})
         b->release();
@@ -135,6 +138,9 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+    if (h->evp0) (void)hipEventDestroy(h->evp0);
+    if (h->evp1) (void)hipEventDestroy(h->evp1);
+    if (h->evp_mid) (void)hipEventDestroy(h->evp_mid);
     if (h->ev_hist) (void)hipEventDestroy(h->ev_hist);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
@@ -298,6 +304,10 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
     float last = 0.f;
     HIPCHK(hipEventElapsedTime(&last, h->ev0, h->ev1));
     *ms = h->accumulated_ms + last;
+    if (h->timed_prev) {  // the first pass of a two-pass decode (recorded earlier on the same stream: complete by now)
+        HIPCHK(hipEventElapsedTime(&last, h->evp0, h->evp1));
+        *ms += last;
+    }
     return LDPC_HIP_OK;
 }
 
@@ -325,6 +335,11 @@ int ldpc_hip_bp_last_phase_ms(ldpc_hip_bp *h, float *persistent_ms, float *per_p
     if (h->timed && h->timed_mid) {
         float last = 0.f;
         HIPCHK(hipEventElapsedTime(&last, h->ev0, h->ev_mid));
+        pers += last;
+    }
+    if (h->timed_prev && h->timed_prev_mid) {
+        float last = 0.f;
+        HIPCHK(hipEventElapsedTime(&last, h->evp0, h->evp_mid));
         pers += last;
     }
     *persistent_ms = pers;

@@ -17,6 +17,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
                          double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
+    if (!h->cont_A) h->timed_prev = h->timed_prev_mid = false;  // (a second pass keeps the first pass's events: ldpc_hip_bp_last_kernel_ms adds them)
     if (h->schedule == 0 || h->schedule == 2) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
     if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22) && batch < (1ll << 30)) {  // (32-bit syndrome indices in the work pools)
         // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
@@ -88,6 +89,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
     h->timed = false;
     h->timed_mid = false;
     hipStream_t st = h->stream;
+    // second pass of a compacted decode: its rows are known to the device only -- `batch` is the most there can be, the kernels read the
+    // real count (cont_rows_dev) and reach the caller's rows through cont_row_map; the grids of the tile-looping kernels follow an estimate
+    const int32_t *row_map = h->cont_A ? h->cont_row_map : nullptr;
+    const unsigned *rows_dev = h->cont_A ? h->cont_rows_dev : nullptr;
+    if (h->cont_A && chunk < tiles_total) return fail(LDPC_HIP_ERR_NOMEM, "internal: the second pass of a compacted decode must be one chunk");
 
     for (int64_t t0 = 0; t0 < tiles_total; t0 += chunk) {
         const int64_t tiles = (tiles_total - t0 < chunk) ? tiles_total - t0 : chunk;
@@ -96,10 +102,11 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 
         HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
         HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)tiles, st));
+        const unsigned loop_tiles = rows_dev ? (unsigned)(h->cont_grid_tiles < tiles ? (h->cont_grid_tiles > 0 ? h->cont_grid_tiles : 1) : tiles) : (unsigned)tiles;
         if (h->m > 0) {
-            dim3 g((unsigned)((h->m + 255) / 256), (unsigned)tiles);
+            dim3 g((unsigned)((h->m + 255) / 256), loop_tiles);
             hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd + b0 * h->m, nb, h->m,
-                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p);
+                               (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p, row_map, rows_dev);
         }
         BpArgs a = {};
         a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter;
@@ -109,7 +116,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge;
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p;
-        if (h->cont_A) { a.A = h->cont_A + (size_t)t0 * (size_t)h->nnz * LDPC_WAVE; a.it_start = h->cont_it_start; }
+        if (h->cont_A) { a.A = h->cont_A; a.C = h->cont_C; a.it_start = h->cont_it_start; a.rows_dev = rows_dev; a.row_map = row_map; }
         a.keep_state = (h->keep_state || h->on("KEEP_LAST_MESSAGES")) ? 1 : 0;
         a.par = (const uint64_t *)h->par.p; a.nzm = (const uint64_t *)h->nzm.p;
         a.invalid = (const uint64_t *)h->invalid.p;
@@ -157,6 +164,13 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         }
         h->timed_mid = false;
         HIPCHK(hipEventRecord(h->ev0, st));
+        if (h->cont_A) {
+            // the listed rows' message state after the first pass, lane by lane, into dense tiles (inside this pass's timed region)
+            const int epw = 16;
+            const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), loop_tiles);
+            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)h->cont_C, row_map, (int64_t)0, h->nnz, epw, h->cont_A, rows_dev);
+            HIPCHK(hipGetLastError());
+        }
         SpreadArgs sa = {};
         sa.bp = a;
         sa.host_flag = h->d_flag;
@@ -165,7 +179,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         // batch skips the persistent kernel (sa.n_tiles >= 0), otherwise the kernels read it from counters[1]
         unsigned grid_tiles = 0;
         int first_round = 1;  // a tile parked by the persistent kernel has completed >= 1 iteration
-        if (handoff > 0 && tiles <= handoff && h->max_iter - a.it_start > 1) {
+        if (handoff > 0 && tiles <= handoff && h->max_iter - a.it_start > 1 && !rows_dev) {
             // so few tiles that they would each sit on one compute unit: per-pass launches from the start
             grid_tiles = (unsigned)tiles;
             sa.n_tiles = (int32_t)tiles;
@@ -242,13 +256,13 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
         }
 
         if (h->n > 0) {
-            dim3 g((unsigned)((h->n + 255) / 256), (unsigned)tiles);
+            dim3 g((unsigned)((h->n + 255) / 256), loop_tiles);
             hipLaunchKernelGGL(unpack_decoding_kernel, g, dim3(256), 0, st,
-                               (const uint64_t *)h->dec.p, nb, h->n, decoding + b0 * h->n);
+                               (const uint64_t *)h->dec.p, nb, h->n, decoding + b0 * h->n, row_map, rows_dev);
             if (llr) {
-                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), (unsigned)tiles);
+                dim3 gt((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), loop_tiles);
                 hipLaunchKernelGGL(transpose_llr_kernel, gt, dim3(256), 0, st,
-                                   (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n);
+                                   (const double *)h->llr_t.p, nb, h->n, llr + (size_t)b0 * h->n, row_map, rows_dev);
             }
         }
         HIPCHK(hipGetLastError());
@@ -270,17 +284,30 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 // gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) / 4 of an iteration (an
 // iteration moves four arrays), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
 // converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
-static int stream_first_pass_length(ldpc_hip_bp *h) {
+static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after) {
+    *live_after = 0.5;
     if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
-    if (!h->hist_pending || h->hist_max_iter != h->max_iter) return 0;
-    if (hipEventSynchronize(h->ev_hist) != hipSuccess) return 0;
+    // The previous decode's histogram, IF its copy has landed -- a look, never a wait (the *_async entry points must not block): a
+    // caller that queues decodes back to back is steered by the last histogram that did land
+    if (h->hist_pending) {
+        const hipError_t q = hipEventQuery(h->ev_hist);
+        if (q == hipSuccess) {
+            std::memcpy(h->hist_landed, h->h_hist, sizeof h->hist_landed);
+            h->hist_landed_max_iter = h->hist_max_iter;
+            h->hist_landed_valid = true;
+            h->hist_pending = false;
+        } else {
+            (void)hipGetLastError();  // hipErrorNotReady is not an error
+        }
+    }
+    if (!h->hist_landed_valid || h->hist_landed_max_iter != h->max_iter) return 0;
     const int full = h->max_iter, top = full < 255 ? full : 255;
     double total = 0;
-    for (int j = 0; j < 256; ++j) total += h->h_hist[j];
+    for (int j = 0; j < 256; ++j) total += h->hist_landed[j];
     if (total <= 0) return 0;
     std::vector<double> F((size_t)top + 1, 0.0);  // F[j]: converged within j iterations
     double acc = 0;
-    for (int j = 1; j <= top; ++j) { acc += h->h_hist[j]; F[(size_t)j] = acc / total; }
+    for (int j = 1; j <= top; ++j) { acc += h->hist_landed[j]; F[(size_t)j] = acc / total; }
     auto Fj = [&](int j) { return F[(size_t)(j < top ? j : top)]; };
     auto tile_runs = [&](int j) { return 1.0 - std::pow(Fj(j - 1), 64.0); };  // still going at iteration j
     double plain = 0;
@@ -299,7 +326,7 @@ static int stream_first_pass_length(ldpc_hip_bp *h) {
             if (r < 1e-9 && j > top) break;
         }
         const double cost = prefix + 0.25 * (1.0 + live) + 0.1 + live * rest;
-        if (cost < best) { best = cost; best_k = k; }
+        if (cost < best) { best = cost; best_k = k; *live_after = live; }
     }
     return best < 0.97 * plain ? best_k : 0;
 }
@@ -319,74 +346,73 @@ static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const ui
     return LDPC_HIP_OK;
 }
 
+// rows_dev[0] = rows listed by osd_collect_kernel, rows_dev[1] = their 64-row tiles (BpArgs::rows_dev)
+__global__ void repack_rows_kernel(const unsigned *__restrict__ counters, unsigned *__restrict__ rows_dev) {
+    const unsigned c = counters[0];
+    rows_dev[0] = c;
+    rows_dev[1] = (c + LDPC_WAVE - 1) / LDPC_WAVE;
+}
+
+// Nothing here waits for the device: the second pass is queued at once, sized for the most rows there can be (all of them), and
+// finds out on the device how many rows the first pass left -- osd_collect_kernel lists them, repack_rows_kernel turns the count
+// into rows / tiles, every kernel of the second pass reads those (BpArgs::rows_dev) and reaches the caller's arrays through the
+// list (BpArgs::row_map), so no row is copied out and back.  No extra message memory either: the compacted bit_to_check state is
+// gathered into the first pass's check_to_bit array (dead by then -- every iteration starts by rewriting it) and the second
+// pass uses the first pass's bit_to_check array as ITS check_to_bit array.
 static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                   double *llr, int32_t *iters, uint8_t *conv) {
     const int full = h->max_iter;
-    const size_t B = (size_t)batch, m1 = (size_t)h->m, n1 = (size_t)h->n;
+    const size_t B = (size_t)batch;
     int rc;
     if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
-    const int k1 = stream_first_pass_length(h);
+    double live = 0.5;
+    int k1 = stream_first_pass_length(h, &live);
+    const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    if (k1 >= 2 && k1 < full) {
+        // the compaction needs the whole batch's message state resident (one chunk); else decode plainly
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t per_tile = 2 * sizeof(double) * (size_t)h->nnz * LDPC_WAVE + (llr ? sizeof(double) * (size_t)h->n * LDPC_WAVE : 0) + 16 * (size_t)(h->m + h->n + 1);
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        if ((double)per_tile * (double)tiles1 > (double)(free_b + have) * 0.85 || tiles1 > 32768 || (h->max_chunk_tiles > 0 && tiles1 > h->max_chunk_tiles) || h->nnz == 0) k1 = 0;
+    }
     if (k1 < 2 || k1 >= full) {
         if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false))) return rc;
         return stream_leave_histogram(h, iters, conv, batch);
     }
-    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
     h->max_iter = k1;
     h->keep_state = true;
     rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
     h->keep_state = false;
     h->max_iter = full;
     if (rc) return rc;
+    if (h->last_chunk_tiles < tiles1) return fail(LDPC_HIP_ERR_DEVICE, "internal: the first pass of a compacted decode was chunked");
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
-    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
-    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
+    if ((rc = h->osd_counters.ensure(4 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 4 * sizeof(unsigned), h->stream));
     hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
                        (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
-    HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
-    const int64_t cnt = (int64_t)h->h_counters[2];
-    if (cnt > 0) {
-        float ms1 = 0.f;
-        (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
-        const size_t C = (size_t)cnt;
-        if ((rc = h->rp_synd.ensure(C * m1)) || (rc = h->rp_dec.ensure(C * n1)) || (rc = h->rp_iters.ensure(C * 4)) ||
-            (rc = h->rp_conv.ensure(C)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
-        const int32_t *list = (const int32_t *)h->osd_list.p;
-        auto grid = [](size_t items) { return flat_grid(items); };
-        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
-        HIPCHK(hipGetLastError());
-        // the listed rows' message state after k1 iterations, lane by lane, into dense tiles -- possible when the first pass kept the
-        // whole batch's messages resident (one chunk) and ran the streamed kernels (they leave bit_to_check in msgA)
-        const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE, tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
-        const size_t per_tile = sizeof(double) * (size_t)h->nnz * LDPC_WAVE;
-        bool carry_on = h->last_chunk_tiles >= tiles1 && h->nnz > 0 && !h->on("REPACK_RESTART");
-        if (carry_on && h->rp_msg.ensure(per_tile * (size_t)tiles2)) { carry_on = false; (void)hipGetLastError(); }
-        if (carry_on) {
-            const int epw = 16;
-            const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)tiles2);
-            HIPCHK(hipEventRecord(h->ev0, h->stream));  // (the compaction belongs to this decode's kernel time)
-            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, h->stream, (const double *)h->msgA.p, list, cnt, h->nnz, epw, (double *)h->rp_msg.p);
-            HIPCHK(hipEventRecord(h->ev1, h->stream));
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventSynchronize(h->ev1));
-            float gms = 0.f;
-            HIPCHK(hipEventElapsedTime(&gms, h->ev0, h->ev1));
-            ms1 += gms;
-            h->cont_A = (double *)h->rp_msg.p;
-            h->cont_it_start = k1;
-        }
-        rc = decode_device(h, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
-                           (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, false);
-        h->cont_A = nullptr;
-        h->cont_it_start = 0;
-        if (rc) return rc;
-        h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
-        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * n1), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
-        if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * n1), dim3(256), 0, h->stream, (const double *)h->rp_llr.p, list, cnt, h->n, llr);
-        hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
-        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
-        HIPCHK(hipGetLastError());
-    }
+    hipLaunchKernelGGL(repack_rows_kernel, dim3(1), dim3(1), 0, h->stream, (const unsigned *)h->osd_counters.p, (unsigned *)h->osd_counters.p + 2);
+    HIPCHK(hipGetLastError());
+    // the first pass's events stay readable while the second pass records its own (ldpc_hip_bp_last_kernel_ms adds both; nobody waits here)
+    std::swap(h->ev0, h->evp0);
+    std::swap(h->ev1, h->evp1);
+    std::swap(h->ev_mid, h->evp_mid);
+    h->timed_prev = h->timed;
+    h->timed_prev_mid = h->timed_mid;
+    h->cont_A = (double *)h->msgC.p;   // compacted bit_to_check state (gathered inside decode_device)
+    h->cont_C = (double *)h->msgA.p;   // the gather's source, then the second pass's check_to_bit array
+    h->cont_it_start = k1;
+    h->cont_row_map = (const int32_t *)h->osd_list.p;
+    h->cont_rows_dev = (const unsigned *)h->osd_counters.p + 2;
+    // grids of the tile-looping kernels: the rows the histogram expects + a margin (they loop, so any count is handled)
+    h->cont_grid_tiles = (int64_t)(live * 1.25 * (double)tiles1) + 8;
+    rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+    h->cont_A = h->cont_C = nullptr;
+    h->cont_it_start = 0;
+    h->cont_row_map = nullptr;
+    h->cont_rows_dev = nullptr;
+    if (rc) return rc;
     return stream_leave_histogram(h, iters, conv, batch);
 }

@@ -7,58 +7,74 @@
 // One-dimensional element-wise kernels run grid-stride loops under a capped grid (flat_grid in bp_hip.hip): item counts
 // such as batch * n pass 2^32 for large batches of large codes.
 
+// Rows known to the device only (the second pass of a compacted decode, decode_stream_repacked): `count_dev` (if not null) holds the
+// number of rows and overrides the by-value count; `row_map` (if not null) says which row of the CALLER's arrays row r of the launch
+// is.  The host sizes grid.y from an estimate, so these kernels loop over the tiles that exist.
+__device__ __forceinline__ int64_t rows_of_launch(int64_t batch, const unsigned *count_dev) {
+    return count_dev ? (int64_t)__hip_atomic_load(count_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : batch;
+}
+
 // syndromes [batch][m] u8  ->  par / nzm [tiles][m] u64, invalid [tiles] u64 (pre-zeroed)
-__global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch, int m,
-                                      uint64_t *par, uint64_t *nzm, uint64_t *invalid) {
+__global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch_arg, int m,
+                                      uint64_t *par, uint64_t *nzm, uint64_t *invalid,
+                                      const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t tile = blockIdx.y;
     if (i >= m) return;
-    uint64_t p = 0, z = 0, inv = 0;
-    const int64_t b0 = tile * LDPC_WAVE;
-    for (int l = 0; l < LDPC_WAVE; ++l) {
-        const int64_t b = b0 + l;
-        if (b < batch) {
-            const uint8_t v = synd[b * m + i];
-            p |= (uint64_t)(v & 1u) << l;
-            z |= (uint64_t)(v != 0u) << l;
-            inv |= (uint64_t)(v > 1u) << l;
+    const int64_t batch = rows_of_launch(batch_arg, count_dev);
+    for (int64_t tile = blockIdx.y; tile * LDPC_WAVE < batch; tile += gridDim.y) {
+        uint64_t p = 0, z = 0, inv = 0;
+        const int64_t b0 = tile * LDPC_WAVE;
+        for (int l = 0; l < LDPC_WAVE; ++l) {
+            const int64_t b = b0 + l;
+            if (b < batch) {
+                const uint8_t v = synd[(row_map ? (int64_t)row_map[b] : b) * m + i];
+                p |= (uint64_t)(v & 1u) << l;
+                z |= (uint64_t)(v != 0u) << l;
+                inv |= (uint64_t)(v > 1u) << l;
+            }
         }
+        par[tile * m + i] = p;
+        nzm[tile * m + i] = z;
+        if (inv) atomicOr((unsigned long long *)&invalid[tile], (unsigned long long)inv);
     }
-    par[tile * m + i] = p;
-    nzm[tile * m + i] = z;
-    if (inv) atomicOr((unsigned long long *)&invalid[tile], (unsigned long long)inv);
 }
 
 // dec [tiles][n] u64 -> decoding [batch][n] u8
-__global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch, int n,
-                                       uint8_t *out) {
+__global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch_arg, int n,
+                                       uint8_t *out, const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t tile = blockIdx.y;
     if (j >= n) return;
-    const uint64_t v = dec[tile * n + j];
-    const int64_t b0 = tile * LDPC_WAVE;
-    for (int l = 0; l < LDPC_WAVE; ++l) {
-        const int64_t b = b0 + l;
-        if (b < batch) out[b * n + j] = (uint8_t)((v >> l) & 1ull);
+    const int64_t batch = rows_of_launch(batch_arg, count_dev);
+    for (int64_t tile = blockIdx.y; tile * LDPC_WAVE < batch; tile += gridDim.y) {
+        const uint64_t v = dec[tile * n + j];
+        const int64_t b0 = tile * LDPC_WAVE;
+        for (int l = 0; l < LDPC_WAVE; ++l) {
+            const int64_t b = b0 + l;
+            if (b < batch) out[(row_map ? (int64_t)row_map[b] : b) * n + j] = (uint8_t)((v >> l) & 1ull);
+        }
     }
 }
 
 // llr_t [tiles][n][64] f64 -> llr [batch][n] f64, 64x64 tiles through LDS
 __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__restrict__ llr_t,
-                                                            int64_t batch, int n, double *out) {
+                                                            int64_t batch_arg, int n, double *out,
+                                                            const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     __shared__ double tilebuf[LDPC_WAVE][LDPC_WAVE + 1];
     const int j0 = blockIdx.x * LDPC_WAVE;
-    const int64_t tile = blockIdx.y;
     const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
-    for (int r = 0; r < 16; ++r) {
-        const int jj = r * 4 + hi;
-        if (j0 + jj < n) tilebuf[jj][lo] = llr_t[((size_t)tile * n + j0 + jj) * LDPC_WAVE + lo];
-    }
-    __syncthreads();
-    for (int r = 0; r < 16; ++r) {
-        const int l = r * 4 + hi;
-        const int64_t b = tile * LDPC_WAVE + l;
-        if (b < batch && j0 + lo < n) out[(size_t)b * n + j0 + lo] = tilebuf[lo][l];
+    const int64_t batch = rows_of_launch(batch_arg, count_dev);
+    for (int64_t tile = blockIdx.y; tile * LDPC_WAVE < batch; tile += gridDim.y) {
+        for (int r = 0; r < 16; ++r) {
+            const int jj = r * 4 + hi;
+            if (j0 + jj < n) tilebuf[jj][lo] = llr_t[((size_t)tile * n + j0 + jj) * LDPC_WAVE + lo];
+        }
+        __syncthreads();
+        for (int r = 0; r < 16; ++r) {
+            const int l = r * 4 + hi;
+            const int64_t b = tile * LDPC_WAVE + l;
+            if (b < batch && j0 + lo < n) out[(size_t)(row_map ? (int64_t)row_map[b] : b) * n + j0 + lo] = tilebuf[lo][l];
+        }
+        __syncthreads();  // (the buffer is refilled for the next tile)
     }
 }
 
@@ -171,16 +187,19 @@ __global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__r
 // message state of listed syndromes, lane by lane, out of the 64-syndrome tiles of a first pass into dense tiles: syndrome
 // list[r] (tile list[r] / 64, lane list[r] % 64) becomes lane r % 64 of tile r / 64; src, dst: [tiles][nnz][64] doubles.
 // One wavefront per (destination tile, edge): 64 gathered 8-byte loads (the live lanes of a source row share sectors), one 512-byte store.
-__global__ void __launch_bounds__(256) gather_lane_state_kernel(const double *__restrict__ src, const int32_t *__restrict__ list, int64_t count,
-                                                                int nnz, int edges_per_wave, double *__restrict__ dst) {
+__global__ void __launch_bounds__(256) gather_lane_state_kernel(const double *__restrict__ src, const int32_t *__restrict__ list, int64_t count_arg,
+                                                                int nnz, int edges_per_wave, double *__restrict__ dst, const unsigned *count_dev = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = blockIdx.y, r = tile * 64 + lane;
-    const bool live = r < count;
-    const int64_t b = live ? (int64_t)list[r] : 0;
-    const double *from = src + ((b >> 6) * (int64_t)nnz) * 64 + (b & 63);
-    double *to = dst + (tile * (int64_t)nnz) * 64 + lane;
-    const int e0 = (blockIdx.x * 4 + wave) * edges_per_wave;
-    for (int e = e0; e < e0 + edges_per_wave && e < nnz; ++e) to[(int64_t)e * 64] = live ? from[(int64_t)e * 64] : 0.0;
+    const int64_t count = rows_of_launch(count_arg, count_dev);
+    for (int64_t tile = blockIdx.y; tile * 64 < count; tile += gridDim.y) {
+        const int64_t r = tile * 64 + lane;
+        const bool live = r < count;
+        const int64_t b = live ? (int64_t)list[r] : 0;
+        const double *from = src + ((b >> 6) * (int64_t)nnz) * 64 + (b & 63);
+        double *to = dst + (tile * (int64_t)nnz) * 64 + lane;
+        const int e0 = (blockIdx.x * 4 + wave) * edges_per_wave;
+        for (int e = e0; e < e0 + edges_per_wave && e < nnz; ++e) to[(int64_t)e * 64] = live ? from[(int64_t)e * 64] : 0.0;
+    }
 }
 
 template <class T>
