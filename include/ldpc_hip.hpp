@@ -126,20 +126,26 @@ public:
     // decoding (osd.hpp:103-187) of method `osd_method` (1 OSD_0, 2 OSD_E, 3 OSD_CS; osd.hpp:18-23) and `osd_order`
     int osd_method = 1, osd_order = 0;
     bool decode_batch(const uint8_t *syndromes, int64_t batch, bool want_llr = true, bool osd = false) {
+        decoding_batch.resize((size_t)batch * bit_count);
+        if (want_llr) log_prob_ratios_batch.resize((size_t)batch * bit_count);
+        iterations_batch.resize((size_t)batch);
+        converge_batch.resize((size_t)batch);
+        return decode_batch_into(syndromes, batch, decoding_batch.data(), want_llr ? log_prob_ratios_batch.data() : nullptr,
+                                 iterations_batch.data(), converge_batch.data(), osd);
+    }
+    // the same into the caller's arrays ([batch][n] decoding, [batch][n] log-ratios or null, [batch] iterations, [batch] converge):
+    // what a binding that hands out NumPy arrays wants -- the results cross the PCIe link straight into them (large batches: in
+    // pinned, double-buffered chunks that overlap the kernels, ldpc_hip.h)
+    bool decode_batch_into(const uint8_t *syndromes, int64_t batch, uint8_t *dec_out, double *llr_out, int32_t *iters_out,
+                           uint8_t *conv_out, bool osd = false) {
         if (!sync_()) return false;
         if (osd) {
             last_status = each_([&](ldpc_hip_bp *h) { return ldpc_hip_bp_set_osd(h, osd_method, osd_order); });
             if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
         }
-        decoding_batch.assign((size_t)batch * bit_count, 0);
-        if (want_llr) log_prob_ratios_batch.assign((size_t)batch * bit_count, 0.0);
-        iterations_batch.assign((size_t)batch, 0);
-        converge_batch.assign((size_t)batch, 0);
         auto fn = osd ? ldpc_hip_bposd_decode_batch : ldpc_hip_bp_decode_batch;
-        double *llr_out = want_llr ? log_prob_ratios_batch.data() : nullptr;
-        last_status = mh_ ? ldpc_hip_bp_multi_decode_batch(mh_, osd ? 1 : -1, syndromes, batch, decoding_batch.data(), llr_out,
-                                                           iterations_batch.data(), converge_batch.data())
-                          : fn(h_, syndromes, batch, decoding_batch.data(), llr_out, iterations_batch.data(), converge_batch.data());
+        last_status = mh_ ? ldpc_hip_bp_multi_decode_batch(mh_, osd ? 1 : -1, syndromes, batch, dec_out, llr_out, iters_out, conv_out)
+                          : fn(h_, syndromes, batch, dec_out, llr_out, iters_out, conv_out);
         if (last_status != LDPC_HIP_OK) { last_error = ldpc_hip_last_error(); return false; }
         osd_status_batch.clear();
         if (osd && !mh_) {  // (the sharded object keeps one status array per GPU; ask the handles for those)

@@ -44,6 +44,7 @@ cdef extern from "ldpc_hip.hpp" namespace "ldpc_hip":
         int osd_order
         vector[uint8_t]& decode(vector[uint8_t]& syndrome)
         cbool decode_batch(const uint8_t *syndromes, int64_t batch, cbool want_llr, cbool osd0) nogil
+        cbool decode_batch_into(const uint8_t *syndromes, int64_t batch, uint8_t *dec, double *llr, int32_t *iters, uint8_t *conv, cbool osd0) nogil
 
 
 cdef class CyBpCore:
@@ -153,33 +154,28 @@ cdef class CyBpCore:
         if b == 0:
             return (np.zeros((0, self.n), np.uint8), np.zeros((0, self.n)) if want_llr else None,
                     np.zeros(0, np.int32), np.zeros(0, bool))
+        # the results go straight into the arrays that are handed out (no intermediate C++ vectors: at 65 536 x 10 000 those were
+        # 6 GB zero-filled and copied once more)
+        dec = np.empty((b, self.n), np.uint8)
+        llr = np.empty((b, self.n), np.float64) if want_llr else None
+        it = np.empty(b, np.int32)
+        cv = np.empty(b, np.uint8)
+        cdef uint8_t[:, ::1] dec_view = dec
+        cdef double[:, ::1] llr_view
+        cdef int32_t[::1] it_view = it
+        cdef uint8_t[::1] cv_view = cv
+        cdef uint8_t dummy = 0
+        cdef uint8_t *dec_p = &dummy  # (n = 0: the C ABI wants a non-null pointer; nothing is written)
+        cdef double *llr_p = NULL
+        if self.n > 0:
+            dec_p = &dec_view[0, 0]
+            if want_llr:
+                llr_view = llr
+                llr_p = &llr_view[0, 0]
         with nogil:
-            ok = self.bpd.decode_batch(&syndromes[0, 0], b, c_llr, c_osd)
+            ok = self.bpd.decode_batch_into(&syndromes[0, 0], b, dec_p, llr_p, &it_view[0], &cv_view[0], c_osd)
         if not ok:
             raise RuntimeError(self.bpd.last_error.decode("utf-8", "replace"))
-        # copy the C++ vectors out through typed memory views (element-wise vector -> list -> array conversion costs
-        # hundreds of microseconds at n = 10 000)
-        cdef size_t total = <size_t>b * <size_t>self.n
-        cdef uint8_t[::1] dec_view
-        cdef double[::1] llr_view
-        cdef int32_t[::1] it_view
-        cdef uint8_t[::1] cv_view
-        dec = np.empty((b, self.n), np.uint8)
-        if total:
-            dec_view = <uint8_t[:total]> &self.bpd.decoding_batch[0]
-            dec.reshape(-1)[:] = dec_view
-        llr = None
-        if want_llr:
-            llr = np.empty((b, self.n), np.float64)
-            if total:
-                llr_view = <double[:total]> &self.bpd.log_prob_ratios_batch[0]
-                llr.reshape(-1)[:] = llr_view
-        it = np.empty(b, np.int32)
-        it_view = <int32_t[:b]> &self.bpd.iterations_batch[0]
-        it[:] = it_view
-        cv = np.empty(b, np.uint8)
-        cv_view = <uint8_t[:b]> &self.bpd.converge_batch[0]
-        cv[:] = cv_view
         self.osd_status = None
         if osd0 and self.bpd.osd_status_batch.size() == <size_t>b:
             self.osd_status = np.empty(b, np.uint8)

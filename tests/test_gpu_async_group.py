@@ -14,12 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _assert_same(got, want):
-    """Outputs equal bit for bit (log-ratios may hold NaN -- inf - inf in the reference's arithmetic too --, so compare their bits)."""
+    """Outputs equal bit for bit; among the log-ratios any NaN matches any NaN (inf - inf in the reference's arithmetic too: the sign /
+    payload of a NaN is not a result -- it depends on which of two bit-identical routes a 64-syndrome tile took, oracle.bits_equal)."""
     import torch
     for g, w in zip(got, want):
         if g.dtype == torch.float64:
-            g, w = g.view(torch.int64), w.view(torch.int64)
-        assert bool(torch.equal(g, w))
+            assert bool(((g.view(torch.int64) == w.view(torch.int64)) | (g.isnan() & w.isnan())).all())
+        else:
+            assert bool(torch.equal(g, w))
 
 
 def _headline_engine(p=0.09, max_iter=50):
