@@ -167,6 +167,7 @@ def parse_args():
     ap.add_argument("--no-llr", action="store_true", help="skip the LLR output (not the BASELINE workload)")
     ap.add_argument("--repack", type=int, default=-1, help="first-pass iterations of the repacked schedule (-1 = steered by the previous decode, 0 = off; diagnostic)")
     ap.add_argument("--secondary", type=int, default=1, help="1: also time configs[2] and configs[4] (N = 1 only); 0: skip")
+    ap.add_argument("--host-io", type=int, default=1, help="1: also time the same batch through BpDecoder.decode_batch with pageable NumPy in / out (N = 1 only); 0: skip")
     ap.add_argument("--dry-ranks", action="store_true", help="launcher self-test: every rank joins a gloo group, rank 0 prints the ranks it saw; no GPU work")
     ap.add_argument("--force-launch", action="store_true", help="go through torch.distributed.run even for --gpus 1 (exercises the N > 1 code path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="diagnostic for a one-GPU box: the N ranks all use cuda:0 and form a gloo group (RCCL refuses two ranks on "
@@ -303,6 +304,36 @@ def secondary_configs(dev, steps):
             entry["counters_match_this_build"] = src["kernel_sources_sha16"] == kernel_sources_sha16()
         out.append(entry)
         eng.close()
+    return out
+
+
+def host_io_leg(h, args, alpha, synd_dev, dec_dev, it_dev, device_value):
+    """The drop-in's own I/O path (_bp_decoder.pyx:642-695 is NumPy in, NumPy out): the SAME batch as pageable host arrays through
+    `BpDecoder.decode_batch` -- validation, the all-zero-row shortcut, H2D, kernels, D2H, all inside the timed call -- without and
+    with the log-ratio output (655 MB resp. 5.9 GB of results at B = 65 536), next to the device-resident rate."""
+    from ldpc_amd.bp_decoder import BpDecoder
+    s_host = synd_dev.cpu().numpy()
+    dec = BpDecoder(h, error_rate=args.p, max_iter=args.max_iter, bp_method=args.bp_method, ms_scaling_factor=alpha, input_vector_type="syndrome")
+    B = s_host.shape[0]
+    out = {"api": "ldpc_amd.bp_decoder.BpDecoder.decode_batch((B, m) uint8 ndarray, pageable) -> (B, n) ndarray", "batch": B, "unit": "syndromes/s"}
+    dec.decode_batch(s_host[: min(B, 4096)], want_log_prob_ratios=False)  # module load, handle, first allocations
+    for key, want in (("no_llr", False), ("with_llr", True)):
+        dec.decode_batch(s_host, want_log_prob_ratios=want)  # warm-up of this shape: pinned staging buffers
+        ms = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            got = dec.decode_batch(s_host, want_log_prob_ratios=want)
+            ms.append((time.perf_counter() - t0) * 1e3)
+        best = min(ms)
+        out[key] = {"value": B / best * 1e3, "ms": best, "ms_calls": [round(v, 2) for v in ms], "vs_device_resident": B / best * 1e3 / device_value}
+        if key == "no_llr":  # what came back is what the device-resident decode produced
+            ok = bool(np.array_equal(dec.iter_batch, it_dev.cpu().numpy()))
+            rows = np.sort(np.random.default_rng(99).choice(B, size=min(B, 2048), replace=False))
+            ok = ok and bool(np.array_equal(got[rows], dec_dev.cpu().numpy()[rows]))
+            out["equal_to_device_resident_outputs"] = ok
+    out["note"] = ("whole call timed on the host clock, best of two after a warm-up; pageable arrays move through pinned double-buffered chunks "
+                   "that overlap the kernels (include/ldpc_hip.h: ldpc_hip_bp_decode_batch with host pointers); chunks of <= 16 384 rows take the "
+                   "per-pass kernels, and the two-pass compaction does not apply to them")
     return out
 
 
@@ -654,6 +685,14 @@ def run(args, real_stdout, stage) -> None:
             res["cpu_baseline"] = "N = 1 only" if world > 1 else None  # (None: --cpu-sample 0 asked for no CPU leg)
             if world > 1:
                 res["roofline"]["traffic_note"] = "PMC traffic is collected at N = 1 only (profiles/hbm_traffic.json)"
+        if world == 1 and not grouped and args.host_io and method_id == 0:
+            stage[0] = "host_io"
+            try:
+                res["host_io"] = host_io_leg(h, args, alpha, synd, dec, it, res["value"])
+                if not res["host_io"].get("equal_to_device_resident_outputs", False):
+                    res["parity_failed"] = True
+            except Exception as exc:  # the headline line must not be lost to this leg
+                res["host_io"] = {"error": repr(exc)[:300]}
         if world == 1 and args.secondary and method_id == 0:
             early = None
             try:  # the headline code at its early-exit operating point (p = 0.05), same engine, same buffers

@@ -468,6 +468,13 @@ class BpDecoderBase:
             self._engine_sched = (self._schedule, tuple(int(v) for v in self._serial_schedule_order))
 
 
+def _zero_rows(vec: np.ndarray) -> np.ndarray:
+    """(B,) bool: rows of a C-contiguous (B, w) uint8 array that are all zero (eight bytes at a time where the row length allows)."""
+    if vec.shape[1] and vec.shape[1] % 8 == 0:
+        return ~vec.view(np.uint64).any(axis=1)
+    return ~vec.any(axis=1)
+
+
 class BpDecoder(BpDecoderBase):
     """Belief-propagation decoder for binary linear codes (drop-in for ``ldpc.BpDecoder``, pyx:581-709)."""
 
@@ -583,17 +590,30 @@ class BpDecoder(BpDecoderBase):
             self._pull_schedule_state()
             return dec
         dtype = input_vectors.dtype
-        vec = np.ascontiguousarray(np.asarray(input_vectors).astype(np.uint8))
+        vec = np.ascontiguousarray(np.asarray(input_vectors).astype(np.uint8, copy=False))
         synd = vec if as_syndrome else eng.mulvec_batch(vec)
-        dec, llr, it, cv = self._decode_numpy(synd, want_llr=want_log_prob_ratios)
+        # which rows take the all-zero shortcut (pyx:679-681): a scan of the whole input -- on a helper thread for large batches, while
+        # the device decodes (the C call releases the GIL)
+        zero_box = []
+        scan = None
+        if vec.size >= (1 << 24):
+            import threading
+            scan = threading.Thread(target=lambda: zero_box.append(_zero_rows(vec)))
+            scan.start()
+        try:
+            dec, llr, it, cv = self._decode_numpy(synd, want_llr=want_log_prob_ratios)
+        finally:
+            if scan is not None:
+                scan.join()
         if not as_syndrome:
             dec ^= vec
-        zero = ~vec.any(axis=1)
-        dec[zero] = 0
-        cv[zero] = True
-        it[zero] = 0
-        if llr is not None:
-            llr[zero] = 0.0
+        zero = zero_box[0] if zero_box else _zero_rows(vec)
+        if zero.any():
+            dec[zero] = 0
+            cv[zero] = True
+            it[zero] = 0
+            if llr is not None:
+                llr[zero] = 0.0
         self.converge_batch, self.iter_batch, self.log_prob_ratios_batch = cv, it, llr
         ran = np.flatnonzero(~zero)
         if len(ran):
@@ -605,7 +625,7 @@ class BpDecoder(BpDecoderBase):
         if len(vec):
             self._converge = bool(cv[-1])
         self._pull_schedule_state()
-        return dec.astype(dtype)
+        return dec.astype(dtype, copy=False)
 
     @property
     def decoding(self) -> np.ndarray:

@@ -94,6 +94,106 @@ int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
     return decode_batch_staged(h, 1, synd, batch, decoding, llr, iters, conv);
 }
 
+// Copy between pinned staging and the caller's pageable arrays, split over a few threads: the caller's pages are usually untouched
+// (np.empty), and first-touch faults -- not memory bandwidth -- bound a single thread at 2 - 4 GB/s.
+static void host_copy_parallel(void *dst, const void *src, size_t bytes) {
+    const size_t slice_min = (size_t)8 << 20;
+    int nt = (int)(bytes / slice_min);
+    if (nt > 8) nt = 8;
+    if (nt < 2) { std::memcpy(dst, src, bytes); return; }
+    const size_t per = ((bytes / (size_t)nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int q = 1; q < nt; ++q) {
+        const size_t off = per * (size_t)q;
+        if (off >= bytes) break;
+        const size_t len = bytes - off < per ? bytes - off : per;
+        th.emplace_back([=]() { std::memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    std::memcpy(dst, src, per < bytes ? per : bytes);
+    for (auto &t : th) t.join();
+}
+
+// A large batch whose buffers all live in (pageable) host memory -- the reference API's only mode: NumPy in, NumPy out
+// (_bp_decoder.pyx:642-695).  One H2D copy, the kernels, four D2H copies in sequence leave the GPU idle while 0.3 - 6 GB cross PCIe
+// through the runtime's own staging.  Instead the batch is cut into chunks of whole tiles that move through pinned double buffers:
+// while the kernels decode chunk c, chunk c + 1's syndromes are already on their way in (copy stream), chunk c - 1's results are on
+// their way out (another copy stream) and the host thread copies chunk c - 2's results from the pinned buffer into the caller's
+// arrays.  Rows are independent under the parallel and the fixed-order serial schedule, so chunking changes no result (the
+// schedules that carry state from row to row are not chunked).  ldpc_hip_bp_last_kernel_ms then describes the LAST chunk only.
+static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                                  double *llr, int32_t *iters, uint8_t *conv, int64_t rows) {
+    auto &P = h->pipe;
+    const size_t m = (size_t)h->m, n = (size_t)h->n;
+    auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+    const size_t R = (size_t)rows;
+    const size_t o_llr = up(R * n), o_it = o_llr + (llr ? up(R * n * 8) : 0), o_cv = o_it + (iters ? up(R * 4) : 0), out_bytes = o_cv + (conv ? up(R) : 0);
+    const size_t in_bytes = up(R * m ? R * m : 1);
+    int rc;
+    if (!P.s_in) {
+        HIPCHK(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
+        for (int q = 0; q < 2; ++q) {
+            HIPCHK(hipEventCreateWithFlags(&P.ev_in[q], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&P.ev_cmp[q], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&P.ev_out[q], hipEventDisableTiming));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));  // (an earlier asynchronous call may still use the workspace)
+    for (int q = 0; q < 2; ++q) {
+        if (P.pin_in_cap < in_bytes) {
+            if (P.pin_in[q]) { (void)hipHostFree(P.pin_in[q]); P.pin_in[q] = nullptr; }
+            HIPCHK(hipHostMalloc((void **)&P.pin_in[q], in_bytes, hipHostMallocDefault));
+        }
+        if (P.pin_out_cap < out_bytes) {
+            if (P.pin_out[q]) { (void)hipHostFree(P.pin_out[q]); P.pin_out[q] = nullptr; }
+            HIPCHK(hipHostMalloc((void **)&P.pin_out[q], out_bytes, hipHostMallocDefault));
+        }
+        if ((rc = P.d_in[q].ensure(in_bytes)) || (rc = P.d_dec[q].ensure(R * n ? R * n : 1)) || (llr && (rc = P.d_llr[q].ensure(R * n * 8 ? R * n * 8 : 1))) ||
+            (rc = P.d_it[q].ensure(R * 4)) || (rc = P.d_cv[q].ensure(R))) return rc;
+    }
+    if (P.pin_in_cap < in_bytes) P.pin_in_cap = in_bytes;
+    if (P.pin_out_cap < out_bytes) P.pin_out_cap = out_bytes;
+    const int64_t chunks = (batch + rows - 1) / rows;
+    auto rows_of = [&](int64_t c) { return c == chunks - 1 ? batch - c * rows : rows; };
+    auto drain = [&](int64_t c) -> int {  // chunk c's results: pinned buffer -> the caller's arrays
+        const int q = (int)(c & 1);
+        const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+        HIPCHK(hipEventSynchronize(P.ev_out[q]));
+        host_copy_parallel(decoding + b0 * n, P.pin_out[q], r * n);
+        if (llr) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
+        if (iters) std::memcpy(iters + b0, P.pin_out[q] + o_it, r * 4);
+        if (conv) std::memcpy(conv + b0, P.pin_out[q] + o_cv, r);
+        return LDPC_HIP_OK;
+    };
+    for (int64_t c = 0; c < chunks; ++c) {
+        const int q = (int)(c & 1);
+        const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+        // in: pin_in[q] is free once chunk c - 2's upload has completed
+        if (c >= 2) HIPCHK(hipEventSynchronize(P.ev_in[q]));
+        host_copy_parallel(P.pin_in[q], synd + b0 * m, r * m);
+        if (c >= 2) HIPCHK(hipStreamWaitEvent(P.s_in, P.ev_cmp[q], 0));  // d_in[q] was chunk c - 2's input
+        if (r * m) HIPCHK(hipMemcpyAsync(P.d_in[q].p, P.pin_in[q], r * m, hipMemcpyHostToDevice, P.s_in));
+        HIPCHK(hipEventRecord(P.ev_in[q], P.s_in));
+        // compute: after this chunk's upload, and after chunk c - 2's results have left d_dec[q] ...
+        HIPCHK(hipStreamWaitEvent(h->stream, P.ev_in[q], 0));
+        if (c >= 2) HIPCHK(hipStreamWaitEvent(h->stream, P.ev_out[q], 0));
+        if ((rc = decode_device(h, (const uint8_t *)P.d_in[q].p, (int64_t)r, (uint8_t *)P.d_dec[q].p, llr ? (double *)P.d_llr[q].p : nullptr,
+                                (int32_t *)P.d_it[q].p, (uint8_t *)P.d_cv[q].p))) return rc;
+        HIPCHK(hipEventRecord(P.ev_cmp[q], h->stream));
+        // out: pin_out[q] is free (chunk c - 2 was drained by this thread in the previous turn of the loop)
+        HIPCHK(hipStreamWaitEvent(P.s_out, P.ev_cmp[q], 0));
+        if (r * n) HIPCHK(hipMemcpyAsync(P.pin_out[q], P.d_dec[q].p, r * n, hipMemcpyDeviceToHost, P.s_out));
+        if (llr && r * n) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_llr, P.d_llr[q].p, r * n * 8, hipMemcpyDeviceToHost, P.s_out));
+        if (iters) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_it, P.d_it[q].p, r * 4, hipMemcpyDeviceToHost, P.s_out));
+        if (conv) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_cv, P.d_cv[q].p, r, hipMemcpyDeviceToHost, P.s_out));
+        HIPCHK(hipEventRecord(P.ev_out[q], P.s_out));
+        if (c >= 1 && (rc = drain(c - 1))) return rc;  // while chunk c runs
+    }
+    if ((rc = drain(chunks - 1))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LDPC_HIP_OK;
+}
+
 static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                double *llr, int32_t *iters, uint8_t *conv) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
@@ -141,6 +241,19 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
             if (conv) std::memcpy(conv, h->pin_host + o_cv, B);
             return LDPC_HIP_OK;
         }
+    }
+    // everything on the host, BP only, rows independent of one another, and enough of them for several chunks: pipelined
+    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && osd < 0 && !h->random_serial && h->schedule != 2 &&
+        !h->on("NO_HOST_PIPELINE")) {
+        // chunk: ~256 MiB of results, between 1 024 and 16 384 rows (whole tiles), or what LDPC_HIP_HOST_CHUNK_ROWS says
+        const size_t per_row = n * (llr ? 9 : 1) + m + 5;
+        int64_t rows = (int64_t)(((size_t)256 << 20) / (per_row ? per_row : 1));
+        if (rows > 16384) rows = 16384;
+        if (rows < 1024) rows = 1024;
+        if (h->sw("HOST_CHUNK_ROWS") > 0) rows = h->sw("HOST_CHUNK_ROWS");
+        rows = (rows + LDPC_WAVE - 1) / LDPC_WAVE * LDPC_WAVE;
+        if (batch >= 3 * rows && (size_t)batch * per_row >= ((size_t)64 << 20))
+            return decode_batch_pipelined(h, synd, batch, decoding, llr, iters, conv, rows);
     }
     if (h_synd) {
         if ((rc = h->st_synd.ensure(B * m ? B * m : 1))) return rc;

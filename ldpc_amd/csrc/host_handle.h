@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <random>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -52,7 +53,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "HOST_CHUNK_ROWS"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -145,6 +146,15 @@ struct ldpc_hip_bp {
     // no copy commands at all, one launch sequence and one wait
     unsigned char *pin_host = nullptr, *pin_dev = nullptr;
     static constexpr size_t PIN_BYTES = 512u * 1024u;
+    // large calls with host buffers: pinned double-buffered chunks, so that PCIe and the host's own copies overlap the kernels
+    // (host_decode_abi.h: decode_batch_pipelined)
+    struct HostPipe {
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        unsigned char *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+        size_t pin_in_cap = 0, pin_out_cap = 0;
+        DeviceBuf d_in[2], d_dec[2], d_llr[2], d_it[2], d_cv[2];
+    } pipe;
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)

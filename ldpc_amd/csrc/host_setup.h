@@ -146,6 +146,16 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->pin_host) (void)hipHostFree(h->pin_host);
+    for (int q = 0; q < 2; ++q) {
+        if (h->pipe.pin_in[q]) (void)hipHostFree(h->pipe.pin_in[q]);
+        if (h->pipe.pin_out[q]) (void)hipHostFree(h->pipe.pin_out[q]);
+        if (h->pipe.ev_in[q]) (void)hipEventDestroy(h->pipe.ev_in[q]);
+        if (h->pipe.ev_cmp[q]) (void)hipEventDestroy(h->pipe.ev_cmp[q]);
+        if (h->pipe.ev_out[q]) (void)hipEventDestroy(h->pipe.ev_out[q]);
+        for (DeviceBuf *b : {&h->pipe.d_in[q], &h->pipe.d_dec[q], &h->pipe.d_llr[q], &h->pipe.d_it[q], &h->pipe.d_cv[q]}) b->release();
+    }
+    if (h->pipe.s_in) (void)hipStreamDestroy(h->pipe.s_in);
+    if (h->pipe.s_out) (void)hipStreamDestroy(h->pipe.s_out);
     if (h->h_hist) (void)hipHostFree(h->h_hist);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;

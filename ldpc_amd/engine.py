@@ -220,10 +220,10 @@ class HipBpEngine:
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"syndromes must have shape (B, {self.m})")
         b = s.shape[0]
-        dec = np.zeros((b, self.n), np.uint8)
-        llr = np.zeros((b, self.n), np.float64) if want_llr else None
-        it = np.zeros(b, np.int32)
-        cv = np.zeros(b, np.uint8)
+        dec = np.empty((b, self.n), np.uint8)  # (every element is written by the call; zero-filling 6 GB first costs as much as the decode)
+        llr = np.empty((b, self.n), np.float64) if want_llr else None
+        it = np.empty(b, np.int32)
+        cv = np.empty(b, np.uint8)
         fn = (self._lib.ldpc_hip_bposd_decode_batch if osd else
               self._lib.ldpc_hip_bposd0_decode_batch if osd0 else self._lib.ldpc_hip_bp_decode_batch)
         _lib.check(fn(self._h, s.ctypes.data, b, dec.ctypes.data, llr.ctypes.data if want_llr else None,

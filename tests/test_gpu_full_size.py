@@ -94,7 +94,7 @@ def test_bench_config4_geometry_under_a_process_group_of_one():
     this box can hold -- torch.distributed.run, an RCCL group, a 131 072-syndrome shard, the gather of bit-packed rows, per-rank parity."""
     from test_gpu_async_group import _bench
     got = _bench(["--gpus", "1", "--force-launch", "--batch-per-gpu", "131072", "--steps", "2", "--warmup", "1", "--rank-parity", "64",
-                  "--secondary", "0"], timeout=1200)
+                  "--secondary", "0", "--cpu-sample", "0", "--host-io", "0"], timeout=1200)
     assert got["n_gpus"] == 1 and got["rccl"]["ranks"] == 1 and got["rccl"]["backend"] == "nccl"
     assert got["config"]["batch_per_gpu"] == 131072 and got["config"]["global_batch"] == 131072
     assert got["gather"]["rows_on_rank0"] == 131072

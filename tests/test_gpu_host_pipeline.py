@@ -1,0 +1,66 @@
+"""Host buffers through ldpc_hip_bp_decode_batch: large batches move in pinned double-buffered chunks that overlap the kernels
+(csrc/host_decode_abi.h: decode_batch_pipelined).  Chunking must change nothing: every row, log-ratio bits included, equals the
+one-shot staged path and the device-resident decode."""
+import numpy as np
+import pytest
+
+from golden_util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("method,alpha,schedule", [(0, 1.0, "parallel"), (1, 0.625, "parallel"), (1, 0.9, "serial")])
+def test_pipelined_host_path_equals_the_one_shot_path(method, alpha, schedule, oracle_built):
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.regular_ldpc_code(2400, 3, 6, seed=8)
+    n, p, B = 2400, 0.055, 20000 + 37  # (a ragged last chunk and a ragged last tile)
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), 12, method, alpha)
+    eng.set_small_code_kernel(0)
+    if schedule == "serial":
+        eng.set_schedule(0, None)
+    s_dev = eng.gen_bsc_syndromes(3, p, shot0=0, shots=B, device="cuda:0")
+    s = s_dev.cpu().numpy()
+    s[5] = 0            # an all-zero row
+    s[B - 1, 0] = 2     # a byte above 1: never converges
+    want = [t.cpu().numpy() if t is not None else None for t in eng.decode_batch(torch.from_numpy(s).cuda(), want_llr=True)]
+    eng.set_debug_switch("NO_HOST_PIPELINE", 1)
+    one = eng.decode_batch(s, want_llr=True)
+    eng.set_debug_switch("NO_HOST_PIPELINE", -1)
+    for rows in (1024, 4096, -1):
+        eng.set_debug_switch("HOST_CHUNK_ROWS", rows)
+        for want_llr in (True, False):
+            got = eng.decode_batch(s, want_llr=want_llr)
+            tag = f"chunk rows {rows} llr {want_llr}"
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[0], one[0]), tag
+            assert np.array_equal(got[2], want[2]) and np.array_equal(got[3].astype(bool), want[3].astype(bool)), tag
+            if want_llr:
+                assert bits_equal(got[1], want[1]) and bits_equal(got[1], one[1]), tag
+            else:
+                assert got[1] is None
+    # against the CPU checker on a sample (the pipelined path is what BpDecoder.decode_batch(numpy) runs)
+    rows = np.r_[0:24, B - 24:B]
+    o = oracle_built.BpOracle(h, error_rate=p, max_iter=12, bp_method=method, ms_scaling_factor=alpha)
+    ref = o.decode_serial_batch(s[rows]) if schedule == "serial" else o.decode_batch(s[rows])
+    assert np.array_equal(got[0][rows], ref[0]) and np.array_equal(got[2][rows], ref[2])
+    eng.close()
+
+
+def test_bpdecoder_numpy_batch_is_the_pipelined_path_and_keeps_the_shortcut(oracle_built):
+    """`BpDecoder.decode_batch` with a NumPy array of another dtype: results in that dtype, the all-zero rows take the reference's
+    shortcut (pyx:679-681), the rest equal the device-resident decode."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.bp_decoder import BpDecoder
+    h = codes.regular_ldpc_code(3000, 3, 6, seed=2)
+    dec = BpDecoder(h, error_rate=0.04, max_iter=10, bp_method="product_sum", input_vector_type="syndrome")
+    eng = dec._get_engine()
+    B = 50000
+    s = eng.gen_bsc_syndromes(9, 0.04, shot0=0, shots=B, device="cuda:0").cpu().numpy().astype(np.int64)
+    s[[3, 777, B - 1]] = 0
+    out = dec.decode_batch(s, want_log_prob_ratios=False)
+    assert out.dtype == np.int64 and out.shape == (B, 3000)
+    assert not out[[3, 777, B - 1]].any() and dec.converge_batch[[3, 777, B - 1]].all() and not dec.iter_batch[[3, 777, B - 1]].any()
+    ref = dec.decode_batch(torch.from_numpy(s.astype(np.uint8)).cuda(), want_log_prob_ratios=False)
+    assert np.array_equal(out, ref.cpu().numpy())

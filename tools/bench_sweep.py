@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 for argset in sys.argv[1:]:
-    cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"] + argset.split()
+    cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--host-io", "0"] + argset.split()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:

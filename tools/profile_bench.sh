@@ -8,7 +8,7 @@ TAG=${1:-r}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --cpu-sample 0 --secondary 0 $*"
+ARGS="--steps 1 --warmup 1 --cpu-sample 0 --secondary 0 --host-io 0 $*"
 echo "== stats: bench.py $ARGS" > "$OUT/log.txt"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python bench.py $ARGS >> "$OUT/log.txt" 2>&1
 i=0
