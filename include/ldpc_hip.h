@@ -168,9 +168,11 @@ int ldpc_hip_bposd0_decode_batch_async(ldpc_hip_bp *h, const uint8_t *syndromes,
  * non-pivot columns; a candidate replaces the current solution only if its weight sum_j x_j log(1 / p_j)
  * (added up in ascending j, as osd.hpp:171-176 does) is STRICTLY smaller.  osd_order == 0 takes the OSD-0
  * branch whatever the method (osd.hpp:114).  Outputs as for ldpc_hip_bposd0_decode_batch.
- * Limits: the LDS bound of OSD-0 (plus 8 m + 4 n bytes); OSD_E osd_order <= 24; OSD_CS osd_order <= 64 (pairs
- * whose second index reaches past the k = n - rank non-pivot columns are skipped -- undefined behaviour in the
- * reference, osd.hpp:92-96); otherwise LDPC_HIP_ERR_UNSUPPORTED.  Syndromes outside the image of H: see below.
+ * Limits: the LDS bound of OSD-0 (plus 8 m + 4 n bytes); OSD_E osd_order <= 24 (2^24 candidates per syndrome; the reference
+ * itself keeps 2^order strings of k bytes in memory and warns above 15), else LDPC_HIP_ERR_UNSUPPORTED.  OSD_CS takes any
+ * osd_order: the k weight-one strings, then the pairs (i, j), i < j < osd_order, among ALL k = n - rank non-pivot columns
+ * (pairs whose second index reaches past k are skipped -- the reference writes past its candidate string there, osd.hpp:92-96,
+ * undefined behaviour).  Syndromes outside the image of H: see below.
  */
 int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order);
 /*

@@ -2,7 +2,7 @@
 
 BP runs in the HIP kernels; rows BP leaves unconverged get ordered-statistics decoding on the device as well
 (``ldpc_hip_bposd_decode_batch``): OSD_0 (``osd.hpp:110-117``), OSD_E and OSD_CS (``osd.hpp:119-187``; OSD_E up to
-order 24, OSD_CS up to order 64).  There is no CPU fallback.
+order 24, OSD_CS at any order).  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -102,10 +102,10 @@ class BpOsdDecoder(BpDecoderBase):
         if self._osd_method == OSD_OFF:
             raise NotImplementedError("osd_method='OSD_OFF': the reference dereferences an unset LU object here (osd.hpp:63, 110); "
                                       "choose OSD_0, OSD_E or OSD_CS.")
-        if (self._osd_method == EXHAUSTIVE and self._osd_order > 24) or (self._osd_method == COMBINATION_SWEEP and self._osd_order > 64):
+        if self._osd_method == EXHAUSTIVE and self._osd_order > 24:
             raise NotImplementedError(
                 f"osd_method={self.osd_method} with osd_order={self._osd_order} is not available on the MI355X path "
-                "(OSD_E up to order 24, OSD_CS up to order 64); there is no CPU fallback.")
+                "(OSD_E up to order 24 = 16.7 million candidates per syndrome; OSD_CS takes any order); there is no CPU fallback.")
 
     def _decode_osd(self, synd2d, want_llr=True, force_osd0=False):
         """BP + OSD through the active backend with this decoder's osd_method / osd_order."""

@@ -21,8 +21,6 @@ int ldpc_hip_bp_set_osd(ldpc_hip_bp *h, int32_t osd_method, int32_t osd_order) {
     if (osd_method == 1 && osd_order != 0) return fail(LDPC_HIP_ERR_INVALID, "osd_method OSD_0 requires osd_order 0");  // pyx:225-226
     if (osd_method == 2 && osd_order > 24)
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_E with osd_order > 24 (more than 16 million candidates per syndrome) is not available");
-    if (osd_method == 3 && osd_order > 64)
-        return fail(LDPC_HIP_ERR_UNSUPPORTED, "OSD_CS with osd_order > 64 is not available on the device");
     h->osd_method = osd_method;
     h->osd_order = osd_order;
     return LDPC_HIP_OK;
@@ -97,9 +95,10 @@ int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
 // Copy between pinned staging and the caller's pageable arrays, split over a few threads: the caller's pages are usually untouched
 // (np.empty), and first-touch faults -- not memory bandwidth -- bound a single thread at 2 - 4 GB/s.
 static void host_copy_parallel(void *dst, const void *src, size_t bytes) {
-    const size_t slice_min = (size_t)8 << 20;
+    const size_t slice_min = (size_t)4 << 20;
     int nt = (int)(bytes / slice_min);
-    if (nt > 8) nt = 8;
+    static const int nt_max = [] { const unsigned hc = std::thread::hardware_concurrency(); return hc >= 32 ? 16 : hc >= 8 ? (int)(hc / 2) : 2; }();
+    if (nt > nt_max) nt = nt_max;
     if (nt < 2) { std::memcpy(dst, src, bytes); return; }
     const size_t per = ((bytes / (size_t)nt) + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;

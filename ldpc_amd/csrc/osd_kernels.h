@@ -392,14 +392,15 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
 // (sequential FP64 sum of log(1/p_j) over the support), and the first strictly lightest candidate wins.
 struct OsdCandidate {
     uint64_t mask;  // chosen columns among the first 64 non-pivot columns (sorted order)
-    int32_t single; // a chosen non-pivot column beyond the first 64 (OSD_CS weight-one strings), else -1
+    int32_t single; // a chosen non-pivot column beyond the first 64 (OSD_CS weight-one strings, pairs that reach past column 63), else -1
+    int32_t single2; // the second such column of a pair, else -1
     bool valid;
 };
 
 __device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int k, long c) {
     OsdCandidate r;
     r.mask = 0;
-    r.single = -1;
+    r.single = r.single2 = -1;
     r.valid = true;
     const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
     if (method == 2) {  // numbers 1 .. 2^order - 1, bit j -> j-th non-pivot column, bits >= k dropped (util.hpp:12-38)
@@ -412,7 +413,10 @@ __device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int
         while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
         const int j = i + 1 + (int)p;
         if (j >= k) r.valid = false;  // past the candidate string in the reference
-        else r.mask = (1ull << i) | (1ull << j);
+        else {  // (any osd_order <= k: columns below 64 go into the mask, the others are named)
+            if (i < 64) r.mask |= 1ull << i; else r.single = i;
+            if (j < 64) r.mask |= 1ull << j; else if (r.single < 0) r.single = j; else r.single2 = j;
+        }
     }
     return r;
 }
@@ -511,10 +515,14 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
                 const int c = npcol[cd.single];
                 v ^= mat[(size_t)cdi * W + (c >> 6)] >> (c & 63);
             }
+            if (cd.single2 >= 0) {
+                const int c = npcol[cd.single2];
+                v ^= mat[(size_t)cdi * W + (c >> 6)] >> (c & 63);
+            }
             return (v & 1ull) != 0;
         }
         const int q = -1 - cdi;
-        return (q < 64 && ((cd.mask >> (q & 63)) & 1ull)) || q == cd.single;  // (q & 63: the shift is defined whichever way the test is compiled)
+        return (q < 64 && ((cd.mask >> (q & 63)) & 1ull)) || q == cd.single || q == cd.single2;  // (q & 63: the shift is defined whichever way the test is compiled)
     };
     auto weight_of = [&](const OsdCandidate &cd) -> double {
         double acc = 0;
@@ -523,7 +531,7 @@ __global__ void __launch_bounds__(256) osdw_kernel(const OsdArgs a) {
         return acc;
     };
     OsdCandidate none;
-    none.mask = 0; none.single = -1; none.valid = true;
+    none.mask = 0; none.single = none.single2 = -1; none.valid = true;
     const double w0 = weight_of(none);  // the OSD-0 solution (osd.hpp:131-136)
     const long ncand = a.method == 2 ? (1L << a.order) - 1 : (long)k + (long)a.order * (a.order - 1) / 2;
     double best_w = w0;
@@ -701,6 +709,24 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
             valid = j < k;  // past the candidate string in the reference
             return valid ? (1ull << i) | (1ull << j) : 0ull;
         };
+        // osd_order > 64: a pair may sit in any two words of T -- each lane reads the two words of ITS pair (no broadcast any more)
+        auto pair_cols = [&](long p, int &i, int &j) -> bool {  // pair number p of the reference's list (i-major, osd.hpp:91-99) -> i < j; false: past the string
+            i = 0;
+            while (p >= a.order - 1 - i) { p -= a.order - 1 - i; ++i; }
+            j = i + 1 + (int)p;
+            return j < k;
+        };
+        auto weigh_pair = [&](int qi, int qj) -> double {
+            double acc = 0;
+            const int wi = 2 + (qi >> 6), wj = 2 + (qj >> 6), si = qi & 63, sj = qj & 63;
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) {
+                const uint64_t x = (rec_r[(size_t)i * RS + wi] >> si) ^ (rec_r[(size_t)i * RS + wj] >> sj) ^ rec_r[(size_t)i * RS + 1];
+                const double wgt = __builtin_bit_cast(double, rec_r[(size_t)i * RS]);
+                acc += (x & 1ull) ? wgt : 0.0;
+            }
+            return acc;
+        };
         double best_w = weigh_mask(0);  // the OSD-0 solution (osd.hpp:131-136)
         long best_c = -1;               // index in the reference's candidate list; -1: the OSD-0 solution
         const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
@@ -710,12 +736,23 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
                 const double w = weigh_single(v);
                 if (v * 64 + lane < k && w < best_w) { best_w = w; best_c = v * 64 + lane; }  // strict: the first lightest candidate stays (osd.hpp:177)
             }
-            for (long p0 = 0; p0 < npairs; p0 += 64) {
-                const long pp = p0 + lane;
-                bool valid = false;
-                const uint64_t mask = pp < npairs ? pair_mask(pp, valid) : 0ull;
-                const double w = weigh_mask(mask);
-                if (valid && w < best_w) { best_w = w; best_c = k + pp; }
+            if (a.order <= 64) {
+                for (long p0 = 0; p0 < npairs; p0 += 64) {
+                    const long pp = p0 + lane;
+                    bool valid = false;
+                    const uint64_t mask = pp < npairs ? pair_mask(pp, valid) : 0ull;
+                    const double w = weigh_mask(mask);
+                    if (valid && w < best_w) { best_w = w; best_c = k + pp; }
+                }
+            } else {
+                for (long p0 = 0; p0 < npairs; p0 += 64) {
+                    const long pp = p0 + lane;
+                    int qi = 0, qj = 0;
+                    const bool valid = pp < npairs && pair_cols(pp, qi, qj);
+                    if (__ballot(valid) == 0) continue;  // (a whole round past the string: osd_order > k)
+                    const double w = weigh_pair(valid ? qi : 0, valid ? qj : 0);
+                    if (valid && w < best_w) { best_w = w; best_c = k + pp; }
+                }
             }
         } else {  // numbers 1 .. 2^order - 1 (order <= 24), bits >= k dropped (util.hpp:12-38)
             const long total = (1L << a.order) - 1;
@@ -733,14 +770,18 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
             if (other_set && (!mine_set || ow < best_w || (ow == best_w && oc < best_c))) { best_w = ow; best_c = oc; }
         }
         const bool single = a.method == 3 && best_c >= 0 && best_c < k;
+        const bool far_pair = a.method == 3 && best_c >= k && a.order > 64;
         uint64_t win = 0;
-        if (best_c >= 0 && !single) {
+        int wq_i = 0, wq_j = 0;
+        if (far_pair) (void)pair_cols(best_c - k, wq_i, wq_j);
+        else if (best_c >= 0 && !single) {
             bool valid;
             win = a.method == 3 ? pair_mask(best_c - k, valid) : (uint64_t)(best_c + 1) & kmask;
         }
         for (int j = lane; j < n; j += 64) {
             uint64_t x = rec_r[(size_t)j * RS + 1];
             if (single) x ^= rec_r[(size_t)j * RS + 2 + (best_c >> 6)] >> (best_c & 63);
+            else if (far_pair) x ^= (rec_r[(size_t)j * RS + 2 + (wq_i >> 6)] >> (wq_i & 63)) ^ (rec_r[(size_t)j * RS + 2 + (wq_j >> 6)] >> (wq_j & 63));
             else x ^= (uint64_t)__builtin_popcountll(rec_r[(size_t)j * RS + 2] & win);
             a.decoding[b * n + j] = (uint8_t)(x & 1ull);
         }
@@ -1374,7 +1415,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // plane it needs in its own buffer and running at its own pace: first the sets of the first `order` non-pivot columns (entry 0
         // = the empty set = the OSD-0 solution, index -1; then the pairs of OSD_CS, index k + pair, or the numbers of OSD_E), then
         // for OSD_CS the single columns, plane by plane (index q).
-        const long nsets = (a.method == 3 ? npairs : (1L << a.order) - 1) + 1;  // (numbers 1 .. 2^order - 1, order <= 24, bits >= k dropped: util.hpp:12-38)
+        // OSD_CS with osd_order > 64: the pairs reach past T plane 0 -- they are weighed plane pair by plane pair further down, and the
+        // "sets" here shrink to the empty set (the OSD-0 solution)
+        const bool far_pairs = a.method == 3 && a.order > 64;
+        const long nsets = (a.method == 3 ? (far_pairs ? 0 : npairs) : (1L << a.order) - 1) + 1;  // (numbers 1 .. 2^order - 1, order <= 24, bits >= k dropped: util.hpp:12-38)
         const long nchunk = (nsets + 63) >> 6, ntask = nchunk + (a.method == 3 ? KW : 0);
         if (tid == 0) sy[m] = 0;  // the dummy row of the non-pivot columns
         __syncthreads();
@@ -1418,6 +1462,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (live) offer(w, q);
                 }
             }
+            if (far_pairs && wave < A.nplanes) {
+                // pairs (i, j), i < j < min(osd_order, k), block by block of T planes (vi <= vj): plane vi staged in this wavefront's
+                // buffer, plane vj read from the T array itself -- column by column both words are the same for all 64 lanes (one
+                // broadcast LDS read, one single-line memory read); a lane's pair picks its two bits.  Index in the reference's list:
+                // k + i (order - 1) - i (i - 1) / 2 + (j - i - 1) (i-major, osd.hpp:91-99).
+                const int reach = a.order < k ? a.order : k;
+                const int P = (reach + 63) >> 6;
+                long task = 0;
+                for (int vi = 0; vi < P; ++vi) {
+                    const int cnt_i = reach - 64 * vi < 64 ? reach - 64 * vi : 64;
+                    for (int vj = vi; vj < P; ++vj) {
+                        const int cnt_j = reach - 64 * vj < 64 ? reach - 64 * vj : 64;
+                        const int npb = vi == vj ? cnt_i * (cnt_i - 1) / 2 : cnt_i * cnt_j;
+                        for (int e0 = 0; e0 < npb; e0 += 64, ++task) {
+                            if ((int)(task % A.nplanes) != wave) continue;
+                            if (held != -3 - vi) {
+                                for (int r = lane; r < m; r += 64) pl[r] = Tm[(int64_t)vi * m + r];
+                                if (lane == 0) pl[m] = 0;
+                                held = -3 - vi;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            }
+                            const int e = e0 + lane;
+                            const bool valid = e < npb;
+                            int ii = 0, jj = 1;
+                            if (valid) {
+                                if (vi != vj) { ii = e / cnt_j; jj = e - ii * cnt_j; }
+                                else { int pp = e; while (pp >= cnt_i - 1 - ii) { pp -= cnt_i - 1 - ii; ++ii; } jj = ii + 1 + pp; }
+                            }
+                            const int qi = 64 * vi + ii, qj = 64 * vj + jj;
+                            const uint64_t *Tj = Tm + (int64_t)vj * m;
+                            double acc = 0;
+                            for (int i = 0; i < n; ++i) {
+                                const int ci = __builtin_amdgcn_readfirstlane(colinfo[i]);
+                                unsigned bit;
+                                if (ci >= 0) bit = (unsigned)(((pl[ci] >> ii) ^ (Tj[ci] >> jj) ^ (uint64_t)sy[ci]) & 1ull);
+                                else bit = (unsigned)(-1 - ci == qi) | (unsigned)(-1 - ci == qj);
+                                acc += bit ? wt[i] : 0.0;
+                            }
+                            if (valid) offer(acc, (long)k + (long)qi * (a.order - 1) - (long)qi * (qi - 1) / 2 + (qj - qi - 1));
+                        }
+                    }
+                }
+            }
         }
         OSD_WG_CLK(5);  // weighing
         // lightest, then earliest: across the lanes of a wavefront, then across the wavefronts
@@ -1432,8 +1521,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         best_w = sh_w[0]; best_c = sh_c[0];
         for (int w = 1; w < 4; ++w) offer(sh_w[w], sh_c[w]);
         const bool single = a.method == 3 && best_c >= 0 && best_c < k;
+        const bool far_win = far_pairs && best_c >= k;
         uint64_t win = 0;
-        if (best_c >= 0 && !single) {
+        int wq_i = 0, wq_j = 0;
+        if (far_win) {
+            long pp = best_c - k;
+            while (pp >= a.order - 1 - wq_i) { pp -= a.order - 1 - wq_i; ++wq_i; }
+            wq_j = wq_i + 1 + (int)pp;
+        } else if (best_c >= 0 && !single) {
             bool valid;
             win = a.method == 3 ? pair_mask(best_c - k, valid) : (uint64_t)(best_c + 1) & kmask;
         }
@@ -1441,7 +1536,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int j = tid; j < n; j += T) {
             const int ci = colinfo[j];
             bool bit;
-            if (ci >= 0) {
+            if (far_win) {
+                if (ci >= 0) bit = (((Tm[(int64_t)(wq_i >> 6) * m + ci] >> (wq_i & 63)) ^ (Tm[(int64_t)(wq_j >> 6) * m + ci] >> (wq_j & 63)) ^ (uint64_t)sy[ci]) & 1ull) != 0;
+                else bit = -1 - ci == wq_i || -1 - ci == wq_j;
+            } else if (ci >= 0) {
                 const uint64_t tw = KW > 0 ? plw[ci] : 0ull;
                 bit = single ? ((((tw >> (best_c & 63)) & 1ull) != 0) != (sy[ci] != 0))
                              : (((__builtin_popcountll(tw & win) + (int)sy[ci]) & 1) != 0);

@@ -34,6 +34,8 @@ def main():
     s = bsc_syndromes(hx, 21, 0.05, 0, 48)
     run("osdw_cs10_hgp1600_ms12", hx, s, osd_method="osd_cs", osd_order=10, max_iter=12, error_rate=0.05, bp_method="minimum_sum",
         ms_scaling_factor=0.625, note="768 x 1600: [H | s] is 156 KiB bit-packed, beyond LDS")
+    run("osdw_cs100_hgp1600_ms12", hx, s[:16], osd_method="osd_cs", osd_order=100, max_iter=12, error_rate=0.05, bp_method="minimum_sum",
+        ms_scaling_factor=0.625, note="osd_order 100: pairs across T planes 0 and 1 of the workgroup kernel (round 4)")
     run("osdw_e6_hgp1600_ms12", hx, s[:24], osd_method="osd_e", osd_order=6, max_iter=12, error_rate=0.05, bp_method="minimum_sum",
         ms_scaling_factor=0.625)
     rng = np.random.default_rng(7)

@@ -54,6 +54,22 @@ def run(name, h, syndromes, *, osd_method, osd_order, max_iter, error_rate=None,
           f"sweep changed={improved:4d} {os.path.getsize(path) / 1024:8.1f} KiB")
 
 
+def wide_orders(hx, s):
+    """Round 4: OSD_CS orders past 64 (the device's former limit) -- pairs that reach beyond the first 64 non-pivot columns."""
+    run("osdw_cs78_bb144_ps8", hx, s[:96], osd_method="osd_cs", osd_order=78, max_iter=8, error_rate=0.08,
+        note="osd_order = k = 78: every pair of non-pivot columns, 78 + 3003 candidates (register-resident elimination)")
+    run("osdw_cs70_bb144_nonuniform", hx, s[:64], osd_method="osd_cs", osd_order=70, max_iter=8,
+        error_channel=0.02 + 0.12 * ((sm64(13, np.arange(144, dtype=np.uint64)) >> np.uint64(11)).astype(np.float64) / 2.0 ** 53),
+        note="64 < osd_order < k with non-uniform priors")
+    rng = np.random.default_rng(11)
+    m, n = 120, 600
+    h = sp.csr_matrix((np.ones(m * 12, np.uint8), (np.repeat(np.arange(m), 12), rng.integers(0, n, size=m * 12))), shape=(m, n))
+    h.sum_duplicates()
+    h.data[:] = 1
+    run("osdw_cs90_random120x600_ps4", h, bsc_syndromes(h, 9, 0.03, 0, 40), osd_method="osd_cs", osd_order=90, max_iter=4,
+        error_channel=rng.uniform(0.01, 0.06, size=n), note="120 x 600 (k >= 480): the one-wavefront kernel with [H | s] in LDS")
+
+
 def main():
     hx = codes.bivariate_bicycle_hx()
     s = bsc_syndromes(hx, 11, 0.08, 0, 384)
@@ -77,10 +93,15 @@ def main():
         note="order > k = 11: bits of the candidate number beyond the k-th are dropped (util.hpp:12-38)")
     run("osdw_cs11_hamming4_ps2", hm, sh, osd_method="osd_cs", osd_order=11, max_iter=2, error_rate=0.2,
         note="order == k: every pair of non-pivot columns")
+    wide_orders(hx, s)
     hr = codes.ring_code(40)
     run("osdw_cs1_ring40_ps3", hr, bsc_syndromes(hr, 7, 0.12, 0, 128), osd_method="osd_cs", osd_order=1, max_iter=3,
         error_rate=0.12, note="rank-deficient square matrix, k = 1")
 
 
 if __name__ == "__main__":
-    main()
+    if "--wide-only" in sys.argv:
+        hx_ = codes.bivariate_bicycle_hx()
+        wide_orders(hx_, bsc_syndromes(hx_, 11, 0.08, 0, 384))
+    else:
+        main()

@@ -456,7 +456,8 @@ def test_bposdw_golden_fixture(name):
 
 
 @pytest.mark.parametrize("name", ["osdw_cs10_hgp1600_ms12", "osdw_e6_hgp1600_ms12", "osdw_cs8_random400x900_ps6", "osdw_cs10_bb144_ps8",
-                                  "osdw_cs64_bb144_ms8", "osdw_e13_hamming4_ps2"])
+                                  "osdw_cs64_bb144_ms8", "osdw_e13_hamming4_ps2", "osdw_cs100_hgp1600_ms12", "osdw_cs78_bb144_ps8",
+                                  "osdw_cs70_bb144_nonuniform", "osdw_cs90_random120x600_ps4"])
 @pytest.mark.parametrize("unblocked", [False, True])
 def test_workgroup_osd_kernel_variants(name, unblocked, monkeypatch):
     """osd_big_kernel in each of its forms -- working copy in an HBM slot (osd_kernel 2) or in LDS, blocked elimination or the
@@ -477,7 +478,8 @@ def test_workgroup_osd_kernel_variants(name, unblocked, monkeypatch):
 
 
 @pytest.mark.parametrize("planes", ["1", "2", "4"])
-@pytest.mark.parametrize("name", ["osdw_cs10_hgp1600_ms12", "osdw_e6_hgp1600_ms12", "osdw_cs8_random400x900_ps6"])
+@pytest.mark.parametrize("name", ["osdw_cs10_hgp1600_ms12", "osdw_e6_hgp1600_ms12", "osdw_cs8_random400x900_ps6", "osdw_cs100_hgp1600_ms12",
+                                  "osdw_cs90_random120x600_ps4"])
 def test_workgroup_osd_kernel_staged_planes(name, planes, monkeypatch):
     """The workgroup kernel weighs candidates with one, two or four wavefronts (one staged T plane each; fewer where LDS would
     otherwise cost resident workgroups and many rows wait): the same solutions whichever it picks."""
