@@ -423,8 +423,11 @@ def test_bposd_decoder_api():
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="nope")
     with pytest.raises(ValueError):
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_0", osd_order=3)
-    with pytest.raises(NotImplementedError):
-        BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_cs", osd_order=65).decode(c["syndromes"][k])
+    # OSD_CS takes any order since round 4 (pairs among all k = 57 non-pivot columns; second indices past k are skipped -- the
+    # reference writes past its candidate string there): order 65 > k gives what order k gives, and it solves the syndrome
+    wide = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_cs", osd_order=65).decode(c["syndromes"][k])
+    at_k = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_cs", osd_order=57).decode(c["syndromes"][k])
+    assert np.array_equal(wide, at_k) and np.array_equal((c["h"] @ wide) % 2, c["syndromes"][k])
     with pytest.raises(NotImplementedError):
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_e", osd_order=25).decode(c["syndromes"][k])
     with pytest.raises(ValueError):
@@ -506,7 +509,10 @@ def test_bposdw_device_pointers_and_oracle_at_batch(oracle_built):
     want, _, wi, wc = oracle_built.BpOracle(h, error_rate=0.06, max_iter=30).bposd_decode_batch(sh[:768], 3, 10)
     assert np.array_equal(d[:768], want) and np.array_equal(cv.cpu().numpy()[:768].astype(bool), wc)
     with pytest.raises(Exception, match="osd_order"):
-        eng.set_osd(3, 65)
+        eng.set_osd(2, 25)   # OSD_E: 2^25 candidates per syndrome
+    eng.set_osd(3, 65)       # OSD_CS: any order since round 4 (the pairs reach past the first 64 non-pivot columns)
+    wide = eng.decode_batch(s[:256].contiguous(), want_llr=False, osd=True)[0].cpu().numpy()
+    assert np.array_equal(wide, oracle_built.BpOracle(h, error_rate=0.06, max_iter=30).bposd_decode_batch(sh[:256], 3, 65, want_llr=False)[0])
     with pytest.raises(Exception, match="OSD_0"):
         eng.set_osd(1, 2)
 
