@@ -112,6 +112,23 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING 
                 check_row_live<METHOD, MATH, DR>(cur, DR, i * DR, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
                 slot = slot + 1 == RING ? 0 : slot + 1;
             }
+        } else if (DR > 8) {
+            // rows of up to 16 entries in registers: 2 x 16 values for the row and its prefix products leave no room for a second row in
+            // flight (a register double buffer spilled 84 - 1 231 VGPRs here) -- the other wavefronts of the SIMD cover the load latency
+            for (int i = wave; i < m; i += nwaves) {
+                const int rs = sload(row_ptr + i), d = sload(row_ptr + i + 1) - rs;
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
+                if (d <= DR) {
+                    double cur[DR];
+#pragma unroll
+                    for (int k = 0; k < DR; ++k)
+                        if (k < d) cur[k] = At.ld(l8, rs + k);
+                    check_row_live<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
+                } else {
+                    check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
+                }
+            }
         } else {
             // The row's inputs are fetched one row ahead (register double buffer): while the wavefront
             // works on row i its loads for row i + nwaves are already in flight.

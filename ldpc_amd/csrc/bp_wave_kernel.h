@@ -65,7 +65,7 @@ __host__ __device__ inline size_t wave_lds_private(int mp, int np, int DR, bool 
 template <int METHOD, int MATH, int DR, int DC, bool TEAM = false>
 __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     // nodes per lane in flight: min-sum has few live values per node, the transcendental chains of product-sum many
-    constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : 2) : (DR <= 6 ? 2 : 1);
+    constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : DR <= 8 ? 2 : 1) : (DR <= 6 ? 2 : 1);
     // (a team has more wavefronts than the check pass has rounds of 64 U rows -- there are half as many rows as columns --: one row
     // per lane there, so that twice as many wavefronts take part)
     constexpr int UC = TEAM ? 1 : U;
@@ -128,9 +128,13 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     team_sync();
 
     int pool = (int)((blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
+    bool first_turn = true;
     for (;;) {
         int64_t b;
-        if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
+        if (TEAM && a.next == nullptr) {  // no more syndromes than teams (a single decode()): team g takes syndrome g, no counter to reset or visit
+            b = first_turn ? (int64_t)blockIdx.x : a.batch;
+            first_turn = false;
+        } else if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
             if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
             __syncthreads();
             b = team_b;
@@ -337,8 +341,10 @@ __host__ __device__ inline size_t wave_ps_lds_private(int m, int np, int DR, boo
 // TEAM: as for bp_wave_kernel -- the workgroup's wavefronts share one syndrome, each taking rounds of 64 lanes of a phase.  For
 // batches so small that a wavefront decodes only a few syndromes the time is the 50 iterations of the slowest one: a team cuts
 // exactly that.
+// DR > 16 (rows of up to 32 entries: hamming(6) and the like): a row's 2 x 32 prefix / suffix values sit in registers, which needs the
+// register budget of a <= 4-wavefront workgroup (the host launches no more).
 template <int MATH, int DR, int DC, bool TEAM = false>
-__global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
+__global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const WavePsArgs a) {
     constexpr int METHOD = LDPC_HIP_PRODUCT_SUM;
     extern __shared__ __attribute__((aligned(16))) unsigned char wv_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
@@ -405,9 +411,13 @@ __global__ void __launch_bounds__(1024) bp_wave_ps_kernel(const WavePsArgs a) {
     }
 
     int pool = (int)((blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
+    bool first_turn = true;
     for (;;) {
         int64_t b;
-        if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
+        if (TEAM && a.next == nullptr) {  // no more syndromes than teams (a single decode()): team g takes syndrome g, no counter to reset or visit
+            b = first_turn ? (int64_t)blockIdx.x : a.batch;
+            first_turn = false;
+        } else if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
             if (tid == 0) team_b = (long long)atomicAdd(a.next, 1ull);
             __syncthreads();
             b = team_b;

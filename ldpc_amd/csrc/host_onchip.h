@@ -68,17 +68,21 @@ static void pick_wave(int max_row, int max_col, WavePlan &p) {
     if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE(4, 2)
     if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE(4, 4)
     if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE(6, 3)
-    if (max_col <= 4) LDPC_PICK_WAVE(8, 4)
-    LDPC_PICK_WAVE(8, 8)
+    if (max_row <= 8 && max_col <= 4) LDPC_PICK_WAVE(8, 4)
+    if (max_row <= 8) LDPC_PICK_WAVE(8, 8)
+    // rows of up to 16 entries (hamming(5) as a full parity-check matrix): min-sum only -- product-sum takes the lane = entry kernel there
+    // (bp_wave_ps_kernel<., 16 | 32, 8>), and its lane = node form would need more registers than a 16-wavefront workgroup has
+    if constexpr (METHOD == LDPC_HIP_MINIMUM_SUM) LDPC_PICK_WAVE(16, 8)
 #undef LDPC_PICK_WAVE
 }
 
 static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
     WavePlan p;
-    if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 8) return p;
+    if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 16 || h->max_col_deg > 8) return p;
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_wave<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, p);
     else pick_wave<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, p);
+    if (!p.kern) return p;
     p.mp = (h->m + 63) / 64 * 64;
     p.np = (h->n + 63) / 64 * 64;
     const size_t rm = (size_t)p.dr * p.mp, cn = (size_t)p.dc * p.np;
@@ -112,7 +116,7 @@ static WavePlan plan_wave(const ldpc_hip_bp *h, bool forced, bool want_llr, int6
     // surface d = 41 / 31 / 21 25 -> 11 / 24 -> 12.6 / 11.0 -> 10.0 ms, 300 x 600 1.03 -> 0.79 ms; d = 13, 17 (the bit pass of one
     // wavefront is a single round of 64 U columns already) 7 % slower -- hence the second condition.
     const bool ms = h->bp_method == LDPC_HIP_MINIMUM_SUM;
-    const int u = ms ? (p.dr <= 4 ? 4 : 2) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
+    const int u = ms ? (p.dr <= 4 ? 4 : p.dr <= 8 ? 2 : 1) : (p.dr <= 6 ? 2 : 1);  // the kernel's nodes per lane in flight
     // A batch of no more than one syndrome per wavefront slot is about latency: a team (two wavefronts at least) then too --
     // surface d = 9 .. 17, BB144 at 512 / 4 096 syndromes: 1.25 - 1.6x / 1.0 - 1.3x faster, at 65 536 up to 16 % slower.
     const bool team = h->small_mode == 5 || (h->small_mode != 4 && (w < 6 || 2 * p.np > 3 * 64 * u || batch <= 256 * (int64_t)w));
@@ -188,19 +192,25 @@ static void pick_wave_ps(int max_row, int max_col, WavePsPlan &p) {
     if (max_row <= 4 && max_col <= 2) LDPC_PICK_WAVE_PS(4, 2)
     if (max_row <= 4 && max_col <= 4) LDPC_PICK_WAVE_PS(4, 4)
     if (max_row <= 6 && max_col <= 3) LDPC_PICK_WAVE_PS(6, 3)
-    LDPC_PICK_WAVE_PS(8, 4)
+    if (max_row <= 8 && max_col <= 4) LDPC_PICK_WAVE_PS(8, 4)
+    // heavier rows (classical codes given as full parity-check matrices: hamming(5) has rows of 16, hamming(6) of 32): until round 4 these
+    // fell to the workgroup ("slot") kernel, ~11 us of barriers per iteration -- a single decode() of hamming(5) took 230 us
+    if (max_row <= 16) LDPC_PICK_WAVE_PS(16, 8)
+    LDPC_PICK_WAVE_PS(32, 8)
 #undef LDPC_PICK_WAVE_PS
 }
 
 static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr, int64_t batch) {
     WavePsPlan p;
-    if (h->bp_method != LDPC_HIP_PRODUCT_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 8 || h->max_col_deg > 4) return p;
+    if (h->bp_method != LDPC_HIP_PRODUCT_SUM || h->m <= 0 || h->n <= 0 || h->nnz <= 0 || h->max_row_deg > 32 || h->max_col_deg > 8) return p;
+    const bool heavy = h->max_row_deg > 8 || h->max_col_deg > 4;  // the (16, 8) / (32, 8) variants
     if (h->math_mode == LDPC_HIP_MATH_FAST) pick_wave_ps<1>(h->max_row_deg, h->max_col_deg, p);
     else pick_wave_ps<0>(h->max_row_deg, h->max_col_deg, p);
     p.np = (h->n + 63) / 64 * 64;
     const size_t rm = (size_t)p.dr * h->m;
     if (rm + 2 >= 65536 || (size_t)p.np + 1 >= 65536) return p;
-    if (!forced && (rm > 2 * (size_t)h->nnz || (size_t)p.dc * h->n > 2 * (size_t)h->nnz)) return p;  // padding would dominate
+    // padding would dominate (a heavy code's phantom column entries only cost unrolled LDS reads of the +0.0 slot: judged by its rows alone)
+    if (!forced && (rm > 2 * (size_t)h->nnz || (!heavy && (size_t)p.dc * h->n > 2 * (size_t)h->nnz))) return p;
     p.shared = wave_ps_lds_shared(h->m, p.np, p.dr, p.dc);
     p.per_wave = wave_ps_lds_private(h->m, p.np, p.dr, want_llr);
     const size_t lds = 160u * 1024u - 64u;  // (the kernels' few bytes of static LDS come on top of the dynamic part)
@@ -208,6 +218,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
     size_t w = (lds - p.shared) / p.per_wave;
     if (w > 16) w = 16;
     if (!forced && w < 8) return p;
+    if (p.dr > 16 && w > 4) w = 4;  // (the kernel's launch bound: bp_wave_ps_kernel<., 32, .>)
     // A batch so small that every wavefront decodes only a few syndromes takes as long as its slowest syndrome: then the
     // workgroup's wavefronts share one (TEAM), one round of 64 entries each per pass.  LDPC_HIP_PS_TEAM=0 / 1 overrides (measurements).
     bool team = batch <= 256 * (int64_t)w * 8;  // (BB144, w = 16: 0.96 -> 0.57 ms at 8 192 syndromes, 1.52 -> 1.37 ms at 32 768, 4.2 -> 4.5 ms at 131 072)
@@ -216,6 +227,7 @@ static WavePsPlan plan_wave_ps(const ldpc_hip_bp *h, bool forced, bool want_llr,
         const size_t rounds = ((size_t)p.dr * h->m + 63) / 64;
         int tw = (int)(rounds < 2 ? 2 : rounds > 8 ? 8 : rounds);
         if (h->sw("PS_TEAM_WAVES") >= 1 && h->sw("PS_TEAM_WAVES") <= 16) tw = h->sw("PS_TEAM_WAVES");  // (measurements)
+        if (p.dr > 16 && tw > 4) tw = 4;
         p.team = true;
         p.waves = tw;
         p.kern = p.kern_team;
@@ -262,8 +274,10 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
                           int32_t *iters, uint8_t *conv) {
     int rc;
     if ((rc = ensure_wave_ps_tables(h, p))) return rc;
+    // (a team per syndrome and no more syndromes than resident teams -- e.g. ONE decode(): static assignment, no work counter to reset)
+    const bool static_teams = p.team && batch <= 256 * (int64_t)p.groups_per_cu;
     if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
+    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     WavePsArgs a = {};
     a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
@@ -271,7 +285,7 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
     a.llr0 = h->d_llr0;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
-    a.next = (unsigned long long *)h->counter.p;
+    a.next = static_teams ? nullptr : (unsigned long long *)h->counter.p;
     a.clk = h->d_clk;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
     a.min_rdeg = h->m;
@@ -296,8 +310,9 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
                        int32_t *iters, uint8_t *conv) {
     int rc;
     if ((rc = ensure_wave_tables(h, p))) return rc;
+    const bool static_teams = p.team && batch <= 256 * (int64_t)p.groups_per_cu;  // (as decode_wave_ps: no work counter for a handful of syndromes)
     if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
+    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
     WaveArgs a = {};
     a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.mp = p.mp; a.np = p.np; a.max_iter = h->max_iter;
@@ -313,7 +328,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     }
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.llr_direct = p.llr_direct ? 1 : 0;
-    a.next = (unsigned long long *)h->counter.p;
+    a.next = static_teams ? nullptr : (unsigned long long *)h->counter.p;
     a.clk = h->d_clk;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
     const size_t dyn = p.shared + (size_t)(p.team ? 1 : p.waves) * p.per_wave;
