@@ -61,6 +61,83 @@ def regular_ldpc_code(n: int = 10_000, dv: int = 3, dc: int = 6, seed: int = 1) 
     return h
 
 
+def irregular_ldpc_code(n: int = 10_000, m: int = 5_000, seed: int = 1,
+                        row_weights=(3, 4, 5, 6, 7, 8, 9, 10, 12, 16),
+                        col_weights=((2, 0.20), (3, 0.50), (6, 0.15), (8, 0.15))) -> sp.csr_matrix:
+    """An irregular LDPC parity-check matrix from the configuration model: check ``i`` has weight ``row_weights[i % len]`` (3 ... 16 by
+    default, mean 8), the bits get the weights of ``col_weights`` (weight, share) in the shares given -- adjusted on the heaviest class
+    so that both sides count the same edges -- and the bit-side sockets are shuffled with the SplitMix64 stream of ``seed``; multi-edges
+    are repaired by socket swaps as in ``regular_ldpc_code``.  The workload of ``tools/bench_configs.py irregular``: every register
+    bound of the streamed kernels (rows of up to 16, columns of up to 8) with one matrix.
+    """
+    rw = [int(row_weights[i % len(row_weights)]) for i in range(m)]
+    edges = sum(rw)
+    cw = []
+    for w, share in col_weights:
+        cw += [int(w)] * int(round(share * n))
+    cw = (cw + [int(col_weights[0][0])] * n)[:n]
+    diff = edges - sum(cw)  # settle the difference one edge at a time, heaviest bits first (down) / lightest first (up)
+    order = sorted(range(n), key=lambda j: -cw[j]) if diff < 0 else sorted(range(n), key=lambda j: cw[j])
+    k = 0
+    while diff != 0:
+        j = order[k % n]
+        if diff < 0 and cw[j] > 1:
+            cw[j] -= 1
+            diff += 1
+        elif diff > 0:
+            cw[j] += 1
+            diff -= 1
+        k += 1
+    # interleave the weight classes over the bit indices (a deterministic shuffle of which bit is heavy)
+    perm = list(range(n))
+    ctr = 0
+    for i in range(n - 1, 0, -1):
+        j = sm64_int(seed ^ 0x5151, ctr) % (i + 1)
+        ctr += 1
+        perm[i], perm[j] = perm[j], perm[i]
+    cw = [cw[perm[j]] for j in range(n)]
+    sock = [b for b in range(n) for _ in range(cw[b])]
+    ctr = 0
+    for i in range(edges - 1, 0, -1):
+        j = sm64_int(seed, ctr) % (i + 1)
+        ctr += 1
+        sock[i], sock[j] = sock[j], sock[i]
+    start = [0] * (m + 1)
+    for i in range(m):
+        start[i + 1] = start[i] + rw[i]
+    owner = [0] * edges
+    for i in range(m):
+        for q in range(start[i], start[i + 1]):
+            owner[q] = i
+
+    def row_ok(c: int) -> bool:
+        r = sock[start[c]: start[c + 1]]
+        return len(set(r)) == len(r)
+
+    for c in range(m):
+        guard = 0
+        while not row_ok(c):
+            row = sock[start[c]: start[c + 1]]
+            pos = next(start[c] + k for k in range(len(row)) if row[k] in row[:k])
+            q = sm64_int(seed, ctr) % edges
+            ctr += 1
+            guard += 1
+            if guard > 100_000:
+                raise RuntimeError("multi-edge repair did not terminate")
+            c2 = owner[q]
+            if c2 == c:
+                continue
+            sock[pos], sock[q] = sock[q], sock[pos]
+            if not row_ok(c2):
+                sock[pos], sock[q] = sock[q], sock[pos]
+    rows = np.repeat(np.arange(m), rw)
+    h = sp.csr_matrix((np.ones(edges, dtype=np.uint8), (rows, np.asarray(sock, dtype=np.int64))), shape=(m, n), dtype=np.uint8)
+    h.sum_duplicates()
+    h.sort_indices()
+    assert h.nnz == edges and int(h.data.max()) == 1
+    return h
+
+
 def rotated_surface_code_x(d: int = 21) -> sp.csr_matrix:
     """X-check matrix of the distance-``d`` rotated surface code (``(d*d-1)/2 x d*d``).
 

@@ -77,6 +77,7 @@ struct KernelChoice {
     bp_kernel_t fn;
     int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
     int ring_depth;
+    int max_waves = 16;   // wavefronts per workgroup the variant was compiled for (stream_max_waves)
 };
 
 template <int METHOD, int MATH>
@@ -88,10 +89,10 @@ static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
     if (ring_depth >= 2 && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
     if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0, 0};
     if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0, 0};
-    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0};
-    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0, 0};
-    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0, 0};
-    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0};  // heavier nodes take the streaming path inside
+    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0, stream_max_waves(8, 0)};
+    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0, 0, stream_max_waves(8, 0)};
+    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0, 0, stream_max_waves(16, 0)};
+    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0, stream_max_waves(16, 0)};  // heavier nodes take the streaming path inside
 }
 
 

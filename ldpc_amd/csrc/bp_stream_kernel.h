@@ -10,8 +10,13 @@
 //   DR, DC  register bounds on row / column weight; heavier nodes are streamed through memory in two sweeps
 //   RING    0: next row / bits prefetched into VGPRs;  2 or 3: slots of the per-wavefront LDS ring filled by
 //           `buffer_load_dwordx4 ... lds` (only for matrices with a single row weight DR and column weight DC)
+// Register budget: the ring variants fit 80 VGPRs (six wavefronts per SIMD, 12-wavefront workgroups); the register-prefetch variants get
+// 128 (four per SIMD) up to DR = 6, 168 at DR = 8 (workgroups of at most 12 wavefronts) and 256 at DR = 16 (at most 8): a row of 16
+// entries with its prefix products and one exact transcendental in flight does not fit 128 without spilling into the row loop
+// (host side: stream_max_waves).
+constexpr int stream_max_waves(int dr, int ring) { return ring ? 16 : dr > 8 ? 8 : dr > 6 ? 12 : 16; }
 template <int METHOD, int MATH, int DR, int DC, int RING>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RING ? 6 : 4))) bp_decode_kernel(const BpArgs a) {
+__global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__((amdgpu_waves_per_eu(RING ? 6 : DR > 8 ? 2 : DR > 6 ? 3 : 4))) bp_decode_kernel(const BpArgs a) {
     constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -143,7 +143,7 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             if (kern.ring_depth) waves = tiles >= 512 ? 12 : 16;
             else waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
         }
-        if (waves > 16) waves = 16;
+        if (waves > kern.max_waves) waves = kern.max_waves;
         // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
         // + the parking space of the exact product-sum check row (LDPC_NEAR_BYTES per wavefront, behind the rings)
         const size_t near_bytes = (h->bp_method == LDPC_HIP_PRODUCT_SUM && h->math_mode == LDPC_HIP_MATH_LIBM_EXACT) ? LDPC_NEAR_BYTES : 0;

@@ -28,3 +28,17 @@ def test_hypergraph_product():
     assert (sp.csr_matrix(load_case("hgp1600_ms20_p030")["h"]) != hx).nnz == 0, "the committed fixtures were made on this matrix"
     h2 = codes.hamming_code(3)
     assert codes.hypergraph_product_hx(h1, h2).shape == (m1 * 7, n1 * 7 + m1 * 3)
+
+
+def test_irregular_ldpc_code_profile():
+    """The irregular generator (tools/bench_configs.py irregular, tests/test_gpu_parity.py): degrees as asked for, no multi-edges, the
+    same matrix for the same seed."""
+    from ldpc_amd import codes
+    h = codes.irregular_ldpc_code(600, 300, seed=3)
+    assert h.shape == (300, 600) and int(h.data.max()) == 1
+    rw = np.diff(h.indptr)
+    assert sorted(set(rw.tolist())) == [3, 4, 5, 6, 7, 8, 9, 10, 12, 16]
+    cw = np.bincount(h.indices, minlength=600)
+    assert cw.min() >= 2 and cw.max() <= 8 and cw.sum() == rw.sum() == h.nnz
+    assert (codes.irregular_ldpc_code(600, 300, seed=3) != h).nnz == 0
+    assert (codes.irregular_ldpc_code(600, 300, seed=4) != h).nnz > 0

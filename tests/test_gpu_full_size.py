@@ -187,3 +187,34 @@ def test_workgroup_osd_beyond_1024_rows_higher_order(oracle_built, monkeypatch, 
         assert not np.any((h @ dec.T % 2).T != s)
         want = o.bposd_decode_batch(s[:4], method, order, want_llr=False)
         assert np.array_equal(dec[:4], want[0]) and np.array_equal(cv[:4], want[3])
+
+
+@pytest.mark.parametrize("method,alpha", [("product_sum", 1.0), ("minimum_sum", 0.0)])
+def test_irregular_code_on_the_generic_degree_streamed_kernels(method, alpha, oracle_built):
+    """An irregular LDPC code (rows of 3 ... 16 entries, columns of 2 ... 8) forced onto the streamed kernels -- the variants with one
+    16-entry row in registers, no register double buffer and 8-wavefront workgroups (bp_decode_kernel<., ., 16, 8, 0>; zero VGPR spills
+    since round 4) -- against the CPU checker on every row, log-ratio bits included; batches that take the persistent kernel with its
+    hand-off and the per-pass kernels alone; every workgroup size the variant allows (and one it does not: clamped)."""
+    from golden_util import bits_equal
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.irregular_ldpc_code(600, 300, seed=3)
+    n, p = 600, 0.03
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), 16, 0 if method == "product_sum" else 1, alpha)
+    eng.set_small_code_kernel(0)
+    s = eng.gen_bsc_syndromes(13, p, shot0=0, shots=40000, device="cuda:0")
+    sh = s.cpu().numpy()
+    rows = np.r_[0:300, 39700:40000]
+    want = oracle_built.BpOracle(h, error_rate=p, max_iter=16, bp_method=method, ms_scaling_factor=alpha).decode_batch(sh[rows])
+    assert 0.2 < want[3].mean() < 0.999, "the case is meant to mix converged and unconverged rows"
+    for waves, handoff in ((0, -1), (4, 0), (8, 64), (16, -1)):
+        eng.set_tuning(waves_per_workgroup=waves)
+        eng.set_handoff(handoff)
+        dec, llr, it, cv = eng.decode_batch(s, want_llr=True)
+        _check_flags_against_syndromes(eng, s, dec, cv, it, 16)
+        tag = f"waves {waves} handoff {handoff}"
+        assert np.array_equal(dec.cpu().numpy()[rows], want[0]) and np.array_equal(it.cpu().numpy()[rows], want[2]), tag
+        assert np.array_equal(cv.cpu().numpy()[rows].astype(bool), want[3]) and bits_equal(llr.cpu().numpy()[rows], want[1]), tag
+    small = eng.decode_batch(s[:300].contiguous(), want_llr=True)  # five tiles: per-pass kernels from the first iteration
+    assert np.array_equal(small[0].cpu().numpy(), want[0][:300]) and bits_equal(small[1].cpu().numpy(), want[1][:300])
+    eng.close()

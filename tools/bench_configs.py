@@ -40,7 +40,8 @@ def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_ex
     alg = float(np.sum(it.astype(np.float64) * 4.0 * h.nnz * 8.0 + (m + n + 8.0 * n + 5.0)))
     print(json.dumps({"config": name, "batch": batch, "syndromes_per_s": batch / ms * 1e3, "ms_per_decode": ms,
                       "bp_kernel_ms": eng.last_kernel_ms(), "mean_iterations": float(it.mean()),
-                      "bp_converged": float(cv.mean()), "algorithmic_GBps": alg / ms / 1e6, "math": math, "schedule": schedule}), flush=True)
+                      "bp_converged": float(cv.mean()), "algorithmic_GBps": alg / ms / 1e6, "math": math, "schedule": schedule,
+                      "hbm_frac_of_8TBps_kernel_time": alg / (eng.last_kernel_ms() * 1e-3) / 8e12 if eng.last_kernel_ms() > 0 else None}), flush=True)
 
 
 def main():
@@ -54,6 +55,13 @@ def main():
         run("c3 surface d=21 min_sum 30 it p=0.01", h, 0.01, 30, 1, 0.625, 262144, False)
     if "c3p05" in args.which:  # config 3 at its primary operating point alone (tools/profile_c3.sh counts its instructions)
         run("c3 surface d=21 min_sum 30 it p=0.05", codes.rotated_surface_code_x(21), 0.05, 30, 1, 0.625, 262144, False)
+    if "irregular" in args.which:
+        # an irregular LDPC code (rows of 3 ... 16 entries, columns of 2 / 3 / 6 / 8): the streamed kernels' generic-degree variants
+        # (bp_decode_kernel<., ., 16, 8, 0>: one row in registers, no register double buffer, 8-wavefront workgroups)
+        h = codes.irregular_ldpc_code(10000, 5000, seed=1)
+        for p_, meth, alpha in ((0.03, 0, 1.0), (0.06, 0, 1.0), (0.06, 1, 0.75)):
+            run(f"irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), {'product_sum' if meth == 0 else 'minimum_sum'} 50 it p={p_}",
+                h, p_, 50, meth, alpha, 32768, False)
     if "serial" in args.which:
         serial()
     if "serial_big" in args.which:
