@@ -291,7 +291,10 @@ int ldpc_hip_gen_bsc_syndromes(ldpc_hip_bp *h, uint64_t seed, uint64_t threshold
                                int64_t batch, uint8_t *syndromes, uint8_t *errors);
 
 /* Duration in milliseconds of the BP kernel launch of the last decode call on this handle,
- * measured with HIP events on the launch stream (0 if none yet). */
+ * measured with HIP events on the launch stream (0 if none yet).  Also 0 after a call of at most four syndromes with host buffers
+ * on a small code (a single decode()): there the two event packets would cost more than they tell -- debug switch
+ * "TIME_SMALL_CALLS" = 1 keeps them.  After a large call with host buffers (pinned chunks, see ldpc_hip_bp_decode_batch) it
+ * describes the LAST chunk only. */
 int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms);
 /* Split of that time for the streaming path: the persistent kernel (bp_decode_kernel) and the per-pass launches
  * (bp_spread_*_kernel: small batches from the first iteration, stragglers of large ones).  Both 0 for other kernels. */

@@ -48,6 +48,7 @@
 #include "bp_spread_kernels.h"
 #include "bp_serial_kernels.h"
 #include "bp_relative_kernel.h"
+#include "bp_relative_lds_kernel.h"
 #include "bp_small_kernel.h"
 #include "bp_wave_kernel.h"
 #include "bp_edge_kernel.h"

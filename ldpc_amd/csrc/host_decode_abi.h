@@ -231,8 +231,11 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
             double *p_llr = (llr || osd >= 0) ? (double *)(dv + o_llr) : nullptr;
             uint8_t *p_cv = (conv || osd >= 0) ? (uint8_t *)(dv + o_cv) : nullptr;
             int32_t *p_it = iters ? (int32_t *)(dv + o_it) : nullptr;
-            if ((rc = osd >= 0 ? bposd_device(h, osd ? h->osd_method : 1, osd ? h->osd_order : 0, dv, batch, dv + o_dec, p_llr, p_it, p_cv)
-                               : decode_device(h, dv, batch, dv + o_dec, p_llr, p_it, p_cv))) return rc;
+            h->untimed_call = batch <= 4 && !h->on("TIME_SMALL_CALLS");
+            rc = osd >= 0 ? bposd_device(h, osd ? h->osd_method : 1, osd ? h->osd_order : 0, dv, batch, dv + o_dec, p_llr, p_it, p_cv)
+                          : decode_device(h, dv, batch, dv + o_dec, p_llr, p_it, p_cv);
+            h->untimed_call = false;
+            if (rc) return rc;
             HIPCHK(hipStreamSynchronize(h->stream));
             std::memcpy(decoding, h->pin_host + o_dec, B * n);
             if (llr) std::memcpy(llr, h->pin_host + o_llr, B * n * 8);

@@ -53,7 +53,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "HOST_CHUNK_ROWS"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -107,6 +107,8 @@ struct ldpc_hip_bp {
     int32_t sched_seed_raw = 0;  // random_schedule_seed as given (the soft-syndrome routine seeds its own engine with it)
     bool random_serial = false;
     DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
+    DeviceBuf rl_edge, rl_chk, rl_cdeg, rl_last;  // per-column tables and the last row's final order of bp_relative_lds_kernel
+    int rl_dc = 0;                                // stride the tables were built for (0: none)
     // The random schedule's table of per-iteration orders (host_serial.h: random_orders_*), kept on the device between calls as a
     // ring of max_iter rows: a call consumes as many rows as its LAST row ran iterations, and only those are generated anew.
     struct RandomOrders {
@@ -138,6 +140,7 @@ struct ldpc_hip_bp {
     hipEvent_t ev_done = nullptr;  // end of the last call that queued work on `stream` (orders a change of stream after it)
     bool work_queued = false;
     bool timed = false, timed_mid = false;
+    bool untimed_call = false;  // a single decode() through the host-mapped block: the two timing events cost more than they tell (ldpc_hip_bp_last_kernel_ms then says 0)
     float accumulated_ms = 0.f, accumulated_persistent_ms = 0.f;
 
     DeviceBuf msgA, msgC, par, nzm, invalid, dec, dcur, llr_t;       // workspace

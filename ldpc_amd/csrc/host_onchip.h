@@ -297,10 +297,11 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     const int64_t resident = 256 * (int64_t)p.groups_per_cu;
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    const bool timed = !(h->untimed_call && static_teams);
+    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    h->timed = true;
+    if (timed) HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = timed;
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
 }
@@ -338,10 +339,11 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     const int64_t resident = 256 * (int64_t)p.groups_per_cu;
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    const bool timed = !(h->untimed_call && static_teams);
+    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    h->timed = true;
+    if (timed) HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = timed;
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
 }

@@ -264,8 +264,91 @@ static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
     return random_orders_consume(h, 0, last);  // the last row consumed `last` shuffles
 }
 
+// serial_relative with a syndrome's whole state in LDS, one wavefront per syndrome (bp_relative_lds_kernel.h): codes with columns of
+// <= 8 and rows of <= 16 entries whose state leaves room for at least four wavefronts per compute unit; LDPC_HIP_REL_LDS=0 keeps the
+// per-lane kernel (A/B, tests).  Returns 1 if the batch was decoded here, 0 if the caller should carry on, < 0 on error.
+static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                      int32_t *iters, uint8_t *conv) {
+    if (h->sw("REL_LDS") == 0 || h->m <= 0 || h->n <= 0 || h->nnz <= 0) return 0;
+    if (h->max_col_deg > 8 || h->max_row_deg > 16 || h->n >= 65535 || h->nnz >= 65535 || h->m >= 65535) return 0;
+    const bool ps = h->bp_method == LDPC_HIP_PRODUCT_SUM;
+    const int dc = h->max_col_deg;
+    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_wave = rel_lds_private(h->m, h->n, h->nnz);
+    const size_t lds = 160u * 1024u - 64u;
+    if (shared + 4 * per_wave > lds) return 0;
+    int waves = (int)((lds - shared) / per_wave);
+    if (waves > 16) waves = 16;
+    // several workgroups per compute unit where the state is small: each pays for its own copy of the shared tables
+    int groups_per_cu = 1;
+    while (waves * (groups_per_cu + 1) <= 32 && (size_t)(groups_per_cu + 1) * (shared + (size_t)waves * per_wave) <= lds) ++groups_per_cu;
+    int rc;
+    if (h->rl_dc != dc) {
+        std::vector<uint16_t> te((size_t)h->n * dc, 0), tc((size_t)h->n * dc, 0);
+        std::vector<uint8_t> cd((size_t)h->n, 0);
+        for (int i = 0; i < h->m; ++i)
+            for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+                const int j = h->h_col_idx[(size_t)e], k = cd[(size_t)j]++;
+                te[(size_t)j * dc + k] = (uint16_t)e;   // (rows ascending: the order of the column's linked list, sparse_matrix_base.hpp:423-482)
+                tc[(size_t)j * dc + k] = (uint16_t)i;
+            }
+        if ((rc = h->rl_edge.ensure(te.size() * 2)) || (rc = h->rl_chk.ensure(tc.size() * 2)) || (rc = h->rl_cdeg.ensure(cd.size())) ||
+            (rc = h->rl_last.ensure((size_t)h->n * sizeof(int32_t)))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->rl_edge.p, te.data(), te.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->rl_chk.p, tc.data(), tc.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->rl_cdeg.p, cd.data(), cd.size(), hipMemcpyHostToDevice));
+        h->rl_dc = dc;
+    }
+    if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16))) return rc;
+    hipStream_t st = h->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
+    RelLdsArgs a = {};
+    a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.dc = dc;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = batch;
+    a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
+    a.t_edge = (const uint16_t *)h->rl_edge.p; a.t_chk = (const uint16_t *)h->rl_chk.p; a.t_cdeg = (const uint8_t *)h->rl_cdeg.p;
+    a.order0 = (const int32_t *)h->sched_order0.p;
+    a.llr0 = h->d_llr0;
+    a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    a.last_order = (int32_t *)h->rl_last.p;
+    a.next = (unsigned long long *)h->counter.p;
+    a.lds_shared = (int32_t)shared; a.lds_per_wave = (int32_t)per_wave;
+    a.clk = h->d_clk;
+    void (*kern)(const RelLdsArgs);
+#define LDPC_PICK_REL(M, F) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8> : bp_relative_lds_kernel<M, F, 16>)
+    if (!ps) kern = LDPC_PICK_REL(LDPC_HIP_MINIMUM_SUM, 0);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 1);
+    else kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 0);
+#undef LDPC_PICK_REL
+    const size_t dyn = shared + (size_t)waves * per_wave;
+    if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    int64_t groups = (batch + waves - 1) / waves;
+    if (groups > 256 * (int64_t)groups_per_cu) groups = 256 * (int64_t)groups_per_cu;
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed_mid = false;
+    h->timed_prev = h->timed_prev_mid = false;
+    HIPCHK(hipEventRecord(h->ev0, st));
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3((unsigned)(waves * 64)), (unsigned)dyn, st, a);
+    HIPCHK(hipEventRecord(h->ev1, st));
+    h->timed = true;
+    HIPCHK(hipGetLastError());
+    // the order the LAST row ended with becomes the object's serial_schedule_order
+    HIPCHK(hipMemcpyAsync(h->sched_state.data(), h->rl_last.p, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 1;
+}
+
 static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                                   int32_t *iters, uint8_t *conv) {
+    {
+        const int took = decode_serial_relative_lds(h, synd, batch, decoding, llr, iters, conv);
+        if (took < 0) return took;
+        if (took > 0) return LDPC_HIP_OK;
+    }
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t n1 = (size_t)(h->n ? h->n : 1), m1 = (size_t)(h->m ? h->m : 1);
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;

@@ -53,38 +53,45 @@ def test_oracle_reproduces_the_reference(name, oracle_built):
         assert same(g, c["carried"]) and np.array_equal(g[4], c["carried_orders"][-1])
 
 
-def _engine(c):
+def _engine(c, rel_lds=None):
     from ldpc_amd.engine import HipBpEngine
     eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["probs"], c["max_iter"], c["bp_method"], c["alpha"])
     eng.set_schedule(c["schedule"])
     if c["random"]:
         eng.set_random_serial(True, c["seed"])
+    if rel_lds is not None:  # serial_relative: 0 = the per-lane kernel (state in HBM), default = one wavefront per syndrome with the state in LDS
+        eng.set_debug_switch("REL_LDS", rel_lds)
     return eng
 
 
+KERNELS = [None, 0]  # (see _engine; the random schedule ignores the switch)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("rel_lds", KERNELS)
 @pytest.mark.parametrize("name", CASES)
-def test_device_batch_is_a_new_decoder_per_row(name):
+def test_device_batch_is_a_new_decoder_per_row(name, rel_lds):
     c = load(name)
-    eng = _engine(c)
+    eng = _engine(c, rel_lds)
     got = eng.decode_batch(c["synd"])
     assert same(got, c["fresh"])
     if not c["random"]:
         assert np.array_equal(eng.schedule_order(), c["fresh_order_last"])
     import torch
-    eng2 = _engine(c)
+    eng2 = _engine(c, rel_lds)
     t = eng2.decode_batch(torch.from_numpy(c["synd"]).cuda())
     assert same(tuple(x.cpu().numpy() for x in t), c["fresh"])
-    eng3 = _engine(c)  # without log-ratios, and a ragged last tile
+    eng3 = _engine(c, rel_lds)  # without log-ratios, and a ragged last tile
     d = eng3.decode_batch(c["synd"][:37], want_llr=False)
     assert d[1] is None and np.array_equal(d[0], c["fresh"][0][:37]) and np.array_equal(d[2], c["fresh"][2][:37])
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rel_lds", KERNELS)
 @pytest.mark.parametrize("name", CASES)
-def test_device_one_row_calls_follow_one_reference_object(name):
+def test_device_one_row_calls_follow_one_reference_object(name, rel_lds):
     c = load(name)
-    eng = _engine(c)
+    eng = _engine(c, rel_lds)
     rows = min(len(c["synd"]), 24)
     for b in range(rows):
         got = eng.decode_batch(c["synd"][b:b + 1])
@@ -118,6 +125,39 @@ def test_mirror_decode_sequence_and_batch(name):
     out = d2.decode_batch(c["synd"])
     assert np.array_equal(out[nz], c["fresh"][0][nz]) and np.array_equal(d2.iter_batch[nz], c["fresh"][2][nz])
     assert bits_equal(d2.log_prob_ratios_batch[nz], c["fresh"][1][nz])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code,method,alpha,p,max_iter", [("surface21", 1, 0.625, 0.05, 30), ("bb144", 0, 1.0, 0.05, 50), ("bb144", 1, 0.0, 0.08, 12),
+                                                          ("ldpc600", 0, 1.0, 0.04, 10)])
+def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_checker(code, method, alpha, p, max_iter, oracle_built):
+    """A few thousand syndromes of the codes the schedule is used on -- thousands of std::sort calls on keys FULL of ties (min-sum
+    posteriors; all-equal priors in iteration 1) -- through bp_relative_lds_kernel (parallel re-enactment of the sort) and
+    bp_serial_relative_kernel (sequential restatement per lane): every output bit for bit, the final order included; a sample against
+    the CPU checker, which is pinned to the real reference (stateful_rel_*.npz) and to the host's std::sort (test_std_sort_port.py)."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = {"surface21": lambda: codes.rotated_surface_code_x(21), "bb144": codes.bivariate_bicycle_hx,
+         "ldpc600": lambda: codes.regular_ldpc_code(600, 3, 6, seed=4)}[code]()
+    m, n = h.shape
+    B = 3000 if code != "ldpc600" else 700
+    outs = {}
+    for lds in (1, 0):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
+        eng.set_schedule("serial_relative")
+        eng.set_debug_switch("REL_LDS", lds)
+        s = eng.gen_bsc_syndromes(17, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+        s[7, 0] = 3  # a byte above 1: never converges
+        outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
+        outs[(lds, "ms")] = eng.last_kernel_ms()
+        eng.close()
+    assert same(outs[1][:4], outs[0][:4]) and np.array_equal(outs[1][4], outs[0][4])
+    assert not outs[1][3][7]
+    o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
+    rows = np.r_[0:40, B - 8:B]
+    want = o.decode_serial_relative_batch(s[rows], fresh=True)
+    assert same(tuple(x[rows] for x in outs[1][:4]), want[:4]) and np.array_equal(outs[1][4], want[4])
+    print(f"[serial_relative {code} method {method}: on-chip {outs[(1, 'ms')]:.1f} ms, per-lane {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
 # ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of
