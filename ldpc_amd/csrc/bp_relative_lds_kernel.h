@@ -1,4 +1,4 @@
-// bp_relative_lds_kernel.h -- schedule = serial_relative with the whole decode of a syndrome on chip: one WAVEFRONT per syndrome
+// bp_relative_lds_kernel.h -- schedule = serial_relative with the whole decode of a syndrome on chip: state in LDS, 1 or 4 syndromes per wavefront
 // Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
 #pragma once
 
@@ -9,21 +9,26 @@
 // with std::sort at the start of every iteration.  bp_serial_relative_kernel (bp_relative_kernel.h) runs that loop per LANE on
 // batch-minor arrays in HBM: every access of a wavefront is 64 separate cache lines and the sort is 64 divergent introsorts --
 // correct, and 24 - 70 x slower than the fixed-order serial kernel (0.09 M syndromes/s on the d = 21 surface code).  For codes whose
-// state fits in LDS (messages 8 nnz + posteriors 8 n + order 2 n + scratch 5 n bytes per syndrome) this kernel instead gives a
-// syndrome ONE WAVEFRONT and keeps all of it in wave-private LDS:
-//   * the sweep stays sequential over the bits of the lane's ... of the SYNDROME's order (that is what the schedule means); per bit,
-//     lane p < column weight owns the bit's p-th check: it multiplies / minimises over the row's other entries in row order (the
-//     reference's association, bp.hpp:491-523), the posterior and the two column sweeps (bp.hpp:501-503 / 520-522, 530-534) run as
-//     scalar chains over v_readlane values, every lane redoing them, lane p keeping its own bit_to_check;
-//   * std::sort is re-enacted IN PARALLEL, result for result: libstdc++'s introsort is (i) median-of-three + an unguarded Hoare
-//     partition down to runs of 16, (ii) heapsort when the depth budget is spent, (iii) one final insertion sort.
+// state fits in LDS this kernel keeps a syndrome's messages, posteriors and order in LDS and gives it a GROUP of GS lanes -- the
+// whole wavefront (GS = 64), or a quarter of it (GS = 16: four syndromes per wavefront share every instruction of the sweep, which is
+// what product-sum wants -- its cost is the instruction stream of one log and one tanh per bit, executed for however many lanes):
+//   * the sweep stays sequential over the bits of the SYNDROME's order (that is what the schedule means); per bit, lane p < column
+//     weight of the group owns the bit's p-th check: it multiplies / minimises over the row's other entries in row order (the
+//     reference's association, bp.hpp:491-523); the posterior and the two column sweeps (bp.hpp:501-503 / 520-522, 530-534) are chains
+//     over the group's values, every lane redoing them, lane p keeping its own bit_to_check.  What the next bit needs that does not
+//     depend on this bit's messages (its number, its table record, its checks' syndrome bits) is fetched while this bit computes;
+//   * std::sort is re-enacted IN PARALLEL by the whole wavefront, result for result (one syndrome of the wavefront after the other).
+//     The keys are first replaced by their dense ranks (rank = how many keys are greater: equal keys, equal ranks -- the comparator
+//     sees exactly what it saw) and packed with the bit number into one word per position, so no step chases a pointer.  libstdc++'s
+//     introsort is (i) median-of-three + an unguarded Hoare partition down to runs of 16, (ii) heapsort when the depth budget is
+//     spent, (iii) one final insertion sort.
 //       (i)  A partition's outcome is a function of the ORIGINAL arrangement: with L = the positions, ascending, whose key does not
 //            precede the pivot's (where the scan from the left stops) and R = the positions, descending, whose key the pivot's does
 //            not precede (where the scan from the right stops), the loop swaps L[k] <-> R[k] while L[k] < R[k] -- both scans only
 //            ever see untouched elements before they meet -- and returns min(L[K], R[K - 1]) after K swaps.  So: two ballots per 64
 //            positions, ranks by mbcnt, K by a count, all swaps at once.
 //       (iii) insertion sort is STABLE, and after (i) every run of <= 16 is ordered against its neighbours: the final pass is a stable
-//            sort of each run by itself -- every element finds its place by counting inside its run.
+//            sort of each run by itself -- a lane takes a run, holds it in registers and places every element by counting.
 //       (ii) (and any NaN key, where the reference's comparator is not a strict weak order) falls back to the sequential restatement
 //            of bp_relative_kernel.h on one lane -- the same code the CPU checker pins to the host's real std::sort.
 // Same operations on the same operands as the per-lane kernel: same bits (tests/golden/stateful_rel_*.npz, test_stateful_schedules.py).
@@ -44,18 +49,25 @@ struct RelLdsArgs {
     uint8_t *conv;
     int32_t *last_order;                // [n] the order the LAST row of the batch ended with (the object's state after the call)
     unsigned long long *next;           // work counter (zeroed before launch)
-    int32_t lds_shared, lds_per_wave;
+    int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
     unsigned long long *clk;            // shader-clock probe or nullptr
 };
 
+// shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
 __host__ __device__ inline size_t rel_lds_shared(int m, int n, int nnz, int dc, bool product_sum) {
-    size_t b = (size_t)n * 8 + (product_sum ? (size_t)n * 8 + 256 * 8 : 0);        // priors, their edge form, log table
-    b += ((size_t)(m + 1) * 2 + (size_t)nnz * 2 + 2 * (size_t)n * dc * 2 + (size_t)n + 15) & ~(size_t)15;  // rstart, rcol, t_edge, t_chk, cdeg
+    size_t b = (size_t)n * 8 + (product_sum ? (size_t)n * 8 + 256 * 8 : 0) + (size_t)n * dc * 8;
+    b += ((size_t)(m + 1) * 2 + (size_t)nnz * 2 + (size_t)n + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t rel_lds_private(int m, int n, int nnz) {
-    // A [nnz] f64, L [n] f64, ord [n] u16, tmp [n] u16, posL [n] u16, posR [n] u16, dbit [n] u8, run starts [n] u8, syndrome bytes [m] u8, stack 64 x 3 u16
-    size_t b = (size_t)nnz * 8 + (size_t)n * 8 + 4 * (((size_t)n * 2 + 7) & ~(size_t)7) + 2 * (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7) + 64 * 3 * 2;
+// one syndrome: [A nnz f64][L n f64][ord n u16][oddtab n dc u8][dbit n u8][sy m u8]
+__host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, int dc) {
+    size_t b = (size_t)nnz * 8 + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n * dc + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
+    return (b + 15) & ~(size_t)15;
+}
+// one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16]
+// [runs n u8][stack 64 x 3 u16]
+__host__ __device__ inline size_t rel_lds_scratch(int n) {
+    size_t b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + 64 * 3 * 2;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -196,20 +208,48 @@ __device__ inline void sort_desc_seq(const CTX &x, long n) {
 }  // namespace rel_sort
 
 namespace rel_lds {
-// std::sort(ord, ord + n, [](a, b) { return key[a] > key[b]; }) by one wavefront.  posL / posR / tmp: u16 [n] scratch each;
-// runs: u8 [n] (start-of-run marks); stack: u16 [64 * 3].  All wave-private LDS.
-__device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int lane, l_u16 *posL, l_u16 *posR, l_u16 *tmp, l_u8 *runs, l_u16 *stack) {
+typedef __attribute__((address_space(3))) uint32_t l_u32;
+typedef __attribute__((address_space(3))) unsigned long long l_u64;
+
+// std::sort(ord, ord + n, [](a, b) { return key[a] > key[b]; }) by one wavefront.  Scratch (wave-private LDS): v / tmp u32 [n], posL /
+// posR / rank u16 [n], list u16 [n + 1], runs u8 [n], stack u16 [64 * 3] (tmp may share the room of posL + posR, list that of rank).  A word of v: (rank of the bit's key << 16) | bit; "x comes
+// before y" (key x > key y) is "rank x < rank y".
+__device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int lane, l_u32 *v, l_u32 *tmp, l_u16 *posL, l_u16 *posR, l_u16 *rank,
+                                      l_u16 *list, l_u8 *runs, l_u16 *stack) {
     if (n <= 1) return;
-    // any NaN key: the comparator is no strict weak order and the reference's own result is whatever its loops happen to do -- take the
-    // sequential restatement (what the per-lane kernel and the CPU checker run)
+    // dense ranks: rank[b] = number of keys greater than key[b] (64 keys compared per broadcast read); any NaN key -- the comparator is no
+    // strict weak order and the reference's own result is whatever its loops happen to do: the sequential restatement (what the
+    // per-lane kernel and the CPU checker run)
     bool nan = false;
-    for (int p = lane; p < n; p += 64) { const double k = key[ord[p]]; nan = nan || k != k; }
+    for (int base0 = 0; base0 < n; base0 += 512) {  // eight keys per lane in registers, every key read once per pass
+        double kb[8];
+        int cnt[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = base0 + i * 64 + lane;
+            kb[i] = b < n ? key[b] : 0.0;
+            nan = nan || kb[i] != kb[i];
+            cnt[i] = 0;
+        }
+#pragma unroll 2
+        for (int j = 0; j < n; ++j) {
+            const double kj = key[j];  // (the same address in every lane: a broadcast read)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cnt[i] += kj > kb[i] ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = base0 + i * 64 + lane;
+            if (b < n) rank[b] = (uint16_t)cnt[i];
+        }
+    }
     if (__builtin_amdgcn_ballot_w64(nan)) {
         if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n); }
         lds_sync();
         return;
     }
-    for (int p = lane; p < n; p += 64) runs[p] = p == 0 ? 1 : 0;
+    lds_sync();
+    for (int p = lane; p < n; p += 64) { const uint32_t b = ord[p]; v[p] = ((uint32_t)rank[b] << 16) | b; runs[p] = p == 0 ? 1 : 0; }
     int depth = 0;
     for (int q = n; q > 1; q >>= 1) depth++;
     depth *= 2;
@@ -221,38 +261,45 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
         int first = __builtin_amdgcn_readfirstlane((int)stack[sp * 3]), last = __builtin_amdgcn_readfirstlane((int)stack[sp * 3 + 1]), d = __builtin_amdgcn_readfirstlane((int)stack[sp * 3 + 2]);
         while (last - first > 16) {
             if (d == 0) {  // depth budget spent: heapsort of this range (sequential, rare: median-of-three on real posteriors stays balanced)
-                if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::heapsort_t(cx, first, last); }
+                if (lane == 0) {
+                    struct PackedCtx {
+                        l_u32 *w;
+                        __device__ __forceinline__ int get(long i) const { return (int)w[i]; }
+                        __device__ __forceinline__ void set(long i, int x) const { w[i] = (uint32_t)x; }
+                        __device__ __forceinline__ bool gt(int a, int b) const { return ((uint32_t)a >> 16) < ((uint32_t)b >> 16); }
+                    } cx{v};
+                    rel_sort::heapsort_t(cx, first, last);
+                }
                 lds_sync();
                 break;
             }
             --d;
             const int mid = first + (last - first) / 2;
-            {   // __move_median_to_first(first, first + 1, mid, last - 1): every lane works it out, lane 0 swaps
-                const int pa = first + 1, pb = mid, pc = last - 1;
-                const int va = ord[pa], vb = ord[pb], vc = ord[pc];
-                const double ka = key[va], kb = key[vb], kc = key[vc];
-                int pick;
-                if (ka > kb) pick = kb > kc ? pb : (ka > kc ? pc : pa);
-                else pick = ka > kc ? pa : (kb > kc ? pc : pb);
-                pick = __builtin_amdgcn_readfirstlane(pick);
-                lds_sync();
-                if (lane == 0) { const uint16_t t = ord[first]; ord[first] = ord[pick]; ord[pick] = t; }
-                lds_sync();
-            }
-            // __unguarded_partition(first + 1, last, pivot = first), all at once (header comment)
-            const double pk = key[ord[first]];
+            // __move_median_to_first(first, first + 1, mid, last - 1) and the pivot it leaves at `first`
+            const int pa = first + 1, pb = mid, pc = last - 1;
+            const uint32_t wa = v[pa], wb = v[pb], wc = v[pc], wf = v[first];
+            const uint32_t ka = wa >> 16, kb = wb >> 16, kc = wc >> 16;  // "key a > key b" = ka < kb
+            int pick;
+            if (ka < kb) pick = kb < kc ? pb : (ka < kc ? pc : pa);
+            else pick = ka < kc ? pa : (kb < kc ? pc : pb);
+            pick = __builtin_amdgcn_readfirstlane(pick);
+            const uint32_t wp = pick == pa ? wa : pick == pb ? wb : wc;
+            const uint32_t pk = __builtin_amdgcn_readfirstlane((int)(wp >> 16));
+            // __unguarded_partition(first + 1, last, pivot = first), all at once (header comment); the median swap rides along:
+            // position `pick` holds the old v[first] from here on
             int nL = 0, nR = 0;
             for (int c = first + 1; c < last; c += 64) {
                 const int p = c + lane;
                 const bool valid = p < last;
-                const double kv = valid ? key[ord[p]] : 0.0;
-                const bool isL = valid && !(kv > pk), isR = valid && !(pk > kv);
+                const uint32_t kv = (valid ? (p == pick ? wf : v[p]) : 0u) >> 16;
+                const bool isL = valid && !(kv < pk), isR = valid && !(pk < kv);
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
                 if (isL) posL[nL + lane_rank(mL)] = (uint16_t)p;
                 if (isR) posR[nR + lane_rank(mR)] = (uint16_t)p;  // ascending here; R[k] = posR[nR - 1 - k]
                 nL += __builtin_popcountll(mL);
                 nR += __builtin_popcountll(mR);
             }
+            if (lane == 0) { v[first] = wp; v[pick] = wf; }
             lds_sync();
             const int nmin = nL < nR ? nL : nR;
             int K = 0;
@@ -265,16 +312,15 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             }
             for (int k = lane; k < K; k += 64) {
                 const int pl = posL[k], pr = posR[nR - 1 - k];
-                const uint16_t t = ord[pl];
-                ord[pl] = ord[pr];
-                ord[pr] = t;
+                const uint32_t t = v[pl];
+                v[pl] = v[pr];
+                v[pr] = t;
             }
             int cut = K > 0 ? (int)posR[nR - K] : last;          // R[K - 1]: it now holds an element the scan from the left stops at
             if (K < nL && (int)posL[K] < cut) cut = posL[K];
             if (cut > last - 1) cut = last - 1;                  // (cannot happen with ordered keys: the median-of-three leaves a stopper)
             if (cut < first + 1) cut = first + 1;
             cut = __builtin_amdgcn_readfirstlane(cut);
-            lds_sync();
             // __introsort_loop(cut, last, d) later; carry on with [first, cut)
             if (lane == 0) { stack[sp * 3] = (uint16_t)cut; stack[sp * 3 + 1] = (uint16_t)last; stack[sp * 3 + 2] = (uint16_t)d; runs[cut] = 1; }
             ++sp;
@@ -282,54 +328,83 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             lds_sync();
         }
     }
-    // __final_insertion_sort = a stable sort of every run by itself (header comment): count inside the run
-    for (int p = lane; p < n; p += 64) {
-        int a = p;
-        while (!runs[a]) --a;
-        int b = p + 1;
-        while (b < n && !runs[b]) ++b;
-        const int v = ord[p];
-        const double kp = key[v];
-        int r = a;
-        for (int q = a; q < b; ++q) {
-            const double kq = key[ord[q]];
-            r += (kq > kp || (q < p && !(kp > kq))) ? 1 : 0;  // q comes first: strictly greater key, or an equal key that stood before p
+    // __final_insertion_sort = a stable sort of every run by itself (header comment).  The runs' starts, listed; then a lane per run:
+    // its <= 16 words in registers, every one placed by counting the words that come before it.
+    int nruns = 0;
+    for (int c = 0; c < n; c += 64) {
+        const int p = c + lane;
+        const bool st = p < n && runs[p] != 0;
+        const uint64_t mk = __builtin_amdgcn_ballot_w64(st);
+        if (st) list[nruns + lane_rank(mk)] = (uint16_t)p;
+        nruns += __builtin_popcountll(mk);
+    }
+    if (lane == 0) list[nruns] = (uint16_t)n;
+    lds_sync();
+    for (int r = lane; r < nruns; r += 64) {
+        const int a = list[r], len = (int)list[r + 1] - a;
+        if (len > 16) {  // (a heapsorted range: in order already, and insertion sort leaves equal keys where they are)
+            for (int i = 0; i < len; ++i) tmp[a + i] = v[a + i];
+            continue;
         }
-        tmp[r] = (uint16_t)v;
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = i < len ? v[a + i] : 0xffffffffu;  // (padding: rank 65535, after everything)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int before = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t kj = w[j] >> 16, ki = w[i] >> 16;
+                before += (kj < ki || (j < i && kj == ki)) ? 1 : 0;  // j comes first: a greater key, or an equal key that stood before i
+            }
+            if (i < len) tmp[a + before] = w[i];
+        }
     }
     lds_sync();
-    for (int p = lane; p < n; p += 64) ord[p] = tmp[p];
+    for (int p = lane; p < n; p += 64) ord[p] = (uint16_t)(tmp[p] & 0xffffu);
     lds_sync();
+}
+
+template <int GS>
+__device__ __forceinline__ double group_lane(double x, int p, int lane) {  // the value of lane p of this lane's group
+    if (GS == 64) return readlane_f64(x, p);
+    const int src = (lane & ~(GS - 1)) + p;
+    return __hiloint2double(__shfl(__double2hiint(x), src, 64), __shfl(__double2loint(x), src, 64));
 }
 }  // namespace rel_lds
 
-// DRT: bound of the row loop (heaviest row <= DRT)
-template <int METHOD, int MATH, int DRT>
+// GS: lanes of a syndrome (64: one per wavefront; 16: four per wavefront).  DRT: bound of the row loop (heaviest row <= DRT).
+template <int METHOD, int MATH, int DRT, int GS>
 __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs a) {
     using namespace rel_lds;
+    constexpr int G = 64 / GS;
     extern __shared__ __attribute__((aligned(16))) unsigned char rl_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl = lane & (GS - 1), g = lane / GS;
     const int m = a.m, n = a.n, nnz = a.nnz, dc = a.dc;
     constexpr bool PS = METHOD == LDPC_HIP_PRODUCT_SUM;
     __shared__ unsigned long long clk_stamp[2];
     if (tid == 0) clock_probe_begin(clk_stamp);
-    // shared: [prior n][pform n][log table 256] (the last two: product-sum) [rstart m + 1][rcol nnz][t_edge n dc][t_chk n dc][cdeg n]
+    // shared (rel_lds_shared)
     l_u8 *base = (l_u8 *)rl_lds;
     l_f64 *prior = (l_f64 *)base;
     l_f64 *pform = prior + n;
     l_f64 *log_tab_l = pform + (PS ? n : 0);
     const double *log_tab = reinterpret_cast<const double *>(rl_lds) + (size_t)n + (PS ? (size_t)n : 0);
-    l_u16 *rstart = (l_u16 *)(log_tab_l + (PS ? 256 : 0));
+    l_u64 *rec = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32
+    l_u16 *rstart = (l_u16 *)(rec + (size_t)n * dc);
     l_u16 *rcol = rstart + (m + 1);
-    l_u16 *t_edge = rcol + nnz;
-    l_u16 *t_chk = t_edge + (size_t)n * dc;
-    l_u8 *cdeg = (l_u8 *)(t_chk + (size_t)n * dc);
+    l_u8 *cdeg = (l_u8 *)(rcol + nnz);
     for (int q = tid; q < n; q += T) { prior[q] = a.llr0[q]; cdeg[q] = a.t_cdeg[q]; }
     for (int q = tid; q <= m; q += T) rstart[q] = (uint16_t)a.row_ptr[q];
     for (int q = tid; q < nnz; q += T) rcol[q] = (uint16_t)a.col_idx[q];
-    for (int q = tid; q < n * dc; q += T) { t_edge[q] = a.t_edge[q]; t_chk[q] = a.t_chk[q]; }
+    for (int q = tid; q < n * dc; q += T) {
+        const int chk = a.t_chk[q];
+        const unsigned long long rs = (unsigned long long)a.row_ptr[chk], rd = (unsigned long long)(a.row_ptr[chk + 1] - a.row_ptr[chk]);
+        rec[q] = (unsigned long long)a.t_edge[q] | (rs << 16) | (rd << 32);
+    }
     if (PS && MATH == 0)
         for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
@@ -337,58 +412,84 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
         for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
     __syncthreads();
 
-    // wave-private: [A nnz f64][L n f64][ord][tmp][posL][posR] (u16 n each, padded to 8 bytes) [dbit n u8][runs n u8][sy m u8][stack 64 x 3 u16]
-    l_u8 *mine = base + a.lds_shared + (size_t)wave * a.lds_per_wave;
-    const int n2 = (n * 2 + 7) & ~7, n1 = (n + 7) & ~7, m1 = (m + 7) & ~7;
+    // this lane's syndrome (rel_lds_per_syndrome) and this wavefront's sort scratch (rel_lds_scratch)
+    const int n2 = (n * 2 + 7) & ~7, n1 = (n + 7) & ~7, nd1 = (n * dc + 7) & ~7;
+    l_u8 *wave_base = base + a.lds_shared + (size_t)wave * ((size_t)G * a.lds_per_syn + a.lds_scratch);
+    auto syn_base = [&](int gg) { return wave_base + (size_t)gg * a.lds_per_syn; };
+    l_u8 *mine = syn_base(g);
     l_f64 *A = (l_f64 *)mine;
     l_f64 *L = A + nnz;
     l_u16 *ord = (l_u16 *)(L + n);
-    l_u16 *tmp = (l_u16 *)((l_u8 *)ord + n2);
-    l_u16 *posL = (l_u16 *)((l_u8 *)tmp + n2);
-    l_u16 *posR = (l_u16 *)((l_u8 *)posL + n2);
-    l_u8 *dbit = (l_u8 *)posR + n2;   // hard decisions (a bit the order never visits keeps its 0)
-    l_u8 *runs = dbit + n1;            // the sort's run marks
-    l_u8 *sy = runs + n1;
-    l_u16 *stack = (l_u16 *)(sy + m1);
+    l_u8 *oddtab = (l_u8 *)ord + n2;  // [n][dc] (byte & 1) of the check of the k-th entry of column j, for THIS syndrome
+    l_u8 *dbit = oddtab + nd1;         // hard decisions (a bit the order never visits keeps its 0)
+    l_u8 *sy = dbit + n1;
+    l_u8 *scr = wave_base + (size_t)G * a.lds_per_syn;
+    l_u32 *s_v = (l_u32 *)scr;
+    l_u32 *s_tmp = s_v + n;                       // (the partitions' position lists are dead when the final pass fills tmp)
+    l_u16 *s_posL = (l_u16 *)s_tmp;
+    l_u16 *s_posR = s_posL + n;
+    l_u16 *s_rank = (l_u16 *)(s_tmp + n);         // (the ranks are dead once v is packed: the run list takes their room)
+    l_u16 *s_list = s_rank;
+    l_u8 *s_runs = (l_u8 *)s_rank + (((n + 1) * 2 + 7) & ~7);
+    l_u16 *s_stack = (l_u16 *)(s_runs + n1);
+    (void)n2;
 
     for (;;) {
         unsigned long long pulled = 0;
-        if (lane == 0) pulled = __hip_atomic_fetch_add(a.next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t b = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pulled);
-        if (b >= a.batch) break;
+        if (lane == 0) pulled = __hip_atomic_fetch_add(a.next, (unsigned long long)G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t b0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pulled);
+        if (b0 >= a.batch) break;
+        const int64_t b = b0 + g;
+        const bool have = b < a.batch;
         bool big = false;
-        for (int i = lane; i < m; i += 64) { const uint8_t v = a.synd[b * m + i]; sy[i] = v; big = big || v > 1; }
-        const bool never = __builtin_amdgcn_ballot_w64(big) != 0;  // a syndrome byte > 1: cannot converge (bp.hpp:539)
-        // initialise_log_domain_bp (bp.hpp:147-157), the starting order, no decision yet
-        for (int e = lane; e < nnz; e += 64) A[e] = PS ? pform[rcol[e]] : prior[rcol[e]];
-        for (int t = lane; t < n; t += 64) { ord[t] = (uint16_t)(a.order0 ? a.order0[t] : t); L[t] = 0.0; dbit[t] = 0; }
+        if (have)
+            for (int i = gl; i < m; i += GS) { const uint8_t v = a.synd[b * m + i]; sy[i] = v; big = big || v > 1; }
+        // a syndrome byte > 1: cannot converge (bp.hpp:539) -- per group
+        const uint64_t bigm = __builtin_amdgcn_ballot_w64(big);
+        const bool never = GS == 64 ? bigm != 0 : ((bigm >> (g * GS)) & ((1ull << (GS & 63)) - 1ull)) != 0;
+        lds_sync();
+        if (have) {
+            // initialise_log_domain_bp (bp.hpp:147-157), the starting order, no decision yet, this syndrome's bits per table entry
+            for (int e = gl; e < nnz; e += GS) A[e] = PS ? pform[rcol[e]] : prior[rcol[e]];
+            for (int t = gl; t < n; t += GS) { ord[t] = (uint16_t)(a.order0 ? a.order0[t] : t); L[t] = 0.0; dbit[t] = 0; }
+            for (int q = gl; q < n * dc; q += GS) oddtab[q] = sy[a.t_chk[q]] & 1;  // pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
+        }
         lds_sync();
         int it = 0;
         bool converged = false;
-        while (it < a.max_iter && !converged) {
-            ++it;
+        bool running = have && a.max_iter > 0;
+        while (__builtin_amdgcn_ballot_w64(running) != 0) {
+            if (running) ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
-            // bp.hpp:469-483: most reliable bits first -- by prior in the first iteration, by the previous posterior afterwards
-            sort_desc_wave(ord, it != 1 ? L : prior, n, lane, posL, posR, tmp, runs, stack);
+            // bp.hpp:469-483: most reliable bits first -- by prior in the first iteration, by the previous posterior afterwards; the
+            // wavefront's syndromes one after the other, all 64 lanes on each
+            const uint64_t runm = __builtin_amdgcn_ballot_w64(running);
+            for (int gg = 0; gg < G; ++gg) {
+                if (!((runm >> (gg * GS)) & 1ull)) continue;
+                l_u8 *sb = syn_base(gg);
+                l_f64 *Lg = (l_f64 *)sb + nnz;
+                const int itg = __builtin_amdgcn_readlane(it, gg * GS);
+                sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, s_stack);
+            }
+            // the sweep: every running group walks its own order
+            int bit = running ? (int)ord[0] : 0;
+            unsigned long long rc = 0;
+            int cd = 0, odd = 0;
+            if (running) { cd = cdeg[bit]; if (gl < cd) { rc = rec[bit * dc + gl]; odd = oddtab[bit * dc + gl]; } }
             for (int t = 0; t < n; ++t) {
-                const int bit = __builtin_amdgcn_readfirstlane((int)ord[t]);  // (the same address in every lane: a broadcast read)
-                const int cd = __builtin_amdgcn_readfirstlane((int)cdeg[bit]);
-                const bool mine_p = lane < cd;
-                int e = 0;
+                const int bit_next = (running && t + 1 < n) ? (int)ord[t + 1] : 0;
+                const bool mine_p = running && gl < cd;
+                const int e = (int)(rc & 0xffffu), rs = (int)((rc >> 16) & 0xffffu), rd = (int)(rc >> 32);
                 double c = 0.0;
                 if (mine_p) {
-                    e = t_edge[bit * dc + lane];
-                    const int chk = t_chk[bit * dc + lane];
-                    const int rs = rstart[chk], rd = rstart[chk + 1] - rs;
-                    const bool odd = (sy[chk] & 1) != 0;  // pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
                     if (PS) {  // bp.hpp:491-503
                         double x = 1.0;
 #pragma unroll
                         for (int k = 0; k < DRT; ++k)
                             if (k < rd && rs + k != e) x *= A[rs + k];
-                        c = ps_message<MATH>(x, odd, log_tab);
+                        c = ps_message<MATH>(x, odd != 0, log_tab);
                     } else {   // bp.hpp:504-523
-                        int sgn = odd ? 1 : 0;
+                        int sgn = odd;
                         double temp = DBL_MAX;
 #pragma unroll
                         for (int k = 0; k < DRT; ++k)
@@ -401,44 +502,57 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                         c = alpha * (sgn ? -1.0 : 1.0) * temp;
                     }
                 }
+                // what the next bit needs and this bit's messages do not change: on its way while the column is summed up
+                unsigned long long rc_next = 0;
+                int cd_next = 0, odd_next = 0;
+                if (running && t + 1 < n) { cd_next = cdeg[bit_next]; if (gl < cd_next) { rc_next = rec[bit_next * dc + gl]; odd_next = oddtab[bit_next * dc + gl]; } }
                 // the column, top down (bp.hpp:488, 501-503 / 520-522): entry p keeps the running sum before its own message joins it
-                double llr = prior[bit], part = 0.0;
-                for (int p = 0; p < cd; ++p) {
-                    const double cp = readlane_f64(c, p);
-                    if (lane == p) part = llr;
-                    llr += cp;
+                double llr = running ? prior[bit] : 0.0, part = 0.0;
+                for (int p = 0; p < dc; ++p) {
+                    const double cp = group_lane<GS>(c, p, lane);
+                    if (gl == p) part = llr;
+                    if (p < cd) llr += cp;
                 }
                 // ... and bottom up (bp.hpp:530-534)
                 double sfx = 0.0, b2c = 0.0;
-                for (int p = cd - 1; p >= 0; --p) {
-                    const double cp = readlane_f64(c, p);
-                    if (lane == p) b2c = part + sfx;
-                    sfx += cp;
+                for (int p = dc - 1; p >= 0; --p) {
+                    const double cp = group_lane<GS>(c, p, lane);
+                    if (gl == p) b2c = part + sfx;
+                    if (p < cd) sfx += cp;
                 }
                 if (mine_p) A[e] = edge_form<METHOD, MATH>(b2c);
-                if (lane == 0) { L[bit] = llr; dbit[bit] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
+                if (running && gl == 0) { L[bit] = llr; dbit[bit] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
                 lds_sync();
+                bit = bit_next; rc = rc_next; cd = cd_next; odd = odd_next;
             }
             // candidate syndrome of the current hard decision vs the syndrome (bp.hpp:537-543)
             bool differ = false;
-            for (int i = lane; i < m; i += 64) {
-                unsigned s = 0;
-                for (int g = rstart[i]; g < rstart[i + 1]; ++g) s ^= dbit[rcol[g]];
-                differ = differ || s != (unsigned)sy[i];
+            if (running)
+                for (int i = gl; i < m; i += GS) {
+                    unsigned s = 0;
+                    for (int q = rstart[i]; q < rstart[i + 1]; ++q) s ^= dbit[rcol[q]];
+                    differ = differ || s != (unsigned)sy[i];
+                }
+            const uint64_t dm = __builtin_amdgcn_ballot_w64(differ);
+            const bool gdiffer = GS == 64 ? dm != 0 : ((dm >> (g * GS)) & ((1ull << (GS & 63)) - 1ull)) != 0;
+            if (running) {
+                converged = !never && !gdiffer;
+                running = !converged && it < a.max_iter;
             }
-            converged = !never && __builtin_amdgcn_ballot_w64(differ) == 0;
             lds_sync();
         }
-        for (int j = lane; j < n; j += 64) {
-            a.decoding[b * n + j] = dbit[j];
-            if (a.llr) a.llr[b * n + j] = L[j];
+        if (have) {
+            for (int j = gl; j < n; j += GS) {
+                a.decoding[b * n + j] = dbit[j];
+                if (a.llr) a.llr[b * n + j] = L[j];
+            }
+            if (gl == 0) {
+                if (a.iters) a.iters[b] = it;
+                if (a.conv) a.conv[b] = converged ? 1 : 0;
+            }
+            if (b == a.batch - 1 && a.last_order)
+                for (int t = gl; t < n; t += GS) a.last_order[t] = ord[t];
         }
-        if (lane == 0) {
-            if (a.iters) a.iters[b] = it;
-            if (a.conv) a.conv[b] = converged ? 1 : 0;
-        }
-        if (b == a.batch - 1 && a.last_order)
-            for (int t = lane; t < n; t += 64) a.last_order[t] = ord[t];
         lds_sync();
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);

@@ -273,14 +273,26 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     if (h->max_col_deg > 8 || h->max_row_deg > 16 || h->n >= 65535 || h->nnz >= 65535 || h->m >= 65535) return 0;
     const bool ps = h->bp_method == LDPC_HIP_PRODUCT_SUM;
     const int dc = h->max_col_deg;
-    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_wave = rel_lds_private(h->m, h->n, h->nnz);
+    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc), scratch = rel_lds_scratch(h->n);
     const size_t lds = 160u * 1024u - 64u;
-    if (shared + 4 * per_wave > lds) return 0;
-    int waves = (int)((lds - shared) / per_wave);
+    // lanes per syndrome: product-sum is bound by the instruction stream of one log + one tanh per bit, which four syndromes can share
+    // (GS = 16) -- where their state still leaves room for a few wavefronts per compute unit; else (and for min-sum, whose sweep waits
+    // on LDS rather than on the vector unit) one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form.
+    int gs = 64;
+    if (ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
+    if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
+    const int G = 64 / gs;
+    const size_t per_wave = (size_t)G * per_syn + scratch;
+    if (shared + (gs == 64 ? 4 : 1) * per_wave > lds) {
+        if (gs == 16 && shared + 4 * (per_syn + scratch) <= lds) gs = 64; else return 0;
+    }
+    const int Gf = 64 / gs;
+    const size_t per_wave_f = (size_t)Gf * per_syn + scratch;
+    int waves = (int)((lds - shared) / per_wave_f);
     if (waves > 16) waves = 16;
     // several workgroups per compute unit where the state is small: each pays for its own copy of the shared tables
     int groups_per_cu = 1;
-    while (waves * (groups_per_cu + 1) <= 32 && (size_t)(groups_per_cu + 1) * (shared + (size_t)waves * per_wave) <= lds) ++groups_per_cu;
+    while (waves * (groups_per_cu + 1) <= 24 && (size_t)(groups_per_cu + 1) * (shared + (size_t)waves * per_wave_f) <= lds) ++groups_per_cu;
     int rc;
     if (h->rl_dc != dc) {
         std::vector<uint16_t> te((size_t)h->n * dc, 0), tc((size_t)h->n * dc, 0);
@@ -315,17 +327,19 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
     a.last_order = (int32_t *)h->rl_last.p;
     a.next = (unsigned long long *)h->counter.p;
-    a.lds_shared = (int32_t)shared; a.lds_per_wave = (int32_t)per_wave;
+    a.lds_shared = (int32_t)shared; a.lds_per_syn = (int32_t)per_syn; a.lds_scratch = (int32_t)scratch;
     a.clk = h->d_clk;
     void (*kern)(const RelLdsArgs);
-#define LDPC_PICK_REL(M, F) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8> : bp_relative_lds_kernel<M, F, 16>)
+#define LDPC_PICK_REL_G(M, F, GSZ) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ> : bp_relative_lds_kernel<M, F, 16, GSZ>)
+#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16) : LDPC_PICK_REL_G(M, F, 64))
     if (!ps) kern = LDPC_PICK_REL(LDPC_HIP_MINIMUM_SUM, 0);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 1);
     else kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 0);
 #undef LDPC_PICK_REL
-    const size_t dyn = shared + (size_t)waves * per_wave;
+#undef LDPC_PICK_REL_G
+    const size_t dyn = shared + (size_t)waves * per_wave_f;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    int64_t groups = (batch + waves - 1) / waves;
+    int64_t groups = (batch + (int64_t)waves * Gf - 1) / ((int64_t)waves * Gf);
     if (groups > 256 * (int64_t)groups_per_cu) groups = 256 * (int64_t)groups_per_cu;
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;

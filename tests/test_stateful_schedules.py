@@ -64,7 +64,7 @@ def _engine(c, rel_lds=None):
     return eng
 
 
-KERNELS = [None, 0]  # (see _engine; the random schedule ignores the switch)
+KERNELS = [None, 0, 16, 64]  # (see _engine: default choice, per-lane kernel, on chip with 16 / 64 lanes per syndrome; the random schedule ignores the switch)
 
 
 @pytest.mark.gpu
@@ -142,7 +142,7 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
     m, n = h.shape
     B = 3000 if code != "ldpc600" else 700
     outs = {}
-    for lds in (1, 0):
+    for lds in (64, 16, 0):  # on chip: one / four syndromes per wavefront; 0: the per-lane kernel
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
         eng.set_schedule("serial_relative")
         eng.set_debug_switch("REL_LDS", lds)
@@ -151,13 +151,14 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
         outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
         outs[(lds, "ms")] = eng.last_kernel_ms()
         eng.close()
-    assert same(outs[1][:4], outs[0][:4]) and np.array_equal(outs[1][4], outs[0][4])
-    assert not outs[1][3][7]
+    for lds in (64, 16):
+        assert same(outs[lds][:4], outs[0][:4]) and np.array_equal(outs[lds][4], outs[0][4]), lds
+    assert not outs[64][3][7]
     o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
     rows = np.r_[0:40, B - 8:B]
     want = o.decode_serial_relative_batch(s[rows], fresh=True)
-    assert same(tuple(x[rows] for x in outs[1][:4]), want[:4]) and np.array_equal(outs[1][4], want[4])
-    print(f"[serial_relative {code} method {method}: on-chip {outs[(1, 'ms')]:.1f} ms, per-lane {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
+    assert same(tuple(x[rows] for x in outs[64][:4]), want[:4]) and np.array_equal(outs[64][4], want[4])
+    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms (64 lanes per syndrome) / {outs[(16, 'ms')]:.1f} ms (16), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
 # ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of
