@@ -434,36 +434,47 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_u16 *s_stack = (l_u16 *)(s_runs + n1);
     (void)n2;
 
+    // Every GROUP draws its own syndromes from the work counter and starts the next one as soon as its current one is done -- a group
+    // never waits for the slowest syndrome of its wavefront (at BB144's operating point 4 % of the syndromes run all 50 iterations, the
+    // rest ~5).  The wavefront's groups move through iterations in lockstep: sort (the groups that run, one after the other), sweep,
+    // syndrome test; a group that has just taken a new syndrome simply is at iteration 1 while its neighbours are further on.
+    int64_t b = 0;
+    bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
+    int it = 0;
     for (;;) {
-        unsigned long long pulled = 0;
-        if (lane == 0) pulled = __hip_atomic_fetch_add(a.next, (unsigned long long)G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t b0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pulled >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pulled);
-        if (b0 >= a.batch) break;
-        const int64_t b = b0 + g;
-        const bool have = b < a.batch;
-        bool big = false;
-        if (have)
-            for (int i = gl; i < m; i += GS) { const uint8_t v = a.synd[b * m + i]; sy[i] = v; big = big || v > 1; }
-        // a syndrome byte > 1: cannot converge (bp.hpp:539) -- per group
-        const uint64_t bigm = __builtin_amdgcn_ballot_w64(big);
-        const bool never = GS == 64 ? bigm != 0 : ((bigm >> (g * GS)) & ((1ull << (GS & 63)) - 1ull)) != 0;
-        lds_sync();
-        if (have) {
-            // initialise_log_domain_bp (bp.hpp:147-157), the starting order, no decision yet, this syndrome's bits per table entry
-            for (int e = gl; e < nnz; e += GS) A[e] = PS ? pform[rcol[e]] : prior[rcol[e]];
-            for (int t = gl; t < n; t += GS) { ord[t] = (uint16_t)(a.order0 ? a.order0[t] : t); L[t] = 0.0; dbit[t] = 0; }
-            for (int q = gl; q < n * dc; q += GS) oddtab[q] = sy[a.t_chk[q]] & 1;  // pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
+        if (need && !exhausted) {  // (whole groups: `need` is the same in every lane of a group)
+            unsigned long long pulled = 0;
+            if (gl == 0) pulled = __hip_atomic_fetch_add(a.next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int lead = lane & ~(GS - 1);
+            b = ((int64_t)__shfl((int)(pulled >> 32), lead, 64) << 32) | (unsigned)__shfl((int)pulled, lead, 64);
+            have = b < a.batch;
+            exhausted = !have;
+            need = false;
+            it = 0;
+            converged = false;
+            running = false;
+            if (have) {
+                bool big = false;
+                for (int i = gl; i < m; i += GS) { const uint8_t v = a.synd[b * m + i]; sy[i] = v; big = big || v > 1; }
+                // a syndrome byte > 1: cannot converge (bp.hpp:539) -- the ballot covers the lanes that are here; a group is here as a whole
+                const uint64_t bigm = __builtin_amdgcn_ballot_w64(big);
+                never = GS == 64 ? bigm != 0 : ((bigm >> (g * GS)) & ((1ull << (GS & 63)) - 1ull)) != 0;
+                // initialise_log_domain_bp (bp.hpp:147-157), the starting order, no decision yet
+                for (int e = gl; e < nnz; e += GS) A[e] = PS ? pform[rcol[e]] : prior[rcol[e]];
+                for (int t = gl; t < n; t += GS) { ord[t] = (uint16_t)(a.order0 ? a.order0[t] : t); L[t] = 0.0; dbit[t] = 0; }
+                lds_sync();
+                // this syndrome's bit per table entry: pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
+                for (int q = gl; q < n * dc; q += GS) oddtab[q] = sy[a.t_chk[q]] & 1;
+                running = a.max_iter > 0;
+            }
         }
         lds_sync();
-        int it = 0;
-        bool converged = false;
-        bool running = have && a.max_iter > 0;
-        while (__builtin_amdgcn_ballot_w64(running) != 0) {
+        const uint64_t runm = __builtin_amdgcn_ballot_w64(running);
+        if (runm != 0) {
             if (running) ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
             // bp.hpp:469-483: most reliable bits first -- by prior in the first iteration, by the previous posterior afterwards; the
-            // wavefront's syndromes one after the other, all 64 lanes on each
-            const uint64_t runm = __builtin_amdgcn_ballot_w64(running);
+            // wavefront's running syndromes one after the other, all 64 lanes on each
             for (int gg = 0; gg < G; ++gg) {
                 if (!((runm >> (gg * GS)) & 1ull)) continue;
                 l_u8 *sb = syn_base(gg);
@@ -539,9 +550,9 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 converged = !never && !gdiffer;
                 running = !converged && it < a.max_iter;
             }
-            lds_sync();
         }
-        if (have) {
+        // groups whose syndrome is done (or never ran: max_iter = 0): results out, next syndrome in
+        if (have && !running) {
             for (int j = gl; j < n; j += GS) {
                 a.decoding[b * n + j] = dbit[j];
                 if (a.llr) a.llr[b * n + j] = L[j];
@@ -552,8 +563,11 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             }
             if (b == a.batch - 1 && a.last_order)
                 for (int t = gl; t < n; t += GS) a.last_order[t] = ord[t];
+            have = false;
+            need = true;
         }
         lds_sync();
+        if (__builtin_amdgcn_ballot_w64(!exhausted) == 0 && __builtin_amdgcn_ballot_w64(have) == 0) break;
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
 }
