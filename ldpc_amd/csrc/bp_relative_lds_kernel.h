@@ -441,6 +441,8 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     int64_t b = 0;
     bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
     int it = 0;
+    for (int t = gl; t < n; t += GS) ord[t] = 0;  // (the sweep's look-ahead reads the order unconditionally, also in a group that has no syndrome yet)
+    lds_sync();
     for (;;) {
         if (need && !exhausted) {  // (whole groups: `need` is the same in every lane of a group)
             unsigned long long pulled = 0;
@@ -488,35 +490,41 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             int cd = 0, odd = 0;
             if (running) { cd = cdeg[bit]; if (gl < cd) { rc = rec[bit * dc + gl]; odd = oddtab[bit * dc + gl]; } }
             for (int t = 0; t < n; ++t) {
-                const int bit_next = (running && t + 1 < n) ? (int)ord[t + 1] : 0;
+                const int bit_next = (int)ord[t + 1 < n ? t + 1 : n - 1];
                 const bool mine_p = running && gl < cd;
                 const int e = (int)(rc & 0xffffu), rs = (int)((rc >> 16) & 0xffffu), rd = (int)(rc >> 32);
+                // the row's entries: all DRT loads go out together (clamped to the row: an entry beyond its weight, or the bit's own, is
+                // read and then replaced by the neutral element -- no branch, one LDS round trip)
                 double c = 0.0;
-                if (mine_p) {
-                    if (PS) {  // bp.hpp:491-503
+                {
+                    double av[DRT];
+                    const int last_k = rd > 0 ? rd - 1 : 0;
+#pragma unroll
+                    for (int k = 0; k < DRT; ++k) av[k] = A[rs + (k < last_k ? k : last_k)];
+                    if (PS) {  // bp.hpp:491-503 (x * 1.0 == x bit for bit, NaN and signed zero included)
                         double x = 1.0;
 #pragma unroll
-                        for (int k = 0; k < DRT; ++k)
-                            if (k < rd && rs + k != e) x *= A[rs + k];
-                        c = ps_message<MATH>(x, odd != 0, log_tab);
+                        for (int k = 0; k < DRT; ++k) x *= (k < rd && rs + k != e) ? av[k] : 1.0;
+                        if (mine_p) c = ps_message<MATH>(x, odd != 0, log_tab);
                     } else {   // bp.hpp:504-523
                         int sgn = odd;
                         double temp = DBL_MAX;
 #pragma unroll
-                        for (int k = 0; k < DRT; ++k)
-                            if (k < rd && rs + k != e) {
-                                const double v = A[rs + k];
-                                const double ab = fabs(v);
-                                if (ab < temp) temp = ab;
-                                if (v <= 0) sgn ^= 1;
-                            }
-                        c = alpha * (sgn ? -1.0 : 1.0) * temp;
+                        for (int k = 0; k < DRT; ++k) {
+                            const bool use = k < rd && rs + k != e;
+                            const double ab = fabs(av[k]);
+                            temp = (use && ab < temp) ? ab : temp;
+                            sgn ^= (use && av[k] <= 0) ? 1 : 0;
+                        }
+                        c = mine_p ? alpha * (sgn ? -1.0 : 1.0) * temp : 0.0;
                     }
                 }
-                // what the next bit needs and this bit's messages do not change: on its way while the column is summed up
-                unsigned long long rc_next = 0;
-                int cd_next = 0, odd_next = 0;
-                if (running && t + 1 < n) { cd_next = cdeg[bit_next]; if (gl < cd_next) { rc_next = rec[bit_next * dc + gl]; odd_next = oddtab[bit_next * dc + gl]; } }
+                // what the next bit needs and this bit's messages do not change: on its way while the column is summed up (unconditional
+                // reads at clamped places: what a lane without an entry reads is never used)
+                const int dcl = gl < dc ? gl : dc - 1;
+                const int cd_next = cdeg[bit_next];
+                const unsigned long long rc_next = rec[bit_next * dc + dcl];
+                const int odd_next = oddtab[bit_next * dc + dcl];
                 // the column, top down (bp.hpp:488, 501-503 / 520-522): entry p keeps the running sum before its own message joins it
                 double llr = running ? prior[bit] : 0.0, part = 0.0;
                 for (int p = 0; p < dc; ++p) {

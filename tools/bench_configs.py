@@ -15,7 +15,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel", osd=None, random_serial=None):
+def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_exact", schedule="parallel", osd=None, random_serial=None, switches=()):
     import torch
     from ldpc_amd.engine import HipBpEngine
     m, n = h.shape
@@ -24,6 +24,8 @@ def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_ex
     eng.set_schedule(schedule)
     if random_serial is not None:
         eng.set_random_serial(True, random_serial)
+    for key, val in switches:
+        eng.set_debug_switch(key, val)
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
     if osd is not None:  # (osd_method, osd_order): 2 = OSD_E, 3 = OSD_CS
         eng.set_osd(*osd)
@@ -151,6 +153,9 @@ def stateful():
         run(f"serial (fixed order): {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial")
         run(f"serial, random order per iteration: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial", random_serial=1234)
         run(f"serial_relative: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial_relative")
+        if os.environ.get("LDPC_BENCH_REL_VARIANTS"):  # the on-chip kernel with 64 / 32 / 16 lanes per syndrome, and the per-lane kernel
+            for gs in (64, 32, 16, 0):
+                run(f"serial_relative [REL_LDS={gs}]: {name} p={p}", h, p, it, method, alpha, 65536 if gs else 8192, False, steps=1, schedule="serial_relative", switches=(("REL_LDS", gs),))
 
 
 def serial_big():
