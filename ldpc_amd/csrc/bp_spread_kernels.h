@@ -31,45 +31,38 @@ __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64
 }
 
 
-// workgroup rows (blockIdx.y) loop over the slots: the host queues every round of a decode at once, sized for the most tiles that
-// can have been parked, and most rounds find few of them still running -- a row that finds nothing costs one launch slot, not one per tile
-__device__ __forceinline__ int spread_slots(const SpreadArgs &a) { return a.n_tiles >= 0 ? a.n_tiles : (int)a.bp.counters[1]; }
-
 template <int METHOD, int MATH, int DR, int NT>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
     typedef MsgBufT<NT ? 2 : 0> Buf;  // cache policy of the message traffic: non-temporal once the tiles outgrow the caches
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     __shared__ double near_bufs[4][LDPC_NEAR_SLOTS];
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;  // (uniform over the workgroup)
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
-    const int slots = spread_slots(a);
-    for (int slot = blockIdx.y; slot < slots; slot += gridDim.y) {
-        int64_t tile;
-        const TileState *st;
-        int it;
-        uint64_t done;
-        if (!spread_tile(a, slot, tile, st, it, done)) continue;  // (uniform over the workgroup)
-        const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-        const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-        const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
-        const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
-        for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
-            const int rs = sload(a.bp.row_ptr + i), d = sload(a.bp.row_ptr + i + 1) - rs;
-            const bool neg = (sload(a.bp.nzm + tile * a.bp.m + i) >> lane) & 1ull;
-            const int parity = (int)((sload(a.bp.par + tile * a.bp.m + i) >> lane) & 1ull);
-            if (d <= DR) {
-                double cur[DR];
+    const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
+    const int i0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int i = i0; i < i0 + a.nodes && i < a.bp.m; ++i) {
+        const int rs = sload(a.bp.row_ptr + i), d = sload(a.bp.row_ptr + i + 1) - rs;
+        const bool neg = (sload(a.bp.nzm + tile * a.bp.m + i) >> lane) & 1ull;
+        const int parity = (int)((sload(a.bp.par + tile * a.bp.m + i) >> lane) & 1ull);
+        if (d <= DR) {
+            double cur[DR];
 #pragma unroll
-                for (int k = 0; k < DR; ++k)
-                    if (k < d) cur[k] = At.ld(l8, rs + k);
-                check_row_live<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab, ~done, near_bufs[wave]);
-            } else {
-                check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
-            }
+            for (int k = 0; k < DR; ++k)
+                if (k < d) cur[k] = At.ld(l8, rs + k);
+            check_row_live<METHOD, MATH, DR>(cur, d, rs, neg, parity, alpha, Ct, l8, log_tab, ~done, near_bufs[wave]);
+        } else {
+            check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
         }
     }
 }
@@ -77,78 +70,72 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
 template <int METHOD, int MATH, int DC, int NT>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
     typedef MsgBufT<NT ? 2 : 0> Buf;
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
-    const int slots = spread_slots(a);
-    for (int slot = blockIdx.y; slot < slots; slot += gridDim.y) {
-        int64_t tile;
-        const TileState *st;
-        int it;
-        uint64_t done;
-        if (!spread_tile(a, slot, tile, st, it, done)) continue;
-        const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-        const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
-        const bool want_llr = a.bp.llr_t != nullptr;
-        const Buf Lt = make_msgbuf<Buf>(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
-        const bool last = it == a.bp.max_iter;
-        const bool lane_live = !((done >> lane) & 1ull);
-        const bool each = st->llr_each[a.round & 1] != 0;  // (as the persistent kernel's llr_each)
-        const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
-        for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
-            const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
-            const double prior = sload(a.bp.llr0 + j);
-            double llr;
-            if (d <= DC) {
-                int e[DC];
-                double c[DC];
+    const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
+    const bool want_llr = a.bp.llr_t != nullptr;
+    const Buf Lt = make_msgbuf<Buf>(want_llr ? a.bp.llr_t + (size_t)tile * (size_t)n * LDPC_WAVE : a.bp.A, want_llr ? (unsigned)n : 0u);
+    const bool last = it == a.bp.max_iter;
+    const bool lane_live = !((done >> lane) & 1ull);
+    const bool each = st->llr_each[a.round & 1] != 0;  // (as the persistent kernel's llr_each)
+    const int j0 = (blockIdx.x * 4 + wave) * a.nodes;
+    for (int j = j0; j < j0 + a.nodes && j < n; ++j) {
+        const int cs = sload(a.bp.col_ptr + j), d = sload(a.bp.col_ptr + j + 1) - cs;
+        const double prior = sload(a.bp.llr0 + j);
+        double llr;
+        if (d <= DC) {
+            int e[DC];
+            double c[DC];
 #pragma unroll
-                for (int k = 0; k < DC; ++k)
-                    if (k < d) { e[k] = sload(a.bp.csc_edge + cs + k); c[k] = Ct.ld(l8, e[k]); }
-                llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8, !last || a.bp.keep_state != 0);
-            } else {  // the reference's two sweeps (bp.hpp:278-281, 313-316) through memory
-                double temp = prior;
-                for (int k = 0; k < d; ++k) {
-                    const int ee = sload(a.bp.csc_edge + cs + k);
-                    At.st(l8, ee, temp);
-                    temp += Ct.ld(l8, ee);
-                }
-                llr = temp;
-                double sfx = 0.0;
-                for (int k = d - 1; k >= 0; --k) {
-                    const int ee = sload(a.bp.csc_edge + cs + k);
-                    At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
-                    sfx += Ct.ld(l8, ee);
-                }
+            for (int k = 0; k < DC; ++k)
+                if (k < d) { e[k] = sload(a.bp.csc_edge + cs + k); c[k] = Ct.ld(l8, e[k]); }
+            llr = bit_column<METHOD, MATH, DC>(c, e, d, prior, At, l8, !last || a.bp.keep_state != 0);
+        } else {  // the reference's two sweeps (bp.hpp:278-281, 313-316) through memory
+            double temp = prior;
+            for (int k = 0; k < d; ++k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, temp);
+                temp += Ct.ld(l8, ee);
             }
-            const uint64_t hard = __ballot(llr <= 0);
-            if (lane == 0) a.bp.dcur[tile * n + j] = hard;
-            if ((last || each) && want_llr && lane_live) Lt.st(l8, j, llr);
+            llr = temp;
+            double sfx = 0.0;
+            for (int k = d - 1; k >= 0; --k) {
+                const int ee = sload(a.bp.csc_edge + cs + k);
+                At.st(l8, ee, edge_form<METHOD, MATH>(At.ld(l8, ee) + sfx));
+                sfx += Ct.ld(l8, ee);
+            }
         }
+        const uint64_t hard = __ballot(llr <= 0);
+        if (lane == 0) a.bp.dcur[tile * n + j] = hard;
+        if ((last || each) && want_llr && lane_live) Lt.st(l8, j, llr);
     }
 }
 
 // candidate syndrome vs syndrome (bp.hpp:292-294, 300-302) for the parked tiles, one thread per (tile, row); the
 // per-tile verdict is OR-accumulated into TileState::unsat for bp_spread_finish_kernel
 __global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a) {
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slots = spread_slots(a);
-    for (int slot = blockIdx.y; slot < slots; slot += gridDim.y) {
-        int64_t tile;
-        const TileState *st;
-        int it;
-        uint64_t done;
-        if (!spread_tile(a, slot, tile, st, it, done)) continue;
-        uint64_t unsat = 0;
-        if (i < a.bp.m) {
-            const uint64_t *dcur = a.bp.dcur + tile * a.bp.n;
-            uint64_t cand = 0;
-            for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
-            unsat = cand ^ a.bp.par[tile * a.bp.m + i];
-        }
-        unsat = wave_or(unsat);
-        if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
+    uint64_t unsat = 0;
+    if (i < a.bp.m) {
+        const uint64_t *dcur = a.bp.dcur + tile * a.bp.n;
+        uint64_t cand = 0;
+        for (int e = a.bp.row_ptr[i]; e < a.bp.row_ptr[i + 1]; ++e) cand ^= dcur[a.bp.col_idx[e]];
+        unsat = cand ^ a.bp.par[tile * a.bp.m + i];
     }
+    unsat = wave_or(unsat);
+    if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
 }
 
 // batches of only a few tiles skip the persistent kernel altogether: state + message initialisation for the per-pass path
@@ -193,13 +180,11 @@ __global__ void __launch_bounds__(256) bp_edge0_kernel(const double *llr0, int n
 // outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
 // to freeze and every workgroup but the first leaves at once.
 __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a) {
-  const int slots = spread_slots(a);
-  for (int slot = blockIdx.y; slot < slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *cst;
     int it;
     uint64_t done;
-    if (!spread_tile(a, slot, tile, cst, it, done)) continue;
+    if (!spread_tile(a, blockIdx.y, tile, cst, it, done)) return;
     TileState *st = a.bp.state + tile;
     const int par = a.round & 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -232,7 +217,7 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
             }
         }
     }
-    if (blockIdx.x != 0) continue;
+    if (blockIdx.x != 0) return;
     if (wave == 0) {
         if (mine) st->lane_iter[lane] = it;
         const int64_t b = tile * LDPC_WAVE + lane;
@@ -253,5 +238,4 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
                 __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-  }
 }

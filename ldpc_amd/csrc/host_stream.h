@@ -223,11 +223,8 @@ static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
             // messages of the tiles in flight: 2 arrays x nnz x 512 B each; beyond ~the MALL they are streamed, not cached
             pick_spread(h, (double)grid_tiles * 2.0 * (double)per_tile_msg > 384.0 * 1024.0 * 1024.0, kc, kb);
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
-            // (workgroup rows loop over the tile slots -- bp_spread_kernels.h: spread_slots -- so a round that finds few tiles still running
-            // launches 32 rows of workgroups, not one per tile that might have been parked)
-            const unsigned rows_y = grid_tiles < 32u ? grid_tiles : 32u;
-            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), rows_y), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), rows_y);
-            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), rows_y), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), rows_y);
+            const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
+            const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
             const int rounds = h->max_iter - (first_round ? first_round : a.it_start);  // (a tile parked by the persistent kernel knows its own it0)
             const volatile unsigned *flag = h->h_flag;
             for (int round = 0; round < rounds; ++round) {
