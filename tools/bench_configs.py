@@ -61,7 +61,7 @@ def main():
         # an irregular LDPC code (rows of 3 ... 16 entries, columns of 2 / 3 / 6 / 8): the streamed kernels' generic-degree variants
         # (bp_decode_kernel<., ., 16, 8, 0>: one row in registers, no register double buffer, 8-wavefront workgroups)
         h = codes.irregular_ldpc_code(10000, 5000, seed=1)
-        for p_, meth, alpha in ((0.03, 0, 1.0), (0.06, 0, 1.0), (0.06, 1, 0.75)):
+        for p_, meth, alpha in ((0.03, 0, 1.0), (0.06, 0, 1.0), (0.06, 1, 0.75), (0.12, 0, 1.0), (0.12, 1, 0.75)):  # (0.12: nothing converges -- every tile runs all 50 iterations)
             run(f"irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), {'product_sum' if meth == 0 else 'minimum_sum'} 50 it p={p_}",
                 h, p_, 50, meth, alpha, 32768, False)
     if "serial" in args.which:
