@@ -124,6 +124,13 @@ int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *hip_stream);
  * Per-syndrome early exit is preserved: the outputs of row b are those of the first iteration whose
  * hard decision reproduces syndrome b (bp.hpp:300-308), or of iteration max_iter.
  * Synchronous with respect to the host: returns after the results are in the output buffers.
+ * Host buffers (the reference API's own mode: NumPy in, NumPy out): a call of at most a few syndromes on a small code works in a
+ * host-mapped block (no copy commands); a large batch (>= 64 MiB of data in at least three chunks, everything in host memory, BP
+ * alone, rows independent of one another: the parallel and the fixed-order serial schedule) is cut into chunks of whole tiles --
+ * <= 16 384 rows, ~256 MiB of results -- that move through PINNED double buffers on two copy streams: while the kernels decode
+ * chunk c, chunk c + 1 is on its way in, chunk c - 1 on its way out, and the calling thread copies chunk c - 2 from the pinned
+ * buffer into the caller's (pageable) arrays.  Results are those of one undivided call.  Debug switches "NO_HOST_PIPELINE",
+ * "HOST_CHUNK_ROWS" (tests, measurements).  Measured (bench.py `host_io`): 0.93 of the device-resident rate without LLRs.
  */
 int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
                              uint8_t *decoding, double *llr, int32_t *iterations,
