@@ -92,6 +92,16 @@ int ldpc_hip_bposd_decode_batch(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
     return decode_batch_staged(h, 1, synd, batch, decoding, llr, iters, conv);
 }
 
+// The caller's result arrays are usually fresh allocations (np.empty) whose pages do not exist yet: writing 5 GB of log-ratios
+// into them is 1.3 million first-touch faults.  Where the kernel offers transparent huge pages on request (THP mode "madvise"),
+// ask for them on the 2 MiB-aligned inside of a large array: 512 times fewer faults.  Advice only -- no effect where THP is off.
+static void advise_huge_pages(void *p, size_t bytes) {
+    if (!p || bytes < ((size_t)64 << 20)) return;
+    const uintptr_t two_mb = (uintptr_t)2 << 20;
+    const uintptr_t lo = ((uintptr_t)p + two_mb - 1) & ~(two_mb - 1), hi = ((uintptr_t)p + bytes) & ~(two_mb - 1);
+    if (hi > lo) (void)madvise((void *)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+}
+
 // Copy between pinned staging and the caller's pageable arrays, split over a few threads: the caller's pages are usually untouched
 // (np.empty), and first-touch faults -- not memory bandwidth -- bound a single thread at 2 - 4 GB/s.
 static void host_copy_parallel(void *dst, const void *src, size_t bytes) {
@@ -138,6 +148,8 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));  // (an earlier asynchronous call may still use the workspace)
+    advise_huge_pages(decoding, (size_t)batch * n);
+    if (llr) advise_huge_pages(llr, (size_t)batch * n * 8);
     for (int q = 0; q < 2; ++q) {
         if (P.pin_in_cap < in_bytes) {
             if (P.pin_in[q]) { (void)hipHostFree(P.pin_in[q]); P.pin_in[q] = nullptr; }

@@ -6,6 +6,8 @@
 #include <random>
 #include <thread>
 
+#include <sys/mman.h>
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------

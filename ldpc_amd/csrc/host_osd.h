@@ -60,6 +60,14 @@ static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uin
     a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx;
     a.synd = synd; a.llr = llr; a.conv = conv; a.decoding = decoding;
     a.method = osd_method; a.order = osd_order; a.wt = h->d_osd_wt;
+    if (osd_method == 3 && osd_order > 0) {
+        // OSD_CS pairs (i, j), i < j < osd_order, are listed i-major and only those with j < k = n - rank exist in the reference's
+        // candidate strings (osd.hpp:91-99; beyond: a write past the string).  Their order in the list -- which is all an index is
+        // used for: the earliest of equally light candidates wins -- does not depend on osd_order once it is >= k, so a larger
+        // order is the same sweep as order k (and the kernels need not walk millions of pair numbers that name nothing).
+        const int k_bound = (double)a.m * a.m * a.words < 4e9 ? osd_k(h) : a.n;
+        if (a.order > k_bound) a.order = k_bound > 0 ? k_bound : 1;
+    }
     // small matrices: the elimination runs in registers (osd0_reg_kernel<R, W>), LDS only holds the column order
     void (*reg0)(const OsdArgs) = nullptr;
     if (!higher && h->osd_reg && !h->osd_big) {

@@ -428,6 +428,10 @@ def test_bposd_decoder_api():
     wide = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_cs", osd_order=65).decode(c["syndromes"][k])
     at_k = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_cs", osd_order=57).decode(c["syndromes"][k])
     assert np.array_equal(wide, at_k) and np.array_equal((c["h"] @ wide) % 2, c["syndromes"][k])
+    # (an absurd order is the same sweep as order k -- the pairs' places in the reference's list do not depend on it -- and must not
+    # walk 5e9 pair numbers that name nothing)
+    huge = BpOsdDecoder(c["h"], error_rate=0.06, max_iter=10, bp_method="product_sum", osd_method="osd_cs", osd_order=100000).decode(c["syndromes"][k])
+    assert np.array_equal(huge, at_k)
     with pytest.raises(NotImplementedError):
         BpOsdDecoder(c["h"], error_rate=0.06, osd_method="osd_e", osd_order=25).decode(c["syndromes"][k])
     with pytest.raises(ValueError):
