@@ -138,32 +138,41 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     const size_t o_llr = up(R * n), o_it = o_llr + (llr ? up(R * n * 8) : 0), o_cv = o_it + (iters ? up(R * 4) : 0), out_bytes = o_cv + (conv ? up(R) : 0);
     const size_t in_bytes = up(R * m ? R * m : 1);
     int rc;
-    if (!P.s_in) {
-        HIPCHK(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
-        for (int q = 0; q < 2; ++q) {
-            HIPCHK(hipEventCreateWithFlags(&P.ev_in[q], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&P.ev_cmp[q], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&P.ev_out[q], hipEventDisableTiming));
+    // streams, events, pinned and device staging: if any of it cannot be had (pinned memory is a limited resource) the caller takes
+    // the one-shot path instead -- nothing has been queued yet
+    auto setup = [&]() -> bool {
+        if (!P.s_in) {
+            if (hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking) != hipSuccess) { P.s_in = nullptr; return false; }
+            if (hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking) != hipSuccess) return false;
+            for (int q = 0; q < 2; ++q)
+                if (hipEventCreateWithFlags(&P.ev_in[q], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&P.ev_cmp[q], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&P.ev_out[q], hipEventDisableTiming) != hipSuccess) return false;
         }
-    }
+        if (!P.s_out || !P.ev_out[1]) return false;  // (an earlier attempt got stuck half way)
+        for (int q = 0; q < 2; ++q) {
+            if (P.pin_in_cap < in_bytes || !P.pin_in[q]) {
+                if (P.pin_in[q]) { (void)hipHostFree(P.pin_in[q]); P.pin_in[q] = nullptr; }
+                if (hipHostMalloc((void **)&P.pin_in[q], in_bytes, hipHostMallocDefault) != hipSuccess) { P.pin_in[q] = nullptr; P.pin_in_cap = 0; return false; }
+            }
+            if (P.pin_out_cap < out_bytes || !P.pin_out[q]) {
+                if (P.pin_out[q]) { (void)hipHostFree(P.pin_out[q]); P.pin_out[q] = nullptr; }
+                if (hipHostMalloc((void **)&P.pin_out[q], out_bytes, hipHostMallocDefault) != hipSuccess) { P.pin_out[q] = nullptr; P.pin_out_cap = 0; return false; }
+            }
+            if (P.d_in[q].ensure(in_bytes) || P.d_dec[q].ensure(R * n ? R * n : 1) || (llr && P.d_llr[q].ensure(R * n * 8 ? R * n * 8 : 1)) ||
+                P.d_it[q].ensure(R * 4) || P.d_cv[q].ensure(R)) return false;
+        }
+        if (P.pin_in_cap < in_bytes) P.pin_in_cap = in_bytes;
+        if (P.pin_out_cap < out_bytes) P.pin_out_cap = out_bytes;
+        return true;
+    };
     HIPCHK(hipStreamSynchronize(h->stream));  // (an earlier asynchronous call may still use the workspace)
+    if (!setup()) {
+        (void)hipGetLastError();
+        g_last_error.clear();
+        return 1;  // "not here": decode_batch_staged carries on with the one-shot path
+    }
     advise_huge_pages(decoding, (size_t)batch * n);
     if (llr) advise_huge_pages(llr, (size_t)batch * n * 8);
-    for (int q = 0; q < 2; ++q) {
-        if (P.pin_in_cap < in_bytes) {
-            if (P.pin_in[q]) { (void)hipHostFree(P.pin_in[q]); P.pin_in[q] = nullptr; }
-            HIPCHK(hipHostMalloc((void **)&P.pin_in[q], in_bytes, hipHostMallocDefault));
-        }
-        if (P.pin_out_cap < out_bytes) {
-            if (P.pin_out[q]) { (void)hipHostFree(P.pin_out[q]); P.pin_out[q] = nullptr; }
-            HIPCHK(hipHostMalloc((void **)&P.pin_out[q], out_bytes, hipHostMallocDefault));
-        }
-        if ((rc = P.d_in[q].ensure(in_bytes)) || (rc = P.d_dec[q].ensure(R * n ? R * n : 1)) || (llr && (rc = P.d_llr[q].ensure(R * n * 8 ? R * n * 8 : 1))) ||
-            (rc = P.d_it[q].ensure(R * 4)) || (rc = P.d_cv[q].ensure(R))) return rc;
-    }
-    if (P.pin_in_cap < in_bytes) P.pin_in_cap = in_bytes;
-    if (P.pin_out_cap < out_bytes) P.pin_out_cap = out_bytes;
     const int64_t chunks = (batch + rows - 1) / rows;
     auto rows_of = [&](int64_t c) { return c == chunks - 1 ? batch - c * rows : rows; };
     auto drain = [&](int64_t c) -> int {  // chunk c's results: pinned buffer -> the caller's arrays
@@ -266,8 +275,10 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
         if (rows < 1024) rows = 1024;
         if (h->sw("HOST_CHUNK_ROWS") > 0) rows = h->sw("HOST_CHUNK_ROWS");
         rows = (rows + LDPC_WAVE - 1) / LDPC_WAVE * LDPC_WAVE;
-        if (batch >= 3 * rows && (size_t)batch * per_row >= ((size_t)64 << 20))
-            return decode_batch_pipelined(h, synd, batch, decoding, llr, iters, conv, rows);
+        if (batch >= 3 * rows && (size_t)batch * per_row >= ((size_t)64 << 20)) {
+            const int prc = decode_batch_pipelined(h, synd, batch, decoding, llr, iters, conv, rows);
+            if (prc <= 0) return prc;  // (1: its staging could not be set up -- the one-shot path below)
+        }
     }
     if (h_synd) {
         if ((rc = h->st_synd.ensure(B * m ? B * m : 1))) return rc;
