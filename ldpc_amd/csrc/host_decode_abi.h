@@ -124,14 +124,17 @@ static void host_copy_parallel(void *dst, const void *src, size_t bytes) {
 
 // A large batch whose buffers all live in (pageable) host memory -- the reference API's only mode: NumPy in, NumPy out
 // (_bp_decoder.pyx:642-695).  One H2D copy, the kernels, four D2H copies in sequence leave the GPU idle while 0.3 - 6 GB cross PCIe
-// through the runtime's own staging.  Instead the batch is cut into chunks of whole tiles that move through pinned double buffers:
-// while the kernels decode chunk c, chunk c + 1's syndromes are already on their way in (copy stream), chunk c - 1's results are on
-// their way out (another copy stream) and the host thread copies chunk c - 2's results from the pinned buffer into the caller's
-// arrays.  Rows are independent under the parallel and the fixed-order serial schedule, so chunking changes no result (the
-// schedules that carry state from row to row are not chunked).  ldpc_hip_bp_last_kernel_ms then describes the LAST chunk only.
+// through the runtime's own staging.  Instead the batch is cut into chunks of whole tiles that move through pinned buffers, three in
+// flight: while the kernels decode chunk c, chunk c + 1's syndromes are on their way in (copy stream), chunk c - 1's results on their
+// way out (another copy stream) and a helper thread copies chunk c - 2's results from its pinned buffer into the caller's arrays
+// (with two buffers and the calling thread doing that copy, "out over PCIe" and "into the caller's array" of one chunk followed one
+// another inside every period: 42 ms against 29 ms of kernels per 2 816-row chunk with log-ratios).  Rows are independent under the
+// parallel and the fixed-order serial schedule, so chunking changes no result (the schedules that carry state from row to row are
+// not chunked).  ldpc_hip_bp_last_kernel_ms then describes the LAST chunk only.  Returns 1 if the staging could not be set up.
 static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                   double *llr, int32_t *iters, uint8_t *conv, int64_t rows) {
     auto &P = h->pipe;
+    constexpr int NB = ldpc_hip_bp::HostPipe::NB;
     const size_t m = (size_t)h->m, n = (size_t)h->n;
     auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
     const size_t R = (size_t)rows;
@@ -144,12 +147,12 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         if (!P.s_in) {
             if (hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking) != hipSuccess) { P.s_in = nullptr; return false; }
             if (hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking) != hipSuccess) return false;
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < NB; ++q)
                 if (hipEventCreateWithFlags(&P.ev_in[q], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&P.ev_cmp[q], hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&P.ev_out[q], hipEventDisableTiming) != hipSuccess) return false;
         }
-        if (!P.s_out || !P.ev_out[1]) return false;  // (an earlier attempt got stuck half way)
-        for (int q = 0; q < 2; ++q) {
+        if (!P.s_out || !P.ev_out[NB - 1]) return false;  // (an earlier attempt got stuck half way)
+        for (int q = 0; q < NB; ++q) {
             if (P.pin_in_cap < in_bytes || !P.pin_in[q]) {
                 if (P.pin_in[q]) { (void)hipHostFree(P.pin_in[q]); P.pin_in[q] = nullptr; }
                 if (hipHostMalloc((void **)&P.pin_in[q], in_bytes, hipHostMallocDefault) != hipSuccess) { P.pin_in[q] = nullptr; P.pin_in_cap = 0; return false; }
@@ -175,41 +178,69 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     if (llr) advise_huge_pages(llr, (size_t)batch * n * 8);
     const int64_t chunks = (batch + rows - 1) / rows;
     auto rows_of = [&](int64_t c) { return c == chunks - 1 ? batch - c * rows : rows; };
-    auto drain = [&](int64_t c) -> int {  // chunk c's results: pinned buffer -> the caller's arrays
-        const int q = (int)(c & 1);
-        const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
-        HIPCHK(hipEventSynchronize(P.ev_out[q]));
-        host_copy_parallel(decoding + b0 * n, P.pin_out[q], r * n);
-        if (llr) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
-        if (iters) std::memcpy(iters + b0, P.pin_out[q] + o_it, r * 4);
-        if (conv) std::memcpy(conv + b0, P.pin_out[q] + o_cv, r);
-        return LDPC_HIP_OK;
+    // the helper: chunk after chunk, wait for its results to have landed in the pinned buffer, copy them into the caller's arrays
+    std::atomic<int64_t> queued{0}, drained{0};
+    std::atomic<int> drain_err{0};
+    std::atomic<bool> stop{false};
+    const int device = h->device;
+    std::thread drainer([&]() {
+        if (hipSetDevice(device) != hipSuccess) { drain_err = 1; return; }
+        for (int64_t c = 0; c < chunks; ++c) {
+            while (queued.load(std::memory_order_acquire) <= c) {
+                if (stop.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const int q = (int)(c % NB);
+            const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+            if (hipEventSynchronize(P.ev_out[q]) != hipSuccess) { drain_err = 1; return; }
+            host_copy_parallel(decoding + b0 * n, P.pin_out[q], r * n);
+            if (llr) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
+            if (iters) std::memcpy(iters + b0, P.pin_out[q] + o_it, r * 4);
+            if (conv) std::memcpy(conv + b0, P.pin_out[q] + o_cv, r);
+            drained.store(c + 1, std::memory_order_release);
+        }
+    });
+    auto finish = [&](int code) {  // (every exit: the helper must be gone before its captures are)
+        if (code) stop.store(true, std::memory_order_release);
+        drainer.join();
+        return code;
     };
+#define PIPECHK(expr)                                                                                                            \
+    do {                                                                                                                         \
+        hipError_t _e = (expr);                                                                                                  \
+        if (_e != hipSuccess) return finish(fail(LDPC_HIP_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__)); \
+    } while (0)
     for (int64_t c = 0; c < chunks; ++c) {
-        const int q = (int)(c & 1);
+        const int q = (int)(c % NB);
         const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
-        // in: pin_in[q] is free once chunk c - 2's upload has completed
-        if (c >= 2) HIPCHK(hipEventSynchronize(P.ev_in[q]));
+        if (c >= NB) {
+            // slot q carried chunk c - NB: its upload has completed (pin_in free), and the helper has emptied its pin_out
+            PIPECHK(hipEventSynchronize(P.ev_in[q]));
+            while (drained.load(std::memory_order_acquire) <= c - NB) {
+                if (drain_err.load()) return finish(fail(LDPC_HIP_ERR_DEVICE, "the copy-out thread of the pipelined host path failed"));
+                std::this_thread::yield();
+            }
+        }
         host_copy_parallel(P.pin_in[q], synd + b0 * m, r * m);
-        if (c >= 2) HIPCHK(hipStreamWaitEvent(P.s_in, P.ev_cmp[q], 0));  // d_in[q] was chunk c - 2's input
-        if (r * m) HIPCHK(hipMemcpyAsync(P.d_in[q].p, P.pin_in[q], r * m, hipMemcpyHostToDevice, P.s_in));
-        HIPCHK(hipEventRecord(P.ev_in[q], P.s_in));
-        // compute: after this chunk's upload, and after chunk c - 2's results have left d_dec[q] ...
-        HIPCHK(hipStreamWaitEvent(h->stream, P.ev_in[q], 0));
-        if (c >= 2) HIPCHK(hipStreamWaitEvent(h->stream, P.ev_out[q], 0));
+        if (c >= NB) PIPECHK(hipStreamWaitEvent(P.s_in, P.ev_cmp[q], 0));  // d_in[q] was chunk c - NB's input
+        if (r * m) PIPECHK(hipMemcpyAsync(P.d_in[q].p, P.pin_in[q], r * m, hipMemcpyHostToDevice, P.s_in));
+        PIPECHK(hipEventRecord(P.ev_in[q], P.s_in));
+        // compute: after this chunk's upload (the results of chunk c - NB have left d_dec[q]: the helper waited for that)
+        PIPECHK(hipStreamWaitEvent(h->stream, P.ev_in[q], 0));
         if ((rc = decode_device(h, (const uint8_t *)P.d_in[q].p, (int64_t)r, (uint8_t *)P.d_dec[q].p, llr ? (double *)P.d_llr[q].p : nullptr,
-                                (int32_t *)P.d_it[q].p, (uint8_t *)P.d_cv[q].p))) return rc;
-        HIPCHK(hipEventRecord(P.ev_cmp[q], h->stream));
-        // out: pin_out[q] is free (chunk c - 2 was drained by this thread in the previous turn of the loop)
-        HIPCHK(hipStreamWaitEvent(P.s_out, P.ev_cmp[q], 0));
-        if (r * n) HIPCHK(hipMemcpyAsync(P.pin_out[q], P.d_dec[q].p, r * n, hipMemcpyDeviceToHost, P.s_out));
-        if (llr && r * n) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_llr, P.d_llr[q].p, r * n * 8, hipMemcpyDeviceToHost, P.s_out));
-        if (iters) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_it, P.d_it[q].p, r * 4, hipMemcpyDeviceToHost, P.s_out));
-        if (conv) HIPCHK(hipMemcpyAsync(P.pin_out[q] + o_cv, P.d_cv[q].p, r, hipMemcpyDeviceToHost, P.s_out));
-        HIPCHK(hipEventRecord(P.ev_out[q], P.s_out));
-        if (c >= 1 && (rc = drain(c - 1))) return rc;  // while chunk c runs
+                                (int32_t *)P.d_it[q].p, (uint8_t *)P.d_cv[q].p))) return finish(rc);
+        PIPECHK(hipEventRecord(P.ev_cmp[q], h->stream));
+        PIPECHK(hipStreamWaitEvent(P.s_out, P.ev_cmp[q], 0));
+        if (r * n) PIPECHK(hipMemcpyAsync(P.pin_out[q], P.d_dec[q].p, r * n, hipMemcpyDeviceToHost, P.s_out));
+        if (llr && r * n) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_llr, P.d_llr[q].p, r * n * 8, hipMemcpyDeviceToHost, P.s_out));
+        if (iters) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_it, P.d_it[q].p, r * 4, hipMemcpyDeviceToHost, P.s_out));
+        if (conv) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_cv, P.d_cv[q].p, r, hipMemcpyDeviceToHost, P.s_out));
+        PIPECHK(hipEventRecord(P.ev_out[q], P.s_out));
+        queued.store(c + 1, std::memory_order_release);
     }
-    if ((rc = drain(chunks - 1))) return rc;
+#undef PIPECHK
+    drainer.join();
+    if (drain_err.load()) return fail(LDPC_HIP_ERR_DEVICE, "the copy-out thread of the pipelined host path failed");
     HIPCHK(hipStreamSynchronize(h->stream));
     return LDPC_HIP_OK;
 }

@@ -4,6 +4,7 @@
 
 #include <chrono>
 #include <random>
+#include <atomic>
 #include <thread>
 
 #include <sys/mman.h>
@@ -154,11 +155,12 @@ struct ldpc_hip_bp {
     // large calls with host buffers: pinned double-buffered chunks, so that PCIe and the host's own copies overlap the kernels
     // (host_decode_abi.h: decode_batch_pipelined)
     struct HostPipe {
+        static constexpr int NB = 3;  // chunks in flight: one being decoded, one on its way out over PCIe, one being copied into the caller's arrays
         hipStream_t s_in = nullptr, s_out = nullptr;
-        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-        unsigned char *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+        hipEvent_t ev_in[NB] = {}, ev_cmp[NB] = {}, ev_out[NB] = {};
+        unsigned char *pin_in[NB] = {}, *pin_out[NB] = {};
         size_t pin_in_cap = 0, pin_out_cap = 0;
-        DeviceBuf d_in[2], d_dec[2], d_llr[2], d_it[2], d_cv[2];
+        DeviceBuf d_in[NB], d_dec[NB], d_llr[NB], d_it[NB], d_cv[NB];
     } pipe;
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel

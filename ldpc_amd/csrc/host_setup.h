@@ -146,7 +146,7 @@ void ldpc_hip_bp_destroy(ldpc_hip_bp *h) {
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->pin_host) (void)hipHostFree(h->pin_host);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < ldpc_hip_bp::HostPipe::NB; ++q) {
         if (h->pipe.pin_in[q]) (void)hipHostFree(h->pipe.pin_in[q]);
         if (h->pipe.pin_out[q]) (void)hipHostFree(h->pipe.pin_out[q]);
         if (h->pipe.ev_in[q]) (void)hipEventDestroy(h->pipe.ev_in[q]);
