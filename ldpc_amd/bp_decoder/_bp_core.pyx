@@ -144,7 +144,7 @@ cdef class CyBpCore:
             raise RuntimeError(self.bpd.last_error.decode("utf-8", "replace"))
         return np.array(self.bpd.decoding, dtype=np.uint8)
 
-    def decode_batch(self, const uint8_t[:, ::1] syndromes, bint want_llr=True, bint osd0=False):
+    def decode_batch(self, const uint8_t[:, ::1] syndromes, bint want_llr=True, bint osd0=False, llr_out=None):
         """``(B, m)`` uint8 -> ``(decoding (B, n), llr (B, n) | None, iterations (B,), converge (B,) bool)``."""
         cdef int64_t b = syndromes.shape[0]
         cdef cbool ok
@@ -157,7 +157,12 @@ cdef class CyBpCore:
         # the results go straight into the arrays that are handed out (no intermediate C++ vectors: at 65 536 x 10 000 those were
         # 6 GB zero-filled and copied once more)
         dec = np.empty((b, self.n), np.uint8)
-        llr = np.empty((b, self.n), np.float64) if want_llr else None
+        if want_llr and llr_out is not None:  # the caller's array for the log-ratios (float64, C-contiguous, (B, n))
+            if llr_out.dtype != np.float64 or llr_out.shape != (b, self.n) or not llr_out.flags.c_contiguous:
+                raise ValueError(f"llr_out must be a C-contiguous float64 array of shape ({b}, {self.n})")
+            llr = llr_out
+        else:
+            llr = np.empty((b, self.n), np.float64) if want_llr else None
         it = np.empty(b, np.int32)
         cv = np.empty(b, np.uint8)
         cdef uint8_t[:, ::1] dec_view = dec

@@ -183,20 +183,27 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     std::atomic<int> drain_err{0};
     std::atomic<bool> stop{false};
     const int device = h->device;
+    const bool clocked = h->on("HOST_PIPE_TIMING");  // (measurement: where the chunks' time goes, printed at the end)
+    double t_wait_queue = 0, t_wait_event = 0, t_copy_out = 0, t_main_in = 0, t_main_wait = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::thread drainer([&]() {
         if (hipSetDevice(device) != hipSuccess) { drain_err = 1; return; }
         for (int64_t c = 0; c < chunks; ++c) {
+            const double t0 = clocked ? now() : 0;
             while (queued.load(std::memory_order_acquire) <= c) {
                 if (stop.load(std::memory_order_acquire)) return;
                 std::this_thread::yield();
             }
             const int q = (int)(c % NB);
             const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+            const double t1 = clocked ? now() : 0;
             if (hipEventSynchronize(P.ev_out[q]) != hipSuccess) { drain_err = 1; return; }
+            const double t2 = clocked ? now() : 0;
             host_copy_parallel(decoding + b0 * n, P.pin_out[q], r * n);
             if (llr) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
             if (iters) std::memcpy(iters + b0, P.pin_out[q] + o_it, r * 4);
             if (conv) std::memcpy(conv + b0, P.pin_out[q] + o_cv, r);
+            if (clocked) { const double t3 = now(); t_wait_queue += t1 - t0; t_wait_event += t2 - t1; t_copy_out += t3 - t2; }
             drained.store(c + 1, std::memory_order_release);
         }
     });
@@ -213,6 +220,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     for (int64_t c = 0; c < chunks; ++c) {
         const int q = (int)(c % NB);
         const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+        const double tm0 = clocked ? now() : 0;
         if (c >= NB) {
             // slot q carried chunk c - NB: its upload has completed (pin_in free), and the helper has emptied its pin_out
             PIPECHK(hipEventSynchronize(P.ev_in[q]));
@@ -221,7 +229,9 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
                 std::this_thread::yield();
             }
         }
+        const double tm1 = clocked ? now() : 0;
         host_copy_parallel(P.pin_in[q], synd + b0 * m, r * m);
+        if (clocked) { t_main_wait += tm1 - tm0; t_main_in += now() - tm1; }
         if (c >= NB) PIPECHK(hipStreamWaitEvent(P.s_in, P.ev_cmp[q], 0));  // d_in[q] was chunk c - NB's input
         if (r * m) PIPECHK(hipMemcpyAsync(P.d_in[q].p, P.pin_in[q], r * m, hipMemcpyHostToDevice, P.s_in));
         PIPECHK(hipEventRecord(P.ev_in[q], P.s_in));
@@ -242,6 +252,10 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     drainer.join();
     if (drain_err.load()) return fail(LDPC_HIP_ERR_DEVICE, "the copy-out thread of the pipelined host path failed");
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (clocked)
+        fprintf(stderr, "[ldpc_hip] host pipeline: %lld chunks of %lld rows; calling thread: waited for a free slot %.1f ms, copied syndromes in %.1f ms; "
+                        "copy-out thread: waited for a queued chunk %.1f ms, for its results to land %.1f ms, copied out %.1f ms\n",
+                (long long)chunks, (long long)rows, t_main_wait * 1e3, t_main_in * 1e3, t_wait_queue * 1e3, t_wait_event * 1e3, t_copy_out * 1e3);
     return LDPC_HIP_OK;
 }
 

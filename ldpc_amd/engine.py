@@ -181,7 +181,7 @@ class HipBpEngine:
         return dc / dt * after[2] / 1e9 if dt > 0 and dc > 0 else None
 
     # -- data path --------------------------------------------------------------------------------
-    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False, osd=False):
+    def decode_batch(self, syndromes, want_llr=True, out=None, asynchronous=False, osd0=False, osd=False, llr_out=None):
         """Decode ``(B, m)`` uint8 syndromes.  Returns ``(decoding, llr|None, iterations, converge)``.
 
         ``osd0=True`` runs BP + OSD-0 (``ldpc_hip_bposd0_decode_batch``): ``decoding`` holds the OSD-0 solution for
@@ -221,7 +221,12 @@ class HipBpEngine:
             raise ValueError(f"syndromes must have shape (B, {self.m})")
         b = s.shape[0]
         dec = np.empty((b, self.n), np.uint8)  # (every element is written by the call; zero-filling 6 GB first costs as much as the decode)
-        llr = np.empty((b, self.n), np.float64) if want_llr else None
+        if want_llr and llr_out is not None:  # (NumPy path only: the caller's array for the log-ratios)
+            if llr_out.dtype != np.float64 or llr_out.shape != (b, self.n) or not llr_out.flags.c_contiguous:
+                raise ValueError(f"llr_out must be a C-contiguous float64 array of shape ({b}, {self.n})")
+            llr = llr_out
+        else:
+            llr = np.empty((b, self.n), np.float64) if want_llr else None
         it = np.empty(b, np.int32)
         cv = np.empty(b, np.uint8)
         fn = (self._lib.ldpc_hip_bposd_decode_batch if osd else

@@ -64,3 +64,27 @@ def test_bpdecoder_numpy_batch_is_the_pipelined_path_and_keeps_the_shortcut(orac
     assert not out[[3, 777, B - 1]].any() and dec.converge_batch[[3, 777, B - 1]].all() and not dec.iter_batch[[3, 777, B - 1]].any()
     ref = dec.decode_batch(torch.from_numpy(s.astype(np.uint8)).cuda(), want_log_prob_ratios=False)
     assert np.array_equal(out, ref.cpu().numpy())
+
+
+def test_log_ratio_array_is_recycled_only_when_nobody_else_holds_it(oracle_built):
+    """`log_prob_ratios_batch` of the previous call takes the next call's log-ratios when this decoder object is its only owner (at
+    65 536 x 10 000 a new 5.2 GB array per call costs more than the PCIe transfer); an array the caller kept is never written again."""
+    from ldpc_amd import codes
+    from ldpc_amd.bp_decoder import BpDecoder
+    h = codes.regular_ldpc_code(600, 3, 6, seed=2)
+    dec = BpDecoder(h, error_rate=0.05, max_iter=8, bp_method="product_sum", input_vector_type="syndrome")
+    eng = dec._get_engine()
+    s1 = eng.gen_bsc_syndromes(1, 0.05, shot0=0, shots=300, device="cuda:0").cpu().numpy()
+    s2 = eng.gen_bsc_syndromes(2, 0.05, shot0=0, shots=300, device="cuda:0").cpu().numpy()
+    dec.decode_batch(s1)
+    first_addr = dec.log_prob_ratios_batch.ctypes.data
+    want1 = dec.log_prob_ratios_batch.copy()
+    dec.decode_batch(s2)                                   # nobody kept the first array: its memory takes the second batch
+    assert dec.log_prob_ratios_batch.ctypes.data == first_addr
+    want2 = dec.log_prob_ratios_batch.copy()
+    kept = dec.log_prob_ratios_batch                       # the caller keeps the second array ...
+    dec.decode_batch(s1)
+    assert dec.log_prob_ratios_batch.ctypes.data != kept.ctypes.data and bits_equal(kept, want2)   # ... and it stays what it was
+    assert bits_equal(dec.log_prob_ratios_batch, want1)
+    dec.decode_batch(s2[:100])                             # another shape: a new array
+    assert dec.log_prob_ratios_batch.shape == (100, 600) and bits_equal(dec.log_prob_ratios_batch, want2[:100])
