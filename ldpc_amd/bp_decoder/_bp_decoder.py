@@ -633,7 +633,7 @@ class BpDecoder(BpDecoderBase):
             last = int(ran[-1])
             self._decoding = dec[last].astype(np.uint8)
             if llr is not None:
-                self._log_prob_ratios = llr[last]
+                self._log_prob_ratios = llr[last].copy()  # (a copy, not a view: a view would pin the whole batch array)
             self._iterations = int(it[last])
         if len(vec):
             self._converge = bool(cv[-1])
