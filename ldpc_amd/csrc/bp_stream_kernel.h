@@ -77,6 +77,26 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
         __syncthreads();
     }
 
+    // Second pass of a compacted decode whose rows (known to the device only) fill no more tiles than the hand-off threshold: a tile
+    // would sit alone on a compute unit (~6 ms for its first iteration on the n = 10 000 code against ~1.4 ms when the chip shares it),
+    // and the host, not knowing the count, could not send the batch to the per-pass kernels itself -- so the tile parks at once, before
+    // its first iteration, exactly as a straggler parks further down.
+    if (a.rows_dev && a.handoff_threshold > 0 && a.it_start > 0 && a.it_start < a.max_iter && (int)sload(a.rows_dev + 1) <= a.handoff_threshold) {
+        TileState *stt = a.state + tile;
+        if (wave == 0) stt->lane_iter[lane] = 0;
+        if (threadIdx.x == 0) {
+            stt->done[0] = done;
+            stt->it0 = a.it_start;
+            stt->end_round = INT32_MAX;
+            stt->unsat[0] = stt->unsat[1] = 0ull;
+            stt->llr_each[0] = 1;  // (lanes compacted out of a first pass are the ones about to converge: as bp_spread_state_init_kernel)
+            a.handoff_list[atomicAdd(&a.counters[1], 1u)] = (int32_t)tile;
+            atomicAdd(&a.counters[2], 1u);
+            clock_probe_end(a.clk, clk_stamp);
+        }
+        return;
+    }
+
     for (int it = a.it_start + 1; it <= a.max_iter; ++it) {
         // ---------------- check pass (bp.hpp:201-273) ----------------
         double alpha = 0.0;

@@ -277,10 +277,11 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     const size_t lds = 160u * 1024u - 64u;
     // lanes per syndrome: product-sum is bound by the instruction stream of one log + one tanh per bit, which four syndromes can share
     // (GS = 16) -- where their state still leaves room for a few wavefronts per compute unit; else (and for min-sum, whose sweep waits
-    // on LDS rather than on the vector unit) one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form.
+    // on LDS rather than on the vector unit) one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form (32 lanes per syndrome
+    // measured in between on both workloads -- profiles/r4_stateful_schedules.jsonl -- and is not built).
     int gs = 64;
     if (ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
-    if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 32 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
+    if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
     const int G = 64 / gs;
     const size_t per_wave = (size_t)G * per_syn + scratch;
     if (shared + (gs == 64 ? 4 : 1) * per_wave > lds) {
@@ -331,7 +332,7 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.clk = h->d_clk;
     void (*kern)(const RelLdsArgs);
 #define LDPC_PICK_REL_G(M, F, GSZ) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ> : bp_relative_lds_kernel<M, F, 16, GSZ>)
-#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16) : gs == 32 ? LDPC_PICK_REL_G(M, F, 32) : LDPC_PICK_REL_G(M, F, 64))
+#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16) : LDPC_PICK_REL_G(M, F, 64))
     if (!ps) kern = LDPC_PICK_REL(LDPC_HIP_MINIMUM_SUM, 0);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 1);
     else kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 0);
