@@ -477,7 +477,7 @@ class HipBpMultiEngine:
             sub = next((s_ for s_ in self.subs if s_.device == idx), sub)
         return sub.gen_bsc_syndromes(seed, error_rate, shot0, shots, device=device, want_errors=want_errors)
 
-    def decode_batch(self, syndromes, want_llr=True, out=None, osd0=False, osd=False, asynchronous=False):
+    def decode_batch(self, syndromes, want_llr=True, out=None, osd0=False, osd=False, asynchronous=False, llr_out=None):
         """As ``HipBpEngine.decode_batch`` (always synchronous: the call returns when every GPU has delivered its rows)."""
         with_osd = 1 if osd else (0 if osd0 else -1)
         if _is_torch(syndromes):
@@ -502,10 +502,15 @@ class HipBpMultiEngine:
         if s.ndim != 2 or s.shape[1] != self.m:
             raise ValueError(f"syndromes must have shape (B, {self.m})")
         b = s.shape[0]
-        dec = np.zeros((b, self.n), np.uint8)
-        llr = np.zeros((b, self.n), np.float64) if want_llr else None
-        it = np.zeros(b, np.int32)
-        cv = np.zeros(b, np.uint8)
+        dec = np.empty((b, self.n), np.uint8)
+        if want_llr and llr_out is not None:
+            if llr_out.dtype != np.float64 or llr_out.shape != (b, self.n) or not llr_out.flags.c_contiguous:
+                raise ValueError(f"llr_out must be a C-contiguous float64 array of shape ({b}, {self.n})")
+            llr = llr_out
+        else:
+            llr = np.empty((b, self.n), np.float64) if want_llr else None
+        it = np.empty(b, np.int32)
+        cv = np.empty(b, np.uint8)
         _lib.check(self._lib.ldpc_hip_bp_multi_decode_batch(self._mh, with_osd, s.ctypes.data, b, dec.ctypes.data,
                                                             llr.ctypes.data if want_llr else None, it.ctypes.data, cv.ctypes.data))
         return dec, llr, it, cv.astype(bool)
