@@ -49,6 +49,7 @@ struct RelLdsArgs {
     uint8_t *conv;
     int32_t *last_order;                // [n] the order the LAST row of the batch ended with (the object's state after the call)
     unsigned long long *next;           // work counter (zeroed before launch)
+    int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
     unsigned long long *clk;            // shader-clock probe or nullptr
 };
@@ -66,8 +67,11 @@ __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, in
 }
 // one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16]
 // [runs n u8][stack 64 x 3 u16]
-__host__ __device__ inline size_t rel_lds_scratch(int n) {
-    size_t b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + 64 * 3 * 2;
+// After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][start n + 2 u16][pred n dc u16].
+__host__ __device__ inline size_t rel_lds_scratch(int n, int dc) {
+    const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + 64 * 3 * 2;
+    const size_t level_b = (size_t)n * 2 * 3 + (size_t)(n + 2) * 2 + (size_t)n * dc * 2 + 8;
+    const size_t b = sort_b > level_b ? sort_b : level_b;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -373,8 +377,9 @@ __device__ __forceinline__ double group_lane(double x, int p, int lane) {  // th
 }
 }  // namespace rel_lds
 
-// GS: lanes of a syndrome (64: one per wavefront; 16: four per wavefront).  DRT: bound of the row loop (heaviest row <= DRT).
-template <int METHOD, int MATH, int DRT, int GS>
+// GS: lanes of a syndrome (64: one per wavefront; 16: four per wavefront).  DRT: bound of the row loop (heaviest row <= DRT).  DCT: bound of
+// the per-lane column arrays of the level-parallel sweep (heaviest column <= DCT; GS = 64 only).
+template <int METHOD, int MATH, int DRT, int GS, int DCT>
 __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs a) {
     using namespace rel_lds;
     constexpr int G = 64 / GS;
@@ -484,6 +489,113 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
                 sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, s_stack);
             }
+            if (GS == 64 && a.levels) {
+                // ---- the sweep, level by level ------------------------------------------------------------------------------------------
+                // Two bits that share no check commute: processing them side by side gives each exactly the operands the bit-by-bit walk
+                // gives it.  So the order is cut into LEVELS -- level(t) = 1 + the highest level among the EARLIER positions whose bit
+                // shares a check with the bit at t (none: 1) -- and a level's bits go through the update one per lane.  The levels depend on
+                // the order, i.e. on this syndrome and this iteration: worked out here, in LDS (the sort's scratch is free again).  On the
+                // d = 21 surface code ~40 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
+                l_u16 *pos = (l_u16 *)scr, *level = pos + n, *llist = level + n, *lstart = llist + n, *pred = lstart + (n + 2);
+                for (int t = lane; t < n; t += 64) pos[ord[t]] = (uint16_t)t;
+                lds_sync();
+                for (int t = lane; t < n; t += 64) {  // per entry of the bit's column: the latest earlier position in that entry's row (0xffff: none)
+                    const int bq = ord[t], cdq = cdeg[bq];
+                    level[t] = 1;
+                    for (int p = 0; p < dc; ++p) {
+                        int best = -1;
+                        if (p < cdq) {
+                            const unsigned long long rq = rec[bq * dc + p];
+                            const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32);
+                            for (int k = 0; k < rdq; ++k) {
+                                const int q = pos[rcol[rsq + k]];
+                                best = (q < t && q > best) ? q : best;
+                            }
+                        }
+                        pred[t * dc + p] = (uint16_t)(best < 0 ? 0xffff : best);
+                    }
+                }
+                lds_sync();
+                for (;;) {  // longest path by relaxation: a position's predecessors all lie before it, so this settles in (number of levels) rounds
+                    bool changed = false;
+                    for (int t = lane; t < n; t += 64) {
+                        int lv = 1;
+                        for (int p = 0; p < dc; ++p) {
+                            const int q = pred[t * dc + p];
+                            if (q != 0xffff) { const int lq = (int)level[q] + 1; lv = lq > lv ? lq : lv; }
+                        }
+                        if (lv != (int)level[t]) { level[t] = (uint16_t)lv; changed = true; }
+                    }
+                    lds_sync();
+                    if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
+                }
+                int nlev = 0;
+                for (int t = lane; t < n; t += 64) nlev = (int)level[t] > nlev ? (int)level[t] : nlev;
+                for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(nlev, off, 64); nlev = o > nlev ? o : nlev; }
+                nlev = __builtin_amdgcn_readfirstlane(nlev);
+                int filled = 0;  // the bits of level 1, then of level 2, ...: ballot compaction, level by level
+                for (int lv = 1; lv <= nlev; ++lv) {
+                    if (lane == 0) lstart[lv] = (uint16_t)filled;
+                    for (int c = 0; c < n; c += 64) {
+                        const int t = c + lane;
+                        const bool in = t < n && (int)level[t] == lv;
+                        const uint64_t mk = __builtin_amdgcn_ballot_w64(in);
+                        if (in) llist[filled + lane_rank(mk)] = ord[t];
+                        filled += __builtin_popcountll(mk);
+                    }
+                }
+                if (lane == 0) lstart[nlev + 1] = (uint16_t)filled;
+                lds_sync();
+                for (int lv = 1; lv <= nlev; ++lv) {
+                    const int i0 = lstart[lv], i1 = lstart[lv + 1];
+                    for (int i = i0 + lane; i < i1; i += 64) {
+                        const int bq = llist[i], cdq = cdeg[bq];
+                        double cvv[DCT], partv[DCT];
+                        int ev[DCT];
+                        double llr = prior[bq];
+#pragma unroll
+                        for (int p = 0; p < DCT; ++p) {  // the column, top down (bp.hpp:488-503 / 504-522)
+                            cvv[p] = 0.0; partv[p] = 0.0; ev[p] = 0;
+                            if (p < cdq) {
+                                const unsigned long long rq = rec[bq * dc + p];
+                                const int e = (int)(rq & 0xffffu), rs = (int)((rq >> 16) & 0xffffu), rd = (int)(rq >> 32);
+                                const int odd = oddtab[bq * dc + p];
+                                double av[DRT];
+                                const int last_k = rd > 0 ? rd - 1 : 0;
+#pragma unroll
+                                for (int k = 0; k < DRT; ++k) av[k] = A[rs + (k < last_k ? k : last_k)];
+                                double c;
+                                if (PS) {
+                                    double x = 1.0;
+#pragma unroll
+                                    for (int k = 0; k < DRT; ++k) x *= (k < rd && rs + k != e) ? av[k] : 1.0;
+                                    c = ps_message<MATH>(x, odd != 0, log_tab);
+                                } else {
+                                    int sgn = odd;
+                                    double temp = DBL_MAX;
+#pragma unroll
+                                    for (int k = 0; k < DRT; ++k) {
+                                        const bool use = k < rd && rs + k != e;
+                                        const double ab = fabs(av[k]);
+                                        temp = (use && ab < temp) ? ab : temp;
+                                        sgn ^= (use && av[k] <= 0) ? 1 : 0;
+                                    }
+                                    c = alpha * (sgn ? -1.0 : 1.0) * temp;
+                                }
+                                cvv[p] = c; partv[p] = llr; ev[p] = e;
+                                llr += c;
+                            }
+                        }
+                        double sfx = 0.0;
+#pragma unroll
+                        for (int p = DCT - 1; p >= 0; --p)  // ... and bottom up (bp.hpp:530-534)
+                            if (p < cdq) { A[ev[p]] = edge_form<METHOD, MATH>(partv[p] + sfx); sfx += cvv[p]; }
+                        L[bq] = llr;
+                        dbit[bq] = llr <= 0 ? 1 : 0;  // bp.hpp:525-529
+                    }
+                    lds_sync();
+                }
+            } else {
             // the sweep: every running group walks its own order
             int bit = running ? (int)ord[0] : 0;
             unsigned long long rc = 0;
@@ -543,6 +655,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 if (running && gl == 0) { L[bit] = llr; dbit[bit] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
                 lds_sync();
                 bit = bit_next; rc = rc_next; cd = cd_next; odd = odd_next;
+            }
             }
             // candidate syndrome of the current hard decision vs the syndrome (bp.hpp:537-543)
             bool differ = false;

@@ -273,15 +273,26 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     if (h->max_col_deg > 8 || h->max_row_deg > 16 || h->n >= 65535 || h->nnz >= 65535 || h->m >= 65535) return 0;
     const bool ps = h->bp_method == LDPC_HIP_PRODUCT_SUM;
     const int dc = h->max_col_deg;
-    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc), scratch = rel_lds_scratch(h->n);
+    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc), scratch = rel_lds_scratch(h->n, dc);
     const size_t lds = 160u * 1024u - 64u;
-    // lanes per syndrome: product-sum is bound by the instruction stream of one log + one tanh per bit, which four syndromes can share
-    // (GS = 16) -- where their state still leaves room for a few wavefronts per compute unit; else (and for min-sum, whose sweep waits
-    // on LDS rather than on the vector unit) one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form (32 lanes per syndrome
-    // measured in between on both workloads -- profiles/r4_stateful_schedules.jsonl -- and is not built).
+    // The sweep goes level by level (bp_relative_lds_kernel.h) when "the position of bit b" is one place: the order must be a permutation
+    // of the bits (it is, unless the caller gave a serial_schedule_order with repeats); LDPC_HIP_REL_LEVELS=0 walks bit by bit (A/B, tests).
+    bool levels = h->sw("REL_LEVELS") != 0 && (int)h->sched_state.size() == h->n;
+    if (levels) {
+        std::vector<char> seen((size_t)h->n, 0);
+        for (int t = 0; levels && t < h->n; ++t) {
+            const int b = h->sched_state[(size_t)t];
+            if (b < 0 || b >= h->n || seen[(size_t)b]) levels = false; else seen[(size_t)b] = 1;
+        }
+    }
+    // lanes per syndrome: 64 with levels (a level's bits fill the lanes).  Bit by bit, product-sum is bound by the instruction stream of
+    // one log + one tanh per bit, which four syndromes can share (GS = 16) where their state leaves room for a few wavefronts per compute
+    // unit; min-sum waits on LDS rather than on the vector unit: one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form
+    // (16 implies bit by bit; 32 lanes per syndrome measured in between -- profiles/r4_stateful_schedules.jsonl -- and is not built).
     int gs = 64;
-    if (ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
+    if (!levels && ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
     if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
+    if (gs == 16) levels = false;
     const int G = 64 / gs;
     const size_t per_wave = (size_t)G * per_syn + scratch;
     if (shared + (gs == 64 ? 4 : 1) * per_wave > lds) {
@@ -329,10 +340,11 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.last_order = (int32_t *)h->rl_last.p;
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)shared; a.lds_per_syn = (int32_t)per_syn; a.lds_scratch = (int32_t)scratch;
+    a.levels = levels ? 1 : 0;
     a.clk = h->d_clk;
     void (*kern)(const RelLdsArgs);
-#define LDPC_PICK_REL_G(M, F, GSZ) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ> : bp_relative_lds_kernel<M, F, 16, GSZ>)
-#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16) : LDPC_PICK_REL_G(M, F, 64))
+#define LDPC_PICK_REL_G(M, F, GSZ, DCT) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ, DCT> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ, DCT> : bp_relative_lds_kernel<M, F, 16, GSZ, DCT>)
+#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16, 8) : dc <= 2 ? LDPC_PICK_REL_G(M, F, 64, 2) : dc <= 4 ? LDPC_PICK_REL_G(M, F, 64, 4) : LDPC_PICK_REL_G(M, F, 64, 8))
     if (!ps) kern = LDPC_PICK_REL(LDPC_HIP_MINIMUM_SUM, 0);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 1);
     else kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 0);

@@ -59,12 +59,15 @@ def _engine(c, rel_lds=None):
     eng.set_schedule(c["schedule"])
     if c["random"]:
         eng.set_random_serial(True, c["seed"])
-    if rel_lds is not None:  # serial_relative: 0 = the per-lane kernel (state in HBM), default = one wavefront per syndrome with the state in LDS
-        eng.set_debug_switch("REL_LDS", rel_lds)
+    if rel_lds is not None:  # serial_relative: 0 = the per-lane kernel (state in HBM); 16 / 64 = on chip, that many lanes per syndrome; "walk" = on chip, bit by bit
+        if rel_lds == "walk":
+            eng.set_debug_switch("REL_LEVELS", 0)
+        else:
+            eng.set_debug_switch("REL_LDS", rel_lds)
     return eng
 
 
-KERNELS = [None, 0, 16, 64]  # (see _engine: default choice, per-lane kernel, on chip with 16 / 64 lanes per syndrome; the random schedule ignores the switch)
+KERNELS = [None, 0, 16, 64, "walk"]  # (see _engine: default = on chip, level by level; the random schedule ignores the switches)
 
 
 @pytest.mark.gpu
@@ -142,23 +145,27 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
     m, n = h.shape
     B = 3000 if code != "ldpc600" else 700
     outs = {}
-    for lds in (64, 16, 0):  # on chip: one / four syndromes per wavefront; 0: the per-lane kernel
+    for lds in (64, "walk", 16, 0):  # on chip: level by level / bit by bit with one / four syndromes per wavefront; 0: the per-lane kernel
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
         eng.set_schedule("serial_relative")
-        eng.set_debug_switch("REL_LDS", lds)
+        if lds == "walk":
+            eng.set_debug_switch("REL_LEVELS", 0)
+        else:
+            eng.set_debug_switch("REL_LDS", lds)
         s = eng.gen_bsc_syndromes(17, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
         s[7, 0] = 3  # a byte above 1: never converges
         outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
         outs[(lds, "ms")] = eng.last_kernel_ms()
         eng.close()
-    for lds in (64, 16):
+    for lds in (64, "walk", 16):
         assert same(outs[lds][:4], outs[0][:4]) and np.array_equal(outs[lds][4], outs[0][4]), lds
     assert not outs[64][3][7]
     o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
     rows = np.r_[0:40, B - 8:B]
     want = o.decode_serial_relative_batch(s[rows], fresh=True)
     assert same(tuple(x[rows] for x in outs[64][:4]), want[:4]) and np.array_equal(outs[64][4], want[4])
-    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms (64 lanes per syndrome) / {outs[(16, 'ms')]:.1f} ms (16), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
+    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms level by level, {outs[('walk', 'ms')]:.1f} / {outs[(16, 'ms')]:.1f} ms bit by bit "
+          f"(64 / 16 lanes per syndrome), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
 # ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of

@@ -154,7 +154,8 @@ def stateful():
         run(f"serial, random order per iteration: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial", random_serial=1234)
         run(f"serial_relative: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=2, schedule="serial_relative")
         if os.environ.get("LDPC_BENCH_REL_VARIANTS"):  # the on-chip kernel with 64 / 16 lanes per syndrome, and the per-lane kernel
-            for gs in (64, 16, 0):
+            run(f"serial_relative [bit by bit, REL_LEVELS=0]: {name} p={p}", h, p, it, method, alpha, 65536, False, steps=1, schedule="serial_relative", switches=(("REL_LEVELS", 0),))
+            for gs in (16, 0):
                 run(f"serial_relative [REL_LDS={gs}]: {name} p={p}", h, p, it, method, alpha, 65536 if gs else 8192, False, steps=1, schedule="serial_relative", switches=(("REL_LDS", gs),))
 
 
