@@ -52,6 +52,8 @@ struct RelLdsArgs {
     int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
     unsigned long long *clk;            // shader-clock probe or nullptr
+    unsigned long long *prof;           // nullptr, or 10 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
+                                        // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts
 };
 
 // shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
@@ -67,10 +69,11 @@ __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, in
 }
 // one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16]
 // [runs n u8][stack 64 x 3 u16]
-// After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][start n + 2 u16][pred n dc u16].
+// After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][count / start n + 2 u32].
 __host__ __device__ inline size_t rel_lds_scratch(int n, int dc) {
     const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + 64 * 3 * 2;
-    const size_t level_b = (size_t)n * 2 * 3 + (size_t)(n + 2) * 2 + (size_t)n * dc * 2 + 8;
+    const size_t level_b = (size_t)n * 2 * 3 + 4 + (size_t)(n + 2) * 4;
+    (void)dc;
     const size_t b = sort_b > level_b ? sort_b : level_b;
     return (b + 15) & ~(size_t)15;
 }
@@ -369,6 +372,30 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
     lds_sync();
 }
 
+template <int CTRL>
+__device__ __forceinline__ double quad_move(double x) {  // (two 32-bit DPP moves: 64-bit DPP allows row_newbcast only)
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true));
+}
+// out[q] = the value of lane q among the W consecutive lanes this lane belongs to (W = 2, 4: quad permutations; 8: LDS-crossbar reads)
+template <int W>
+__device__ __forceinline__ void bits_lanes(double x, int lane, double *out) {
+    if constexpr (W == 2) {
+        out[0] = quad_move<0xA0>(x);  // quad_perm [0, 0, 2, 2]
+        out[1] = quad_move<0xF5>(x);  // quad_perm [1, 1, 3, 3]
+    } else if constexpr (W == 4) {
+        out[0] = quad_move<0x00>(x);
+        out[1] = quad_move<0x55>(x);
+        out[2] = quad_move<0xAA>(x);
+        out[3] = quad_move<0xFF>(x);
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const int src = (lane & ~(W - 1)) + q;
+            out[q] = __hiloint2double(__shfl(__double2hiint(x), src, 64), __shfl(__double2loint(x), src, 64));
+        }
+    }
+}
+
 template <int GS>
 __device__ __forceinline__ double group_lane(double x, int p, int lane) {  // the value of lane p of this lane's group
     if (GS == 64) return readlane_f64(x, p);
@@ -446,6 +473,9 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     int64_t b = 0;
     bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
     int it = 0;
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = a.prof ? __builtin_readcyclecounter() : 0;
+    const unsigned long long pf_t0 = pf_t;
+#define RL_MARK(k) do { if (a.prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pf[k] += now_ - pf_t; pf_t = now_; } } while (0)
     for (int t = gl; t < n; t += GS) ord[t] = 0;  // (the sweep's look-ahead reads the order unconditionally, also in a group that has no syndrome yet)
     lds_sync();
     for (;;) {
@@ -476,8 +506,10 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             }
         }
         lds_sync();
+        RL_MARK(0);
         const uint64_t runm = __builtin_amdgcn_ballot_w64(running);
         if (runm != 0) {
+            ++pf[6];
             if (running) ++it;
             const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
             // bp.hpp:469-483: most reliable bits first -- by prior in the first iteration, by the previous posterior afterwards; the
@@ -489,6 +521,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
                 sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, s_stack);
             }
+            RL_MARK(1);
             if (GS == 64 && a.levels) {
                 // ---- the sweep, level by level ------------------------------------------------------------------------------------------
                 // Two bits that share no check commute: processing them side by side gives each exactly the operands the bit-by-bit walk
@@ -496,102 +529,137 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 // shares a check with the bit at t (none: 1) -- and a level's bits go through the update one per lane.  The levels depend on
                 // the order, i.e. on this syndrome and this iteration: worked out here, in LDS (the sort's scratch is free again).  On the
                 // d = 21 surface code ~40 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
-                l_u16 *pos = (l_u16 *)scr, *level = pos + n, *llist = level + n, *lstart = llist + n, *pred = lstart + (n + 2);
+                l_u16 *pos = (l_u16 *)scr, *level = pos + n, *llist = level + n;
+                l_u32 *lcnt = (l_u32 *)(scr + (((size_t)n * 6 + 3) & ~(size_t)3));  // [n + 2]
                 for (int t = lane; t < n; t += 64) pos[ord[t]] = (uint16_t)t;
+                for (int q = lane; q < n + 2; q += 64) lcnt[q] = 0;
                 lds_sync();
-                for (int t = lane; t < n; t += 64) {  // per entry of the bit's column: the latest earlier position in that entry's row (0xffff: none)
-                    const int bq = ord[t], cdq = cdeg[bq];
-                    level[t] = 1;
-                    for (int p = 0; p < dc; ++p) {
-                        int best = -1;
-                        if (p < cdq) {
-                            const unsigned long long rq = rec[bq * dc + p];
-                            const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32);
-                            for (int k = 0; k < rdq; ++k) {
-                                const int q = pos[rcol[rsq + k]];
-                                best = (q < t && q > best) ? q : best;
-                            }
-                        }
-                        pred[t * dc + p] = (uint16_t)(best < 0 ? 0xffff : best);
-                    }
-                }
-                lds_sync();
-                for (;;) {  // longest path by relaxation: a position's predecessors all lie before it, so this settles in (number of levels) rounds
-                    bool changed = false;
-                    for (int t = lane; t < n; t += 64) {
-                        int lv = 1;
-                        for (int p = 0; p < dc; ++p) {
-                            const int q = pred[t * dc + p];
-                            if (q != 0xffff) { const int lq = (int)level[q] + 1; lv = lq > lv ? lq : lv; }
-                        }
-                        if (lv != (int)level[t]) { level[t] = (uint16_t)lv; changed = true; }
-                    }
-                    lds_sync();
-                    if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
-                }
+                // level(t), 64 positions at a time in the order's direction: what a position depends on lies before it, so the earlier
+                // chunks' levels are final; chains INSIDE a chunk settle by a few rounds of relaxation among its 64 lanes
                 int nlev = 0;
-                for (int t = lane; t < n; t += 64) nlev = (int)level[t] > nlev ? (int)level[t] : nlev;
-                for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(nlev, off, 64); nlev = o > nlev ? o : nlev; }
-                nlev = __builtin_amdgcn_readfirstlane(nlev);
-                int filled = 0;  // the bits of level 1, then of level 2, ...: ballot compaction, level by level
-                for (int lv = 1; lv <= nlev; ++lv) {
-                    if (lane == 0) lstart[lv] = (uint16_t)filled;
-                    for (int c = 0; c < n; c += 64) {
-                        const int t = c + lane;
-                        const bool in = t < n && (int)level[t] == lv;
-                        const uint64_t mk = __builtin_amdgcn_ballot_w64(in);
-                        if (in) llist[filled + lane_rank(mk)] = ord[t];
-                        filled += __builtin_popcountll(mk);
-                    }
-                }
-                if (lane == 0) lstart[nlev + 1] = (uint16_t)filled;
-                lds_sync();
-                for (int lv = 1; lv <= nlev; ++lv) {
-                    const int i0 = lstart[lv], i1 = lstart[lv + 1];
-                    for (int i = i0 + lane; i < i1; i += 64) {
-                        const int bq = llist[i], cdq = cdeg[bq];
-                        double cvv[DCT], partv[DCT];
-                        int ev[DCT];
-                        double llr = prior[bq];
+                for (int c = 0; c < n; c += 64) {
+                    const int t = c + lane;
+                    const bool valid = t < n;
+                    int pr[DCT];  // per entry of the bit's column: the latest earlier position in that entry's row (-1: none)
+                    int lv = 1;
+                    bool inside = false;
+                    if (valid) {
+                        const int bq = ord[t], cdq = cdeg[bq];
 #pragma unroll
-                        for (int p = 0; p < DCT; ++p) {  // the column, top down (bp.hpp:488-503 / 504-522)
-                            cvv[p] = 0.0; partv[p] = 0.0; ev[p] = 0;
+                        for (int p = 0; p < DCT; ++p) {
+                            int best = -1;
                             if (p < cdq) {
                                 const unsigned long long rq = rec[bq * dc + p];
-                                const int e = (int)(rq & 0xffffu), rs = (int)((rq >> 16) & 0xffffu), rd = (int)(rq >> 32);
-                                const int odd = oddtab[bq * dc + p];
-                                double av[DRT];
-                                const int last_k = rd > 0 ? rd - 1 : 0;
-#pragma unroll
-                                for (int k = 0; k < DRT; ++k) av[k] = A[rs + (k < last_k ? k : last_k)];
-                                double c;
-                                if (PS) {
-                                    double x = 1.0;
-#pragma unroll
-                                    for (int k = 0; k < DRT; ++k) x *= (k < rd && rs + k != e) ? av[k] : 1.0;
-                                    c = ps_message<MATH>(x, odd != 0, log_tab);
-                                } else {
-                                    int sgn = odd;
-                                    double temp = DBL_MAX;
-#pragma unroll
-                                    for (int k = 0; k < DRT; ++k) {
-                                        const bool use = k < rd && rs + k != e;
-                                        const double ab = fabs(av[k]);
-                                        temp = (use && ab < temp) ? ab : temp;
-                                        sgn ^= (use && av[k] <= 0) ? 1 : 0;
-                                    }
-                                    c = alpha * (sgn ? -1.0 : 1.0) * temp;
+                                const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32);
+                                for (int k = 0; k < rdq; ++k) {
+                                    const int q = pos[rcol[rsq + k]];
+                                    best = (q < t && q > best) ? q : best;
                                 }
-                                cvv[p] = c; partv[p] = llr; ev[p] = e;
-                                llr += c;
                             }
+                            pr[p] = best;
+                            if (best >= c) inside = true;
+                            else if (best >= 0) { const int lq = (int)level[best] + 1; lv = lq > lv ? lq : lv; }
                         }
-                        double sfx = 0.0;
+                        level[t] = (uint16_t)lv;
+                    } else {
 #pragma unroll
-                        for (int p = DCT - 1; p >= 0; --p)  // ... and bottom up (bp.hpp:530-534)
-                            if (p < cdq) { A[ev[p]] = edge_form<METHOD, MATH>(partv[p] + sfx); sfx += cvv[p]; }
-                        L[bq] = llr;
-                        dbit[bq] = llr <= 0 ? 1 : 0;  // bp.hpp:525-529
+                        for (int p = 0; p < DCT; ++p) pr[p] = -1;
+                    }
+                    lds_sync();
+                    if (__builtin_amdgcn_ballot_w64(inside) != 0)
+                        for (;;) {
+                            int nl = lv;
+                            if (inside) {
+#pragma unroll
+                                for (int p = 0; p < DCT; ++p)
+                                    if (pr[p] >= c) { const int lq = (int)level[pr[p]] + 1; nl = lq > nl ? lq : nl; }
+                            }
+                            lds_sync();
+                            const bool changed = nl != lv;
+                            if (changed) { lv = nl; level[t] = (uint16_t)lv; }
+                            lds_sync();
+                            if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
+                        }
+                    if (valid) {
+                        __hip_atomic_fetch_add(&lcnt[lv], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        nlev = lv > nlev ? lv : nlev;
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(nlev, off, 64); nlev = o > nlev ? o : nlev; }
+                nlev = __builtin_amdgcn_readfirstlane(nlev);
+                lds_sync();
+                // the bits level after level: counts -> where each level starts -> every position takes the next free place of its level
+                // (which of a level's bits stands where is of no consequence: they touch disjoint messages)
+                {
+                    unsigned carry = 0;
+                    for (int base_l = 1; base_l <= nlev; base_l += 64) {
+                        const int lq = base_l + lane;
+                        const unsigned x = lq <= nlev ? lcnt[lq] : 0u;
+                        unsigned inc = x;
+                        for (int off = 1; off < 64; off <<= 1) { const unsigned o = (unsigned)__shfl_up((int)inc, off, 64); if (lane >= off) inc += o; }
+                        if (lq <= nlev) lcnt[lq] = carry + inc - x;
+                        carry += (unsigned)__shfl((int)inc, 63, 64);
+                    }
+                }
+                lds_sync();
+                for (int t = lane; t < n; t += 64) {
+                    const unsigned at = __hip_atomic_fetch_add(&lcnt[level[t]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    llist[at] = ord[t];
+                }
+                lds_sync();  // now lcnt[lv] = where level lv ends = where level lv + 1 starts; lcnt[0] = 0
+                RL_MARK(2);
+                pf[7] += (unsigned)nlev;
+                // a level's bits, DCT lanes to a bit: lane p of the bit's lanes owns the p-th entry of its column -- the row product / minimum of
+                // that check (bp.hpp:488-503 / 504-522) -- and the two column sweeps run over the lanes' values (quad moves)
+                constexpr int BPP = 64 / DCT;
+                const int slot = lane / DCT, pl = lane % DCT;
+                for (int lv = 1; lv <= nlev; ++lv) {
+                    const int i0 = (int)lcnt[lv - 1], i1 = (int)lcnt[lv];
+                    for (int i = i0 + slot; i < i1; i += BPP) {  // (a bit's lanes enter and leave together)
+                        const int bq = llist[i], cdq = cdeg[bq];
+                        const bool mine_p = pl < cdq;
+                        const int pc = mine_p ? pl : 0;  // (a lane without an entry reads entry 0's places -- its own table rows are zeroes -- and drops the result)
+                        const unsigned long long rq = rec[bq * dc + pc];
+                        const int e = (int)(rq & 0xffffu), rs = (int)((rq >> 16) & 0xffffu), rd = (int)(rq >> 32);
+                        const int odd = oddtab[bq * dc + pc];
+                        double av[DRT];
+                        const int last_k = rd > 0 ? rd - 1 : 0;
+#pragma unroll
+                        for (int k = 0; k < DRT; ++k) av[k] = A[rs + (k < last_k ? k : last_k)];
+                        double c;
+                        if (PS) {
+                            double x = 1.0;
+#pragma unroll
+                            for (int k = 0; k < DRT; ++k) x *= (k < rd && rs + k != e) ? av[k] : 1.0;
+                            c = ps_message<MATH>(x, odd != 0, log_tab);
+                        } else {
+                            int sgn = odd;
+                            double temp = DBL_MAX;
+#pragma unroll
+                            for (int k = 0; k < DRT; ++k) {
+                                const bool use = k < rd && rs + k != e;
+                                const double ab = fabs(av[k]);
+                                temp = (use && ab < temp) ? ab : temp;
+                                sgn ^= (use && av[k] <= 0) ? 1 : 0;
+                            }
+                            c = alpha * (sgn ? -1.0 : 1.0) * temp;
+                        }
+                        double cq[DCT];
+                        bits_lanes<DCT>(c, lane, cq);
+                        double llr = prior[bq], part = 0.0;
+#pragma unroll
+                        for (int q = 0; q < DCT; ++q) {  // the column, top down: entry q keeps the running sum before its own message joins it
+                            if (pl == q) part = llr;
+                            if (q < cdq) llr += cq[q];
+                        }
+                        double sfx = 0.0, b2c = 0.0;
+#pragma unroll
+                        for (int q = DCT - 1; q >= 0; --q) {  // ... and bottom up (bp.hpp:530-534)
+                            if (pl == q) b2c = part + sfx;
+                            if (q < cdq) sfx += cq[q];
+                        }
+                        if (mine_p) A[e] = edge_form<METHOD, MATH>(b2c);
+                        if (pl == 0) { L[bq] = llr; dbit[bq] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
                     }
                     lds_sync();
                 }
@@ -657,6 +725,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 bit = bit_next; rc = rc_next; cd = cd_next; odd = odd_next;
             }
             }
+            RL_MARK(3);
             // candidate syndrome of the current hard decision vs the syndrome (bp.hpp:537-543)
             bool differ = false;
             if (running)
@@ -671,6 +740,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 converged = !never && !gdiffer;
                 running = !converged && it < a.max_iter;
             }
+            RL_MARK(4);
         }
         // groups whose syndrome is done (or never ran: max_iter = 0): results out, next syndrome in
         if (have && !running) {
@@ -688,7 +758,14 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             need = true;
         }
         lds_sync();
+        RL_MARK(5);
         if (__builtin_amdgcn_ballot_w64(!exhausted) == 0 && __builtin_amdgcn_ballot_w64(have) == 0) break;
+    }
+#undef RL_MARK
+    if (a.prof && lane == 0) {
+        for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(a.prof + k, pf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.prof + 8, __builtin_readcyclecounter() - pf_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.prof + 9, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
 }

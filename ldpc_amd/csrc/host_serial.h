@@ -323,11 +323,11 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
         HIPCHK(hipMemcpy(h->rl_cdeg.p, cd.data(), cd.size(), hipMemcpyHostToDevice));
         h->rl_dc = dc;
     }
-    if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16))) return rc;
+    if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16 + 10 * 8))) return rc;
     hipStream_t st = h->stream;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 16 + 10 * 8, st));
     RelLdsArgs a = {};
     a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.dc = dc;
     a.ms_scaling_factor = h->ms_scaling_factor;
@@ -342,6 +342,7 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.lds_shared = (int32_t)shared; a.lds_per_syn = (int32_t)per_syn; a.lds_scratch = (int32_t)scratch;
     a.levels = levels ? 1 : 0;
     a.clk = h->d_clk;
+    a.prof = h->sw("REL_PROF") > 0 ? (unsigned long long *)((char *)h->counter.p + 16) : nullptr;
     void (*kern)(const RelLdsArgs);
 #define LDPC_PICK_REL_G(M, F, GSZ, DCT) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ, DCT> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ, DCT> : bp_relative_lds_kernel<M, F, 16, GSZ, DCT>)
 #define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16, 8) : dc <= 2 ? LDPC_PICK_REL_G(M, F, 64, 2) : dc <= 4 ? LDPC_PICK_REL_G(M, F, 64, 4) : LDPC_PICK_REL_G(M, F, 64, 8))
@@ -366,6 +367,14 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     // the order the LAST row ended with becomes the object's serial_schedule_order
     HIPCHK(hipMemcpyAsync(h->sched_state.data(), h->rl_last.p, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (a.prof) {  // LDPC_HIP_REL_PROF=1: where the wavefronts' cycles went (tools/profile_serial_relative.sh)
+        unsigned long long v[10];
+        HIPCHK(hipMemcpy(v, a.prof, sizeof v, hipMemcpyDeviceToHost));
+        const double tot = v[8] ? (double)v[8] : 1.0, its = v[6] ? (double)v[6] : 1.0;
+        std::fprintf(stderr, "[rel_lds gs=%d levels=%d waves/group=%d groups=%lld] cycles per wavefront-iteration %.0f: refill %.1f%% sort %.1f%% levels %.1f%% sweep %.1f%% test %.1f%% out %.1f%%; "
+                     "levels per iteration %.1f; wavefront-iterations %llu\n", gs, a.levels, waves, (long long)groups, tot / its, 100.0 * v[0] / tot, 100.0 * v[1] / tot, 100.0 * v[2] / tot,
+                     100.0 * v[3] / tot, 100.0 * v[4] / tot, 100.0 * v[5] / tot, (double)v[7] / its, v[6]);
+    }
     return 1;
 }
 
