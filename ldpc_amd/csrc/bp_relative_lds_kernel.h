@@ -52,8 +52,9 @@ struct RelLdsArgs {
     int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
     unsigned long long *clk;            // shader-clock probe or nullptr
-    unsigned long long *prof;           // nullptr, or 10 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
-                                        // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts
+    unsigned long long *prof;           // nullptr, or 14 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
+                                        // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts,
+                                        // the sort's {ranks, partitions, final pass}, partition depths
 };
 
 // shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
@@ -68,10 +69,10 @@ __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, in
     return (b + 15) & ~(size_t)15;
 }
 // one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16]
-// [runs n u8][stack 64 x 3 u16]
+// [runs n u8]
 // After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][count / start n + 2 u32].
 __host__ __device__ inline size_t rel_lds_scratch(int n, int dc) {
-    const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + 64 * 3 * 2;
+    const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7);
     const size_t level_b = (size_t)n * 2 * 3 + 4 + (size_t)(n + 2) * 4;
     (void)dc;
     const size_t b = sort_b > level_b ? sort_b : level_b;
@@ -218,24 +219,89 @@ namespace rel_lds {
 typedef __attribute__((address_space(3))) uint32_t l_u32;
 typedef __attribute__((address_space(3))) unsigned long long l_u64;
 
-// std::sort(ord, ord + n, [](a, b) { return key[a] > key[b]; }) by one wavefront.  Scratch (wave-private LDS): v / tmp u32 [n], posL /
-// posR / rank u16 [n], list u16 [n + 1], runs u8 [n], stack u16 [64 * 3] (tmp may share the room of posL + posR, list that of rank).  A word of v: (rank of the bit's key << 16) | bit; "x comes
-// before y" (key x > key y) is "rank x < rank y".
-__device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int lane, l_u32 *v, l_u32 *tmp, l_u16 *posL, l_u16 *posR, l_u16 *rank,
-                                      l_u16 *list, l_u8 *runs, l_u16 *stack) {
-    if (n <= 1) return;
-    // dense ranks: rank[b] = number of keys greater than key[b] (64 keys compared per broadcast read); any NaN key -- the comparator is no
-    // strict weak order and the reference's own result is whatever its loops happen to do: the sequential restatement (what the
-    // per-lane kernel and the CPU checker run)
+// rank[b] = number of keys greater than key[b] (equal keys, equal ranks), n <= 64 E: a bitonic network over (key, bit) pairs, E consecutive
+// places of the sequence per lane (strides < E stay in the lane's registers, the others exchange with lane ^ stride / E), descending; then a
+// key's rank is the place where its run of equal keys begins.  Which of two equal keys the network puts first does not matter: they get
+// the same rank.  Returns true (in every lane) and leaves `rank` alone if a key is NaN.
+template <int E>
+__device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l_u16 *rank) {
+    double kk[E];
+    int bb[E];
     bool nan = false;
-    for (int base0 = 0; base0 < n; base0 += 512) {  // eight keys per lane in registers, every key read once per pass
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int b = lane * E + i;
+        kk[i] = b < n ? key[b] : -__builtin_inf();  // (padding sorts last; it shares a rank with real -inf keys, after all others either way)
+        bb[i] = b < n ? b : 0xffff;
+        nan = nan || kk[i] != kk[i];
+    }
+    if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    if ((i & j) == 0) {
+                        const bool desc = ((lane * E + i) & k) == 0;
+                        // the lower place takes the greater key where this stretch runs downwards
+                        const bool sw = desc ? !(kk[i] > kk[i | j]) : !(kk[i] < kk[i | j]);
+                        const double tk = kk[i];
+                        const int tb = bb[i];
+                        kk[i] = sw ? kk[i | j] : tk;
+                        bb[i] = sw ? bb[i | j] : tb;
+                        kk[i | j] = sw ? tk : kk[i | j];
+                        bb[i | j] = sw ? tb : bb[i | j];
+                    }
+                }
+            } else {
+                const int lx = j / E;
+                const bool low = (lane & lx) == 0;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const double ok = __hiloint2double(__shfl_xor(__double2hiint(kk[i]), lx, 64), __shfl_xor(__double2loint(kk[i]), lx, 64));
+                    const int ob = __shfl_xor(bb[i], lx, 64);
+                    const bool desc = ((lane * E + i) & k) == 0;
+                    const bool want_greater = low == desc;
+                    const bool take = want_greater ? !(kk[i] > ok) : !(kk[i] < ok);  // (equal keys: both sides take the other's -- a swap)
+                    kk[i] = take ? ok : kk[i];
+                    bb[i] = take ? ob : bb[i];
+                }
+            }
+        }
+    }
+    // rank of place s = s if its key is smaller than the key before it, else the rank of the place before: a running maximum
+    const double prev_last = __hiloint2double(__shfl_up(__double2hiint(kk[E - 1]), 1, 64), __shfl_up(__double2loint(kk[E - 1]), 1, 64));
+    int rk[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const bool head = i == 0 ? (lane == 0 || prev_last > kk[0]) : kk[i > 0 ? i - 1 : 0] > kk[i];
+        const int own = head ? lane * E + i : 0;
+        rk[i] = i == 0 ? own : (own > rk[i > 0 ? i - 1 : 0] ? own : rk[i > 0 ? i - 1 : 0]);
+    }
+    int run = rk[E - 1];
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(run, off, 64); if (lane >= off && o > run) run = o; }
+    int carry = __shfl_up(run, 1, 64);
+    if (lane == 0) carry = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        if (bb[i] != 0xffff) rank[bb[i]] = (uint16_t)(rk[i] > carry ? rk[i] : carry);
+    return false;
+}
+
+// the same ranks by counting, any n: 64 keys compared per broadcast read, eight keys per lane in registers and every key read once per pass
+__device__ inline bool dense_ranks_counting(const l_f64 *key, int n, int lane, l_u16 *rank) {
+    bool nan = false;
+    for (int j = lane; j < n; j += 64) nan = nan || key[j] != key[j];
+    if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
+    for (int base0 = 0; base0 < n; base0 += 512) {
         double kb[8];
         int cnt[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int b = base0 + i * 64 + lane;
             kb[i] = b < n ? key[b] : 0.0;
-            nan = nan || kb[i] != kb[i];
             cnt[i] = 0;
         }
 #pragma unroll 2
@@ -250,31 +316,49 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             if (b < n) rank[b] = (uint16_t)cnt[i];
         }
     }
-    if (__builtin_amdgcn_ballot_w64(nan)) {
+    return false;
+}
+
+struct PackedCtx {  // rel_sort's routines on packed words
+    l_u32 *w;
+    __device__ __forceinline__ int get(long i) const { return (int)w[i]; }
+    __device__ __forceinline__ void set(long i, int x) const { w[i] = (uint32_t)x; }
+    __device__ __forceinline__ bool gt(int a, int b) const { return ((uint32_t)a >> 16) < ((uint32_t)b >> 16); }
+};
+
+// std::sort(ord, ord + n, [](a, b) { return key[a] > key[b]; }) by one wavefront.  Scratch (wave-private LDS): v / tmp u32 [n],
+// posL / posR / rank u16 [n], list u16 [n + 1], runs u8 [n] (tmp may share the room of posL + posR; list that of rank).  A word
+// of v: (rank of the bit's key << 16) | bit; "x comes before y" (key x > key y) is "rank x < rank y".
+__device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int lane, l_u32 *v, l_u32 *tmp, l_u16 *posL, l_u16 *posR, l_u16 *rank,
+                                      l_u16 *list, l_u8 *runs, unsigned long long *pfs) {
+    if (n <= 1) return;
+    unsigned long long pfs_t = pfs ? __builtin_readcyclecounter() : 0;
+#define RL_SMARK(k) do { if (pfs) { const unsigned long long now_ = __builtin_readcyclecounter(); pfs[k] += now_ - pfs_t; pfs_t = now_; } } while (0)
+    // any NaN key -- the comparator is no strict weak order and the reference's own result is whatever its loops happen to do: the
+    // sequential restatement (what the per-lane kernel and the CPU checker run)
+    const bool nan = n <= 256 ? dense_ranks<4>(key, n, lane, rank) : n <= 512 ? dense_ranks<8>(key, n, lane, rank) : dense_ranks_counting(key, n, lane, rank);
+    if (nan) {
         if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n); }
         lds_sync();
         return;
     }
     lds_sync();
+    RL_SMARK(0);
     for (int p = lane; p < n; p += 64) { const uint32_t b = ord[p]; v[p] = ((uint32_t)rank[b] << 16) | b; runs[p] = p == 0 ? 1 : 0; }
     int depth = 0;
     for (int q = n; q > 1; q >>= 1) depth++;
     depth *= 2;
-    int sp = 1;  // (wave-uniform; the entries live in LDS, written by lane 0)
-    if (lane == 0) { stack[0] = 0; stack[1] = (uint16_t)n; stack[2] = (uint16_t)depth; }
+    // the ranges still to do: entry i of the stack sits in lane i of two registers (the stack is wave-uniform and never deeper than `depth` < 64)
+    int sp = 1, stk_range = n << 16, stk_depth = depth;
     lds_sync();
     while (sp > 0) {
         --sp;
-        int first = __builtin_amdgcn_readfirstlane((int)stack[sp * 3]), last = __builtin_amdgcn_readfirstlane((int)stack[sp * 3 + 1]), d = __builtin_amdgcn_readfirstlane((int)stack[sp * 3 + 2]);
+        const int range = __builtin_amdgcn_readlane(stk_range, sp);
+        int first = range & 0xffff, last = (int)((unsigned)range >> 16), d = __builtin_amdgcn_readlane(stk_depth, sp);
         while (last - first > 16) {
             if (d == 0) {  // depth budget spent: heapsort of this range (sequential, rare: median-of-three on real posteriors stays balanced)
                 if (lane == 0) {
-                    struct PackedCtx {
-                        l_u32 *w;
-                        __device__ __forceinline__ int get(long i) const { return (int)w[i]; }
-                        __device__ __forceinline__ void set(long i, int x) const { w[i] = (uint32_t)x; }
-                        __device__ __forceinline__ bool gt(int a, int b) const { return ((uint32_t)a >> 16) < ((uint32_t)b >> 16); }
-                    } cx{v};
+                    PackedCtx cx{v};
                     rel_sort::heapsort_t(cx, first, last);
                 }
                 lds_sync();
@@ -285,6 +369,7 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             // __move_median_to_first(first, first + 1, mid, last - 1) and the pivot it leaves at `first`
             const int pa = first + 1, pb = mid, pc = last - 1;
             const uint32_t wa = v[pa], wb = v[pb], wc = v[pc], wf = v[first];
+            const uint32_t w_near = v[first + 1 + lane < last ? first + 1 + lane : last - 1];  // (the first 64 places of the partition, on their way with the median's reads)
             const uint32_t ka = wa >> 16, kb = wb >> 16, kc = wc >> 16;  // "key a > key b" = ka < kb
             int pick;
             if (ka < kb) pick = kb < kc ? pb : (ka < kc ? pc : pa);
@@ -298,7 +383,7 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             for (int c = first + 1; c < last; c += 64) {
                 const int p = c + lane;
                 const bool valid = p < last;
-                const uint32_t kv = (valid ? (p == pick ? wf : v[p]) : 0u) >> 16;
+                const uint32_t kv = (valid ? (p == pick ? wf : c == first + 1 ? w_near : v[p]) : 0u) >> 16;
                 const bool isL = valid && !(kv < pk), isR = valid && !(pk < kv);
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
                 if (isL) posL[nL + lane_rank(mL)] = (uint16_t)p;
@@ -329,12 +414,14 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             if (cut < first + 1) cut = first + 1;
             cut = __builtin_amdgcn_readfirstlane(cut);
             // __introsort_loop(cut, last, d) later; carry on with [first, cut)
-            if (lane == 0) { stack[sp * 3] = (uint16_t)cut; stack[sp * 3 + 1] = (uint16_t)last; stack[sp * 3 + 2] = (uint16_t)d; runs[cut] = 1; }
+            if (lane == sp) { stk_range = cut | (last << 16); stk_depth = d; }
+            if (lane == 0) runs[cut] = 1;
             ++sp;
             last = cut;
             lds_sync();
         }
     }
+    RL_SMARK(1);
     // __final_insertion_sort = a stable sort of every run by itself (header comment).  The runs' starts, listed; then a lane per run:
     // its <= 16 words in registers, every one placed by counting the words that come before it.
     int nruns = 0;
@@ -370,6 +457,8 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
     lds_sync();
     for (int p = lane; p < n; p += 64) ord[p] = (uint16_t)(tmp[p] & 0xffffu);
     lds_sync();
+    RL_SMARK(2);
+#undef RL_SMARK
 }
 
 template <int CTRL>
@@ -463,7 +552,6 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_u16 *s_rank = (l_u16 *)(s_tmp + n);         // (the ranks are dead once v is packed: the run list takes their room)
     l_u16 *s_list = s_rank;
     l_u8 *s_runs = (l_u8 *)s_rank + (((n + 1) * 2 + 7) & ~7);
-    l_u16 *s_stack = (l_u16 *)(s_runs + n1);
     (void)n2;
 
     // Every GROUP draws its own syndromes from the work counter and starts the next one as soon as its current one is done -- a group
@@ -473,6 +561,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     int64_t b = 0;
     bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
     int it = 0;
+    unsigned long long pfs[4] = {0, 0, 0, 0};
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = a.prof ? __builtin_readcyclecounter() : 0;
     const unsigned long long pf_t0 = pf_t;
 #define RL_MARK(k) do { if (a.prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pf[k] += now_ - pf_t; pf_t = now_; } } while (0)
@@ -519,7 +608,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 l_u8 *sb = syn_base(gg);
                 l_f64 *Lg = (l_f64 *)sb + nnz;
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
-                sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, s_stack);
+                sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, a.prof ? pfs : nullptr);
             }
             RL_MARK(1);
             if (GS == 64 && a.levels) {
@@ -766,6 +855,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
         for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(a.prof + k, pf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 8, __builtin_readcyclecounter() - pf_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 9, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 4; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
 }
