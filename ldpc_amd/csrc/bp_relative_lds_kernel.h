@@ -350,13 +350,17 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
     depth *= 2;
     // the ranges still to do: entry i of the stack sits in lane i of two registers (the stack is wave-uniform and never deeper than `depth` < 64)
     int sp = 1, stk_range = n << 16, stk_depth = depth;
+    bool in_regs = false;
+    uint32_t w_reg = 0, wf_reg = 0;
     lds_sync();
     while (sp > 0) {
         --sp;
+        in_regs = false;  // (a range from the stack: its words are in LDS)
         const int range = __builtin_amdgcn_readlane(stk_range, sp);
         int first = range & 0xffff, last = (int)((unsigned)range >> 16), d = __builtin_amdgcn_readlane(stk_depth, sp);
         while (last - first > 16) {
             if (d == 0) {  // depth budget spent: heapsort of this range (sequential, rare: median-of-three on real posteriors stays balanced)
+                lds_sync();
                 if (lane == 0) {
                     PackedCtx cx{v};
                     rel_sort::heapsort_t(cx, first, last);
@@ -366,61 +370,112 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             }
             --d;
             const int mid = first + (last - first) / 2;
-            // __move_median_to_first(first, first + 1, mid, last - 1) and the pivot it leaves at `first`
-            const int pa = first + 1, pb = mid, pc = last - 1;
-            const uint32_t wa = v[pa], wb = v[pb], wc = v[pc], wf = v[first];
-            const uint32_t w_near = v[first + 1 + lane < last ? first + 1 + lane : last - 1];  // (the first 64 places of the partition, on their way with the median's reads)
-            const uint32_t ka = wa >> 16, kb = wb >> 16, kc = wc >> 16;  // "key a > key b" = ka < kb
-            int pick;
-            if (ka < kb) pick = kb < kc ? pb : (ka < kc ? pc : pa);
-            else pick = ka < kc ? pa : (kb < kc ? pc : pb);
-            pick = __builtin_amdgcn_readfirstlane(pick);
-            const uint32_t wp = pick == pa ? wa : pick == pb ? wb : wc;
-            const uint32_t pk = __builtin_amdgcn_readfirstlane((int)(wp >> 16));
-            // __unguarded_partition(first + 1, last, pivot = first), all at once (header comment); the median swap rides along:
-            // position `pick` holds the old v[first] from here on
-            int nL = 0, nR = 0;
-            for (int c = first + 1; c < last; c += 64) {
-                const int p = c + lane;
-                const bool valid = p < last;
-                const uint32_t kv = (valid ? (p == pick ? wf : c == first + 1 ? w_near : v[p]) : 0u) >> 16;
+            const int np = last - first - 1;  // the places of the partition: first + 1 ... last - 1
+            int cut;
+            if (pfs) { ++pfs[3]; if (np > 64) pfs[3] += 1ull << 32; }
+            const unsigned long long t_part = pfs ? __builtin_readcyclecounter() : 0;
+            if (np <= 64) {
+                // The whole partition inside one 64-place window: lane i stands for place first + 1 + i and the words stay in registers.  The
+                // loop carries on with [first, cut) -- the same window, the same lanes -- so a chain of partitions reads LDS once, at its start.
+                if (!in_regs) {
+                    lds_sync();
+                    w_reg = v[first + 1 + (lane < np ? lane : np - 1)];
+                    wf_reg = v[first];
+                    in_regs = true;
+                }
+                // __move_median_to_first(first, first + 1, mid, last - 1)
+                const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)w_reg, 0), wb = (uint32_t)__builtin_amdgcn_readlane((int)w_reg, mid - first - 1),
+                               wc = (uint32_t)__builtin_amdgcn_readlane((int)w_reg, np - 1), wf = (uint32_t)__builtin_amdgcn_readfirstlane((int)wf_reg);
+                const uint32_t ka = wa >> 16, kb = wb >> 16, kc = wc >> 16;  // "key a > key b" = ka < kb
+                int pick_l;  // (as a lane of the window)
+                if (ka < kb) pick_l = kb < kc ? mid - first - 1 : (ka < kc ? np - 1 : 0);
+                else pick_l = ka < kc ? 0 : (kb < kc ? np - 1 : mid - first - 1);
+                const uint32_t wp = pick_l == 0 ? wa : pick_l == np - 1 ? wc : wb;
+                const uint32_t pk = wp >> 16;
+                const uint32_t w_here = lane == pick_l ? wf : w_reg;  // place `pick` holds the old v[first] from here on
+                // __unguarded_partition: the stoppers of the scan from the left (L, ascending) and from the right (R, descending) by rank --
+                // lane k learns L[k] and R[k] through two lane permutations (stoppers go to their rank, the other lanes fill up behind)
+                const bool valid = lane < np;
+                const uint32_t kv = w_here >> 16;
                 const bool isL = valid && !(kv < pk), isR = valid && !(pk < kv);
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
-                if (isL) posL[nL + lane_rank(mL)] = (uint16_t)p;
-                if (isR) posR[nR + lane_rank(mR)] = (uint16_t)p;  // ascending here; R[k] = posR[nR - 1 - k]
-                nL += __builtin_popcountll(mL);
-                nR += __builtin_popcountll(mR);
+                const int nL = __builtin_popcountll(mL), nR = __builtin_popcountll(mR);
+                const int rL = lane_rank(mL), aboveR = nR - lane_rank(mR) - (isR ? 1 : 0);
+                const int Lk = __builtin_amdgcn_ds_permute((isL ? rL : nL + lane - rL) << 2, lane);
+                const int Rk = __builtin_amdgcn_ds_permute((isR ? aboveR : nR + (63 - lane) - aboveR) << 2, lane);
+                const int nmin = nL < nR ? nL : nR;
+                const int K = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < nmin && Lk < Rk));  // swap L[k] <-> R[k] while L[k] < R[k]
+                const int with_l = __builtin_amdgcn_ds_bpermute(rL << 2, Rk), with_r = __builtin_amdgcn_ds_bpermute(aboveR << 2, Lk);
+                const bool swl = isL && rL < K, swr = isR && aboveR < K;  // (never both: the swapped L's all lie left of the swapped R's)
+                const uint32_t w_far = (uint32_t)__builtin_amdgcn_ds_bpermute((swl ? with_l : with_r) << 2, (int)w_here);
+                const uint32_t w_after = (swl || swr) ? w_far : w_here;
+                if (valid) v[first + 1 + lane] = w_after;
+                if (lane == 0) v[first] = wp;
+                w_reg = w_after;
+                wf_reg = wp;
+                cut = K > 0 ? first + 1 + __builtin_amdgcn_readlane(Rk, K > 0 ? K - 1 : 0) : last;  // R[K - 1]: it now holds an element the scan from the left stops at
+                if (K < nL) { const int c2 = first + 1 + __builtin_amdgcn_readlane(Lk, K < 63 ? K : 63); cut = c2 < cut ? c2 : cut; }
+                if (cut > last - 1) cut = last - 1;
+                if (cut < first + 1) cut = first + 1;
+            } else {
+                // __move_median_to_first(first, first + 1, mid, last - 1) and the pivot it leaves at `first`
+                const int pa = first + 1, pb = mid, pc = last - 1;
+                const uint32_t wa = v[pa], wb = v[pb], wc = v[pc], wf = v[first];
+                const uint32_t w_near = v[first + 1 + lane < last ? first + 1 + lane : last - 1];  // (the first 64 places of the partition, on their way with the median's reads)
+                const uint32_t ka = wa >> 16, kb = wb >> 16, kc = wc >> 16;  // "key a > key b" = ka < kb
+                int pick;
+                if (ka < kb) pick = kb < kc ? pb : (ka < kc ? pc : pa);
+                else pick = ka < kc ? pa : (kb < kc ? pc : pb);
+                pick = __builtin_amdgcn_readfirstlane(pick);
+                const uint32_t wp = pick == pa ? wa : pick == pb ? wb : wc;
+                const uint32_t pk = __builtin_amdgcn_readfirstlane((int)(wp >> 16));
+                // __unguarded_partition(first + 1, last, pivot = first), all at once (header comment); the median swap rides along:
+                // position `pick` holds the old v[first] from here on
+                int nL = 0, nR = 0;
+                for (int c = first + 1; c < last; c += 64) {
+                    const int p = c + lane;
+                    const bool valid = p < last;
+                    const uint32_t kv = (valid ? (p == pick ? wf : c == first + 1 ? w_near : v[p]) : 0u) >> 16;
+                    const bool isL = valid && !(kv < pk), isR = valid && !(pk < kv);
+                    const uint64_t mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
+                    if (isL) posL[nL + lane_rank(mL)] = (uint16_t)p;
+                    if (isR) posR[nR + lane_rank(mR)] = (uint16_t)p;  // ascending here; R[k] = posR[nR - 1 - k]
+                    nL += __builtin_popcountll(mL);
+                    nR += __builtin_popcountll(mR);
+                }
+                if (lane == 0) { v[first] = wp; v[pick] = wf; }
+                lds_sync();
+                const int nmin = nL < nR ? nL : nR;
+                int K = 0;
+                for (int k0 = 0; k0 < nmin; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool sw = k < nmin && posL[k] < posR[nR - 1 - k];
+                    const uint64_t ms = __builtin_amdgcn_ballot_w64(sw);
+                    K += __builtin_popcountll(ms);
+                    if (ms != ~0ull) break;  // L ascends, R descends: once a pair has crossed all later ones have
+                }
+                for (int k = lane; k < K; k += 64) {
+                    const int pl = posL[k], pr = posR[nR - 1 - k];
+                    const uint32_t t = v[pl];
+                    v[pl] = v[pr];
+                    v[pr] = t;
+                }
+                cut = K > 0 ? (int)posR[nR - K] : last;          // R[K - 1]: it now holds an element the scan from the left stops at
+                if (K < nL && (int)posL[K] < cut) cut = posL[K];
+                if (cut > last - 1) cut = last - 1;                  // (cannot happen with ordered keys: the median-of-three leaves a stopper)
+                if (cut < first + 1) cut = first + 1;
+                cut = __builtin_amdgcn_readfirstlane(cut);
+                lds_sync();
             }
-            if (lane == 0) { v[first] = wp; v[pick] = wf; }
-            lds_sync();
-            const int nmin = nL < nR ? nL : nR;
-            int K = 0;
-            for (int k0 = 0; k0 < nmin; k0 += 64) {
-                const int k = k0 + lane;
-                const bool sw = k < nmin && posL[k] < posR[nR - 1 - k];
-                const uint64_t ms = __builtin_amdgcn_ballot_w64(sw);
-                K += __builtin_popcountll(ms);
-                if (ms != ~0ull) break;  // L ascends, R descends: once a pair has crossed all later ones have
-            }
-            for (int k = lane; k < K; k += 64) {
-                const int pl = posL[k], pr = posR[nR - 1 - k];
-                const uint32_t t = v[pl];
-                v[pl] = v[pr];
-                v[pr] = t;
-            }
-            int cut = K > 0 ? (int)posR[nR - K] : last;          // R[K - 1]: it now holds an element the scan from the left stops at
-            if (K < nL && (int)posL[K] < cut) cut = posL[K];
-            if (cut > last - 1) cut = last - 1;                  // (cannot happen with ordered keys: the median-of-three leaves a stopper)
-            if (cut < first + 1) cut = first + 1;
-            cut = __builtin_amdgcn_readfirstlane(cut);
+            if (pfs && np <= 64) pfs[4] += __builtin_readcyclecounter() - t_part;
             // __introsort_loop(cut, last, d) later; carry on with [first, cut)
             if (lane == sp) { stk_range = cut | (last << 16); stk_depth = d; }
             if (lane == 0) runs[cut] = 1;
             ++sp;
             last = cut;
-            lds_sync();
         }
     }
+    lds_sync();
     RL_SMARK(1);
     // __final_insertion_sort = a stable sort of every run by itself (header comment).  The runs' starts, listed; then a lane per run:
     // its <= 16 words in registers, every one placed by counting the words that come before it.
@@ -561,7 +616,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     int64_t b = 0;
     bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
     int it = 0;
-    unsigned long long pfs[4] = {0, 0, 0, 0};
+    unsigned long long pfs[5] = {0, 0, 0, 0, 0};
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = a.prof ? __builtin_readcyclecounter() : 0;
     const unsigned long long pf_t0 = pf_t;
 #define RL_MARK(k) do { if (a.prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pf[k] += now_ - pf_t; pf_t = now_; } } while (0)
@@ -855,7 +910,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
         for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(a.prof + k, pf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 8, __builtin_readcyclecounter() - pf_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 9, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int k = 0; k < 4; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
 }
