@@ -2,6 +2,8 @@
 // Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
 #pragma once
 
+#include <type_traits>
+
 #include "bp_device_common.h"
 #include "bp_relative_kernel.h"
 
@@ -54,7 +56,7 @@ struct RelLdsArgs {
     unsigned long long *clk;            // shader-clock probe or nullptr
     unsigned long long *prof;           // nullptr, or 14 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
                                         // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts,
-                                        // the sort's {ranks, partitions, final pass}, partition depths
+                                        // the sort's {ranks, partitions, final pass}, partitions (those of more than 64 places << 32)
 };
 
 // shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
@@ -219,6 +221,30 @@ namespace rel_lds {
 typedef __attribute__((address_space(3))) uint32_t l_u32;
 typedef __attribute__((address_space(3))) unsigned long long l_u64;
 
+// the value of lane ^ LX: data-parallel-primitive moves inside a row of 16 lanes, the LDS crossbar beyond
+template <int LX>
+__device__ __forceinline__ int lane_xor(int x) {
+    if constexpr (LX == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]
+    else if constexpr (LX == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+    else if constexpr (LX == 4) {
+        const int lo = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);           // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11 of a row)
+        return __builtin_amdgcn_update_dpp(lo, x, 0x114, 0xf, 0xa, false);                  // row_shr:4 -> banks 1, 3
+    } else if constexpr (LX == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, true);  // row_ror:8
+    else return __shfl_xor(x, LX, 64);
+}
+// compile-time loop (the permutation controls above are instruction fields: the stage numbers must be constants in the source)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// stage t of the bitonic network: stretches of k = 2, 4, 8, ... places, strides j = k / 2, k / 4, ..., 1 inside each
+constexpr int bitonic_k(int t) { int k = 2, steps = 1; while (t >= steps) { t -= steps; ++steps; k <<= 1; } return k; }
+constexpr int bitonic_j(int t) { int k = 2, steps = 1; while (t >= steps) { t -= steps; ++steps; k <<= 1; } return (k >> 1) >> t; }
+constexpr int bitonic_stages(int places) { int m = 0; while ((1 << m) < places) ++m; return m * (m + 1) / 2; }
+
 // rank[b] = number of keys greater than key[b] (equal keys, equal ranks), n <= 64 E: a bitonic network over (key, bit) pairs, E consecutive
 // places of the sequence per lane (strides < E stay in the lane's registers, the others exchange with lane ^ stride / E), descending; then a
 // key's rank is the place where its run of equal keys begins.  Which of two equal keys the network puts first does not matter: they get
@@ -236,41 +262,38 @@ __device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l
         nan = nan || kk[i] != kk[i];
     }
     if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
+    static_for<0, bitonic_stages(64 * E)>([&](auto tc) {
+        constexpr int k = bitonic_k(decltype(tc)::value), j = bitonic_j(decltype(tc)::value);
+        if constexpr (j < E) {
 #pragma unroll
-    for (int k = 2; k <= 64 * E; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < E) {
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    if ((i & j) == 0) {
-                        const bool desc = ((lane * E + i) & k) == 0;
-                        // the lower place takes the greater key where this stretch runs downwards
-                        const bool sw = desc ? !(kk[i] > kk[i | j]) : !(kk[i] < kk[i | j]);
-                        const double tk = kk[i];
-                        const int tb = bb[i];
-                        kk[i] = sw ? kk[i | j] : tk;
-                        bb[i] = sw ? bb[i | j] : tb;
-                        kk[i | j] = sw ? tk : kk[i | j];
-                        bb[i | j] = sw ? tb : bb[i | j];
-                    }
-                }
-            } else {
-                const int lx = j / E;
-                const bool low = (lane & lx) == 0;
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const double ok = __hiloint2double(__shfl_xor(__double2hiint(kk[i]), lx, 64), __shfl_xor(__double2loint(kk[i]), lx, 64));
-                    const int ob = __shfl_xor(bb[i], lx, 64);
+            for (int i = 0; i < E; ++i) {
+                if ((i & j) == 0) {
                     const bool desc = ((lane * E + i) & k) == 0;
-                    const bool want_greater = low == desc;
-                    const bool take = want_greater ? !(kk[i] > ok) : !(kk[i] < ok);  // (equal keys: both sides take the other's -- a swap)
-                    kk[i] = take ? ok : kk[i];
-                    bb[i] = take ? ob : bb[i];
+                    // the lower place takes the greater key where this stretch runs downwards
+                    const bool sw = desc ? !(kk[i] > kk[i | j]) : !(kk[i] < kk[i | j]);
+                    const double tk = kk[i];
+                    const int tb = bb[i];
+                    kk[i] = sw ? kk[i | j] : tk;
+                    bb[i] = sw ? bb[i | j] : tb;
+                    kk[i | j] = sw ? tk : kk[i | j];
+                    bb[i | j] = sw ? tb : bb[i | j];
                 }
             }
+        } else {
+            constexpr int lx = j / E;
+            const bool low = (lane & lx) == 0;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const double ok = __hiloint2double(lane_xor<lx>(__double2hiint(kk[i])), lane_xor<lx>(__double2loint(kk[i])));
+                const int ob = lane_xor<lx>(bb[i]);
+                const bool desc = ((lane * E + i) & k) == 0;
+                const bool want_greater = low == desc;
+                const bool take = want_greater ? !(kk[i] > ok) : !(kk[i] < ok);  // (equal keys: both sides take the other's -- a swap)
+                kk[i] = take ? ok : kk[i];
+                bb[i] = take ? ob : bb[i];
+            }
         }
-    }
+    });
     // rank of place s = s if its key is smaller than the key before it, else the rank of the place before: a running maximum
     const double prev_last = __hiloint2double(__shfl_up(__double2hiint(kk[E - 1]), 1, 64), __shfl_up(__double2loint(kk[E - 1]), 1, 64));
     int rk[E];
@@ -373,7 +396,6 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
             const int np = last - first - 1;  // the places of the partition: first + 1 ... last - 1
             int cut;
             if (pfs) { ++pfs[3]; if (np > 64) pfs[3] += 1ull << 32; }
-            const unsigned long long t_part = pfs ? __builtin_readcyclecounter() : 0;
             if (np <= 64) {
                 // The whole partition inside one 64-place window: lane i stands for place first + 1 + i and the words stay in registers.  The
                 // loop carries on with [first, cut) -- the same window, the same lanes -- so a chain of partitions reads LDS once, at its start.
@@ -467,7 +489,6 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
                 cut = __builtin_amdgcn_readfirstlane(cut);
                 lds_sync();
             }
-            if (pfs && np <= 64) pfs[4] += __builtin_readcyclecounter() - t_part;
             // __introsort_loop(cut, last, d) later; carry on with [first, cut)
             if (lane == sp) { stk_range = cut | (last << 16); stk_depth = d; }
             if (lane == 0) runs[cut] = 1;
@@ -616,7 +637,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     int64_t b = 0;
     bool have = false, need = true, exhausted = false, never = false, running = false, converged = false;
     int it = 0;
-    unsigned long long pfs[5] = {0, 0, 0, 0, 0};
+    unsigned long long pfs[4] = {0, 0, 0, 0};
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t = a.prof ? __builtin_readcyclecounter() : 0;
     const unsigned long long pf_t0 = pf_t;
 #define RL_MARK(k) do { if (a.prof) { const unsigned long long now_ = __builtin_readcyclecounter(); pf[k] += now_ - pf_t; pf_t = now_; } } while (0)
@@ -679,55 +700,60 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 for (int q = lane; q < n + 2; q += 64) lcnt[q] = 0;
                 lds_sync();
                 // level(t), 64 positions at a time in the order's direction: what a position depends on lies before it, so the earlier
-                // chunks' levels are final; chains INSIDE a chunk settle by a few rounds of relaxation among its 64 lanes
+                // chunks' levels are final; chains INSIDE a chunk settle by a few rounds of relaxation among its 64 lanes (lane to lane, no LDS).
+                // pr[p]: per entry of the bit's column, the latest earlier position in that entry's row (-1: none) -- all loads of a chunk go out
+                // together (rows read to their bound DRT, clamped), and the next chunk's are on their way while this chunk's levels settle.
+                auto latest_before = [&](int c, int (&pr)[DCT]) {
+                    const int t = c + lane;
+                    const int bq = ord[t < n ? t : n - 1], cdq = t < n ? (int)cdeg[bq] : 0;
+#pragma unroll
+                    for (int p = 0; p < DCT; ++p) {
+                        const unsigned long long rq = rec[bq * dc + (p < cdq ? p : 0)];
+                        const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32), last_k = rdq > 0 ? rdq - 1 : 0;
+                        int best = -1;
+#pragma unroll
+                        for (int k = 0; k < DRT; ++k) {
+                            const int q = pos[rcol[rsq + (k < last_k ? k : last_k)]];
+                            best = (p < cdq && k < rdq && q < t && q > best) ? q : best;
+                        }
+                        pr[p] = best;
+                    }
+                };
                 int nlev = 0;
+                int pr_next[DCT];
+                latest_before(0, pr_next);
                 for (int c = 0; c < n; c += 64) {
                     const int t = c + lane;
                     const bool valid = t < n;
-                    int pr[DCT];  // per entry of the bit's column: the latest earlier position in that entry's row (-1: none)
+                    int pr[DCT];
+#pragma unroll
+                    for (int p = 0; p < DCT; ++p) pr[p] = pr_next[p];
+                    if (c + 64 < n) latest_before(c + 64, pr_next);
                     int lv = 1;
+#pragma unroll
+                    for (int p = 0; p < DCT; ++p)
+                        if (pr[p] >= 0 && pr[p] < c) { const int lq = (int)level[pr[p]] + 1; lv = lq > lv ? lq : lv; }
                     bool inside = false;
-                    if (valid) {
-                        const int bq = ord[t], cdq = cdeg[bq];
 #pragma unroll
-                        for (int p = 0; p < DCT; ++p) {
-                            int best = -1;
-                            if (p < cdq) {
-                                const unsigned long long rq = rec[bq * dc + p];
-                                const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32);
-                                for (int k = 0; k < rdq; ++k) {
-                                    const int q = pos[rcol[rsq + k]];
-                                    best = (q < t && q > best) ? q : best;
-                                }
-                            }
-                            pr[p] = best;
-                            if (best >= c) inside = true;
-                            else if (best >= 0) { const int lq = (int)level[best] + 1; lv = lq > lv ? lq : lv; }
-                        }
-                        level[t] = (uint16_t)lv;
-                    } else {
-#pragma unroll
-                        for (int p = 0; p < DCT; ++p) pr[p] = -1;
-                    }
-                    lds_sync();
+                    for (int p = 0; p < DCT; ++p) inside = inside || pr[p] >= c;
                     if (__builtin_amdgcn_ballot_w64(inside) != 0)
                         for (;;) {
                             int nl = lv;
-                            if (inside) {
 #pragma unroll
-                                for (int p = 0; p < DCT; ++p)
-                                    if (pr[p] >= c) { const int lq = (int)level[pr[p]] + 1; nl = lq > nl ? lq : nl; }
+                            for (int p = 0; p < DCT; ++p) {
+                                const int lq = __builtin_amdgcn_ds_bpermute((pr[p] >= c ? pr[p] - c : lane) << 2, lv) + 1;
+                                nl = (pr[p] >= c && lq > nl) ? lq : nl;
                             }
-                            lds_sync();
                             const bool changed = nl != lv;
-                            if (changed) { lv = nl; level[t] = (uint16_t)lv; }
-                            lds_sync();
+                            lv = nl;
                             if (__builtin_amdgcn_ballot_w64(changed) == 0) break;
                         }
                     if (valid) {
+                        level[t] = (uint16_t)lv;
                         __hip_atomic_fetch_add(&lcnt[lv], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         nlev = lv > nlev ? lv : nlev;
                     }
+                    lds_sync();
                 }
                 for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(nlev, off, 64); nlev = o > nlev ? o : nlev; }
                 nlev = __builtin_amdgcn_readfirstlane(nlev);
@@ -746,6 +772,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                     }
                 }
                 lds_sync();
+#pragma unroll 4
                 for (int t = lane; t < n; t += 64) {
                     const unsigned at = __hip_atomic_fetch_add(&lcnt[level[t]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     llist[at] = ord[t];
@@ -910,7 +937,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
         for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(a.prof + k, pf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 8, __builtin_readcyclecounter() - pf_t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(a.prof + 9, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 4; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
 }

@@ -323,11 +323,11 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
         HIPCHK(hipMemcpy(h->rl_cdeg.p, cd.data(), cd.size(), hipMemcpyHostToDevice));
         h->rl_dc = dc;
     }
-    if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16 + 15 * 8))) return rc;
+    if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16 + 14 * 8))) return rc;
     hipStream_t st = h->stream;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemsetAsync(h->counter.p, 0, 16 + 15 * 8, st));
+    HIPCHK(hipMemsetAsync(h->counter.p, 0, 16 + 14 * 8, st));
     RelLdsArgs a = {};
     a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.dc = dc;
     a.ms_scaling_factor = h->ms_scaling_factor;
@@ -368,12 +368,12 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     HIPCHK(hipMemcpyAsync(h->sched_state.data(), h->rl_last.p, (size_t)h->n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (a.prof) {  // LDPC_HIP_REL_PROF=1: where the wavefronts' cycles went (tools/profile_serial_relative.sh)
-        unsigned long long v[15];
+        unsigned long long v[14];
         HIPCHK(hipMemcpy(v, a.prof, sizeof v, hipMemcpyDeviceToHost));
         const double tot = v[8] ? (double)v[8] : 1.0, its = v[6] ? (double)v[6] : 1.0;
         std::fprintf(stderr, "[rel_lds gs=%d levels=%d waves/group=%d groups=%lld] cycles per wavefront-iteration %.0f: refill %.1f%% sort %.1f%% levels %.1f%% sweep %.1f%% test %.1f%% out %.1f%%; "
-                     "levels per iteration %.1f; wavefront-iterations %llu; of the sort: ranks %.1f%% partitions %.1f%% final pass %.1f%%, partitions per sort %.1f (of more than 64 places: %.1f), cycles in the small ones %.1f%%\n", gs, a.levels, waves, (long long)groups, tot / its, 100.0 * v[0] / tot, 100.0 * v[1] / tot, 100.0 * v[2] / tot,
-                     100.0 * v[3] / tot, 100.0 * v[4] / tot, 100.0 * v[5] / tot, (double)v[7] / its, v[6], 100.0 * v[10] / tot, 100.0 * v[11] / tot, 100.0 * v[12] / tot, (double)(v[13] & 0xffffffffull) / its, (double)(v[13] >> 32) / its, 100.0 * v[14] / tot);
+                     "levels per iteration %.1f; wavefront-iterations %llu; of the sort: ranks %.1f%% partitions %.1f%% final pass %.1f%%, partitions per sort %.1f (of more than 64 places: %.1f)\n", gs, a.levels, waves, (long long)groups, tot / its, 100.0 * v[0] / tot, 100.0 * v[1] / tot, 100.0 * v[2] / tot,
+                     100.0 * v[3] / tot, 100.0 * v[4] / tot, 100.0 * v[5] / tot, (double)v[7] / its, v[6], 100.0 * v[10] / tot, 100.0 * v[11] / tot, 100.0 * v[12] / tot, (double)(v[13] & 0xffffffffull) / its, (double)(v[13] >> 32) / its);
     }
     return 1;
 }
