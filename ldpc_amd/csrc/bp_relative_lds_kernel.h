@@ -52,6 +52,7 @@ struct RelLdsArgs {
     int32_t *last_order;                // [n] the order the LAST row of the batch ended with (the object's state after the call)
     unsigned long long *next;           // work counter (zeroed before launch)
     int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
+    int32_t scratch_in_l;               // 1: most of the sort's and the levels' scratch lives in the syndrome's posterior array (rel_lds_scratch)
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
     unsigned long long *clk;            // shader-clock probe or nullptr
     unsigned long long *prof;           // nullptr, or 14 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
@@ -70,13 +71,17 @@ __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, in
     size_t b = (size_t)nnz * 8 + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n * dc + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
     return (b + 15) & ~(size_t)15;
 }
-// one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16]
-// [runs n u8]
-// After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][count / start n + 2 u32].
-__host__ __device__ inline size_t rel_lds_scratch(int n, int dc) {
-    const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7);
-    const size_t level_b = (size_t)n * 2 * 3 + 4 + (size_t)(n + 2) * 4;
+// one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16][runs n u8]
+// After the sort the same room holds the sweep's levels: [pos n u16][level n u16][list n u16][count / start n + 2 u16].
+// in_l: between the moment the sort has the keys' ranks and the sweep, the syndrome's posteriors L[n] (8 n bytes) are dead -- the keys are read,
+// and the level-parallel sweep rewrites every bit's posterior -- so everything but v (later: the level lists and counts, which the sweep
+// reads while it writes L) can live THERE: posL / posR / tmp, rank / list, runs during the sort, pos and level afterwards.  (n <= 512: the
+// ranks of a longer code are counted in passes that read the keys again; host_serial.h decides.)
+__host__ __device__ inline size_t rel_lds_scratch(int n, int dc, bool in_l) {
     (void)dc;
+    if (in_l) return ((size_t)n * 4 + 8 + 15) & ~(size_t)15;
+    const size_t sort_b = 2 * (size_t)n * 4 + (((size_t)(n + 1) * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7);
+    const size_t level_b = (size_t)n * 2 * 3 + 4 + (size_t)(n + 2) * 2;
     const size_t b = sort_b > level_b ? sort_b : level_b;
     return (b + 15) & ~(size_t)15;
 }
@@ -621,8 +626,10 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_u8 *dbit = oddtab + nd1;         // hard decisions (a bit the order never visits keeps its 0)
     l_u8 *sy = dbit + n1;
     l_u8 *scr = wave_base + (size_t)G * a.lds_per_syn;
+    const bool in_l = a.scratch_in_l != 0;  // (GS = 64 only: `L` is the wavefront's one syndrome's)
     l_u32 *s_v = (l_u32 *)scr;
-    l_u32 *s_tmp = s_v + n;                       // (the partitions' position lists are dead when the final pass fills tmp)
+    l_u8 *room = in_l ? (l_u8 *)L : scr + (size_t)n * 4;
+    l_u32 *s_tmp = (l_u32 *)room;                 // (the partitions' position lists are dead when the final pass fills tmp)
     l_u16 *s_posL = (l_u16 *)s_tmp;
     l_u16 *s_posR = s_posL + n;
     l_u16 *s_rank = (l_u16 *)(s_tmp + n);         // (the ranks are dead once v is packed: the run list takes their room)
@@ -694,10 +701,15 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 // shares a check with the bit at t (none: 1) -- and a level's bits go through the update one per lane.  The levels depend on
                 // the order, i.e. on this syndrome and this iteration: worked out here, in LDS (the sort's scratch is free again).  On the
                 // d = 21 surface code ~40 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
-                l_u16 *pos = (l_u16 *)scr, *level = pos + n, *llist = level + n;
-                l_u32 *lcnt = (l_u32 *)(scr + (((size_t)n * 6 + 3) & ~(size_t)3));  // [n + 2]
+                l_u16 *pos = in_l ? (l_u16 *)L : (l_u16 *)scr + n, *level = pos + n, *llist = (l_u16 *)scr;
+                l_u16 *lcnt = in_l ? llist + n + (n & 1) : level + n + (n & 1);  // [n + 2], on a 4-byte boundary: counted with 32-bit atomics, two counts to a word
+                l_u32 *lcnt_w = (l_u32 *)lcnt;
+                auto count_up = [&](int lv) {  // ++lcnt[lv], returns the old count (counts stay below 65536: no carry into the neighbour)
+                    const unsigned old = __hip_atomic_fetch_add(&lcnt_w[lv >> 1], (lv & 1) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    return (lv & 1) ? old >> 16 : old & 0xffffu;
+                };
                 for (int t = lane; t < n; t += 64) pos[ord[t]] = (uint16_t)t;
-                for (int q = lane; q < n + 2; q += 64) lcnt[q] = 0;
+                for (int q = lane; q < (n + 3) / 2; q += 64) lcnt_w[q] = 0;
                 lds_sync();
                 // level(t), 64 positions at a time in the order's direction: what a position depends on lies before it, so the earlier
                 // chunks' levels are final; chains INSIDE a chunk settle by a few rounds of relaxation among its 64 lanes (lane to lane, no LDS).
@@ -750,7 +762,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                         }
                     if (valid) {
                         level[t] = (uint16_t)lv;
-                        __hip_atomic_fetch_add(&lcnt[lv], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        (void)count_up(lv);
                         nlev = lv > nlev ? lv : nlev;
                     }
                     lds_sync();
@@ -767,14 +779,14 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                         const unsigned x = lq <= nlev ? lcnt[lq] : 0u;
                         unsigned inc = x;
                         for (int off = 1; off < 64; off <<= 1) { const unsigned o = (unsigned)__shfl_up((int)inc, off, 64); if (lane >= off) inc += o; }
-                        if (lq <= nlev) lcnt[lq] = carry + inc - x;
+                        if (lq <= nlev) lcnt[lq] = (uint16_t)(carry + inc - x);
                         carry += (unsigned)__shfl((int)inc, 63, 64);
                     }
                 }
                 lds_sync();
 #pragma unroll 4
                 for (int t = lane; t < n; t += 64) {
-                    const unsigned at = __hip_atomic_fetch_add(&lcnt[level[t]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const unsigned at = count_up(level[t]);
                     llist[at] = ord[t];
                 }
                 lds_sync();  // now lcnt[lv] = where level lv ends = where level lv + 1 starts; lcnt[0] = 0

@@ -273,7 +273,8 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     if (h->max_col_deg > 8 || h->max_row_deg > 16 || h->n >= 65535 || h->nnz >= 65535 || h->m >= 65535) return 0;
     const bool ps = h->bp_method == LDPC_HIP_PRODUCT_SUM;
     const int dc = h->max_col_deg;
-    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc), scratch = rel_lds_scratch(h->n, dc);
+    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc);
+    size_t scratch = rel_lds_scratch(h->n, dc, false);
     const size_t lds = 160u * 1024u - 64u;
     // The sweep goes level by level (bp_relative_lds_kernel.h) when "the position of bit b" is one place: the order must be a permutation
     // of the bits (it is, unless the caller gave a serial_schedule_order with repeats); LDPC_HIP_REL_LEVELS=0 walks bit by bit (A/B, tests).
@@ -293,6 +294,10 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     if (!levels && ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
     if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
     if (gs == 16) levels = false;
+    // level by level every bit's posterior is rewritten by the sweep: the array is free from the sort's ranks to the sweep and houses most of the
+    // scratch (rel_lds_scratch) -- more wavefronts per compute unit.  LDPC_HIP_REL_SCRATCH_IN_L=0: separate scratch (A/B, tests).
+    const bool in_l = levels && gs == 64 && h->n >= 16 && h->n <= 512 && h->sw("REL_SCRATCH_IN_L") != 0;
+    if (in_l) scratch = rel_lds_scratch(h->n, dc, true);
     const int G = 64 / gs;
     const size_t per_wave = (size_t)G * per_syn + scratch;
     if (shared + (gs == 64 ? 4 : 1) * per_wave > lds) {
@@ -341,6 +346,7 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.next = (unsigned long long *)h->counter.p;
     a.lds_shared = (int32_t)shared; a.lds_per_syn = (int32_t)per_syn; a.lds_scratch = (int32_t)scratch;
     a.levels = levels ? 1 : 0;
+    a.scratch_in_l = in_l ? 1 : 0;
     a.clk = h->d_clk;
     a.prof = h->sw("REL_PROF") > 0 ? (unsigned long long *)((char *)h->counter.p + 16) : nullptr;
     void (*kern)(const RelLdsArgs);

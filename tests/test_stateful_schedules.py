@@ -62,12 +62,14 @@ def _engine(c, rel_lds=None):
     if rel_lds is not None:  # serial_relative: 0 = the per-lane kernel (state in HBM); 16 / 64 = on chip, that many lanes per syndrome; "walk" = on chip, bit by bit
         if rel_lds == "walk":
             eng.set_debug_switch("REL_LEVELS", 0)
+        elif rel_lds == "apart":
+            eng.set_debug_switch("REL_SCRATCH_IN_L", 0)
         else:
             eng.set_debug_switch("REL_LDS", rel_lds)
     return eng
 
 
-KERNELS = [None, 0, 16, 64, "walk"]  # (see _engine: default = on chip, level by level; the random schedule ignores the switches)
+KERNELS = [None, 0, 16, 64, "walk", "apart"]  # (see _engine: default = on chip, level by level; the random schedule ignores the switches)
 
 
 @pytest.mark.gpu
@@ -145,11 +147,13 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
     m, n = h.shape
     B = 3000 if code != "ldpc600" else 700
     outs = {}
-    for lds in (64, "walk", 16, 0):  # on chip: level by level / bit by bit with one / four syndromes per wavefront; 0: the per-lane kernel
+    for lds in (64, "apart", "walk", 16, 0):  # on chip: level by level (scratch in the posterior array / apart), bit by bit with one / four syndromes per wavefront; 0: the per-lane kernel
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
         eng.set_schedule("serial_relative")
         if lds == "walk":
             eng.set_debug_switch("REL_LEVELS", 0)
+        elif lds == "apart":
+            eng.set_debug_switch("REL_SCRATCH_IN_L", 0)
         else:
             eng.set_debug_switch("REL_LDS", lds)
         s = eng.gen_bsc_syndromes(17, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
@@ -157,14 +161,14 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
         outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
         outs[(lds, "ms")] = eng.last_kernel_ms()
         eng.close()
-    for lds in (64, "walk", 16):
+    for lds in (64, "apart", "walk", 16):
         assert same(outs[lds][:4], outs[0][:4]) and np.array_equal(outs[lds][4], outs[0][4]), lds
     assert not outs[64][3][7]
     o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
     rows = np.r_[0:40, B - 8:B]
     want = o.decode_serial_relative_batch(s[rows], fresh=True)
     assert same(tuple(x[rows] for x in outs[64][:4]), want[:4]) and np.array_equal(outs[64][4], want[4])
-    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms level by level, {outs[('walk', 'ms')]:.1f} / {outs[(16, 'ms')]:.1f} ms bit by bit "
+    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms level by level ({outs[('apart', 'ms')]:.1f} with the scratch apart), {outs[('walk', 'ms')]:.1f} / {outs[(16, 'ms')]:.1f} ms bit by bit "
           f"(64 / 16 lanes per syndrome), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
