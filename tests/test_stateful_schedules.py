@@ -172,6 +172,35 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
           f"(64 / 16 lanes per syndrome), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["permutation", "repeats"])
+def test_serial_relative_on_chip_with_a_starting_order(kind, oracle_built):
+    """A serial_schedule_order given by the caller: a permutation of the bits goes level by level; one with repeated bits (the reference
+    takes any n bit numbers) has no "position of bit b" and must take the bit-by-bit walk -- both against the per-lane kernel and the checker."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.bivariate_bicycle_hx()
+    m, n = h.shape
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n).astype(np.int32)
+    if kind == "repeats":
+        order[10:30] = order[40:60]  # twenty bits twice, twenty never
+    p, max_iter, B = 0.06, 9, 500
+    outs = {}
+    for lds in (None, 0):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 1, 0.625)
+        eng.set_schedule("serial_relative", order)
+        if lds is not None:
+            eng.set_debug_switch("REL_LDS", lds)
+        s = eng.gen_bsc_syndromes(23, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+        outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
+        eng.close()
+    assert same(outs[None][:4], outs[0][:4]) and np.array_equal(outs[None][4], outs[0][4])
+    o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=1, ms_scaling_factor=0.625)
+    want = o.decode_serial_relative_batch(s, order_state=order, fresh=True)
+    assert same(outs[None][:4], want[:4]) and np.array_equal(outs[None][4], want[4])
+
+
 # ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of
 # every iteration that runs by std::shuffle with a NEW std::default_random_engine(random_schedule_seed) -----------------------------
 
