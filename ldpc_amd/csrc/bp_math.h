@@ -288,9 +288,9 @@ LDPC_HD double log_libm(double q, const double *tab) {
     double y;
     if (ix - LO < HI - LO) {
         const double r = q - 1.0, r2 = r * r, r3 = r * r2;
-        const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_(r, B[8], B[7])));
-        const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_(r, B[5], B[4])));
-        const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_(r, B[2], B[1])));
+        const double p3 = fma_(r3, B[10], fma_(r2, B[9], fma_kk(r, B[8], B[7])));
+        const double p2 = fma_(r3, p3, fma_(r2, B[6], fma_kk(r, B[5], B[4])));
+        const double p1 = fma_(r3, p2, fma_(r2, B[3], fma_kk(r, B[2], B[1])));
         double w = r * 0x1p27;
         const double rhi = r + w - w;
         const double rlo = r - rhi;
@@ -312,7 +312,7 @@ LDPC_HD double log_libm(double q, const double *tab) {
         const double hi = w + r;
         const double lo = fma_(kd, Ln2lo, w - hi + r);
         const double r2 = r * r;
-        const double poly = fma_(r2, fma_(r, A[4], A[3]), fma_(r, A[2], A[1]));
+        const double poly = fma_(r2, fma_kk(r, A[4], A[3]), fma_kk(r, A[2], A[1]));
         y = fma_(r * r2, poly, fma_(r2, A[0], lo)) + hi;
     }
     if (LDPC_ANY(ix - 0x0010000000000000ull >= 0x7ff0000000000000ull - 0x0010000000000000ull)) {  // 0, inf, NaN (never subnormal here)

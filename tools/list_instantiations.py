@@ -24,8 +24,7 @@ RULES = {  # template -> who selects which instantiation
     "bp_serial_level_kernel": "host_serial.h pick_serial_level: serial schedule, level-parallel",
     "bp_softinfo_kernel": "host_serial.h soft_info_device", "bp_softinfo_level_kernel": "host_serial.h soft_info_device (level-parallel)",
     "bp_serial_relative_kernel": "host_serial.h decode_serial_relative: codes beyond LDS (or LDPC_HIP_REL_LDS=0)",
-    "bp_relative_lds_kernel": "host_serial.h decode_serial_relative_lds: <METHOD, MATH, DRT in 4/8/16, GS>: GS = 16 for product-sum where four syndromes per wavefront fit, "
-                              "else 64 (32: measurement switch)",
+    "bp_relative_lds_kernel": "host_serial.h decode_serial_relative_lds: <METHOD, MATH, DRT in 4/8/16, GS, DCT>: GS = 64 lanes per syndrome and the level-by-level sweep (DCT = 2/4/8 lanes per bit >= the heaviest column) when the order is a permutation of the bits; else bit by bit, product-sum with GS = 16 where four syndromes per wavefront fit (DCT 8 unused).  The 1 - 2 spilled VGPRs of the min-sum forms (~30 of the product-sum ones) sit around the call of the out-of-line sort, once per iteration",
     "osd0_reg_kernel": "host_osd.h: OSD-0, m <= 64/128/256", "osdw_reg_kernel": "host_osd.h: OSD_E / OSD_CS, m <= 256 and n <= 511",
     "osd_big_kernel": "host_osd.h: <HIGHER, MAT_LDS> workgroup per syndrome", "osd0_kernel": "host_osd.h", "osdw_kernel": "host_osd.h",
 }

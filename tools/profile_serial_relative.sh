@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC picture of bp_relative_lds_kernel on the surface code (serial_relative, min-sum) and BB144 (product-sum)
+# PMC picture of bp_relative_lds_kernel on the surface code (serial_relative, min-sum) and BB144 (product-sum), and where its wavefronts spend their cycles
 set -u
 OUT=$PWD/gpurun_out/prof_serial_relative
 mkdir -p "$OUT"
@@ -31,7 +31,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   timeout 300 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/$which$i" -o pmc -- python /tmp/rel_run.py $which >> "$OUT/log.txt" 2>&1
 done
 done
-python - "$OUT" <<'PY'
+python - "$OUT" > "$OUT/summary.txt" <<'PY'
 import glob, os, sqlite3, sys
 out = sys.argv[1]
 for which in ("surface", "bb"):
@@ -45,3 +45,6 @@ for which in ("surface", "bb"):
     for k, (v, ms) in sorted(res.items()):
         print(f"  {k:28s} {v:16.0f} per dispatch   ({ms:.2f} ms)")
 PY
+echo "phases (LDPC_HIP_REL_PROF=1, tools/serial_relative_phases.py; 65 536 syndromes):" >> "$OUT/summary.txt"
+timeout 300 python tools/serial_relative_phases.py surface bb bbms 2>&1 | grep -v amdgpu.ids >> "$OUT/summary.txt"
+cat "$OUT/summary.txt"
