@@ -1,4 +1,4 @@
-// bp_relative_lds_kernel.h -- schedule = serial_relative with the whole decode of a syndrome on chip: state in LDS, 1 or 4 syndromes per wavefront
+// bp_relative_lds_kernel.h -- schedule = serial_relative with the whole decode of a syndrome on chip: state in LDS, a wavefront (or a quarter of one) per syndrome
 // Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
 #pragma once
 
@@ -12,23 +12,27 @@
 // batch-minor arrays in HBM: every access of a wavefront is 64 separate cache lines and the sort is 64 divergent introsorts --
 // correct, and 24 - 70 x slower than the fixed-order serial kernel (0.09 M syndromes/s on the d = 21 surface code).  For codes whose
 // state fits in LDS this kernel keeps a syndrome's messages, posteriors and order in LDS and gives it a GROUP of GS lanes -- the
-// whole wavefront (GS = 64), or a quarter of it (GS = 16: four syndromes per wavefront share every instruction of the sweep, which is
-// what product-sum wants -- its cost is the instruction stream of one log and one tanh per bit, executed for however many lanes):
-//   * the sweep stays sequential over the bits of the SYNDROME's order (that is what the schedule means); per bit, lane p < column
-//     weight of the group owns the bit's p-th check: it multiplies / minimises over the row's other entries in row order (the
-//     reference's association, bp.hpp:491-523); the posterior and the two column sweeps (bp.hpp:501-503 / 520-522, 530-534) are chains
-//     over the group's values, every lane redoing them, lane p keeping its own bit_to_check.  What the next bit needs that does not
-//     depend on this bit's messages (its number, its table record, its checks' syndrome bits) is fetched while this bit computes;
-//   * std::sort is re-enacted IN PARALLEL by the whole wavefront, result for result (one syndrome of the wavefront after the other).
-//     The keys are first replaced by their dense ranks (rank = how many keys are greater: equal keys, equal ranks -- the comparator
-//     sees exactly what it saw) and packed with the bit number into one word per position, so no step chases a pointer.  libstdc++'s
+// whole wavefront (GS = 64, the form host_serial.h picks), or a quarter of it (GS = 16, bit-by-bit product-sum only):
+//   * THE SWEEP, LEVEL BY LEVEL (GS = 64, the order a permutation of the bits).  Two bits that share no check commute: side by side
+//     each gets exactly the operands the one-after-the-other walk gives it.  So per syndrome and iteration the order is cut into
+//     levels -- level(position) = 1 + the highest level among the earlier positions whose bit shares a check with this one -- and a
+//     level's bits are updated together, DCT lanes to a bit: lane p owns the p-th entry of the bit's column, forms that check's
+//     message from the row's other entries in row order (the reference's association, bp.hpp:491-523), and the posterior and the
+//     two column sweeps (bp.hpp:501-503 / 520-522, 530-534) run over the DCT lanes' values by quad moves.  25 levels stand for the 441
+//     bit steps of the d = 21 surface code, 33 for BB144's 144;
+//   * the sweep, bit by bit (a caller's order with repeated bits, GS = 16, LDPC_HIP_REL_LEVELS=0): per bit, lane p < column weight of
+//     the group owns the bit's p-th check; the chains run over the group's values, every lane redoing them;
+//   * std::sort is re-enacted IN PARALLEL by the whole wavefront, result for result.  The keys are first replaced by their dense
+//     ranks (rank = how many keys are greater: equal keys, equal ranks -- the comparator sees exactly what it saw; a bitonic network in
+//     registers up to 512 keys) and packed with the bit number into one word per position, so no step chases a pointer.  libstdc++'s
 //     introsort is (i) median-of-three + an unguarded Hoare partition down to runs of 16, (ii) heapsort when the depth budget is
 //     spent, (iii) one final insertion sort.
 //       (i)  A partition's outcome is a function of the ORIGINAL arrangement: with L = the positions, ascending, whose key does not
 //            precede the pivot's (where the scan from the left stops) and R = the positions, descending, whose key the pivot's does
 //            not precede (where the scan from the right stops), the loop swaps L[k] <-> R[k] while L[k] < R[k] -- both scans only
 //            ever see untouched elements before they meet -- and returns min(L[K], R[K - 1]) after K swaps.  So: two ballots per 64
-//            positions, ranks by mbcnt, K by a count, all swaps at once.
+//            positions, ranks by mbcnt, K by a count, all swaps at once -- through LDS lists for a range of more than 64 places, in
+//            registers (a lane per place, stoppers sent to their ranks by lane permutations) below that.
 //       (iii) insertion sort is STABLE, and after (i) every run of <= 16 is ordered against its neighbours: the final pass is a stable
 //            sort of each run by itself -- a lane takes a run, holds it in registers and places every element by counting.
 //       (ii) (and any NaN key, where the reference's comparator is not a strict weak order) falls back to the sequential restatement
@@ -66,9 +70,10 @@ __host__ __device__ inline size_t rel_lds_shared(int m, int n, int nnz, int dc, 
     b += ((size_t)(m + 1) * 2 + (size_t)nnz * 2 + (size_t)n + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
 }
-// one syndrome: [A nnz f64][L n f64][ord n u16][oddtab n dc u8][dbit n u8][sy m u8]
+// one syndrome: [A nnz f64][L n f64][ord n u16][dbit n u8][sy m u8]
 __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, int dc) {
-    size_t b = (size_t)nnz * 8 + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n * dc + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
+    size_t b = (size_t)nnz * 8 + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
+    (void)dc;
     return (b + 15) & ~(size_t)15;
 }
 // one wavefront's sort scratch: [v n u32][posL n u16, posR n u16 -- later tmp n u32 in the same room][rank n u16 -- later the run list n + 1 u16][runs n u8]
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_f64 *pform = prior + n;
     l_f64 *log_tab_l = pform + (PS ? n : 0);
     const double *log_tab = reinterpret_cast<const double *>(rl_lds) + (size_t)n + (PS ? (size_t)n : 0);
-    l_u64 *rec = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32
+    l_u64 *rec = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32 | check << 48
     l_u16 *rstart = (l_u16 *)(rec + (size_t)n * dc);
     l_u16 *rcol = rstart + (m + 1);
     l_u8 *cdeg = (l_u8 *)(rcol + nnz);
@@ -605,7 +610,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     for (int q = tid; q < n * dc; q += T) {
         const int chk = a.t_chk[q];
         const unsigned long long rs = (unsigned long long)a.row_ptr[chk], rd = (unsigned long long)(a.row_ptr[chk + 1] - a.row_ptr[chk]);
-        rec[q] = (unsigned long long)a.t_edge[q] | (rs << 16) | (rd << 32);
+        rec[q] = (unsigned long long)a.t_edge[q] | (rs << 16) | (rd << 32) | ((unsigned long long)chk << 48);
     }
     if (PS && MATH == 0)
         for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
@@ -615,15 +620,14 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     __syncthreads();
 
     // this lane's syndrome (rel_lds_per_syndrome) and this wavefront's sort scratch (rel_lds_scratch)
-    const int n2 = (n * 2 + 7) & ~7, n1 = (n + 7) & ~7, nd1 = (n * dc + 7) & ~7;
+    const int n2 = (n * 2 + 7) & ~7, n1 = (n + 7) & ~7;
     l_u8 *wave_base = base + a.lds_shared + (size_t)wave * ((size_t)G * a.lds_per_syn + a.lds_scratch);
     auto syn_base = [&](int gg) { return wave_base + (size_t)gg * a.lds_per_syn; };
     l_u8 *mine = syn_base(g);
     l_f64 *A = (l_f64 *)mine;
     l_f64 *L = A + nnz;
     l_u16 *ord = (l_u16 *)(L + n);
-    l_u8 *oddtab = (l_u8 *)ord + n2;  // [n][dc] (byte & 1) of the check of the k-th entry of column j, for THIS syndrome
-    l_u8 *dbit = oddtab + nd1;         // hard decisions (a bit the order never visits keeps its 0)
+    l_u8 *dbit = (l_u8 *)ord + n2;     // hard decisions (a bit the order never visits keeps its 0)
     l_u8 *sy = dbit + n1;
     l_u8 *scr = wave_base + (size_t)G * a.lds_per_syn;
     const bool in_l = a.scratch_in_l != 0;  // (GS = 64 only: `L` is the wavefront's one syndrome's)
@@ -671,9 +675,6 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 // initialise_log_domain_bp (bp.hpp:147-157), the starting order, no decision yet
                 for (int e = gl; e < nnz; e += GS) A[e] = PS ? pform[rcol[e]] : prior[rcol[e]];
                 for (int t = gl; t < n; t += GS) { ord[t] = (uint16_t)(a.order0 ? a.order0[t] : t); L[t] = 0.0; dbit[t] = 0; }
-                lds_sync();
-                // this syndrome's bit per table entry: pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
-                for (int q = gl; q < n * dc; q += GS) oddtab[q] = sy[a.t_chk[q]] & 1;
                 running = a.max_iter > 0;
             }
         }
@@ -698,9 +699,9 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 // ---- the sweep, level by level ------------------------------------------------------------------------------------------
                 // Two bits that share no check commute: processing them side by side gives each exactly the operands the bit-by-bit walk
                 // gives it.  So the order is cut into LEVELS -- level(t) = 1 + the highest level among the EARLIER positions whose bit
-                // shares a check with the bit at t (none: 1) -- and a level's bits go through the update one per lane.  The levels depend on
+                // shares a check with the bit at t (none: 1) -- and a level's bits go through the update side by side.  The levels depend on
                 // the order, i.e. on this syndrome and this iteration: worked out here, in LDS (the sort's scratch is free again).  On the
-                // d = 21 surface code ~40 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
+                // d = 21 surface code 25 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
                 l_u16 *pos = in_l ? (l_u16 *)L : (l_u16 *)scr + n, *level = pos + n, *llist = (l_u16 *)scr;
                 l_u16 *lcnt = in_l ? llist + n + (n & 1) : level + n + (n & 1);  // [n + 2], on a 4-byte boundary: counted with 32-bit atomics, two counts to a word
                 l_u32 *lcnt_w = (l_u32 *)lcnt;
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
 #pragma unroll
                     for (int p = 0; p < DCT; ++p) {
                         const unsigned long long rq = rec[bq * dc + (p < cdq ? p : 0)];
-                        const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)(rq >> 32), last_k = rdq > 0 ? rdq - 1 : 0;
+                        const int rsq = (int)((rq >> 16) & 0xffffu), rdq = (int)((rq >> 32) & 0xffffu), last_k = rdq > 0 ? rdq - 1 : 0;
                         int best = -1;
 #pragma unroll
                         for (int k = 0; k < DRT; ++k) {
@@ -803,8 +804,8 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                         const bool mine_p = pl < cdq;
                         const int pc = mine_p ? pl : 0;  // (a lane without an entry reads entry 0's places -- its own table rows are zeroes -- and drops the result)
                         const unsigned long long rq = rec[bq * dc + pc];
-                        const int e = (int)(rq & 0xffffu), rs = (int)((rq >> 16) & 0xffffu), rd = (int)(rq >> 32);
-                        const int odd = oddtab[bq * dc + pc];
+                        const int e = (int)(rq & 0xffffu), rs = (int)((rq >> 16) & 0xffffu), rd = (int)((rq >> 32) & 0xffffu);
+                        const int odd = sy[rq >> 48] & 1;  // pow(-1, syndrome[check]) / sgn = syndrome[check] (bp.hpp:499, 506)
                         double av[DRT];
                         const int last_k = rd > 0 ? rd - 1 : 0;
 #pragma unroll
@@ -851,11 +852,11 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             int bit = running ? (int)ord[0] : 0;
             unsigned long long rc = 0;
             int cd = 0, odd = 0;
-            if (running) { cd = cdeg[bit]; if (gl < cd) { rc = rec[bit * dc + gl]; odd = oddtab[bit * dc + gl]; } }
+            if (running) { cd = cdeg[bit]; if (gl < cd) { rc = rec[bit * dc + gl]; odd = sy[rc >> 48] & 1; } }
             for (int t = 0; t < n; ++t) {
                 const int bit_next = (int)ord[t + 1 < n ? t + 1 : n - 1];
                 const bool mine_p = running && gl < cd;
-                const int e = (int)(rc & 0xffffu), rs = (int)((rc >> 16) & 0xffffu), rd = (int)(rc >> 32);
+                const int e = (int)(rc & 0xffffu), rs = (int)((rc >> 16) & 0xffffu), rd = (int)((rc >> 32) & 0xffffu);
                 // the row's entries: all DRT loads go out together (clamped to the row: an entry beyond its weight, or the bit's own, is
                 // read and then replaced by the neutral element -- no branch, one LDS round trip)
                 double c = 0.0;
@@ -887,7 +888,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 const int dcl = gl < dc ? gl : dc - 1;
                 const int cd_next = cdeg[bit_next];
                 const unsigned long long rc_next = rec[bit_next * dc + dcl];
-                const int odd_next = oddtab[bit_next * dc + dcl];
+                const int odd_next = sy[rc_next >> 48] & 1;
                 // the column, top down (bp.hpp:488, 501-503 / 520-522): entry p keeps the running sum before its own message joins it
                 double llr = running ? prior[bit] : 0.0, part = 0.0;
                 for (int p = 0; p < dc; ++p) {
