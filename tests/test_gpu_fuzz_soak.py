@@ -1,6 +1,7 @@
-"""A bounded slice of the two differential soaks (tests/fuzz_differential.py, tests/fuzz_streamed.py) with FIXED seeds, so the driver's
+"""A bounded slice of the three differential soaks (tests/fuzz_differential.py, tests/fuzz_streamed.py, tests/fuzz_schedules.py) with FIXED seeds, so the driver's
 `-m gpu` run exercises them: random regular codes through every on-chip kernel form and four OSD variants, and through the streamed
-kernels (hand-off thresholds, chunked workspaces, ring depths, the two-pass decode) -- decisions, iterations, flags and log-ratio BITS of
+kernels (hand-off thresholds, chunked workspaces, ring depths, the two-pass decode), and serial_relative with random starting orders
+through every form of the on-chip kernel and the per-lane kernel -- decisions, iterations, flags and log-ratio BITS of
 every row against the CPU checker.  The same files run for minutes by hand (`python tests/fuzz_differential.py <seconds> <seed>`)."""
 import pytest
 
@@ -19,3 +20,10 @@ def test_streamed_soak_slice(seed, oracle_built):
     import fuzz_streamed
     cases = fuzz_streamed.run(seconds=20.0, seed=seed, max_cases=16)
     assert cases >= 3, f"only {cases} cases in 20 s"
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_schedules_soak_slice(seed, oracle_built):
+    import fuzz_schedules
+    cases = fuzz_schedules.run(seconds=20.0, seed=seed, max_cases=60)
+    assert cases >= 10, f"only {cases} cases in 20 s"
