@@ -34,6 +34,9 @@ struct SerialArgs {
     // random serial schedule (bp.hpp:467-468): iteration it walks orders[min(it, n_orders) - 1][0 .. n) instead of `order`
     const int32_t *orders;
     int32_t n_orders, orders_first;  // (the table is a ring: its first row sits at orders_first)
+    // the same table for bp_serial_level_kernel: row r level-major in orders_lvl[r][0 .. n), orders_lvl_ptr[r][0] = its number of levels,
+    // orders_lvl_ptr[r][1 + l] = where level l starts (stride n + 2)
+    const int32_t *orders_lvl, *orders_lvl_ptr;
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the
@@ -235,10 +238,19 @@ __global__ void __launch_bounds__(1024) bp_serial_level_kernel(const SerialArgs 
     for (int it = 1; it <= a.max_iter; ++it) {
         const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
         const bool lane_live = !((done >> lane) & 1ull);
-        for (int l = 0; l < a.n_levels; ++l) {
-            const int p1 = sload(a.lvl_ptr + l + 1);
-            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves)
-                serial_update_bit<METHOD, MATH, DCS, DRS>(a, sload(a.lvl_bits + p), At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab,
+        // the levels of this iteration's order: the schedule's own, or (random schedule) row min(it, n_orders) - 1 of the ring
+        const int32_t *lvl_ptr = a.lvl_ptr, *lvl_bits = a.lvl_bits;
+        int n_levels = a.n_levels;
+        if (a.orders_lvl) {
+            const size_t row = (size_t)(((it < a.n_orders ? it : a.n_orders) - 1 + a.orders_first) % a.n_orders);
+            lvl_ptr = a.orders_lvl_ptr + row * (size_t)(n + 2) + 1;
+            lvl_bits = a.orders_lvl + row * (size_t)n;
+            n_levels = sload(a.orders_lvl_ptr + row * (size_t)(n + 2));
+        }
+        for (int l = 0; l < n_levels; ++l) {
+            const int p1 = sload(lvl_ptr + l + 1);
+            for (int p = sload(lvl_ptr + l) + wave; p < p1; p += nwaves)
+                serial_update_bit<METHOD, MATH, DCS, DRS>(a, sload(lvl_bits + p), At, Ct, Lt, par, dcur, lane, l8, alpha, log_tab,
                                                           want_llr, lane_live);
             __syncthreads();  // the next level reads what this one wrote
         }

@@ -110,6 +110,7 @@ struct ldpc_hip_bp {
     int32_t sched_seed_raw = 0;  // random_schedule_seed as given (the soft-syndrome routine seeds its own engine with it)
     bool random_serial = false;
     DeviceBuf rel_ord, rel_dbit, sched_orders, sched_order0;
+    DeviceBuf sched_lvl_bits, sched_lvl_ptr;      // the random schedule's orders once more, level-major, and their level bounds (host_serial.h: random_orders_*)
     DeviceBuf rl_edge, rl_chk, rl_cdeg, rl_last;  // per-column tables and the last row's final order of bp_relative_lds_kernel
     int rl_dc = 0;                                // stride the tables were built for (0: none)
     // The random schedule's table of per-iteration orders (host_serial.h: random_orders_*), kept on the device between calls as a
@@ -120,6 +121,8 @@ struct ldpc_hip_bp {
         int32_t seed_raw = 0;
         std::mt19937 rng_end;                       // generator behind the table's last row (kind 0)
         std::vector<int> row_end;                   // the table's last row
+        std::vector<int32_t> csc_ptr, csc_row;      // the checks of every bit (levels of an order: host_serial.h random_orders_levels)
+        std::vector<int32_t> n_levels;              // levels of every row of the ring (0: row not built)
         std::vector<int32_t> expect_state;          // what the handle's order / generator must be for the table to be current
         std::mt19937 expect_rng;
     } rnd;

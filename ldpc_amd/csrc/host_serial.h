@@ -85,9 +85,18 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
     void (*kern)(const SerialArgs);
     // level-parallel variant when the schedule has at least two bits per level on average (or when asked for)
     int level_waves = 0;
-    if (h->serial_kernel != 0 && h->n > 0 && !orders) {  // (a schedule that changes per iteration has no fixed levels)
-        if ((rc = ensure_serial_levels(h))) return rc;
-        const double per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+    const bool orders_levels = orders && h->rnd.kind == 0 && h->rnd.valid && h->sched_lvl_bits.p && h->sched_lvl_ptr.p;  // (the ring carries levels: random_orders_append)
+    if (h->serial_kernel != 0 && h->n > 0 && (!orders || orders_levels)) {
+        double per_level;
+        if (orders) {  // a schedule that changes per iteration: the levels of every row of the ring
+            double sum = 0.0;
+            int cnt = 0;
+            for (int32_t nl : h->rnd.n_levels) if (nl > 0) { sum += (double)nl; ++cnt; }
+            per_level = cnt ? (double)h->n / (sum / cnt) : 0.0;
+        } else {
+            if ((rc = ensure_serial_levels(h))) return rc;
+            per_level = (double)h->n / (double)(h->n_levels ? h->n_levels : 1);
+        }
         if (h->serial_kernel == 1 || per_level >= 2.0) {
             level_waves = (int)(per_level + 0.999);
             if (level_waves > 8) level_waves = 8;
@@ -142,6 +151,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         HIPCHK(hipEventRecord(h->ev0, st));
         a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
         a.orders = orders; a.n_orders = n_orders; a.orders_first = orders_first;
+        if (orders && level_waves) { a.orders_lvl = (const int32_t *)h->sched_lvl_bits.p; a.orders_lvl_ptr = (const int32_t *)h->sched_lvl_ptr.p; }
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
@@ -186,22 +196,58 @@ static void random_orders_shuffle(ldpc_hip_bp *h, int kind, std::vector<int> &v,
     else std::shuffle(v.begin(), v.end(), std::default_random_engine(h->sched_seed_raw));
 }
 
-// rows [pos, pos + count) of the ring <- `count` further rearrangements of r.row_end (host staging in blocks)
+// One order cut into levels of mutually check-disjoint POSITIONS (as ensure_serial_levels does for the fixed schedule): `bits` gets the
+// order level-major (schedule order inside a level), ptr[0] the number of levels, ptr[1 + l] where level l starts.  Levels belong to
+// positions, so an order with repeated bits (a caller's serial_schedule_order being shuffled) is handled like any other.
+static void random_orders_levels(ldpc_hip_bp *h, const std::vector<int> &order, int32_t *bits, int32_t *ptr, std::vector<int32_t> &check_level,
+                                 std::vector<int32_t> &level) {
+    auto &r = h->rnd;
+    const int n = r.n;
+    std::fill(check_level.begin(), check_level.end(), 0);
+    int32_t n_levels = n ? 1 : 0;
+    for (int t = 0; t < n; ++t) {
+        const int j = order[(size_t)t];
+        int32_t l = 1;
+        for (int q = r.csc_ptr[(size_t)j]; q < r.csc_ptr[(size_t)j + 1]; ++q) l = std::max(l, check_level[(size_t)r.csc_row[(size_t)q]] + 1);
+        for (int q = r.csc_ptr[(size_t)j]; q < r.csc_ptr[(size_t)j + 1]; ++q) check_level[(size_t)r.csc_row[(size_t)q]] = l;
+        level[(size_t)t] = l;
+        n_levels = std::max(n_levels, l);
+    }
+    std::fill(ptr, ptr + n + 2, 0);
+    ptr[0] = n_levels;
+    for (int t = 0; t < n; ++t) ptr[1 + level[(size_t)t]]++;        // (count of level l at ptr[1 + l], shifted into starts below)
+    for (int l = 0; l < n_levels; ++l) ptr[2 + l] += ptr[1 + l];
+    std::vector<int32_t> fill(ptr + 1, ptr + 1 + n_levels);
+    for (int t = 0; t < n; ++t) bits[(size_t)fill[(size_t)level[(size_t)t] - 1]++] = order[(size_t)t];
+}
+
+// rows [pos, pos + count) of the ring <- `count` further rearrangements of r.row_end (host staging in blocks); for the plain serial
+// schedule (kind 0) every row also goes up level-major with its level bounds, for bp_serial_level_kernel
 static int random_orders_append(ldpc_hip_bp *h, int pos, int count) {
     auto &r = h->rnd;
     const size_t n = (size_t)r.n;
+    const bool with_levels = r.kind == 0 && h->sched_lvl_bits.p && h->sched_lvl_ptr.p;
     const int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)1 << 22) / (n ? n : 1)));
-    std::vector<int32_t> stage((size_t)block * n);
+    std::vector<int32_t> stage((size_t)block * n), stage_bits(with_levels ? (size_t)block * n : 0), stage_ptr(with_levels ? (size_t)block * (n + 2) : 0);
+    std::vector<int32_t> check_level(with_levels ? (size_t)(h->m ? h->m : 1) : 0), level(with_levels ? (n ? n : 1) : 0);
     for (int done = 0; done < count;) {
         const int now = std::min(block, count - done);
         for (int q = 0; q < now; ++q) {
             random_orders_shuffle(h, r.kind, r.row_end, r.rng_end);
             std::copy(r.row_end.begin(), r.row_end.end(), stage.begin() + (size_t)q * n);
+            if (with_levels) {
+                random_orders_levels(h, r.row_end, stage_bits.data() + (size_t)q * n, stage_ptr.data() + (size_t)q * (n + 2), check_level, level);
+                r.n_levels[(size_t)((pos + done + q) % r.rows)] = stage_ptr[(size_t)q * (n + 2)];
+            }
         }
         for (int q = 0; q < now;) {  // (the ring may wrap inside a block)
             const int at = (pos + done + q) % r.rows;
             const int run = std::min(now - q, r.rows - at);
             HIPCHK(hipMemcpy((int32_t *)h->sched_orders.p + (size_t)at * n, stage.data() + (size_t)q * n, (size_t)run * n * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (with_levels) {
+                HIPCHK(hipMemcpy((int32_t *)h->sched_lvl_bits.p + (size_t)at * n, stage_bits.data() + (size_t)q * n, (size_t)run * n * sizeof(int32_t), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy((int32_t *)h->sched_lvl_ptr.p + (size_t)at * (n + 2), stage_ptr.data() + (size_t)q * (n + 2), (size_t)run * (n + 2) * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
             q += run;
         }
         done += now;
@@ -217,12 +263,24 @@ static int random_orders_prepare(ldpc_hip_bp *h, int kind) {
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", rows, n);
     int rc;
     if ((rc = h->sched_orders.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
+    if (kind == 0 && ((rc = h->sched_lvl_bits.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16)) ||
+                      (rc = h->sched_lvl_ptr.ensure((size_t)rows * ((size_t)n + 2) * sizeof(int32_t) + 16)))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the table
     const bool current = r.valid && r.kind == kind && r.rows == rows && r.n == n && r.expect_state == h->sched_state &&
                          (kind == 0 ? r.expect_rng == h->sched_rng : r.seed_raw == h->sched_seed_raw);
     if (current || rows == 0 || n == 0) return LDPC_HIP_OK;
     r.valid = false;
     r.kind = kind; r.rows = rows; r.n = n; r.first = 0; r.seed_raw = h->sched_seed_raw;
+    r.n_levels.assign((size_t)rows, 0);
+    if (kind == 0) {  // the checks of every bit, for the levels
+        r.csc_ptr.assign((size_t)n + 1, 0);
+        for (int e = 0; e < h->nnz; ++e) r.csc_ptr[(size_t)h->h_col_idx[(size_t)e] + 1]++;
+        for (int j = 0; j < n; ++j) r.csc_ptr[(size_t)j + 1] += r.csc_ptr[(size_t)j];
+        r.csc_row.assign((size_t)(h->nnz ? h->nnz : 1), 0);
+        std::vector<int32_t> at(r.csc_ptr.begin(), r.csc_ptr.end() - 1);
+        for (int i = 0; i < h->m; ++i)
+            for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) r.csc_row[(size_t)at[(size_t)h->h_col_idx[(size_t)e]]++] = i;
+    }
     r.row_end.assign(h->sched_state.begin(), h->sched_state.end());
     r.rng_end = h->sched_rng;
     if ((rc = random_orders_append(h, 0, rows))) return rc;

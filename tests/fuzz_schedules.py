@@ -3,7 +3,7 @@
 tests/test_gpu_fuzz_soak.py): random regular and irregular codes of 24 .. 700 bits, random priors (uniform or per bit), methods, iteration
 limits, batch sizes and STARTING ORDERS (identity, a permutation, an order with repeated bits), schedule = serial_relative through every
 form of the on-chip kernel -- level by level with the scratch in the posterior array / apart, bit by bit with 64 / 16 lanes per syndrome --
-and through the per-lane kernel, plus the fixed-order serial schedule: decisions, iteration counts, flags, log-ratio BITS and the order
+and through the per-lane kernel, plus the fixed-order serial schedule and the random one (walking kernel / level kernel): decisions, iteration counts, flags, log-ratio BITS and the order
 left behind, every row against the CPU checker (oracle/, pinned to the reference and to the host's std::sort).
     python tests/fuzz_schedules.py <seconds> <seed>"""
 import sys, os, time
@@ -79,6 +79,20 @@ def run(seconds=120.0, seed=1, max_cases=None):
             eng.close()
             ws = o.decode_serial_batch(s, order)
             assert np.array_equal(got[0], ws[0]) and np.array_equal(got[2], ws[2]) and oracle.bits_equal(got[1], ws[1]), "serial " + tag0
+        # the random serial schedule (a new order per iteration, the same for every row): one wavefront per tile walking the order, and the
+        # level kernel on the per-iteration level tables -- rows of the call start from the handle's state, which moves on call by call
+        if order is None:
+            seed_r = int(rng.integers(0, 2**31 - 1))
+            wr = o.decode_random_serial_batch(s, seed_r)
+            for mode in (0, 1, -1):
+                eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, method, alpha)
+                eng.set_schedule("serial")
+                eng.set_random_serial(True, seed_r)
+                eng.set_serial_kernel(mode)
+                got = eng.decode_batch(s)
+                eng.close()
+                assert np.array_equal(got[0], wr[0]) and np.array_equal(got[2], wr[2]) and np.array_equal(np.asarray(got[3], bool), wr[3]), f"random serial {tag0} kernel={mode}"
+                assert oracle.bits_equal(got[1], wr[1]), f"random serial llr {tag0} kernel={mode}"
         n_ok += 1
     return n_ok
 

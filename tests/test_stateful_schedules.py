@@ -201,6 +201,39 @@ def test_serial_relative_on_chip_with_a_starting_order(kind, oracle_built):
     assert same(outs[None][:4], want[:4]) and np.array_equal(outs[None][4], want[4])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("code,method,alpha,p,max_iter", [("surface21", 1, 0.625, 0.05, 30), ("bb144", 0, 1.0, 0.05, 50), ("ldpc600", 0, 1.0, 0.04, 10)])
+def test_random_serial_level_kernel_against_the_walking_kernel_and_the_checker(code, method, alpha, p, max_iter, oracle_built):
+    """random_serial_schedule: every iteration has its own order (the same for all rows).  The ring of per-iteration orders also goes up
+    cut into levels of check-disjoint bits, and bp_serial_level_kernel takes iteration t's levels from row t -- against the kernel that
+    walks the order bit by bit (set_serial_kernel(0)) and the checker; two calls in a row (the second starts where the first one's last
+    row left the generator, and reuses the ring minus the rows consumed)."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = {"surface21": lambda: codes.rotated_surface_code_x(21), "bb144": codes.bivariate_bicycle_hx,
+         "ldpc600": lambda: codes.regular_ldpc_code(600, 3, 6, seed=4)}[code]()
+    m, n = h.shape
+    B = 2000
+    outs = {}
+    for mode in (1, 0, -1):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
+        eng.set_schedule("serial")
+        eng.set_random_serial(True, 77)
+        eng.set_serial_kernel(mode)
+        s = eng.gen_bsc_syndromes(19, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+        first = eng.decode_batch(s)
+        ms = eng.last_kernel_ms()
+        second = eng.decode_batch(s[:64])
+        outs[mode] = (first, second, eng.schedule_order(), ms)
+        eng.close()
+    for mode in (1, -1):
+        assert same(outs[mode][0], outs[0][0]) and same(outs[mode][1], outs[0][1]) and np.array_equal(outs[mode][2], outs[0][2]), mode
+    o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
+    rows = np.r_[0:40, B - 8:B]
+    assert same(tuple(x[rows] for x in outs[1][0]), o.decode_random_serial_batch(s[rows], 77))
+    print(f"[random serial {code} method {method}: level kernel {outs[1][3]:.2f} ms, walking kernel {outs[0][3]:.2f} ms, default {outs[-1][3]:.2f} ms for {B} syndromes]")
+
+
 # ---- SoftInfoBpDecoder with random_serial_schedule (bp.hpp:573-577): the order the object carries is rearranged at the top of
 # every iteration that runs by std::shuffle with a NEW std::default_random_engine(random_schedule_seed) -----------------------------
 
