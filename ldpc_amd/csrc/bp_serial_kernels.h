@@ -300,6 +300,7 @@ struct SoftArgs {
     const int32_t *row_ptr, *col_idx, *col_ptr, *csc_edge, *csc_row, *order;  // order may be nullptr (0..n-1)
     const int32_t *orders;  // random serial schedule (bp.hpp:573-577): [n_orders][n], iteration it walks orders[min(it, n_orders) - 1]; else nullptr
     int32_t n_orders, orders_first;  // (a ring: its first row sits at orders_first)
+    const int32_t *orders_lvl, *orders_lvl_ptr;  // the same rows level-major with their level bounds, as in SerialArgs (bp_softinfo_level_kernel)
     const double *llr0;
     double *A;        // [tiles][nnz][64] bit->check messages
     double *C;        // [tiles][nnz][64] check->bit messages of the bit being updated
@@ -563,11 +564,19 @@ __global__ void __launch_bounds__(1024) bp_softinfo_level_kernel(const SoftArgs 
 
     for (int it = 1; it <= a.max_iter; ++it) {
         const bool lane_live = !((done >> lane) & 1ull);
-        for (int l = 0; l < a.n_levels; ++l) {
-            const int p1 = sload(a.lvl_ptr + l + 1);
-            for (int p = sload(a.lvl_ptr + l) + wave; p < p1; p += nwaves) {
-                if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, sload(a.lvl_bits + p), At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
-                else soft_update_bit(a, sload(a.lvl_bits + p), At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+        const int32_t *lvl_ptr = a.lvl_ptr, *lvl_bits = a.lvl_bits;
+        int n_levels = a.n_levels;
+        if (a.orders_lvl) {  // random schedule: the levels of this iteration's order
+            const size_t row = (size_t)(((it < a.n_orders ? it : a.n_orders) - 1 + a.orders_first) % a.n_orders);
+            lvl_ptr = a.orders_lvl_ptr + row * (size_t)(n + 2) + 1;
+            lvl_bits = a.orders_lvl + row * (size_t)n;
+            n_levels = sload(a.orders_lvl_ptr + row * (size_t)(n + 2));
+        }
+        for (int l = 0; l < n_levels; ++l) {
+            const int p1 = sload(lvl_ptr + l + 1);
+            for (int p = sload(lvl_ptr + l) + wave; p < p1; p += nwaves) {
+                if constexpr (DCS > 0) soft_update_bit_fast<DCS, DRS>(a, sload(lvl_bits + p), At, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
+                else soft_update_bit(a, sload(lvl_bits + p), At, Ct, St, Lt, syn, dcur, lane, l8, want_llr, lane_live);
             }
             __syncthreads();
         }

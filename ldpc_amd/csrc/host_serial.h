@@ -85,7 +85,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
     void (*kern)(const SerialArgs);
     // level-parallel variant when the schedule has at least two bits per level on average (or when asked for)
     int level_waves = 0;
-    const bool orders_levels = orders && h->rnd.kind == 0 && h->rnd.valid && h->sched_lvl_bits.p && h->sched_lvl_ptr.p;  // (the ring carries levels: random_orders_append)
+    const bool orders_levels = orders && h->rnd.valid && h->sched_lvl_bits.p && h->sched_lvl_ptr.p;  // (the ring carries levels: random_orders_append)
     if (h->serial_kernel != 0 && h->n > 0 && (!orders || orders_levels)) {
         double per_level;
         if (orders) {  // a schedule that changes per iteration: the levels of every row of the ring
@@ -221,12 +221,12 @@ static void random_orders_levels(ldpc_hip_bp *h, const std::vector<int> &order, 
     for (int t = 0; t < n; ++t) bits[(size_t)fill[(size_t)level[(size_t)t] - 1]++] = order[(size_t)t];
 }
 
-// rows [pos, pos + count) of the ring <- `count` further rearrangements of r.row_end (host staging in blocks); for the plain serial
-// schedule (kind 0) every row also goes up level-major with its level bounds, for bp_serial_level_kernel
+// rows [pos, pos + count) of the ring <- `count` further rearrangements of r.row_end (host staging in blocks); every row also goes up
+// level-major with its level bounds, for bp_serial_level_kernel / bp_softinfo_level_kernel
 static int random_orders_append(ldpc_hip_bp *h, int pos, int count) {
     auto &r = h->rnd;
     const size_t n = (size_t)r.n;
-    const bool with_levels = r.kind == 0 && h->sched_lvl_bits.p && h->sched_lvl_ptr.p;
+    const bool with_levels = h->sched_lvl_bits.p && h->sched_lvl_ptr.p;
     const int block = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, ((size_t)1 << 22) / (n ? n : 1)));
     std::vector<int32_t> stage((size_t)block * n), stage_bits(with_levels ? (size_t)block * n : 0), stage_ptr(with_levels ? (size_t)block * (n + 2) : 0);
     std::vector<int32_t> check_level(with_levels ? (size_t)(h->m ? h->m : 1) : 0), level(with_levels ? (n ? n : 1) : 0);
@@ -263,8 +263,8 @@ static int random_orders_prepare(ldpc_hip_bp *h, int kind) {
         return fail(LDPC_HIP_ERR_UNSUPPORTED, "random serial schedule: max_iter x n = %d x %d orders exceed the 1 GiB table of per-iteration orders; lower max_iter", rows, n);
     int rc;
     if ((rc = h->sched_orders.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16))) return rc;  // (+16: max_iter = 0 leaves the table empty)
-    if (kind == 0 && ((rc = h->sched_lvl_bits.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16)) ||
-                      (rc = h->sched_lvl_ptr.ensure((size_t)rows * ((size_t)n + 2) * sizeof(int32_t) + 16)))) return rc;
+    if ((rc = h->sched_lvl_bits.ensure((size_t)rows * (size_t)n * sizeof(int32_t) + 16)) ||
+        (rc = h->sched_lvl_ptr.ensure((size_t)rows * ((size_t)n + 2) * sizeof(int32_t) + 16))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));  // a previous launch may still read the table
     const bool current = r.valid && r.kind == kind && r.rows == rows && r.n == n && r.expect_state == h->sched_state &&
                          (kind == 0 ? r.expect_rng == h->sched_rng : r.seed_raw == h->sched_seed_raw);
@@ -272,7 +272,7 @@ static int random_orders_prepare(ldpc_hip_bp *h, int kind) {
     r.valid = false;
     r.kind = kind; r.rows = rows; r.n = n; r.first = 0; r.seed_raw = h->sched_seed_raw;
     r.n_levels.assign((size_t)rows, 0);
-    if (kind == 0) {  // the checks of every bit, for the levels
+    {   // the checks of every bit, for the levels
         r.csc_ptr.assign((size_t)n + 1, 0);
         for (int e = 0; e < h->nnz; ++e) r.csc_ptr[(size_t)h->h_col_idx[(size_t)e] + 1]++;
         for (int j = 0; j < n; ++j) r.csc_ptr[(size_t)j + 1] += r.csc_ptr[(size_t)j];
@@ -629,8 +629,19 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
     const bool shuffled = h->random_serial && h->n > 0;
     int32_t *d_iters_last = nullptr;
     if (shuffled) {
-        level_waves = 0;  // the levels belong to one fixed order
         if ((rc = random_orders_prepare(h, 1))) return rc;  // (random_orders_*, above)
+        level_waves = 0;  // the fixed order's levels do not apply: those of the ring's rows do (random_orders_append)
+        if (h->serial_kernel != 0 && h->rnd.valid) {
+            double sum = 0.0;
+            int cnt = 0;
+            for (int32_t nl : h->rnd.n_levels) if (nl > 0) { sum += (double)nl; ++cnt; }
+            const double per_level = cnt ? (double)h->n / (sum / cnt) : 0.0;
+            if (h->serial_kernel == 1 || per_level >= 2.0) {
+                level_waves = (int)(per_level + 0.999);
+                if (level_waves > 8) level_waves = 8;
+                if (level_waves < 1) level_waves = 1;
+            }
+        }
         if (!iters) { if ((rc = h->sp_iters.ensure((size_t)batch * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
         d_iters_last = iters + (batch - 1);
     }
@@ -664,7 +675,10 @@ static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, d
         a.batch = nb;
         a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr;
         a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row; a.order = h->custom_order ? h->d_order : nullptr;
-        if (shuffled && h->max_iter > 0) { a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; a.orders_first = h->rnd.first; }
+        if (shuffled && h->max_iter > 0) {
+            a.orders = (const int32_t *)h->sched_orders.p; a.n_orders = h->max_iter; a.orders_first = h->rnd.first;
+            if (level_waves) { a.orders_lvl = (const int32_t *)h->sched_lvl_bits.p; a.orders_lvl_ptr = (const int32_t *)h->sched_lvl_ptr.p; }
+        }
         a.llr0 = h->d_llr0;
         a.A = (double *)h->msgA.p; a.C = (double *)h->msgC.p; a.S = (double *)h->soft_S.p;
         a.syn = (const uint64_t *)h->par.p;

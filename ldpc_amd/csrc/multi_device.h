@@ -203,7 +203,7 @@ static void multi_copy_schedule_state(ldpc_hip_bp_multi *mh, int from) {
             (void)hipGetLastError();
             continue;
         }
-        if (r.kind == 0) {  // ... and the same rows level-major with their level bounds (bp_serial_level_kernel reads those)
+        {   // ... and the same rows level-major with their level bounds (the level kernels read those)
             const size_t ptr_bytes = (size_t)r.rows * ((size_t)r.n + 2) * sizeof(int32_t);
             if (!src->sched_lvl_bits.p || !src->sched_lvl_ptr.p || dst->sched_lvl_bits.ensure(bytes + 16) || dst->sched_lvl_ptr.ensure(ptr_bytes + 16) ||
                 hipMemcpyPeer(dst->sched_lvl_bits.p, dst->device, src->sched_lvl_bits.p, src->device, bytes) != hipSuccess ||

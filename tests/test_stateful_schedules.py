@@ -276,12 +276,30 @@ def test_oracle_reproduces_the_reference_soft(name, oracle_built):
         assert np.array_equal(order, c["carried_orders"][b])
 
 
-def _soft_engine(c):
+def _soft_engine(c, serial_kernel=-1):
     from ldpc_amd.engine import HipBpEngine
     eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["probs"], c["max_iter"], 1, c["alpha"])
     eng.set_schedule("serial")
     eng.set_random_serial(True, c["seed"] & 0xffffffff)
+    eng.set_serial_kernel(serial_kernel)  # 0: the kernel that walks the order; 1: the level kernel on the ring's per-iteration levels; -1: by the levels' width
     return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("serial_kernel", [0, 1])
+@pytest.mark.parametrize("name", SOFT_CASES)
+def test_device_soft_batch_both_kernels(name, serial_kernel):
+    c = load_soft(name)
+    eng = _soft_engine(c, serial_kernel)
+    assert same_soft(eng.soft_info_decode_batch(c["soft"], c["cutoff"], c["sigma"]), c["fresh"])
+    assert np.array_equal(eng.schedule_order(), c["fresh_order_last"])
+    eng.close()
+    eng3 = _soft_engine(c, serial_kernel)
+    for b in range(min(len(c["soft"]), 12)):
+        got = eng3.soft_info_decode_batch(c["soft"][b:b + 1], c["cutoff"], c["sigma"])
+        assert same_soft(got, tuple(x[b:b + 1] for x in c["carried"])), f"row {b}"
+        assert np.array_equal(eng3.schedule_order(), c["carried_orders"][b])
+    eng3.close()
 
 
 @pytest.mark.gpu
