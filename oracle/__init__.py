@@ -329,12 +329,32 @@ def ref_soft_random(h, soft_syndromes, cutoff, sigma, *, error_rate=None, error_
 
 
 def ref_decode_stateful(h, syndromes, *, schedule, error_rate=None, error_channel=None, max_iter=0, bp_method="product_sum",
-                        ms_scaling_factor=1.0, random_serial=False, seed=0, fresh=True):
+                        ms_scaling_factor=1.0, random_serial=False, seed=0, fresh=True, order0=None):
     """The REAL reference with a schedule that keeps state in the decoder object: a new object per row (``fresh``) or one
-    object for all rows.  Returns (decoding, llr, iterations, converge, final order per row)."""
+    object for all rows; ``order0``: the ``serial_schedule_order`` handed to the constructor (any n bit numbers).
+    Returns (decoding, llr, iterations, converge, final order per row)."""
     if not have_ref():
         raise RuntimeError("oracle/_ref/libref_bp.so not built (needs /root/reference: make -C oracle ref)")
     lib = C.CDLL(REF_SO)
+    if order0 is not None:
+        if random_serial:
+            raise ValueError("the reference refuses a fixed order together with the random schedule (bp.hpp:112-114)")
+        fo = lib.ref_bp_decode_batch_order
+        fo.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_double, _i32p, C.c_int,
+                       _u8p, C.c_int64, _u8p, _f64p, _i32p, _u8p, _i32p]
+        m, n, row_ptr, col_idx = csr_arrays(h)
+        rows = np.ascontiguousarray(np.repeat(np.arange(m, dtype=np.int32), np.diff(row_ptr)).astype(np.int32))
+        probs = _probs(n, error_rate, error_channel)
+        s = np.ascontiguousarray(syndromes, np.uint8)
+        b = s.shape[0]
+        dec = np.zeros((b, n), np.uint8)
+        llr = np.zeros((b, n), np.float64)
+        it = np.zeros(b, np.int32)
+        conv = np.zeros(b, np.uint8)
+        final = np.zeros((b, n), np.int32)
+        fo(m, n, len(col_idx), rows, col_idx, probs, int(max_iter) if max_iter else n, _method_id(bp_method), RefBp.SCHEDULE[schedule],
+           float(ms_scaling_factor), np.ascontiguousarray(order0, np.int32), 0 if fresh else 1, s, b, dec, llr, it, conv, final.reshape(-1))
+        return dec, llr, it, conv.astype(bool), final
     fn = lib.ref_bp_decode_fresh_batch if fresh else lib.ref_bp_decode_carried_batch
     fn.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                    _u8p, C.c_int64, _u8p, _f64p, _i32p, _u8p, _i32p]

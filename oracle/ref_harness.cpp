@@ -117,6 +117,36 @@ void ref_bp_decode_fresh_batch(int m, int n, int nnz, const int32_t *rows, const
     }
 }
 
+/* The same with a serial_schedule_order given to the constructor (bp.hpp:85, 110-111: any n bit numbers, taken as they are): a new
+ * object per row (carried == 0) or one object for all rows. */
+void ref_bp_decode_batch_order(int m, int n, int nnz, const int32_t *rows, const int32_t *cols, const double *channel_probs,
+                               int max_iter, int bp_method, int schedule, double ms_scaling_factor, const int32_t *order0, int carried,
+                               const uint8_t *inputs, int64_t shots, uint8_t *decodings, double *llr, int32_t *iterations,
+                               uint8_t *converge, int32_t *final_order) {
+    BpSparse pcm(m, n, nnz);
+    for (int k = 0; k < nnz; k++) pcm.insert_entry(rows[k], cols[k]);
+    std::vector<double> probs(channel_probs, channel_probs + n);
+    std::vector<int> start(order0, order0 + n);
+    BpDecoder *one = nullptr;
+    if (carried)
+        one = new BpDecoder(pcm, probs, max_iter, static_cast<ldpc::bp::BpMethod>(bp_method), static_cast<ldpc::bp::BpSchedule>(schedule),
+                            ms_scaling_factor, 1, start, 0, false, ldpc::bp::SYNDROME);
+    for (int64_t b = 0; b < shots; b++) {
+        BpDecoder *dec = one ? one
+                             : new BpDecoder(pcm, probs, max_iter, static_cast<ldpc::bp::BpMethod>(bp_method),
+                                             static_cast<ldpc::bp::BpSchedule>(schedule), ms_scaling_factor, 1, start, 0, false, ldpc::bp::SYNDROME);
+        std::vector<uint8_t> in(inputs + b * m, inputs + (b + 1) * m);
+        dec->decode(in);
+        std::memcpy(decodings + b * n, dec->decoding.data(), (size_t)n);
+        if (llr) std::memcpy(llr + b * n, dec->log_prob_ratios.data(), sizeof(double) * (size_t)n);
+        iterations[b] = dec->iterations;
+        converge[b] = dec->converge ? 1 : 0;
+        if (final_order) for (int j = 0; j < n; j++) final_order[b * n + j] = dec->serial_schedule_order[(size_t)j];
+        if (!one) delete dec;
+    }
+    delete one;
+}
+
 /* ONE decoder object for all rows, as a loop of BpDecoder.decode calls on one Python object: the order (and generator) carry over */
 void ref_bp_decode_carried_batch(int m, int n, int nnz, const int32_t *rows, const int32_t *cols, const double *channel_probs,
                                  int max_iter, int bp_method, int schedule, double ms_scaling_factor, int random_serial,

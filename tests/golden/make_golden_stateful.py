@@ -28,7 +28,7 @@ from make_golden import bsc_syndromes, h_crc  # noqa: E402
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial=False, seed=0, varied=False):
+def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial=False, seed=0, varied=False, order0=None):
     h = sp.csr_matrix(h, dtype=np.uint8)
     m, n, rp, ci = csr_arrays(h)
     s = bsc_syndromes(h, 31, p, 0, rows)
@@ -36,7 +36,8 @@ def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial
     if varied:
         probs = np.clip(p * np.random.default_rng(9).uniform(0.5, 1.5, n), 1e-3, 0.4)
     kw = dict(schedule=schedule, error_channel=probs, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=alpha,
-              random_serial=random_serial, seed=seed)
+              random_serial=random_serial, seed=seed, order0=order0)
+    extra = {} if order0 is None else {"order0": np.asarray(order0, np.int32)}  # the serial_schedule_order given to the constructor
     fd, fl, fi, fc, fo = oracle.ref_decode_stateful(h, s, fresh=True, **kw)
     cd, cl, ci_, cc, co = oracle.ref_decode_stateful(h, s, fresh=False, **kw)
     path = os.path.join(OUT, name + ".npz")
@@ -46,7 +47,7 @@ def run(name, h, p, *, schedule, max_iter, bp_method, alpha, rows, random_serial
                         syndromes=np.packbits(s, axis=1),
                         fresh_decoding=np.packbits(fd, axis=1), fresh_llr=fl, fresh_iterations=fi, fresh_converge=fc, fresh_order_last=fo[-1],
                         carried_decoding=np.packbits(cd, axis=1), carried_llr=cl, carried_iterations=ci_, carried_converge=cc,
-                        carried_orders=co.astype(np.int16 if n < 32768 else np.int32))
+                        carried_orders=co.astype(np.int16 if n < 32768 else np.int32), **extra)
     differ = int((fd != cd).any(axis=1).sum())
     print(f"{name:34s} {m} x {n} rows={rows} converged={int(fc.sum())} rows where carried != fresh: {differ}  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -86,6 +87,16 @@ def main():
         random_serial=True, seed=123)
     run("stateful_rnd_ldpc600_ps_s1", codes.regular_ldpc_code(600, 3, 6, seed=3), 0.06, schedule="serial", max_iter=8, bp_method="product_sum", alpha=1.0, rows=48,
         random_serial=True, seed=1)
+    # a serial_schedule_order from the caller (bp.hpp:110-111: taken as it is): a permutation, and one with bits twice and bits never
+    og = np.random.default_rng(77)
+    perm = og.permutation(144).astype(np.int32)
+    run("stateful_rel_bb144_ms_startperm", bb, 0.06, schedule="serial_relative", max_iter=10, bp_method="minimum_sum", alpha=0.625, rows=64, order0=perm)
+    rep = perm.copy()
+    rep[20:44] = rep[60:84]
+    run("stateful_rel_bb144_ps_startrepeats", bb, 0.06, schedule="serial_relative", max_iter=10, bp_method="product_sum", alpha=1.0, rows=64, order0=rep)
+    s7 = codes.rotated_surface_code_x(7)
+    rep7 = og.integers(0, 49, 49).astype(np.int32)
+    run("stateful_rel_surf7_ms_startrepeats", s7, 0.06, schedule="serial_relative", max_iter=10, bp_method="minimum_sum", alpha=0.0, rows=48, order0=rep7)
     # the random flag wins over serial_relative (bp.hpp:467-469)
     run("stateful_rnd_over_rel_ham4_s5", codes.hamming_code(4), 0.08, schedule="serial_relative", max_iter=9, bp_method="product_sum", alpha=1.0, rows=40,
         random_serial=True, seed=5)

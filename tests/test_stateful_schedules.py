@@ -28,6 +28,7 @@ def load(name):
                    z[kind + "_converge"].astype(bool))
     c["fresh_order_last"] = z["fresh_order_last"].astype(np.int32)
     c["carried_orders"] = z["carried_orders"].astype(np.int32)
+    c["order0"] = z["order0"].astype(np.int32) if "order0" in z.files else None  # a serial_schedule_order given to the constructor (*_start*.npz)
     return c
 
 
@@ -37,7 +38,7 @@ def same(got, want):
 
 
 def test_cases_present():
-    assert len(CASES) >= 9 and any("_rel_" in c for c in CASES) and any("_rnd_" in c for c in CASES)
+    assert len(CASES) >= 12 and any("_rel_" in c for c in CASES) and any("_rnd_" in c for c in CASES) and sum("_start" in c for c in CASES) >= 3
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -47,16 +48,16 @@ def test_oracle_reproduces_the_reference(name, oracle_built):
     if c["random"]:
         assert same(o.decode_random_serial_batch(c["synd"], c["seed"]), c["fresh"])
     else:
-        g = o.decode_serial_relative_batch(c["synd"], fresh=True)
+        g = o.decode_serial_relative_batch(c["synd"], order_state=c["order0"], fresh=True)
         assert same(g, c["fresh"]) and np.array_equal(g[4], c["fresh_order_last"])
-        g = o.decode_serial_relative_batch(c["synd"], fresh=False)
+        g = o.decode_serial_relative_batch(c["synd"], order_state=c["order0"], fresh=False)
         assert same(g, c["carried"]) and np.array_equal(g[4], c["carried_orders"][-1])
 
 
 def _engine(c, rel_lds=None):
     from ldpc_amd.engine import HipBpEngine
     eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["probs"], c["max_iter"], c["bp_method"], c["alpha"])
-    eng.set_schedule(c["schedule"])
+    eng.set_schedule(c["schedule"], c["order0"])
     if c["random"]:
         eng.set_random_serial(True, c["seed"])
     if rel_lds is not None:  # serial_relative: 0 = the per-lane kernel (state in HBM); 16 / 64 = on chip, that many lanes per syndrome; "walk" = on chip, bit by bit
