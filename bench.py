@@ -17,7 +17,7 @@ plus, when a process group exists, the single gather of decoded rows (bit-packed
     python bench.py [--gpus N] [--steps K] [--warmup W]        # N > 1: spawns its N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-After the headline, at N = 1, the two on-chip BASELINE configs are timed as well (`secondary`): configs[2] (rotated
+After the headline, at N = 1, the two on-chip BASELINE configs (and schedule = serial_relative on the same two codes: `schedule_configs`) are timed as well (`secondary`): configs[2] (rotated
 surface code d = 21, min-sum 30, B = 262 144) and configs[4] (BB [[144,12,12]] product-sum 50 + OSD-0, B = 8 192).
 """
 from __future__ import annotations
@@ -304,6 +304,62 @@ def secondary_configs(dev, steps):
             entry["counters_match_this_build"] = src["kernel_sources_sha16"] == kernel_sources_sha16()
         out.append(entry)
         eng.close()
+    return out
+
+
+def schedule_configs(dev, steps):
+    """SURVEY.md section 8 f1: schedule = serial_relative (every syndrome its own bit order, re-sorted with std::sort at the top of every
+    iteration) on the two codes it is used on, B = 65 536, through `bp_relative_lds_kernel` (a syndrome's whole decode in LDS; DESIGN.md
+    section 6).  The bound is instruction issue at LDS-bound occupancy; what is reported is throughput and a BIT-EXACT sample against
+    the checker (decisions, iterations, flags, log-ratio bits, the order left behind)."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    import oracle  # checker only
+
+    out = []
+    specs = [
+        dict(key="f1_rel_surface", name="serial_relative: rotated surface code d=21 X checks (220 x 441), minimum_sum alpha=0.625, max_iter=30, batch=65536, BSC p=0.05",
+             h=codes.rotated_surface_code_x(21), p=0.05, max_iter=30, method=1, alpha=0.625),
+        dict(key="f1_rel_bb144", name="serial_relative: BB [[144,12,12]] hx (72 x 144), product_sum max_iter=50, batch=65536, BSC p=0.05",
+             h=codes.bivariate_bicycle_hx(), p=0.05, max_iter=50, method=0, alpha=1.0),
+    ]
+    B = 65536
+    for sp in specs:
+        h, p = sp["h"], sp["p"]
+        n = h.shape[1]
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), sp["max_iter"], sp["method"], sp["alpha"], device=dev.index or 0)
+        eng.set_schedule("serial_relative")
+        s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+        res = eng.decode_batch(s)  # warm-up; every row starts from the handle's order, which a call leaves as its last row left it:
+        step_ms, kms = [], []      # the timed calls start from that (a permutation either way)
+        for _ in range(max(2, min(steps, 3))):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = eng.decode_batch(s)
+            torch.cuda.synchronize()
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+            kms.append(eng.last_kernel_ms())
+        eng.close()
+        ms = float(np.median(step_ms))
+        # parity: the first rows and the last one on a fresh handle against the checker (a batch's rows all start from the same order)
+        rows = np.r_[0:24, B - 1]
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), sp["max_iter"], sp["method"], sp["alpha"], device=dev.index or 0)
+        eng.set_schedule("serial_relative")
+        s_host = s[torch.from_numpy(rows).to(dev)].cpu().numpy()
+        got = eng.decode_batch(s_host)
+        order_after = eng.schedule_order()
+        eng.close()
+        orc = oracle.BpOracle(h, error_rate=p, max_iter=sp["max_iter"], bp_method=sp["method"], ms_scaling_factor=sp["alpha"])
+        want = orc.decode_serial_relative_batch(s_host, fresh=True)
+        ok = bool(np.array_equal(got[0], want[0]) and oracle.bits_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+                  and np.array_equal(np.asarray(got[3], bool), want[3]) and np.array_equal(order_after, want[4]))
+        it = res[2].cpu().numpy() if hasattr(res[2], "cpu") else np.asarray(res[2])
+        cv = res[3].cpu().numpy() if hasattr(res[3], "cpu") else np.asarray(res[3])
+        out.append({"config": sp["name"], "key": sp["key"], "value": B / ms * 1e3, "unit": "syndromes/s", "ms": ms, "ms_steps": [round(v, 3) for v in step_ms],
+                    "bp_kernel_ms": float(np.median(kms)), "mean_iterations": float(np.asarray(it, np.float64).mean()),
+                    "bp_converged_fraction": float(np.asarray(cv, np.float64).mean()), "parity_vs_oracle": ok, "parity": "bit-exact, 25 rows, order left behind included",
+                    "bound": "instruction issue at LDS-bound occupancy (profiles/r4_serial_relative_pmc.txt)", "frac": None})
     return out
 
 
@@ -704,6 +760,7 @@ def run(args, real_stdout, stage) -> None:
             torch.cuda.empty_cache()
             try:
                 res["secondary"] = [early] + secondary_configs(dev, max(5, args.steps))  # (millisecond calls: a median of at least five)
+                res["secondary"] += schedule_configs(dev, args.steps)
                 if not all(e.get("parity_vs_oracle", False) for e in res["secondary"]):
                     res["parity_failed"] = True
             except Exception as exc:  # the headline line must not be lost to a secondary config
