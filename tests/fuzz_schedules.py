@@ -3,7 +3,7 @@
 tests/test_gpu_fuzz_soak.py): random regular and irregular codes of 24 .. 700 bits, random priors (uniform or per bit), methods, iteration
 limits, batch sizes and STARTING ORDERS (identity, a permutation, an order with repeated bits), schedule = serial_relative through every
 form of the on-chip kernel -- level by level with the scratch in the posterior array / apart, bit by bit with 64 / 16 lanes per syndrome --
-and through the per-lane kernel, plus the fixed-order serial schedule and the random one (walking kernel / level kernel): decisions, iteration counts, flags, log-ratio BITS and the order
+and through the per-lane kernel, plus the fixed-order serial schedule and the random one (walking kernel / level kernel), and soft-syndrome decoding with both: decisions, iteration counts, flags, log-ratio BITS and the order
 left behind, every row against the CPU checker (oracle/, pinned to the reference and to the host's std::sort).
     python tests/fuzz_schedules.py <seconds> <seed>"""
 import sys, os, time
@@ -93,6 +93,26 @@ def run(seconds=120.0, seed=1, max_cases=None):
                 eng.close()
                 assert np.array_equal(got[0], wr[0]) and np.array_equal(got[2], wr[2]) and np.array_equal(np.asarray(got[3], bool), wr[3]), f"random serial {tag0} kernel={mode}"
                 assert oracle.bits_equal(got[1], wr[1]), f"random serial llr {tag0} kernel={mode}"
+        # soft-syndrome decoding (serial min-sum, bp.hpp:547-660), fixed order and with the random schedule (a NEW engine seeded alike per
+        # shuffle, bp.hpp:573-577): walking kernel / level kernel
+        if method == 1 and order is None and rng.random() < 0.5:
+            Bs = min(B, 300)
+            soft = (1 - 2 * s[:Bs].astype(np.float64) % 2) * 2 + rng.uniform(-3.0, 3.0, (Bs, m))
+            cutoff, sigma = float(rng.choice([2.0, 4.0])), float(rng.choice([1.0, 1.5]))
+            seed_s = int(rng.integers(-5, 2**31 - 1))
+            for shuffled in (False, True):
+                ws = o.soft_info_decode_random_batch(soft, cutoff, sigma, seed_s) if shuffled else o.soft_info_decode_batch(soft, cutoff, sigma)
+                for mode in (0, 1, -1):
+                    eng = HipBpEngine(h.indptr, h.indices, n, probs, max_iter, 1, alpha)
+                    eng.set_schedule("serial")
+                    if shuffled:
+                        eng.set_random_serial(True, seed_s & 0xffffffff)
+                    eng.set_serial_kernel(mode)
+                    got = eng.soft_info_decode_batch(soft, cutoff, sigma)
+                    eng.close()
+                    t = f"soft {tag0} shuffled={shuffled} kernel={mode} cutoff={cutoff} sigma={sigma}"
+                    assert np.array_equal(got[0], ws[0]) and np.array_equal(got[2], ws[2]) and np.array_equal(np.asarray(got[3], bool), ws[3]), t
+                    assert oracle.bits_equal(got[1], ws[1]) and oracle.bits_equal(got[4], ws[4]), "values " + t
         n_ok += 1
     return n_ok
 
