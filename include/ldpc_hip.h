@@ -354,7 +354,10 @@ int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
  * are streamed).  Results are identical. */
 int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Measurement / test switches: kernel-shape choices that never change a result (profiles/README.md lists them: "PS_TEAM",
- * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", ...).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
+ * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", ...; for schedule = serial_relative: "REL_LDS" 0 = the
+ * per-lane kernel with the state in HBM, 16 / 64 = lanes per syndrome of the on-chip kernel; "REL_LEVELS" 0 = sweep bit by bit instead of
+ * level by level; "REL_SCRATCH_IN_L" 0 = scratch apart from the posterior array; "REL_PROF" 1 = print the kernel's cycle shares per phase
+ * to stderr).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
  * created; afterwards only this call changes a switch (value < 0: back to "not set").  Unknown names are an error. */
 int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value);
 
