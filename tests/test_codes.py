@@ -42,3 +42,26 @@ def test_irregular_ldpc_code_profile():
     assert cw.min() >= 2 and cw.max() <= 8 and cw.sum() == rw.sum() == h.nnz
     assert (codes.irregular_ldpc_code(600, 300, seed=3) != h).nnz == 0
     assert (codes.irregular_ldpc_code(600, 300, seed=4) != h).nnz > 0
+
+
+def test_schedules_soak_generator_and_checker(oracle_built):
+    """The code generator of tests/fuzz_schedules.py stays inside what the on-chip serial_relative kernel takes (columns <= 8, rows <= 16
+    entries) and the checker runs its cases (no GPU here: the soak itself is tests/test_gpu_fuzz_soak.py)."""
+    import numpy as np
+    import fuzz_schedules
+    rng = np.random.default_rng(12)
+    shapes = set()
+    for _ in range(25):
+        h = fuzz_schedules.random_code(rng)
+        m, n = h.shape
+        shapes.add((m, n))
+        assert h.nnz > 0 and int(h.sum(0).max()) <= 8 and int(h.sum(1).max()) <= 16 and n <= 1024
+    assert len(shapes) >= 6
+    h = fuzz_schedules.random_code(np.random.default_rng(3))
+    n = h.shape[1]
+    o = oracle_built.BpOracle(h, error_rate=0.05, max_iter=6, bp_method=1, ms_scaling_factor=0.625)
+    e = (np.random.default_rng(4).random((5, n)) < 0.05).astype(np.uint8)
+    s = np.asarray((h @ e.T % 2).T, dtype=np.uint8)
+    order = np.random.default_rng(5).integers(0, n, n).astype(np.int32)  # repeats allowed
+    d, l, it, cv, last = o.decode_serial_relative_batch(s, order_state=order, fresh=True)
+    assert d.shape == (5, n) and sorted(last.tolist()) == sorted(order.tolist())  # the order is rearranged, never changed as a multiset
