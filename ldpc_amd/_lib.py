@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
     "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_set_random_serial", "ldpc_hip_bp_get_schedule_order", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
     "ldpc_hip_bp_set_osd", "ldpc_hip_bposd_get_status", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
-    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms", "ldpc_hip_bp_clock_probe",
+    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms", "ldpc_hip_bp_clock_probe", "ldpc_hip_host_alloc", "ldpc_hip_host_free",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
     "ldpc_hip_bp_set_debug_switch", "ldpc_hip_bp_multi_create", "ldpc_hip_bp_multi_destroy", "ldpc_hip_bp_multi_devices", "ldpc_hip_bp_multi_handle",
@@ -94,6 +94,10 @@ def load():
     lib.ldpc_hip_bp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldpc_hip_bp_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ldpc_hip_bp_clock_probe.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    lib.ldpc_hip_host_alloc.argtypes = [C.c_size_t]
+    lib.ldpc_hip_host_alloc.restype = C.c_void_p
+    lib.ldpc_hip_host_free.argtypes = [vp]
+    lib.ldpc_hip_host_free.restype = None
     lib.ldpc_hip_bp_workspace_bytes.argtypes = [vp, i64]
     lib.ldpc_hip_bp_workspace_bytes.restype = i64
     lib.ldpc_hip_bp_set_tuning.argtypes = [vp, i32, i32]
@@ -122,3 +126,42 @@ def check(rc: int) -> None:
     if rc != 0:
         msg = load().ldpc_hip_last_error().decode("utf-8", "replace")
         raise LdpcHipError(f"libldpc_hip error {rc}: {msg}")
+
+
+class PinnedBlock:
+    """A block of page-locked host memory (``ldpc_hip_host_alloc``) that NumPy arrays can sit on: ``array(shape, dtype)`` gives an array
+    whose ``base`` is this object -- views of it refer to the block too -- and the memory goes back when the last of them is gone.
+    ``PinnedBlock.try_new`` returns None where the memory cannot be had."""
+
+    def __init__(self, lib, ptr: int, nbytes: int):
+        self._lib, self.ptr, self.nbytes = lib, ptr, nbytes
+
+    @classmethod
+    def try_new(cls, nbytes: int):
+        try:
+            lib = load()
+            ptr = lib.ldpc_hip_host_alloc(int(nbytes))
+        except Exception:
+            return None
+        return cls(lib, ptr, int(nbytes)) if ptr else None
+
+    def array(self, shape, dtype):
+        import numpy as np
+        dt = np.dtype(dtype)
+        if int(np.prod(shape)) * dt.itemsize > self.nbytes:
+            raise ValueError("array larger than the block")
+
+        class _Iface:  # (what np.asarray reads; it keeps `owner` as the array's base)
+            pass
+        holder = _Iface()
+        holder.owner = self
+        holder.__array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": dt.str, "data": (self.ptr, False), "version": 3}
+        return np.asarray(holder)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", 0), 0
+        if ptr:
+            try:
+                self._lib.ldpc_hip_host_free(ptr)
+            except Exception:
+                pass

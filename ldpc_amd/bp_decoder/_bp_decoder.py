@@ -457,8 +457,27 @@ class BpDecoderBase:
         import sys
         old = getattr(self, "log_prob_ratios_batch", None)
         if isinstance(old, np.ndarray) and old.dtype == np.float64 and old.shape == (rows, self.n) and old.flags.c_contiguous \
-                and old.flags.owndata and old.flags.writeable and sys.getrefcount(old) <= 3:  # the attribute, `old`, getrefcount's argument
+                and (old.flags.owndata or getattr(old.base, "owner", None) is not None) and old.flags.writeable \
+                and sys.getrefcount(old) <= 3:  # the attribute, `old`, getrefcount's argument (a view someone kept holds `old` as its base)
             return old
+        return None
+
+    def _llr_destination(self, rows: int):
+        """Where a batch's log-ratios go: the previous batch's array if it is free (``_recyclable_llr``); else, ONCE per decoder and
+        shape and only for arrays of 256 MiB and more, a new array on page-locked memory (``ldpc_hip_host_alloc``) -- the device-to-host
+        copies then write it directly, with no staging buffer and no host-side copy (include/ldpc_hip.h), and the next call recycles
+        it; else None (the backend makes an ordinary array).  A caller who keeps every batch's array gets ordinary arrays from the
+        second call on: page-locked memory is not something to allocate per call."""
+        out = self._recyclable_llr(rows)
+        if out is not None:
+            return out
+        nbytes = rows * self.n * 8
+        if nbytes >= (256 << 20) and getattr(self, "_pinned_llr_shape", None) != (rows, self.n):
+            self._pinned_llr_shape = (rows, self.n)
+            from .._lib import PinnedBlock
+            blk = PinnedBlock.try_new(nbytes)
+            if blk is not None:
+                return blk.array((rows, self.n), np.float64)
         return None
 
     def _require_parallel(self):
@@ -614,7 +633,7 @@ class BpDecoder(BpDecoderBase):
             scan.start()
         try:
             dec, llr, it, cv = self._decode_numpy(synd, want_llr=want_log_prob_ratios,
-                                                  llr_out=self._recyclable_llr(len(synd)) if want_log_prob_ratios else None)
+                                                  llr_out=self._llr_destination(len(synd)) if want_log_prob_ratios else None)
         finally:
             if scan is not None:
                 scan.join()

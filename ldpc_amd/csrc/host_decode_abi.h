@@ -138,7 +138,10 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     const size_t m = (size_t)h->m, n = (size_t)h->n;
     auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
     const size_t R = (size_t)rows;
-    const size_t o_llr = up(R * n), o_it = o_llr + (llr ? up(R * n * 8) : 0), o_cv = o_it + (iters ? up(R * 4) : 0), out_bytes = o_cv + (conv ? up(R) : 0);
+    // log-ratios into page-locked memory of the caller's (ldpc_hip_host_alloc, hipHostRegister): the copy engine writes them where they
+    // belong -- no staging buffer, no host-side copy for the one array that is eight ninths of the results
+    const bool llr_direct = llr && is_pinned_host_ptr(llr) && is_pinned_host_ptr(llr + (size_t)batch * n - 1) && !h->on("NO_DIRECT_LLR");
+    const size_t o_llr = up(R * n), o_it = o_llr + (llr && !llr_direct ? up(R * n * 8) : 0), o_cv = o_it + (iters ? up(R * 4) : 0), out_bytes = o_cv + (conv ? up(R) : 0);
     const size_t in_bytes = up(R * m ? R * m : 1);
     int rc;
     // streams, events, pinned and device staging: if any of it cannot be had (pinned memory is a limited resource) the caller takes
@@ -175,7 +178,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         return 1;  // "not here": decode_batch_staged carries on with the one-shot path
     }
     advise_huge_pages(decoding, (size_t)batch * n);
-    if (llr) advise_huge_pages(llr, (size_t)batch * n * 8);
+    if (llr && !llr_direct) advise_huge_pages(llr, (size_t)batch * n * 8);
     const int64_t chunks = (batch + rows - 1) / rows;
     auto rows_of = [&](int64_t c) { return c == chunks - 1 ? batch - c * rows : rows; };
     // the helper: chunk after chunk, wait for its results to have landed in the pinned buffer, copy them into the caller's arrays
@@ -200,7 +203,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
             if (hipEventSynchronize(P.ev_out[q]) != hipSuccess) { drain_err = 1; return; }
             const double t2 = clocked ? now() : 0;
             host_copy_parallel(decoding + b0 * n, P.pin_out[q], r * n);
-            if (llr) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
+            if (llr && !llr_direct) host_copy_parallel(llr + b0 * n, P.pin_out[q] + o_llr, r * n * 8);
             if (iters) std::memcpy(iters + b0, P.pin_out[q] + o_it, r * 4);
             if (conv) std::memcpy(conv + b0, P.pin_out[q] + o_cv, r);
             if (clocked) { const double t3 = now(); t_wait_queue += t1 - t0; t_wait_event += t2 - t1; t_copy_out += t3 - t2; }
@@ -242,7 +245,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         PIPECHK(hipEventRecord(P.ev_cmp[q], h->stream));
         PIPECHK(hipStreamWaitEvent(P.s_out, P.ev_cmp[q], 0));
         if (r * n) PIPECHK(hipMemcpyAsync(P.pin_out[q], P.d_dec[q].p, r * n, hipMemcpyDeviceToHost, P.s_out));
-        if (llr && r * n) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_llr, P.d_llr[q].p, r * n * 8, hipMemcpyDeviceToHost, P.s_out));
+        if (llr && r * n) PIPECHK(hipMemcpyAsync(llr_direct ? (void *)(llr + b0 * n) : (void *)(P.pin_out[q] + o_llr), P.d_llr[q].p, r * n * 8, hipMemcpyDeviceToHost, P.s_out));
         if (iters) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_it, P.d_it[q].p, r * 4, hipMemcpyDeviceToHost, P.s_out));
         if (conv) PIPECHK(hipMemcpyAsync(P.pin_out[q] + o_cv, P.d_cv[q].p, r, hipMemcpyDeviceToHost, P.s_out));
         PIPECHK(hipEventRecord(P.ev_out[q], P.s_out));
@@ -313,8 +316,10 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
     // everything on the host, BP only, rows independent of one another, and enough of them for several chunks: pipelined
     if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && osd < 0 && !h->random_serial && h->schedule != 2 &&
         !h->on("NO_HOST_PIPELINE")) {
-        // chunk: ~256 MiB of results, between 1 024 and 16 384 rows (whole tiles), or what LDPC_HIP_HOST_CHUNK_ROWS says
-        const size_t per_row = n * (llr ? 9 : 1) + m + 5;
+        // chunk: ~256 MiB of staged results, between 1 024 and 16 384 rows (whole tiles), or what LDPC_HIP_HOST_CHUNK_ROWS says; log-ratios
+        // that go straight into page-locked memory of the caller's (decode_batch_pipelined) are not staged and do not count
+        const bool llr_staged = llr && !(is_pinned_host_ptr(llr) && !h->on("NO_DIRECT_LLR"));
+        const size_t per_row = n * (llr_staged ? 9 : 1) + m + 5;
         int64_t rows = (int64_t)(((size_t)256 << 20) / (per_row ? per_row : 1));
         if (rows > 16384) rows = 16384;
         if (rows < 1024) rows = 1024;

@@ -321,6 +321,19 @@ int ldpc_hip_bp_last_kernel_ms(ldpc_hip_bp *h, float *ms) {
     return LDPC_HIP_OK;
 }
 
+void *ldpc_hip_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void ldpc_hip_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int ldpc_hip_bp_clock_probe(ldpc_hip_bp *h, uint64_t *cycles, uint64_t *ticks, double *tick_hz) {
     if (!h || !cycles || !ticks || !tick_hz) return fail(LDPC_HIP_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(h->device));

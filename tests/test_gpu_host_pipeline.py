@@ -88,3 +88,57 @@ def test_log_ratio_array_is_recycled_only_when_nobody_else_holds_it(oracle_built
     assert bits_equal(dec.log_prob_ratios_batch, want1)
     dec.decode_batch(s2[:100])                             # another shape: a new array
     assert dec.log_prob_ratios_batch.shape == (100, 600) and bits_equal(dec.log_prob_ratios_batch, want2[:100])
+
+
+def test_log_ratios_into_page_locked_memory_take_the_direct_route(oracle_built):
+    """`llr` in page-locked host memory (ldpc_hip_host_alloc): the pipelined path lets the device-to-host copies write it directly (no
+    staging buffer, no host-side copy).  Same bits as the staged route, chunk sizes and a ragged tail included; the switch
+    NO_DIRECT_LLR sends the same pinned array through the staged route."""
+    from ldpc_amd import codes
+    from ldpc_amd._lib import PinnedBlock
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.regular_ldpc_code(2400, 3, 6, seed=8)
+    n, p, B = 2400, 0.055, 20000 + 37
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), 12, 0, 1.0)
+    eng.set_small_code_kernel(0)
+    s = eng.gen_bsc_syndromes(3, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+    want = eng.decode_batch(s, want_llr=True)
+    blk = PinnedBlock.try_new(B * n * 8)
+    assert blk is not None
+    pinned = blk.array((B, n), np.float64)
+    for rows in (1024, 4096, -1):
+        eng.set_debug_switch("HOST_CHUNK_ROWS", rows)
+        for direct in (True, False):
+            eng.set_debug_switch("NO_DIRECT_LLR", 0 if direct else 1)
+            pinned[:] = np.nan
+            got = eng.decode_batch(s, want_llr=True, llr_out=pinned)
+            assert got[1] is pinned or got[1].ctypes.data == pinned.ctypes.data
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and bits_equal(pinned, want[1]), (rows, direct)
+    eng.close()
+    view = pinned[7]
+    del pinned, blk, got
+    assert bits_equal(view, want[1][7])  # (a view keeps the block alive)
+
+
+def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracle_built):
+    """`BpDecoder.decode_batch(numpy)`: the first large batch gets its log-ratio array on page-locked memory and the next call recycles
+    it; a caller who keeps the array gets an ordinary one next time (no page-locked allocation per call)."""
+    from ldpc_amd import codes
+    from ldpc_amd.bp_decoder import BpDecoder
+    h = codes.regular_ldpc_code(3000, 3, 6, seed=2)
+    dec = BpDecoder(h, error_rate=0.04, max_iter=8, bp_method="minimum_sum", ms_scaling_factor=0.75, input_vector_type="syndrome")
+    eng = dec._get_engine()
+    B = 12000  # 12 000 x 3 000 x 8 = 288 MB
+    s = eng.gen_bsc_syndromes(9, 0.04, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+    out1 = dec.decode_batch(s)
+    a1 = dec.log_prob_ratios_batch
+    assert not a1.flags.owndata and getattr(a1.base, "owner", None) is not None  # on a PinnedBlock
+    want = a1.copy()
+    addr = a1.ctypes.data
+    del a1
+    out2 = dec.decode_batch(s)
+    assert dec.log_prob_ratios_batch.ctypes.data == addr and bits_equal(dec.log_prob_ratios_batch, want) and np.array_equal(out1, out2)
+    kept = dec.log_prob_ratios_batch
+    dec.decode_batch(s)
+    assert dec.log_prob_ratios_batch.ctypes.data != addr and dec.log_prob_ratios_batch.flags.owndata  # an ordinary array this time
+    assert bits_equal(kept, want) and bits_equal(dec.log_prob_ratios_batch, want)
