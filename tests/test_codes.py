@@ -65,3 +65,33 @@ def test_schedules_soak_generator_and_checker(oracle_built):
     order = np.random.default_rng(5).integers(0, n, n).astype(np.int32)  # repeats allowed
     d, l, it, cv, last = o.decode_serial_relative_batch(s, order_state=order, fresh=True)
     assert d.shape == (5, n) and sorted(last.tolist()) == sorted(order.tolist())  # the order is rearranged, never changed as a multiset
+
+
+def test_pinned_block_arrays_keep_the_block_alive():
+    """ldpc_amd._lib.PinnedBlock: arrays on the block refer to it through their base, views of them too; the memory goes back when the
+    last one is gone (here on ordinary memory behind a stand-in for the library: no GPU)."""
+    import ctypes
+    import gc
+    import numpy as np
+    from ldpc_amd._lib import PinnedBlock
+    buf = ctypes.create_string_buffer(80)
+    freed = []
+
+    class FakeLib:
+        def ldpc_hip_host_free(self, p):
+            freed.append(p)
+
+    blk = PinnedBlock(FakeLib(), ctypes.addressof(buf), 80)
+    a = blk.array((2, 5), np.float64)
+    assert not a.flags.owndata and a.flags.writeable and a.flags.c_contiguous and getattr(a.base, "owner", None) is blk
+    a[:] = 1.5
+    v = a[1]
+    del a, blk
+    gc.collect()
+    assert freed == [] and v.tolist() == [1.5] * 5
+    del v
+    gc.collect()
+    assert freed == [ctypes.addressof(buf)]
+    import pytest
+    with pytest.raises(ValueError):
+        PinnedBlock(FakeLib(), ctypes.addressof(buf), 80).array((3, 5), np.float64)
