@@ -28,8 +28,10 @@
 //
 // Built with: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 //
-// One translation unit.  Device code lives in the kernel headers included below; the host side is split by subsystem into the
-// host_*.h files included after them (handle, setup ABI, serial schedules, on-chip kernels, streamed kernels, OSD, decode ABI):
+// Five translation units, compiled side by side and linked into one library (Makefile): this one carries the C ABI (handle, setup,
+// decode entry points, layout kernels); tu_stream.hip, tu_serial.hip, tu_onchip.hip and tu_osd.hip carry one kernel family each
+// together with its host side (host_stream.h, host_serial.h, host_onchip.h, host_osd.h).  What they call in each other is
+// declared at the end of host_handle.h.  Device code lives in the kernel headers:
 //   bp_device_common.h   argument blocks, buffer-descriptor message addressing, per-node arithmetic, LDS-DMA helpers
 //   bp_math.h            tanh / log / division: bit-identical twins of the host libm + the fast variants
 //   bp_stream_kernel.h   bp_decode_kernel        persistent workgroup per 64-syndrome tile (register / LDS-ring variants)
@@ -44,78 +46,10 @@
 //   multi_device.h       ldpc_hip_bp_multi_*: a batch sharded over several GPUs inside one process (host code only)
 
 #include "bp_device_common.h"
-#include "bp_stream_kernel.h"
-#include "bp_spread_kernels.h"
-#include "bp_serial_kernels.h"
-#include "bp_relative_kernel.h"
-#include "bp_relative_lds_kernel.h"
-#include "bp_small_kernel.h"
-#include "bp_wave_kernel.h"
-#include "bp_edge_kernel.h"
-#include "osd_kernels.h"
-#include "osd_exact_kernel.h"
 #include "io_kernels.h"
 
 #include "host_handle.h"
 #include "host_setup.h"
-
-
-typedef void (*bp_kernel_t)(const BpArgs);
-typedef void (*spread_kernel_t)(const SpreadArgs);
-
-template <int METHOD, int MATH>
-static void pick_spread_m(int max_row, int max_col, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
-    if (nt) {
-        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 1> : bp_spread_check_kernel<METHOD, MATH, 16, 1>;
-        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 1> : bp_spread_bit_kernel<METHOD, MATH, 8, 1>;
-    } else {
-        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 0> : bp_spread_check_kernel<METHOD, MATH, 16, 0>;
-        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 0> : bp_spread_bit_kernel<METHOD, MATH, 8, 0>;
-    }
-}
-
-struct KernelChoice {
-    bp_kernel_t fn;
-    int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
-    int ring_depth;
-    int max_waves = 16;   // wavefronts per workgroup the variant was compiled for (stream_max_waves)
-};
-
-template <int METHOD, int MATH>
-static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
-    // Register arrays are sized by the template bounds, so the common regular codes get exact fits:
-    // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
-    if (ring_depth == 2 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 2>, 3 * 1024, 2};
-    if (ring_depth >= 3 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 3>, 3 * 1024, 3};
-    if (ring_depth >= 2 && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
-    if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0, 0};
-    if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0, 0};
-    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0, stream_max_waves(8, 0)};
-    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0, 0, stream_max_waves(8, 0)};
-    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0, 0, stream_max_waves(16, 0)};
-    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0, stream_max_waves(16, 0)};  // heavier nodes take the streaming path inside
-}
-
-
-
-static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
-                         double *llr, int32_t *iters, uint8_t *conv, bool may_repack = true);
-
-// Serial schedule: one wavefront per 64-syndrome tile (bp_serial_kernel).  Device pointers, on h->stream.
-
-#include "host_serial.h"
-#include "host_onchip.h"
-#include "host_stream.h"
-#include "host_osd.h"
 #include "host_decode_abi.h"
 
 #include "multi_device.h"  // ldpc_hip_bp_multi_*: one decoder over several GPUs in one process (host code over the entry points above)
-
-#ifdef LDPC_HIP_OSD_CLOCKS
-extern "C" int ldpc_hip_debug_osd_clocks(unsigned long long *out, int reset) {
-    if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(osd_phase_clocks), sizeof(unsigned long long) * 16));
-    if (reset) { unsigned long long z[16] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(osd_phase_clocks), z, sizeof z)); }
-    return LDPC_HIP_OK;
-}
-#endif
-

@@ -1,5 +1,6 @@
 // host_handle.h -- the handle (struct ldpc_hip_bp), error reporting, device buffers, measurement switches
-// Part of libldpc_hip.so: included by bp_hip.hip (one translation unit), in the order given there.
+// Part of libldpc_hip.so: included by every translation unit (bp_hip.hip = the C ABI; tu_stream / tu_serial / tu_onchip / tu_osd.hip = one kernel
+// family each with its host side).  What one unit calls in another is declared at the end of this header.
 #pragma once
 
 #include <chrono>
@@ -13,7 +14,7 @@
 // host side
 // ------------------------------------------------------------------------------------------------
 
-static thread_local std::string g_last_error;
+inline thread_local std::string g_last_error;  // (one per thread for the whole library: C++17 inline variable)
 
 static int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -242,3 +243,17 @@ static bool is_device_ptr(const void *p) {
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
+
+// ---- what the translation units call in each other (device pointers, on h->stream) -------------------------------------------------
+// tu_stream.hip: the dispatch of a batch to a kernel family, and the streamed kernels themselves
+int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv,
+                  bool may_repack = true);
+// tu_onchip.hip: the kernels that keep a syndrome's messages on chip; *took = false: no such kernel applies to this matrix
+int decode_onchip(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv, bool *took);
+// tu_serial.hip: serial / serial_relative / random serial schedules, soft-syndrome decoding
+int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv);
+int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, double cutoff, double sigma, uint8_t *decoding, double *llr,
+                     int32_t *iters, uint8_t *conv, double *soft_out);
+// tu_osd.hip: BP followed by ordered-statistics post-processing of the rows it left unconverged
+int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                 int32_t *iters, uint8_t *conv);

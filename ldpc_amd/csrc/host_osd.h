@@ -42,7 +42,7 @@ static int osd_status_pass(ldpc_hip_bp *h, const OsdArgs &a, int64_t batch) {
     return LDPC_HIP_OK;
 }
 
-static int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                         double *llr, int32_t *iters, uint8_t *conv) {
     if (osd_method == 0)  // OSD_OFF: BpOsdDecoder still calls OsdDecoder::decode, which then has no LU object -- refuse instead
         return fail(LDPC_HIP_ERR_INVALID, "osd_method is OSD_OFF");

@@ -534,7 +534,7 @@ static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     return LDPC_HIP_OK;
 }
 
-static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                          int32_t *iters, uint8_t *conv) {
     if (h->random_serial) return decode_serial_random(h, synd, batch, decoding, llr, iters, conv);  // (takes precedence, bp.hpp:467-469)
     if (h->schedule == 2) return decode_serial_relative(h, synd, batch, decoding, llr, iters, conv);
@@ -580,7 +580,7 @@ static int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uin
 }
 
 // soft_info_decode_serial over a batch (bp_softinfo_kernel).  Device pointers, on h->stream.
-static int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, double cutoff, double sigma, uint8_t *decoding,
+int soft_info_device(ldpc_hip_bp *h, const double *soft, int64_t batch, double cutoff, double sigma, uint8_t *decoding,
                             double *llr, int32_t *iters, uint8_t *conv, double *soft_out) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;

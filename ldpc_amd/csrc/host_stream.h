@@ -13,35 +13,16 @@ static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spre
 // Everything below runs on h->stream with device pointers only.
 static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                   double *llr, int32_t *iters, uint8_t *conv);
-static int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
-                         double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
+int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
+                  double *llr, int32_t *iters, uint8_t *conv, bool may_repack) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (tiles_total == 0) return LDPC_HIP_OK;
     if (!h->cont_A) h->timed_prev = h->timed_prev_mid = false;  // (a second pass keeps the first pass's events: ldpc_hip_bp_last_kernel_ms adds them)
     if (h->schedule == 0 || h->schedule == 2) return decode_serial(h, synd, batch, decoding, llr, iters, conv);
-    if (h->small_mode != 0 && h->m > 0 && h->n > 0 && h->nnz > 0 && (int64_t)h->nnz * 16 < (1 << 22) && batch < (1ll << 30)) {  // (32-bit syndrome indices in the work pools)
-        // small code: keep the messages on chip.  Bounded degrees: one wavefront per syndrome (bp_wave_kernel).
-        // Otherwise the slot kernel -- auto: the most resident syndromes (<= 4) per workgroup that still leave
-        // four workgroups per CU (<= 39.5 KiB each); forced: whatever fits in 150 KiB
-        if (h->small_mode < 2 || h->small_mode == 6) {  // (mode 6: as -1 wherever the lane = edge variants do not apply) product-sum: one lane per entry keeps the lanes busy with transcendentals
-            const WavePsPlan pp = plan_wave_ps(h, h->small_mode == 1, llr != nullptr, batch);
-            if (pp.waves) return decode_wave_ps(h, pp, synd, batch, decoding, llr, iters, conv);
-        }
-        if (h->small_mode == -1 || h->small_mode == 1 || h->small_mode == 6) {  // min-sum on the surface-code family: lane = edge
-            const EdgePlan ep = plan_edge(h);
-            if (ep.rounds) return decode_edge(h, ep, synd, batch, decoding, llr, iters, conv);
-            const Edge8Plan e8 = plan_edge8(h);  // heavier nodes (rows <= 8, columns <= 4): rows in 8-lane groups
-            if (e8.rounds) return decode_edge8(h, e8, synd, batch, decoding, llr, iters, conv);
-        }
-        if (h->small_mode != 2) {
-            const WavePlan wp = plan_wave(h, h->small_mode == 1 || (h->small_mode >= 3 && h->small_mode != 6), llr != nullptr, batch);
-            if (wp.waves) return decode_wave(h, wp, synd, batch, decoding, llr, iters, conv);
-        }
-        int slots = 0;
-        const size_t budget = (h->small_mode == 1 || h->small_mode == 2) ? 150u * 1024u : 39u * 1024u + 512u;
-        for (int sl = 4; sl >= 1 && !slots; --sl)
-            if (small_lds_bytes(h, sl) <= budget) slots = sl;
-        if (slots) return decode_small(h, synd, batch, decoding, llr, iters, conv, slots);
+    {   // small code: the kernels that keep a syndrome's messages on chip (tu_onchip.hip), where one applies
+        bool took = false;
+        const int rc_onchip = decode_onchip(h, synd, batch, decoding, llr, iters, conv, &took);
+        if (took || rc_onchip) return rc_onchip;
     }
     // streamed tiles: a tile runs until the slowest of its 64 syndromes is done.  Where most syndromes converge early
     // a short first pass + a second pass over the compacted rest does the same work in a fraction of the tile-iterations

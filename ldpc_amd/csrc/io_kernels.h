@@ -1,8 +1,11 @@
 // io_kernels.h -- layout changes either side of the decoders: pack / unpack / transpose, H v, b8 shot data, synthetic shots
-// Part of libldpc_hip.so (one translation unit: bp_hip.hip includes every kernel header).
+// Part of libldpc_hip.so.  Included by every translation unit (bp_hip.hip, tu_*.hip): the kernels here are small and have internal
+// linkage (LDPC_IO_KERNEL), so each unit that launches one carries its own copy.
 #pragma once
 
 #include "bp_device_common.h"
+
+#define LDPC_IO_KERNEL static __global__
 
 // One-dimensional element-wise kernels run grid-stride loops under a capped grid (flat_grid in bp_hip.hip): item counts
 // such as batch * n pass 2^32 for large batches of large codes.
@@ -15,7 +18,7 @@ __device__ __forceinline__ int64_t rows_of_launch(int64_t batch, const unsigned 
 }
 
 // syndromes [batch][m] u8  ->  par / nzm [tiles][m] u64, invalid [tiles] u64 (pre-zeroed)
-__global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch_arg, int m,
+LDPC_IO_KERNEL void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t batch_arg, int m,
                                       uint64_t *par, uint64_t *nzm, uint64_t *invalid,
                                       const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,7 +43,7 @@ __global__ void pack_syndromes_kernel(const uint8_t *__restrict__ synd, int64_t 
 }
 
 // dec [tiles][n] u64 -> decoding [batch][n] u8
-__global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch_arg, int n,
+LDPC_IO_KERNEL void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t batch_arg, int n,
                                        uint8_t *out, const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -56,7 +59,7 @@ __global__ void unpack_decoding_kernel(const uint64_t *__restrict__ dec, int64_t
 }
 
 // llr_t [tiles][n][64] f64 -> llr [batch][n] f64, 64x64 tiles through LDS
-__global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__restrict__ llr_t,
+LDPC_IO_KERNEL void __launch_bounds__(256) transpose_llr_kernel(const double *__restrict__ llr_t,
                                                             int64_t batch_arg, int n, double *out,
                                                             const int32_t *__restrict__ row_map = nullptr, const unsigned *count_dev = nullptr) {
     __shared__ double tilebuf[LDPC_WAVE][LDPC_WAVE + 1];
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256) transpose_llr_kernel(const double *__rest
 }
 
 // GF2Sparse::mulvec over a batch (gf2sparse.hpp:177-214): one thread per (vector, check)
-__global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
+LDPC_IO_KERNEL void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
                                   const int32_t *__restrict__ col_idx, int m, int n,
                                   const uint8_t *__restrict__ in, int64_t batch, uint8_t *out) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * m; t += (int64_t)gridDim.x * blockDim.x) {
@@ -93,7 +96,7 @@ __global__ void gf2_mulvec_kernel(const int32_t *__restrict__ row_ptr,
 
 // ---- bit-packed shot data ("b8": bit i of a shot is bit i % 8 of its byte i / 8; every shot starts on a byte) --
 // the wire format of the reference's sinter decoders (sinter_decoders/sinter_bposd_decoder.py:57-130)
-__global__ void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+LDPC_IO_KERNEL void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * bits; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / bits;
         const int i = (int)(t - b * bits);
@@ -101,7 +104,7 @@ __global__ void unpack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, 
     }
 }
 
-__global__ void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
+LDPC_IO_KERNEL void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, int bits, uint8_t *__restrict__ out) {
     const int nb = (bits + 7) >> 3;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * nb; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / nb;
@@ -114,7 +117,7 @@ __global__ void pack_b8_kernel(const uint8_t *__restrict__ in, int64_t batch, in
 
 // BpDecoder.decode / BpOsdDecoder.decode return the zero vector for an all-zero input without running BP
 // (_bp_decoder.pyx:679-681, _bposd_decoder.pyx:118-123): converge = True, iterations reported as 0 by the batch API
-__global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, int64_t batch, int m, int n, uint8_t *dec,
+LDPC_IO_KERNEL void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, int64_t batch, int m, int n, uint8_t *dec,
                                           int32_t *iters, uint8_t *conv) {
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (int64_t)gridDim.x * blockDim.x) {
         const int mb = (m + 7) >> 3;
@@ -133,7 +136,7 @@ __global__ void zero_shot_shortcut_kernel(const uint8_t *__restrict__ dets_b8, i
 
 // predicted observables L x (mod 2) of every decoding, bit-packed: one thread per (shot, output byte)
 // (SinterBpOsdDecoder.decode: `(observables_matrix @ corr) % 2`, sinter_bposd_decoder.py:128-130)
-__global__ void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx, int k, int n,
+LDPC_IO_KERNEL void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col_idx, int k, int n,
                                       const uint8_t *__restrict__ dec, int64_t batch, uint8_t *__restrict__ out) {
     const int nb = (k + 7) >> 3;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * nb; t += (int64_t)gridDim.x * blockDim.x) {
@@ -151,7 +154,7 @@ __global__ void observables_b8_kernel(const int32_t *__restrict__ row_ptr, const
 }
 
 // synthetic BSC shots: syndrome[b][i] = XOR_{j in row i} bernoulli(seed, (shot0+b)*n + j)
-__global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
+LDPC_IO_KERNEL void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
                                          const int32_t *__restrict__ col_idx, int m, int n,
                                          uint64_t seed, uint64_t threshold, int64_t shot0,
                                          int64_t batch, uint8_t *synd) {
@@ -166,7 +169,7 @@ __global__ void gen_bsc_syndromes_kernel(const int32_t *__restrict__ row_ptr,
     }
 }
 
-__global__ void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, int64_t shot0,
+LDPC_IO_KERNEL void gen_bsc_errors_kernel(int n, uint64_t seed, uint64_t threshold, int64_t shot0,
                                       int64_t batch, uint8_t *err) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < batch * n; t += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t idx = (uint64_t)shot0 * (uint64_t)n + (uint64_t)t;
@@ -187,7 +190,7 @@ __global__ void gather_rows_kernel(const T *__restrict__ src, const int32_t *__r
 // message state of listed syndromes, lane by lane, out of the 64-syndrome tiles of a first pass into dense tiles: syndrome
 // list[r] (tile list[r] / 64, lane list[r] % 64) becomes lane r % 64 of tile r / 64; src, dst: [tiles][nnz][64] doubles.
 // One wavefront per (destination tile, edge): 64 gathered 8-byte loads (the live lanes of a source row share sectors), one 512-byte store.
-__global__ void __launch_bounds__(256) gather_lane_state_kernel(const double *__restrict__ src, const int32_t *__restrict__ list, int64_t count_arg,
+LDPC_IO_KERNEL void __launch_bounds__(256) gather_lane_state_kernel(const double *__restrict__ src, const int32_t *__restrict__ list, int64_t count_arg,
                                                                 int nnz, int edges_per_wave, double *__restrict__ dst, const unsigned *count_dev = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t count = rows_of_launch(count_arg, count_dev);
@@ -213,7 +216,7 @@ __global__ void scatter_rows_kernel(const T *__restrict__ src, const int32_t *__
 
 // How many rows converged after exactly j iterations (bin j, j capped at 255) and how many did not converge (bin 0):
 // what the host needs to see whether a short first pass + a second pass over the rest would have been cheaper
-__global__ void __launch_bounds__(256) iteration_histogram_kernel(const int32_t *__restrict__ iters, const uint8_t *__restrict__ conv,
+LDPC_IO_KERNEL void __launch_bounds__(256) iteration_histogram_kernel(const int32_t *__restrict__ iters, const uint8_t *__restrict__ conv,
                                                                   int64_t batch, unsigned *__restrict__ hist) {
     __shared__ unsigned local[256];
     local[threadIdx.x] = 0;
@@ -224,5 +227,19 @@ __global__ void __launch_bounds__(256) iteration_histogram_kernel(const int32_t 
     }
     __syncthreads();
     if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], local[threadIdx.x]);
+}
+
+// Rows that need OSD are a few percent of a batch and scattered: list them first, then persistent wavefronts pull rows
+// from the list, so every resident wavefront has work (one wavefront per batch row would leave the chip almost empty).
+LDPC_IO_KERNEL void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restrict__ conv, int64_t batch, int32_t *list, unsigned *counters) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool need = b < batch && !conv[b];
+    const uint64_t mask = __ballot(need);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&counters[0], (unsigned)__builtin_popcountll(mask));
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (need) list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
 }
 

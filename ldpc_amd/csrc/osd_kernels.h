@@ -52,19 +52,7 @@ struct OsdArgs {
     unsigned *counters;    // [0] number of entries of `list`, [1] next entry to hand out (both zeroed before the collect)
 };
 
-// Rows that need OSD are a few percent of a batch and scattered: list them first, then persistent wavefronts pull rows
-// from the list, so every resident wavefront has work (one wavefront per batch row would leave the chip almost empty).
-__global__ void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restrict__ conv, int64_t batch, int32_t *list, unsigned *counters) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool need = b < batch && !conv[b];
-    const uint64_t mask = __ballot(need);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&counters[0], (unsigned)__builtin_popcountll(mask));
-    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (need) list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
-}
+// (osd_collect_kernel -- the list of rows BP left unconverged -- lives in io_kernels.h: the streamed and serial hosts use it too)
 
 // What became of every row that went through OSD: status[b] = 1 if the returned x satisfies H x = s, 2 if it does not.
 // The latter happens exactly when s lies outside the image of H (rank-deficient H with a syndrome that violates a

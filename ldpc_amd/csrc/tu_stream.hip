@@ -1,0 +1,47 @@
+// tu_stream.hip -- libldpc_hip.so, translation unit of the streamed kernels: bp_decode_kernel (persistent workgroup per 64-syndrome
+// tile, bp.hpp:192-325) and the chip-wide per-pass kernels bp_spread_*, with their host side (host_stream.h: decode_device, the
+// two-pass decode with lane compaction).  See bp_hip.hip for the design notes and the list of kernel headers.
+#include "bp_device_common.h"
+#include "bp_stream_kernel.h"
+#include "bp_spread_kernels.h"
+#include "io_kernels.h"
+
+#include "host_handle.h"
+
+typedef void (*bp_kernel_t)(const BpArgs);
+typedef void (*spread_kernel_t)(const SpreadArgs);
+
+template <int METHOD, int MATH>
+static void pick_spread_m(int max_row, int max_col, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
+    if (nt) {
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 1> : bp_spread_check_kernel<METHOD, MATH, 16, 1>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 1> : bp_spread_bit_kernel<METHOD, MATH, 8, 1>;
+    } else {
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 0> : bp_spread_check_kernel<METHOD, MATH, 16, 0>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 0> : bp_spread_bit_kernel<METHOD, MATH, 8, 0>;
+    }
+}
+
+struct KernelChoice {
+    bp_kernel_t fn;
+    int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
+    int ring_depth;
+    int max_waves = 16;   // wavefronts per workgroup the variant was compiled for (stream_max_waves)
+};
+
+template <int METHOD, int MATH>
+static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
+    // Register arrays are sized by the template bounds, so the common regular codes get exact fits:
+    // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
+    if (ring_depth == 2 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 2>, 3 * 1024, 2};
+    if (ring_depth >= 3 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 3>, 3 * 1024, 3};
+    if (ring_depth >= 2 && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
+    if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0, 0};
+    if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0, 0};
+    if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0, stream_max_waves(8, 0)};
+    if (max_row <= 8 && max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 8, 8, 0>, 0, 0, stream_max_waves(8, 0)};
+    if (max_col <= 8) return {bp_decode_kernel<METHOD, MATH, 16, 8, 0>, 0, 0, stream_max_waves(16, 0)};
+    return {bp_decode_kernel<METHOD, MATH, 16, 16, 0>, 0, 0, stream_max_waves(16, 0)};  // heavier nodes take the streaming path inside
+}
+
+#include "host_stream.h"

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Every kernel instantiation of libldpc_hip.so with its register budget, grouped by template, and the dispatch rule that selects it.
-    make -C ldpc_amd/csrc resource-usage > /tmp/ru.txt 2>&1 ; python tools/list_instantiations.py /tmp/ru.txt > profiles/r4_kernel_instantiations.txt
+    make -C ldpc_amd/csrc resource-usage > /tmp/ru.txt 2>&1 ; python tools/list_instantiations.py /tmp/ru.txt > profiles/r5_kernel_instantiations.txt
 (no GPU needed: hipcc's -Rpass-analysis=kernel-resource-usage remarks)"""
 import re
 import subprocess
 import sys
 
 RULES = {  # template -> who selects which instantiation
-    "bp_decode_kernel": "host_stream.h decode_device via pick_kernel(bp_hip.hip): <METHOD, MATH, DR, DC, RING> -- RING 2 (default) / 3 for exactly (6,3)- or (8,4)-regular H "
+    "bp_decode_kernel": "host_stream.h decode_device via pick_kernel(tu_stream.hip): <METHOD, MATH, DR, DC, RING> -- RING 2 (default) / 3 for exactly (6,3)- or (8,4)-regular H "
                         "(ldpc_hip_bp_set_ring picks the depth, 0 = register variant); else the smallest (DR, DC) of (4,3) (6,3) (8,4) (8,8) (16,8) (16,16) that "
                         "bounds the heaviest row / column (heavier nodes stream through memory inside the kernel)",
     "bp_spread_check_kernel": "host_stream.h pick_spread: <METHOD, MATH, DR in 4/6/8/16, NT> (NT: tiles in flight outgrow the MALL)",
