@@ -37,6 +37,13 @@ struct SerialArgs {
     // the same table for bp_serial_level_kernel: row r level-major in orders_lvl[r][0 .. n), orders_lvl_ptr[r][0] = its number of levels,
     // orders_lvl_ptr[r][1 + l] = where level l starts (stride n + 2)
     const int32_t *orders_lvl, *orders_lvl_ptr;
+    // bp_serial_stream_kernel (bp_serial_stream_kernel.h): one record per position of the level-major order; the table of initial edge
+    // values that stands in for the initial messages (or nullptr: they are written out); > 0: the message array holds the state after
+    // it_start iterations (lanes compacted out of the tiles of a first pass), iterations count on from there
+    const int32_t *pos_tab;
+    const double *edge0;
+    int32_t it_start;
+    unsigned long long *clk;  // shader-clock probe (clock_probe_*), or nullptr
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the

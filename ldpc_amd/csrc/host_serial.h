@@ -37,7 +37,70 @@ static int ensure_serial_levels(ldpc_hip_bp *h) {
     if (n) HIPCHK(hipMemcpy(h->lvl_bits.p, bits.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
     h->n_levels = n_levels;
     h->levels_valid = true;
+    h->h_lvl_ptr = std::move(ptr);
+    h->h_lvl_bits = std::move(bits);
+    h->ser_pos_valid = false;
     return LDPC_HIP_OK;
+}
+
+// bp_serial_stream_kernel: which form (if any) takes the fixed-order serial schedule of this matrix.  Single row weight, single column
+// weight (the records and the ring slots are sized by them), levels wide enough to keep a workgroup's wavefronts busy.
+struct SerialStreamPlan {
+    int dr = 0, dc = 0;  // 0: not applicable
+};
+static SerialStreamPlan plan_serial_stream(const ldpc_hip_bp *h) {
+    SerialStreamPlan p;
+    if (!h->regular || h->m <= 0 || h->n <= 0 || h->nnz >= (1 << 22) || h->n_levels <= 0) return p;
+    if (!(h->max_row_deg == 6 && h->max_col_deg == 3)) return p;
+    if (h->serial_kernel != 2 && (double)h->n / (double)h->n_levels < 32.0) return p;  // (narrow levels: the wavefronts would idle at the barriers)
+    p.dr = h->max_row_deg;
+    p.dc = h->max_col_deg;
+    return p;
+}
+
+// the records of the positions (layout: bp_serial_stream_kernel.h), from the host copies of the levels
+static int ensure_serial_stream_table(ldpc_hip_bp *h, const SerialStreamPlan &sp) {
+    if (h->ser_pos_valid) return LDPC_HIP_OK;
+    const int n = h->n, dr = sp.dr, dc = sp.dc;
+    const int no = dc * (dr - 1), no_pad = serial_stream_no_pad(dr, dc), rec = serial_stream_rec(dr, dc);
+    std::vector<int32_t> tab((size_t)n * (size_t)rec, 0);
+    std::vector<int32_t> col_fill((size_t)n, 0), col_edges((size_t)n * (size_t)dc, 0);
+    for (int e = 0; e < h->nnz; ++e) {  // (CSR order: a column's edges come out rows ascending, the order of its linked list)
+        const int j = h->h_col_idx[(size_t)e];
+        col_edges[(size_t)j * dc + col_fill[(size_t)j]++] = e;
+    }
+    std::vector<char> written((size_t)h->nnz, 0);
+    for (int p = 0; p < n; ++p) {
+        const int j = h->h_lvl_bits[(size_t)p];
+        int32_t *r = tab.data() + (size_t)p * rec;
+        int t = 0;
+        uint32_t mask = 0;
+        for (int k = 0; k < dc; ++k) {
+            const int e = col_edges[(size_t)j * dc + k], rs = e / dr * dr;
+            for (int q = 0; q < dr; ++q)
+                if (rs + q != e) {
+                    if (written[(size_t)(rs + q)]) mask |= 1u << t;
+                    r[t++] = rs + q;
+                }
+            r[no_pad + k] = e;
+        }
+        (void)no;
+        r[no_pad + dc] = j;
+        r[no_pad + dc + 1] = (int32_t)mask;
+        // (positions of one level share no row, so marking at once is marking at the end of the level)
+        for (int k = 0; k < dc; ++k) written[(size_t)col_edges[(size_t)j * dc + k]] = 1;
+    }
+    int rc;
+    if ((rc = h->ser_pos_tab.ensure(tab.size() * sizeof(int32_t)))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->ser_pos_tab.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->ser_pos_valid = true;
+    return LDPC_HIP_OK;
+}
+
+template <int METHOD, int MATH>
+static void (*pick_serial_stream(int ring))(const SerialArgs) {
+    return ring >= 2 ? bp_serial_stream_kernel<METHOD, MATH, 6, 3, 2> : bp_serial_stream_kernel<METHOD, MATH, 6, 3, 1>;
 }
 
 template <int METHOD, int MATH>
@@ -54,8 +117,10 @@ static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
     return bp_serial_kernel<METHOD, MATH, 4, 8>;  // also the variant that streams heavier nodes (SerialArgs::fast == 0)
 }
 
+// it_start > 0 (the streamed kernel only): the message state after it_start iterations already sits in the handle's SECOND message array
+// (lanes compacted out of the tiles of a first pass, decode_serial) and the pass carries on from there.
 static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0, int orders_first = 0) {
+                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0, int orders_first = 0, int it_start = 0) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
@@ -74,7 +139,8 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         if (chunk > fit) chunk = fit;
     }
     int rc;
-    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if (it_start > 0 && chunk < tiles_total) return fail(LDPC_HIP_ERR_NOMEM, "internal: the second pass of a compacted serial decode must be one chunk");
+    if (it_start == 0 && (rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
     if ((rc = h->msgC.ensure(fast ? 16 : per_tile_msg * (size_t)chunk))) return rc;
     if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
     if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
@@ -103,7 +169,24 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
             if (level_waves < 1) level_waves = 1;
         }
     }
-    if (level_waves) {
+    // the streamed form (bp_serial_stream_kernel.h) where the matrix and the schedule allow it: automatic, or asked for (mode 2)
+    SerialStreamPlan sp;
+    int ser_ring = 1, ser_waves = 16;
+    if (level_waves && !orders && (h->serial_kernel == -1 || h->serial_kernel == 2)) sp = plan_serial_stream(h);
+    if (it_start > 0 && !sp.dr) return fail(LDPC_HIP_ERR_INVALID, "internal: only the streamed serial kernel carries a first pass on");
+    h->ser_streamed = sp.dr != 0;
+    h->ser_chunk_tiles = chunk;
+    if (sp.dr) {
+        if ((rc = ensure_serial_stream_table(h, sp))) return rc;
+        if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
+        if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
+        const int slot = serial_stream_slot_bytes(sp.dr, sp.dc);
+        while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot) > 150u * 1024u) --ser_waves;
+        if (ser_waves > 16) ser_waves = 16;
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 1>(ser_ring);
+        else kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 0>(ser_ring);
+    } else if (level_waves) {
         if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_level<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg);
         else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg);
         else kern = pick_serial_level<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg);
@@ -152,6 +235,23 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
         a.orders = orders; a.n_orders = n_orders; a.orders_first = orders_first;
         if (orders && level_waves) { a.orders_lvl = (const int32_t *)h->sched_lvl_bits.p; a.orders_lvl_ptr = (const int32_t *)h->sched_lvl_ptr.p; }
+        if (sp.dr) {
+            a.pos_tab = (const int32_t *)h->ser_pos_tab.p;
+            a.clk = h->d_clk;
+            a.it_start = it_start;
+            if (it_start > 0) a.A = (double *)h->msgC.p;
+            if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads this table instead of initial messages
+                if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
+                const dim3 ge((unsigned)((h->n + 255) / 256));
+                if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                else hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+                a.edge0 = (const double *)h->d_edge0.p;
+            }
+            const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * serial_stream_slot_bytes(sp.dr, sp.dc));
+            if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
+        } else
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * (level_waves ? level_waves : 1))), 0, st, a);
         HIPCHK(hipEventRecord(h->ev1, st));
         h->timed = true;
@@ -535,18 +635,43 @@ static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
 }
 
 int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                         int32_t *iters, uint8_t *conv) {
+                  int32_t *iters, uint8_t *conv) {
     if (h->random_serial) return decode_serial_random(h, synd, batch, decoding, llr, iters, conv);  // (takes precedence, bp.hpp:467-469)
     if (h->schedule == 2) return decode_serial_relative(h, synd, batch, decoding, llr, iters, conv);
-    int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
-    if (h->repack_iters < 0 && k1 < 2) k1 = 2;
-    if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
-        return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
     const size_t B = (size_t)batch, m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
     int rc;
-    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    // Will the streamed kernel (bp_serial_stream_kernel.h) take this schedule?  Then a second pass CARRIES ON from the first one's message
+    // state (the unconverged lanes compacted into dense tiles) instead of starting again, and where to cut is priced with the iteration
+    // histogram the previous decode on this handle left behind (stream_first_pass_length; no histogram yet, or none that pays: one pass).
+    bool streamed = false;
+    if ((h->serial_kernel == -1 || h->serial_kernel == 2) && h->n > 0 && h->m > 0) {
+        if ((rc = ensure_serial_levels(h))) return rc;
+        streamed = plan_serial_stream(h).dr != 0;
+    }
+    int k1;
+    if (streamed) {
+        if (h->repack_iters >= 0) k1 = h->repack_iters;
+        else {
+            double live = 0.5;
+            k1 = batch >= 64 * LDPC_WAVE ? stream_first_pass_length(h, &live, 1.0 / 6.0) : 0;
+        }
+        if (k1 >= h->max_iter) k1 = 0;
+        if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+        if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+        if (k1 <= 0) {
+            if ((rc = decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv))) return rc;
+            return stream_leave_histogram(h, iters, conv, batch);
+        }
+    } else {
+        k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
+        if (h->repack_iters < 0 && k1 < 2) k1 = 2;
+        if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
+            return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
+        if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    }
     if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
     if ((rc = decode_serial_pass(h, k1, synd, batch, decoding, llr, iters, conv))) return rc;
+    const bool carry_on = streamed && h->ser_streamed && h->ser_chunk_tiles >= (int64_t)((batch + LDPC_WAVE - 1) / LDPC_WAVE);  // (the whole batch's state is resident)
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
     if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
     HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
@@ -555,7 +680,7 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
     const int64_t cnt = (int64_t)h->h_counters[2];
-    if (cnt == 0) return LDPC_HIP_OK;
+    if (cnt == 0) return streamed ? stream_leave_histogram(h, iters, conv, batch) : LDPC_HIP_OK;
     float ms1 = 0.f;
     (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
     const size_t C = (size_t)cnt;
@@ -566,8 +691,19 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if (h->m > 0)
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * h->m), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
     HIPCHK(hipGetLastError());
+    int it_start = 0;
+    if (carry_on) {
+        // the listed rows' message state after the first pass, lane by lane, into dense tiles of the second message array
+        const int64_t tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
+        if ((rc = h->msgC.ensure(sizeof(double) * (size_t)h->nnz * LDPC_WAVE * (size_t)tiles2))) return rc;
+        const int epw = 16;
+        const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)(tiles2 < 32768 ? tiles2 : 32768));
+        hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, h->stream, (const double *)h->msgA.p, list, cnt, h->nnz, epw, (double *)h->msgC.p, (const unsigned *)nullptr);
+        HIPCHK(hipGetLastError());
+        it_start = k1;
+    }
     if ((rc = decode_serial_pass(h, h->max_iter, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p,
-                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
+                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, nullptr, 0, 0, it_start))) return rc;
     h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
     if (h->n > 0) {
         hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * h->n), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
@@ -576,7 +712,7 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if (iters) hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
     hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
     HIPCHK(hipGetLastError());
-    return LDPC_HIP_OK;
+    return streamed ? stream_leave_histogram(h, iters, conv, batch) : LDPC_HIP_OK;
 }
 
 // soft_info_decode_serial over a batch (bp_softinfo_kernel).  Device pointers, on h->stream.

@@ -262,7 +262,7 @@ int ldpc_hip_bp_get_schedule_order(ldpc_hip_bp *h, int32_t *order) {
 
 int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode) {
     if (!h) return fail(LDPC_HIP_ERR_INVALID, "null handle");
-    if (mode < -1 || mode > 1) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic), 0 (one wavefront per tile) or 1 (level-parallel)");
+    if (mode < -1 || mode > 2) return fail(LDPC_HIP_ERR_INVALID, "mode must be -1 (automatic), 0 (one wavefront per tile), 1 (level-parallel) or 2 (level-parallel, streamed through LDS rings where the matrix allows it)");
     h->serial_kernel = mode;
     return LDPC_HIP_OK;
 }

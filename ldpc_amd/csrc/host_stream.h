@@ -262,10 +262,10 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
 // alternatives with it, in tile-iterations per tile of the batch: F(j) = fraction converged within j iterations,
 //     plain        sum_j (1 - F(j-1)^64)
 //     cut at k     sum_{j<=k} (1 - F(j-1)^64)  +  gather  +  (1 - F(k)) sum_{j>k} (1 - G_k(j-1)^64),  G_k = F conditioned on > k,
-// gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) / 4 of an iteration (an
-// iteration moves four arrays), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
+// gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) * gather_cost of an iteration (the
+// flooding schedule moves four arrays per iteration: 1/4; the serial schedule six segments per edge: 1/6), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
 // converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
-static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after) {
+int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost) {
     *live_after = 0.5;
     if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
     // The previous decode's histogram, IF its copy has landed -- a look, never a wait (the *_async entry points must not block): a
@@ -306,13 +306,13 @@ static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after) {
             rest += r;
             if (r < 1e-9 && j > top) break;
         }
-        const double cost = prefix + 0.25 * (1.0 + live) + 0.1 + live * rest;
+        const double cost = prefix + gather_cost * (1.0 + live) + 0.1 + live * rest;
         if (cost < best) { best = cost; best_k = k; *live_after = live; }
     }
     return best < 0.97 * plain ? best_k : 0;
 }
 
-static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
+int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
     int rc;
     if ((rc = h->sp_hist.ensure(256 * sizeof(unsigned)))) return rc;
     if (!h->h_hist) HIPCHK(hipHostMalloc((void **)&h->h_hist, 256 * sizeof(unsigned), hipHostMallocDefault));
@@ -348,7 +348,7 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
     double live = 0.5;
-    int k1 = stream_first_pass_length(h, &live);
+    int k1 = stream_first_pass_length(h, &live, 0.25);
     const int64_t tiles1 = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     if (k1 >= 2 && k1 < full) {
         // the compaction needs the whole batch's message state resident (one chunk); else decode plainly

@@ -2,6 +2,7 @@
 // and of soft-syndrome decoding (bp.hpp:547-660), with their host side (host_serial.h).
 #include "bp_device_common.h"
 #include "bp_serial_kernels.h"
+#include "bp_serial_stream_kernel.h"
 #include "bp_relative_kernel.h"
 #include "bp_relative_lds_kernel.h"
 #include "io_kernels.h"

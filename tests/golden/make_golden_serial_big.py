@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Golden fixtures of the serial schedule (bp.hpp:451-545) on the BASELINE.json configs[1] code and a mid-size sibling, through the
+REAL reference (oracle/_ref/libref_bp.so).  Run in the build container only:
+
+    make -C oracle ref && python tests/golden/make_golden_serial_big.py
+
+Data only: the matrix as a generator recipe (+ checksum) or CSR arrays, the syndromes, the reference's outputs.  The big code's rows
+carry two full log-ratio vectors and the row sums of all of them (80 KB per vector).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import RefBp, csr_arrays, have_ref  # noqa: E402
+from ldpc_amd import codes  # noqa: E402
+from ldpc_amd.prng import sm64  # noqa: E402
+from make_golden import bsc_syndromes, h_crc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(name, h, syndromes, *, error_rate, max_iter, bp_method, alpha=1.0, order=None, recipe="", full_llr=2, note=""):
+    h = sp.csr_matrix(h, dtype=np.uint8)
+    m, n, rp, ci = csr_arrays(h)
+    ref = RefBp(h, error_rate=error_rate, max_iter=max_iter, bp_method=bp_method, ms_scaling_factor=alpha, schedule="serial")
+    if order is not None:
+        ref.set_serial_order(order)
+    syndromes = np.ascontiguousarray(syndromes, np.uint8).reshape(-1, m)
+    dec, llr, it, conv = ref.decode_batch(syndromes)
+    extra = dict(recipe=recipe) if recipe else dict(row_ptr=rp, col_idx=ci, recipe="")
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, name=name, note=note, m=m, n=n, h_crc=np.uint32(h_crc(h)), channel_probs=ref.channel_probs,
+                        max_iter=np.int32(ref.max_iter), bp_method=np.int32(0 if bp_method == "product_sum" else 1),
+                        ms_scaling_factor=np.float64(alpha),
+                        syndromes=np.packbits(syndromes, axis=1) if syndromes.max(initial=0) <= 1 else syndromes,
+                        syndromes_packed=np.bool_(syndromes.max(initial=0) <= 1),
+                        decoding=np.packbits(dec, axis=1), converge=conv, iterations=it, llr=llr[:full_llr],
+                        llr_rowsum=np.sum(np.where(np.abs(llr) < 1e100, llr, 0.0), axis=1),
+                        order=np.asarray(order if order is not None else [], np.int32), **extra)
+    print(f"{name:40s} k={len(syndromes):4d} conv={conv.mean():.3f} iters={it.mean():6.2f} hist={np.bincount(it).tolist()} "
+          f"{os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def main():
+    if not have_ref():
+        sys.exit("oracle/_ref/libref_bp.so missing: make -C oracle ref")
+    h = codes.regular_ldpc_code(10_000, 3, 6, seed=1)
+    rec = "regular_ldpc_code(10000,3,6,seed=1)"
+    # configs[1]'s code and error stream (seed 7) at its early-exit point: a tile and a half, so lanes stop at different iterations
+    run("serial_ldpc36_n10000_ps50_p050", h, bsc_syndromes(h, 7, 0.05, 0, 96), error_rate=0.05, max_iter=50, bp_method="product_sum",
+        recipe=rec, note="BASELINE.json configs[1] shape, schedule = serial; error seed 7, shots 0..95")
+    perm = (sm64(29, np.arange(10_000, dtype=np.uint64)) % np.uint64(1 << 40)).argsort().astype(np.int32)
+    run("serial_ldpc36_n10000_ms50_p050_order", h, bsc_syndromes(h, 7, 0.05, 96, 70), error_rate=0.05, max_iter=50,
+        bp_method="minimum_sum", alpha=0.75, order=perm, recipe=rec, note="a caller's serial_schedule_order (a permutation); shots 96..165")
+    # above the threshold: nothing converges, every row runs all its iterations (adaptive min-sum scaling: alpha depends on the iteration)
+    run("serial_ldpc36_n10000_ms12_p090_adaptive", h, bsc_syndromes(h, 7, 0.09, 0, 66), error_rate=0.09, max_iter=12,
+        bp_method="minimum_sum", alpha=0.0, recipe=rec)
+    # mid-size sibling around the threshold: converging and hopeless rows in the same tile, some syndrome bytes > 1
+    h2 = codes.regular_ldpc_code(2400, 3, 6, seed=5)
+    s2 = bsc_syndromes(h2, 13, 0.078, 0, 200)
+    s2[::37, 3] = 2
+    run("serial_ldpc36_n2400_ps40_p078_bytes", h2, s2, error_rate=0.078, max_iter=40, bp_method="product_sum", full_llr=8,
+        note="syndrome bytes > 1 in some rows: pow(-1, byte) sign, never converges (bp.hpp:499, 540)")
+
+
+if __name__ == "__main__":
+    main()

@@ -658,7 +658,7 @@ def test_serial_schedule_golden_fixture(name):
     c = load_case(name)
     eng = _engine(c)
     eng.set_schedule("serial", c.get("order"))
-    for serial_kernel in (-1, 0, 1):  # automatic, bit by bit, level-parallel
+    for serial_kernel in (-1, 0, 1, 2):  # automatic, bit by bit, level-parallel, streamed (where the matrix allows it)
         eng.set_serial_kernel(serial_kernel)
         dec, llr, it, cv = eng.decode_batch(c["syndromes"])
         assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])

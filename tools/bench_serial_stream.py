@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Serial schedule on the BASELINE configs[1] code ((3,6)-regular n = 10 000, product-sum, 50 iterations, p = 0.05, B = 65 536): the
+level-parallel kernel against the forms of the streamed one (bp_serial_stream_kernel.h).  One JSON line per form:
+
+    python tools/bench_serial_stream.py [--batch 65536] [--p 0.05] [--forms all|default]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--p", type=float, default=0.05)
+    ap.add_argument("--method", type=int, default=0)
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--forms", default="all")
+    args = ap.parse_args()
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    m, n = h.shape
+    forms = [  # (label, serial_kernel, repack, switches, want_llr)
+        ("level kernel (round 1-4)", 1, -1, (), True),
+        ("streamed, one pass, 16 waves ring 1", 2, 0, (), True),
+        ("streamed, auto passes, 16 waves ring 1", 2, -1, (), True),
+        ("streamed, auto passes, 16 waves ring 1, no log-ratios", 2, -1, (), False),
+        ("streamed, auto, 8 waves ring 1", 2, -1, (("SER_WAVES", 8),), True),
+        ("streamed, auto, 8 waves ring 2", 2, -1, (("SER_WAVES", 8), ("SER_RING", 2)), True),
+        ("streamed, auto, 9 waves ring 1", 2, -1, (("SER_WAVES", 9),), True),
+        ("streamed, auto, 12 waves ring 1", 2, -1, (("SER_WAVES", 12),), True),
+        ("streamed, auto, 6 waves ring 1", 2, -1, (("SER_WAVES", 6),), True),
+        ("streamed, auto, 16 waves, initial messages written out", 2, -1, (("EXPLICIT_INIT", 1),), True),
+        ("streamed, cut at 3", 2, 3, (), True),
+        ("streamed, cut at 4", 2, 4, (), True),
+        ("streamed, cut at 5", 2, 5, (), True),
+    ]
+    if args.forms == "default":
+        forms = forms[:1] + forms[2:4]
+    ref = None
+    for label, mode, repack, switches, want_llr in forms:
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), 50, args.method, args.alpha)
+        eng.set_schedule("serial")
+        eng.set_serial_kernel(mode)
+        eng.set_repack(repack)
+        for k, v in switches:
+            eng.set_debug_switch(k, v)
+        s = eng.gen_bsc_syndromes(7, args.p, shot0=0, shots=args.batch, device="cuda:0")
+        out = eng.decode_batch(s, want_llr=want_llr)  # warm-up (and the histogram that steers the next call)
+        out = eng.decode_batch(s, want_llr=want_llr, out=out)
+        torch.cuda.synchronize()
+        c0 = eng.clock_probe()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.decode_batch(s, want_llr=want_llr, out=out)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        c1 = eng.clock_probe()
+        it = out[2].cpu().numpy()
+        cv = out[3].cpu().numpy().astype(bool)
+        dec = out[0].cpu().numpy()
+        if ref is None:
+            ref = (dec, it, cv)
+        same = bool(np.array_equal(dec, ref[0]) and np.array_equal(it, ref[1]) and np.array_equal(cv, ref[2]))
+        alg = float(np.sum(it.astype(np.float64) * 4.0 * h.nnz * 8.0 + (m + n + 8.0 * n + 5.0)))
+        moved = float(np.sum(it.astype(np.float64) * 6.0 * h.nnz * 8.0))  # what the schedule itself moves: 18 segments per bit and iteration
+        print(json.dumps({"form": label, "batch": args.batch, "p": args.p, "syndromes_per_s": round(args.batch / ms * 1e3), "ms_per_decode": round(ms, 2),
+                          "kernel_ms": round(eng.last_kernel_ms(), 2), "mean_iterations": round(float(it.mean()), 3), "converged": round(float(cv.mean()), 5),
+                          "hbm_frac_4E_bytes": round(alg / (ms * 1e-3) / 8e12, 4), "hbm_frac_serial_bytes_per_lane_iteration": round(moved / (ms * 1e-3) / 8e12, 4),
+                          "clock_ghz": round(HipBpEngine.clock_ghz(c0, c1) or 0.0, 3), "same_as_first_form": same}), flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()
