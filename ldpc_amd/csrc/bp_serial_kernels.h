@@ -42,7 +42,9 @@ struct SerialArgs {
     // it_start iterations (lanes compacted out of the tiles of a first pass), iterations count on from there
     const int32_t *pos_tab;
     const double *edge0;
+    const double *pos_e0;  // [positions][16] initial values of the other entries of every position (with edge0)
     int32_t it_start;
+    int32_t resume;  // 1: the same tiles carry on after a pass that stopped at it_start -- lanes whose `conv` says so are done (their `iters` kept), dec / llr_t are the pass's
     unsigned long long *clk;  // shader-clock probe (clock_probe_*), or nullptr
 };
 

@@ -57,7 +57,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -91,8 +91,6 @@ struct ldpc_hip_bp {
     const unsigned *cont_rows_dev = nullptr;      // {rows, tiles} on the device (BpArgs::rows_dev)
     int64_t cont_grid_tiles = 0;                  // grid.y of its tile-looping kernels (an estimate; they loop)
     bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
-    int64_t ser_chunk_tiles = 0;   // tiles per chunk of the last serial pass, and whether bp_serial_stream_kernel ran it
-    bool ser_streamed = false;
     int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
     DeviceBuf e_partner, e_kind, e_scol, e_prior;
@@ -182,6 +180,8 @@ struct ldpc_hip_bp {
     int32_t n_levels = 0;
     DeviceBuf lvl_ptr, lvl_bits;
     std::vector<int32_t> h_lvl_ptr, h_lvl_bits;                     // host copies (the streamed serial kernel's position records are built from them)
+    DeviceBuf ser_pos_e0;                                            // ... and the initial values of every position's other entries (first iteration)
+    DeviceBuf ser_rows[2], ser_synd2;                                // decode_serial_streamed: the rows of a compacted pass (numbers in the caller's arrays), their syndromes
     DeviceBuf ser_pos_tab;                                           // bp_serial_stream_kernel: one record per position of the level-major order
     bool ser_pos_valid = false;                                     // ... describing the current levels
     // repacking of the streamed parallel schedule (decode_stream_repacked), steered by what the previous decode looked like
@@ -253,10 +253,6 @@ static bool is_device_ptr(const void *p) {
 // tu_stream.hip: the dispatch of a batch to a kernel family, and the streamed kernels themselves
 int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv,
                   bool may_repack = true);
-// ... and the steering of the two-pass decodes (host_stream.h): the length of the first pass priced with the iteration histogram the previous
-// decode on the handle left behind (0: run plain), and leaving that histogram
-int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost);
-int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch);
 // tu_onchip.hip: the kernels that keep a syndrome's messages on chip; *took = false: no such kernel applies to this matrix
 int decode_onchip(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv, bool *took);
 // tu_serial.hip: serial / serial_relative / random serial schedules, soft-syndrome decoding

@@ -62,7 +62,7 @@ static SerialStreamPlan plan_serial_stream(const ldpc_hip_bp *h) {
 static int ensure_serial_stream_table(ldpc_hip_bp *h, const SerialStreamPlan &sp) {
     if (h->ser_pos_valid) return LDPC_HIP_OK;
     const int n = h->n, dr = sp.dr, dc = sp.dc;
-    const int no = dc * (dr - 1), no_pad = serial_stream_no_pad(dr, dc), rec = serial_stream_rec(dr, dc);
+    const int rec = SERIAL_STREAM_REC;
     std::vector<int32_t> tab((size_t)n * (size_t)rec, 0);
     std::vector<int32_t> col_fill((size_t)n, 0), col_edges((size_t)n * (size_t)dc, 0);
     for (int e = 0; e < h->nnz; ++e) {  // (CSR order: a column's edges come out rows ascending, the order of its linked list)
@@ -82,11 +82,11 @@ static int ensure_serial_stream_table(ldpc_hip_bp *h, const SerialStreamPlan &sp
                     if (written[(size_t)(rs + q)]) mask |= 1u << t;
                     r[t++] = rs + q;
                 }
-            r[no_pad + k] = e;
+            r[16 + k] = e;
         }
-        (void)no;
-        r[no_pad + dc] = j;
-        r[no_pad + dc + 1] = (int32_t)mask;
+        r[15] = (int32_t)mask;
+        r[16 + dc] = j;
+        r[16 + dc + 1] = (int32_t)mask;
         // (positions of one level share no row, so marking at once is marking at the end of the level)
         for (int k = 0; k < dc; ++k) written[(size_t)col_edges[(size_t)j * dc + k]] = 1;
     }
@@ -117,10 +117,8 @@ static void (*pick_serial(int max_row, int max_col))(const SerialArgs) {
     return bp_serial_kernel<METHOD, MATH, 4, 8>;  // also the variant that streams heavier nodes (SerialArgs::fast == 0)
 }
 
-// it_start > 0 (the streamed kernel only): the message state after it_start iterations already sits in the handle's SECOND message array
-// (lanes compacted out of the tiles of a first pass, decode_serial) and the pass carries on from there.
 static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
-                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0, int orders_first = 0, int it_start = 0) {
+                              int32_t *iters, uint8_t *conv, const int32_t *orders = nullptr, int n_orders = 0, int orders_first = 0) {
     const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
     const size_t per_tile_msg = sizeof(double) * (size_t)(h->nnz ? h->nnz : 1) * LDPC_WAVE;
     const size_t per_tile_llr = llr ? sizeof(double) * (size_t)(h->n ? h->n : 1) * LDPC_WAVE : 0;
@@ -139,8 +137,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         if (chunk > fit) chunk = fit;
     }
     int rc;
-    if (it_start > 0 && chunk < tiles_total) return fail(LDPC_HIP_ERR_NOMEM, "internal: the second pass of a compacted serial decode must be one chunk");
-    if (it_start == 0 && (rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)chunk))) return rc;
     if ((rc = h->msgC.ensure(fast ? 16 : per_tile_msg * (size_t)chunk))) return rc;
     if ((rc = h->par.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
     if ((rc = h->nzm.ensure(sizeof(uint64_t) * (size_t)(h->m ? h->m : 1) * (size_t)chunk))) return rc;
@@ -169,13 +166,11 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
             if (level_waves < 1) level_waves = 1;
         }
     }
-    // the streamed form (bp_serial_stream_kernel.h) where the matrix and the schedule allow it: automatic, or asked for (mode 2)
+    // the streamed form (bp_serial_stream_kernel.h) where the matrix and the schedule allow it: automatic, or asked for (mode 2).  (Here: batches
+    // whose state is not resident at once, chunk by chunk, one pass each; resident batches go through decode_serial_streamed.)
     SerialStreamPlan sp;
     int ser_ring = 1, ser_waves = 16;
     if (level_waves && !orders && (h->serial_kernel == -1 || h->serial_kernel == 2)) sp = plan_serial_stream(h);
-    if (it_start > 0 && !sp.dr) return fail(LDPC_HIP_ERR_INVALID, "internal: only the streamed serial kernel carries a first pass on");
-    h->ser_streamed = sp.dr != 0;
-    h->ser_chunk_tiles = chunk;
     if (sp.dr) {
         if ((rc = ensure_serial_stream_table(h, sp))) return rc;
         if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
@@ -238,15 +233,17 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         if (sp.dr) {
             a.pos_tab = (const int32_t *)h->ser_pos_tab.p;
             a.clk = h->d_clk;
-            a.it_start = it_start;
-            if (it_start > 0) a.A = (double *)h->msgC.p;
-            if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads this table instead of initial messages
+            if (h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads this table instead of initial messages
                 if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
                 const dim3 ge((unsigned)((h->n + 255) / 256));
                 if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
                 else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
                 else hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
                 a.edge0 = (const double *)h->d_edge0.p;
+                if ((rc = h->ser_pos_e0.ensure(sizeof(double) * 16 * (size_t)h->n))) return rc;
+                hipLaunchKernelGGL(serial_pos_e0_kernel, dim3((unsigned)((h->n * 16 + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ser_pos_tab.p, h->d_col_idx,
+                                   (const double *)h->d_edge0.p, h->n, sp.dc * (sp.dr - 1), (double *)h->ser_pos_e0.p);
+                a.pos_e0 = (const double *)h->ser_pos_e0.p;
             }
             const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * serial_stream_slot_bytes(sp.dr, sp.dc));
             if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -634,44 +631,266 @@ static int decode_serial_relative(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     return LDPC_HIP_OK;
 }
 
+// ---- the streamed serial schedule (bp_serial_stream_kernel.h) over a batch whose message state is resident ----------------------------
+// One launch of bp_serial_stream_kernel: iterations it_start + 1 .. it_end over `rows` rows whose state is (it_start > 0) or will be in
+// `state`.  resume: the same tiles as the launch before (their packed syndromes, frozen decisions and posteriors are still in the
+// workspace; lanes it finished stay finished).
+// row_map (or nullptr): row r of the launch is row row_map[r] of `decoding` / `llr`; `iters` / `conv` are indexed by the launch's own rows.
+static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int it_start, int it_end, bool resume, double *state, const uint8_t *synd,
+                                int64_t rows, const int32_t *row_map, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv, int waves_cap = 16) {
+    const int64_t tiles = (rows + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t m1 = (size_t)h->m, n1 = (size_t)h->n;
+    hipStream_t st = h->stream;
+    int rc;
+    if ((rc = h->par.ensure(sizeof(uint64_t) * m1 * (size_t)tiles)) || (rc = h->nzm.ensure(sizeof(uint64_t) * m1 * (size_t)tiles)) ||
+        (rc = h->invalid.ensure(sizeof(uint64_t) * (size_t)tiles)) || (rc = h->dec.ensure(sizeof(uint64_t) * n1 * (size_t)tiles)) ||
+        (rc = h->dcur.ensure(sizeof(uint64_t) * n1 * (size_t)tiles)) || (llr && (rc = h->llr_t.ensure(sizeof(double) * n1 * LDPC_WAVE * (size_t)tiles)))) return rc;
+    if (!resume) {
+        HIPCHK(hipMemsetAsync(h->invalid.p, 0, sizeof(uint64_t) * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dec.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        HIPCHK(hipMemsetAsync(h->dcur.p, 0, sizeof(uint64_t) * n1 * (size_t)tiles, st));
+        if (llr && !h->order_visits_all) HIPCHK(hipMemsetAsync(h->llr_t.p, 0, sizeof(double) * n1 * LDPC_WAVE * (size_t)tiles, st));  // bits the order never visits report 0
+        dim3 g((unsigned)((h->m + 255) / 256), (unsigned)(tiles < 32768 ? tiles : 32768));
+        hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd, rows, h->m, (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p,
+                           (const int32_t *)nullptr, (const unsigned *)nullptr);
+    }
+    int ser_ring = 1, ser_waves = 16;
+    if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
+    if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
+    if (ser_waves > waves_cap) ser_waves = waves_cap;
+    const int slot = serial_stream_slot_bytes(sp.dr, sp.dc);
+    while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot) > 150u * 1024u) --ser_waves;
+    if (ser_waves > 16) ser_waves = 16;
+    void (*kern)(const SerialArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 1>(ser_ring);
+    else kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 0>(ser_ring);
+    SerialArgs a = {};
+    a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = it_end; a.fast = 1;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.batch = rows;
+    a.row_ptr = h->d_row_ptr; a.col_idx = h->d_col_idx; a.col_ptr = h->d_col_ptr; a.csc_edge = h->d_csc_edge; a.csc_row = h->d_csc_row;
+    a.llr0 = h->d_llr0;
+    a.A = state;
+    a.par = (const uint64_t *)h->par.p; a.invalid = (const uint64_t *)h->invalid.p;
+    a.dec = (uint64_t *)h->dec.p; a.dcur = (uint64_t *)h->dcur.p;
+    a.llr_t = llr ? (double *)h->llr_t.p : nullptr;
+    a.iters = iters; a.conv = conv;
+    a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
+    a.pos_tab = (const int32_t *)h->ser_pos_tab.p;
+    a.clk = h->d_clk;
+    a.it_start = it_start;
+    a.resume = resume ? 1 : 0;
+    if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads these tables instead of initial messages
+        a.edge0 = (const double *)h->d_edge0.p;
+        a.pos_e0 = (const double *)h->ser_pos_e0.p;
+    }
+    const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * slot);
+    if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
+    HIPCHK(hipGetLastError());
+    {   // (these kernels loop over the tiles beyond their grid)
+        const unsigned gy = (unsigned)(tiles < 32768 ? tiles : 32768);
+        hipLaunchKernelGGL(unpack_decoding_kernel, dim3((unsigned)((h->n + 255) / 256), gy), dim3(256), 0, st, (const uint64_t *)h->dec.p, rows, h->n, decoding, row_map,
+                           (const unsigned *)nullptr);
+        if (llr)
+            hipLaunchKernelGGL(transpose_llr_kernel, dim3((unsigned)((h->n + LDPC_WAVE - 1) / LDPC_WAVE), gy), dim3(256), 0, st, (const double *)h->llr_t.p, rows, h->n, llr, row_map,
+                               (const unsigned *)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// A handful of rows on bp_serial_lane_kernel (one workgroup per syndrome): iterations it_start + 1 .. max_iter; `state_rows`: [rows][nnz]
+static int serial_lane_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int it_start, double *state_rows, const uint8_t *synd, int64_t rows,
+                              uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
+    SerialLaneArgs a = {};
+    a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.it_start = it_start; a.n_levels = h->n_levels;
+    a.ms_scaling_factor = h->ms_scaling_factor;
+    a.rows = rows;
+    a.col_idx = h->d_col_idx; a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.pos_tab = (const int32_t *)h->ser_pos_tab.p;
+    a.llr0 = h->d_llr0;
+    a.A = state_rows; a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    void (*kern)(const SerialLaneArgs);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = bp_serial_lane_kernel<LDPC_HIP_MINIMUM_SUM, 0, 6, 3>;
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = bp_serial_lane_kernel<LDPC_HIP_PRODUCT_SUM, 1, 6, 3>;
+    else kern = bp_serial_lane_kernel<LDPC_HIP_PRODUCT_SUM, 0, 6, 3>;
+    (void)sp;
+    if (llr && !h->order_visits_all) HIPCHK(hipMemsetAsync(llr, 0, sizeof(double) * (size_t)h->n * (size_t)rows, h->stream));  // bits the order never visits report 0
+    const size_t dyn = ((size_t)h->n + 15) & ~(size_t)15;
+    if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(512), (unsigned)dyn, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return LDPC_HIP_OK;
+}
+
+// new_list[i] = list[sub[i]]
+__global__ void __launch_bounds__(256) compose_lists_kernel(const int32_t *__restrict__ list, const int32_t *__restrict__ sub, int64_t count, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = list[sub[i]];
+}
+
+// The whole decode.  A tile runs until the slowest of its 64 lanes is done, so the batch is decoded in PASSES that end after 4, 8, 16, ...
+// iterations (ldpc_hip_bp_set_repack: where the first one ends; 0 = one pass).  After a pass the rows still decoding are counted (the
+// one place the host waits) and
+//   * a handful of them (<= SER_LANE_MAX, default 2048) finish on bp_serial_lane_kernel, a workgroup per syndrome -- the hopeless
+//     syndrome that would keep a tile on one compute unit for max_iter iterations costs a few milliseconds instead;
+//   * most of the rows (> 60 %): the same tiles carry on where they stopped;
+//   * else their message state is compacted, lane by lane, into dense tiles (the other message array) and the next pass runs on those.
+// Every row keeps decoding from the state it had -- nothing restarts -- so the results are those of one uninterrupted decode.
+// Returns 1 if the batch was decoded here, 0 if the caller should take the chunked path (the state of the whole batch must be resident).
+static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
+                                  int32_t *iters, uint8_t *conv) {
+    const int full = h->max_iter;
+    const size_t B = (size_t)batch, m1 = (size_t)h->m, n1 = (size_t)h->n;
+    const int64_t tiles_total = (batch + LDPC_WAVE - 1) / LDPC_WAVE;
+    const size_t per_tile_msg = sizeof(double) * (size_t)h->nnz * LDPC_WAVE;
+    int lane_max = h->sw("SER_LANE_MAX") >= 0 ? h->sw("SER_LANE_MAX") : 2048;
+    if (h->n > 60000) lane_max = 0;  // (the lane kernel keeps a byte per bit in LDS)
+    const bool lane_only = lane_max > 0 && batch <= (lane_max < 256 ? lane_max : 256) && h->repack_iters != 0;  // a small batch: a workgroup per syndrome from the start
+    int rc;
+    if (full <= 0) return 0;
+    if (!lane_only) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+        const size_t per_tile = per_tile_msg + (llr ? sizeof(double) * n1 * LDPC_WAVE : 0) + 24 * (m1 + n1 + 1);
+        if ((double)per_tile * (double)tiles_total > (double)(free_b + have) * 0.8 || (h->max_chunk_tiles > 0 && tiles_total > h->max_chunk_tiles)) return 0;
+    }
+    if ((rc = ensure_serial_stream_table(h, sp))) return rc;
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
+    if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
+    if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
+    hipStream_t st = h->stream;
+    h->accumulated_ms = 0.f;
+    h->accumulated_persistent_ms = 0.f;
+    h->timed = h->timed_mid = false;
+    h->timed_prev = h->timed_prev_mid = false;
+    HIPCHK(hipEventRecord(h->ev0, st));
+    auto finish = [&]() -> int {
+        HIPCHK(hipEventRecord(h->ev1, st));
+        h->timed = true;
+        return 1;
+    };
+    if (lane_only) {
+        if ((rc = h->msgC.ensure(sizeof(double) * (size_t)h->nnz * B))) return rc;
+        if ((rc = serial_lane_launch(h, sp, 0, (double *)h->msgC.p, synd, batch, decoding, llr, iters, conv))) return rc;
+        return finish();
+    }
+    if (h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the tables that stand in for the initial messages (bp_serial_stream_kernel.h)
+        if ((rc = h->d_edge0.ensure(sizeof(double) * n1)) || (rc = h->ser_pos_e0.ensure(sizeof(double) * 16 * n1))) return rc;
+        const dim3 ge((unsigned)((h->n + 255) / 256));
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+        else hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+        hipLaunchKernelGGL(serial_pos_e0_kernel, dim3((unsigned)((h->n * 16 + 255) / 256)), dim3(256), 0, st, (const int32_t *)h->ser_pos_tab.p, h->d_col_idx,
+                           (const double *)h->d_edge0.p, h->n, sp.dc * (sp.dr - 1), (double *)h->ser_pos_e0.p);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = h->msgA.ensure(per_tile_msg * (size_t)tiles_total))) return rc;
+    DeviceBuf *state = &h->msgA, *other = &h->msgC;
+    // the rows of the running pass: the caller's (identity) or a compacted subset -- their syndromes, their numbers in the caller's arrays
+    bool identity = true;
+    int64_t R = batch;
+    const uint8_t *cur_synd = synd;
+    int cur = 0;  // which of the two row-list / syndrome buffers describes the running rows
+    DeviceBuf *lists[2] = {&h->ser_rows[0], &h->ser_rows[1]}, *synds[2] = {&h->rp_synd, &h->ser_synd2};
+    auto grid = [](size_t items) { return flat_grid(items); };
+    auto scatter_out = [&](const int32_t *rows_list, int64_t cnt, bool big) -> int {  // rp_* -> the caller's arrays
+        const size_t C = (size_t)cnt;
+        if (big) {
+            hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * n1), dim3(256), 0, st, (const uint8_t *)h->rp_dec.p, rows_list, cnt, h->n, decoding);
+            if (llr) hipLaunchKernelGGL(scatter_rows_kernel<double>, grid(C * n1), dim3(256), 0, st, (const double *)h->rp_llr.p, rows_list, cnt, h->n, llr);
+        }
+        hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, st, (const int32_t *)h->rp_iters.p, rows_list, cnt, 1, iters);
+        hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, st, (const uint8_t *)h->rp_conv.p, rows_list, cnt, 1, conv);
+        HIPCHK(hipGetLastError());
+        return LDPC_HIP_OK;
+    };
+    const int first = h->repack_iters > 0 ? h->repack_iters : 4;
+    int it = 0;
+    bool resume = false;
+    for (;;) {
+        int next = h->repack_iters == 0 ? full : (it == 0 ? first : it * 2);
+        if (next > full || next <= it) next = full;
+        // (a compacted pass reaches the caller's decoding / llr rows through its row list; its iteration counts and flags go by the pass's own rows)
+        int32_t *o_it = identity ? iters : (int32_t *)h->rp_iters.p;
+        uint8_t *o_cv = identity ? conv : (uint8_t *)h->rp_conv.p;
+        if ((rc = serial_stream_launch(h, sp, it, next, resume, (double *)state->p, cur_synd, R, identity ? nullptr : (const int32_t *)lists[cur]->p, decoding, llr, o_it, o_cv))) return rc;
+        if (!identity && (rc = scatter_out((const int32_t *)lists[cur]->p, R, false))) return rc;
+        if (next >= full) break;
+        // the rows of this pass that are still decoding: listed (numbers within the pass) and counted
+        if ((rc = h->osd_list.ensure((size_t)R * sizeof(int32_t))) || (rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
+        HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), st));
+        hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, o_cv, R, (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+        HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));  // the size of what is left is needed on the host
+        const int64_t cnt = (int64_t)h->h_counters[2];
+        if (cnt == 0) break;
+        it = next;
+        const int32_t *sub = (const int32_t *)h->osd_list.p;
+        const size_t C = (size_t)cnt;
+        const bool to_lanes = cnt <= lane_max;
+        if (!to_lanes && cnt * 10 > R * 6) { resume = true; continue; }  // most rows are still decoding: the same tiles carry on
+        // the rows that go on: their numbers in the caller's arrays, their syndromes
+        const int nxt = cur ^ 1;
+        if ((rc = lists[nxt]->ensure(C * sizeof(int32_t))) || (rc = synds[nxt]->ensure(C * m1))) return rc;
+        if (identity) HIPCHK(hipMemcpyAsync(lists[nxt]->p, sub, C * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        else hipLaunchKernelGGL(compose_lists_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const int32_t *)lists[cur]->p, sub, cnt, (int32_t *)lists[nxt]->p);
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, st, cur_synd, sub, cnt, h->m, (uint8_t *)synds[nxt]->p);
+        HIPCHK(hipGetLastError());
+        if ((rc = h->rp_iters.ensure(C * 4)) || (rc = h->rp_conv.ensure(C))) return rc;
+        if (to_lanes) {
+            if ((rc = h->rp_dec.ensure(C * n1)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
+            if ((rc = other->ensure(sizeof(double) * (size_t)h->nnz * C))) return rc;
+            hipLaunchKernelGGL(serial_rows_from_tiles_kernel, dim3((unsigned)((h->nnz + 1023) / 1024), (unsigned)cnt), dim3(256), 0, st, (const double *)state->p, sub, cnt, h->nnz,
+                               (double *)other->p);
+            HIPCHK(hipGetLastError());
+            if ((rc = serial_lane_launch(h, sp, it, (double *)other->p, (const uint8_t *)synds[nxt]->p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
+                                         (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
+            if ((rc = scatter_out((const int32_t *)lists[nxt]->p, cnt, true))) return rc;
+            break;
+        }
+        // their message state, lane by lane, into dense tiles of the other array
+        const int64_t tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
+        if ((rc = other->ensure(per_tile_msg * (size_t)tiles2))) return rc;
+        const int epw = 16;
+        const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)(tiles2 < 32768 ? tiles2 : 32768));
+        hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)state->p, sub, cnt, h->nnz, epw, (double *)other->p, (const unsigned *)nullptr);
+        HIPCHK(hipGetLastError());
+        std::swap(state, other);
+        cur = nxt;
+        cur_synd = (const uint8_t *)synds[cur]->p;
+        identity = false;
+        resume = false;
+        R = cnt;
+    }
+    return finish();
+}
+
 int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                   int32_t *iters, uint8_t *conv) {
     if (h->random_serial) return decode_serial_random(h, synd, batch, decoding, llr, iters, conv);  // (takes precedence, bp.hpp:467-469)
     if (h->schedule == 2) return decode_serial_relative(h, synd, batch, decoding, llr, iters, conv);
     const size_t B = (size_t)batch, m1 = (size_t)(h->m ? h->m : 1), n1 = (size_t)(h->n ? h->n : 1);
     int rc;
-    // Will the streamed kernel (bp_serial_stream_kernel.h) take this schedule?  Then a second pass CARRIES ON from the first one's message
-    // state (the unconverged lanes compacted into dense tiles) instead of starting again, and where to cut is priced with the iteration
-    // histogram the previous decode on this handle left behind (stream_first_pass_length; no histogram yet, or none that pays: one pass).
-    bool streamed = false;
-    if ((h->serial_kernel == -1 || h->serial_kernel == 2) && h->n > 0 && h->m > 0) {
+    // the streamed kernels (bp_serial_stream_kernel.h) where the matrix and the schedule allow them: automatic, or asked for (mode 2)
+    if ((h->serial_kernel == -1 || h->serial_kernel == 2) && h->n > 0 && h->m > 0 && batch > 0) {
         if ((rc = ensure_serial_levels(h))) return rc;
-        streamed = plan_serial_stream(h).dr != 0;
-    }
-    int k1;
-    if (streamed) {
-        if (h->repack_iters >= 0) k1 = h->repack_iters;
-        else {
-            double live = 0.5;
-            k1 = batch >= 64 * LDPC_WAVE ? stream_first_pass_length(h, &live, 1.0 / 6.0) : 0;
+        const SerialStreamPlan sp = plan_serial_stream(h);
+        if (sp.dr) {
+            const int took = decode_serial_streamed(h, sp, synd, batch, decoding, llr, iters, conv);
+            if (took < 0) return took;
+            if (took > 0) return LDPC_HIP_OK;
         }
-        if (k1 >= h->max_iter) k1 = 0;
-        if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
-        if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
-        if (k1 <= 0) {
-            if ((rc = decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv))) return rc;
-            return stream_leave_histogram(h, iters, conv, batch);
-        }
-    } else {
-        k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
-        if (h->repack_iters < 0 && k1 < 2) k1 = 2;
-        if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
-            return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
-        if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     }
+    int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;
+    if (h->repack_iters < 0 && k1 < 2) k1 = 2;
+    if (k1 <= 0 || k1 >= h->max_iter || batch <= 4 * LDPC_WAVE)
+        return decode_serial_pass(h, h->max_iter, synd, batch, decoding, llr, iters, conv);
+    if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
     if ((rc = decode_serial_pass(h, k1, synd, batch, decoding, llr, iters, conv))) return rc;
-    const bool carry_on = streamed && h->ser_streamed && h->ser_chunk_tiles >= (int64_t)((batch + LDPC_WAVE - 1) / LDPC_WAVE);  // (the whole batch's state is resident)
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
     if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
     HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
@@ -680,7 +899,7 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     HIPCHK(hipMemcpyAsync(&h->h_counters[2], h->osd_counters.p, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // the size of the second pass is needed on the host
     const int64_t cnt = (int64_t)h->h_counters[2];
-    if (cnt == 0) return streamed ? stream_leave_histogram(h, iters, conv, batch) : LDPC_HIP_OK;
+    if (cnt == 0) return LDPC_HIP_OK;
     float ms1 = 0.f;
     (void)ldpc_hip_bp_last_kernel_ms(h, &ms1);
     const size_t C = (size_t)cnt;
@@ -691,19 +910,8 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if (h->m > 0)
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * h->m), dim3(256), 0, h->stream, synd, list, cnt, h->m, (uint8_t *)h->rp_synd.p);
     HIPCHK(hipGetLastError());
-    int it_start = 0;
-    if (carry_on) {
-        // the listed rows' message state after the first pass, lane by lane, into dense tiles of the second message array
-        const int64_t tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
-        if ((rc = h->msgC.ensure(sizeof(double) * (size_t)h->nnz * LDPC_WAVE * (size_t)tiles2))) return rc;
-        const int epw = 16;
-        const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)(tiles2 < 32768 ? tiles2 : 32768));
-        hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, h->stream, (const double *)h->msgA.p, list, cnt, h->nnz, epw, (double *)h->msgC.p, (const unsigned *)nullptr);
-        HIPCHK(hipGetLastError());
-        it_start = k1;
-    }
     if ((rc = decode_serial_pass(h, h->max_iter, (const uint8_t *)h->rp_synd.p, cnt, (uint8_t *)h->rp_dec.p,
-                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p, nullptr, 0, 0, it_start))) return rc;
+                                 llr ? (double *)h->rp_llr.p : nullptr, (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
     h->accumulated_ms += ms1;  // both passes count as this decode's kernel time
     if (h->n > 0) {
         hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C * h->n), dim3(256), 0, h->stream, (const uint8_t *)h->rp_dec.p, list, cnt, h->n, decoding);
@@ -712,7 +920,7 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if (iters) hipLaunchKernelGGL(scatter_rows_kernel<int32_t>, grid(C), dim3(256), 0, h->stream, (const int32_t *)h->rp_iters.p, list, cnt, 1, iters);
     hipLaunchKernelGGL(scatter_rows_kernel<uint8_t>, grid(C), dim3(256), 0, h->stream, (const uint8_t *)h->rp_conv.p, list, cnt, 1, conv);
     HIPCHK(hipGetLastError());
-    return streamed ? stream_leave_histogram(h, iters, conv, batch) : LDPC_HIP_OK;
+    return LDPC_HIP_OK;
 }
 
 // soft_info_decode_serial over a batch (bp_softinfo_kernel).  Device pointers, on h->stream.

@@ -265,7 +265,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
 // gather = reading one message array of every tile and writing the live share = (1 + (1 - F(k))) * gather_cost of an iteration (the
 // flooding schedule moves four arrays per iteration: 1/4; the serial schedule six segments per edge: 1/6), plus the first pass's outputs for rows that are decoded on.  No work is wasted when nothing
 // converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
-int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost) {
+static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost = 0.25) {
     *live_after = 0.5;
     if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
     // The previous decode's histogram, IF its copy has landed -- a look, never a wait (the *_async entry points must not block): a
@@ -312,7 +312,7 @@ int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_c
     return best < 0.97 * plain ? best_k : 0;
 }
 
-int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
+static int stream_leave_histogram(ldpc_hip_bp *h, const int32_t *iters, const uint8_t *conv, int64_t batch) {
     int rc;
     if ((rc = h->sp_hist.ensure(256 * sizeof(unsigned)))) return rc;
     if (!h->h_hist) HIPCHK(hipHostMalloc((void **)&h->h_hist, 256 * sizeof(unsigned), hipHostMallocDefault));

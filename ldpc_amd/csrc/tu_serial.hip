@@ -9,3 +9,12 @@
 
 #include "host_handle.h"
 #include "host_serial.h"
+
+#ifdef LDPC_SER_PROF
+extern "C" int ldpc_hip_debug_serial_stream_clocks(unsigned long long *out, int reset) {
+    if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ser_phase_clocks), sizeof(unsigned long long) * 8));
+    if (out && reset == 2) HIPCHK(hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(ser_wg_trace), sizeof(unsigned long long) * 4096 * 4));
+    if (reset == 1) { unsigned long long z[8] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(ser_phase_clocks), z, sizeof z)); }
+    return LDPC_HIP_OK;
+}
+#endif

@@ -65,7 +65,7 @@ def test_streamed_serial_kernel_against_the_checker_and_the_walking_kernel(metho
     rng = np.random.default_rng(5)
     perm = rng.permutation(n).astype(np.int32)
     holes = perm.copy()
-    holes[::9] = holes[1::9][: len(holes[::9])]  # some bits twice, some never: the initial messages must be written out
+    holes[0:1800:9] = holes[1:1800:9]  # some bits twice, some never: the initial messages must be written out
     for order in (None, perm, holes):
         want = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha).decode_serial_batch(synd, order)
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, meth, alpha)
@@ -84,15 +84,19 @@ def test_streamed_serial_kernel_against_the_checker_and_the_walking_kernel(metho
         assert np.array_equal(d0, dec) and np.array_equal(i0, it) and bits_equal(l0, llr)
 
 
+@pytest.mark.parametrize("lane_max", [-1, 0, 40])
 @pytest.mark.parametrize("first_pass", [-1, 1, 2, 4, 7])
-def test_streamed_serial_two_pass_decode_gives_identical_results(first_pass, oracle_built):
-    """The first pass's unconverged lanes are compacted into dense tiles and CARRY ON (no restart): same bits as one pass."""
+def test_streamed_serial_decode_in_passes_gives_identical_results(first_pass, lane_max, oracle_built):
+    """Passes that end after 4, 8, 16, ... iterations (or first_pass, 2 first_pass, ...): after each the rows still decoding either carry on
+    in their tiles, are compacted into dense tiles, or -- a handful -- finish a workgroup per syndrome (bp_serial_lane_kernel; lane_max 0:
+    never, 40: only the last few).  Nothing restarts: same bits as one pass."""
     from ldpc_amd.engine import HipBpEngine
     from ldpc_amd.codes import regular_ldpc_code
     from oracle import bits_equal
     n = 1800
     h = regular_ldpc_code(n, 3, 6, seed=9)
     synd = _synd(h, 0.072, seed=77, shots=1500)
+    synd[3, 5] = 3  # never converges
     for meth, alpha in ((0, 1.0), (1, 0.0)):
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.072), 30, meth, alpha)
         eng.set_schedule("serial")
@@ -101,9 +105,45 @@ def test_streamed_serial_two_pass_decode_gives_identical_results(first_pass, ora
         d0, l0, i0, c0 = eng.decode_batch(synd)
         assert 0.02 < 1 - c0.mean() < 0.95 and i0[c0].min() < i0[c0].max()
         eng.set_repack(first_pass)
+        eng.set_debug_switch("SER_LANE_MAX", lane_max)
         d1, l1, i1, c1 = eng.decode_batch(synd)
         assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1) and bits_equal(l0, l1)
         d2, l2, i2, c2 = eng.decode_batch(synd, want_llr=False)
         assert l2 is None and np.array_equal(d2, d0) and np.array_equal(i2, i0) and np.array_equal(c2, c0)
     want = oracle_built.BpOracle(h, error_rate=0.072, max_iter=30, bp_method="minimum_sum", ms_scaling_factor=0.0).decode_serial_batch(synd[:200], None)
     assert np.array_equal(d1[:200], want[0]) and np.array_equal(i1[:200], want[2]) and bits_equal(l1[:200], want[1])
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_small_batches_take_the_lane_kernel_from_the_start(name):
+    """<= 256 rows: a workgroup per syndrome from the first iteration (what a `for shot: decode(shot)` caller of the big code gets)."""
+    from oracle import bits_equal
+    c = load_case(name)
+    eng = _engine(c)
+    order = c.get("order")
+    eng.set_schedule("serial", order if order is not None and len(order) else None)
+    eng.set_serial_kernel(2)
+    dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+    assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"])
+    assert bits_equal(llr[: len(c["llr"])], c["llr"])
+    d1, l1, i1, c1 = eng.decode_batch(c["syndromes"][:1])
+    assert np.array_equal(d1[0], c["decoding"][0]) and int(i1[0]) == int(c["iterations"][0]) and bits_equal(l1[0], c["llr"][0])
+
+
+def test_lane_kernel_with_orders_that_skip_bits(oracle_built):
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import regular_ldpc_code
+    from oracle import bits_equal
+    n = 1800
+    h = regular_ldpc_code(n, 3, 6, seed=9)
+    synd = _synd(h, 0.07, seed=3, shots=90)
+    rng = np.random.default_rng(8)
+    holes = rng.permutation(n).astype(np.int32)
+    holes[0:1792:7] = holes[1:1792:7]  # some bits twice, some never
+    for method, alpha in (("product_sum", 1.0), ("minimum_sum", 0.7)):
+        want = oracle_built.BpOracle(h, error_rate=0.07, max_iter=20, bp_method=method, ms_scaling_factor=alpha).decode_serial_batch(synd, holes)
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.07), 20, 0 if method == "product_sum" else 1, alpha)
+        eng.set_schedule("serial", holes)
+        eng.set_serial_kernel(2)
+        dec, llr, it, cv = eng.decode_batch(synd)
+        assert np.array_equal(dec, want[0]) and np.array_equal(it, want[2]) and np.array_equal(cv, want[3]) and bits_equal(llr, want[1])

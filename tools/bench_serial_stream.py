@@ -32,17 +32,17 @@ def main():
     forms = [  # (label, serial_kernel, repack, switches, want_llr)
         ("level kernel (round 1-4)", 1, -1, (), True),
         ("streamed, one pass, 16 waves ring 1", 2, 0, (), True),
-        ("streamed, auto passes, 16 waves ring 1", 2, -1, (), True),
-        ("streamed, auto passes, 16 waves ring 1, no log-ratios", 2, -1, (), False),
-        ("streamed, auto, 8 waves ring 1", 2, -1, (("SER_WAVES", 8),), True),
-        ("streamed, auto, 8 waves ring 2", 2, -1, (("SER_WAVES", 8), ("SER_RING", 2)), True),
-        ("streamed, auto, 9 waves ring 1", 2, -1, (("SER_WAVES", 9),), True),
-        ("streamed, auto, 12 waves ring 1", 2, -1, (("SER_WAVES", 12),), True),
-        ("streamed, auto, 6 waves ring 1", 2, -1, (("SER_WAVES", 6),), True),
-        ("streamed, auto, 16 waves, initial messages written out", 2, -1, (("EXPLICIT_INIT", 1),), True),
-        ("streamed, cut at 3", 2, 3, (), True),
-        ("streamed, cut at 4", 2, 4, (), True),
-        ("streamed, cut at 5", 2, 5, (), True),
+        ("streamed, passes 4 8 16 .., 16 waves ring 1", 2, -1, (), True),
+        ("streamed, passes, no log-ratios", 2, -1, (), False),
+        ("streamed, passes, lanes never", 2, -1, (("SER_LANE_MAX", 0),), True),
+        ("streamed, passes, 8 waves ring 1", 2, -1, (("SER_WAVES", 8),), True),
+        ("streamed, passes, 8 waves ring 2", 2, -1, (("SER_WAVES", 8), ("SER_RING", 2)), True),
+        ("streamed, passes, 9 waves ring 1", 2, -1, (("SER_WAVES", 9),), True),
+        ("streamed, passes, 12 waves ring 1", 2, -1, (("SER_WAVES", 12),), True),
+        ("streamed, passes, initial messages written out", 2, -1, (("EXPLICIT_INIT", 1),), True),
+        ("streamed, first pass 3", 2, 3, (), True),
+        ("streamed, first pass 5", 2, 5, (), True),
+        ("streamed, first pass 6", 2, 6, (), True),
     ]
     if args.forms == "default":
         forms = forms[:1] + forms[2:4]
