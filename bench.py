@@ -363,6 +363,56 @@ def schedule_configs(dev, steps):
     return out
 
 
+def serial_headline_config(dev, steps):
+    """SURVEY.md section 8 f1 on the code the bench is quoted on: schedule = serial (fixed order, bp.hpp:451-545) on configs[1]'s
+    (3,6)-regular n = 10 000 code, product_sum, 50 iterations, B = 65 536, at its early-exit point p = 0.05 -- bp_serial_stream_kernel +
+    bp_serial_lane_kernel (csrc/bp_serial_stream_kernel.h; passes).  Two fractions of 8 TB/s, both over the whole
+    step: `frac` with SURVEY.md 8(d)'s bytes (iterations x 4 E x 8 + I/O, the figure every entry of this file uses), `frac_moved` with
+    what the serial schedule itself moves per lane and iteration (18 segments per bit = 6 E x 8: a bit update reads the 15 other entries
+    of its three rows and writes its own three).  Parity: a sample of rows bit-exact against the checker (LLR bits included)."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    import oracle  # checker only
+
+    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    m, n = h.shape
+    p, B, max_iter = 0.05, 65536, 50
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 0, 1.0, device=dev.index or 0)
+    eng.set_schedule("serial")
+    s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+    out = eng.decode_batch(s)
+    step_ms, kms = [], []
+    c0 = eng.clock_probe()
+    for _ in range(max(2, min(steps, 3))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.decode_batch(s, out=out)
+        torch.cuda.synchronize()
+        step_ms.append((time.perf_counter() - t0) * 1e3)
+        kms.append(eng.last_kernel_ms())
+    c1 = eng.clock_probe()
+    ms = float(np.median(step_ms))
+    it = out[2].cpu().numpy()
+    cv = out[3].cpu().numpy()
+    rows = np.r_[0:160, B - 32:B]
+    idx = torch.from_numpy(rows).to(dev)
+    s_host = s[idx].cpu().numpy()
+    want = oracle.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=0).decode_serial_batch(s_host, None)
+    ok = bool(np.array_equal(out[0][idx].cpu().numpy(), want[0]) and oracle.bits_equal(out[1][idx].cpu().numpy(), want[1])
+              and np.array_equal(it[rows], want[2]) and np.array_equal(cv[rows].astype(bool), want[3]))
+    eng.close()
+    alg = algorithmic_bytes(it, m, n, h.nnz)
+    moved = float(np.sum(it.astype(np.float64)) * 6.0 * h.nnz * 8.0 + B * (m + 9.0 * n + 5.0))
+    return {"config": "serial schedule (fixed order): (3,6)-regular LDPC n=10000, product_sum max_iter=50, batch=65536, BSC p=0.05", "key": "f1_serial_c2",
+            "value": B / ms * 1e3, "unit": "syndromes/s", "ms": ms, "ms_steps": [round(v, 3) for v in step_ms], "bp_kernel_ms": float(np.median(kms)),
+            "mean_iterations": float(it.mean()), "bp_converged_fraction": float(cv.astype(np.float64).mean()), "parity_vs_oracle": ok,
+            "parity": "bit-exact, 192 rows (decisions, iterations, flags, log-ratio bits)", "bound": "hbm",
+            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_moved": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "clock_ghz_this_run": HipBpEngine.clock_ghz(c0, c1),
+            "bound_note": "frac: SURVEY 8(d) bytes (4 E x 8 per iteration) over the step; frac_moved: the 6 E x 8 per lane-iteration the serial schedule moves; "
+                          "counters of the first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
+
+
 def host_io_leg(h, args, alpha, synd_dev, dec_dev, it_dev, device_value):
     """The drop-in's own I/O path (_bp_decoder.pyx:642-695 is NumPy in, NumPy out): the SAME batch as pageable host arrays through
     `BpDecoder.decode_batch` -- validation, the all-zero-row shortcut, H2D, kernels, D2H, all inside the timed call -- without and
@@ -761,6 +811,7 @@ def run(args, real_stdout, stage) -> None:
             try:
                 res["secondary"] = [early] + secondary_configs(dev, max(5, args.steps))  # (millisecond calls: a median of at least five)
                 res["secondary"] += schedule_configs(dev, args.steps)
+                res["secondary"].append(serial_headline_config(dev, args.steps))
                 if not all(e.get("parity_vs_oracle", False) for e in res["secondary"]):
                     res["parity_failed"] = True
             except Exception as exc:  # the headline line must not be lost to a secondary config

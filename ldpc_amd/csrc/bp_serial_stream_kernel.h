@@ -72,6 +72,66 @@ __global__ void __launch_bounds__(256) serial_pos_e0_kernel(const int32_t *__res
     out[q] = t < no ? edge0[col_idx[pos_tab[(size_t)p * SERIAL_STREAM_REC + t]]] : 0.0;
 }
 
+// The DC check->bit messages of one bit, product-sum with the libm-exact `log`: the fast path of the flooding kernel's check row
+// (check_row_ps_exact_fast, bp_device_common.h) for the serial schedule's bit update.  Every lane evaluates the TABLE branch of the `log`
+// for each of its messages; lanes whose argument is near 1 park it in a wave-private LDS buffer, compacted over the bit's DC messages,
+// and the near-1 branch runs once per 64 parked arguments (usually once per bit instead of DC times).  Preconditions, tested once per
+// bit over the LIVE lanes: every tanh value that enters has magnitude below 1 and is no NaN -- then each product x has |x| < 1 and
+// q = (1 + x) / (1 - x) is a normal number (no 0 / inf / NaN patches).  Same operations on the same operands: same bits.  false: take
+// the generic routine.
+template <int DC, int DRM1>
+__device__ __forceinline__ bool bit_messages_ps_exact_fast(const double (&v)[DC * DRM1], const bool (&odd)[DC], double (&c)[DC], const double *log_tab,
+                                                           uint64_t live, double *near_buf) {
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < DC * DRM1; ++t) bad = bad || !(__builtin_fabs(v[t]) < 1.0);
+    if (__builtin_amdgcn_ballot_w64(bad) & live) return false;
+    const int lane = (int)(threadIdx.x & (LDPC_WAVE - 1));
+    const bool lane_live = (live >> lane) & 1ull;
+    uint64_t parked[DC];
+    int first[DC];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < DC; ++k) {
+        double x = 1.0;  // bp.hpp:492-498: the product over the row's other entries, in the row's order
+#pragma unroll
+        for (int q = 0; q < DRM1; ++q) x *= v[k * DRM1 + q];
+        const double q = ldpc_math::div_cr(1.0 + x, 1.0 - x);
+        const bool near_any = ldpc_math::log_near_one(q);
+        double y = ldpc_math::log_libm_general(q, log_tab);
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(near_any) & live;  // (dead lanes park nothing)
+        const bool near = near_any && lane_live;
+        parked[k] = 0;
+        first[k] = 0;
+        if (mask) {
+            const int cnt = __builtin_popcountll(mask);
+            if (total + cnt <= LDPC_NEAR_SLOTS) {
+                if (near) near_buf[total + lane_rank(mask)] = q;
+                parked[k] = mask;
+                first[k] = total;
+                total += cnt;
+            } else if (near) {
+                y = ldpc_math::log_libm_near_one(q);  // buffer full: in place, as the generic routine would
+            }
+        }
+        c[k] = y;
+        LDPC_EDGE_FENCE();
+    }
+    if (total) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS operations of a wavefront execute in order; this only pins the compiler
+        for (int s = lane; s < total; s += LDPC_WAVE) near_buf[s] = ldpc_math::log_libm_near_one(near_buf[s]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < DC; ++k)
+            if (parked[k]) {
+                if ((parked[k] >> lane) & 1ull) c[k] = near_buf[first[k] + lane_rank(parked[k])];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < DC; ++k) c[k] = ldpc_math::as_f64(ldpc_math::as_u64(c[k]) ^ (odd[k] ? 0x8000000000000000ull : 0ull));  // pow(-1, syndrome byte) (bp.hpp:499)
+    return true;
+}
+
 // Scalar data is fetched one and two steps AHEAD of the step that uses it (loop-carried in SGPRs): a record line is a scalar-cache miss
 // by construction (1.3 MB streamed once per iteration), the syndrome word and the prior hang off it, and a wavefront that asked for them
 // where it needs them stood still for three dependent round trips per bit.
@@ -102,6 +162,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
     const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
     const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
+    // parking space of the exact product-sum messages (bit_messages_ps_exact_fast): behind the rings, LDPC_NEAR_BYTES per wavefront
+    double *near_buf = reinterpret_cast<double *>(ldpc_dyn_lds + (size_t)nwaves * (RING * SLOT_BYTES) + (size_t)wave * LDPC_NEAR_BYTES);
     const unsigned l16 = (unsigned)(lane & 31) * 16u;
     const bool upper = lane >= 32;
     const unsigned beyond = (unsigned)nnz << 9;  // an offset the buffer's range check rejects: zeros, no memory access
@@ -204,14 +266,21 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5)
                 const int bit = cur.own[DC];
                 double llr = cur.llr0;  // bp.hpp:488
                 double c[DC], pre[DC];
+                bool odd_k[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) odd_k[k] = (cur.par[k] >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
+                bool have_c = false;
+                if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0) have_c = bit_messages_ps_exact_fast<DC, DR - 1>(v, odd_k, c, log_tab, ~done, near_buf);
 #pragma unroll
                 for (int k = 0; k < DC; ++k) {
-                    const bool odd = (cur.par[k] >> lane) & 1ull;  // pow(-1, syndrome byte) / syndrome parity
+                    const bool odd = odd_k[k];
                     if (METHOD == LDPC_HIP_PRODUCT_SUM) {
-                        double x = 1.0;  // bp.hpp:492-498: the product over the row's other entries, in the row's order
+                        if (!have_c) {  // (wave-uniform)
+                            double x = 1.0;  // bp.hpp:492-498: the product over the row's other entries, in the row's order
 #pragma unroll
-                        for (int q = 0; q < DR - 1; ++q) x *= v[k * (DR - 1) + q];
-                        c[k] = ps_message<MATH>(x, odd, log_tab);
+                            for (int q = 0; q < DR - 1; ++q) x *= v[k * (DR - 1) + q];
+                            c[k] = ps_message<MATH>(x, odd, log_tab);
+                        }
                     } else {
                         int sgn = odd ? 1 : 0;  // bp.hpp:505-519
                         double temp = DBL_MAX;
@@ -309,7 +378,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5)
 // going for 46 more iterations of ~2 ms while the rest of the chip had nothing to do -- as long as the whole first pass.  Few syndromes
 // are decoded here instead: a syndrome's messages as one row-major array [nnz] (240 KB on the n = 10 000 code: it lives in L2), the
 // bits of a level one per LANE (a level's ~286 bits are one step of a 512-thread workgroup), the same position records, the same
-// operations on the same operands in the same order -- the same bits.  Used for the rows a streamed pass left (decode_serial, host_serial.h:
+// operations on the same operands in the same order -- the same bits (how the lanes share a bit: at the kernel).  Used for the rows a streamed pass left (decode_serial, host_serial.h:
 // state taken over lane by lane through serial_rows_from_tiles_kernel) and for small batches from the start (it_start = 0).
 struct SerialLaneArgs {
     int32_t m, n, nnz, max_iter, it_start, n_levels;
@@ -334,14 +403,21 @@ __global__ void __launch_bounds__(256) serial_rows_from_tiles_kernel(const doubl
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += gridDim.x * blockDim.x) out[r * (int64_t)nnz + e] = from[(int64_t)e * 64];
 }
 
+// lane = (bit of the level, one of its DC checks): DC neighbouring lanes share a bit.  Each forms ITS check's message (the product or
+// minimum over the row's other entries, the `log`), the DC messages go round the group by lane permutation, every lane of the group adds
+// them up in the reference's order (bp.hpp:500-501, 530-534 -- a handful of additions, done DC times over rather than waited for) and
+// evaluates its own edge's new bit->check message (the `tanh`): the dependent chain of a level is one `log` and one `tanh` long instead of DC of each.
 template <int METHOD, int MATH, int DR, int DC>
-__global__ void __launch_bounds__(512) bp_serial_lane_kernel(const SerialLaneArgs a) {
-    constexpr int NO = DC * (DR - 1);
+__global__ void __launch_bounds__(1024) bp_serial_lane_kernel(const SerialLaneArgs a) {
     constexpr int REC = SERIAL_STREAM_REC;
+    constexpr int PER_WAVE = LDPC_WAVE / DC;  // bits per wavefront step (lanes beyond PER_WAVE * DC idle)
     extern __shared__ __attribute__((aligned(16))) unsigned char lane_lds[];
     uint8_t *dbit = lane_lds;  // [n] this iteration's hard decisions
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = T >> 6;
+    const int grp = lane / DC, k = lane - grp * DC;  // this lane's bit within the wavefront's step, and which of the bit's checks
+    const bool active = grp < PER_WAVE;
     const int64_t r = blockIdx.x;
     const int m = a.m, n = a.n, nnz = a.nnz;
     double *A = a.A + r * (int64_t)nnz;
@@ -358,53 +434,56 @@ __global__ void __launch_bounds__(512) bp_serial_lane_kernel(const SerialLaneArg
     for (int it = a.it_start + 1; it <= a.max_iter; ++it) {
         const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
         for (int l = 0; l < a.n_levels; ++l) {
-            const int p1 = a.lvl_ptr[l + 1];
-            for (int p = a.lvl_ptr[l] + tid; p < p1; p += T) {
-                const int4 *rec = reinterpret_cast<const int4 *>(a.pos_tab + (size_t)p * REC);
-                int oth[16], own[8];
+            const int p0 = a.lvl_ptr[l], p1 = a.lvl_ptr[l + 1];
+            for (int pb = p0 + wave * PER_WAVE; pb < p1; pb += nwaves * PER_WAVE) {  // (wave-uniform trip count: the permutations below need whole wavefronts)
+                const int p = pb + grp;
+                const bool on = active && p < p1;
+                const int32_t *rec = a.pos_tab + (size_t)(on ? p : p0) * REC;
+                const int own = rec[16 + k], bit = rec[16 + DC];
+                double c;
+                {
+                    double v[DR - 1];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int4 w = rec[q]; oth[4 * q] = w.x; oth[4 * q + 1] = w.y; oth[4 * q + 2] = w.z; oth[4 * q + 3] = w.w; }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { const int4 w = rec[4 + q]; own[4 * q] = w.x; own[4 * q + 1] = w.y; own[4 * q + 2] = w.z; own[4 * q + 3] = w.w; }
-                double v[NO];
-#pragma unroll
-                for (int t = 0; t < NO; ++t) v[t] = A[oth[t]];
-                const int bit = own[DC];
-                double llr = a.llr0[bit];  // bp.hpp:488
-                double c[DC], pre[DC];
-#pragma unroll
-                for (int k = 0; k < DC; ++k) {
-                    const bool odd = synd[own[k] / DR] & 1;  // pow(-1, syndrome byte) / syndrome parity
+                    for (int q = 0; q < DR - 1; ++q) v[q] = A[rec[k * (DR - 1) + q]];
+                    const bool odd = synd[own / DR] & 1;  // pow(-1, syndrome byte) / syndrome parity
                     if (METHOD == LDPC_HIP_PRODUCT_SUM) {
                         double x = 1.0;  // bp.hpp:492-498
 #pragma unroll
-                        for (int q = 0; q < DR - 1; ++q) x *= v[k * (DR - 1) + q];
-                        c[k] = ps_message<MATH>(x, odd, log_tab);
+                        for (int q = 0; q < DR - 1; ++q) x *= v[q];
+                        c = ps_message<MATH>(x, odd, log_tab);
                     } else {
                         int sgn = odd ? 1 : 0;  // bp.hpp:505-519
                         double temp = DBL_MAX;
 #pragma unroll
                         for (int q = 0; q < DR - 1; ++q) {
-                            const double b = v[k * (DR - 1) + q];
-                            const double ab = fabs(b);
+                            const double ab = fabs(v[q]);
                             if (ab < temp) temp = ab;
-                            if (b <= 0) sgn ^= 1;
+                            if (v[q] <= 0) sgn ^= 1;
                         }
-                        c[k] = (alpha * (sgn ? -1.0 : 1.0)) * temp;
+                        c = (alpha * (sgn ? -1.0 : 1.0)) * temp;
                     }
-                    pre[k] = llr;
-                    llr += c[k];
-                    if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
                 }
-                double temp = 0.0;  // bp.hpp:530-534
+                double cs[DC];
 #pragma unroll
-                for (int k = DC - 1; k >= 0; --k) {
-                    A[own[k]] = edge_form<METHOD, MATH>(pre[k] + temp);
-                    temp += c[k];
-                    if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
+                for (int j = 0; j < DC; ++j) cs[j] = __shfl(c, grp * DC + j, LDPC_WAVE);
+                double llr = a.llr0[bit], pre = 0.0;  // bp.hpp:488, 500-501
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    if (j == k) pre = llr;
+                    llr += cs[j];
                 }
-                dbit[bit] = llr <= 0 ? 1 : 0;  // bp.hpp:525-529
-                if (llr_out) llr_out[bit] = llr;
+                double temp = 0.0;  // bp.hpp:530-534: what the entries after this one add
+#pragma unroll
+                for (int j = DC - 1; j >= 0; --j)
+                    if (j > k) temp += cs[j];
+                const double out = edge_form<METHOD, MATH>(pre + temp);
+                if (on) {
+                    A[own] = out;
+                    if (k == 0) {
+                        dbit[bit] = llr <= 0 ? 1 : 0;  // bp.hpp:525-529
+                        if (llr_out) llr_out[bit] = llr;
+                    }
+                }
             }
             __syncthreads();  // the next level reads what this one wrote
         }

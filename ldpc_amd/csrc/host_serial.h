@@ -176,7 +176,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
         if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
         const int slot = serial_stream_slot_bytes(sp.dr, sp.dc);
-        while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot) > 150u * 1024u) --ser_waves;
+        while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES) > 150u * 1024u) --ser_waves;
         if (ser_waves > 16) ser_waves = 16;
         if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
         else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 1>(ser_ring);
@@ -245,7 +245,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
                                    (const double *)h->d_edge0.p, h->n, sp.dc * (sp.dr - 1), (double *)h->ser_pos_e0.p);
                 a.pos_e0 = (const double *)h->ser_pos_e0.p;
             }
-            const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * serial_stream_slot_bytes(sp.dr, sp.dc));
+            const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * serial_stream_slot_bytes(sp.dr, sp.dc) + LDPC_NEAR_BYTES);
             if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
         } else
@@ -659,7 +659,7 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
     if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
     if (ser_waves > waves_cap) ser_waves = waves_cap;
     const int slot = serial_stream_slot_bytes(sp.dr, sp.dc);
-    while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot) > 150u * 1024u) --ser_waves;
+    while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES) > 150u * 1024u) --ser_waves;
     if (ser_waves > 16) ser_waves = 16;
     void (*kern)(const SerialArgs);
     if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
@@ -685,7 +685,7 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
         a.edge0 = (const double *)h->d_edge0.p;
         a.pos_e0 = (const double *)h->ser_pos_e0.p;
     }
-    const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * slot);
+    const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES);
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
     HIPCHK(hipGetLastError());
@@ -719,7 +719,7 @@ static int serial_lane_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int it
     if (llr && !h->order_visits_all) HIPCHK(hipMemsetAsync(llr, 0, sizeof(double) * (size_t)h->n * (size_t)rows, h->stream));  // bits the order never visits report 0
     const size_t dyn = ((size_t)h->n + 15) & ~(size_t)15;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(512), (unsigned)dyn, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3((unsigned)(h->sw("SER_LANE_THREADS") > 0 ? h->sw("SER_LANE_THREADS") : rows <= 2048 ? 1024 : 512)), (unsigned)dyn, h->stream, a);
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
 }
@@ -730,8 +730,10 @@ __global__ void __launch_bounds__(256) compose_lists_kernel(const int32_t *__res
     if (i < count) out[i] = list[sub[i]];
 }
 
-// The whole decode.  A tile runs until the slowest of its 64 lanes is done, so the batch is decoded in PASSES that end after 4, 8, 16, ...
-// iterations (ldpc_hip_bp_set_repack: where the first one ends; 0 = one pass).  After a pass the rows still decoding are counted (the
+// The whole decode.  A tile runs until the slowest of its 64 lanes is done, so the batch is decoded in PASSES: the first ends after 4
+// iterations (ldpc_hip_bp_set_repack: where; 0 = one pass), the next after twice as many -- or, when a pass left less than 40 % of its
+// rows (they are converging now), after ONE more iteration: a second pass of two iterations where half of the tiles need one keeps a
+// compute unit on a two-tile queue for four tile-iterations while the others idle.  After a pass the rows still decoding are counted (the
 // one place the host waits) and
 //   * a handful of them (<= SER_LANE_MAX, default 2048) finish on bp_serial_lane_kernel, a workgroup per syndrome -- the hopeless
 //     syndrome that would keep a tile on one compute unit for max_iter iterations costs a few milliseconds instead;
@@ -810,13 +812,15 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
     const int first = h->repack_iters > 0 ? h->repack_iters : 4;
     int it = 0;
     bool resume = false;
+    bool thinning = false;  // the last pass left a minority of its rows: they are converging now, look again after one more iteration
     for (;;) {
-        int next = h->repack_iters == 0 ? full : (it == 0 ? first : it * 2);
+        int next = h->repack_iters == 0 ? full : (it == 0 ? first : thinning ? it + 1 : it * 2);
         if (next > full || next <= it) next = full;
         // (a compacted pass reaches the caller's decoding / llr rows through its row list; its iteration counts and flags go by the pass's own rows)
         int32_t *o_it = identity ? iters : (int32_t *)h->rp_iters.p;
         uint8_t *o_cv = identity ? conv : (uint8_t *)h->rp_conv.p;
-        if ((rc = serial_stream_launch(h, sp, it, next, resume, (double *)state->p, cur_synd, R, identity ? nullptr : (const int32_t *)lists[cur]->p, decoding, llr, o_it, o_cv))) return rc;
+        const int waves_cap = !identity && h->sw("SER_WAVES2") > 0 ? h->sw("SER_WAVES2") : 16;  // (workgroups of 8 for a second pass of 257 .. 512 tiles measured slower than a second round of 16)
+        if ((rc = serial_stream_launch(h, sp, it, next, resume, (double *)state->p, cur_synd, R, identity ? nullptr : (const int32_t *)lists[cur]->p, decoding, llr, o_it, o_cv, waves_cap))) return rc;
         if (!identity && (rc = scatter_out((const int32_t *)lists[cur]->p, R, false))) return rc;
         if (next >= full) break;
         // the rows of this pass that are still decoding: listed (numbers within the pass) and counted
@@ -831,6 +835,7 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
         const int32_t *sub = (const int32_t *)h->osd_list.p;
         const size_t C = (size_t)cnt;
         const bool to_lanes = cnt <= lane_max;
+        thinning = cnt * 10 <= R * 4;
         if (!to_lanes && cnt * 10 > R * 6) { resume = true; continue; }  // most rows are still decoding: the same tiles carry on
         // the rows that go on: their numbers in the caller's arrays, their syndromes
         const int nxt = cur ^ 1;

@@ -32,20 +32,18 @@ def main():
     forms = [  # (label, serial_kernel, repack, switches, want_llr)
         ("level kernel (round 1-4)", 1, -1, (), True),
         ("streamed, one pass, 16 waves ring 1", 2, 0, (), True),
-        ("streamed, passes 4 8 16 .., 16 waves ring 1", 2, -1, (), True),
+        ("streamed, passes (default)", 2, -1, (), True),
         ("streamed, passes, no log-ratios", 2, -1, (), False),
-        ("streamed, passes, lanes never", 2, -1, (("SER_LANE_MAX", 0),), True),
-        ("streamed, passes, 8 waves ring 1", 2, -1, (("SER_WAVES", 8),), True),
-        ("streamed, passes, 8 waves ring 2", 2, -1, (("SER_WAVES", 8), ("SER_RING", 2)), True),
-        ("streamed, passes, 9 waves ring 1", 2, -1, (("SER_WAVES", 9),), True),
-        ("streamed, passes, 12 waves ring 1", 2, -1, (("SER_WAVES", 12),), True),
-        ("streamed, passes, initial messages written out", 2, -1, (("EXPLICIT_INIT", 1),), True),
-        ("streamed, first pass 3", 2, 3, (), True),
+        ("streamed, passes, later passes 8 waves", 2, -1, (("SER_WAVES2", 8),), True),
+        ("streamed, passes, lanes <= 512 rows", 2, -1, (("SER_LANE_MAX", 512),), True),
+        ("streamed, passes, lanes <= 8192 rows", 2, -1, (("SER_LANE_MAX", 8192),), True),
         ("streamed, first pass 5", 2, 5, (), True),
-        ("streamed, first pass 6", 2, 6, (), True),
+        ("streamed, first pass 3", 2, 3, (), True),
     ]
     if args.forms == "default":
         forms = forms[:1] + forms[2:4]
+    if args.forms == "one":
+        forms = forms[2:3]
     ref = None
     for label, mode, repack, switches, want_llr in forms:
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), 50, args.method, args.alpha)
