@@ -422,6 +422,7 @@ def host_io_leg(h, args, alpha, synd_dev, dec_dev, it_dev, device_value):
     dec = BpDecoder(h, error_rate=args.p, max_iter=args.max_iter, bp_method=args.bp_method, ms_scaling_factor=alpha, input_vector_type="syndrome")
     B = s_host.shape[0]
     out = {"api": "ldpc_amd.bp_decoder.BpDecoder.decode_batch((B, m) uint8 ndarray, pageable) -> (B, n) ndarray", "batch": B, "unit": "syndromes/s"}
+    dec.recycle_log_prob_ratios = True  # (this loop does not keep a call's log-ratio array: the next call may write the same page-locked memory)
     dec.decode_batch(s_host[: min(B, 4096)], want_log_prob_ratios=False)  # module load, handle, first allocations
     for key, want in (("no_llr", False), ("with_llr", True)):
         dec.decode_batch(s_host, want_log_prob_ratios=want)  # warm-up of this shape: pinned staging buffers

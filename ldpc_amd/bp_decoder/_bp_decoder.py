@@ -450,27 +450,26 @@ class BpDecoderBase:
             return cy.decode_batch(np.ascontiguousarray(synd2d, np.uint8), want_llr, osd0, llr_out)
         return self._get_engine().decode_batch(synd2d, want_llr=want_llr, osd0=osd0, llr_out=llr_out)
 
-    def _recyclable_llr(self, rows: int):
-        """The previous batch's log-ratio array, if it can take this batch's: same shape, and nobody but this object still refers to
-        it (a caller who kept ``log_prob_ratios_batch`` keeps it untouched -- then a new array is made).  At 65 536 x 10 000 the array
-        is 5.2 GB: allocating a new one each call means 1.3 million first-touch faults going in and a 0.27 s ``munmap`` of the old one."""
-        import sys
-        old = getattr(self, "log_prob_ratios_batch", None)
-        if isinstance(old, np.ndarray) and old.dtype == np.float64 and old.shape == (rows, self.n) and old.flags.c_contiguous \
-                and (old.flags.owndata or getattr(old.base, "owner", None) is not None) and old.flags.writeable \
-                and sys.getrefcount(old) <= 3:  # the attribute, `old`, getrefcount's argument (a view someone kept holds `old` as its base)
-            return old
-        return None
+    # Whether ``decode_batch`` may overwrite the log-ratio array it handed out last time (same shape).  Off by default: ownership is never
+    # inferred (reference counts are an interpreter detail -- CPython 3.14 borrows stack references, other interpreters have none).  A
+    # caller who is done with ``log_prob_ratios_batch`` when the next call starts sets this (or passes ``reuse_log_prob_ratios=True`` /
+    # its own array as ``log_prob_ratios_out``): at 65 536 x 10 000 the array is 5.2 GB, and a new one per call costs 1.3 million
+    # first-touch faults going in and a 0.27 s ``munmap`` of the old one.
+    recycle_log_prob_ratios = False
 
-    def _llr_destination(self, rows: int):
-        """Where a batch's log-ratios go: the previous batch's array if it is free (``_recyclable_llr``); else, ONCE per decoder and
-        shape and only for arrays of 256 MiB and more, a new array on page-locked memory (``ldpc_hip_host_alloc``) -- the device-to-host
-        copies then write it directly, with no staging buffer and no host-side copy (include/ldpc_hip.h), and the next call recycles
-        it; else None (the backend makes an ordinary array).  A caller who keeps every batch's array gets ordinary arrays from the
-        second call on: page-locked memory is not something to allocate per call."""
-        out = self._recyclable_llr(rows)
+    def _llr_destination(self, rows: int, out=None, reuse=None):
+        """Where a batch's log-ratios go: the caller's array; else the previous batch's array if the caller SAID it may be overwritten;
+        else, once per decoder and shape and only for arrays of 256 MiB and more, a new array on page-locked memory
+        (``ldpc_hip_host_alloc``: the device-to-host copies write it directly, no staging buffer, no host-side copy); else None (the
+        backend makes an ordinary array)."""
         if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (rows, self.n) and out.flags.c_contiguous and out.flags.writeable):
+                raise ValueError(f"log_prob_ratios_out must be a writeable C-contiguous float64 array of shape ({rows}, {self.n}).")
             return out
+        if self.recycle_log_prob_ratios if reuse is None else reuse:
+            old = getattr(self, "log_prob_ratios_batch", None)
+            if isinstance(old, np.ndarray) and old.dtype == np.float64 and old.shape == (rows, self.n) and old.flags.c_contiguous and old.flags.writeable:
+                return old
         nbytes = rows * self.n * 8
         if nbytes >= (256 << 20) and getattr(self, "_pinned_llr_shape", None) != (rows, self.n):
             self._pinned_llr_shape = (rows, self.n)
@@ -579,8 +578,12 @@ class BpDecoder(BpDecoderBase):
         return out.astype(dtype)
 
     # ---- batch (additive) -----------------------------------------------------------------------
-    def decode_batch(self, input_vectors, want_log_prob_ratios: bool = True):
+    def decode_batch(self, input_vectors, want_log_prob_ratios: bool = True, *, log_prob_ratios_out=None, reuse_log_prob_ratios=None):
         """Decode every row of a 2-D array in one launch.
+
+        ``log_prob_ratios_out`` (NumPy inputs): a ``(B, n)`` float64 C-contiguous array that receives the log-ratios;
+        ``reuse_log_prob_ratios=True`` (or the attribute ``recycle_log_prob_ratios``): the array the previous call handed out as
+        ``log_prob_ratios_batch`` may be overwritten by this one -- nothing is reused unless the caller says so.
 
         ``input_vectors``: ``(B, m)`` syndromes or ``(B, n)`` received vectors (same rule as
         ``decode``), NumPy array (any integer dtype; result has the same dtype) or a torch CUDA uint8
@@ -633,7 +636,7 @@ class BpDecoder(BpDecoderBase):
             scan.start()
         try:
             dec, llr, it, cv = self._decode_numpy(synd, want_llr=want_log_prob_ratios,
-                                                  llr_out=self._llr_destination(len(synd)) if want_log_prob_ratios else None)
+                                                  llr_out=self._llr_destination(len(synd), log_prob_ratios_out, reuse_log_prob_ratios) if want_log_prob_ratios else None)
         finally:
             if scan is not None:
                 scan.join()

@@ -213,6 +213,11 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     auto finish = [&](int code) {  // (every exit: the helper must be gone before its captures are)
         if (code) stop.store(true, std::memory_order_release);
         drainer.join();
+        if (code) {  // a failed call leaves no copy in flight: the next call reuses the slots, their staging buffers and their events
+            (void)hipStreamSynchronize(P.s_in);
+            (void)hipStreamSynchronize(P.s_out);
+            (void)hipGetLastError();
+        }
         return code;
     };
 #define PIPECHK(expr)                                                                                                            \

@@ -368,7 +368,12 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     h->keep_state = false;
     h->max_iter = full;
     if (rc) return rc;
-    if (h->last_chunk_tiles < tiles1) return fail(LDPC_HIP_ERR_DEVICE, "internal: the first pass of a compacted decode was chunked");
+    if (h->last_chunk_tiles < tiles1) {
+        // the first pass was cut into chunks after all (free memory moved between the estimate above and decode_device's own): its message
+        // state is not resident at once, so there is nothing to compact -- decode the batch plainly (same results; the first pass's work is lost)
+        if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false))) return rc;
+        return stream_leave_histogram(h, iters, conv, batch);
+    }
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
     if ((rc = h->osd_counters.ensure(4 * sizeof(unsigned)))) return rc;
     HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 4 * sizeof(unsigned), h->stream));

@@ -66,9 +66,9 @@ def test_bpdecoder_numpy_batch_is_the_pipelined_path_and_keeps_the_shortcut(orac
     assert np.array_equal(out, ref.cpu().numpy())
 
 
-def test_log_ratio_array_is_recycled_only_when_nobody_else_holds_it(oracle_built):
-    """`log_prob_ratios_batch` of the previous call takes the next call's log-ratios when this decoder object is its only owner (at
-    65 536 x 10 000 a new 5.2 GB array per call costs more than the PCIe transfer); an array the caller kept is never written again."""
+def test_log_ratio_array_is_reused_only_when_the_caller_says_so(oracle_built):
+    """`log_prob_ratios_batch` of the previous call is overwritten by the next one only on request (`reuse_log_prob_ratios=True`, the
+    attribute `recycle_log_prob_ratios`, or the caller's own `log_prob_ratios_out`): ownership is never inferred from reference counts."""
     from ldpc_amd import codes
     from ldpc_amd.bp_decoder import BpDecoder
     h = codes.regular_ldpc_code(600, 3, 6, seed=2)
@@ -79,15 +79,26 @@ def test_log_ratio_array_is_recycled_only_when_nobody_else_holds_it(oracle_built
     dec.decode_batch(s1)
     first_addr = dec.log_prob_ratios_batch.ctypes.data
     want1 = dec.log_prob_ratios_batch.copy()
-    dec.decode_batch(s2)                                   # nobody kept the first array: its memory takes the second batch
-    assert dec.log_prob_ratios_batch.ctypes.data == first_addr
+    dec.decode_batch(s2)                                   # by default a new array, whoever holds the old one
+    assert dec.log_prob_ratios_batch.ctypes.data != first_addr or True  # (the allocator may hand the freed block out again)
     want2 = dec.log_prob_ratios_batch.copy()
     kept = dec.log_prob_ratios_batch                       # the caller keeps the second array ...
     dec.decode_batch(s1)
-    assert dec.log_prob_ratios_batch.ctypes.data != kept.ctypes.data and bits_equal(kept, want2)   # ... and it stays what it was
+    assert dec.log_prob_ratios_batch is not kept and bits_equal(kept, want2)   # ... and it stays what it was
     assert bits_equal(dec.log_prob_ratios_batch, want1)
+    addr = dec.log_prob_ratios_batch.ctypes.data
+    dec.decode_batch(s2, reuse_log_prob_ratios=True)       # on request: the same memory takes the next batch
+    assert dec.log_prob_ratios_batch.ctypes.data == addr and bits_equal(dec.log_prob_ratios_batch, want2)
+    dec.recycle_log_prob_ratios = True
+    dec.decode_batch(s1)
+    assert dec.log_prob_ratios_batch.ctypes.data == addr and bits_equal(dec.log_prob_ratios_batch, want1)
     dec.decode_batch(s2[:100])                             # another shape: a new array
     assert dec.log_prob_ratios_batch.shape == (100, 600) and bits_equal(dec.log_prob_ratios_batch, want2[:100])
+    mine = np.full((300, 600), np.nan)
+    dec.decode_batch(s2, log_prob_ratios_out=mine)         # the caller's own array
+    assert dec.log_prob_ratios_batch is mine and bits_equal(mine, want2)
+    with pytest.raises(ValueError):
+        dec.decode_batch(s2, log_prob_ratios_out=np.zeros((300, 599)))
 
 
 def test_log_ratios_into_page_locked_memory_take_the_direct_route(oracle_built):
@@ -121,8 +132,9 @@ def test_log_ratios_into_page_locked_memory_take_the_direct_route(oracle_built):
 
 
 def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracle_built):
-    """`BpDecoder.decode_batch(numpy)`: the first large batch gets its log-ratio array on page-locked memory and the next call recycles
-    it; a caller who keeps the array gets an ordinary one next time (no page-locked allocation per call)."""
+    """`BpDecoder.decode_batch(numpy)`: the first large batch gets its log-ratio array on page-locked memory; a caller who says so
+    (`reuse_log_prob_ratios`) has the next call write the same memory, everybody else gets an ordinary array next time (no page-locked
+    allocation per call)."""
     from ldpc_amd import codes
     from ldpc_amd.bp_decoder import BpDecoder
     h = codes.regular_ldpc_code(3000, 3, 6, seed=2)
@@ -136,7 +148,7 @@ def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracl
     want = a1.copy()
     addr = a1.ctypes.data
     del a1
-    out2 = dec.decode_batch(s)
+    out2 = dec.decode_batch(s, reuse_log_prob_ratios=True)
     assert dec.log_prob_ratios_batch.ctypes.data == addr and bits_equal(dec.log_prob_ratios_batch, want) and np.array_equal(out1, out2)
     kept = dec.log_prob_ratios_batch
     dec.decode_batch(s)

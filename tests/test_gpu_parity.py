@@ -803,3 +803,75 @@ def test_streaming_variants_for_other_regular_codes(dv, dc, oracle_built):
             got = eng.decode_batch(synd)
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
             assert bits_equal(got[1], want[1])
+
+
+# ---- every output element is written (the result arrays are np.empty / torch.empty: ADVICE round 4) ------------------------------------
+
+def _poisoned_outputs(b, n):
+    import torch
+    dec = torch.full((b, n), 0xAB, dtype=torch.uint8, device="cuda")
+    llr = torch.full((b, n), -1.2345678e300, dtype=torch.float64, device="cuda")  # (NaN would not do: inf - inf is a legitimate log-ratio)
+    it = torch.full((b,), -12345, dtype=torch.int32, device="cuda")
+    cv = torch.full((b,), 0xAB, dtype=torch.uint8, device="cuda")
+    return dec, llr, it, cv
+
+
+@pytest.mark.parametrize("path", ["streamed", "streamed_two_pass", "spread", "wave_ps", "edge", "wave", "small", "serial_level", "serial_walk", "serial_stream",
+                                  "serial_lanes", "serial_relative", "serial_relative_per_lane", "random_serial", "osd0", "osd_cs"])
+def test_no_output_element_is_left_unwritten(path):
+    """Outputs pre-filled with a poison pattern come back without it on every kernel path (a path that skipped rows would hand out
+    uninitialised memory: the result arrays are not zero-filled)."""
+    import torch
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd import codes
+    cfg = {
+        "streamed": (codes.regular_ldpc_code(1200, 3, 6, seed=3), 0.07, 12, 0, 1.0, 70000),
+        "streamed_two_pass": (codes.regular_ldpc_code(1200, 3, 6, seed=3), 0.04, 30, 0, 1.0, 40000),
+        "spread": (codes.regular_ldpc_code(1200, 3, 6, seed=3), 0.07, 12, 0, 1.0, 333),
+        "wave_ps": (codes.bivariate_bicycle_hx(), 0.05, 20, 0, 1.0, 1000),
+        "edge": (codes.rotated_surface_code_x(9), 0.05, 15, 1, 0.625, 1000),
+        "wave": (codes.bivariate_bicycle_hx(), 0.05, 20, 1, 0.8, 1000),
+        "small": (codes.hamming_code(6), 0.03, 10, 0, 1.0, 300),
+        "serial_level": (codes.bivariate_bicycle_hx(), 0.06, 20, 0, 1.0, 1000),
+        "serial_walk": (codes.bivariate_bicycle_hx(), 0.06, 20, 1, 0.7, 1000),
+        "serial_stream": (codes.regular_ldpc_code(1800, 3, 6, seed=9), 0.07, 20, 0, 1.0, 5000),
+        "serial_lanes": (codes.regular_ldpc_code(1800, 3, 6, seed=9), 0.07, 20, 1, 0.8, 77),
+        "serial_relative": (codes.bivariate_bicycle_hx(), 0.06, 12, 0, 1.0, 700),
+        "serial_relative_per_lane": (codes.bivariate_bicycle_hx(), 0.06, 12, 1, 0.8, 300),
+        "random_serial": (codes.bivariate_bicycle_hx(), 0.06, 12, 0, 1.0, 500),
+        "osd0": (codes.bivariate_bicycle_hx(), 0.06, 10, 0, 1.0, 900),
+        "osd_cs": (codes.bivariate_bicycle_hx(), 0.06, 10, 1, 0.625, 900),
+    }[path]
+    h, p, max_iter, method, alpha, b = cfg
+    m, n = h.shape
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
+    kw = {}
+    if path in ("streamed", "streamed_two_pass", "spread"):
+        eng.set_small_code_kernel(0)
+    if path == "small":
+        eng.set_small_code_kernel(2)
+    if path.startswith("serial_") and not path.startswith("serial_relative"):
+        eng.set_schedule("serial")
+        eng.set_serial_kernel({"serial_level": 1, "serial_walk": 0, "serial_stream": 2, "serial_lanes": 2}[path])
+    if path.startswith("serial_relative"):
+        eng.set_schedule("serial_relative")
+        if path.endswith("per_lane"):
+            eng.set_debug_switch("REL_LDS", 0)
+    if path == "random_serial":
+        eng.set_schedule("serial")
+        eng.set_random_serial(True, 5)
+    if path == "osd0":
+        kw["osd0"] = True
+    if path == "osd_cs":
+        eng.set_osd(3, 5)
+        kw["osd"] = True
+    s = eng.gen_bsc_syndromes(3, p, shot0=0, shots=b, device="cuda:0")
+    for rep in range(2):  # (the second call of the streamed path is steered by the first one's histogram: two passes)
+        out = _poisoned_outputs(b, n)
+        dec, llr, it, cv = eng.decode_batch(s, out=out, **kw)
+        torch.cuda.synchronize()
+        assert int((dec > 1).sum()) == 0, path
+        assert int((cv > 1).sum()) == 0, path
+        assert int((it < 0).sum()) == 0 and int((it > max(max_iter, 0)).sum()) == 0, path
+        assert int((llr == -1.2345678e300).sum()) == 0, path
+    eng.close()
