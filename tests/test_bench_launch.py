@@ -86,3 +86,24 @@ def test_a_failing_rank_leaves_one_json_error_line():
         got = json.loads(lines[0])
         assert got["value"] is None and "error" in got and got["n_gpus"] == 2
         assert got["rccl"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and got["rccl"]["ranks"] == 2
+
+
+def test_eight_ranks_as_the_driver_launches_them():
+    """`--gpus 8`: the launch the driver's scaling run uses -- eight ranks of one group (gloo here), each with its shard's geometry:
+    rank r of 8 holds rows [r B/8, (r + 1) B/8) of configs[3]'s 1 048 576."""
+    r = _torchrun(["--dry-ranks"], nproc=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    got = json.loads(lines[0])
+    assert got["world"] == 8 and sorted(d["rank"] for d in got["dry_ranks"]) == list(range(8))
+    assert len({d["pid"] for d in got["dry_ranks"]}) == 8
+    assert sorted(d["local_rank"] for d in got["dry_ranks"]) == list(range(8))
+    from ldpc_amd.sharding import shard_range
+    B = 1048576
+    cuts = [shard_range(B, rank, 8) for rank in range(8)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == B and all(b - a == 131072 for a, b in cuts) and all(cuts[k][1] == cuts[k + 1][0] for k in range(7))
+    r2 = _run(["--gpus", "8", "--dry-ranks"])  # and bench.py's own launcher
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    got2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert got2["world"] == 8 and len({d["pid"] for d in got2["dry_ranks"]}) == 8

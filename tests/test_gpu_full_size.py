@@ -218,3 +218,54 @@ def test_irregular_code_on_the_generic_degree_streamed_kernels(method, alpha, or
     small = eng.decode_batch(s[:300].contiguous(), want_llr=True)  # five tiles: per-pass kernels from the first iteration
     assert np.array_equal(small[0].cpu().numpy(), want[0][:300]) and bits_equal(small[1].cpu().numpy(), want[1][:300])
     eng.close()
+
+
+def test_config4_full_batch_one_gpu(oracle_built):
+    """BASELINE configs[3]'s WHOLE batch -- 1 048 576 syndromes of the (3,6)-regular n = 10 000 code, product_sum, 50 iterations, p = 0.09 --
+    in ONE decode_batch on one GPU: 504 GB of messages, so the memory-driven chunk loop of decode_device (hipMemGetInfo) cuts it into
+    several chunks of thousands of tiles.  flag <=> H x == s on every row; rows [0, 131 072) -- the first GPU's share of the eight --
+    equal to a decode of that share alone (decisions, iteration counts, flags), an oracle subset from both ends of the batch."""
+    import torch
+    from ldpc_amd.codes import regular_ldpc_code
+    from ldpc_amd.engine import HipBpEngine
+    dev = torch.device("cuda", 0)
+    p = 0.09
+    h = regular_ldpc_code(10000, 3, 6, seed=1)
+    eng = HipBpEngine(h.indptr, h.indices, 10000, np.full(10000, p), 50, 0, 1.0)
+    B, share = 1048576, 131072
+    synd = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+    dec, _, it, cv = eng.decode_batch(synd, want_llr=False)
+    torch.cuda.synchronize()
+    tiles, per_tile = B // 64, 2 * 30000 * 64 * 8
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert tiles * per_tile > total_b, "the batch's messages must not fit the GPU at once (else this is not the chunk loop)"
+    for lo in range(0, B, share):  # (H x for 131 072 rows at a time: the residual of the whole batch is another 5 GB)
+        sl = slice(lo, lo + share)
+        cvb = _check_flags_against_syndromes(eng, synd[sl], dec[sl], cv[sl], it[sl], 50)
+        assert cvb.float().mean().item() < 0.05
+    d1, _, i1, c1 = eng.decode_batch(synd[:share].contiguous(), want_llr=False)
+    assert bool(torch.equal(d1, dec[:share])) and bool(torch.equal(i1, it[:share])) and bool(torch.equal(c1, cv[:share]))
+    rows = torch.from_numpy(np.r_[0:6, B // 2 - 3:B // 2 + 3, B - 6:B]).to(dev)
+    _subset_vs_oracle(oracle_built, h, p, 50, "product_sum", 1.0, synd, dec, it, cv, None, rows)
+    eng.close()
+
+
+def test_eight_shards_on_one_device_equal_the_single_handle():
+    """ldpc_hip_bp_multi with the device listed eight times: eight handles, eight host threads, eight shards of 8 192 rows of configs[1]'s
+    stream -- what an eight-GPU node runs in one process, on the one GPU of this box -- against the single-handle decode of the 65 536 rows."""
+    import torch
+    from ldpc_amd.codes import regular_ldpc_code
+    from ldpc_amd.engine import HipBpEngine, HipBpMultiEngine
+    dev = torch.device("cuda", 0)
+    p = 0.05
+    h = regular_ldpc_code(10000, 3, 6, seed=1)
+    one = HipBpEngine(h.indptr, h.indices, 10000, np.full(10000, p), 50, 0, 1.0)
+    many = HipBpMultiEngine(h.indptr, h.indices, 10000, np.full(10000, p), 50, 0, 1.0, [0] * 8)
+    B = 8 * 8192
+    synd = one.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+    a = one.decode_batch(synd, want_llr=True)
+    b = many.decode_batch(synd, want_llr=True)
+    assert bool(torch.equal(a[0], b[0])) and bool(torch.equal(a[2], b[2])) and bool(torch.equal(a[3], b[3]))
+    same = (a[1].view(torch.int64) == b[1].view(torch.int64)) | (a[1].isnan() & b[1].isnan())
+    assert bool(same.all())
+    assert len(many.last_kernel_ms()) == 8
