@@ -212,6 +212,13 @@ int ldpc_hip_bposd_get_status(ldpc_hip_bp *h, uint8_t *status, int64_t batch);
  * repacking a first pass of `first_pass_iters` iterations runs over the whole batch and the rows it leaves unconverged are
  * packed into dense tiles and decoded again from the start with the full max_iter (deterministic: same results).
  * -1 = automatic (max_iter / 8, default), 0 = off.  With repacking the call waits once for the device.
+ * The STREAMED serial kernels (ldpc_hip_bp_set_serial_kernel: (3,6)-regular-shaped matrices beyond LDS, e.g. the n = 10 000 code)
+ * decode in PASSES and never start again: the first pass ends after first_pass_iters iterations (-1 = automatic: 4), the next after
+ * twice as many -- or, when a pass left less than 40 % of its rows, after one more iteration.  After a pass the rows still decoding
+ * are counted (the call waits for the device once per pass) and either carry on in their tiles (most rows left), or have their
+ * message state compacted, lane by lane, into dense tiles, or -- 2048 rows and fewer -- finish a workgroup per syndrome
+ * (bp_serial_lane_kernel: the one hopeless syndrome of a batch costs milliseconds instead of keeping a 64-syndrome tile on one
+ * compute unit for max_iter iterations).  0 = one pass.  Same results whatever the passes (tests/test_gpu_serial_stream.py).
  * The streamed parallel schedule (codes too large for the on-chip kernels, batches of >= 32768 syndromes) cuts a decode in two
  * as well, but CARRIES ON instead of starting again: after the first pass the message state of the unconverged rows is
  * gathered, lane by lane, out of the first pass's 64-syndrome tiles into dense tiles and the second pass continues from
@@ -229,7 +236,15 @@ int ldpc_hip_bp_set_repack(ldpc_hip_bp *h, int32_t first_pass_iters);
 /* Serial schedule kernels: bits that share no check commute, so the schedule is cut into levels of mutually check-disjoint
  * bits (level = 1 + the highest level among the EARLIER bits sharing a check) and a workgroup runs a tile level by level
  * with its wavefronts sharing each level's bits -- same results as the bit-by-bit walk.  -1 = automatic (level-parallel
- * when a level holds >= 2 bits on average), 0 = one wavefront walks the tile bit by bit, 1 = always level-parallel. */
+ * when a level holds >= 2 bits on average; STREAMED -- below -- where the matrix allows it and a level holds >= 32 bits),
+ * 0 = one wavefront walks the tile bit by bit, 1 = always level-parallel (never streamed), 2 = streamed whenever the matrix allows
+ * it.  Streamed (csrc/bp_serial_stream_kernel.h; matrices with one row weight 6 and one column weight 3): the level-parallel
+ * form with the message traffic of the flooding kernel -- one record per position of the level-major order (the 15 segments to
+ * fetch, the 3 to write, the bit) read through the scalar cache two steps ahead, the segments of the next position in flight into
+ * a per-wavefront LDS ring (buffer_load ... lds, counted waits), no initial messages in memory (entries nobody has written yet
+ * are the same in all lanes: a per-position table), a decode in passes (ldpc_hip_bp_set_repack) and, for a handful of syndromes
+ * (what a pass leaves, or a batch of <= 256), a workgroup per syndrome with the level's bits across the lanes.  The n = 10 000
+ * code at p = 0.05, B = 65 536: 171 k -> 692 k syndromes/s; its first pass moves 5.1 TB/s (profiles/r5_serial_stream_summary.txt). */
 int ldpc_hip_bp_set_serial_kernel(ldpc_hip_bp *h, int32_t mode);
 /* Where the elimination keeps [H | s]: -1 = automatic (in the wavefront's registers when m <= 256 and n <= 511, else
  * one wavefront per syndrome with [H | s] bit-packed in LDS while four of them fit a CU, else one workgroup per syndrome
