@@ -705,8 +705,14 @@ def run(args, real_stdout, stage) -> None:
                 # match) x this run's edge-iterations, against the issue turns of 1024 SIMDs at THIS run's clock over THIS run's kernel time
                 per = float(vj["valu_insts_per_edge_iteration"])
                 wave_insts = float(iters.astype(np.float64).sum()) * nnz * per / 64.0
-                second = {"kind": "fp64_valu", "issue_frac": wave_insts * 4.0 / (SIMDS * clock_run * 1e9 * k_ms * 1e-3),
-                          "clock_ghz_this_run": clock_run, "sclk_sysfs_ghz": sclk.ghz(), "insts_per_edge_iter": per,
+                turns = SIMDS * clock_run * 1e9 * k_ms * 1e-3
+                f64_per = float(vj.get("fp64_arith_insts_per_edge_iteration") or 0.0)
+                second = {"kind": "fp64_valu", "issue_frac": wave_insts * 4.0 / turns,
+                          # the same count with FP64 arithmetic at 4 cycles and everything else (selects, moves, compares, integer work) at 2: a LOWER
+                          # bound of the occupancy; the hardware's own figure of the profiled run is valu_busy_frac_in_profile
+                          "issue_frac_fp64_at_4_others_at_2": (wave_insts * (f64_per / per) * 4.0 + wave_insts * (1.0 - f64_per / per) * 2.0) / turns if f64_per else None,
+                          "valu_busy_frac_in_profile": vj.get("valu_busy_frac"),
+                          "clock_ghz_this_run": clock_run, "sclk_sysfs_ghz": sclk.ghz(), "insts_per_edge_iter": per, "fp64_arith_insts_per_edge_iter": f64_per or None,
                           "issue_frac_in_profile": vj.get("valu_issue_frac"), "clock_ghz_in_profile": vj.get("clock_ghz"),
                           "source": "instructions per edge-iteration: profiles/valu_clock.json (SQ_INSTS_VALU of this workload); clock: shader cycles / "
                                     "constant-rate ticks summed over the persistent kernel's workgroups during the timed steps (ldpc_hip_bp_clock_probe); "

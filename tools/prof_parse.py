@@ -106,10 +106,18 @@ if n_dec and "GRBM_GUI_ACTIVE" in sums and "SQ_INSTS_VALU" in sums:
            "dominant_kernel_ms_in_that_pass": dom_ns["GRBM_GUI_ACTIVE"] / n_dec / 1e6,
            "formulae": "clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same pass; issue = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x cycles)",
            "source": root, **key}
+    # What the hardware says about the same thing: SQ_ACTIVE_INST_VALU = quad-cycles the vector units spent executing (a wave64 instruction
+    # holds its 16-lane SIMD for four cycles whatever its width; v_rcp_f64 and friends longer), against the quad-cycles the 1024 SIMDs offered
+    if "SQ_ACTIVE_INST_VALU" in sums and "GRBM_GUI_ACTIVE" in sums:
+        out["valu_busy_frac"] = sums["SQ_ACTIVE_INST_VALU"]["dom"] * 4.0 / (SIMDS * cycles_per_xcd)
+        out["valu_busy_formula"] = "SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), dominant kernel"
+    f64 = sum(sums[k]["all"] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64") if k in sums) / n_dec
     if bench:
         c = bench["config"]
         wave_edge_iters = 30000.0 * c["mean_iterations"] * c["batch_per_gpu"] / 64.0  # E x iterations x 64-syndrome tiles
         out["valu_insts_per_edge_iteration"] = valu_all / wave_edge_iters
+        if f64 > 0:
+            out["fp64_arith_insts_per_edge_iteration"] = f64 / wave_edge_iters  # add / mul / fma F64 (the rest: selects, moves, compares, conversions, integer field work)
     print(f"# dominant kernel: effective clock {clock_ghz:.3f} GHz, VALU issue {issue:.3f} of the SIMD cycles on offer, "
           f"{out.get('valu_insts_per_edge_iteration', float('nan')):.1f} VALU instructions per edge-iteration (all BP kernels)")
     if outdir:
