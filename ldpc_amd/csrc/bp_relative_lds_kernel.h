@@ -160,20 +160,22 @@ __device__ inline void heapsort_t(const CTX &x, long first, long last) {  // __p
         adjust_heap_t(x, first, 0, last - first, value);
     }
 }
-// the whole std::sort, sequentially (NaN keys: as bp_serial_relative_kernel does it, loops bounded by their range)
+// the whole std::sort, sequentially (NaN keys: as bp_serial_relative_kernel does it, loops bounded by their range).  `stk`: room for the
+// ranges still to do, three 16-bit words each, never more than 2 log2 n + 2 of them (the depth budget) -- in LDS: as a private array
+// (3 x 48 ints, indexed by the stack pointer) it was 576 of the kernel's 640 - 800 bytes of scratch per lane, in every instantiation,
+// for a path that runs when a key is NaN.
 template <class CTX>
-__device__ inline void sort_desc_seq(const CTX &x, long n) {
+__device__ inline void sort_desc_seq(const CTX &x, long n, rel_lds::l_u16 *stk) {
     if (n <= 0) return;
     int depth = 0;
     for (long q = n; q > 1; q >>= 1) depth++;
     depth *= 2;
-    int stack_first[48], stack_last[48], stack_depth[48];
     int sp = 1;
-    stack_first[0] = 0; stack_last[0] = (int)n; stack_depth[0] = depth;
+    stk[0] = 0; stk[1] = (uint16_t)n; stk[2] = (uint16_t)depth;
     while (sp > 0) {
         --sp;
-        long first = stack_first[sp], last = stack_last[sp];
-        int d = stack_depth[sp];
+        long first = stk[3 * sp], last = stk[3 * sp + 1];
+        int d = stk[3 * sp + 2];
         while (last - first > 16) {
             if (d == 0) { heapsort_t(x, first, last); break; }
             --d;
@@ -200,7 +202,7 @@ __device__ inline void sort_desc_seq(const CTX &x, long n) {
                 x.swap(f, l);
                 ++f;
             }
-            stack_first[sp] = (int)cut; stack_last[sp] = (int)last; stack_depth[sp] = d; ++sp;
+            stk[3 * sp] = (uint16_t)cut; stk[3 * sp + 1] = (uint16_t)last; stk[3 * sp + 2] = (uint16_t)d; ++sp;
             last = cut;
         }
     }
@@ -371,7 +373,7 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
     // sequential restatement (what the per-lane kernel and the CPU checker run)
     const bool nan = n <= 256 ? dense_ranks<4>(key, n, lane, rank) : n <= 512 ? dense_ranks<8>(key, n, lane, rank) : dense_ranks_counting(key, n, lane, rank);
     if (nan) {
-        if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n); }
+        if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n, reinterpret_cast<l_u16 *>(v)); }  // (v: 4 n bytes, not yet in use; the stack needs 6 (2 log2 n + 2) for n > 16, 6 below)
         lds_sync();
         return;
     }

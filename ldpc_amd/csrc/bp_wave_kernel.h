@@ -65,7 +65,8 @@ __host__ __device__ inline size_t wave_lds_private(int mp, int np, int DR, bool 
 template <int METHOD, int MATH, int DR, int DC, bool TEAM = false>
 __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
     // nodes per lane in flight: min-sum has few live values per node, the transcendental chains of product-sum many
-    constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? 4 : DR <= 8 ? 2 : 1) : (DR <= 6 ? 2 : 1);
+    // (four nodes of four / two of eight entries each spilled 62 / 38 VGPRs in the bit pass: heavier columns take fewer nodes per lane)
+    constexpr int U = METHOD == LDPC_HIP_MINIMUM_SUM ? (DR <= 4 ? (DC <= 2 ? 4 : 2) : DR <= 8 ? (DC <= 4 ? 2 : 1) : 1) : (DR <= 6 ? 2 : 1);
     // (a team has more wavefronts than the check pass has rounds of 64 U rows -- there are half as many rows as columns --: one row
     // per lane there, so that twice as many wavefronts take part)
     constexpr int UC = TEAM ? 1 : U;
