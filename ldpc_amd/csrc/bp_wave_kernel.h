@@ -326,6 +326,14 @@ struct WavePsArgs {
     int32_t lds_shared, lds_per_wave;
     int32_t min_rdeg;        // lightest row (a row of weight 1 has x = the empty product 1: q = 2 / 0, generic path only)
     unsigned long long *clk; // shader-clock probe (clock_probe_*, bp_device_common.h) or nullptr
+    // RESIDENT form (TEAM, one workgroup, batch = 1; host_onchip.h: decode_onchip_resident): the workgroup does not leave after its
+    // syndrome but waits for the next one -- the caller's `for shot: decode(shot)` loop finds the kernel there, tables in LDS, and a
+    // decode costs neither a launch nor a completion.  mail: four 32-bit words in the host-mapped block the syndrome and the results
+    // live in -- [0] request number (host writes), [1] the last request served (device writes, after the results), [2] alive (host
+    // sets 1 before the launch, the device 0 when it leaves), [3] quit (host: leave now).  The workgroup leaves by itself after
+    // linger_ticks (100 MHz) without a request: it can never spin for good.
+    unsigned *mail;
+    unsigned served0, linger_ticks;
 };
 
 #define LDPC_PS_NEAR_SLOTS 64  // entries whose log argument is near 1, listed per wavefront and iteration (see check B)
@@ -355,6 +363,8 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
     const int wt = TEAM ? wave : 0, W = TEAM ? T >> 6 : 1;
     __shared__ int team_unsat[2];
     __shared__ long long team_b;
+    __shared__ unsigned team_req;   // resident form: the request being served, and whether the workgroup leaves after it
+    __shared__ int team_leaving;
     __shared__ unsigned long long clk_stamp[2];
     if (threadIdx.x == 0) clock_probe_begin(clk_stamp);
     auto team_sync = [&]() { if (TEAM) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
@@ -364,6 +374,7 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
     typedef __attribute__((address_space(3))) double lds_f64;
     typedef __attribute__((address_space(3))) uint16_t lds_u16;
     lds_u8 *base = (lds_u8 *)wv_lds;
+    unsigned served = a.served0;
     // shared: [log table][llr0 np + 2][edge form of llr0 np + 2][col][epos][rdeg]
     lds_f64 *log_tab_l = (lds_f64 *)base;
     const double *log_tab = reinterpret_cast<const double *>(wv_lds);
@@ -415,7 +426,32 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
     bool first_turn = true;
     for (;;) {
         int64_t b;
-        if (TEAM && a.next == nullptr) {  // no more syndromes than teams (a single decode()): team g takes syndrome g, no counter to reset or visit
+        if (TEAM && a.mail) {  // resident: wait for the next request (see WavePsArgs::mail)
+            if (tid == 0) {
+                const unsigned long long t_idle = (unsigned long long)__builtin_readsteadycounter();
+                unsigned r;
+                int leaving = 0;
+                for (;;) {
+                    r = __hip_atomic_load(a.mail + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (r != served) break;
+                    if (__hip_atomic_load(a.mail + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ||
+                        (unsigned long long)__builtin_readsteadycounter() - t_idle > (unsigned long long)a.linger_ticks) {
+                        // leaving: say so FIRST, then look once more -- a request posted while this was being decided is either seen here and
+                        // served, or its poster sees alive == 0 (store / load on both sides: one of the two must see the other)
+                        __hip_atomic_store(a.mail + 2, 0u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                        r = __hip_atomic_load(a.mail + 0, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                        leaving = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                team_req = r;
+                team_leaving = leaving;
+                team_b = r != served ? 0ll : (long long)a.batch;
+            }
+            __syncthreads();
+            b = team_b;
+        } else if (TEAM && a.next == nullptr) {  // no more syndromes than teams (a single decode()): team g takes syndrome g, no counter to reset or visit
             b = first_turn ? (int64_t)blockIdx.x : a.batch;
             first_turn = false;
         } else if (TEAM) {  // (a team pulls rarely: the first counter alone, which keeps the pool logic's registers out of this form)
@@ -548,6 +584,14 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
         if (tl == 0) {
             if (a.iters) a.iters[b] = it;
             if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
+        }
+        if (TEAM && a.mail) {  // resident: the results are in the host's memory -- then, and only then, the request counts as served
+            __threadfence_system();
+            __syncthreads();
+            served = team_req;
+            const bool leaving = team_leaving != 0;
+            if (tid == 0) __hip_atomic_store(a.mail + 1, served, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (leaving) break;
         }
         team_sync();
     }

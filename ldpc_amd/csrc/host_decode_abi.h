@@ -288,7 +288,7 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
     // and their completion cost more than the kernels.  The kernels work in a host-mapped block instead.
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_dec = up16(B * m), o_llr = o_dec + up16(B * n), o_it = o_llr + up16(B * n * 8), o_cv = o_it + up16(B * 4), pin_need = o_cv + up16(B);
-    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && pin_need <= ldpc_hip_bp::PIN_BYTES && !h->on("NO_PINNED_PATH")) {
+    if (h_synd && h_dec && (!llr || h_llr) && (!iters || h_it) && (!conv || h_cv) && pin_need <= ldpc_hip_bp::PIN_MAIL && !h->on("NO_PINNED_PATH")) {
         if (!h->pin_host) {
             if (hipHostMalloc((void **)&h->pin_host, ldpc_hip_bp::PIN_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&h->pin_dev, h->pin_host, 0) != hipSuccess) {
@@ -305,6 +305,17 @@ static int decode_batch_staged(ldpc_hip_bp *h, int osd, const uint8_t *synd, int
             double *p_llr = (llr || osd >= 0) ? (double *)(dv + o_llr) : nullptr;
             uint8_t *p_cv = (conv || osd >= 0) ? (uint8_t *)(dv + o_cv) : nullptr;
             int32_t *p_it = iters ? (int32_t *)(dv + o_it) : nullptr;
+            if (batch == 1 && osd < 0 && !h->on("TIME_SMALL_CALLS")) {  // ONE syndrome: the resident workgroup, where one applies
+                bool took = false;
+                if ((rc = decode_onchip_resident(h, llr != nullptr, &took))) return rc;
+                if (took) {
+                    std::memcpy(decoding, h->pin_host + o_dec, B * n);
+                    if (llr) std::memcpy(llr, h->pin_host + o_llr, B * n * 8);
+                    if (iters) std::memcpy(iters, h->pin_host + o_it, B * 4);
+                    if (conv) std::memcpy(conv, h->pin_host + o_cv, B);
+                    return LDPC_HIP_OK;
+                }
+            }
             h->untimed_call = batch <= 4 && !h->on("TIME_SMALL_CALLS");
             rc = osd >= 0 ? bposd_device(h, osd ? h->osd_method : 1, osd ? h->osd_order : 0, dv, batch, dv + o_dec, p_llr, p_it, p_cv)
                           : decode_device(h, dv, batch, dv + o_dec, p_llr, p_it, p_cv);

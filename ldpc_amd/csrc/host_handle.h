@@ -57,7 +57,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -156,6 +156,17 @@ struct ldpc_hip_bp {
     // no copy commands at all, one launch sequence and one wait
     unsigned char *pin_host = nullptr, *pin_dev = nullptr;
     static constexpr size_t PIN_BYTES = 512u * 1024u;
+    static constexpr size_t PIN_MAIL = PIN_BYTES - 64;  // the last 64 bytes: the resident kernel's mailbox (WavePsArgs::mail)
+    // A single decode() of a small code (host buffers, product-sum, parallel schedule) is served by a RESIDENT workgroup that stays for
+    // `linger` after its last request (host_onchip.h: decode_onchip_resident): no launch, no completion, tables already in LDS.
+    struct Resident {
+        hipStream_t stream = nullptr;
+        hipEvent_t ended = nullptr;       // behind the resident kernel's launch: has it left?
+        bool launched = false;            // a launch whose end has not been seen yet
+        unsigned seq = 0;                 // the last request number handed out
+        unsigned long long key[6] = {};   // what the kernel in flight was launched for (parameters, priors, plan): a change retires it
+    } res;
+    unsigned long long priors_version = 0;  // bumped whenever the priors on the device change (upload_priors)
     // large calls with host buffers: pinned double-buffered chunks, so that PCIe and the host's own copies overlap the kernels
     // (host_decode_abi.h: decode_batch_pipelined)
     struct HostPipe {
@@ -201,6 +212,7 @@ struct ldpc_hip_bp {
 };
 
 static int upload_priors(ldpc_hip_bp *h) {
+    ++h->priors_version;
     // bp.hpp:150-151, evaluated by the host libm so that priors are bit-identical to the reference's
     std::vector<double> llr0((size_t)h->n);
     for (int j = 0; j < h->n; ++j)
@@ -253,6 +265,10 @@ static bool is_device_ptr(const void *p) {
 // tu_stream.hip: the dispatch of a batch to a kernel family, and the streamed kernels themselves
 int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv,
                   bool may_repack = true);
+// tu_onchip.hip: ONE syndrome in the handle's host-mapped block (already copied in) through the resident workgroup; *took = false: not
+// applicable (then the ordinary path).  resident_retire: the resident workgroup leaves now (destroy, or a change it must not outlive)
+int decode_onchip_resident(ldpc_hip_bp *h, bool want_llr, bool *took);
+void resident_retire(ldpc_hip_bp *h);
 // tu_onchip.hip: the kernels that keep a syndrome's messages on chip; *took = false: no such kernel applies to this matrix
 int decode_onchip(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv, bool *took);
 // tu_serial.hip: serial / serial_relative / random serial schedules, soft-syndrome decoding

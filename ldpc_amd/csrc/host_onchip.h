@@ -583,3 +583,117 @@ int decode_onchip(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     }
     return LDPC_HIP_OK;
 }
+
+// ---- a single decode() through the resident workgroup ------------------------------------------------------------------------------------
+// What the reference's callers do is `for shot: decoder.decode(shot)`: one syndrome per call, host arrays.  A launch and its completion
+// cost ~15 us of such a call and the kernel's table set-up ~10 us more (profiles/r4_single_decode_latency.txt) -- so the workgroup that
+// decoded one syndrome STAYS (bp_wave_ps_kernel<., ., ., TEAM>, WavePsArgs::mail): the next call writes its syndrome into the handle's
+// host-mapped block, bumps the request word, and spins on the served word; the workgroup polls the request word over PCIe, decodes with
+// the tables it already has in LDS, writes the results into the block and bumps the served word.  It leaves after `linger` (100 us,
+// LDPC_HIP_RESIDENT_LINGER_US) without a request -- it cannot outlive a caller by more than that, and a torch.cuda.synchronize() behind a
+// decode() waits that long at most -- or at once when told to (resident_retire: parameters or priors changed, handle destroyed).
+// The block's layout for one syndrome is decode_batch_staged's (host_decode_abi.h); the syndrome is already in it.
+void resident_retire(ldpc_hip_bp *h) {
+    auto &r = h->res;
+    if (!h->pin_host || !r.stream) return;
+    volatile unsigned *mail = reinterpret_cast<volatile unsigned *>(h->pin_host + ldpc_hip_bp::PIN_MAIL);
+    if (r.launched) {
+        __atomic_store_n(const_cast<unsigned *>(mail + 3), 1u, __ATOMIC_SEQ_CST);
+        (void)hipStreamSynchronize(r.stream);
+        __atomic_store_n(const_cast<unsigned *>(mail + 3), 0u, __ATOMIC_SEQ_CST);
+        r.launched = false;
+    }
+}
+
+int decode_onchip_resident(ldpc_hip_bp *h, bool want_llr, bool *took) {
+    *took = false;
+    (void)want_llr;
+    if (h->sw("RESIDENT") == 0 || !h->pin_host || h->schedule != 1 || h->small_mode == 0 || h->small_mode == 2) return LDPC_HIP_OK;
+    if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || (int64_t)h->nnz * 16 >= (1 << 22)) return LDPC_HIP_OK;
+    const WavePsPlan p = plan_wave_ps(h, h->small_mode == 1, true, 1);  // (the posteriors are always formed: one plan whatever the caller asks for)
+    if (!p.waves || !p.team) return LDPC_HIP_OK;
+    auto &r = h->res;
+    int rc;
+    if (!r.stream) {
+        if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r.ended, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
+            return LDPC_HIP_OK;
+        }
+    }
+    unsigned *mail = reinterpret_cast<unsigned *>(h->pin_host + ldpc_hip_bp::PIN_MAIL);
+    unsigned long long alpha_bits;
+    std::memcpy(&alpha_bits, &h->ms_scaling_factor, 8);
+    const unsigned long long key[6] = {((unsigned long long)(unsigned)h->max_iter << 32) | (unsigned)h->math_mode, h->priors_version, alpha_bits,
+                                       ((unsigned long long)(unsigned)p.dr << 48) | ((unsigned long long)(unsigned)p.dc << 32) | (unsigned)p.waves,
+                                       (unsigned long long)(uintptr_t)h->d_llr0, (unsigned long long)(unsigned)h->small_mode};
+    if (r.launched && std::memcmp(key, r.key, sizeof key) != 0) resident_retire(h);  // (launched for other parameters: it leaves, a new one comes)
+    const size_t m = (size_t)h->m, n = (size_t)h->n;
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_dec = up16(m), o_llr = o_dec + up16(n), o_it = o_llr + up16(n * 8), o_cv = o_it + up16(4);
+    auto launch = [&]() -> int {
+        if ((rc = ensure_wave_ps_tables(h, p))) return rc;
+        WavePsArgs a = {};
+        a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
+        a.batch = 1;
+        a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
+        a.llr0 = h->d_llr0;
+        unsigned char *dv = h->pin_dev;
+        a.synd = dv; a.decoding = dv + o_dec; a.llr = (double *)(dv + o_llr); a.iters = (int32_t *)(dv + o_it); a.conv = dv + o_cv;
+        a.next = nullptr;
+        a.clk = nullptr;
+        a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
+        a.min_rdeg = h->m;
+        for (int i = 0; i < h->m; ++i) a.min_rdeg = std::min(a.min_rdeg, h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i]);
+        a.mail = reinterpret_cast<unsigned *>(h->pin_dev + ldpc_hip_bp::PIN_MAIL);
+        a.served0 = __atomic_load_n(mail + 1, __ATOMIC_ACQUIRE);
+        const int linger_us = h->sw("RESIDENT_LINGER_US") > 0 ? h->sw("RESIDENT_LINGER_US") : 100;
+        a.linger_ticks = (unsigned)linger_us * 100u;  // (the constant-rate counter runs at 100 MHz)
+        const size_t dyn = p.shared + p.per_wave;
+        if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)p.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        __atomic_store_n(mail + 3, 0u, __ATOMIC_SEQ_CST);
+        __atomic_store_n(mail + 2, 1u, __ATOMIC_SEQ_CST);
+        hipLaunchKernelGGL(p.kern, dim3(1), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, r.stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(r.ended, r.stream));
+        std::memcpy(r.key, key, sizeof key);
+        r.launched = true;
+        return LDPC_HIP_OK;
+    };
+    if (r.launched && __atomic_load_n(mail + 2, __ATOMIC_ACQUIRE) == 0u) {  // it said it was leaving: see it gone before the next one is launched
+        HIPCHK(hipStreamSynchronize(r.stream));
+        r.launched = false;
+    }
+    if (!r.launched) {
+        if (r.seq == 0) { __atomic_store_n(mail + 0, 0u, __ATOMIC_SEQ_CST); __atomic_store_n(mail + 1, 0u, __ATOMIC_SEQ_CST); }
+        if ((rc = launch())) return rc;
+    }
+    const unsigned seq = ++r.seq ? r.seq : ++r.seq;  // (never 0: the words' initial value)
+    __atomic_store_n(mail + 0, seq, __ATOMIC_SEQ_CST);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(mail + 1, __ATOMIC_ACQUIRE) == seq) break;
+        if (__atomic_load_n(mail + 2, __ATOMIC_SEQ_CST) == 0u) {
+            // it is leaving (or gone): either it saw this request on its last look and serves it before it goes, or it did not
+            const hipError_t q = hipEventQuery(r.ended);
+            if (q == hipSuccess) {
+                r.launched = false;
+                if (__atomic_load_n(mail + 1, __ATOMIC_ACQUIRE) == seq) break;
+                if ((rc = launch())) return rc;  // (the new one finds the request waiting)
+            } else if (q != hipErrorNotReady) {
+                return fail(LDPC_HIP_ERR_DEVICE, "the resident decode kernel failed: %s", hipGetErrorString(q));
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+            return fail(LDPC_HIP_ERR_DEVICE, "the resident decode kernel did not answer within 20 s");
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    h->timed = false;
+    h->accumulated_ms = 0.f;
+    *took = true;
+    return LDPC_HIP_OK;
+}
