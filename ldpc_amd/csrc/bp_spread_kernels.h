@@ -17,17 +17,40 @@ struct SpreadArgs {
     unsigned seq;
 };
 
-// tile handled by workgroup row `slot`, its iteration number and converged mask in this round; false: already final
+// How many tiles the list holds.  The host sizes the grid for the most tiles that can have been parked and queues every round without
+// waiting for the device (the *_async entry points never synchronise): workgroup rows beyond the count, and tiles that are final, leave.
+// A workgroup row serves slots blockIdx.y, blockIdx.y + gridDim.y, ...: in the early rounds the grid has a row per slot; later -- when
+// all but a few tiles are final and a launch of 256 rows of workgroups that leave at once costs ~50 us, 4 launches a round, for the 40
+// rounds one hopeless syndrome keeps its tile going -- the list is compacted (bp_spread_compact_kernel) and the grid has a few rows.
+__device__ __forceinline__ int spread_count(const SpreadArgs &a) { return a.n_tiles >= 0 ? a.n_tiles : (int)a.bp.counters[1]; }
+// tile in `slot`, its iteration number and converged mask in this round; false: already final
 __device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
-    // The host sizes the grid for the most tiles that can have been parked and queues every round without waiting for
-    // the device (the *_async entry points never synchronise): rows beyond the parked count and tiles that are final leave here.
-    const int n_tiles = a.n_tiles >= 0 ? a.n_tiles : (int)a.bp.counters[1];
-    if (slot >= n_tiles) return false;
     tile = a.bp.handoff_list[slot];
     st = a.bp.state + tile;
     it = st->it0 + a.round + 1;
     done = st->done[a.round & 1];
     return a.round <= st->end_round;
+}
+
+// the list without the tiles that are final (in place, one wavefront; counters[1] = how many are left): see spread_count
+__global__ void __launch_bounds__(64) bp_spread_compact_kernel(const SpreadArgs a) {
+    const int lane = threadIdx.x;
+    const int n_tiles = spread_count(a);
+    int kept = 0;
+    for (int s0 = 0; s0 < n_tiles; s0 += 64) {  // (a chunk is read whole before any of it is overwritten: kept <= s0)
+        const int slot = s0 + lane;
+        int32_t tile = 0;
+        bool live = false;
+        if (slot < n_tiles) {
+            tile = a.bp.handoff_list[slot];
+            live = a.round <= a.bp.state[tile].end_round;
+        }
+        const uint64_t mask = __ballot(live);
+        __builtin_amdgcn_wave_barrier();
+        if (live) a.bp.handoff_list[kept + lane_rank(mask)] = tile;
+        kept += __builtin_popcountll(mask);
+    }
+    if (lane == 0) a.bp.counters[1] = (unsigned)kept;
 }
 
 
@@ -36,17 +59,20 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
     typedef MsgBufT<NT ? 2 : 0> Buf;  // cache policy of the message traffic: non-temporal once the tiles outgrow the caches
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     __shared__ double near_bufs[4][LDPC_NEAR_SLOTS];
-    int64_t tile;
-    const TileState *st;
-    int it;
-    uint64_t done;
-    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;  // (uniform over the workgroup)
+    const int n_slots = spread_count(a);
+    if ((int)blockIdx.y >= n_slots) return;  // (uniform over the workgroup)
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
+    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    if (!spread_tile(a, slot, tile, st, it, done)) continue;
     const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
@@ -65,19 +91,22 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
             check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
         }
     }
+    }
 }
 
 template <int METHOD, int MATH, int DC, int NT>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
     typedef MsgBufT<NT ? 2 : 0> Buf;
+    const int n_slots = spread_count(a);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
+    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *st;
     int it;
     uint64_t done;
-    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
+    if (!spread_tile(a, slot, tile, st, it, done)) continue;
     const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const bool want_llr = a.bp.llr_t != nullptr;
@@ -116,16 +145,19 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
         if (lane == 0) a.bp.dcur[tile * n + j] = hard;
         if ((last || each) && want_llr && lane_live) Lt.st(l8, j, llr);
     }
+    }
 }
 
 // candidate syndrome vs syndrome (bp.hpp:292-294, 300-302) for the parked tiles, one thread per (tile, row); the
 // per-tile verdict is OR-accumulated into TileState::unsat for bp_spread_finish_kernel
 __global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a) {
+    const int n_slots = spread_count(a);
+    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *st;
     int it;
     uint64_t done;
-    if (!spread_tile(a, blockIdx.y, tile, st, it, done)) return;
+    if (!spread_tile(a, slot, tile, st, it, done)) continue;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t unsat = 0;
     if (i < a.bp.m) {
@@ -136,6 +168,7 @@ __global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a)
     }
     unsat = wave_or(unsat);
     if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
+    }
 }
 
 // batches of only a few tiles skip the persistent kernel altogether: state + message initialisation for the per-pass path
@@ -180,11 +213,13 @@ __global__ void __launch_bounds__(256) bp_edge0_kernel(const double *llr0, int n
 // outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
 // to freeze and every workgroup but the first leaves at once.
 __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a) {
+    const int n_slots = spread_count(a);
+    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *cst;
     int it;
     uint64_t done;
-    if (!spread_tile(a, blockIdx.y, tile, cst, it, done)) return;
+    if (!spread_tile(a, slot, tile, cst, it, done)) continue;
     TileState *st = a.bp.state + tile;
     const int par = a.round & 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,7 +252,7 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
             }
         }
     }
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0) continue;
     if (wave == 0) {
         if (mine) st->lane_iter[lane] = it;
         const int64_t b = tile * LDPC_WAVE + lane;
@@ -237,5 +272,6 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
             if (atomicSub(&a.bp.counters[2], 1u) == 1u && a.host_flag)  // that was the last live tile
                 __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
     }
 }

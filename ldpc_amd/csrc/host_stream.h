@@ -208,13 +208,23 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
             const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
             const int rounds = h->max_iter - (first_round ? first_round : a.it_start);  // (a tile parked by the persistent kernel knows its own it0)
             const volatile unsigned *flag = h->h_flag;
+            // After a few rounds all but a handful of the tiles are final (what is left is what never converges), and a launch of `grid_tiles`
+            // rows of workgroups that leave at once costs ~50 us, four times a round: every 8 rounds the list of tiles is compacted on the
+            // device (bp_spread_compact_kernel) and from then on the grids have at most 16 rows, each serving every 16th slot of the list.
+            unsigned rows_now = grid_tiles;
             for (int round = 0; round < rounds; ++round) {
                 if (*flag == sa.seq) break;  // a look, not a wait
                 sa.round = round;
-                hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(bp_spread_synd_kernel, gs, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(bp_spread_finish_kernel, gf, dim3(256), 0, st, sa);
+                if (round >= 8 && round % 8 == 0 && grid_tiles > 16 && !h->on("NO_SPREAD_COMPACT")) {
+                    hipLaunchKernelGGL(bp_spread_compact_kernel, dim3(1), dim3(64), 0, st, sa);
+                    sa.n_tiles = -1;  // (the count is the device's from here on: counters[1])
+                    rows_now = 16;
+                }
+                const dim3 gcr(gc.x, rows_now), gbr(gb.x, rows_now), gsr(gs.x, rows_now), gfr(gf.x, rows_now);
+                hipLaunchKernelGGL(kc, gcr, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(kb, gbr, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_synd_kernel, gsr, dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(bp_spread_finish_kernel, gfr, dim3(256), 0, st, sa);
             }
             HIPCHK(hipGetLastError());
         }
