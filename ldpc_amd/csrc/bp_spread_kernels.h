@@ -15,24 +15,18 @@ struct SpreadArgs {
     int32_t round;    // 0-based per-pass round; a tile's iteration number is it0 + round + 1
     unsigned *host_flag;  // host-mapped word: receives `seq` when the last parked tile becomes final (the host stops queueing rounds)
     unsigned seq;
+    int32_t slot0;    // the first slot of the list this launch serves (workgroup row y: slot0 + y; the LOOP forms: and every gridDim.y-th after it)
 };
 
-// How many tiles the list holds.  The host sizes the grid for the most tiles that can have been parked and queues every round without
-// waiting for the device (the *_async entry points never synchronise): workgroup rows beyond the count, and tiles that are final, leave.
-// A workgroup row serves slots blockIdx.y, blockIdx.y + gridDim.y, ...: in the early rounds the grid has a row per slot; later -- when
-// all but a few tiles are final and a launch of 256 rows of workgroups that leave at once costs ~50 us, 4 launches a round, for the 40
-// rounds one hopeless syndrome keeps its tile going -- the list is compacted (bp_spread_compact_kernel) and the grid has a few rows.
+// Late rounds.  After a few rounds all but a handful of the tiles are final (what is left is what never converges), yet a launch of a row of
+// workgroups per parked tile -- 256 rows that leave at once -- costs ~50 us, four times a round, for the 40 rounds one hopeless syndrome keeps
+// its tile going.  Where the host expects that (host_stream.h) the list is compacted on the device every 8 rounds (bp_spread_compact_kernel:
+// the running tiles to the front) and a round is then TWO launches per kernel: 32 rows for slots 0 .. 31, exactly as before, and 8 rows of
+// the LOOP form for whatever lies beyond (slot0 = 32: every 8th slot each; nothing, normally -- they leave at once).  The row-per-slot form
+// stays as it was: with a loop over slots in it the check kernel needed 109 VGPRs instead of 73 and the headline lost 3 %.
 __device__ __forceinline__ int spread_count(const SpreadArgs &a) { return a.n_tiles >= 0 ? a.n_tiles : (int)a.bp.counters[1]; }
-// tile in `slot`, its iteration number and converged mask in this round; false: already final
-__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
-    tile = a.bp.handoff_list[slot];
-    st = a.bp.state + tile;
-    it = st->it0 + a.round + 1;
-    done = st->done[a.round & 1];
-    return a.round <= st->end_round;
-}
 
-// the list without the tiles that are final (in place, one wavefront; counters[1] = how many are left): see spread_count
+// the list without the tiles that are final (in place, one wavefront; counters[1] = how many are left)
 __global__ void __launch_bounds__(64) bp_spread_compact_kernel(const SpreadArgs a) {
     const int lane = threadIdx.x;
     const int n_tiles = spread_count(a);
@@ -53,26 +47,39 @@ __global__ void __launch_bounds__(64) bp_spread_compact_kernel(const SpreadArgs 
     if (lane == 0) a.bp.counters[1] = (unsigned)kept;
 }
 
+// tile in `slot`, its iteration number and converged mask in this round; false: no such slot, or the tile is final
+__device__ __forceinline__ bool spread_tile(const SpreadArgs &a, int slot, int64_t &tile, const TileState *&st, int &it, uint64_t &done) {
+    // The host sizes the grid for the most tiles that can have been parked and queues every round without waiting for
+    // the device (the *_async entry points never synchronise): rows beyond the parked count and tiles that are final leave here.
+    if (slot >= spread_count(a)) return false;
+    tile = a.bp.handoff_list[slot];
+    st = a.bp.state + tile;
+    it = st->it0 + a.round + 1;
+    done = st->done[a.round & 1];
+    return a.round <= st->end_round;
+}
 
-template <int METHOD, int MATH, int DR, int NT>
+
+template <int METHOD, int MATH, int DR, int NT, bool LOOP = false>
 __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a) {
     typedef MsgBufT<NT ? 2 : 0> Buf;  // cache policy of the message traffic: non-temporal once the tiles outgrow the caches
     __shared__ __attribute__((aligned(16))) double log_tab[256];
     __shared__ double near_bufs[4][LDPC_NEAR_SLOTS];
-    const int n_slots = spread_count(a);
-    if ((int)blockIdx.y >= n_slots) return;  // (uniform over the workgroup)
+    int64_t tile;
+    const TileState *st;
+    int it;
+    uint64_t done;
+    int slot = a.slot0 + (int)blockIdx.y;
+    if (LOOP) { if (slot >= spread_count(a)) return; }
+    else if (!spread_tile(a, slot, tile, st, it, done)) return;  // (uniform over the workgroup)
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0)
         for (int q = threadIdx.x; q < 256; q += blockDim.x) log_tab[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nnz = a.bp.nnz, l8 = lane * 8;
-    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
-    int64_t tile;
-    const TileState *st;
-    int it;
-    uint64_t done;
-    if (!spread_tile(a, slot, tile, st, it, done)) continue;
+    do {
+    if (LOOP && !spread_tile(a, slot, tile, st, it, done)) continue;
     const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const double alpha = (a.bp.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.bp.ms_scaling_factor;
@@ -91,22 +98,24 @@ __global__ void __launch_bounds__(256) bp_spread_check_kernel(const SpreadArgs a
             check_row_streamed<METHOD, MATH>(d, rs, neg, parity, alpha, At, Ct, l8, log_tab);
         }
     }
-    }
+    } while (LOOP && (slot += (int)gridDim.y) < spread_count(a));
 }
 
-template <int METHOD, int MATH, int DC, int NT>
+template <int METHOD, int MATH, int DC, int NT, bool LOOP = false>
 __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) {
     typedef MsgBufT<NT ? 2 : 0> Buf;
-    const int n_slots = spread_count(a);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
-    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *st;
     int it;
     uint64_t done;
-    if (!spread_tile(a, slot, tile, st, it, done)) continue;
+    int slot = a.slot0 + (int)blockIdx.y;
+    if (LOOP) { if (slot >= spread_count(a)) return; }
+    else if (!spread_tile(a, slot, tile, st, it, done)) return;
+    do {
+    if (LOOP && !spread_tile(a, slot, tile, st, it, done)) continue;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nnz = a.bp.nnz, n = a.bp.n, l8 = lane * 8;
     const Buf At = make_msgbuf<Buf>(a.bp.A + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const Buf Ct = make_msgbuf<Buf>(a.bp.C + (size_t)tile * (size_t)nnz * LDPC_WAVE, (unsigned)nnz);
     const bool want_llr = a.bp.llr_t != nullptr;
@@ -145,19 +154,22 @@ __global__ void __launch_bounds__(256) bp_spread_bit_kernel(const SpreadArgs a) 
         if (lane == 0) a.bp.dcur[tile * n + j] = hard;
         if ((last || each) && want_llr && lane_live) Lt.st(l8, j, llr);
     }
-    }
+    } while (LOOP && (slot += (int)gridDim.y) < spread_count(a));
 }
 
 // candidate syndrome vs syndrome (bp.hpp:292-294, 300-302) for the parked tiles, one thread per (tile, row); the
 // per-tile verdict is OR-accumulated into TileState::unsat for bp_spread_finish_kernel
+template <bool LOOP = false>
 __global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a) {
-    const int n_slots = spread_count(a);
-    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *st;
     int it;
     uint64_t done;
-    if (!spread_tile(a, slot, tile, st, it, done)) continue;
+    int slot = a.slot0 + (int)blockIdx.y;
+    if (LOOP) { if (slot >= spread_count(a)) return; }
+    else if (!spread_tile(a, slot, tile, st, it, done)) return;
+    do {
+    if (LOOP && !spread_tile(a, slot, tile, st, it, done)) continue;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t unsat = 0;
     if (i < a.bp.m) {
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(256) bp_spread_synd_kernel(const SpreadArgs a)
     }
     unsat = wave_or(unsat);
     if ((threadIdx.x & 63) == 0 && unsat) atomicOr(&a.bp.state[tile].unsat[a.round & 1], (unsigned long long)unsat);
-    }
+    } while (LOOP && (slot += (int)gridDim.y) < spread_count(a));
 }
 
 // batches of only a few tiles skip the persistent kernel altogether: state + message initialisation for the per-pass path
@@ -212,14 +224,17 @@ __global__ void __launch_bounds__(256) bp_edge0_kernel(const double *llr0, int n
 // (decisions + posterior of THIS iteration), a tile whose lanes are all frozen or that reached max_iter gets its
 // outputs.  64 bits per workgroup; workgroup 0 of a tile also advances its state.  Almost always there is nothing
 // to freeze and every workgroup but the first leaves at once.
+template <bool LOOP = false>
 __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs a) {
-    const int n_slots = spread_count(a);
-    for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
     int64_t tile;
     const TileState *cst;
     int it;
     uint64_t done;
-    if (!spread_tile(a, slot, tile, cst, it, done)) continue;
+    int slot = a.slot0 + (int)blockIdx.y;
+    if (LOOP) { if (slot >= spread_count(a)) return; }
+    else if (!spread_tile(a, slot, tile, cst, it, done)) return;
+    do {
+    if (LOOP && !spread_tile(a, slot, tile, cst, it, done)) continue;
     TileState *st = a.bp.state + tile;
     const int par = a.round & 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -273,5 +288,5 @@ __global__ void __launch_bounds__(256) bp_spread_finish_kernel(const SpreadArgs 
                 __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    }
+    } while (LOOP && (slot += (int)gridDim.y) < spread_count(a));
 }

@@ -179,8 +179,29 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     }
     advise_huge_pages(decoding, (size_t)batch * n);
     if (llr && !llr_direct) advise_huge_pages(llr, (size_t)batch * n * 8);
-    const int64_t chunks = (batch + rows - 1) / rows;
-    auto rows_of = [&](int64_t c) { return c == chunks - 1 ? batch - c * rows : rows; };
+    // The chunks: `rows` each -- but with log-ratios the LAST chunk's results (90 KB a row on the n = 10 000 code: 1.5 GB for 16 384 rows, ~30 ms
+    // of PCIe) cross after its kernels with nothing left to overlap them, so the last quarter of the batch goes in chunks that halve down
+    // to 4 096 rows: what is left exposed is a quarter of that.  (LDPC_HIP_HOST_TAPER=0: uniform chunks; measurement.)
+    std::vector<int64_t> chunk_start, chunk_rows;
+    {
+        int64_t at = 0;
+        const bool taper = llr && h->sw("HOST_TAPER") != 0 && rows >= 8192 && batch >= 3 * rows;
+        while (at < batch) {
+            int64_t r = rows;
+            const int64_t left = batch - at;
+            if (taper && left <= rows) {
+                r = left / 2 / LDPC_WAVE * LDPC_WAVE;
+                if (r < 4096 || left < 8192) r = left;
+            }
+            if (r > left) r = left;
+            chunk_start.push_back(at);
+            chunk_rows.push_back(r);
+            at += r;
+        }
+    }
+    const int64_t chunks = (int64_t)chunk_rows.size();
+    auto rows_of = [&](int64_t c) { return chunk_rows[(size_t)c]; };
+    auto start_of = [&](int64_t c) { return chunk_start[(size_t)c]; };
     // the helper: chunk after chunk, wait for its results to have landed in the pinned buffer, copy them into the caller's arrays
     std::atomic<int64_t> queued{0}, drained{0};
     std::atomic<int> drain_err{0};
@@ -198,7 +219,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
                 std::this_thread::yield();
             }
             const int q = (int)(c % NB);
-            const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+            const size_t r = (size_t)rows_of(c), b0 = (size_t)start_of(c);
             const double t1 = clocked ? now() : 0;
             if (hipEventSynchronize(P.ev_out[q]) != hipSuccess) { drain_err = 1; return; }
             const double t2 = clocked ? now() : 0;
@@ -227,7 +248,7 @@ static int decode_batch_pipelined(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     } while (0)
     for (int64_t c = 0; c < chunks; ++c) {
         const int q = (int)(c % NB);
-        const size_t r = (size_t)rows_of(c), b0 = (size_t)(c * rows);
+        const size_t r = (size_t)rows_of(c), b0 = (size_t)start_of(c);
         const double tm0 = clocked ? now() : 0;
         if (c >= NB) {
             // slot q carried chunk c - NB: its upload has completed (pin_in free), and the helper has emptied its pin_out

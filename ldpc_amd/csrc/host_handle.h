@@ -57,7 +57,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -89,6 +89,7 @@ struct ldpc_hip_bp {
     int32_t cont_it_start = 0;
     const int32_t *cont_row_map = nullptr;        // its rows in the caller's arrays (BpArgs::row_map)
     const unsigned *cont_rows_dev = nullptr;      // {rows, tiles} on the device (BpArgs::rows_dev)
+    int64_t cont_late_rows = -1;                  // rows the steering histogram expects to be still running 8 iterations into it (-1: unknown)
     int64_t cont_grid_tiles = 0;                  // grid.y of its tile-looping kernels (an estimate; they loop)
     bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
     int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)

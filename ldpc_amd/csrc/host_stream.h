@@ -4,10 +4,11 @@
 
 
 // nt: non-temporal cache policy for the message traffic (tiles that outgrow the 256 MB MALL; see MsgBufT)
+template <bool LOOP>
 static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
-    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) pick_spread_m<LDPC_HIP_MINIMUM_SUM, 0, LOOP>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) pick_spread_m<LDPC_HIP_PRODUCT_SUM, 1, LOOP>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
+    else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0, LOOP>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
 }
 
 // Everything below runs on h->stream with device pointers only.
@@ -200,31 +201,49 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
             // leaves each kernel at its first instruction, and once the device has reported "nothing left" through
             // the host-mapped flag the host stops queueing -- which only matters when max_iter is far larger than
             // the iterations needed (the reference's default max_iter = n).
-            spread_kernel_t kc, kb;
+            spread_kernel_t kc, kb, kcl, kbl;
             // messages of the tiles in flight: 2 arrays x nnz x 512 B each; beyond ~the MALL they are streamed, not cached
-            pick_spread(h, (double)grid_tiles * 2.0 * (double)per_tile_msg > 384.0 * 1024.0 * 1024.0, kc, kb);
+            const bool nt = (double)grid_tiles * 2.0 * (double)per_tile_msg > 384.0 * 1024.0 * 1024.0;
+            pick_spread<false>(h, nt, kc, kb);
+            pick_spread<true>(h, nt, kcl, kbl);
             const unsigned per_wg = 4u * (unsigned)sa.nodes;
             const dim3 gc((unsigned)(h->m ? (h->m + per_wg - 1) / per_wg : 1), grid_tiles), gb((unsigned)(h->n ? (h->n + per_wg - 1) / per_wg : 1), grid_tiles);
             const dim3 gs((unsigned)(h->m ? (h->m + 255) / 256 : 1), grid_tiles), gf((unsigned)(h->n ? (h->n + 63) / 64 : 1), grid_tiles);
             const int rounds = h->max_iter - (first_round ? first_round : a.it_start);  // (a tile parked by the persistent kernel knows its own it0)
             const volatile unsigned *flag = h->h_flag;
-            // After a few rounds all but a handful of the tiles are final (what is left is what never converges), and a launch of `grid_tiles`
-            // rows of workgroups that leave at once costs ~50 us, four times a round: every 8 rounds the list of tiles is compacted on the
-            // device (bp_spread_compact_kernel) and from then on the grids have at most 16 rows, each serving every 16th slot of the list.
-            unsigned rows_now = grid_tiles;
+            // Late rounds (bp_spread_kernels.h): where the steering histogram of a two-pass decode shows at most 24 rows still running 8
+            // iterations into the second pass, its list of tiles is compacted on the device every 8 rounds and a round becomes 32 rows of
+            // workgroups for the list's first 32 slots + 8 rows of the looping form for whatever lies beyond (normally nothing), instead of
+            // `grid_tiles` rows that leave at once at ~50 us a launch.  Not elsewhere: when most tiles keep going (the headline's last 256
+            // tiles run to iteration 50, a chunk of the pipelined host path likewise) the row-per-tile grid is what runs them fastest.
+            const bool may_compact = rows_dev != nullptr && h->cont_late_rows >= 0 && h->cont_late_rows <= 24 && grid_tiles > 40 && !h->on("NO_SPREAD_COMPACT");
+            bool compacted = false;
             for (int round = 0; round < rounds; ++round) {
                 if (*flag == sa.seq) break;  // a look, not a wait
                 sa.round = round;
-                if (round >= 8 && round % 8 == 0 && grid_tiles > 16 && !h->on("NO_SPREAD_COMPACT")) {
+                sa.slot0 = 0;
+                if (may_compact && round >= 8 && round % 8 == 0) {
                     hipLaunchKernelGGL(bp_spread_compact_kernel, dim3(1), dim3(64), 0, st, sa);
                     sa.n_tiles = -1;  // (the count is the device's from here on: counters[1])
-                    rows_now = 16;
+                    compacted = true;
                 }
-                const dim3 gcr(gc.x, rows_now), gbr(gb.x, rows_now), gsr(gs.x, rows_now), gfr(gf.x, rows_now);
-                hipLaunchKernelGGL(kc, gcr, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(kb, gbr, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(bp_spread_synd_kernel, gsr, dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(bp_spread_finish_kernel, gfr, dim3(256), 0, st, sa);
+                if (!compacted) {
+                    hipLaunchKernelGGL(kc, gc, dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(kb, gb, dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(bp_spread_synd_kernel<false>, gs, dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(bp_spread_finish_kernel<false>, gf, dim3(256), 0, st, sa);
+                } else {
+                    SpreadArgs sb = sa;
+                    sb.slot0 = 32;
+                    hipLaunchKernelGGL(kc, dim3(gc.x, 32), dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(kcl, dim3(gc.x, 8), dim3(256), 0, st, sb);
+                    hipLaunchKernelGGL(kb, dim3(gb.x, 32), dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(kbl, dim3(gb.x, 8), dim3(256), 0, st, sb);
+                    hipLaunchKernelGGL(bp_spread_synd_kernel<false>, dim3(gs.x, 32), dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(bp_spread_synd_kernel<true>, dim3(gs.x, 8), dim3(256), 0, st, sb);
+                    hipLaunchKernelGGL(bp_spread_finish_kernel<false>, dim3(gf.x, 32), dim3(256), 0, st, sa);
+                    hipLaunchKernelGGL(bp_spread_finish_kernel<true>, dim3(gf.x, 8), dim3(256), 0, st, sb);
+                }
             }
             HIPCHK(hipGetLastError());
         }
@@ -277,6 +296,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
 // converges (the first call, and every call whose predecessor says "plain", run plain); results do not depend on any of this.
 static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost = 0.25) {
     *live_after = 0.5;
+    h->cont_late_rows = -1;
     if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
     // The previous decode's histogram, IF its copy has landed -- a look, never a wait (the *_async entry points must not block): a
     // caller that queues decodes back to back is steered by the last histogram that did land
@@ -318,6 +338,11 @@ static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double g
         }
         const double cost = prefix + gather_cost * (1.0 + live) + 0.1 + live * rest;
         if (cost < best) { best = cost; best_k = k; *live_after = live; }
+    }
+    if (best_k > 0) {  // rows (of the histogram's batch) still running 8 iterations into the second pass: the stragglers its late rounds are for
+        double late = h->hist_landed[0];
+        for (int j = best_k + 9; j < 256; ++j) late += h->hist_landed[j];
+        h->cont_late_rows = (int64_t)late;
     }
     return best < 0.97 * plain ? best_k : 0;
 }

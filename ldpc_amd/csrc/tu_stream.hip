@@ -11,14 +11,15 @@
 typedef void (*bp_kernel_t)(const BpArgs);
 typedef void (*spread_kernel_t)(const SpreadArgs);
 
-template <int METHOD, int MATH>
+// (the LOOP forms serve the slots beyond the first 32 of a compacted list: bp_spread_kernels.h, "late rounds")
+template <int METHOD, int MATH, bool LOOP>
 static void pick_spread_m(int max_row, int max_col, bool nt, spread_kernel_t &kc, spread_kernel_t &kb) {
     if (nt) {
-        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 1> : bp_spread_check_kernel<METHOD, MATH, 16, 1>;
-        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 1> : bp_spread_bit_kernel<METHOD, MATH, 8, 1>;
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 1, LOOP> : bp_spread_check_kernel<METHOD, MATH, 16, 1, LOOP>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 1, LOOP> : bp_spread_bit_kernel<METHOD, MATH, 8, 1, LOOP>;
     } else {
-        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 0> : bp_spread_check_kernel<METHOD, MATH, 16, 0>;
-        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 0> : bp_spread_bit_kernel<METHOD, MATH, 8, 0>;
+        kc = max_row <= 8 ? bp_spread_check_kernel<METHOD, MATH, 8, 0, LOOP> : bp_spread_check_kernel<METHOD, MATH, 16, 0, LOOP>;
+        kb = max_col <= 4 ? bp_spread_bit_kernel<METHOD, MATH, 4, 0, LOOP> : bp_spread_bit_kernel<METHOD, MATH, 8, 0, LOOP>;
     }
 }
 
