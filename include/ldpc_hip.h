@@ -125,11 +125,17 @@ int ldpc_hip_bp_set_stream(ldpc_hip_bp *h, void *hip_stream);
  * hard decision reproduces syndrome b (bp.hpp:300-308), or of iteration max_iter.
  * Synchronous with respect to the host: returns after the results are in the output buffers.
  * Host buffers (the reference API's own mode: NumPy in, NumPy out): a call of at most a few syndromes on a small code works in a
- * host-mapped block (no copy commands); a large batch (>= 64 MiB of data in at least three chunks, everything in host memory, BP
+ * host-mapped block (no copy commands).  ONE syndrome of a small code, product-sum, parallel schedule -- the reference's
+ * `for shot: decoder.decode(shot)` -- is served by a RESIDENT workgroup (bp_wave_ps_kernel's team form; csrc/host_onchip.h): the kernel
+ * that decoded the last syndrome is still there, tables in LDS, polling a request word in the block; the call writes its syndrome,
+ * bumps the word and spins on the served word -- no launch, no completion (BB144: 31 -> 22 us a call, hamming(5): 60 -> 50 us;
+ * profiles/r5_single_decode_latency.txt).  The workgroup leaves by itself 100 us after its last request ("RESIDENT_LINGER_US"), at
+ * once when the handle's parameters or priors change or the handle is destroyed; "RESIDENT" 0 = a launch per call.  A large batch (>= 64 MiB of data in at least three chunks, everything in host memory, BP
  * alone, rows independent of one another: the parallel and the fixed-order serial schedule) is cut into chunks of whole tiles --
  * <= 16 384 rows, ~256 MiB of results -- that move through PINNED double buffers on two copy streams: while the kernels decode
  * chunk c, chunk c + 1 is on its way in, chunk c - 1 on its way out, and the calling thread copies chunk c - 2 from the pinned
- * buffer into the caller's (pageable) arrays.  Results are those of one undivided call.  Debug switches "NO_HOST_PIPELINE",
+ * buffer into the caller's (pageable) arrays; with log-ratios the last quarter of the batch goes in chunks that halve down to 4 096 rows
+ * (the last chunk's results cross PCIe with nothing left to overlap them: "HOST_TAPER" 0 = uniform chunks).  Results are those of one undivided call.  Debug switches "NO_HOST_PIPELINE",
  * "HOST_CHUNK_ROWS" (tests, measurements).  Measured (bench.py `host_io`): 0.93 of the device-resident rate without LLRs.
  */
 int ldpc_hip_bp_decode_batch(ldpc_hip_bp *h, const uint8_t *syndromes, int64_t batch,
@@ -372,7 +378,9 @@ int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
  * "OSD_UNBLOCKED", "OSD_PLANES", "TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", ...; for schedule = serial_relative: "REL_LDS" 0 = the
  * per-lane kernel with the state in HBM, 16 / 64 = lanes per syndrome of the on-chip kernel; "REL_LEVELS" 0 = sweep bit by bit instead of
  * level by level; "REL_SCRATCH_IN_L" 0 = scratch apart from the posterior array; "REL_PROF" 1 = print the kernel's cycle shares per phase
- * to stderr).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
+ * to stderr; for the streamed serial schedule: "SER_WAVES" / "SER_RING" wavefronts per tile and ring depth, "SER_LANE_MAX" rows at or below
+ * which what a pass left finishes a workgroup per syndrome (0 = never), "SER_LANE_THREADS"; "NO_SPREAD_COMPACT" 1 = per-pass rounds never
+ * compact their list of tiles).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
  * created; afterwards only this call changes a switch (value < 0: back to "not set").  Unknown names are an error. */
 int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value);
 
