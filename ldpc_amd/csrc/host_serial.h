@@ -884,9 +884,30 @@ int decode_serial(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
         if ((rc = ensure_serial_levels(h))) return rc;
         const SerialStreamPlan sp = plan_serial_stream(h);
         if (sp.dr) {
-            const int took = decode_serial_streamed(h, sp, synd, batch, decoding, llr, iters, conv);
+            int took = decode_serial_streamed(h, sp, synd, batch, decoding, llr, iters, conv);
             if (took < 0) return took;
             if (took > 0) return LDPC_HIP_OK;
+            // The batch's message state is not resident at once (e.g. 1 048 576 rows of the n = 10 000 code: 252 GB): in pieces that are, each
+            // decoded in passes by itself -- a piece's stragglers finish a workgroup per syndrome instead of holding their tiles to max_iter.
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            const size_t have = h->msgA.cap + h->msgC.cap + h->llr_t.cap;
+            const size_t per_tile = sizeof(double) * (size_t)h->nnz * LDPC_WAVE + (llr ? sizeof(double) * n1 * LDPC_WAVE : 0) + 24 * (m1 + n1 + 1);
+            int64_t fit = (int64_t)((double)(free_b + have) * 0.7 / (double)per_tile);
+            if (h->max_chunk_tiles > 0 && fit > h->max_chunk_tiles) fit = h->max_chunk_tiles;
+            if (fit >= 64) {
+                float ms_sum = 0.f;
+                for (int64_t b0 = 0; b0 < batch; b0 += fit * LDPC_WAVE) {
+                    const int64_t nb = batch - b0 < fit * LDPC_WAVE ? batch - b0 : fit * LDPC_WAVE;
+                    took = decode_serial_streamed(h, sp, synd + b0 * h->m, nb, decoding + b0 * h->n, llr ? llr + (size_t)b0 * h->n : nullptr, iters ? iters + b0 : nullptr,
+                                                  conv ? conv + b0 : nullptr);
+                    if (took < 0) return took;
+                    if (took == 0) return fail(LDPC_HIP_ERR_NOMEM, "serial schedule: a piece of %lld rows sized from free device memory did not fit after all", (long long)nb);
+                    if (b0 + nb < batch) { float ms = 0.f; (void)ldpc_hip_bp_last_kernel_ms(h, &ms); ms_sum += ms; }
+                }
+                h->accumulated_ms += ms_sum;  // (the last piece's events are still the handle's)
+                return LDPC_HIP_OK;
+            }
         }
     }
     int k1 = h->repack_iters < 0 ? h->max_iter / 8 : h->repack_iters;

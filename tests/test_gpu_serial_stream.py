@@ -147,3 +147,25 @@ def test_lane_kernel_with_orders_that_skip_bits(oracle_built):
         eng.set_serial_kernel(2)
         dec, llr, it, cv = eng.decode_batch(synd)
         assert np.array_equal(dec, want[0]) and np.array_equal(it, want[2]) and np.array_equal(cv, want[3]) and bits_equal(llr, want[1])
+
+
+def test_batches_beyond_device_memory_are_decoded_in_resident_pieces(oracle_built):
+    """A batch whose message state is not resident at once (forced here: at most 70 tiles at a time) is cut into pieces that are, each
+    decoded in passes by itself; below 64 tiles the chunk loop of the one-pass path takes over.  Same bits either way."""
+    from ldpc_amd.engine import HipBpEngine
+    from ldpc_amd.codes import regular_ldpc_code
+    from oracle import bits_equal
+    n = 1800
+    h = regular_ldpc_code(n, 3, 6, seed=9)
+    synd = _synd(h, 0.072, seed=12, shots=10000)
+    synd[77, 1] = 2
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.072), 25, 0, 1.0)
+    eng.set_schedule("serial")
+    eng.set_serial_kernel(2)
+    d0, l0, i0, c0 = eng.decode_batch(synd)
+    for cap in (70, 9):
+        eng.set_tuning(max_chunk_tiles=cap)
+        d1, l1, i1, c1 = eng.decode_batch(synd)
+        assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1) and bits_equal(l0, l1), cap
+    want = oracle_built.BpOracle(h, error_rate=0.072, max_iter=25, bp_method="product_sum").decode_serial_batch(synd[:150], None)
+    assert np.array_equal(d0[:150], want[0]) and np.array_equal(i0[:150], want[2]) and bits_equal(l0[:150], want[1])
