@@ -57,7 +57,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -89,6 +89,7 @@ struct ldpc_hip_bp {
     int32_t cont_it_start = 0;
     const int32_t *cont_row_map = nullptr;        // its rows in the caller's arrays (BpArgs::row_map)
     const unsigned *cont_rows_dev = nullptr;      // {rows, tiles} on the device (BpArgs::rows_dev)
+    int64_t cont_alive[4] = {-1, -1, -1, -1}, cont_alive_total = 0;  // ... still running after the first pass + 0 .. 3 iterations, of how many
     int64_t cont_late_rows = -1;                  // rows the steering histogram expects to be still running 8 iterations into it (-1: unknown)
     int64_t cont_grid_tiles = 0;                  // grid.y of its tile-looping kernels (an estimate; they loop)
     bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
@@ -192,6 +193,8 @@ struct ldpc_hip_bp {
     int32_t n_levels = 0;
     DeviceBuf lvl_ptr, lvl_bits;
     std::vector<int32_t> h_lvl_ptr, h_lvl_bits;                     // host copies (the streamed serial kernel's position records are built from them)
+    DeviceBuf flood_list2, flood_pos;                                // rows a second pass of a few rounds left, and every row's place in that pass's tiles
+    DeviceBuf flood_lane_scratch;                                    // bp_flood_lane_kernel: a workgroup's two row-major message arrays, 1024 workgroups
     DeviceBuf ser_pos_e0;                                            // ... and the initial values of every position's other entries (first iteration)
     DeviceBuf ser_rows[2], ser_synd2;                                // decode_serial_streamed: the rows of a compacted pass (numbers in the caller's arrays), their syndromes
     DeviceBuf ser_pos_tab;                                           // bp_serial_stream_kernel: one record per position of the level-major order

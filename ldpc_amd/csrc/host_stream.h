@@ -297,6 +297,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
 static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double gather_cost = 0.25) {
     *live_after = 0.5;
     h->cont_late_rows = -1;
+    for (int R = 0; R <= 3; ++R) h->cont_alive[R] = -1;
     if (h->repack_iters > 0) return h->repack_iters < h->max_iter ? h->repack_iters : 0;
     // The previous decode's histogram, IF its copy has landed -- a look, never a wait (the *_async entry points must not block): a
     // caller that queues decodes back to back is steered by the last histogram that did land
@@ -343,6 +344,12 @@ static int stream_first_pass_length(ldpc_hip_bp *h, double *live_after, double g
         double late = h->hist_landed[0];
         for (int j = best_k + 9; j < 256; ++j) late += h->hist_landed[j];
         h->cont_late_rows = (int64_t)late;
+        h->cont_alive_total = (int64_t)total;  // ... and those still running after best_k + R iterations, R = 0 .. 3 (where the lane kernel takes over)
+        for (int R = 0; R <= 3; ++R) {
+            double alive = h->hist_landed[0];
+            for (int j = best_k + R + 1; j < 256; ++j) alive += h->hist_landed[j];
+            h->cont_alive[R] = (int64_t)alive;
+        }
     }
     return best < 0.97 * plain ? best_k : 0;
 }
@@ -367,6 +374,12 @@ __global__ void repack_rows_kernel(const unsigned *__restrict__ counters, unsign
     const unsigned c = counters[0];
     rows_dev[0] = c;
     rows_dev[1] = (c + LDPC_WAVE - 1) / LDPC_WAVE;
+}
+
+// pos[list[r]] = r for the listed rows: where a row of the caller's arrays sits in the second pass's compacted tiles
+__global__ void __launch_bounds__(256) row_positions_kernel(const int32_t *__restrict__ list, const unsigned *__restrict__ count_dev, int32_t *__restrict__ pos) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < (int64_t)count_dev[0]) pos[list[r]] = (int32_t)r;
 }
 
 // Nothing here waits for the device: the second pass is queued at once, sized for the most rows there can be (all of them), and
@@ -410,8 +423,8 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         return stream_leave_histogram(h, iters, conv, batch);
     }
     if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
-    if ((rc = h->osd_counters.ensure(4 * sizeof(unsigned)))) return rc;
-    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 4 * sizeof(unsigned), h->stream));
+    if ((rc = h->osd_counters.ensure(8 * sizeof(unsigned)))) return rc;
+    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 8 * sizeof(unsigned), h->stream));
     hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
                        (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
     hipLaunchKernelGGL(repack_rows_kernel, dim3(1), dim3(1), 0, h->stream, (const unsigned *)h->osd_counters.p, (unsigned *)h->osd_counters.p + 2);
@@ -422,6 +435,62 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     std::swap(h->ev_mid, h->evp_mid);
     h->timed_prev = h->timed;
     h->timed_prev_mid = h->timed_mid;
+    // What is left after the first pass -- or after a few more rounds in compacted tiles -- CAN finish a workgroup per syndrome
+    // (bp_flood_lane_kernel.h) instead of in tiles that keep moving 64 lanes for the one or two still alive in each: lane_after = the rounds
+    // in tiles before that (0: none; -1: tiles to the end).  Measured on the headline code at p = 0.05 (round 5, same box, 64 .. 1024 workgroups,
+    // after 0 .. 3 rounds): 108.8 - 111.2 ms against 109.4 ms for tiles to the end -- no gain: a row's two message arrays are 480 KB of 8-byte
+    // gathers that only stay in L2 for a few dozen rows at a time, and 11 000 rows straight after the first pass cost 10 ms MORE than their
+    // tiles.  So it is not chosen automatically; "FLOOD_LANES" 1 = straight after the first pass, 2 .. 4 = after 1 .. 3 rounds in tiles
+    // (tests keep the path honest: it gives the tiles' bits).  The serial schedule's lane kernel (bp_serial_stream_kernel.h) is another
+    // matter: there a tile-iteration is a chain of ~35 level barriers on one compute unit, here it is spread over the chip by the per-pass rounds.
+    int lane_after = -1;
+    {
+        const int fl = h->sw("FLOOD_LANES");
+        const bool fits = h->n <= 60000 && h->m <= 60000 && h->m > 0;  // (a byte per bit and per check in LDS; nodes heavier than the register bounds stream through memory)
+        if (fits && fl != 0) {
+            if (fl >= 1) lane_after = fl - 1 < full - k1 ? fl - 1 : -1;
+        }
+    }
+    auto launch_lanes = [&](int it_start, const double *tiles, const int32_t *pos, const int32_t *rows, const unsigned *count_dev, bool own_interval) -> int {
+        const int64_t groups = h->sw("FLOOD_LANE_GROUPS") > 0 ? h->sw("FLOOD_LANE_GROUPS") : 1024;
+        if ((rc = h->flood_lane_scratch.ensure(2 * sizeof(double) * (size_t)h->nnz * (size_t)groups))) return rc;
+        FloodLaneArgs fa = {};
+        fa.m = h->m; fa.n = h->n; fa.nnz = h->nnz; fa.max_iter = full; fa.it_start = it_start;
+        fa.ms_scaling_factor = h->ms_scaling_factor;
+        fa.row_ptr = h->d_row_ptr; fa.col_idx = h->d_col_idx; fa.col_ptr = h->d_col_ptr; fa.csc_edge = h->d_csc_edge;
+        fa.llr0 = h->d_llr0;
+        fa.A_tiles = tiles;
+        fa.pos = pos;
+        fa.rows = rows;
+        fa.count_dev = count_dev;
+        fa.A = (double *)h->flood_lane_scratch.p;
+        fa.C = fa.A + (size_t)h->nnz * (size_t)groups;
+        fa.synd = synd; fa.decoding = decoding; fa.llr = llr; fa.iters = iters; fa.conv = conv;
+        void (*kern)(const FloodLaneArgs);
+        const bool wide = h->max_row_deg > 8 || h->max_col_deg > 4;
+#define LDPC_PICK_FLOOD_LANE(M, F) (wide ? bp_flood_lane_kernel<M, F, 16, 8> : bp_flood_lane_kernel<M, F, 8, 4>)
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = LDPC_PICK_FLOOD_LANE(LDPC_HIP_MINIMUM_SUM, 0);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_FLOOD_LANE(LDPC_HIP_PRODUCT_SUM, 1);
+        else kern = LDPC_PICK_FLOOD_LANE(LDPC_HIP_PRODUCT_SUM, 0);
+#undef LDPC_PICK_FLOOD_LANE
+        const size_t dyn = (((size_t)h->n + 15) & ~(size_t)15) + (((size_t)h->m + 15) & ~(size_t)15);
+        if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        if (own_interval) {
+            h->accumulated_ms = 0.f;
+            h->accumulated_persistent_ms = 0.f;
+            h->timed_mid = false;
+            HIPCHK(hipEventRecord(h->ev0, h->stream));
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(512), (unsigned)dyn, h->stream, fa);
+        HIPCHK(hipEventRecord(h->ev1, h->stream));  // (behind a second pass: its interval now ends here)
+        h->timed = true;
+        HIPCHK(hipGetLastError());
+        return LDPC_HIP_OK;
+    };
+    if (lane_after == 0) {
+        if ((rc = launch_lanes(k1, (const double *)h->msgA.p, nullptr, (const int32_t *)h->osd_list.p, (const unsigned *)h->osd_counters.p, true))) return rc;
+        return stream_leave_histogram(h, iters, conv, batch);
+    }
     h->cont_A = (double *)h->msgC.p;   // compacted bit_to_check state (gathered inside decode_device)
     h->cont_C = (double *)h->msgA.p;   // the gather's source, then the second pass's check_to_bit array
     h->cont_it_start = k1;
@@ -429,11 +498,26 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     h->cont_rows_dev = (const unsigned *)h->osd_counters.p + 2;
     // grids of the tile-looping kernels: the rows the histogram expects + a margin (they loop, so any count is handled)
     h->cont_grid_tiles = (int64_t)(live * 1.25 * (double)tiles1) + 8;
+    if (lane_after > 0) { h->max_iter = k1 + lane_after; h->keep_state = true; }  // (lanes follow: these rounds leave their messages behind)
     rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+    h->keep_state = false;
+    h->max_iter = full;
     h->cont_A = h->cont_C = nullptr;
     h->cont_it_start = 0;
     h->cont_row_map = nullptr;
     h->cont_rows_dev = nullptr;
     if (rc) return rc;
+    if (lane_after > 0) {
+        // what those rounds left: the rows of the whole batch whose flag is still down (only rows of the second pass can be), where each sat in
+        // the second pass's tiles (the inverse of its row list), and the lane kernel on them from the second pass's bit->check array
+        if ((rc = h->flood_list2.ensure(B * sizeof(int32_t))) || (rc = h->flood_pos.ensure(B * sizeof(int32_t)))) return rc;
+        unsigned *count2 = (unsigned *)h->osd_counters.p + 4;
+        HIPCHK(hipMemsetAsync(count2, 0, 2 * sizeof(unsigned), h->stream));
+        hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch, (int32_t *)h->flood_list2.p, count2);
+        hipLaunchKernelGGL(row_positions_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, (const int32_t *)h->osd_list.p,
+                           (const unsigned *)h->osd_counters.p, (int32_t *)h->flood_pos.p);
+        HIPCHK(hipGetLastError());
+        if ((rc = launch_lanes(k1 + lane_after, (const double *)h->msgC.p, (const int32_t *)h->flood_pos.p, (const int32_t *)h->flood_list2.p, count2, false))) return rc;
+    }
     return stream_leave_histogram(h, iters, conv, batch);
 }

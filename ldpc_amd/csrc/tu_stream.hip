@@ -4,6 +4,7 @@
 #include "bp_device_common.h"
 #include "bp_stream_kernel.h"
 #include "bp_spread_kernels.h"
+#include "bp_flood_lane_kernel.h"
 #include "io_kernels.h"
 
 #include "host_handle.h"

@@ -333,8 +333,9 @@ def test_streamed_parallel_schedule_repacks_from_the_previous_histogram(oracle_b
 
 
 
+@pytest.mark.parametrize("flood_lanes", [0, 1, 2, 4])
 @pytest.mark.parametrize("method,alpha", [(0, 1.0), (1, 0.0)])
-def test_lane_compaction_carries_the_decode_on_at_any_cut(method, alpha, oracle_built):
+def test_lane_compaction_carries_the_decode_on_at_any_cut(method, alpha, flood_lanes, oracle_built):
     """The streamed two-pass decode (ldpc_hip_bp_set_repack(k)): k iterations for all, then the unconverged rows' message state is
     compacted lane by lane into dense tiles and iterations k + 1 ... follow on those.  Any cut must give the arrays of the plain
     run -- including a cut after which nothing is left, one that leaves almost everything, the last possible one, the adaptive
@@ -347,6 +348,8 @@ def test_lane_compaction_carries_the_decode_on_at_any_cut(method, alpha, oracle_
     max_iter = 14
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, 0.04), max_iter, method, alpha)
     eng.set_small_code_kernel(0)
+    # 1: what the first pass leaves finishes a workgroup per syndrome (bp_flood_lane_kernel) instead of in tiles; 2 / 4: after one / three rounds in compacted tiles
+    eng.set_debug_switch("FLOOD_LANES", flood_lanes)
     s = torch.cat([eng.gen_bsc_syndromes(5, 0.03, shot0=0, shots=33000, device="cuda:0"),
                    eng.gen_bsc_syndromes(6, 0.09, shot0=0, shots=900, device="cuda:0")])
     s = s[torch.randperm(len(s), generator=torch.Generator().manual_seed(2)).to(s.device)].contiguous()
@@ -369,3 +372,38 @@ def test_lane_compaction_carries_the_decode_on_at_any_cut(method, alpha, oracle_
     rows = np.r_[0:48, np.flatnonzero(it == max_iter)[:48]]
     want = oracle_built.BpOracle(h, error_rate=0.04, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha).decode_batch(s.cpu().numpy()[rows])
     assert np.array_equal(plain[0][rows], want[0]) and np.array_equal(plain[2][rows], want[2]) and bits_equal(plain[1][rows], want[1])
+
+
+@pytest.mark.parametrize("code", ["ldpc36_n1200", "irregular", "hamming_heavy"])
+def test_rows_a_first_pass_leaves_finish_a_workgroup_per_syndrome(code, oracle_built):
+    """bp_flood_lane_kernel on regular, irregular (rows and columns heavier than the register bounds included) and product-sum / min-sum
+    decodes, forced after first passes of several lengths: the arrays of the plain run, bit for bit, and the checker's on a sample."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    if code == "ldpc36_n1200":
+        h, p, max_iter = sp.csr_matrix(codes.regular_ldpc_code(n=1200, dv=3, dc=6, seed=3)), 0.055, 20
+    elif code == "irregular":
+        h, p, max_iter = sp.csr_matrix(codes.irregular_ldpc_code(1500, 750, seed=4)), 0.03, 16
+    else:
+        h, p, max_iter = sp.csr_matrix(codes.hamming_code(7)), 0.01, 10  # rows of 64 entries: beyond the register bounds
+    n = h.shape[1]
+    for method, alpha in ((0, 1.0), (1, 0.75)):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
+        eng.set_small_code_kernel(0)
+        s = eng.gen_bsc_syndromes(9, p, shot0=0, shots=33000 + 17, device="cuda:0")
+        s[5, 0] = 2
+        eng.set_repack(0)
+        plain = [t.cpu().numpy() for t in eng.decode_batch(s)]
+        for k, fl in ((1, 1), (3, 1), (max_iter - 1, 1), (2, 2), (3, 3), (1, 4)):
+            eng.set_debug_switch("FLOOD_LANES", fl)
+            eng.set_repack(k)
+            got = [t.cpu().numpy() for t in eng.decode_batch(s)]
+            for a, b in zip(plain, got):
+                assert bits_equal(a, b) if a.dtype == np.float64 else np.array_equal(a, b), (code, method, k, fl)
+            lean = eng.decode_batch(s, want_llr=False)
+            assert lean[1] is None and np.array_equal(lean[0].cpu().numpy(), plain[0]) and np.array_equal(lean[2].cpu().numpy(), plain[2])
+        rows = np.r_[0:40, np.flatnonzero(~plain[3].astype(bool))[:24]]
+        want = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha).decode_batch(s.cpu().numpy()[rows])
+        assert np.array_equal(plain[0][rows], want[0]) and np.array_equal(plain[2][rows], want[2]) and bits_equal(plain[1][rows], want[1])
+        eng.close()
