@@ -845,30 +845,39 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid(C * m1), dim3(256), 0, st, cur_synd, sub, cnt, h->m, (uint8_t *)synds[nxt]->p);
         HIPCHK(hipGetLastError());
         if ((rc = h->rp_iters.ensure(C * 4)) || (rc = h->rp_conv.ensure(C))) return rc;
-        if (to_lanes) {
-            if ((rc = h->rp_dec.ensure(C * n1)) || (llr && (rc = h->rp_llr.ensure(C * n1 * 8)))) return rc;
-            if ((rc = other->ensure(sizeof(double) * (size_t)h->nnz * C))) return rc;
-            hipLaunchKernelGGL(serial_rows_from_tiles_kernel, dim3((unsigned)((h->nnz + 1023) / 1024), (unsigned)cnt), dim3(256), 0, st, (const double *)state->p, sub, cnt, h->nnz,
-                               (double *)other->p);
-            HIPCHK(hipGetLastError());
-            if ((rc = serial_lane_launch(h, sp, it, (double *)other->p, (const uint8_t *)synds[nxt]->p, cnt, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
-                                         (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
-            if ((rc = scatter_out((const int32_t *)lists[nxt]->p, cnt, true))) return rc;
-            break;
+        // A compute unit holds one 16-wavefront tile: a pass of 267 tiles is a round of 256 and a round of 11 that takes as long.  The rows
+        // beyond the last whole round of tiles -- if they are few enough for the lane kernel -- finish there instead, at once.
+        int64_t keep = cnt;  // rows that go on in tiles
+        if (!to_lanes && lane_max > 0) {
+            const int64_t round_rows = (h->sw("SER_ROUND_TILES") > 0 ? h->sw("SER_ROUND_TILES") : 256) * (int64_t)LDPC_WAVE, over = cnt % round_rows;
+            if (cnt > round_rows && over > 0 && over <= lane_max && h->sw("SER_NO_REMAINDER") <= 0) keep = cnt - over;
         }
-        // their message state, lane by lane, into dense tiles of the other array
-        const int64_t tiles2 = (cnt + LDPC_WAVE - 1) / LDPC_WAVE;
-        if ((rc = other->ensure(per_tile_msg * (size_t)tiles2))) return rc;
+        const int64_t tiles2 = to_lanes ? 0 : (keep + LDPC_WAVE - 1) / LDPC_WAVE, n_lane = to_lanes ? cnt : cnt - keep;
+        // (one allocation for both: the compacted tiles first, the lane kernel's row-major arrays behind them)
+        if ((rc = other->ensure(per_tile_msg * (size_t)tiles2 + sizeof(double) * (size_t)h->nnz * (size_t)n_lane))) return rc;
+        if (n_lane > 0) {
+            const int64_t at = cnt - n_lane;  // the last n_lane rows of the list
+            double *rows_state = (double *)((char *)other->p + per_tile_msg * (size_t)tiles2);
+            if ((rc = h->rp_dec.ensure((size_t)n_lane * n1)) || (llr && (rc = h->rp_llr.ensure((size_t)n_lane * n1 * 8)))) return rc;
+            hipLaunchKernelGGL(serial_rows_from_tiles_kernel, dim3((unsigned)((h->nnz + 1023) / 1024), (unsigned)n_lane), dim3(256), 0, st, (const double *)state->p, sub + at, n_lane,
+                               h->nnz, rows_state);
+            HIPCHK(hipGetLastError());
+            if ((rc = serial_lane_launch(h, sp, it, rows_state, (const uint8_t *)synds[nxt]->p + (size_t)at * m1, n_lane, (uint8_t *)h->rp_dec.p, llr ? (double *)h->rp_llr.p : nullptr,
+                                         (int32_t *)h->rp_iters.p, (uint8_t *)h->rp_conv.p))) return rc;
+            if ((rc = scatter_out((const int32_t *)lists[nxt]->p + at, n_lane, true))) return rc;
+            if (to_lanes) break;
+        }
+        // the others' message state, lane by lane, into dense tiles of the other array
         const int epw = 16;
         const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), (unsigned)(tiles2 < 32768 ? tiles2 : 32768));
-        hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)state->p, sub, cnt, h->nnz, epw, (double *)other->p, (const unsigned *)nullptr);
+        hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)state->p, sub, keep, h->nnz, epw, (double *)other->p, (const unsigned *)nullptr);
         HIPCHK(hipGetLastError());
         std::swap(state, other);
         cur = nxt;
         cur_synd = (const uint8_t *)synds[cur]->p;
         identity = false;
         resume = false;
-        R = cnt;
+        R = keep;
     }
     return finish();
 }

@@ -84,7 +84,7 @@ def test_streamed_serial_kernel_against_the_checker_and_the_walking_kernel(metho
         assert np.array_equal(d0, dec) and np.array_equal(i0, it) and bits_equal(l0, llr)
 
 
-@pytest.mark.parametrize("lane_max", [-1, 0, 40])
+@pytest.mark.parametrize("lane_max", [-1, 0, 40, 200])
 @pytest.mark.parametrize("first_pass", [-1, 1, 2, 4, 7])
 def test_streamed_serial_decode_in_passes_gives_identical_results(first_pass, lane_max, oracle_built):
     """Passes that end after 4, 8, 16, ... iterations (or first_pass, 2 first_pass, ...): after each the rows still decoding either carry on
@@ -106,6 +106,8 @@ def test_streamed_serial_decode_in_passes_gives_identical_results(first_pass, la
         assert 0.02 < 1 - c0.mean() < 0.95 and i0[c0].min() < i0[c0].max()
         eng.set_repack(first_pass)
         eng.set_debug_switch("SER_LANE_MAX", lane_max)
+        if lane_max == 200:  # a "round" of 4 tiles instead of 256: what a pass leaves beyond whole rounds goes to the lane kernel, the rest on in tiles
+            eng.set_debug_switch("SER_ROUND_TILES", 4)
         d1, l1, i1, c1 = eng.decode_batch(synd)
         assert np.array_equal(d0, d1) and np.array_equal(i0, i1) and np.array_equal(c0, c1) and bits_equal(l0, l1)
         d2, l2, i2, c2 = eng.decode_batch(synd, want_llr=False)
