@@ -10,8 +10,8 @@ RULES = {  # template -> who selects which instantiation
     "bp_decode_kernel": "host_stream.h decode_device via pick_kernel(tu_stream.hip): <METHOD, MATH, DR, DC, RING> -- RING 2 (default) / 3 for exactly (6,3)- or (8,4)-regular H "
                         "(ldpc_hip_bp_set_ring picks the depth, 0 = register variant); else the smallest (DR, DC) of (4,3) (6,3) (8,4) (8,8) (16,8) (16,16) that "
                         "bounds the heaviest row / column (heavier nodes stream through memory inside the kernel)",
-    "bp_spread_check_kernel": "host_stream.h pick_spread: <METHOD, MATH, DR in 4/6/8/16, NT> (NT: tiles in flight outgrow the MALL)",
-    "bp_spread_bit_kernel": "host_stream.h pick_spread: <METHOD, MATH, DC in 3/4/8/16, NT>",
+    "bp_spread_check_kernel": "host_stream.h pick_spread: <METHOD, MATH, DR in 8/16, NT, LOOP> (NT: tiles in flight outgrow the MALL; LOOP: the slots beyond the first 32 of a compacted list)",
+    "bp_spread_bit_kernel": "host_stream.h pick_spread: <METHOD, MATH, DC in 4/8, NT, LOOP>",
     "bp_spread_init_kernel": "host_stream.h: batches of <= 256 tiles (per-pass kernels from the first iteration)",
     "bp_edge0_kernel": "host_stream.h: initial edge values of the ring variants",
     "bp_wave_kernel": "host_onchip.h plan_wave / pick_wave: <METHOD, MATH, DR, DC, TEAM> for (4,2) (4,4) (6,3) (8,4) (8,8) and, min-sum only, (16,8); TEAM where LDS leaves "
@@ -22,6 +22,10 @@ RULES = {  # template -> who selects which instantiation
     "bp_small_kernel": "host_onchip.h decode_small: small codes no wavefront kernel takes (rows > 32 or columns > 8)",
     "bp_serial_kernel": "host_serial.h pick_serial: serial schedule, one wavefront per tile",
     "bp_serial_level_kernel": "host_serial.h pick_serial_level: serial schedule, level-parallel",
+    "bp_serial_stream_kernel": "host_serial.h decode_serial_streamed / decode_serial_pass: serial schedule on (6,3)-shaped matrices with >= 32 bits a level: <METHOD, MATH, 6, 3, RING 1 (default) / 2>",
+    "bp_serial_lane_kernel": "host_serial.h serial_lane_launch: what a streamed pass leaves (<= 2048 rows), batches of <= 256 rows: a workgroup per syndrome",
+    "bp_flood_lane_kernel": "host_stream.h decode_stream_repacked, on request only (FLOOD_LANES): the rows a first pass of the flooding schedule leaves, a workgroup per syndrome",
+    "bp_spread_compact_kernel": "host_stream.h: the list of parked tiles without the final ones, every 8 rounds of a second pass with few expected stragglers",
     "bp_softinfo_kernel": "host_serial.h soft_info_device", "bp_softinfo_level_kernel": "host_serial.h soft_info_device (level-parallel)",
     "bp_serial_relative_kernel": "host_serial.h decode_serial_relative: codes beyond LDS (or LDPC_HIP_REL_LDS=0)",
     "bp_relative_lds_kernel": "host_serial.h decode_serial_relative_lds: <METHOD, MATH, DRT in 4/8/16, GS, DCT>: GS = 64 lanes per syndrome and the level-by-level sweep (DCT = 2/4/8 lanes per bit >= the heaviest column) when the order is a permutation of the bits; else bit by bit, product-sum with GS = 16 where four syndromes per wavefront fit (DCT 8 unused).  The 1 - 2 spilled VGPRs of the min-sum forms (~30 of the product-sum ones) sit around the call of the out-of-line sort, once per iteration",
