@@ -34,6 +34,7 @@ done
 python - "$OUT" > "$OUT/summary.txt" <<'PY'
 import glob, os, sqlite3, sys
 out = sys.argv[1]
+allres = {}
 for which in ("surface", "bb"):
     res = {}
     for p in sorted(glob.glob(os.path.join(out, which + "*", "**", "*.db"), recursive=True)):
@@ -44,6 +45,30 @@ for which in ("surface", "bb"):
     print(which)
     for k, (v, ms) in sorted(res.items()):
         print(f"  {k:28s} {v:16.0f} per dispatch   ({ms:.2f} ms)")
+    allres[which] = res
+# what bench.py's f1_rel_* entries price their VALU bound with: wave-instructions per syndrome-iteration (16 384 syndromes a dispatch; mean
+# iterations from the run's own line in log.txt), stamped with the kernel sources' fingerprint
+import json, re
+sys.path.insert(0, os.getcwd())
+try:
+    import bench
+    tag = bench.kernel_sources_sha16()
+except Exception:
+    tag = None
+its = {}
+for line in open(os.path.join(out, "log.txt")):
+    mm = re.match(r"(surface|bb) kernel ms [0-9.]+ mean it ([0-9.]+)", line)
+    if mm:
+        its[mm.group(1)] = float(mm.group(2))
+doc = {"source": "tools/profile_serial_relative.sh: rocprofv3 --pmc over bp_relative_lds_kernel, 16 384 syndromes, p = 0.05", "kernel_sources_sha16": tag}
+for which, key in (("surface", "f1_rel_surface"), ("bb", "f1_rel_bb144")):
+    r = allres.get(which, {})
+    if which in its and "SQ_INSTS_VALU" in r and "GRBM_GUI_ACTIVE" in r:
+        si = 16384.0 * its[which]
+        doc[key] = {"valu_wave_insts_per_syndrome_iteration": r["SQ_INSTS_VALU"][0] / si, "salu_wave_insts_per_syndrome_iteration": r.get("SQ_INSTS_SALU", (0, 0))[0] / si,
+                    "lds_wave_insts_per_syndrome_iteration": r.get("SQ_INSTS_LDS", (0, 0))[0] / si,
+                    "valu_busy_frac_in_profile": r["SQ_ACTIVE_INST_VALU"][0] * 4.0 / (1024.0 * r["GRBM_GUI_ACTIVE"][0] / 8.0), "mean_iterations_in_profile": its[which]}
+json.dump(doc, open(os.path.join(out, "f1_rel_valu.json"), "w"), indent=1)
 PY
 echo "phases (LDPC_HIP_REL_PROF=1, tools/serial_relative_phases.py; 65 536 syndromes):" >> "$OUT/summary.txt"
 timeout 300 python tools/serial_relative_phases.py surface bb bbms 2>&1 | grep -v amdgpu.ids >> "$OUT/summary.txt"
