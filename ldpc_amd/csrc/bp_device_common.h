@@ -64,6 +64,12 @@ struct BpArgs {
     const int32_t *row_map;
     // shader-clock probe (clock_probe_*, below): {cycles, constant-rate ticks} summed over this kernel's workgroups, or nullptr
     unsigned long long *clk;
+    // Variable-degree LDS ring (bp_decode_kernel<..., LDPC_RING_VAR>): the check rows and the bit-column pairs in the order the
+    // wavefronts take them (entry w + step * wavefronts), four ints each -- row: {first edge, row, weight, 0}; pair of columns
+    // (2g, 2g + 1): {first position in csc_edge, g, weight of column 2g, weight of column 2g + 1 or -1 if there is none}.
+    // ring_units: 1 KiB units of LDS per wavefront.
+    const int32_t *row_items, *pair_items;
+    int32_t ring_units;
 };
 
 // What a 64-syndrome tile needs besides its message arrays to continue in the per-pass kernels.  Those run in
@@ -396,6 +402,18 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N < 63 ? N : 63) : "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the same wait with a count known only at run time (wave-uniform): `s_waitcnt` takes an immediate, so one of 64 instructions is
+// picked by a scalar branch.  As above a count that is too small only waits longer; 63 is the most the counter can express.
+#define LDPC_WAIT_CASE(k) case (k): wait_vmcnt<(k)>(); break;
+#define LDPC_WAIT_CASE8(b) LDPC_WAIT_CASE((b) + 0) LDPC_WAIT_CASE((b) + 1) LDPC_WAIT_CASE((b) + 2) LDPC_WAIT_CASE((b) + 3) \
+                           LDPC_WAIT_CASE((b) + 4) LDPC_WAIT_CASE((b) + 5) LDPC_WAIT_CASE((b) + 6) LDPC_WAIT_CASE((b) + 7)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (__builtin_amdgcn_readfirstlane(n)) {
+        LDPC_WAIT_CASE8(0) LDPC_WAIT_CASE8(8) LDPC_WAIT_CASE8(16) LDPC_WAIT_CASE8(24) LDPC_WAIT_CASE8(32) LDPC_WAIT_CASE8(40) LDPC_WAIT_CASE8(48)
+        LDPC_WAIT_CASE(56) LDPC_WAIT_CASE(57) LDPC_WAIT_CASE(58) LDPC_WAIT_CASE(59) LDPC_WAIT_CASE(60) LDPC_WAIT_CASE(61) LDPC_WAIT_CASE(62)
+        default: wait_vmcnt<63>(); break;
+    }
+}
 
 // ---- kernel arguments read on demand ---------------------------------------------------------------------------------------------
 // A kernel whose inner loop fills the scalar register file (bp_edge_kernel: 56 lane masks) cannot also keep a dozen pointers it

@@ -11,7 +11,7 @@
 struct SpreadArgs {
     BpArgs bp;
     int32_t n_tiles;  // entries of bp.handoff_list; < 0: only the device knows (bp.counters[1], left by the persistent kernel)
-    int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4 otherwise: amortises the table load)
+    int32_t nodes;    // rows / columns per wavefront (1 for a handful of tiles: latency; 4, or 16 for >= 512 tiles from the start: amortises the table load)
     int32_t round;    // 0-based per-pass round; a tile's iteration number is it0 + round + 1
     unsigned *host_flag;  // host-mapped word: receives `seq` when the last parked tile becomes final (the host stops queueing rounds)
     unsigned seq;

@@ -9,14 +9,29 @@
 //   METHOD  LDPC_HIP_PRODUCT_SUM | LDPC_HIP_MINIMUM_SUM      MATH  0 libm-exact | 1 fast (product-sum only)
 //   DR, DC  register bounds on row / column weight; heavier nodes are streamed through memory in two sweeps
 //   RING    0: next row / bits prefetched into VGPRs;  2 or 3: slots of the per-wavefront LDS ring filled by
-//           `buffer_load_dwordx4 ... lds` (only for matrices with a single row weight DR and column weight DC)
+//           `buffer_load_dwordx4 ... lds` (only for matrices with a single row weight DR and column weight DC);
+//           LDPC_RING_VAR: the ring as a queue of 1 KiB units for rows of 0 .. DR entries and column pairs of 0 .. 2 DC entries
+//           (irregular matrices; "variable-degree ring" below)
 // Register budget: the ring variants fit 80 VGPRs (six wavefronts per SIMD, 12-wavefront workgroups); the register-prefetch variants get
 // 128 (four per SIMD) up to DR = 6, 168 at DR = 8 (workgroups of at most 12 wavefronts) and 256 at DR = 16 (at most 8): a row of 16
 // entries with its prefix products and one exact transcendental in flight does not fit 128 without spilling into the row loop
 // (host side: stream_max_waves).
-constexpr int stream_max_waves(int dr, int ring) { return ring ? 16 : dr > 8 ? 8 : dr > 6 ? 12 : 16; }
+// Variable-degree ring.  A wavefront's LDS is a circular queue of U units of 1 KiB (one DMA instruction = two 512-byte edge segments).
+// An item -- a check row (its entries are consecutive edges of A) or a pair of bit columns (their entries are gathered from C through
+// csc_edge, the second column's behind the first's) -- takes ceil(entries / 2) units at the queue's head.  The wavefront copies the
+// current item from LDS into registers, frees its units, queues the DMAs of up to two items ahead as far as they fit, and computes.
+// Items come in an order the host chose so that heavy and light ones alternate along each wavefront's sequence (BpArgs::row_items,
+// pair_items): two consecutive ones then fit the queue nearly always.  The wait before an item is read is the counted one of the
+// fixed-degree ring, with the count kept at run time: `ops` counts the vector-memory instructions this wavefront has issued (DMAs,
+// message stores, decision words -- the posterior stores, which depend on the tile's state, are left out: a count that is too small
+// only waits longer), an item remembers `ops` after its last DMA, and the difference is what may still be outstanding.
+// 168 VGPRs (three wavefronts per SIMD, 12 per workgroup): a row of 16 entries with its prefix products and the results of the table
+// branch of the exact logarithm fits without spilling.
+#define LDPC_RING_VAR 9
+typedef int ldpc_v4i __attribute__((ext_vector_type(4)));
+constexpr int stream_max_waves(int dr, int ring) { return ring == LDPC_RING_VAR ? 12 : ring ? 16 : dr > 8 ? 8 : dr > 6 ? 12 : 16; }
 template <int METHOD, int MATH, int DR, int DC, int RING>
-__global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__((amdgpu_waves_per_eu(RING ? 6 : DR > 8 ? 2 : DR > 6 ? 3 : 4))) bp_decode_kernel(const BpArgs a) {
+__global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__((amdgpu_waves_per_eu(RING == LDPC_RING_VAR ? 3 : RING ? 6 : DR > 8 ? 2 : DR > 6 ? 3 : 4))) bp_decode_kernel(const BpArgs a) {
     constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -56,10 +71,14 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
     constexpr int N_CHECK = RING * DR + (RING - 1) * ROW_DMAS;
     constexpr int N_BIT = RING * (2 * DC + 2) + (RING - 1) * DC;
     constexpr int N_BIT_QUIET = RING * 2 + (RING - 1) * DC;  // the decode's last bit pass sends no messages: only the two decision words per step are stored
-    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * (RING * SLOT_BYTES);
-    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * (RING * SLOT_BYTES));
+    constexpr bool VAR = RING == LDPC_RING_VAR;
+    static_assert(!VAR || (DR % 2 == 0 && DR <= 16 && DC <= 8), "an item of the variable-degree ring is at most 8 units");
+    const int U = VAR ? a.ring_units : 0;  // units of the variable-degree queue
+    const unsigned ring_bytes = VAR ? (unsigned)U * 1024u : (unsigned)(RING * SLOT_BYTES);  // per wavefront
+    const unsigned ring_addr = (unsigned)(uintptr_t)ldpc_dyn_lds + (unsigned)wave * ring_bytes;
+    const double *ringp = reinterpret_cast<const double *>(ldpc_dyn_lds + (size_t)wave * ring_bytes);
     // parking space of the exact product-sum check row (check_row_ps_exact_fast): behind the rings, LDPC_NEAR_BYTES per wavefront
-    double *near_buf = reinterpret_cast<double *>(ldpc_dyn_lds + (size_t)nwaves * (RING * SLOT_BYTES) + (size_t)wave * LDPC_NEAR_BYTES);
+    double *near_buf = reinterpret_cast<double *>(ldpc_dyn_lds + (size_t)nwaves * ring_bytes + (size_t)wave * LDPC_NEAR_BYTES);
     const unsigned l16 = (unsigned)lane * 16u;
 
     bool llr_each = false;  // tile-uniform: posteriors are stored by every bit pass (set at the first convergence event)
@@ -71,7 +90,7 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
 
     // initialise_log_domain_bp (bp.hpp:147-157): every edge of column j starts at llr0[j] -- written out, or (ring variant, a.edge0)
     // left implicit: the first check pass reads the table of initial values instead of the message array
-    const bool implicit_init = RING != 0 && a.edge0 != nullptr;
+    const bool implicit_init = RING != 0 && !VAR && a.edge0 != nullptr;
     if (!implicit_init && a.it_start == 0) {
         for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(llr0 + sload(col_idx + e))));
         __syncthreads();
@@ -103,7 +122,70 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
         if (METHOD == LDPC_HIP_MINIMUM_SUM)
             alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
 
-        if (RING && implicit_init && it == 1) {
+        if (VAR) {
+            // ---- variable-degree ring: rows of 0 .. DR entries (see the top of the file)
+            const int nsteps = wave < m ? (m - wave + nwaves - 1) / nwaves : 0;
+            const ldpc_v4i *items = reinterpret_cast<const ldpc_v4i *>(a.row_items);
+            int head = 0;
+            unsigned ops = 0;
+            auto issue_row = [&](const ldpc_v4i &item, int &pos, unsigned &mark) {
+                const int units = (item.z + 1) >> 1;
+                pos = head;
+#pragma unroll
+                for (int c = 0; c < DR / 2; ++c)
+                    if (c < units) {
+                        int u = head + c;
+                        if (u >= U) u -= U;
+                        lds_dma16(At.rsrc, l16, (unsigned)(item.x + 2 * c) << 9, ring_addr + (unsigned)u * 1024u);
+                    }
+                head += units;
+                if (head >= U) head -= U;
+                ops += (unsigned)units;
+                mark = ops;
+            };
+            ldpc_v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, nx = c0;  // current item, the (up to) two queued behind it, the first not queued
+            int p0 = 0, p1 = 0, p2 = 0, ahead = 0, queued = 0;
+            unsigned m0 = 0, m1 = 0, m2 = 0;
+            if (nsteps > 0) {
+                c0 = sload(items + wave);
+                issue_row(c0, p0, m0);
+                queued = 1;
+                if (nsteps > 1) nx = sload(items + wave + nwaves);
+            }
+            for (int idx = 0; idx < nsteps; ++idx) {
+                wait_vmcnt_dyn((int)(ops - m0));
+                const int d = c0.z;
+                double cur[DR];
+#pragma unroll
+                for (int k = 0; k < DR; ++k)
+                    if (k < d) {
+                        int u = p0 + (k >> 1);
+                        if (u >= U) u -= U;
+                        cur[k] = ringp[u * 128 + (k & 1) * LDPC_WAVE + lane];
+                    }
+                wait_lds_reads();  // the item's units are free
+                if (ahead == 0 && queued < nsteps) {
+                    c1 = nx;
+                    issue_row(c1, p1, m1);
+                    ahead = 1;
+                    if (++queued < nsteps) nx = sload(items + wave + queued * nwaves);
+                }
+                if (ahead == 1 && queued < nsteps && ((c1.z + 1) >> 1) + ((nx.z + 1) >> 1) <= U) {
+                    c2 = nx;
+                    issue_row(c2, p2, m2);
+                    ahead = 2;
+                    if (++queued < nsteps) nx = sload(items + wave + queued * nwaves);
+                }
+                const int i = c0.y;
+                const bool neg = (sload(nzm + i) >> lane) & 1ull;
+                const int parity = (int)((sload(par + i) >> lane) & 1ull);
+                check_row_live<METHOD, MATH, DR>(cur, d, c0.x, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
+                ops += (unsigned)d;  // one message store per entry, whichever routine ran
+                c0 = c1; p0 = p1; m0 = m1;
+                c1 = c2; p1 = p2; m1 = m2;
+                if (ahead > 0) --ahead;
+            }
+        } else if (RING && implicit_init && it == 1) {
             for (int i = wave; i < m; i += nwaves) {
                 double cur[DR];
 #pragma unroll
@@ -196,7 +278,91 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
         // ---------------- bit pass (bp.hpp:276-298 and 311-318, fused) ----------------
         const bool last = (it == a.max_iter);
         const bool lane_live = !((done >> lane) & 1ull);
-        if (RING) {
+        if (VAR) {
+            // ---- variable-degree ring: pairs of columns of 0 .. DC entries each; the pair's entries are positions
+            // [item.x, item.x + d0 + d1) of csc_edge, a DMA instruction gathers two of them (lanes 0-31 one segment, 32-63 the next)
+            const int ngroups = (n + 1) / 2;
+            const int nsteps = wave < ngroups ? (ngroups - wave + nwaves - 1) / nwaves : 0;
+            const ldpc_v4i *items = reinterpret_cast<const ldpc_v4i *>(a.pair_items);
+            const bool sends = !last || a.keep_state != 0;
+            int head = 0;
+            unsigned ops = 0;
+            auto entries = [](const ldpc_v4i &item) { return item.z + (item.w > 0 ? item.w : 0); };
+            auto issue_pair = [&](const ldpc_v4i &item, int &pos, unsigned &mark) {
+                const int units = (entries(item) + 1) >> 1;
+                pos = head;
+#pragma unroll
+                for (int c = 0; c < DC; ++c)
+                    if (c < units) {
+                        const int q0 = item.x + 2 * c, q1 = q0 + 1;
+                        const unsigned ea = (unsigned)sload(csc_edge + q0);
+                        const unsigned eb = (unsigned)sload(csc_edge + (q1 < nnz ? q1 : 0));
+                        const unsigned voff = ((lane < 32 ? ea : eb) << 9) + (unsigned)(lane & 31) * 16u;
+                        int u = head + c;
+                        if (u >= U) u -= U;
+                        lds_dma16(Ct.rsrc, voff, 0u, ring_addr + (unsigned)u * 1024u);
+                    }
+                head += units;
+                if (head >= U) head -= U;
+                ops += (unsigned)units;
+                mark = ops;
+            };
+            ldpc_v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, nx = c0;
+            int p0 = 0, p1 = 0, p2 = 0, ahead = 0, queued = 0;
+            unsigned m0 = 0, m1 = 0, m2 = 0;
+            if (nsteps > 0) {
+                c0 = sload(items + wave);
+                issue_pair(c0, p0, m0);
+                queued = 1;
+                if (nsteps > 1) nx = sload(items + wave + nwaves);
+            }
+            for (int idx = 0; idx < nsteps; ++idx) {
+                wait_vmcnt_dyn((int)(ops - m0));
+                const int d0 = c0.z, d1 = c0.w;  // (d1 < 0: the matrix has an odd number of columns and this is the last)
+                double c[2][DC];
+#pragma unroll
+                for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+                    for (int k = 0; k < DC; ++k)
+                        if (k < (u2 ? d1 : d0)) {
+                            const int rel = (u2 ? d0 : 0) + k;
+                            int u = p0 + (rel >> 1);
+                            if (u >= U) u -= U;
+                            c[u2][k] = ringp[u * 128 + (rel & 1) * LDPC_WAVE + lane];
+                        }
+                wait_lds_reads();
+                if (ahead == 0 && queued < nsteps) {
+                    c1 = nx;
+                    issue_pair(c1, p1, m1);
+                    ahead = 1;
+                    if (++queued < nsteps) nx = sload(items + wave + queued * nwaves);
+                }
+                if (ahead == 1 && queued < nsteps && ((entries(c1) + 1) >> 1) + ((entries(nx) + 1) >> 1) <= U) {
+                    c2 = nx;
+                    issue_pair(c2, p2, m2);
+                    ahead = 2;
+                    if (++queued < nsteps) nx = sload(items + wave + queued * nwaves);
+                }
+#pragma unroll
+                for (int u2 = 0; u2 < 2; ++u2) {
+                    const int j = 2 * c0.y + u2, dj = u2 ? d1 : d0;
+                    if (dj >= 0) {
+                        int e[DC];
+#pragma unroll
+                        for (int k = 0; k < DC; ++k)
+                            if (k < dj) e[k] = sload(csc_edge + c0.x + (u2 ? d0 : 0) + k);
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u2], e, dj, sload(llr0 + j), At, l8, sends);
+                        const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
+                        if (lane == 0) dcur[j] = hard;
+                        if ((last || llr_each) && want_llr && lane_live) Lt.st(l8, j, llr);
+                        ops += (unsigned)(sends ? dj : 0) + 1u;  // message stores + the decision word
+                    }
+                }
+                c0 = c1; p0 = p1; m0 = m1;
+                c1 = c2; p1 = p2; m1 = m2;
+                if (ahead > 0) --ahead;
+            }
+        } else if (RING) {
             // every column has exactly DC entries; a step handles the column pair (2g, 2g + 1), whose
             // 2*DC gathered segments arrive as DC DMA instructions (lanes 0-31 one segment, 32-63 the next)
             const int ngroups = (n + 1) / 2;

@@ -3,6 +3,8 @@
 // family each with its host side).  What one unit calls in another is declared at the end of this header.
 #pragma once
 
+#include <algorithm>
+#include <array>
 #include <chrono>
 #include <random>
 #include <atomic>
@@ -57,7 +59,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -84,6 +86,8 @@ struct ldpc_hip_bp {
     DeviceBuf wp_rdeg, wp_col, wp_epos;
     DeviceBuf w_rdeg, w_cdeg, w_col, w_apos, w_prior;
     DeviceBuf d_edge0;       // [n] initial edge values of the streamed kernel (BpArgs::edge0)
+    DeviceBuf var_row_items, var_pair_items;  // item tables of the variable-degree ring (BpArgs::row_items, pair_items; host_stream.h: ensure_var_ring_items)
+    bool var_items_built = false;
     // continuation of a first pass (decode_stream_repacked): decode_device takes its message state from here and counts on from cont_it_start
     double *cont_A = nullptr, *cont_C = nullptr;  // its bit_to_check (compacted) / check_to_bit arrays
     int32_t cont_it_start = 0;

@@ -11,6 +11,44 @@ static void pick_spread(const ldpc_hip_bp *h, bool nt, spread_kernel_t &kc, spre
     else pick_spread_m<LDPC_HIP_PRODUCT_SUM, 0, LOOP>(h->max_row_deg, h->max_col_deg, nt, kc, kb);
 }
 
+// Item tables of the variable-degree ring (bp_stream_kernel.h, LDPC_RING_VAR): the check rows, and the pairs of bit columns, in the
+// order the wavefronts take them -- wavefront w of a workgroup of W takes entries w, w + W, w + 2 W, ...  Blocks of W items come
+// alternately from the heavy and from the light end of the items sorted by size, so that along a wavefront's sequence a heavy item
+// is followed by a light one and two consecutive items fit its queue together.  (The order changes nothing in the results: the rows
+// of a check pass, and the columns of a bit pass, are independent of each other.)
+static int ensure_var_ring_items(ldpc_hip_bp *h, int W) {
+    if (h->var_items_built) return 0;
+    const int m = h->m, n = h->n, pairs = (n + 1) / 2;
+    std::vector<int32_t> col_ptr((size_t)n + 1, 0);
+    for (int32_t c : h->h_col_idx) ++col_ptr[(size_t)c + 1];
+    for (int j = 0; j < n; ++j) col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
+    auto interleave = [W](std::vector<std::array<int32_t, 4>> &items) {
+        auto units = [](const std::array<int32_t, 4> &it) { return (it[2] + (it[3] > 0 ? it[3] : 0) + 1) / 2; };
+        std::stable_sort(items.begin(), items.end(), [&](const std::array<int32_t, 4> &x, const std::array<int32_t, 4> &y) { return units(x) > units(y); });
+        std::vector<std::array<int32_t, 4>> out;
+        out.reserve(items.size());
+        size_t lo = 0, hi = items.size();
+        for (bool heavy = true; lo < hi; heavy = !heavy)
+            for (int k = 0; k < W && lo < hi; ++k) out.push_back(heavy ? items[lo++] : items[--hi]);
+        items.swap(out);
+    };
+    std::vector<std::array<int32_t, 4>> rows((size_t)m), prs((size_t)pairs);
+    for (int i = 0; i < m; ++i) rows[(size_t)i] = {h->h_row_ptr[(size_t)i], i, h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i], 0};
+    for (int g = 0; g < pairs; ++g) {
+        const int j0 = 2 * g, j1 = j0 + 1;
+        prs[(size_t)g] = {col_ptr[(size_t)j0], g, col_ptr[(size_t)j0 + 1] - col_ptr[(size_t)j0], j1 < n ? col_ptr[(size_t)j1 + 1] - col_ptr[(size_t)j1] : -1};
+    }
+    interleave(rows);
+    interleave(prs);
+    int rc;
+    if ((rc = h->var_row_items.ensure(16 * (size_t)(m ? m : 1)))) return rc;
+    if ((rc = h->var_pair_items.ensure(16 * (size_t)(pairs ? pairs : 1)))) return rc;
+    if (m) HIPCHK(hipMemcpy(h->var_row_items.p, rows.data(), 16 * (size_t)m, hipMemcpyHostToDevice));
+    if (pairs) HIPCHK(hipMemcpy(h->var_pair_items.p, prs.data(), 16 * (size_t)pairs, hipMemcpyHostToDevice));
+    h->var_items_built = true;
+    return 0;
+}
+
 // Everything below runs on h->stream with device pointers only.
 static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding,
                                   double *llr, int32_t *iters, uint8_t *conv);
@@ -54,7 +92,15 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
-    const int handoff = h->handoff < 0 ? 256 : h->handoff;
+    // Irregular matrices with rows of more than 8 entries, product-sum: the persistent kernel holds the check pass and the bit pass in
+    // ONE register allocation (158 VGPRs: three wavefronts per SIMD, the variable-degree ring no fewer), the per-pass kernels one
+    // each (106 and 62: four and eight per SIMD) and get through a tile-iteration ~1.5x faster (profiles/r5_irregular_paths.txt): unless
+    // the caller set a threshold, the whole batch takes the per-pass kernels from its first iteration.  Min-sum stays with the
+    // persistent kernel (0.71-0.76 of HBM against 0.68), and so does the regular headline code (its ring variant fits 80 VGPRs: 0.65
+    // against 0.60).
+    const bool per_pass_first = h->handoff < 0 && !h->regular && h->max_row_deg > 8 && h->max_row_deg <= 16 && h->max_col_deg <= 8 &&
+                                h->bp_method == LDPC_HIP_PRODUCT_SUM && !h->on("VAR_RING");
+    const int handoff = h->handoff < 0 ? (per_pass_first ? INT32_MAX : 256) : h->handoff;
     h->last_chunk_tiles = chunk;
     if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
     if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
@@ -62,10 +108,16 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
 
     const int ring = h->regular ? h->ring_depth : 0;
+    // the variable-degree ring (bp_stream_kernel.h, LDPC_RING_VAR) on request (VAR_RING 1) wherever it applies -- rows <= 16, columns <= 8.
+    // Measured on the irregular n = 10 000 code (profiles/r5_irregular_paths.txt): +5 % over the register variant for product-sum, -4 % for
+    // min-sum, and below the per-pass kernels for product-sum -- so it is not what runs by default anywhere.
+    const bool var_ring = h->m > 0 && h->n > 0 && h->max_row_deg <= 16 && h->max_col_deg <= 8 && h->on("VAR_RING");
     KernelChoice kern;
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, ring);
-    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring);
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_kernel<LDPC_HIP_MINIMUM_SUM, 0>(h->max_row_deg, h->max_col_deg, ring, var_ring);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 1>(h->max_row_deg, h->max_col_deg, ring, var_ring);
+    else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring, var_ring);
+    const int var_units = !kern.var_ring ? 0 : h->sw("VAR_RING_UNITS") >= 8 ? (h->sw("VAR_RING_UNITS") <= 40 ? h->sw("VAR_RING_UNITS") : 40) : 11;
+    if (kern.var_ring && (rc = ensure_var_ring_items(h, kern.max_waves))) return rc;
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed = false;
@@ -113,6 +165,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
         a.total_tiles = (int32_t)tiles;
         a.handoff_threshold = handoff;
         a.clk = h->d_clk;
+        if (kern.var_ring) { a.row_items = (const int32_t *)h->var_row_items.p; a.pair_items = (const int32_t *)h->var_pair_items.p; a.ring_units = var_units; }
         HIPCHK(hipMemsetAsync(h->counter.p, 0, 16, st));
 
         // Wavefronts per workgroup (one workgroup = one 64-syndrome tile).  Register variant: 128 VGPRs,
@@ -123,13 +176,14 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
         int waves = h->waves_per_wg;
         if (waves <= 0) {
             if (kern.ring_depth) waves = tiles >= 512 ? 12 : 16;
+            else if (kern.var_ring) waves = kern.max_waves;
             else waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
         }
         if (waves > kern.max_waves) waves = kern.max_waves;
         // ring variant: each wavefront owns RING slots of dynamic LDS; stay below the 160 KiB of a CU
         // + the parking space of the exact product-sum check row (LDPC_NEAR_BYTES per wavefront, behind the rings)
         const size_t near_bytes = (h->bp_method == LDPC_HIP_PRODUCT_SUM && h->math_mode == LDPC_HIP_MATH_LIBM_EXACT) ? LDPC_NEAR_BYTES : 0;
-        const size_t lds_per_wave = (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth + near_bytes;
+        const size_t lds_per_wave = (kern.var_ring ? (size_t)var_units * 1024u : (size_t)kern.ring_slot_bytes * (size_t)kern.ring_depth) + near_bytes;
         while (lds_per_wave * (size_t)waves > 144u * 1024u) --waves;
         const size_t dyn_lds = lds_per_wave * (size_t)waves;
         if (dyn_lds > 48u * 1024u)
@@ -165,7 +219,11 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
             // so few tiles that they would each sit on one compute unit: per-pass launches from the start
             grid_tiles = (unsigned)tiles;
             sa.n_tiles = (int32_t)tiles;
-            sa.nodes = tiles <= 8 ? 1 : 4;
+            // rows (columns) per wavefront of a per-pass workgroup: 1 when a handful of tiles must fill the chip, 4 up to a few hundred
+            // tiles (the chunks of the pipelined host path among them), 16 from 512 on -- a workgroup's start (the logarithm table into
+            // LDS, the tile's state) is then paid per 64 rows instead of per 16: 0.563 against 0.535 of HBM on the irregular code's 512
+            // tiles, same box (profiles/r5_irregular_paths.txt)
+            sa.nodes = h->sw("SPREAD_NODES") > 0 ? h->sw("SPREAD_NODES") : tiles <= 8 ? 1 : tiles < 512 ? 4 : 16;
             first_round = 0;
             hipLaunchKernelGGL(bp_spread_state_init_kernel, dim3((grid_tiles + 255) / 256), dim3(256), 0, st, sa);
             const dim3 gi((unsigned)(h->nnz ? (h->nnz + 63) / 64 : 1), grid_tiles);  // (a grid dimension must not be 0: empty matrices)
@@ -192,7 +250,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
                 // how many it did park stays on the device
                 grid_tiles = (unsigned)(tiles < handoff ? tiles : handoff);
                 sa.n_tiles = -1;
-                sa.nodes = 4;
+                sa.nodes = h->sw("SPREAD_NODES2") > 0 ? h->sw("SPREAD_NODES2") : 4;  // (4, 8 and 16 measure the same on the headline's last 256 tiles)
             }
         }
         if (grid_tiles > 0) {

@@ -29,10 +29,12 @@ struct KernelChoice {
     int ring_slot_bytes;  // 0: register-prefetch variant, no dynamic LDS
     int ring_depth;
     int max_waves = 16;   // wavefronts per workgroup the variant was compiled for (stream_max_waves)
+    bool var_ring = false;  // the variable-degree ring (LDPC_RING_VAR): dynamic LDS = units x 1 KiB per wavefront, chosen at launch
 };
 
 template <int METHOD, int MATH>
-static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth) {
+static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth, bool var_ring) {
+    if (var_ring) return {bp_decode_kernel<METHOD, MATH, 16, 8, LDPC_RING_VAR>, 0, 0, stream_max_waves(16, LDPC_RING_VAR), true};
     // Register arrays are sized by the template bounds, so the common regular codes get exact fits:
     // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
     if (ring_depth == 2 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 2>, 3 * 1024, 2};

@@ -26,6 +26,8 @@ def run(name, h, p, max_iter, method, alpha, batch, osd0, steps=3, math="libm_ex
         eng.set_random_serial(True, random_serial)
     for key, val in switches:
         eng.set_debug_switch(key, val)
+    if os.environ.get("LDPC_BENCH_HANDOFF"):  # (A/B of the hand-off threshold: a value >= the number of tiles sends the whole batch to the per-pass kernels)
+        eng.set_handoff(int(os.environ["LDPC_BENCH_HANDOFF"]))
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=batch, device="cuda:0")
     if osd is not None:  # (osd_method, osd_order): 2 = OSD_E, 3 = OSD_CS
         eng.set_osd(*osd)
@@ -64,6 +66,12 @@ def main():
         for p_, meth, alpha in ((0.03, 0, 1.0), (0.06, 0, 1.0), (0.06, 1, 0.75), (0.12, 0, 1.0), (0.12, 1, 0.75)):  # (0.12: nothing converges -- every tile runs all 50 iterations)
             run(f"irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), {'product_sum' if meth == 0 else 'minimum_sum'} 50 it p={p_}",
                 h, p_, 50, meth, alpha, 32768, False)
+    if "irregular_fast" in args.which:  # the same code with the fast arithmetic (~1 ulp), product-sum
+        h = codes.irregular_ldpc_code(10000, 5000, seed=1)
+        for p_ in (0.06, 0.12):
+            run(f"irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), product_sum fast math 50 it p={p_}", h, p_, 50, 0, 1.0, 32768, False, math="fast")
+    if "irregular_ps12" in args.which:  # the all-50-iterations point alone (counter passes)
+        run("irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), product_sum 50 it p=0.12", codes.irregular_ldpc_code(10000, 5000, seed=1), 0.12, 50, 0, 1.0, 32768, False)
     if "serial" in args.which:
         serial()
     if "serial_big" in args.which:
