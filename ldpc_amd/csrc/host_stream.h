@@ -92,15 +92,6 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     if ((rc = h->dec.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if ((rc = h->dcur.ensure(sizeof(uint64_t) * (size_t)(h->n ? h->n : 1) * (size_t)chunk))) return rc;
     if (llr && (rc = h->llr_t.ensure(per_tile_llr * (size_t)chunk))) return rc;
-    // Irregular matrices with rows of more than 8 entries, product-sum: the persistent kernel holds the check pass and the bit pass in
-    // ONE register allocation (158 VGPRs: three wavefronts per SIMD, the variable-degree ring no fewer), the per-pass kernels one
-    // each (106 and 62: four and eight per SIMD) and get through a tile-iteration ~1.5x faster (profiles/r5_irregular_paths.txt): unless
-    // the caller set a threshold, the whole batch takes the per-pass kernels from its first iteration.  Min-sum stays with the
-    // persistent kernel (0.71-0.76 of HBM against 0.68), and so does the regular headline code (its ring variant fits 80 VGPRs: 0.65
-    // against 0.60).
-    const bool per_pass_first = h->handoff < 0 && !h->regular && h->max_row_deg > 8 && h->max_row_deg <= 16 && h->max_col_deg <= 8 &&
-                                h->bp_method == LDPC_HIP_PRODUCT_SUM && !h->on("VAR_RING");
-    const int handoff = h->handoff < 0 ? (per_pass_first ? INT32_MAX : 256) : h->handoff;
     h->last_chunk_tiles = chunk;
     if ((rc = h->tile_state.ensure(sizeof(TileState) * (size_t)chunk))) return rc;
     if ((rc = h->handoff_list.ensure(sizeof(int32_t) * (size_t)chunk))) return rc;
@@ -118,6 +109,17 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     else kern = pick_kernel<LDPC_HIP_PRODUCT_SUM, 0>(h->max_row_deg, h->max_col_deg, ring, var_ring);
     const int var_units = !kern.var_ring ? 0 : h->sw("VAR_RING_UNITS") >= 8 ? (h->sw("VAR_RING_UNITS") <= 40 ? h->sw("VAR_RING_UNITS") : 40) : 11;
     if (kern.var_ring && (rc = ensure_var_ring_items(h, kern.max_waves))) return rc;
+    // Product-sum on a matrix without a fixed-degree ring variant (irregular, or regular of another shape than (6,3) / (8,4), or the ring
+    // switched off): the persistent kernel holds the check pass AND the bit pass in one register allocation -- 128 VGPRs with rows of up to 6
+    // entries, 158-168 with 8 or 16: four, then three wavefronts per SIMD -- while the per-pass kernels hold one pass each (73-106 and 46-62
+    // VGPRs: 4-6 and 8 per SIMD), and the exact product-sum arithmetic is a dependent chain per wavefront that needs the wavefronts: they get
+    // through the same tile-iterations in 0.64 of the cycles (counter pass in profiles/r5_irregular_paths.txt).  So unless the caller set a
+    // threshold such a batch takes the per-pass kernels from its first iteration: 0.45 -> 0.56 of HBM on the irregular code with rows of 3 .. 16
+    // entries, 0.49 -> 0.63 and 0.46 -> 0.59 with rows of 3 .. 8, 0.57 -> 0.60 on the headline code with its ring off.  Min-sum has no such
+    // chain and stays with the persistent kernel (0.69-0.77 against 0.65-0.68), and so do the ring variants (80 VGPRs: 0.65 against 0.60).
+    const bool per_pass_first = h->handoff < 0 && h->bp_method == LDPC_HIP_PRODUCT_SUM && kern.ring_depth == 0 && !kern.var_ring &&
+                                h->max_row_deg <= 16 && h->max_col_deg <= 8;
+    const int handoff = h->handoff < 0 ? (per_pass_first ? INT32_MAX : 256) : h->handoff;
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed = false;

@@ -70,6 +70,11 @@ def main():
         h = codes.irregular_ldpc_code(10000, 5000, seed=1)
         for p_ in (0.06, 0.12):
             run(f"irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), product_sum fast math 50 it p={p_}", h, p_, 50, 0, 1.0, 32768, False, math="fast")
+    if "irregular8" in args.which:  # irregular codes whose rows fit the 8-entry register variants: <8,4,0> (columns 2..4) and <8,8,0> (columns 2..8)
+        for tag, cw in (("columns 2..4", ((2, 0.3), (3, 0.5), (4, 0.2))), ("columns 2..8", ((2, 0.35), (3, 0.5), (8, 0.15)))):
+            h = codes.irregular_ldpc_code(10000, 5000, seed=2, row_weights=(3, 4, 5, 6, 7, 8), col_weights=cw)
+            for p_, meth, alpha in ((0.05, 0, 1.0), (0.12, 0, 1.0), (0.12, 1, 0.75)):
+                run(f"irregular LDPC n=10000 m=5000 E={h.nnz} (rows 3..8, {tag}), {'product_sum' if meth == 0 else 'minimum_sum'} 50 it p={p_}", h, p_, 50, meth, alpha, 32768, False)
     if "irregular_ps12" in args.which:  # the all-50-iterations point alone (counter passes)
         run("irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), product_sum 50 it p=0.12", codes.irregular_ldpc_code(10000, 5000, seed=1), 0.12, 50, 0, 1.0, 32768, False)
     if "serial" in args.which:
