@@ -9,10 +9,12 @@ import sys
 RULES = {  # template -> who selects which instantiation
     "bp_decode_kernel": "host_stream.h decode_device via pick_kernel(tu_stream.hip): <METHOD, MATH, DR, DC, RING> -- RING 2 (default) / 3 for exactly (6,3)- or (8,4)-regular H "
                         "(ldpc_hip_bp_set_ring picks the depth, 0 = register variant); else the smallest (DR, DC) of (4,3) (6,3) (8,4) (8,8) (16,8) (16,16) that "
-                        "bounds the heaviest row / column (heavier nodes stream through memory inside the kernel)",
+                        "bounds the heaviest row / column (heavier nodes stream through memory inside the kernel); <., ., 16, 8, 9> = the variable-degree LDS ring, on request "
+                        "(VAR_RING 1).  Since round 5 a product-sum batch WITHOUT a ring variant skips this kernel unless the caller sets a hand-off threshold: it takes "
+                        "bp_spread_* from its first iteration (host_stream.h: per_pass_first)",
     "bp_spread_check_kernel": "host_stream.h pick_spread: <METHOD, MATH, DR in 8/16, NT, LOOP> (NT: tiles in flight outgrow the MALL; LOOP: the slots beyond the first 32 of a compacted list)",
     "bp_spread_bit_kernel": "host_stream.h pick_spread: <METHOD, MATH, DC in 4/8, NT, LOOP>",
-    "bp_spread_init_kernel": "host_stream.h: batches of <= 256 tiles (per-pass kernels from the first iteration)",
+    "bp_spread_init_kernel": "host_stream.h: batches of <= 256 tiles, and product-sum batches without a ring variant (per-pass kernels from the first iteration)",
     "bp_edge0_kernel": "host_stream.h: initial edge values of the ring variants",
     "bp_wave_kernel": "host_onchip.h plan_wave / pick_wave: <METHOD, MATH, DR, DC, TEAM> for (4,2) (4,4) (6,3) (8,4) (8,8) and, min-sum only, (16,8); TEAM where LDS leaves "
                       "few wavefronts per CU or the batch is small",
