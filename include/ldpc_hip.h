@@ -347,7 +347,9 @@ int ldpc_hip_bp_set_tuning(ldpc_hip_bp *h, int32_t waves_per_workgroup, int32_t 
 /* For matrices whose rows all have one weight and whose columns all have one weight the BP kernel
  * streams messages through a per-wavefront LDS ring filled by asynchronous global->LDS loads
  * (default: 2 slots per wavefront).  depth 0 forces the register-prefetch variant used for irregular
- * matrices, 2 or 3 select the ring depth (1 = default); results are identical in every case. */
+ * matrices, 2 or 3 select the ring depth (1 = default); results are identical in every case.  (Irregular matrices with rows of
+ * <= 16 and columns of <= 8 entries have a ring of their own -- a queue of 1 KiB units, debug switch "VAR_RING" 1 -- which is built and
+ * tested but not selected by default: see ldpc_hip_bp_set_handoff.) */
 int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
 
 /* Straggler hand-off of the streaming BP kernel.  A 64-syndrome tile is decoded by one persistent workgroup,
@@ -355,7 +357,10 @@ int ldpc_hip_bp_set_ring(ldpc_hip_bp *h, int32_t depth);
  * refuse to converge, a tiny batch, or the reference's default max_iter = n) those tiles park their state and
  * their remaining iterations run as per-pass launches (check pass, bit pass, syndrome test, bookkeeping) spread
  * over the whole chip; a batch of no more than `threshold_tiles` tiles runs that way from the first iteration.
- * -1 = automatic (256 tiles, default), 0 = off.  Results are identical.  The hand-off costs no host synchronisation. */
+ * -1 = automatic (default): 256 tiles -- except for product-sum on a matrix that has no fixed-degree ring variant (irregular codes; rows <= 16,
+ * columns <= 8 entries), where every batch runs as per-pass launches from its first iteration (the persistent kernel's single register
+ * allocation leaves three wavefronts per SIMD there, the per-pass kernels run 4 - 8: 0.45 -> 0.56 of HBM on the irregular n = 10 000 code);
+ * 0 = off; any value set here is taken as given.  Results are identical.  The hand-off costs no host synchronisation. */
 int ldpc_hip_bp_set_handoff(ldpc_hip_bp *h, int32_t threshold_tiles);
 
 /* Codes whose two message arrays fit in a few KiB per syndrome (surface codes, bivariate-bicycle codes)

@@ -119,7 +119,8 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_set_ring(self._h, int(depth)))
 
     def set_handoff(self, threshold_tiles):
-        """Straggler hand-off of the streaming kernel: -1 automatic (default), 0 off, k = park when <= k tiles run."""
+        """Straggler hand-off of the streaming kernel: -1 automatic (default: 256 tiles; product-sum batches on matrices without a ring variant
+        run as per-pass launches from the first iteration), 0 off, k = park when <= k tiles run."""
         _lib.check(self._lib.ldpc_hip_bp_set_handoff(self._h, int(threshold_tiles)))
 
     def set_osd(self, osd_method, osd_order):
