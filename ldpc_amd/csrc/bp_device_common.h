@@ -408,7 +408,7 @@ __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmc
 #define LDPC_WAIT_CASE8(b) LDPC_WAIT_CASE((b) + 0) LDPC_WAIT_CASE((b) + 1) LDPC_WAIT_CASE((b) + 2) LDPC_WAIT_CASE((b) + 3) \
                            LDPC_WAIT_CASE((b) + 4) LDPC_WAIT_CASE((b) + 5) LDPC_WAIT_CASE((b) + 6) LDPC_WAIT_CASE((b) + 7)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    switch (__builtin_amdgcn_readfirstlane(n)) {
+    switch (__builtin_amdgcn_readfirstlane(n < 0 ? 0 : n)) {  // (a count can not be negative; if it ever were, wait for everything)
         LDPC_WAIT_CASE8(0) LDPC_WAIT_CASE8(8) LDPC_WAIT_CASE8(16) LDPC_WAIT_CASE8(24) LDPC_WAIT_CASE8(32) LDPC_WAIT_CASE8(40) LDPC_WAIT_CASE8(48)
         LDPC_WAIT_CASE(56) LDPC_WAIT_CASE(57) LDPC_WAIT_CASE(58) LDPC_WAIT_CASE(59) LDPC_WAIT_CASE(60) LDPC_WAIT_CASE(61) LDPC_WAIT_CASE(62)
         default: wait_vmcnt<63>(); break;

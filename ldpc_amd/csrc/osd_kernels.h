@@ -385,6 +385,30 @@ struct OsdCandidate {
     bool valid;
 };
 
+// Pair number p of the reference's i-major list of pairs i < j < order (osd.hpp:91-99) -> (i, j).  Row i starts at
+// S(i) = i (2 order - 1 - i) / 2.  Small orders walk the rows (a few steps); larger ones -- OSD_CS takes any order up to n - rank, millions of
+// pairs on hypergraph-product codes -- invert the triangular number: i = floor((b - sqrt(b^2 - 8 p)) / 2), b = 2 order - 1, and the two loops
+// after it make the result exact whatever the rounding of the square root did (each runs at most a step or two).  p < order (order - 1) / 2.
+__device__ __forceinline__ void osd_pair_of(long p, int order, int &i, int &j) {
+    if (order <= 48) {
+        i = 0;
+        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
+        j = i + 1 + (int)p;
+        return;
+    }
+    const double b = 2.0 * (double)order - 1.0;
+    double disc = b * b - 8.0 * (double)p;
+    if (disc < 0.0) disc = 0.0;
+    long r = (long)((b - sqrt(disc)) * 0.5);
+    if (r < 0) r = 0;
+    if (r > order - 2) r = order - 2;
+    const long n2 = 2L * order - 1;
+    while (r > 0 && r * (n2 - r) / 2 > p) --r;
+    while (r < order - 2 && (r + 1) * (n2 - (r + 1)) / 2 <= p) ++r;
+    i = (int)r;
+    j = i + 1 + (int)(p - r * (n2 - r) / 2);
+}
+
 __device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int k, long c) {
     OsdCandidate r;
     r.mask = 0;
@@ -396,10 +420,8 @@ __device__ __forceinline__ OsdCandidate osd_candidate(int method, int order, int
     } else if (c < k) {  // weight one, every non-pivot column (osd.hpp:84-89)
         if (c < 64) r.mask = 1ull << c; else r.single = (int32_t)c;
     } else {  // pairs (i, j), i < j < order, i-major (osd.hpp:91-99)
-        long p = c - k;
-        int i = 0;
-        while (p >= order - 1 - i) { p -= order - 1 - i; ++i; }
-        const int j = i + 1 + (int)p;
+        int i, j;
+        osd_pair_of(c - k, order, i, j);
         if (j >= k) r.valid = false;  // past the candidate string in the reference
         else {  // (any osd_order <= k: columns below 64 go into the mask, the others are named)
             if (i < 64) r.mask |= 1ull << i; else r.single = i;
@@ -699,9 +721,7 @@ __global__ void __launch_bounds__(256) osdw_reg_kernel(const OsdArgs a) {
         };
         // osd_order > 64: a pair may sit in any two words of T -- each lane reads the two words of ITS pair (no broadcast any more)
         auto pair_cols = [&](long p, int &i, int &j) -> bool {  // pair number p of the reference's list (i-major, osd.hpp:91-99) -> i < j; false: past the string
-            i = 0;
-            while (p >= a.order - 1 - i) { p -= a.order - 1 - i; ++i; }
-            j = i + 1 + (int)p;
+            osd_pair_of(p, a.order, i, j);
             return j < k;
         };
         auto weigh_pair = [&](int qi, int qj) -> double {
@@ -1513,9 +1533,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         uint64_t win = 0;
         int wq_i = 0, wq_j = 0;
         if (far_win) {
-            long pp = best_c - k;
-            while (pp >= a.order - 1 - wq_i) { pp -= a.order - 1 - wq_i; ++wq_i; }
-            wq_j = wq_i + 1 + (int)pp;
+            osd_pair_of(best_c - k, a.order, wq_i, wq_j);
         } else if (best_c >= 0 && !single) {
             bool valid;
             win = a.method == 3 ? pair_mask(best_c - k, valid) : (uint64_t)(best_c + 1) & kmask;
