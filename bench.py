@@ -433,6 +433,50 @@ def serial_headline_config(dev, steps):
                           "counters of the first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
 
 
+def irregular_config(dev, steps):
+    """matrices that are not regular.  The irregular LDPC code of tools/bench_configs.py (n = 10 000, m = 5 000,
+    E = 40 000; rows of 3 .. 16 entries, columns of 2 .. 8), product_sum, 50 iterations, B = 32 768 at p = 0.12 (nothing converges: every
+    syndrome runs all 50 iterations) -- since round 5 on the per-pass kernels from the first iteration (csrc/host_stream.h: per_pass_first).
+    `frac` = SURVEY.md 8(d)'s bytes over the step over 8 TB/s; the path's second bound is FP64 issue (VALU busy 0.80 / 0.96 in the
+    check / bit kernel: profiles/r5_irregular_per_pass_pmc_summary.txt).  Parity: rows bit-exact against the checker, LLR bits included."""
+    import torch
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    import oracle  # checker only
+
+    h = codes.irregular_ldpc_code(10000, 5000, seed=1)
+    m, n = h.shape
+    p, B, max_iter = 0.12, 32768, 50
+    eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 0, 1.0, device=dev.index or 0)
+    s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=B, device=dev)
+    out = eng.decode_batch(s)
+    step_ms, kms = [], []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.decode_batch(s, out=out)
+        torch.cuda.synchronize()
+        step_ms.append((time.perf_counter() - t0) * 1e3)
+        kms.append(eng.last_kernel_ms())
+    ms = float(np.median(step_ms))
+    it = out[2].cpu().numpy()
+    cv = out[3].cpu().numpy()
+    rows = np.r_[0:24, B - 8:B]
+    idx = torch.from_numpy(rows).to(dev)
+    want = oracle.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=0).decode_batch(s[idx].cpu().numpy())
+    ok = bool(np.array_equal(out[0][idx].cpu().numpy(), want[0]) and oracle.bits_equal(out[1][idx].cpu().numpy(), want[1])
+              and np.array_equal(it[rows], want[2]) and np.array_equal(cv[rows].astype(bool), want[3].astype(bool)))
+    eng.close()
+    alg = algorithmic_bytes(it, m, n, h.nnz)
+    return {"config": "irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8), product_sum max_iter=50, batch=32768, BSC p=0.12", "key": "f3_irregular",
+            "value": B / ms * 1e3, "unit": "syndromes/s", "ms": ms, "ms_steps": [round(v, 3) for v in step_ms], "bp_kernel_ms": float(np.median(kms)),
+            "mean_iterations": float(it.mean()), "bp_converged_fraction": float(cv.astype(np.float64).mean()), "parity_vs_oracle": ok,
+            "parity": "bit-exact, 32 rows (decisions, iterations, flags, log-ratio bits)", "bound": "hbm",
+            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "bound_note": "SURVEY 8(d) bytes over the step; per-pass kernels from the first iteration (traffic 1.00 x algorithmic, VALU busy 0.80 check / 0.96 bit: "
+                          "profiles/r5_irregular_per_pass_pmc_summary.txt; the three paths side by side: profiles/r5_irregular_paths.txt)"}
+
+
 def host_io_leg(h, args, alpha, synd_dev, dec_dev, it_dev, device_value):
     """The drop-in's own I/O path (_bp_decoder.pyx:642-695 is NumPy in, NumPy out): the SAME batch as pageable host arrays through
     `BpDecoder.decode_batch` -- validation, the all-zero-row shortcut, H2D, kernels, D2H, all inside the timed call -- without and
@@ -839,6 +883,7 @@ def run(args, real_stdout, stage) -> None:
                 res["secondary"] = [early] + secondary_configs(dev, max(5, args.steps))  # (millisecond calls: a median of at least five)
                 res["secondary"] += schedule_configs(dev, args.steps)
                 res["secondary"].append(serial_headline_config(dev, args.steps))
+                res["secondary"].append(irregular_config(dev, args.steps))
                 if not all(e.get("parity_vs_oracle", False) for e in res["secondary"]):
                     res["parity_failed"] = True
             except Exception as exc:  # the headline line must not be lost to a secondary config
