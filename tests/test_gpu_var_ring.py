@@ -118,3 +118,33 @@ def test_regular_codes_forced_onto_the_variable_ring_equal_the_fixed_ring(dv, dc
             eng.set_handoff(handoff)
             _same(_decode(eng, s, want_llr=True), ref, f"({dv},{dc}) method {meth} handoff {handoff}")
         eng.close()
+
+
+IRREGULAR_FIXTURES = ["irregular_ldpc_n600_ps16_p030", "irregular_ldpc_n600_ms16_p030_adaptive", "irregular_ldpc_n2400_ps30_p075",
+                      "irregular_ldpc_n2400_ms30_p060_a0625", "irregular8_ldpc_n1200_ps20_p040"]
+
+
+@pytest.mark.parametrize("name", IRREGULAR_FIXTURES)
+def test_real_reference_fixtures_on_every_streamed_path(name):
+    """Irregular-code fixtures captured from the real reference (tests/golden/make_golden_irregular.py), forced off the on-chip kernels: the
+    default streamed path (product-sum: per-pass kernels from the first iteration; min-sum: the persistent register variant with its
+    hand-off), the persistent kernel alone, the variable-degree ring with two queue sizes, per-pass kernels with 1 and 16 rows per
+    wavefront -- decisions, flags, iteration counts, log-ratio BITS and the row sums of every log-ratio vector."""
+    from golden_util import bits_equal, load_case, rowsum
+    from ldpc_amd.engine import HipBpEngine
+    c = load_case(name)
+    eng = HipBpEngine(c["h"].indptr, c["h"].indices, c["n"], c["channel_probs"], c["max_iter"], 0 if c["bp_method"] == "product_sum" else 1, c["ms_scaling_factor"])
+    eng.set_small_code_kernel(0)
+    k = len(c["llr"])
+    for tag, handoff, switches in (("default", -1, ()), ("persistent", 0, ()), ("ring", 0, (("VAR_RING", 1),)), ("ring 8 units + hand-off", 1, (("VAR_RING", 1), ("VAR_RING_UNITS", 8))),
+                                   ("per-pass, 1 row a wavefront", 100000, (("SPREAD_NODES", 1),)), ("per-pass, 16 rows a wavefront", 100000, (("SPREAD_NODES", 16),))):
+        eng.set_handoff(handoff)
+        for key, val in switches:
+            eng.set_debug_switch(key, val)
+        dec, llr, it, cv = eng.decode_batch(c["syndromes"])
+        for key, _ in switches:
+            eng.set_debug_switch(key, -1)
+        assert np.array_equal(dec, c["decoding"]) and np.array_equal(cv, c["converge"]) and np.array_equal(it, c["iterations"]), (name, tag)
+        assert bits_equal(llr[:k], c["llr"]), (name, tag)
+        assert np.array_equal(rowsum(llr), c["llr_rowsum"]), (name, tag)
+    eng.close()
