@@ -101,6 +101,12 @@ def main():
     run("stateful_rnd_over_rel_ham4_s5", codes.hamming_code(4), 0.08, schedule="serial_relative", max_iter=9, bp_method="product_sum", alpha=1.0, rows=40,
         random_serial=True, seed=5)
 
+    # a code whose state does not fit LDS (768 x 1600, the [[1600,64]] hypergraph product of tools/bench_configs.py hgp1600): serial_relative takes the
+    # per-lane kernel with its state in HBM there
+    hx = codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))
+    run("stateful_rel_hgp1600_ms", hx, 0.03, schedule="serial_relative", max_iter=8, bp_method="minimum_sum", alpha=0.625, rows=16)
+    run("stateful_rel_hgp1600_ps", hx, 0.03, schedule="serial_relative", max_iter=6, bp_method="product_sum", alpha=1.0, rows=12)
+
     # SoftInfoBpDecoder with random_serial_schedule
     from make_golden_soft import noisy  # noqa: E402
     run_soft("stateful_softrnd_bb144_s7", bb, noisy(bb, 21, 0.02, 64, 3.0), 0.02, max_iter=12, alpha=0.8, cutoff=4.0, sigma=1.5, seed=7)
