@@ -42,6 +42,7 @@ def build(scratch: str = "/tmp/ldpc_ref_py") -> str:
     open(os.path.join(pkg, "__init__.py"), "w").write(
         "from ldpc.bp_decoder import BpDecoder, SoftInfoBpDecoder\nfrom ldpc.bposd_decoder import BpOsdDecoder\n")
     open(os.path.join(pkg, "ckt_noise", "__init__.py"), "w").write("")  # (the original imports the LSD / PyMatching window decoders)
+    open(os.path.join(pkg, "sinter_decoders", "__init__.py"), "w").write("")  # (the original imports the belief-find / LSD sinter decoders)
     return os.path.join(scratch, "src_python")
 
 

@@ -4,7 +4,8 @@
 tests/golden/make_golden_mcs.py imports the reference's ``MonteCarloBscSimulation`` (monte_carlo_simulation/mcs.py:10-171);
 tests/golden/make_golden_window.py imports the reference's ``BaseOverlappingWindowDecoder`` / ``BpOsdOverlappingWindowDecoder``
 (ckt_noise/base_overlapping_window_decoder.py:139-226, bposd_overlapping_window.py) behind a ``stim`` placeholder that raises
-on any use.  On a machine without /root/reference (the GPU box) these tests skip: the fixtures are what travels."""
+on any use; tests/golden/make_golden_sinter.py imports the reference's ``SinterBpOsdDecoder`` (sinter_decoders/sinter_bposd_decoder.py:57-130)
+and ``detector_error_model_to_check_matrices`` (ckt_noise/dem_matrices.py:61-171) and hands them the model as data and b8 files.  On a machine without /root/reference (the GPU box) these tests skip: the fixtures are what travels."""
 import os
 import subprocess
 import sys
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/src_python/ldpc"), reason="the reference is not on this machine")
 
 
-@pytest.mark.parametrize("script", ["make_golden_mcs.py", "make_golden_window.py"])
+@pytest.mark.parametrize("script", ["make_golden_mcs.py", "make_golden_window.py", "make_golden_sinter.py"])
 def test_generator_reproduces_the_committed_fixtures_from_the_reference_itself(script):
     pytest.importorskip("Cython")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", script), "--check"], capture_output=True, text=True, timeout=1500)
