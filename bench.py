@@ -702,6 +702,14 @@ def run(args, real_stdout, stage) -> None:
     elapsed = time.perf_counter() - t0
     sclk.__exit__()
     clock_run = eng.clock_ghz(probe0, eng.clock_probe())  # shader clock of the persistent kernel's workgroups over the timed steps
+    # box normaliser (outside the timed steps): a bare copy of the same message segments between the handle's two message arrays --
+    # what THIS box gives, right after the timed steps (same thermal state), to any kernel that moves these bytes once
+    copy_gbps = None
+    try:
+        copy_runs = [eng.copy_probe(min((B + 63) // 64, 1024), eng.nnz, passes=2)[1] for _ in range(3)]
+        copy_gbps = float(np.median(copy_runs))
+    except Exception as exc:  # an older library build (LDPC_HIP_LIB A/B runs) has no probe
+        print(f"[bench] copy probe unavailable: {exc}", file=sys.stderr)
     if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -806,6 +814,10 @@ def run(args, real_stdout, stage) -> None:
                 "kernel": "bp_decode_kernel (persistent, one workgroup per 64-syndrome tile) + bp_spread_* per-pass launches for the last tiles",
                 "kernel_ms": k_ms, "kernel_ms_persistent": pers_ms, "kernel_ms_per_pass": spread_ms,
                 "clock_ghz_this_run": clock_run,
+                "copy_GBps_this_run": copy_gbps, "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None,
+                "copy_note": "copy_GBps_this_run = bytes read + written per second by ldpc_hip_bp_copy_probe right after the timed steps: one workgroup per "
+                             "tile copying the tile's 30 000 message segments of 512 bytes to the other message array, non-temporal, no arithmetic "
+                             "(median of 3 x 2 passes, events on the launch stream); boxes of the pool differ by ~10 % here, builds do not",
                 "algorithmic_bytes_per_launch": alg,
                 "second_bound": second,
                 "counters_from_build": profile_tag, "this_build": build_tag,

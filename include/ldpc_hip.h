@@ -403,6 +403,14 @@ int ldpc_hip_bp_set_math(ldpc_hip_bp *h, int32_t math_mode);
  * workgroups and weighted by their lifetime. */
 int ldpc_hip_bp_clock_probe(ldpc_hip_bp *h, uint64_t *cycles, uint64_t *ticks, double *tick_hz);
 
+/* The copy rate of THIS box, now (a measurement aid; no counterpart in the reference).  Copies `tiles` x `segments_per_tile` segments of
+ * 512 bytes (64 syndromes x one double: the unit every streamed BP kernel moves) from one of the handle's message arrays to the other and
+ * back, `passes` times, one workgroup per tile, non-temporal, on the handle's stream, timed with events on that stream.
+ * gbytes_per_s = bytes read + bytes written per second.  bench.py prints it beside the roofline fraction so that one JSON line tells a slow
+ * box from a slow build: boxes of the pool differ by ~10 % in what they give ANY kernel that moves these bytes once.  The handle's
+ * message arrays are (re)allocated to the probe's size if they are smaller; their contents are scratch between decodes anyway. */
+int ldpc_hip_bp_copy_probe(ldpc_hip_bp *h, int64_t tiles, int32_t segments_per_tile, int32_t passes, float *ms, double *gbytes_per_s);
+
 /* Page-locked host memory for a caller's result arrays (no counterpart in the reference: its arrays never leave the host).  A host
  * pointer into such a block -- or into memory the caller registered with hipHostRegister -- handed to ldpc_hip_bp_decode_batch as `llr`
  * is written by the device-to-host copies themselves: the pipelined host path (above) skips its pinned staging buffer and the

@@ -18,7 +18,7 @@ SYMBOLS = (
     "ldpc_hip_bp_create", "ldpc_hip_bp_destroy", "ldpc_hip_bp_set_channel", "ldpc_hip_bp_set_params",
     "ldpc_hip_bp_set_stream", "ldpc_hip_bp_set_schedule", "ldpc_hip_bp_set_random_serial", "ldpc_hip_bp_get_schedule_order", "ldpc_hip_bp_decode_batch", "ldpc_hip_bp_decode_batch_async", "ldpc_hip_bposd0_decode_batch", "ldpc_hip_bposd0_decode_batch_async",
     "ldpc_hip_bp_set_osd", "ldpc_hip_bposd_get_status", "ldpc_hip_bp_set_osd_kernel", "ldpc_hip_bp_set_repack", "ldpc_hip_bp_set_serial_kernel", "ldpc_hip_bposd_decode_batch", "ldpc_hip_bposd_decode_batch_async",
-    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms", "ldpc_hip_bp_clock_probe", "ldpc_hip_host_alloc", "ldpc_hip_host_free",
+    "ldpc_hip_bp_set_observables", "ldpc_hip_bp_decode_b8", "ldpc_hip_bp_soft_info_decode_batch", "ldpc_hip_pack_b8", "ldpc_hip_unpack_b8", "ldpc_hip_bp_last_phase_ms", "ldpc_hip_bp_clock_probe", "ldpc_hip_bp_copy_probe", "ldpc_hip_host_alloc", "ldpc_hip_host_free",
     "ldpc_hip_gf2_mulvec_batch", "ldpc_hip_gen_bsc_syndromes", "ldpc_hip_bp_last_kernel_ms",
     "ldpc_hip_bp_workspace_bytes", "ldpc_hip_bp_set_tuning", "ldpc_hip_bp_set_math", "ldpc_hip_bp_set_ring", "ldpc_hip_bp_set_small_code_kernel", "ldpc_hip_bp_set_handoff", "ldpc_hip_last_error", "ldpc_hip_version",
     "ldpc_hip_bp_set_debug_switch", "ldpc_hip_bp_multi_create", "ldpc_hip_bp_multi_destroy", "ldpc_hip_bp_multi_devices", "ldpc_hip_bp_multi_handle",
@@ -94,6 +94,8 @@ def load():
     lib.ldpc_hip_bp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldpc_hip_bp_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.ldpc_hip_bp_clock_probe.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double)]
+    if not os.environ.get("LDPC_HIP_LIB") or hasattr(lib, "ldpc_hip_bp_copy_probe"):  # (an older build under A/B measurement may lack the probe)
+        lib.ldpc_hip_bp_copy_probe.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     lib.ldpc_hip_host_alloc.argtypes = [C.c_size_t]
     lib.ldpc_hip_host_alloc.restype = C.c_void_p
     lib.ldpc_hip_host_free.argtypes = [vp]

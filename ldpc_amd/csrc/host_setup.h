@@ -352,6 +352,35 @@ int ldpc_hip_bp_clock_probe(ldpc_hip_bp *h, uint64_t *cycles, uint64_t *ticks, d
     return LDPC_HIP_OK;
 }
 
+int ldpc_hip_bp_copy_probe(ldpc_hip_bp *h, int64_t tiles, int32_t segments_per_tile, int32_t passes, float *ms, double *gbytes_per_s) {
+    if (!h || !ms || !gbytes_per_s) return fail(LDPC_HIP_ERR_INVALID, "null argument");
+    if (tiles <= 0 || segments_per_tile <= 0 || passes <= 0 || passes > 64) return fail(LDPC_HIP_ERR_INVALID, "copy probe: tiles, segments_per_tile > 0, passes in 1 .. 64");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)tiles * (size_t)segments_per_tile * 512u;
+    int rc;
+    // (the message arrays of the handle: a decode of the same geometry has them already, and the next decode initialises what it reads)
+    if ((rc = h->msgA.ensure(bytes)) || (rc = h->msgC.ensure(bytes))) return rc;
+    hipStream_t st = h->stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    double *a = (double *)h->msgA.p, *c = (double *)h->msgC.p;
+    hipLaunchKernelGGL(segcopy_probe_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a, c, (int)segments_per_tile);  // untimed: page tables, clocks
+    HIPCHK(hipEventRecord(e0, st));
+    for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(segcopy_probe_kernel, dim3((unsigned)tiles), dim3(768), 0, st, (p & 1) ? c : a, (p & 1) ? a : c, (int)segments_per_tile);
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    *ms = t;
+    *gbytes_per_s = t > 0.f ? 2.0 * (double)bytes * (double)passes / ((double)t * 1e-3) / 1e9 : 0.0;
+    return LDPC_HIP_OK;
+}
+
 int ldpc_hip_bp_last_phase_ms(ldpc_hip_bp *h, float *persistent_ms, float *per_pass_ms) {
     if (!h || !persistent_ms || !per_pass_ms) return fail(LDPC_HIP_ERR_INVALID, "null argument");
     *persistent_ms = *per_pass_ms = 0.f;

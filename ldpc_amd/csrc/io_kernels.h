@@ -243,3 +243,24 @@ LDPC_IO_KERNEL void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__r
     if (need) list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)b;
 }
 
+
+// ---- copy-rate probe (ldpc_hip_bp_copy_probe): what HBM gives THIS box, now, for the traffic pattern of the streamed kernels --------
+// A workgroup per tile copies the tile's `nseg` 512-byte segments (64 lanes x one double: one edge of the code) from src to dst, six
+// segments in flight per wavefront, non-temporal -- the streamed kernels' access size and policy with no arithmetic
+// (tools/membench/segcopy.hip is the stand-alone form with gather / scatter orders; every order copies at the same rate there).
+LDPC_IO_KERNEL void __launch_bounds__(768) segcopy_probe_kernel(const double *__restrict__ src, double *__restrict__ dst, int nseg) {
+    constexpr int U = 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
+    const size_t base = (size_t)blockIdx.x * (size_t)nseg * 64;
+    for (int e0 = wave * U; e0 < nseg; e0 += nwaves * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u < nseg ? e0 + u : nseg - 1;
+            v[u] = __builtin_nontemporal_load(src + base + (size_t)e * 64 + lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e0 + u < nseg) __builtin_nontemporal_store(v[u], dst + base + (size_t)(e0 + u) * 64 + lane);
+    }
+}

@@ -175,6 +175,13 @@ class HipBpEngine:
         _lib.check(self._lib.ldpc_hip_bp_clock_probe(self._h, C.byref(c), C.byref(t), C.byref(hz)))
         return int(c.value), int(t.value), float(hz.value)
 
+    def copy_probe(self, tiles: int, segments_per_tile: int | None = None, passes: int = 2):
+        """(ms, GB/s read + written) of a bare copy of ``tiles`` x ``segments_per_tile`` 512-byte message segments between the handle's
+        two message arrays (``ldpc_hip_bp_copy_probe``): what this box gives the streamed kernels' traffic with no arithmetic."""
+        ms, rate = C.c_float(0.0), C.c_double(0.0)
+        _lib.check(self._lib.ldpc_hip_bp_copy_probe(self._h, int(tiles), int(segments_per_tile or self.nnz), int(passes), C.byref(ms), C.byref(rate)))
+        return float(ms.value), float(rate.value)
+
     @staticmethod
     def clock_ghz(before, after):
         """Average shader clock (GHz) of the BP kernels that ran between two ``clock_probe()`` readings, or None if none did."""
