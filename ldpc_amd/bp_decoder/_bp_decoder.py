@@ -458,10 +458,9 @@ class BpDecoderBase:
     recycle_log_prob_ratios = False
 
     def _llr_destination(self, rows: int, out=None, reuse=None):
-        """Where a batch's log-ratios go: the caller's array; else the previous batch's array if the caller SAID it may be overwritten;
-        else, once per decoder and shape and only for arrays of 256 MiB and more, a new array on page-locked memory
-        (``ldpc_hip_host_alloc``: the device-to-host copies write it directly, no staging buffer, no host-side copy); else None (the
-        backend makes an ordinary array)."""
+        """Where a batch's log-ratios go: the caller's array; else, if the caller SAID the previous batch's array may be overwritten, that
+        array -- or, when there is none yet and it would be 256 MiB or more, a new one on page-locked memory (``ldpc_hip_host_alloc``: the
+        device-to-host copies write it directly, no staging buffer, no host-side copy); else None (the backend makes an ordinary array)."""
         if out is not None:
             if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (rows, self.n) and out.flags.c_contiguous and out.flags.writeable):
                 raise ValueError(f"log_prob_ratios_out must be a writeable C-contiguous float64 array of shape ({rows}, {self.n}).")
@@ -470,13 +469,14 @@ class BpDecoderBase:
             old = getattr(self, "log_prob_ratios_batch", None)
             if isinstance(old, np.ndarray) and old.dtype == np.float64 and old.shape == (rows, self.n) and old.flags.c_contiguous and old.flags.writeable:
                 return old
-        nbytes = rows * self.n * 8
-        if nbytes >= (256 << 20) and getattr(self, "_pinned_llr_shape", None) != (rows, self.n):
-            self._pinned_llr_shape = (rows, self.n)
-            from .._lib import PinnedBlock
-            blk = PinnedBlock.try_new(nbytes)
-            if blk is not None:
-                return blk.array((rows, self.n), np.float64)
+            # nothing to reuse yet: the caller has said the array will be written again and again -- that is when page-locked memory pays
+            # (a caller on the default path gets an ordinary array: a pinned block used once as an ordinary array is a waste of a limited resource)
+            nbytes = rows * self.n * 8
+            if nbytes >= (256 << 20):
+                from .._lib import PinnedBlock
+                blk = PinnedBlock.try_new(nbytes)
+                if blk is not None:
+                    return blk.array((rows, self.n), np.float64)
         return None
 
     def _require_parallel(self):
@@ -608,6 +608,9 @@ class BpDecoder(BpDecoderBase):
         eng = self._get_engine()
         if _is_torch(input_vectors):
             import torch
+            if log_prob_ratios_out is not None or reuse_log_prob_ratios:
+                raise ValueError("log_prob_ratios_out / reuse_log_prob_ratios apply to NumPy inputs only: with device tensors the log-ratios "
+                                 "are returned as a device tensor (log_prob_ratios_batch).")
             vec = input_vectors
             synd = vec if as_syndrome else eng.mulvec_batch(vec)
             dec, llr, it, cv = eng.decode_batch(synd, want_llr=want_log_prob_ratios)

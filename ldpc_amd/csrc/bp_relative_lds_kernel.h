@@ -166,7 +166,7 @@ __device__ inline void heapsort_t(const CTX &x, long first, long last) {  // __p
 // for a path that runs when a key is NaN.
 template <class CTX>
 __device__ inline void sort_desc_seq(const CTX &x, long n, rel_lds::l_u16 *stk) {
-    if (n <= 0) return;
+    if (n <= 1) return;  // (nothing to sort -- and a caller's scratch of 4 n bytes would not hold the first range's three words at n = 1)
     int depth = 0;
     for (long q = n; q > 1; q >>= 1) depth++;
     depth *= 2;

@@ -608,7 +608,8 @@ void resident_retire(ldpc_hip_bp *h) {
 int decode_onchip_resident(ldpc_hip_bp *h, bool want_llr, bool *took) {
     *took = false;
     (void)want_llr;
-    if (h->sw("RESIDENT") == 0 || !h->pin_host || h->schedule != 1 || h->small_mode == 0 || h->small_mode == 2) return LDPC_HIP_OK;
+    // (the same predicate as decode_onchip's bp_wave_ps branch: a caller who FORCED another small-code kernel -- modes 3, 4, 5, 2 -- gets that kernel)
+    if (h->sw("RESIDENT") == 0 || !h->pin_host || h->schedule != 1 || !(h->small_mode < 2 || h->small_mode == 6) || h->small_mode == 0) return LDPC_HIP_OK;
     if (h->m <= 0 || h->n <= 0 || h->nnz <= 0 || (int64_t)h->nnz * 16 >= (1 << 22)) return LDPC_HIP_OK;
     const WavePsPlan p = plan_wave_ps(h, h->small_mode == 1, true, 1);  // (the posteriors are always formed: one plan whatever the caller asks for)
     if (!p.waves || !p.team) return LDPC_HIP_OK;
@@ -686,8 +687,18 @@ int decode_onchip_resident(ldpc_hip_bp *h, bool want_llr, bool *took) {
                 (void)hipGetLastError();
             }
         }
-        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
-            return fail(LDPC_HIP_ERR_DEVICE, "the resident decode kernel did not answer within 20 s");
+        if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            // The resident workgroup was never scheduled (the GPU is busy with someone else's long kernel) or is stuck: tell it to leave, wait
+            // for its stream, and if it did serve the request on its way out take that; otherwise withdraw the request (the next resident
+            // kernel starts from served = request: no stale sequence number) and let the ordinary launch path decode this call.
+            resident_retire(h);
+            if (__atomic_load_n(mail + 1, __ATOMIC_ACQUIRE) == seq) break;
+            __atomic_store_n(mail + 0, 0u, __ATOMIC_SEQ_CST);
+            __atomic_store_n(mail + 1, 0u, __ATOMIC_SEQ_CST);
+            r.seq = 0;
+            return LDPC_HIP_OK;  // (*took stays false)
+        }
+        if ((spins & 0x3ffu) == 0x3ffu) std::this_thread::yield();  // (a core shared with the caller's other threads is not held hostage)
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif

@@ -117,8 +117,13 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     // threshold such a batch takes the per-pass kernels from its first iteration: 0.45 -> 0.56 of HBM on the irregular code with rows of 3 .. 16
     // entries, 0.49 -> 0.63 and 0.46 -> 0.59 with rows of 3 .. 8, 0.57 -> 0.60 on the headline code with its ring off.  Min-sum has no such
     // chain and stays with the persistent kernel (0.69-0.77 against 0.65-0.68), and so do the ring variants (80 VGPRs: 0.65 against 0.60).
+    // Bounded: a per-pass round is four launches over EVERY tile of the chunk (a row of workgroups per tile, leaving at once when the tile is
+    // final: ~50 us per 256 rows and launch), queued by the host until the device reports the last tile final.  With one hopeless syndrome
+    // and the reference's default max_iter = n that is thousands of full-size, empty rounds -- a cost that grows with the batch.  So only
+    // decodes of at most 128 iterations start per-pass; longer ones keep the persistent kernel, whose hand-off parks at most 256 tiles
+    // (the cost of an empty round is then the fixed ~0.2 ms it always was).
     const bool per_pass_first = h->handoff < 0 && h->bp_method == LDPC_HIP_PRODUCT_SUM && kern.ring_depth == 0 && !kern.var_ring &&
-                                h->max_row_deg <= 16 && h->max_col_deg <= 8;
+                                h->max_row_deg <= 16 && h->max_col_deg <= 8 && h->max_iter <= 128;
     const int handoff = h->handoff < 0 ? (per_pass_first ? INT32_MAX : 256) : h->handoff;
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;

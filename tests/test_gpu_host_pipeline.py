@@ -131,10 +131,10 @@ def test_log_ratios_into_page_locked_memory_take_the_direct_route(oracle_built):
     assert bits_equal(view, want[1][7])  # (a view keeps the block alive)
 
 
-def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracle_built):
-    """`BpDecoder.decode_batch(numpy)`: the first large batch gets its log-ratio array on page-locked memory; a caller who says so
-    (`reuse_log_prob_ratios`) has the next call write the same memory, everybody else gets an ordinary array next time (no page-locked
-    allocation per call)."""
+def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_on_request(oracle_built):
+    """`BpDecoder.decode_batch(numpy)`: a caller who says the log-ratio array may be overwritten by later calls (`reuse_log_prob_ratios`)
+    gets it on page-locked memory and has the next such call write the same memory; everybody else gets an ordinary array (no page-locked
+    allocation on the default path); with device tensors the keywords are refused, not ignored."""
     from ldpc_amd import codes
     from ldpc_amd.bp_decoder import BpDecoder
     h = codes.regular_ldpc_code(3000, 3, 6, seed=2)
@@ -142,7 +142,11 @@ def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracl
     eng = dec._get_engine()
     B = 12000  # 12 000 x 3 000 x 8 = 288 MB
     s = eng.gen_bsc_syndromes(9, 0.04, shot0=0, shots=B, device="cuda:0").cpu().numpy()
-    out1 = dec.decode_batch(s)
+    out0 = dec.decode_batch(s)
+    assert dec.log_prob_ratios_batch.flags.owndata  # default path: an ordinary array
+    dec.log_prob_ratios_batch = None
+    out1 = dec.decode_batch(s, reuse_log_prob_ratios=True)
+    assert np.array_equal(out0, out1)
     a1 = dec.log_prob_ratios_batch
     assert not a1.flags.owndata and getattr(a1.base, "owner", None) is not None  # on a PinnedBlock
     want = a1.copy()
@@ -154,3 +158,8 @@ def test_bpdecoder_puts_a_large_log_ratio_array_on_page_locked_memory_once(oracl
     dec.decode_batch(s)
     assert dec.log_prob_ratios_batch.ctypes.data != addr and dec.log_prob_ratios_batch.flags.owndata  # an ordinary array this time
     assert bits_equal(kept, want) and bits_equal(dec.log_prob_ratios_batch, want)
+    import torch
+    with pytest.raises(ValueError, match="NumPy inputs only"):
+        dec.decode_batch(torch.from_numpy(s[:64]).cuda(), log_prob_ratios_out=np.zeros((64, 3000)))
+    with pytest.raises(ValueError, match="NumPy inputs only"):
+        dec.decode_batch(torch.from_numpy(s[:64]).cuda(), reuse_log_prob_ratios=True)

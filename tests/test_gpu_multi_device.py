@@ -167,3 +167,35 @@ def test_soft_info_on_a_multi_engine_runs_on_its_first_gpu():
     rng = np.random.default_rng(5)
     soft = rng.normal(1.0, 0.8, size=(100, h.shape[0]))
     _same(one.soft_info_decode_batch(soft, 2.0, 0.7), many.soft_info_decode_batch(soft, 2.0, 0.7))
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """The first box with two GPUs proves the N > 1 path: `python bench.py --gpus 2` as the driver launches
+    it -- torch.distributed.run, one rank per GPU, an RCCL group of two, contiguous row shards, per-rank parity against the CPU checker,
+    one gather of bit-packed decoded rows + flags onto rank 0 (ldpc_amd/sharding.py).  On the one-GPU boxes of this pool it skips; no
+    N > 1 curve has been measured anywhere yet."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from test_gpu_async_group import _bench
+    got = _bench(["--gpus", "2", "--batch-per-gpu", "16384", "--steps", "2", "--warmup", "1", "--rank-parity", "64",
+                  "--secondary", "0", "--cpu-sample", "0", "--host-io", "0"], timeout=1500)
+    assert got["n_gpus"] == 2 and got["rccl"]["ranks"] == 2 and got["rccl"]["backend"] == "nccl"
+    assert got["config"]["batch_per_gpu"] == 16384 and got["config"]["global_batch"] == 32768
+    assert got["gather"]["rows_on_rank0"] == 32768
+    assert got["per_rank"]["parity_all_ranks"] is True and len(got["per_rank"]["parity_ok"]) == 2 and all(got["per_rank"]["parity_ok"])
+    assert "parity_failed" not in got and got["value"] > 0 and got["scaling"] == "weak"
+    assert abs(got["value"] - 32768 / (got["ms_per_step"] * 1e-3)) < 1e-6 * got["value"]
+    # and the one-process form with a real peer copy between two distinct devices
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine, HipBpMultiEngine
+    h = codes.regular_ldpc_code(600, 3, 6, seed=3)
+    one = HipBpEngine(h.indptr, h.indices, 600, np.full(600, 0.04), 20, 0, 1.0)
+    two = HipBpMultiEngine(h.indptr, h.indices, 600, np.full(600, 0.04), 20, 0, 1.0, device_ids=[0, 1])
+    s = one.gen_bsc_syndromes(5, 0.04, shot0=0, shots=9000, device="cuda:0")
+    a = [x.cpu().numpy() for x in one.decode_batch(s, want_llr=True)]
+    b = [x.cpu().numpy() if hasattr(x, "cpu") else x for x in two.decode_batch(s, want_llr=True)]
+    from golden_util import bits_equal
+    assert np.array_equal(a[0], b[0]) and bits_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    one.close()
+    two.close()
