@@ -46,6 +46,10 @@ struct SerialArgs {
     int32_t it_start;
     int32_t resume;  // 1: the same tiles carry on after a pass that stopped at it_start -- lanes whose `conv` says so are done (their `iters` kept), dec / llr_t are the pass's
     unsigned long long *clk;  // shader-clock probe (clock_probe_*), or nullptr
+    // bp_serial_stream_var_kernel (bp_serial_var_kernel.h): item records, where the stream of (level l, wavefront w) starts
+    // ([l * wavefronts + w], one more entry at the end), 1 KiB units of a wavefront's LDS queue
+    const int32_t *var_items, *var_wq;
+    int32_t var_units;
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the

@@ -40,6 +40,7 @@ static int ensure_serial_levels(ldpc_hip_bp *h) {
     h->h_lvl_ptr = std::move(ptr);
     h->h_lvl_bits = std::move(bits);
     h->ser_pos_valid = false;
+    h->ser_var_valid = false;
     return LDPC_HIP_OK;
 }
 
@@ -47,15 +48,106 @@ static int ensure_serial_levels(ldpc_hip_bp *h) {
 // weight (the records and the ring slots are sized by them), levels wide enough to keep a workgroup's wavefronts busy.
 struct SerialStreamPlan {
     int dr = 0, dc = 0;  // 0: not applicable
+    bool var = false;    // the item form (bp_serial_var_kernel.h): dr, dc are the register bounds of the instantiation (8 | 16, 4 | 8)
 };
 static SerialStreamPlan plan_serial_stream(const ldpc_hip_bp *h) {
     SerialStreamPlan p;
-    if (!h->regular || h->m <= 0 || h->n <= 0 || h->nnz >= (1 << 22) || h->n_levels <= 0) return p;
-    if (!(h->max_row_deg == 6 && h->max_col_deg == 3)) return p;
+    if (h->m <= 0 || h->n <= 0 || h->nnz >= (1 << 22) || h->n_levels <= 0) return p;
     if (h->serial_kernel != 2 && (double)h->n / (double)h->n_levels < 32.0) return p;  // (narrow levels: the wavefronts would idle at the barriers)
-    p.dr = h->max_row_deg;
-    p.dc = h->max_col_deg;
+    if (h->regular && h->max_row_deg == 6 && h->max_col_deg == 3 && h->sw("SER_VAR") <= 0) {  // the form built around the (6,3) record
+        p.dr = h->max_row_deg;
+        p.dc = h->max_col_deg;
+        return p;
+    }
+    // any other degree profile with rows of <= 16 and columns of 1 .. 8 entries: items ("SER_VAR" 0: never -- bp_serial_level_kernel as before round 6)
+    if (h->sw("SER_VAR") == 0 || h->max_row_deg > 16 || h->max_col_deg > 8 || h->min_col_deg < 1) return p;
+    p.var = true;
+    p.dr = h->max_row_deg <= 8 ? 8 : 16;
+    p.dc = h->max_col_deg <= 4 ? 4 : 8;
     return p;
+}
+
+// wavefronts per tile and units of 1 KiB per wavefront of bp_serial_stream_var_kernel
+static void serial_var_geometry(const ldpc_hip_bp *h, int waves_cap, int &waves, int &units) {
+    units = h->sw("SER_VAR_UNITS") > 0 ? h->sw("SER_VAR_UNITS") : 8;
+    if (units < h->max_row_deg / 2) units = h->max_row_deg / 2;  // (an item must fit the queue)
+    if (units < 1) units = 1;
+    if (units > 32) units = 32;
+    waves = h->sw("SER_WAVES") > 0 ? h->sw("SER_WAVES") : 16;
+    if (waves > waves_cap) waves = waves_cap;
+    if (waves > 16) waves = 16;
+    while (waves > 1 && (size_t)waves * (size_t)units * 1024u > 150u * 1024u) --waves;
+}
+
+// item tables of bp_serial_var_kernel.h from the host copies of the levels: the streams of `waves` wavefronts per tile, and the lane
+// kernel's level-major list (a position's items never straddle a wavefront)
+static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
+    if (h->ser_var_valid && h->ser_var_waves == waves) return LDPC_HIP_OK;
+    const int n = h->n, m = h->m, L = h->n_levels;
+    std::vector<int32_t> col_ptr((size_t)n + 1, 0), col_edge((size_t)(h->nnz ? h->nnz : 1)), row_of((size_t)(h->nnz ? h->nnz : 1));
+    for (int e = 0; e < h->nnz; ++e) col_ptr[(size_t)h->h_col_idx[(size_t)e] + 1]++;
+    for (int j = 0; j < n; ++j) col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
+    {
+        std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+        for (int i = 0; i < m; ++i)
+            for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {  // (CSR order: a column's edges come out rows ascending, the order of its linked list)
+                col_edge[(size_t)fill[(size_t)h->h_col_idx[(size_t)e]]++] = e;
+                row_of[(size_t)e] = i;
+            }
+    }
+    auto record = [&](int32_t *r, int j, int k, bool lane_form) {
+        const int e = col_edge[(size_t)col_ptr[(size_t)j] + k], i = row_of[(size_t)e], rs = h->h_row_ptr[(size_t)i], d = h->h_row_ptr[(size_t)i + 1] - rs;
+        const int dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
+        r[0] = e; r[1] = rs; r[2] = d | ((e - rs) << 8) | (k << 16) | (dj << 24); r[3] = j; r[4] = i; r[5] = lane_form ? 1 : 0; r[6] = r[7] = 0;
+    };
+    std::vector<int32_t> items, wq((size_t)L * (size_t)waves + 1, 0), lane_items, lane_lvl((size_t)L + 1, 0);
+    items.reserve((size_t)h->nnz * SERIAL_VAR_REC);
+    for (int l = 0; l < L; ++l) {
+        const int p0 = h->h_lvl_ptr[(size_t)l], p1 = h->h_lvl_ptr[(size_t)l + 1];
+        for (int w = 0; w < waves; ++w) {
+            wq[(size_t)l * waves + w] = (int32_t)(items.size() / SERIAL_VAR_REC);
+            for (int p = p0 + w; p < p1; p += waves) {
+                const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
+                for (int k = 0; k < dj; ++k) {
+                    items.resize(items.size() + SERIAL_VAR_REC);
+                    record(items.data() + items.size() - SERIAL_VAR_REC, j, k, false);
+                }
+            }
+        }
+        lane_lvl[(size_t)l] = (int32_t)(lane_items.size() / SERIAL_VAR_REC);
+        for (int p = p0; p < p1; ++p) {
+            const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
+            const size_t at = lane_items.size() / SERIAL_VAR_REC;
+            if (at % 64 + (size_t)dj > 64) lane_items.resize((at + 63) / 64 * 64 * SERIAL_VAR_REC, 0);  // padding: the position starts a new wavefront
+            for (int k = 0; k < dj; ++k) {
+                lane_items.resize(lane_items.size() + SERIAL_VAR_REC);
+                record(lane_items.data() + lane_items.size() - SERIAL_VAR_REC, j, k, true);
+            }
+        }
+        lane_items.resize((lane_items.size() / SERIAL_VAR_REC + 63) / 64 * 64 * SERIAL_VAR_REC, 0);  // a level ends on a wavefront boundary
+    }
+    wq[(size_t)L * waves] = (int32_t)(items.size() / SERIAL_VAR_REC);
+    lane_lvl[(size_t)L] = (int32_t)(lane_items.size() / SERIAL_VAR_REC);
+    int rc;
+    if ((rc = h->ser_var_items.ensure((items.size() + SERIAL_VAR_REC) * sizeof(int32_t))) || (rc = h->ser_var_wq.ensure(wq.size() * sizeof(int32_t))) ||
+        (rc = h->ser_var_lane_items.ensure((lane_items.size() + SERIAL_VAR_REC) * sizeof(int32_t))) || (rc = h->ser_var_lane_lvl.ensure(lane_lvl.size() * sizeof(int32_t)))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!items.empty()) HIPCHK(hipMemcpy(h->ser_var_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->ser_var_wq.p, wq.data(), wq.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!lane_items.empty()) HIPCHK(hipMemcpy(h->ser_var_lane_items.p, lane_items.data(), lane_items.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->ser_var_lane_lvl.p, lane_lvl.data(), lane_lvl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->ser_var_valid = true;
+    h->ser_var_waves = waves;
+    return LDPC_HIP_OK;
+}
+
+template <int METHOD, int MATH>
+static void (*pick_serial_var(const SerialStreamPlan &sp))(const SerialArgs) {
+    return sp.dr <= 8 && sp.dc <= 4 ? bp_serial_stream_var_kernel<METHOD, MATH, 8, 4> : bp_serial_stream_var_kernel<METHOD, MATH, 16, 8>;
+}
+template <int METHOD, int MATH>
+static void (*pick_serial_lane_var(const SerialStreamPlan &sp))(const SerialLaneVarArgs) {
+    return sp.dr <= 8 && sp.dc <= 4 ? bp_serial_lane_var_kernel<METHOD, MATH, 8, 4> : bp_serial_lane_var_kernel<METHOD, MATH, 16, 8>;
 }
 
 // the records of the positions (layout: bp_serial_stream_kernel.h), from the host copies of the levels
@@ -171,7 +263,14 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
     SerialStreamPlan sp;
     int ser_ring = 1, ser_waves = 16;
     if (level_waves && !orders && (h->serial_kernel == -1 || h->serial_kernel == 2)) sp = plan_serial_stream(h);
-    if (sp.dr) {
+    int var_units = 0;
+    if (sp.var) {
+        serial_var_geometry(h, 16, ser_waves, var_units);
+        if ((rc = ensure_serial_var_tables(h, ser_waves))) return rc;
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_var<LDPC_HIP_MINIMUM_SUM, 0>(sp);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_var<LDPC_HIP_PRODUCT_SUM, 1>(sp);
+        else kern = pick_serial_var<LDPC_HIP_PRODUCT_SUM, 0>(sp);
+    } else if (sp.dr) {
         if ((rc = ensure_serial_stream_table(h, sp))) return rc;
         if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
         if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
@@ -230,7 +329,13 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         a.lvl_ptr = (const int32_t *)h->lvl_ptr.p; a.lvl_bits = (const int32_t *)h->lvl_bits.p; a.n_levels = h->n_levels;
         a.orders = orders; a.n_orders = n_orders; a.orders_first = orders_first;
         if (orders && level_waves) { a.orders_lvl = (const int32_t *)h->sched_lvl_bits.p; a.orders_lvl_ptr = (const int32_t *)h->sched_lvl_ptr.p; }
-        if (sp.dr) {
+        if (sp.var) {
+            a.var_items = (const int32_t *)h->ser_var_items.p; a.var_wq = (const int32_t *)h->ser_var_wq.p; a.var_units = var_units;
+            a.clk = h->d_clk;
+            const size_t dyn = (size_t)ser_waves * (size_t)var_units * 1024u;
+            if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
+        } else if (sp.dr) {
             a.pos_tab = (const int32_t *)h->ser_pos_tab.p;
             a.clk = h->d_clk;
             if (h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads this table instead of initial messages
@@ -654,17 +759,28 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
         hipLaunchKernelGGL(pack_syndromes_kernel, g, dim3(256), 0, st, synd, rows, h->m, (uint64_t *)h->par.p, (uint64_t *)h->nzm.p, (uint64_t *)h->invalid.p,
                            (const int32_t *)nullptr, (const unsigned *)nullptr);
     }
-    int ser_ring = 1, ser_waves = 16;
-    if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
-    if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
-    if (ser_waves > waves_cap) ser_waves = waves_cap;
-    const int slot = serial_stream_slot_bytes(sp.dr, sp.dc);
-    while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES) > 150u * 1024u) --ser_waves;
-    if (ser_waves > 16) ser_waves = 16;
+    int ser_ring = 1, ser_waves = 16, var_units = 0;
     void (*kern)(const SerialArgs);
-    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
-    else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 1>(ser_ring);
-    else kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 0>(ser_ring);
+    int slot = 0;
+    if (sp.var) {
+        // (one table for every pass of a decode: the streams are cut for a number of wavefronts, so a pass asked to use fewer keeps the table's)
+        serial_var_geometry(h, 16, ser_waves, var_units);
+        (void)waves_cap;
+        if ((rc = ensure_serial_var_tables(h, ser_waves))) return rc;
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_var<LDPC_HIP_MINIMUM_SUM, 0>(sp);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_var<LDPC_HIP_PRODUCT_SUM, 1>(sp);
+        else kern = pick_serial_var<LDPC_HIP_PRODUCT_SUM, 0>(sp);
+    } else {
+        if (h->sw("SER_RING") > 0) ser_ring = h->sw("SER_RING") >= 2 ? 2 : 1;
+        if (h->sw("SER_WAVES") > 0) ser_waves = h->sw("SER_WAVES");
+        if (ser_waves > waves_cap) ser_waves = waves_cap;
+        slot = serial_stream_slot_bytes(sp.dr, sp.dc);
+        while (ser_waves > 1 && (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES) > 150u * 1024u) --ser_waves;
+        if (ser_waves > 16) ser_waves = 16;
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kern = pick_serial_stream<LDPC_HIP_MINIMUM_SUM, 0>(ser_ring);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 1>(ser_ring);
+        else kern = pick_serial_stream<LDPC_HIP_PRODUCT_SUM, 0>(ser_ring);
+    }
     SerialArgs a = {};
     a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = it_end; a.fast = 1;
     a.ms_scaling_factor = h->ms_scaling_factor;
@@ -681,11 +797,13 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
     a.clk = h->d_clk;
     a.it_start = it_start;
     a.resume = resume ? 1 : 0;
-    if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads these tables instead of initial messages
+    if (sp.var) {
+        a.var_items = (const int32_t *)h->ser_var_items.p; a.var_wq = (const int32_t *)h->ser_var_wq.p; a.var_units = var_units;
+    } else if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads these tables instead of initial messages
         a.edge0 = (const double *)h->d_edge0.p;
         a.pos_e0 = (const double *)h->ser_pos_e0.p;
     }
-    const size_t dyn = (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES);
+    const size_t dyn = sp.var ? (size_t)ser_waves * (size_t)var_units * 1024u : (size_t)ser_waves * (size_t)(ser_ring * slot + LDPC_NEAR_BYTES);
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
     HIPCHK(hipGetLastError());
@@ -704,6 +822,29 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
 // A handful of rows on bp_serial_lane_kernel (one workgroup per syndrome): iterations it_start + 1 .. max_iter; `state_rows`: [rows][nnz]
 static int serial_lane_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int it_start, double *state_rows, const uint8_t *synd, int64_t rows,
                               uint8_t *decoding, double *llr, int32_t *iters, uint8_t *conv) {
+    if (sp.var) {
+        int waves = 0, units = 0, rc;
+        serial_var_geometry(h, 16, waves, units);
+        if ((rc = ensure_serial_var_tables(h, waves))) return rc;
+        SerialLaneVarArgs v = {};
+        v.m = h->m; v.n = h->n; v.nnz = h->nnz; v.max_iter = h->max_iter; v.it_start = it_start; v.n_levels = h->n_levels;
+        v.ms_scaling_factor = h->ms_scaling_factor;
+        v.rows = rows;
+        v.row_ptr = h->d_row_ptr; v.col_idx = h->d_col_idx;
+        v.lane_lvl = (const int32_t *)h->ser_var_lane_lvl.p; v.lane_items = (const int32_t *)h->ser_var_lane_items.p;
+        v.llr0 = h->d_llr0;
+        v.A = state_rows; v.synd = synd; v.decoding = decoding; v.llr = llr; v.iters = iters; v.conv = conv;
+        void (*kv)(const SerialLaneVarArgs);
+        if (h->bp_method == LDPC_HIP_MINIMUM_SUM) kv = pick_serial_lane_var<LDPC_HIP_MINIMUM_SUM, 0>(sp);
+        else if (h->math_mode == LDPC_HIP_MATH_FAST) kv = pick_serial_lane_var<LDPC_HIP_PRODUCT_SUM, 1>(sp);
+        else kv = pick_serial_lane_var<LDPC_HIP_PRODUCT_SUM, 0>(sp);
+        if (llr && !h->order_visits_all) HIPCHK(hipMemsetAsync(llr, 0, sizeof(double) * (size_t)h->n * (size_t)rows, h->stream));  // bits the order never visits report 0
+        const size_t dynv = ((size_t)h->n + 15) & ~(size_t)15;
+        if (dynv > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynv));
+        hipLaunchKernelGGL(kv, dim3((unsigned)rows), dim3((unsigned)(h->sw("SER_LANE_THREADS") > 0 ? h->sw("SER_LANE_THREADS") : rows <= 2048 ? 1024 : 512)), (unsigned)dynv, h->stream, v);
+        HIPCHK(hipGetLastError());
+        return LDPC_HIP_OK;
+    }
     SerialLaneArgs a = {};
     a.m = h->m; a.n = h->n; a.nnz = h->nnz; a.max_iter = h->max_iter; a.it_start = it_start; a.n_levels = h->n_levels;
     a.ms_scaling_factor = h->ms_scaling_factor;
@@ -759,7 +900,7 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
         const size_t per_tile = per_tile_msg + (llr ? sizeof(double) * n1 * LDPC_WAVE : 0) + 24 * (m1 + n1 + 1);
         if ((double)per_tile * (double)tiles_total > (double)(free_b + have) * 0.8 || (h->max_chunk_tiles > 0 && tiles_total > h->max_chunk_tiles)) return 0;
     }
-    if ((rc = ensure_serial_stream_table(h, sp))) return rc;
+    if (!sp.var && (rc = ensure_serial_stream_table(h, sp))) return rc;
     if (!conv) { if ((rc = h->osd_conv.ensure(B))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     if (!iters) { if ((rc = h->sp_iters.ensure(B * 4))) return rc; iters = (int32_t *)h->sp_iters.p; }
     if (!h->h_counters) HIPCHK(hipHostMalloc((void **)&h->h_counters, 16, hipHostMallocDefault));
@@ -779,7 +920,7 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
         if ((rc = serial_lane_launch(h, sp, 0, (double *)h->msgC.p, synd, batch, decoding, llr, iters, conv))) return rc;
         return finish();
     }
-    if (h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the tables that stand in for the initial messages (bp_serial_stream_kernel.h)
+    if (!sp.var && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the tables that stand in for the initial messages (bp_serial_stream_kernel.h)
         if ((rc = h->d_edge0.ensure(sizeof(double) * n1)) || (rc = h->ser_pos_e0.ensure(sizeof(double) * 16 * n1))) return rc;
         const dim3 ge((unsigned)((h->n + 255) / 256));
         if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_MINIMUM_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);

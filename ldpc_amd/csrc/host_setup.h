@@ -61,6 +61,7 @@ int ldpc_hip_bp_create(const ldpc_hip_bp_desc *d, ldpc_hip_bp **out) {
         col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
     }
     h->regular = d->m > 0 && d->n > 0 && min_row == max_row && min_col == h->max_col_deg;
+    h->min_col_deg = min_col;
     {
         std::vector<int32_t> fill(col_ptr.begin(), col_ptr.end() - 1);
         for (int i = 0; i < d->m; ++i)

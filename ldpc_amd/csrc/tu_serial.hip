@@ -3,6 +3,7 @@
 #include "bp_device_common.h"
 #include "bp_serial_kernels.h"
 #include "bp_serial_stream_kernel.h"
+#include "bp_serial_var_kernel.h"
 #include "bp_relative_kernel.h"
 #include "bp_relative_lds_kernel.h"
 #include "io_kernels.h"

@@ -71,5 +71,39 @@ def main():
         note="syndrome bytes > 1 in some rows: pow(-1, byte) sign, never converges (bp.hpp:499, 540)")
 
 
+def main_shapes():
+    """Round 6: the streamed serial kernels for ANY degree profile (csrc/bp_serial_var_kernel.h) -- (4,8)-regular (rows of 8, columns of 4)
+    and irregular (rows of 3 .. 16, columns of 2 .. 8) codes, both methods, a caller's order, syndrome bytes > 1, and the irregular
+    n = 10 000 code of tools/bench_configs.py at its early-exit point."""
+    if not have_ref():
+        sys.exit("oracle/_ref/libref_bp.so missing: make -C oracle ref")
+    h48 = codes.regular_ldpc_code(2400, 4, 8, seed=7)
+    run("serial_ldpc48_n2400_ps30_p055", h48, bsc_syndromes(h48, 31, 0.055, 0, 150), error_rate=0.055, max_iter=30, bp_method="product_sum",
+        full_llr=6, note="(4,8)-regular: rows of 8, columns of 4; converging and hopeless rows in the same tiles")
+    s = bsc_syndromes(h48, 32, 0.05, 0, 130)
+    s[::29, 11] = 3
+    run("serial_ldpc48_n2400_ms24_p050_adaptive_bytes", h48, s, error_rate=0.05, max_iter=24, bp_method="minimum_sum", alpha=0.0, full_llr=6,
+        note="adaptive min-sum scaling; syndrome bytes > 1 in some rows")
+    hi = codes.irregular_ldpc_code(2400, 1200, seed=3)
+    run("serial_irregular_n2400_ps30_p045", hi, bsc_syndromes(hi, 33, 0.045, 0, 150), error_rate=0.045, max_iter=30, bp_method="product_sum", full_llr=6,
+        note="rows of 3 .. 16, columns of 2 .. 8")
+    perm = (sm64(41, np.arange(2400, dtype=np.uint64)) % np.uint64(1 << 40)).argsort().astype(np.int32)
+    run("serial_irregular_n2400_ms30_p040_order", hi, bsc_syndromes(hi, 34, 0.04, 0, 140), error_rate=0.04, max_iter=30, bp_method="minimum_sum", alpha=0.8,
+        order=perm, full_llr=6, note="a caller's serial_schedule_order (a permutation)")
+    rep = perm.copy()
+    rep[100:140] = rep[60:100]  # an order that is no permutation: 40 bits twice, 40 never
+    run("serial_irregular_n2400_ps12_p040_repeats", hi, bsc_syndromes(hi, 35, 0.04, 0, 80), error_rate=0.04, max_iter=12, bp_method="product_sum",
+        order=rep, full_llr=6, note="serial_schedule_order with repeated bits (the reference accepts any n bit numbers)")
+    hb = codes.irregular_ldpc_code(10_000, 5_000, seed=1)
+    run("serial_irregular_n10000_ps50_p050", hb, bsc_syndromes(hb, 7, 0.05, 0, 96), error_rate=0.05, max_iter=50, bp_method="product_sum",
+        recipe="irregular_ldpc_code(10000,5000,seed=1)", note="the irregular code of tools/bench_configs.py, schedule = serial; error seed 7, shots 0..95")
+    h48b = codes.regular_ldpc_code(10_000, 4, 8, seed=1)
+    run("serial_ldpc48_n10000_ps50_p050", h48b, bsc_syndromes(h48b, 7, 0.05, 0, 96), error_rate=0.05, max_iter=50, bp_method="product_sum",
+        recipe="regular_ldpc_code(10000,4,8,seed=1)", note="(4,8)-regular n = 10 000, schedule = serial; error seed 7, shots 0..95")
+
+
 if __name__ == "__main__":
-    main()
+    if "--shapes" in sys.argv:
+        main_shapes()
+    else:
+        main()

@@ -35,7 +35,7 @@ def osdw_case_names():
 
 def _h_from_recipe(recipe: str):
     from ldpc_amd import codes
-    allowed = {"regular_ldpc_code": codes.regular_ldpc_code}
+    allowed = {"regular_ldpc_code": codes.regular_ldpc_code, "irregular_ldpc_code": codes.irregular_ldpc_code}
     fn, args = recipe.split("(", 1)
     args = args.rstrip(")")
     pos, kw = [], {}
