@@ -383,19 +383,24 @@ def schedule_configs(dev, steps):
     return out
 
 
-def serial_headline_config(dev, steps):
-    """SURVEY.md section 8 f1 on the code the bench is quoted on: schedule = serial (fixed order, bp.hpp:451-545) on configs[1]'s
-    (3,6)-regular n = 10 000 code, product_sum, 50 iterations, B = 65 536, at its early-exit point p = 0.05 -- bp_serial_stream_kernel +
-    bp_serial_lane_kernel (csrc/bp_serial_stream_kernel.h; passes).  Two fractions of 8 TB/s, both over the whole
-    step: `frac` with SURVEY.md 8(d)'s bytes (iterations x 4 E x 8 + I/O, the figure every entry of this file uses), `frac_moved` with
-    what the serial schedule itself moves per lane and iteration (18 segments per bit = 6 E x 8: a bit update reads the 15 other entries
-    of its three rows and writes its own three).  Parity: a sample of rows bit-exact against the checker (LLR bits included)."""
+def serial_headline_config(dev, steps, code="ldpc36"):
+    """SURVEY.md section 8 (f1), codes beyond LDS: schedule = serial (bp.hpp:451-545) at the early-exit point p = 0.05, product_sum, 50
+    iterations, B = 65 536, n = 10 000 -- on configs[1]'s (3,6)-regular code (`f1_serial_c2`: bp_serial_stream_kernel, the form built around
+    the (6,3) record) and, since round 6, on a (4,8)-regular code (rows of 8, columns of 4) and the irregular code of `f3_irregular` (rows of
+    3 .. 16, columns of 2 .. 8), both on the item form (bp_serial_var_kernel.h); all decoded in passes with what they leave finishing a
+    workgroup per syndrome.  `frac` is priced in SURVEY.md 8(d)'s bytes (4 E x 8 per iteration) like every other entry; `frac_moved` in the
+    bytes the serial schedule itself moves per lane-iteration -- every entry is read once by each OTHER bit of its row and written once: 8 x the
+    sum of the squared row weights = 6 E x 8 on the (6,3) code, 8 E x 8 on the (4,8) code, 9.75 E x 8 on the irregular one.  Parity: a sample of
+    rows bit-exact against the checker (LLR bits included)."""
     import torch
     from ldpc_amd import codes
     from ldpc_amd.engine import HipBpEngine
     import oracle  # checker only
 
-    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    h, what, key = {"ldpc36": (lambda: codes.regular_ldpc_code(10000, 3, 6, seed=1), "(3,6)-regular LDPC n=10000", "f1_serial_c2"),
+                    "ldpc48": (lambda: codes.regular_ldpc_code(10000, 4, 8, seed=1), "(4,8)-regular LDPC n=10000 (rows of 8, columns of 4)", "f1_serial_ldpc48"),
+                    "irregular": (lambda: codes.irregular_ldpc_code(10000, 5000, seed=1), "irregular LDPC n=10000 m=5000 E=40000 (rows 3..16, columns 2..8)", "f1_serial_irregular")}[code]
+    h = h()
     m, n = h.shape
     p, B, max_iter = 0.05, 65536, 50
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, 0, 1.0, device=dev.index or 0)
@@ -415,7 +420,7 @@ def serial_headline_config(dev, steps):
     ms = float(np.median(step_ms))
     it = out[2].cpu().numpy()
     cv = out[3].cpu().numpy()
-    rows = np.r_[0:160, B - 32:B]
+    rows = np.r_[0:160, B - 32:B] if code == "ldpc36" else np.r_[0:40, B - 8:B]
     idx = torch.from_numpy(rows).to(dev)
     s_host = s[idx].cpu().numpy()
     want = oracle.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=0).decode_serial_batch(s_host, None)
@@ -423,14 +428,18 @@ def serial_headline_config(dev, steps):
               and np.array_equal(it[rows], want[2]) and np.array_equal(cv[rows].astype(bool), want[3]))
     eng.close()
     alg = algorithmic_bytes(it, m, n, h.nnz)
-    moved = float(np.sum(it.astype(np.float64)) * 6.0 * h.nnz * 8.0 + B * (m + 9.0 * n + 5.0))
-    return {"config": "serial schedule (fixed order): (3,6)-regular LDPC n=10000, product_sum max_iter=50, batch=65536, BSC p=0.05", "key": "f1_serial_c2",
+    row_deg = np.diff(h.indptr).astype(np.float64)
+    sq = float(np.sum(row_deg * row_deg))
+    moved = float(np.sum(it.astype(np.float64)) * sq * 8.0 + B * (m + 9.0 * n + 5.0))
+    return {"config": f"serial schedule (fixed order): {what}, product_sum max_iter=50, batch=65536, BSC p=0.05", "key": key,
             "value": B / ms * 1e3, "unit": "syndromes/s", "ms": ms, "ms_steps": [round(v, 3) for v in step_ms], "bp_kernel_ms": float(np.median(kms)),
             "mean_iterations": float(it.mean()), "bp_converged_fraction": float(cv.astype(np.float64).mean()), "parity_vs_oracle": ok,
-            "parity": "bit-exact, 192 rows (decisions, iterations, flags, log-ratio bits)", "bound": "hbm",
+            "parity": f"bit-exact, {len(rows)} rows (decisions, iterations, flags, log-ratio bits)", "bound": "hbm",
             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_moved": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "clock_ghz_this_run": HipBpEngine.clock_ghz(c0, c1),
-            "bound_note": "frac: SURVEY 8(d) bytes (4 E x 8 per iteration) over the step; frac_moved: the 6 E x 8 per lane-iteration the serial schedule moves; "
-                          "counters of the first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
+            "moved_segments_per_edge_iteration": sq / h.nnz,
+            "bound_note": "frac: SURVEY 8(d) bytes (4 E x 8 per iteration) over the step; frac_moved: the bytes the serial schedule itself moves per lane-iteration "
+                          f"(sum of squared row weights x 8 = {sq / h.nnz:.2f} E x 8 here: with exact in-order products an entry must be read by every other bit of its row, "
+                          "DESIGN.md section 4); counters of the (6,3) form's first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
 
 
 def irregular_config(dev, steps):
@@ -895,6 +904,8 @@ def run(args, real_stdout, stage) -> None:
                 res["secondary"] = [early] + secondary_configs(dev, max(5, args.steps))  # (millisecond calls: a median of at least five)
                 res["secondary"] += schedule_configs(dev, args.steps)
                 res["secondary"].append(serial_headline_config(dev, args.steps))
+                res["secondary"].append(serial_headline_config(dev, 2, "ldpc48"))
+                res["secondary"].append(serial_headline_config(dev, 2, "irregular"))
                 res["secondary"].append(irregular_config(dev, args.steps))
                 if not all(e.get("parity_vs_oracle", False) for e in res["secondary"]):
                     res["parity_failed"] = True

@@ -104,13 +104,39 @@ static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
     items.reserve((size_t)h->nnz * SERIAL_VAR_REC);
     for (int l = 0; l < L; ++l) {
         const int p0 = h->h_lvl_ptr[(size_t)l], p1 = h->h_lvl_ptr[(size_t)l + 1];
-        for (int w = 0; w < waves; ++w) {
-            wq[(size_t)l * waves + w] = (int32_t)(items.size() / SERIAL_VAR_REC);
-            for (int p = p0 + w; p < p1; p += waves) {
-                const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
-                for (int k = 0; k < dj; ++k) {
-                    items.resize(items.size() + SERIAL_VAR_REC);
-                    record(items.data() + items.size() - SERIAL_VAR_REC, j, k, false);
+        // The level's positions dealt to the wavefronts so that every wavefront gets about the same work (the level ends with a barrier:
+        // it takes as long as its slowest wavefront): heaviest position first, each to the wavefront with the least so far.  Work of a
+        // position ~ segments it fetches + a constant per message (the `log`) and per own entry (the `tanh`, the store).  The positions of a
+        // level share no check, so their order changes no result.
+        {
+            std::vector<std::pair<int, int>> cost;  // (work, position)
+            cost.reserve((size_t)(p1 - p0));
+            for (int p = p0; p < p1; ++p) {
+                const int j = h->h_lvl_bits[(size_t)p];
+                int c = 0;
+                for (int q = col_ptr[(size_t)j]; q < col_ptr[(size_t)j + 1]; ++q) {
+                    const int i = row_of[(size_t)col_edge[(size_t)q]];
+                    c += (h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i] - 1) + 8;
+                }
+                cost.emplace_back(c, p);
+            }
+            std::stable_sort(cost.begin(), cost.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+            std::vector<std::vector<int>> deal((size_t)waves);
+            std::vector<long> load((size_t)waves, 0);
+            for (const auto &cp : cost) {
+                int best = 0;
+                for (int w = 1; w < waves; ++w) if (load[(size_t)w] < load[(size_t)best]) best = w;
+                deal[(size_t)best].push_back(cp.second);
+                load[(size_t)best] += cp.first;
+            }
+            for (int w = 0; w < waves; ++w) {
+                wq[(size_t)l * waves + w] = (int32_t)(items.size() / SERIAL_VAR_REC);
+                for (int p : deal[(size_t)w]) {
+                    const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
+                    for (int k = 0; k < dj; ++k) {
+                        items.resize(items.size() + SERIAL_VAR_REC);
+                        record(items.data() + items.size() - SERIAL_VAR_REC, j, k, false);
+                    }
                 }
             }
         }
@@ -955,7 +981,9 @@ static int decode_serial_streamed(ldpc_hip_bp *h, const SerialStreamPlan &sp, co
     bool resume = false;
     bool thinning = false;  // the last pass left a minority of its rows: they are converging now, look again after one more iteration
     for (;;) {
-        int next = h->repack_iters == 0 ? full : (it == 0 ? first : thinning ? it + 1 : it * 2);
+        // (resume: most rows of the last pass are still decoding and carry on in their tiles -- a look after every iteration costs a launch
+        // and a count, while a pass that runs on to twice the iterations keeps every tile going to its slowest lane)
+        int next = h->repack_iters == 0 ? full : (it == 0 ? first : (thinning || resume) ? it + 1 : it * 2);
         if (next > full || next <= it) next = full;
         // (a compacted pass reaches the caller's decoding / llr rows through its row list; its iteration counts and flags go by the pass's own rows)
         int32_t *o_it = identity ? iters : (int32_t *)h->rp_iters.p;

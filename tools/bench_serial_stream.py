@@ -23,12 +23,16 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--forms", default="all")
+    ap.add_argument("--code", default="ldpc36", choices=["ldpc36", "ldpc48", "irregular"],
+                    help="ldpc36: (3,6)-regular (configs[1]); ldpc48: (4,8)-regular (rows of 8, columns of 4); irregular: rows of 3 .. 16, columns of 2 .. 8 -- all n = 10 000")
     args = ap.parse_args()
     import torch
     from ldpc_amd import codes
     from ldpc_amd.engine import HipBpEngine
-    h = codes.regular_ldpc_code(10000, 3, 6, seed=1)
+    h = {"ldpc36": lambda: codes.regular_ldpc_code(10000, 3, 6, seed=1), "ldpc48": lambda: codes.regular_ldpc_code(10000, 4, 8, seed=1),
+         "irregular": lambda: codes.irregular_ldpc_code(10000, 5000, seed=1)}[args.code]()
     m, n = h.shape
+    row_deg = np.diff(h.indptr).astype(np.float64)
     forms = [  # (label, serial_kernel, repack, switches, want_llr)
         ("level kernel (round 1-4)", 1, -1, (), True),
         ("streamed, one pass, 16 waves ring 1", 2, 0, (), True),
@@ -40,6 +44,17 @@ def main():
         ("streamed, first pass 5", 2, 5, (), True),
         ("streamed, first pass 3", 2, 3, (), True),
     ]
+    if args.code != "ldpc36":  # the item form (bp_serial_var_kernel.h) against the level kernel it replaces
+        forms = [("level kernel (before round 6)", 2, -1, (("SER_VAR", 0),), True),
+                 ("items, one pass", 2, 0, (), True),
+                 ("items, passes (default)", 2, -1, (), True),
+                 ("items, passes, no log-ratios", 2, -1, (), False),
+                 ("items, passes, 12 KiB queues", 2, -1, (("SER_VAR_UNITS", 12), ("SER_WAVES", 12)), True),
+                 ("items, passes, 16 KiB queues", 2, -1, (("SER_VAR_UNITS", 16), ("SER_WAVES", 9)), True),
+                 ("items, passes, 8 wavefronts", 2, -1, (("SER_WAVES", 8),), True),
+                 ("items, first pass 3", 2, 3, (), True)]
+    elif args.forms == "all":
+        forms.append(("items (SER_VAR 1), passes", 2, -1, (("SER_VAR", 1),), True))
     if args.forms == "default":
         forms = forms[:1] + forms[2:4]
     if args.forms == "one":
@@ -70,8 +85,9 @@ def main():
             ref = (dec, it, cv)
         same = bool(np.array_equal(dec, ref[0]) and np.array_equal(it, ref[1]) and np.array_equal(cv, ref[2]))
         alg = float(np.sum(it.astype(np.float64) * 4.0 * h.nnz * 8.0 + (m + n + 8.0 * n + 5.0)))
-        moved = float(np.sum(it.astype(np.float64) * 6.0 * h.nnz * 8.0))  # what the schedule itself moves: 18 segments per bit and iteration
-        print(json.dumps({"form": label, "batch": args.batch, "p": args.p, "syndromes_per_s": round(args.batch / ms * 1e3), "ms_per_decode": round(ms, 2),
+        # what the schedule itself moves per lane and iteration: every entry read once by each other bit of its row, written once = sum d^2 segments
+        moved = float(np.sum(it.astype(np.float64) * float(np.sum(row_deg * row_deg)) * 8.0))
+        print(json.dumps({"form": label, "code": args.code, "batch": args.batch, "p": args.p, "syndromes_per_s": round(args.batch / ms * 1e3), "ms_per_decode": round(ms, 2),
                           "kernel_ms": round(eng.last_kernel_ms(), 2), "mean_iterations": round(float(it.mean()), 3), "converged": round(float(cv.mean()), 5),
                           "hbm_frac_4E_bytes": round(alg / (ms * 1e-3) / 8e12, 4), "hbm_frac_serial_bytes_per_lane_iteration": round(moved / (ms * 1e-3) / 8e12, 4),
                           "clock_ghz": round(HipBpEngine.clock_ghz(c0, c1) or 0.0, 3), "same_as_first_form": same}), flush=True)
