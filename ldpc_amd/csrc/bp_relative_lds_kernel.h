@@ -58,6 +58,13 @@ struct RelLdsArgs {
     int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
     int32_t scratch_in_l;               // 1: most of the sort's and the levels' scratch lives in the syndrome's posterior array (rel_lds_scratch)
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
+    // EXT = 1 (state beyond LDS, round 6): a syndrome's messages A[nnz] and the per-entry records live in global memory -- A in a slot of
+    // its wavefront (A_g: [workgroups][wavefronts][nnz], L2 / Infinity Cache resident: written and read by that one wavefront), the records as a
+    // read-only table shared by everybody (rec_g: [n][dc], the words the kernel otherwise builds in LDS) -- and LDS keeps posteriors, order,
+    // decisions, syndrome, priors and the sort's scratch: three wavefronts per compute unit on the [[1600,64]] hypergraph-product code
+    // instead of one (min-sum) or none (product-sum)
+    double *A_g;
+    const unsigned long long *rec_g;
     unsigned long long *clk;            // shader-clock probe or nullptr
     unsigned long long *prof;           // nullptr, or 14 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
                                         // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts,
@@ -65,14 +72,14 @@ struct RelLdsArgs {
 };
 
 // shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
-__host__ __device__ inline size_t rel_lds_shared(int m, int n, int nnz, int dc, bool product_sum) {
-    size_t b = (size_t)n * 8 + (product_sum ? (size_t)n * 8 + 256 * 8 : 0) + (size_t)n * dc * 8;
+__host__ __device__ inline size_t rel_lds_shared(int m, int n, int nnz, int dc, bool product_sum, bool ext = false) {
+    size_t b = (size_t)n * 8 + (product_sum ? (size_t)n * 8 + 256 * 8 : 0) + (ext ? 0 : (size_t)n * dc * 8);
     b += ((size_t)(m + 1) * 2 + (size_t)nnz * 2 + (size_t)n + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
 }
 // one syndrome: [A nnz f64][L n f64][ord n u16][dbit n u8][sy m u8]
-__host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, int dc) {
-    size_t b = (size_t)nnz * 8 + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
+__host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, int dc, bool ext = false) {
+    size_t b = (ext ? 0 : (size_t)nnz * 8) + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
     (void)dc;
     return (b + 15) & ~(size_t)15;
 }
@@ -261,14 +268,16 @@ constexpr int bitonic_stages(int places) { int m = 0; while ((1 << m) < places) 
 // places of the sequence per lane (strides < E stay in the lane's registers, the others exchange with lane ^ stride / E), descending; then a
 // key's rank is the place where its run of equal keys begins.  Which of two equal keys the network puts first does not matter: they get
 // the same rank.  Returns true (in every lane) and leaves `rank` alone if a key is NaN.
+// With base0 / sorted: the same for the keys [base0, min(n, base0 + 64 E)) alone -- ranks within that chunk -- and the chunk's keys, descending,
+// written to sorted[0 .. its size) (dense_ranks_chunked below).
 template <int E>
-__device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l_u16 *rank) {
+__device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l_u16 *rank, int base0 = 0, l_f64 *sorted = nullptr) {
     double kk[E];
     int bb[E];
     bool nan = false;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int b = lane * E + i;
+        const int b = base0 + lane * E + i;
         kk[i] = b < n ? key[b] : -__builtin_inf();  // (padding sorts last; it shares a rank with real -inf keys, after all others either way)
         bb[i] = b < n ? b : 0xffff;
         nan = nan || kk[i] != kk[i];
@@ -322,6 +331,62 @@ __device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l
 #pragma unroll
     for (int i = 0; i < E; ++i)
         if (bb[i] != 0xffff) rank[bb[i]] = (uint16_t)(rk[i] > carry ? rk[i] : carry);
+    if (sorted) {
+        const int real = n - base0 < 64 * E ? n - base0 : 64 * E;  // (the padding sorts behind every real key, equal -inf keys included: the first `real` places)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if (lane * E + i < real) sorted[lane * E + i] = kk[i];
+    }
+    return false;
+}
+
+// the same ranks for any n, in chunks of 512 keys: every chunk goes through the network above (ranks within the chunk, its keys descending
+// into `sorted` -- n doubles of scratch), then a key's rank is its rank at home plus, for every other chunk, the number of that chunk's keys
+// that are greater: the place a binary search for the key stops in the chunk's descending list.  (Counting against all keys one by one --
+// dense_ranks_counting below, what ran until round 6 -- is n^2 / 64 comparisons per lane: 58 % of a wavefront-iteration at n = 1600.)
+__device__ inline bool dense_ranks_chunked(const l_f64 *key, int n, int lane, l_u16 *rank, l_f64 *sorted) {
+    bool nan = false;
+    for (int j = lane; j < n; j += 64) nan = nan || key[j] != key[j];
+    if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
+    const int chunks = (n + 511) / 512;
+    for (int c = 0; c < chunks; ++c) (void)dense_ranks<8>(key, n, lane, rank, c * 512, sorted + c * 512);
+    lds_sync();
+    for (int b0 = 0; b0 < n; b0 += 256) {  // four keys per lane at a time: their searches are independent chains
+        double x[4];
+        int home[4], add[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * 64 + lane;
+            x[u] = key[b < n ? b : n - 1];
+            home[u] = b >> 9;
+            add[u] = 0;
+        }
+        for (int c = 0; c < chunks; ++c) {
+            const l_f64 *sc = sorted + c * 512;
+            const int size = n - c * 512 < 512 ? n - c * 512 : 512;
+            int lo[4], hi[4];  // the answer lies in [lo, hi]: places below lo hold greater keys, places from hi on do not
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { lo[u] = 0; hi[u] = size; }
+            for (int step = 0; step < 10; ++step) {  // (2^10 > 512: every interval has closed)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    const bool open = lo[u] < hi[u];
+                    const double km = sc[open ? mid : 0];
+                    const bool greater = km > x[u];
+                    lo[u] = open && greater ? mid + 1 : lo[u];
+                    hi[u] = open && !greater ? mid : hi[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add[u] += c != home[u] ? lo[u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * 64 + lane;
+            if (b < n) rank[b] = (uint16_t)(rank[b] + add[u]);
+        }
+    }
     return false;
 }
 
@@ -371,7 +436,11 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
 #define RL_SMARK(k) do { if (pfs) { const unsigned long long now_ = __builtin_readcyclecounter(); pfs[k] += now_ - pfs_t; pfs_t = now_; } } while (0)
     // any NaN key -- the comparator is no strict weak order and the reference's own result is whatever its loops happen to do: the
     // sequential restatement (what the per-lane kernel and the CPU checker run)
-    const bool nan = n <= 256 ? dense_ranks<4>(key, n, lane, rank) : n <= 512 ? dense_ranks<8>(key, n, lane, rank) : dense_ranks_counting(key, n, lane, rank);
+    // (n > 512: v and tmp -- 8 n bytes next to each other when the scratch is not housed in the posterior array, which it never is beyond 512
+    // bits -- are not yet in use and take the chunks' sorted keys)
+    const bool chunked = n > 512 && (l_u8 *)tmp == (l_u8 *)v + (size_t)n * 4 && (n & 1) == 0;
+    const bool nan = n <= 256 ? dense_ranks<4>(key, n, lane, rank) : n <= 512 ? dense_ranks<8>(key, n, lane, rank)
+                     : chunked ? dense_ranks_chunked(key, n, lane, rank, (l_f64 *)v) : dense_ranks_counting(key, n, lane, rank);
     if (nan) {
         if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n, reinterpret_cast<l_u16 *>(v)); }  // (v: 4 n bytes, not yet in use; the stack needs 6 (2 log2 n + 2) for n > 16, 6 below)
         lds_sync();
@@ -583,10 +652,19 @@ __device__ __forceinline__ double group_lane(double x, int p, int lane) {  // th
 
 // GS: lanes of a syndrome (64: one per wavefront; 16: four per wavefront).  DRT: bound of the row loop (heaviest row <= DRT).  DCT: bound of
 // the per-lane column arrays of the level-parallel sweep (heaviest column <= DCT; GS = 64 only).
-template <int METHOD, int MATH, int DRT, int GS, int DCT>
+template <int METHOD, int MATH, int DRT, int GS, int DCT, int EXT = 0>
 __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs a) {
     using namespace rel_lds;
     constexpr int G = 64 / GS;
+    static_assert(!EXT || GS == 64, "state in global memory: a wavefront per syndrome");
+    typedef typename std::conditional<EXT != 0, double, l_f64>::type a_f64;                            // where the messages live
+    typedef typename std::conditional<EXT != 0, const unsigned long long, l_u64>::type rec_u64;       // ... and the records
+    // (EXT: a wavefront's stores to A must have completed before its next level's loads -- same wavefront, same L1: a wait, no invalidate)
+    auto state_sync = [&]() {
+        if (EXT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_sync();
+        if (EXT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     extern __shared__ __attribute__((aligned(16))) unsigned char rl_lds[];
     const int tid = threadIdx.x, T = blockDim.x;
     const int lane = tid & 63;
@@ -602,18 +680,21 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_f64 *pform = prior + n;
     l_f64 *log_tab_l = pform + (PS ? n : 0);
     const double *log_tab = reinterpret_cast<const double *>(rl_lds) + (size_t)n + (PS ? (size_t)n : 0);
-    l_u64 *rec = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32 | check << 48
-    l_u16 *rstart = (l_u16 *)(rec + (size_t)n * dc);
+    l_u64 *rec_l = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32 | check << 48
+    rec_u64 *rec;
+    if constexpr (EXT != 0) rec = a.rec_g; else rec = rec_l;
+    l_u16 *rstart = (l_u16 *)(rec_l + (EXT ? 0 : (size_t)n * dc));
     l_u16 *rcol = rstart + (m + 1);
     l_u8 *cdeg = (l_u8 *)(rcol + nnz);
     for (int q = tid; q < n; q += T) { prior[q] = a.llr0[q]; cdeg[q] = a.t_cdeg[q]; }
     for (int q = tid; q <= m; q += T) rstart[q] = (uint16_t)a.row_ptr[q];
     for (int q = tid; q < nnz; q += T) rcol[q] = (uint16_t)a.col_idx[q];
-    for (int q = tid; q < n * dc; q += T) {
-        const int chk = a.t_chk[q];
-        const unsigned long long rs = (unsigned long long)a.row_ptr[chk], rd = (unsigned long long)(a.row_ptr[chk + 1] - a.row_ptr[chk]);
-        rec[q] = (unsigned long long)a.t_edge[q] | (rs << 16) | (rd << 32) | ((unsigned long long)chk << 48);
-    }
+    if constexpr (EXT == 0)
+        for (int q = tid; q < n * dc; q += T) {
+            const int chk = a.t_chk[q];
+            const unsigned long long rs = (unsigned long long)a.row_ptr[chk], rd = (unsigned long long)(a.row_ptr[chk + 1] - a.row_ptr[chk]);
+            rec_l[q] = (unsigned long long)a.t_edge[q] | (rs << 16) | (rd << 32) | ((unsigned long long)chk << 48);
+        }
     if (PS && MATH == 0)
         for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
@@ -626,8 +707,9 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
     l_u8 *wave_base = base + a.lds_shared + (size_t)wave * ((size_t)G * a.lds_per_syn + a.lds_scratch);
     auto syn_base = [&](int gg) { return wave_base + (size_t)gg * a.lds_per_syn; };
     l_u8 *mine = syn_base(g);
-    l_f64 *A = (l_f64 *)mine;
-    l_f64 *L = A + nnz;
+    a_f64 *A;
+    if constexpr (EXT != 0) A = a.A_g + ((size_t)blockIdx.x * (size_t)(T >> 6) + (size_t)wave) * (size_t)nnz; else A = (l_f64 *)mine;
+    l_f64 *L = (l_f64 *)mine + (EXT ? 0 : nnz);
     l_u16 *ord = (l_u16 *)(L + n);
     l_u8 *dbit = (l_u8 *)ord + n2;     // hard decisions (a bit the order never visits keeps its 0)
     l_u8 *sy = dbit + n1;
@@ -680,7 +762,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 running = a.max_iter > 0;
             }
         }
-        lds_sync();
+        state_sync();
         RL_MARK(0);
         const uint64_t runm = __builtin_amdgcn_ballot_w64(running);
         if (runm != 0) {
@@ -692,7 +774,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
             for (int gg = 0; gg < G; ++gg) {
                 if (!((runm >> (gg * GS)) & 1ull)) continue;
                 l_u8 *sb = syn_base(gg);
-                l_f64 *Lg = (l_f64 *)sb + nnz;
+                l_f64 *Lg = (l_f64 *)sb + (EXT ? 0 : nnz);
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
                 sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, a.prof ? pfs : nullptr);
             }
@@ -847,7 +929,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                         if (mine_p) A[e] = edge_form<METHOD, MATH>(b2c);
                         if (pl == 0) { L[bq] = llr; dbit[bq] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
                     }
-                    lds_sync();
+                    state_sync();
                 }
             } else {
             // the sweep: every running group walks its own order
@@ -907,7 +989,7 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 }
                 if (mine_p) A[e] = edge_form<METHOD, MATH>(b2c);
                 if (running && gl == 0) { L[bit] = llr; dbit[bit] = llr <= 0 ? 1 : 0; }  // bp.hpp:525-529
-                lds_sync();
+                state_sync();
                 bit = bit_next; rc = rc_next; cd = cd_next; odd = odd_next;
             }
             }

@@ -553,15 +553,29 @@ static int decode_serial_random(ldpc_hip_bp *h, const uint8_t *synd, int64_t bat
 // serial_relative with a syndrome's whole state in LDS, one wavefront per syndrome (bp_relative_lds_kernel.h): codes with columns of
 // <= 8 and rows of <= 16 entries whose state leaves room for at least four wavefronts per compute unit; LDPC_HIP_REL_LDS=0 keeps the
 // per-lane kernel (A/B, tests).  Returns 1 if the batch was decoded here, 0 if the caller should carry on, < 0 on error.
+// the record of an entry beyond its column's weight, as bp_relative_lds_kernel builds it from the zero-filled tables: edge 0 of check 0
+static unsigned long long m_pad_word(const ldpc_hip_bp *h) {
+    const unsigned long long rs = (unsigned long long)h->h_row_ptr[0], rd = (unsigned long long)(h->h_row_ptr[1] - h->h_row_ptr[0]);
+    return 0ull | (rs << 16) | (rd << 32);
+}
+
 static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *decoding, double *llr,
                                       int32_t *iters, uint8_t *conv) {
     if (h->sw("REL_LDS") == 0 || h->m <= 0 || h->n <= 0 || h->nnz <= 0) return 0;
     if (h->max_col_deg > 8 || h->max_row_deg > 16 || h->n >= 65535 || h->nnz >= 65535 || h->m >= 65535) return 0;
     const bool ps = h->bp_method == LDPC_HIP_PRODUCT_SUM;
     const int dc = h->max_col_deg;
-    const size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc);
+    size_t shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps), per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc);
     size_t scratch = rel_lds_scratch(h->n, dc, false);
     const size_t lds = 160u * 1024u - 64u;
+    // State beyond LDS (round 6): where everything in LDS leaves fewer than four wavefronts per compute unit, the messages (the bulk of a
+    // syndrome's state) and the per-entry records (the bulk of the shared tables) move to global memory -- bp_relative_lds_kernel<..., EXT = 1>.
+    bool ext = h->sw("REL_EXT") > 0 || (h->sw("REL_EXT") != 0 && shared + 4 * (per_syn + scratch) > lds);
+    if (h->max_row_deg <= 4 || dc <= 2) ext = false;  // (instantiated for rows of 5 .. 16 and columns of 3 .. 8 entries)
+    if (ext) {
+        shared = rel_lds_shared(h->m, h->n, h->nnz, dc, ps, true);
+        per_syn = rel_lds_per_syndrome(h->m, h->n, h->nnz, dc, true);
+    }
     // The sweep goes level by level (bp_relative_lds_kernel.h) when "the position of bit b" is one place: the order must be a permutation
     // of the bits (it is, unless the caller gave a serial_schedule_order with repeats); LDPC_HIP_REL_LEVELS=0 walks bit by bit (A/B, tests).
     bool levels = h->sw("REL_LEVELS") != 0 && (int)h->sched_state.size() == h->n;
@@ -577,17 +591,19 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     // unit; min-sum waits on LDS rather than on the vector unit: one syndrome per wavefront.  LDPC_HIP_REL_LDS = 64 / 16 forces a form
     // (16 implies bit by bit; 32 lanes per syndrome measured in between -- profiles/r4_stateful_schedules.jsonl -- and is not built).
     int gs = 64;
-    if (!levels && ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
-    if (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64) gs = h->sw("REL_LDS");
+    if (!ext && !levels && ps && shared + 4 * (4 * per_syn + scratch) <= lds) gs = 16;
+    if (!ext && (h->sw("REL_LDS") == 16 || h->sw("REL_LDS") == 64)) gs = h->sw("REL_LDS");
     if (gs == 16) levels = false;
     // level by level every bit's posterior is rewritten by the sweep: the array is free from the sort's ranks to the sweep and houses most of the
     // scratch (rel_lds_scratch) -- more wavefronts per compute unit.  LDPC_HIP_REL_SCRATCH_IN_L=0: separate scratch (A/B, tests).
-    const bool in_l = levels && gs == 64 && h->n >= 16 && h->n <= 512 && h->sw("REL_SCRATCH_IN_L") != 0;
+    const bool in_l = !ext && levels && gs == 64 && h->n >= 16 && h->n <= 512 && h->sw("REL_SCRATCH_IN_L") != 0;
     if (in_l) scratch = rel_lds_scratch(h->n, dc, true);
     const int G = 64 / gs;
     const size_t per_wave = (size_t)G * per_syn + scratch;
-    if (shared + (gs == 64 ? 4 : 1) * per_wave > lds) {
-        if (gs != 64 && shared + 4 * (per_syn + scratch) <= lds) gs = 64; else return 0;
+    // (round 6: ONE wavefront per compute unit is enough -- measured on the [[1600,64]] hypergraph-product code, whose 61 KB of state per
+    // syndrome + 93 KB of tables leave exactly that: 60.7 k syndromes/s against the per-lane kernel's 7.0 k, profiles/r6_serial_relative_hgp1600.txt)
+    if (shared + (gs == 64 ? 1 : 4) * per_wave > lds) {
+        if (gs != 64 && shared + (per_syn + scratch) <= lds) gs = 64; else return 0;
     }
     const int Gf = 64 / gs;
     const size_t per_wave_f = (size_t)Gf * per_syn + scratch;
@@ -617,6 +633,24 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     if ((rc = h->sched_order0.ensure((size_t)h->n * sizeof(int32_t))) || (rc = h->counter.ensure(16 + 14 * 8))) return rc;
     hipStream_t st = h->stream;
     HIPCHK(hipStreamSynchronize(st));
+    if (ext && !h->rl_rec_valid) {  // the records the kernel otherwise builds in LDS: CSR edge | row start << 16 | row weight << 32 | check << 48 per (bit, entry of its column)
+        std::vector<unsigned long long> rec((size_t)h->n * dc, 0ull);
+        std::vector<uint8_t> cd((size_t)h->n, 0);
+        for (int i = 0; i < h->m; ++i) {
+            const unsigned long long rs = (unsigned long long)h->h_row_ptr[(size_t)i], rd = (unsigned long long)(h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i]);
+            for (int e = h->h_row_ptr[(size_t)i]; e < h->h_row_ptr[(size_t)i + 1]; ++e) {
+                const int j = h->h_col_idx[(size_t)e], k = cd[(size_t)j]++;
+                rec[(size_t)j * dc + k] = (unsigned long long)e | (rs << 16) | (rd << 32) | ((unsigned long long)i << 48);
+            }
+        }
+        // (entries beyond a column's weight: the kernel's words for t_chk = t_edge = 0 -- check 0's row)
+        const unsigned long long pad = m_pad_word(h);
+        for (int j = 0; j < h->n; ++j)
+            for (int k = cd[(size_t)j]; k < dc; ++k) rec[(size_t)j * dc + k] = pad;
+        if ((rc = h->rl_rec.ensure(rec.size() * 8))) return rc;
+        HIPCHK(hipMemcpy(h->rl_rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
+        h->rl_rec_valid = true;
+    }
     HIPCHK(hipMemcpy(h->sched_order0.p, h->sched_state.data(), (size_t)h->n * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemsetAsync(h->counter.p, 0, 16 + 14 * 8, st));
     RelLdsArgs a = {};
@@ -637,16 +671,24 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     a.prof = h->sw("REL_PROF") > 0 ? (unsigned long long *)((char *)h->counter.p + 16) : nullptr;
     void (*kern)(const RelLdsArgs);
 #define LDPC_PICK_REL_G(M, F, GSZ, DCT) (h->max_row_deg <= 4 ? bp_relative_lds_kernel<M, F, 4, GSZ, DCT> : h->max_row_deg <= 8 ? bp_relative_lds_kernel<M, F, 8, GSZ, DCT> : bp_relative_lds_kernel<M, F, 16, GSZ, DCT>)
-#define LDPC_PICK_REL(M, F) (gs == 16 ? LDPC_PICK_REL_G(M, F, 16, 8) : dc <= 2 ? LDPC_PICK_REL_G(M, F, 64, 2) : dc <= 4 ? LDPC_PICK_REL_G(M, F, 64, 4) : LDPC_PICK_REL_G(M, F, 64, 8))
+#define LDPC_PICK_REL_X(M, F) (h->max_row_deg <= 8 ? (dc <= 4 ? bp_relative_lds_kernel<M, F, 8, 64, 4, 1> : bp_relative_lds_kernel<M, F, 8, 64, 8, 1>) \
+                                                   : (dc <= 4 ? bp_relative_lds_kernel<M, F, 16, 64, 4, 1> : bp_relative_lds_kernel<M, F, 16, 64, 8, 1>))
+#define LDPC_PICK_REL(M, F) (ext ? LDPC_PICK_REL_X(M, F) : gs == 16 ? LDPC_PICK_REL_G(M, F, 16, 8) : dc <= 2 ? LDPC_PICK_REL_G(M, F, 64, 2) : dc <= 4 ? LDPC_PICK_REL_G(M, F, 64, 4) : LDPC_PICK_REL_G(M, F, 64, 8))
     if (!ps) kern = LDPC_PICK_REL(LDPC_HIP_MINIMUM_SUM, 0);
     else if (h->math_mode == LDPC_HIP_MATH_FAST) kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 1);
     else kern = LDPC_PICK_REL(LDPC_HIP_PRODUCT_SUM, 0);
 #undef LDPC_PICK_REL
+#undef LDPC_PICK_REL_X
 #undef LDPC_PICK_REL_G
     const size_t dyn = shared + (size_t)waves * per_wave_f;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     int64_t groups = (batch + (int64_t)waves * Gf - 1) / ((int64_t)waves * Gf);
     if (groups > 256 * (int64_t)groups_per_cu) groups = 256 * (int64_t)groups_per_cu;
+    if (ext) {
+        if ((rc = h->rl_ext_A.ensure((size_t)groups * (size_t)waves * (size_t)h->nnz * sizeof(double)))) return rc;
+        a.A_g = (double *)h->rl_ext_A.p;
+        a.rec_g = (const unsigned long long *)h->rl_rec.p;
+    }
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
     h->timed_mid = false;

@@ -65,12 +65,18 @@ def _engine(c, rel_lds=None):
             eng.set_debug_switch("REL_LEVELS", 0)
         elif rel_lds == "apart":
             eng.set_debug_switch("REL_SCRATCH_IN_L", 0)
+        elif rel_lds in ("ext", "ext_walk"):  # messages and records in global memory (round 6; rows of 5 .. 16, columns of 3 .. 8 entries, else ignored)
+            eng.set_debug_switch("REL_EXT", 1)
+            if rel_lds == "ext_walk":
+                eng.set_debug_switch("REL_LEVELS", 0)
+        elif rel_lds == "lds_only":
+            eng.set_debug_switch("REL_EXT", 0)
         else:
             eng.set_debug_switch("REL_LDS", rel_lds)
     return eng
 
 
-KERNELS = [None, 0, 16, 64, "walk", "apart"]  # (see _engine: default = on chip, level by level; the random schedule ignores the switches)
+KERNELS = [None, 0, 16, 64, "walk", "apart", "ext", "ext_walk", "lds_only"]  # (see _engine: default = on chip, level by level; the random schedule ignores the switches)
 
 
 @pytest.mark.gpu
@@ -135,7 +141,7 @@ def test_mirror_decode_sequence_and_batch(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("code,method,alpha,p,max_iter", [("surface21", 1, 0.625, 0.05, 30), ("bb144", 0, 1.0, 0.05, 50), ("bb144", 1, 0.0, 0.08, 12),
-                                                          ("ldpc600", 0, 1.0, 0.04, 10)])
+                                                          ("ldpc600", 0, 1.0, 0.04, 10), ("hgp1600", 1, 0.625, 0.02, 20), ("hgp1600", 0, 1.0, 0.025, 8)])
 def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_checker(code, method, alpha, p, max_iter, oracle_built):
     """A few thousand syndromes of the codes the schedule is used on -- thousands of std::sort calls on keys FULL of ties (min-sum
     posteriors; all-equal priors in iteration 1) -- through bp_relative_lds_kernel (parallel re-enactment of the sort) and
@@ -144,17 +150,22 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
     from ldpc_amd import codes
     from ldpc_amd.engine import HipBpEngine
     h = {"surface21": lambda: codes.rotated_surface_code_x(21), "bb144": codes.bivariate_bicycle_hx,
-         "ldpc600": lambda: codes.regular_ldpc_code(600, 3, 6, seed=4)}[code]()
+         "ldpc600": lambda: codes.regular_ldpc_code(600, 3, 6, seed=4),
+         "hgp1600": lambda: codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))}[code]()  # (state beyond LDS: the EXT form by default)
     m, n = h.shape
-    B = 3000 if code != "ldpc600" else 700
+    B = 3000 if code not in ("ldpc600", "hgp1600") else 700
     outs = {}
-    for lds in (64, "apart", "walk", 16, 0):  # on chip: level by level (scratch in the posterior array / apart), bit by bit with one / four syndromes per wavefront; 0: the per-lane kernel
+    for lds in (64, "apart", "walk", 16, "ext", "ext_walk", 0):  # on chip: level by level (scratch in the posterior array / apart), bit by bit with one / four syndromes per wavefront; 0: the per-lane kernel
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), max_iter, method, alpha)
         eng.set_schedule("serial_relative")
         if lds == "walk":
             eng.set_debug_switch("REL_LEVELS", 0)
         elif lds == "apart":
             eng.set_debug_switch("REL_SCRATCH_IN_L", 0)
+        elif lds in ("ext", "ext_walk"):
+            eng.set_debug_switch("REL_EXT", 1)
+            if lds == "ext_walk":
+                eng.set_debug_switch("REL_LEVELS", 0)
         else:
             eng.set_debug_switch("REL_LDS", lds)
         s = eng.gen_bsc_syndromes(17, p, shot0=0, shots=B, device="cuda:0").cpu().numpy()
@@ -162,14 +173,14 @@ def test_serial_relative_on_chip_kernel_against_the_per_lane_kernel_and_the_chec
         outs[lds] = eng.decode_batch(s) + (eng.schedule_order(),)
         outs[(lds, "ms")] = eng.last_kernel_ms()
         eng.close()
-    for lds in (64, "apart", "walk", 16):
+    for lds in (64, "apart", "walk", 16, "ext", "ext_walk"):
         assert same(outs[lds][:4], outs[0][:4]) and np.array_equal(outs[lds][4], outs[0][4]), lds
     assert not outs[64][3][7]
     o = oracle_built.BpOracle(h, error_rate=p, max_iter=max_iter, bp_method=method, ms_scaling_factor=alpha)
     rows = np.r_[0:40, B - 8:B]
     want = o.decode_serial_relative_batch(s[rows], fresh=True)
     assert same(tuple(x[rows] for x in outs[64][:4]), want[:4]) and np.array_equal(outs[64][4], want[4])
-    print(f"[serial_relative {code} method {method}: on chip {outs[(64, 'ms')]:.1f} ms level by level ({outs[('apart', 'ms')]:.1f} with the scratch apart), {outs[('walk', 'ms')]:.1f} / {outs[(16, 'ms')]:.1f} ms bit by bit "
+    print(f"[serial_relative {code} method {method}: messages in global memory {outs[('ext', 'ms')]:.1f} ms; on chip {outs[(64, 'ms')]:.1f} ms level by level ({outs[('apart', 'ms')]:.1f} with the scratch apart), {outs[('walk', 'ms')]:.1f} / {outs[(16, 'ms')]:.1f} ms bit by bit "
           f"(64 / 16 lanes per syndrome), per-lane kernel {outs[(0, 'ms')]:.1f} ms for {B} syndromes]")
 
 
