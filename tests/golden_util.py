@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def case_names(prefix: str = ""):
     """BP fixtures (``decoding`` = BpDecoder output).  BP+OSD-0 fixtures are listed by ``osd_case_names``."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [n for n in names if not n.startswith(("osd_", "osdw_", "serial_", "mcs_", "soft_", "lusolve_", "qcodes_", "window_", "outimage_", "stateful_"))]
+    return [n for n in names if not n.startswith(("osd_", "osdw_", "serial_", "mcs_", "soft_", "lusolve_", "qcodes_", "window_", "outimage_", "stateful_", "sinter_"))]
 
 
 def serial_case_names():
