@@ -65,6 +65,10 @@ struct RelLdsArgs {
     // instead of one (min-sum) or none (product-sum)
     double *A_g;
     const unsigned long long *rec_g;
+    // [n] the order after the FIRST iteration's sort, or nullptr: every row of a call starts from the same order and the first sort's keys are
+    // the priors, so its outcome is the same for every row -- worked out once per call (rel_first_order_kernel) instead of once per syndrome
+    // (with uniform priors all its keys are equal: the sort whose re-enactment costs most)
+    const int32_t *first_order;
     unsigned long long *clk;            // shader-clock probe or nullptr
     unsigned long long *prof;           // nullptr, or 14 words (LDPC_HIP_REL_PROF=1): shader cycles per phase, summed over the wavefronts --
                                         // {refill, sort, levels, sweep, syndrome test, results out}, wavefront-iterations, levels, cycles, wavefronts,
@@ -447,6 +451,27 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
         return;
     }
     lds_sync();
+    // No two elements of the order with equal keys (the usual case for product-sum posteriors from the second iteration on): the comparator
+    // is a strict total order on them and ANY correct sort ends with the element of rank r in place r -- no partition needs re-enacting.
+    // (Equal keys -- min-sum posteriors, uniform priors, a caller's order with a bit twice -- leave where std::sort's own sequence of swaps
+    // leaves them: the re-enactment below.)  Counted per rank in tmp (not yet in use, 4 n bytes).
+    {
+        for (int p = lane; p < n; p += 64) tmp[p] = 0;
+        lds_sync();
+        bool tie = false;
+        for (int p = lane; p < n; p += 64)
+            tie = tie || __hip_atomic_fetch_add(&tmp[rank[ord[p]]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != 0u;
+        if (__builtin_amdgcn_ballot_w64(tie) == 0) {
+            lds_sync();
+            for (int p = lane; p < n; p += 64) v[p] = ord[p];  // (all of the order read before any of it is rewritten)
+            lds_sync();
+            for (int p = lane; p < n; p += 64) { const uint32_t bq = v[p]; ord[rank[bq]] = (uint16_t)bq; }
+            lds_sync();
+            RL_SMARK(0);
+            return;
+        }
+        lds_sync();
+    }
     RL_SMARK(0);
     for (int p = lane; p < n; p += 64) { const uint32_t b = ord[p]; v[p] = ((uint32_t)rank[b] << 16) | b; runs[p] = p == 0 ? 1 : 0; }
     int depth = 0;
@@ -776,6 +801,12 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
                 l_u8 *sb = syn_base(gg);
                 l_f64 *Lg = (l_f64 *)sb + (EXT ? 0 : nnz);
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
+                if (itg == 1 && a.first_order) {
+                    l_u16 *og = (l_u16 *)(Lg + n);
+                    for (int t = lane; t < n; t += 64) og[t] = (uint16_t)a.first_order[t];
+                    lds_sync();
+                    continue;
+                }
                 sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, a.prof ? pfs : nullptr);
             }
             RL_MARK(1);
@@ -1037,4 +1068,27 @@ __global__ void __launch_bounds__(1024) bp_relative_lds_kernel(const RelLdsArgs 
         for (int k = 0; k < 4; ++k) __hip_atomic_fetch_add(a.prof + 10 + k, pfs[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) clock_probe_end(a.clk, clk_stamp);
+}
+
+
+// The first iteration's sort of a call, once (RelLdsArgs::first_order): order0 sorted by descending prior with the re-enactment above.
+// One wavefront; dynamic LDS: [prior n f64][ord n u16 (padded to 8)][the sort's scratch, rel_lds_scratch(n, ., false)].
+__global__ void __launch_bounds__(64) rel_first_order_kernel(const double *__restrict__ llr0, const int32_t *__restrict__ order0, int n, int32_t *__restrict__ out) {
+    using namespace rel_lds;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rl_lds[];
+    const int lane = threadIdx.x;
+    l_u8 *base = (l_u8 *)rl_lds;
+    l_f64 *prior = (l_f64 *)base;
+    l_u16 *ord = (l_u16 *)(prior + n);
+    l_u8 *scr = (l_u8 *)ord + (((size_t)n * 2 + 15) & ~(size_t)15);
+    l_u32 *s_v = (l_u32 *)scr;
+    l_u32 *s_tmp = s_v + n;
+    l_u16 *s_posL = (l_u16 *)s_tmp, *s_posR = s_posL + n;
+    l_u16 *s_rank = (l_u16 *)(s_tmp + n);
+    l_u8 *s_runs = (l_u8 *)s_rank + (((n + 1) * 2 + 7) & ~7);
+    for (int t = lane; t < n; t += 64) { prior[t] = llr0[t]; ord[t] = (uint16_t)(order0 ? order0[t] : t); }
+    lds_sync();
+    sort_desc_wave(ord, prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_rank, s_runs, nullptr);
+    lds_sync();
+    for (int t = lane; t < n; t += 64) out[t] = (int32_t)ord[t];
 }

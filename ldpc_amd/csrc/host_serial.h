@@ -682,6 +682,17 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
 #undef LDPC_PICK_REL_G
     const size_t dyn = shared + (size_t)waves * per_wave_f;
     if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    {   // the first iteration's sort, once per call (every row starts from the same order with the same keys): bp_relative_lds_kernel.h
+        const size_t n1 = (size_t)h->n;
+        const size_t pre = n1 * 8 + ((n1 * 2 + 15) & ~(size_t)15) + rel_lds_scratch(h->n, dc, false);
+        if (h->sw("REL_FIRST_ONCE") != 0 && batch > 1 && h->max_iter > 0 && pre <= 150u * 1024u && (int)h->sched_state.size() == h->n) {
+            if ((rc = h->rl_first.ensure(n1 * sizeof(int32_t)))) return rc;
+            if (pre > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)rel_first_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pre));
+            hipLaunchKernelGGL(rel_first_order_kernel, dim3(1), dim3(64), (unsigned)pre, st, h->d_llr0, (const int32_t *)h->sched_order0.p, h->n, (int32_t *)h->rl_first.p);
+            HIPCHK(hipGetLastError());
+            a.first_order = (const int32_t *)h->rl_first.p;
+        }
+    }
     int64_t groups = (batch + (int64_t)waves * Gf - 1) / ((int64_t)waves * Gf);
     if (groups > 256 * (int64_t)groups_per_cu) groups = 256 * (int64_t)groups_per_cu;
     if (ext) {
