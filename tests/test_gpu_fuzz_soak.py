@@ -27,3 +27,12 @@ def test_schedules_soak_slice(seed, oracle_built):
     import fuzz_schedules
     cases = fuzz_schedules.run(seconds=20.0, seed=seed, max_cases=60)
     assert cases >= 10, f"only {cases} cases in 20 s"
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_serial_stream_soak_slice(seed, oracle_built):
+    """tests/fuzz_serial_stream.py: the streamed serial schedule -- (3,6), (4,8), (3,4), (5,10)-regular and irregular codes, the form built around the
+    (6,3) record and the item form, passes, compaction, the per-syndrome kernels, batches whose state is not resident at once."""
+    import fuzz_serial_stream
+    cases = fuzz_serial_stream.run(seconds=25.0, seed=seed, max_cases=10)
+    assert cases >= 2, f"only {cases} cases in 25 s"
