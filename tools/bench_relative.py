@@ -37,6 +37,8 @@ def main():
         h = codes.bivariate_bicycle_hx()
     m, n = h.shape
     forms = [("per-lane kernel (REL_LDS 0)", (("REL_LDS", 0),)), ("default", ())]
+    if args.forms == "one":
+        forms = forms[1:2]
     if args.forms == "all":
         forms += [("REL_GLOBAL 0 (all state in LDS)", (("REL_GLOBAL", 0),)), ("REL_GLOBAL 1", (("REL_GLOBAL", 1),)), ("REL_GLOBAL 2", (("REL_GLOBAL", 2),))]
     ref = None

@@ -58,7 +58,7 @@ def main():
     if args.forms == "default":
         forms = forms[:1] + forms[2:4]
     if args.forms == "one":
-        forms = forms[2:3]
+        forms = forms[2:3]  # (the default form of either list: passes)
     ref = None
     for label, mode, repack, switches, want_llr in forms:
         eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, args.p), 50, args.method, args.alpha)
