@@ -421,6 +421,10 @@ def serial_headline_config(dev, steps, code="ldpc36"):
         step_ms.append((time.perf_counter() - t0) * 1e3)
         kms.append(eng.last_kernel_ms())
     c1 = eng.clock_probe()
+    try:  # the box's copy rate for tiles of this size (ldpc_hip_bp_copy_probe), right after the timed decodes
+        copy_gbps = float(np.median([eng.copy_probe(1024, h.nnz, passes=2)[1] for _ in range(2)]))
+    except Exception:
+        copy_gbps = None
     ms = float(np.median(step_ms))
     it = out[2].cpu().numpy()
     cv = out[3].cpu().numpy()
@@ -440,10 +444,11 @@ def serial_headline_config(dev, steps, code="ldpc36"):
             "mean_iterations": float(it.mean()), "bp_converged_fraction": float(cv.astype(np.float64).mean()), "parity_vs_oracle": ok,
             "parity": f"bit-exact, {len(rows)} rows (decisions, iterations, flags, log-ratio bits)", "bound": "hbm",
             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "frac_moved": moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "clock_ghz_this_run": HipBpEngine.clock_ghz(c0, c1),
-            "moved_segments_per_edge_iteration": sq / h.nnz,
+            "moved_segments_per_edge_iteration": sq / h.nnz, "copy_GBps_this_run": copy_gbps,
+            "frac_ceiling_at_copy_rate": (copy_gbps / HBM_PEAK_GBPS * 4.0 * h.nnz / sq) if copy_gbps else None,
             "bound_note": "frac: SURVEY 8(d) bytes (4 E x 8 per iteration) over the step; frac_moved: the bytes the serial schedule itself moves per lane-iteration "
                           f"(sum of squared row weights x 8 = {sq / h.nnz:.2f} E x 8 here: with exact in-order products an entry must be read by every other bit of its row, "
-                          "DESIGN.md section 4); counters of the (6,3) form's first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
+                          "DESIGN.md section 4) -- so in the 4 E accounting the schedule cannot exceed frac_ceiling_at_copy_rate = this run's bare copy rate / 8 TB/s x 4 E / sum d^2; counters of the (6,3) form's first pass in profiles/r5_serial_stream_summary.txt (traffic 5.1 TB/s = the chip's copy rate)"}
 
 
 def irregular_config(dev, steps):
