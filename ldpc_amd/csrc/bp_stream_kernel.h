@@ -30,8 +30,10 @@
 #define LDPC_RING_VAR 9
 typedef int ldpc_v4i __attribute__((ext_vector_type(4)));
 constexpr int stream_max_waves(int dr, int ring) { return ring == LDPC_RING_VAR ? 12 : ring ? 16 : dr > 8 ? 8 : dr > 6 ? 12 : 16; }
+// (fixed-degree ring variants with rows of more than 8 entries -- (5,10)-regular codes, round 6 -- get 128 VGPRs: a row of 10 with its prefix products does not fit 80)
+constexpr int stream_waves_per_eu(int dr, int ring) { return ring == LDPC_RING_VAR ? 3 : ring ? (dr > 8 ? 4 : 6) : dr > 8 ? 2 : dr > 6 ? 3 : 4; }
 template <int METHOD, int MATH, int DR, int DC, int RING>
-__global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__((amdgpu_waves_per_eu(RING == LDPC_RING_VAR ? 3 : RING ? 6 : DR > 8 ? 2 : DR > 6 ? 3 : 4))) bp_decode_kernel(const BpArgs a) {
+__global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__((amdgpu_waves_per_eu(stream_waves_per_eu(DR, RING)))) bp_decode_kernel(const BpArgs a) {
     constexpr int UB = DC <= 4 ? 4 : (DC <= 8 ? 2 : 1);  // bits in flight per wavefront (register variant)
     const int lane = threadIdx.x & (LDPC_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

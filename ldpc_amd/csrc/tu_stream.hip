@@ -39,7 +39,14 @@ static KernelChoice pick_kernel(int max_row, int max_col, int ring_depth, bool v
     // (3,6)-LDPC / bivariate-bicycle rows of 6 and columns of 3 use the LDS-DMA ring variant.
     if (ring_depth == 2 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 2>, 3 * 1024, 2};
     if (ring_depth >= 3 && max_row == 6 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 3>, 3 * 1024, 3};
-    if (ring_depth >= 2 && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
+    // (8,4): min-sum only by default -- product-sum runs 3 % faster on the per-pass kernels from the first iteration (0.605 against 0.587 of HBM at
+    // 512 tiles, profiles/r6_ring_shapes.jsonl); ldpc_hip_bp_set_ring(h, 3) still selects the ring for it
+    if (ring_depth >= (METHOD == LDPC_HIP_PRODUCT_SUM ? 3 : 2) && max_row == 8 && max_col == 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 3>, 4 * 1024, 3};
+    // round 6: (3,4)- and (3,5)-regular codes (rows of 4 / 5 entries, columns of 3), product-sum only: +4 % over the per-pass kernels there,
+    // nothing (3,4) or -2.5 % (3,5) for min-sum against the register variant; a (10,5) ring measured equal (product-sum) and -8 % (min-sum)
+    // and is not built (profiles/r6_ring_shapes.jsonl)
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && ring_depth >= 2 && max_row == 4 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 2>, 3 * 1024, 2};
+    if (METHOD == LDPC_HIP_PRODUCT_SUM && ring_depth >= 2 && max_row == 5 && max_col == 3) return {bp_decode_kernel<METHOD, MATH, 5, 3, 2>, 3 * 1024, 2};
     if (max_row <= 4 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 4, 3, 0>, 0, 0};
     if (max_row <= 6 && max_col <= 3) return {bp_decode_kernel<METHOD, MATH, 6, 3, 0>, 0, 0};
     if (max_row <= 8 && max_col <= 4) return {bp_decode_kernel<METHOD, MATH, 8, 4, 0>, 0, 0, stream_max_waves(8, 0)};

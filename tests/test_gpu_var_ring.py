@@ -148,3 +148,38 @@ def test_real_reference_fixtures_on_every_streamed_path(name):
         assert bits_equal(llr[:k], c["llr"]), (name, tag)
         assert np.array_equal(rowsum(llr), c["llr_rowsum"]), (name, tag)
     eng.close()
+
+
+@pytest.mark.parametrize("dv,dc,p", [(3, 4, 0.15), (3, 5, 0.11), (5, 10, 0.035), (3, 6, 0.06), (4, 8, 0.045)])
+def test_fixed_degree_ring_variants_of_every_regular_shape(dv, dc, p, oracle_built):
+    """The LDS-DMA ring instantiations (csrc/tu_stream.hip: pick_kernel) -- (6,3), (8,4) and, since round 6, (4,3), (5,3)-shaped matrices (rows x columns;
+    a (10,5)-shaped one takes the register variant / per-pass kernels) -- against the register variant of the same persistent kernel, the per-pass kernels and the CPU checker: every row bit for
+    bit, both methods, every hand-off, the two-pass decode, with and without the table of initial values."""
+    from golden_util import bits_equal
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    n = 1200 if dc != 10 else 1500
+    h = codes.regular_ldpc_code(n, dv, dc, seed=6)
+    for meth, alpha, name in ((0, 1.0, "product_sum"), (1, 0.0, "minimum_sum"), (1, 0.8, "minimum_sum")):
+        eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), 24, meth, alpha)
+        eng.set_small_code_kernel(0)
+        s = eng.gen_bsc_syndromes(19, p, shot0=0, shots=21000, device="cuda:0")
+        eng.set_ring(0)
+        eng.set_handoff(0)   # the persistent kernel's register variant for every tile
+        eng.set_repack(0)
+        ref = _decode(eng, s, want_llr=True)
+        assert 0.02 < ref[3].mean() < 0.9995, (dv, dc, ref[3].mean())
+        rows = np.r_[0:60, 20940:21000]
+        want = oracle_built.BpOracle(h, error_rate=p, max_iter=24, bp_method=name, ms_scaling_factor=alpha).decode_batch(s.cpu().numpy()[rows])
+        assert np.array_equal(ref[0][rows], want[0]) and np.array_equal(ref[2][rows], want[2]) and bits_equal(ref[1][rows], want[1])
+        for ring, handoff, repack, switches in ((1, -1, -1, ()), (1, 0, 0, ()), (2, 64, 0, ()), (3, -1, 3, ()), (1, 0, 0, (("EXPLICIT_INIT", 1),)), (0, -1, 0, ())):
+            eng.set_ring(ring)
+            eng.set_handoff(handoff)
+            eng.set_repack(repack)
+            for k, v in switches:
+                eng.set_debug_switch(k, v)
+            for want_llr in (True, False):
+                _same(_decode(eng, s, want_llr=want_llr), ref, f"({dv},{dc}) method {meth} alpha {alpha} ring {ring} handoff {handoff} repack {repack} {switches} llr {want_llr}")
+            for k, _ in switches:
+                eng.set_debug_switch(k, -1)
+        eng.close()
