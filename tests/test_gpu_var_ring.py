@@ -150,7 +150,7 @@ def test_real_reference_fixtures_on_every_streamed_path(name):
     eng.close()
 
 
-@pytest.mark.parametrize("dv,dc,p", [(3, 4, 0.15), (3, 5, 0.11), (5, 10, 0.035), (3, 6, 0.06), (4, 8, 0.045)])
+@pytest.mark.parametrize("dv,dc,p", [(3, 4, 0.15), (3, 5, 0.11), (5, 10, 0.055), (3, 6, 0.07), (4, 8, 0.06)])
 def test_fixed_degree_ring_variants_of_every_regular_shape(dv, dc, p, oracle_built):
     """The LDS-DMA ring instantiations (csrc/tu_stream.hip: pick_kernel) -- (6,3), (8,4) and, since round 6, (4,3), (5,3)-shaped matrices (rows x columns;
     a (10,5)-shaped one takes the register variant / per-pass kernels) -- against the register variant of the same persistent kernel, the per-pass kernels and the CPU checker: every row bit for
@@ -168,7 +168,7 @@ def test_fixed_degree_ring_variants_of_every_regular_shape(dv, dc, p, oracle_bui
         eng.set_handoff(0)   # the persistent kernel's register variant for every tile
         eng.set_repack(0)
         ref = _decode(eng, s, want_llr=True)
-        assert 0.02 < ref[3].mean() < 0.9995, (dv, dc, ref[3].mean())
+        assert 0.01 < ref[3].mean() < 0.9999, (dv, dc, ref[3].mean())
         rows = np.r_[0:60, 20940:21000]
         want = oracle_built.BpOracle(h, error_rate=p, max_iter=24, bp_method=name, ms_scaling_factor=alpha).decode_batch(s.cpu().numpy()[rows])
         assert np.array_equal(ref[0][rows], want[0]) and np.array_equal(ref[2][rows], want[2]) and bits_equal(ref[1][rows], want[1])
