@@ -50,6 +50,7 @@ struct SerialArgs {
     // ([l * wavefronts + w], one more entry at the end), 1 KiB units of a wavefront's LDS queue
     const int32_t *var_items, *var_wq;
     int32_t var_units;
+    const double *var_init;  // [nnz][64] initial segments shared by all tiles (the first iteration fetches what nobody has written yet from here), or nullptr
 };
 
 // One bit update of the serial schedule (bp.hpp:485-535) for the 64 syndromes of a tile: for every incident check the

@@ -23,15 +23,36 @@
 //   * per lane and iteration the traffic is what the schedule itself needs: every entry is read once by each OTHER bit of its row and
 //     written once.
 //
-// Same operations on the same operands in the same order as bp_serial_kernel's walk: the same bits.  The first iteration's messages are
-// written out (no table of initial values here).  Orders that are no permutation work as there: levels and items belong to positions.
+// Same operations on the same operands in the same order as bp_serial_kernel's walk: the same bits.  Orders that are no permutation work
+// as there: levels and items belong to positions.
+//   * The first iteration needs no initial messages in the tile's array: an entry no earlier position of the schedule has written still
+//     holds its initial value tanh(llr0 / 2) | llr0, the same in all 64 lanes and in every tile -- the record carries a mask of the
+//     entries already written ([6]), and the others are fetched from ONE array of initial segments shared by all tiles
+//     (SerialArgs::var_init, [nnz][64]: 20 MB on the n = 10 000 codes, served by L2 / the Infinity Cache, not by HBM): in that
+//     iteration the DMAs are `global_load_lds_dwordx4` with a 64-bit address per lane (either array), the array is neither written
+//     beforehand (1 / sum-d^2-th of an iteration per tile) nor read from HBM for what nobody has written (about half of the first
+//     iteration's reads).  Only when the order visits every bit (else the messages are written out as before).
 //
 // Item record, int32[8], 32-byte aligned:
 //   [0] the bit's own edge in this row        [1] first edge of the row        [2] d | k_own << 8 | k << 16 | dj << 24
 //         (d = entries of the row, k_own = which of them is the bit's, k = which of the bit's dj checks this is, rows ascending)
-//   [3] the bit                               [4] the check                    [5 .. 7] 0
+//   [3] the bit                               [4] the check                    [5] 0 (the lane kernel's list: 1 = a real item)
+//   [6] mask: bit t set = the row's t-th OTHER entry has been written by an earlier position of the schedule (first iteration)       [7] 0
 constexpr int SERIAL_VAR_REC = 8;
 typedef int ldpc_v8i_rec __attribute__((ext_vector_type(8)));
+
+// one DMA instruction with a 64-bit address per lane: 16 bytes per lane to LDS at lds_addr + 16 * lane (lds_dma16's twin for two arrays)
+__device__ __forceinline__ void lds_dma16_flat(unsigned long long vaddr, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vaddr), "s"(lds_addr) : "memory");
+}
+// [nnz][64] what an edge holds before the first iteration, in all 64 lanes: tanh(llr0[column] / 2) | llr0[column]
+template <int METHOD, int MATH>
+__global__ void __launch_bounds__(256) serial_var_init_kernel(const double *__restrict__ llr0, const int32_t *__restrict__ col_idx, int nnz, double *__restrict__ out) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e < nnz) out[(size_t)e * 64 + lane] = edge_form<METHOD, MATH>(llr0[col_idx[e]]);
+}
 
 template <int METHOD, int MATH, int DRMAX, int DCMAX>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) bp_serial_stream_var_kernel(const SerialArgs a) {
@@ -72,15 +93,20 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (was) my_iter = a.iters[b];
         done |= __ballot(was);
     }
-    if (a.it_start == 0)  // initialise_log_domain_bp (bp.hpp:147-157)
+    const bool implicit_init = a.var_init != nullptr && a.it_start == 0;
+    if (a.it_start == 0 && !implicit_init)  // initialise_log_domain_bp (bp.hpp:147-157)
         for (int e = wave; e < nnz; e += nwaves) At.st(l8, e, edge_form<METHOD, MATH>(sload(a.llr0 + sload(a.col_idx + e))));
     __syncthreads();
     const ldpc_v8i_rec *items = reinterpret_cast<const ldpc_v8i_rec *>(a.var_items);
+    const unsigned long long tile_base = (unsigned long long)(uintptr_t)(a.A + (size_t)tile * (size_t)nnz * LDPC_WAVE);
+    const unsigned long long init_base = (unsigned long long)(uintptr_t)a.var_init;
 
     for (int it = a.it_start + 1; it <= a.max_iter; ++it) {
         const double alpha = (a.ms_scaling_factor == 0.0) ? 1.0 - ldexp(1.0, -it) : a.ms_scaling_factor;
         const bool lane_live = !((done >> lane) & 1ull);
-        for (int l = 0; l < a.n_levels; ++l) {
+        // One level: this wavefront's stream of items.  FRESH = the first iteration of an implicitly initialised decode.
+        auto run_level = [&](auto fresh_tag, const int l) {
+            constexpr bool FRESH = decltype(fresh_tag)::value;
             const int q0 = sload(a.var_wq + l * nwaves + wave), q1 = sload(a.var_wq + l * nwaves + wave + 1);
             const int nitems = q1 - q0;
             int head = 0;
@@ -98,15 +124,23 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
                 const int d = s.r[2] & 255, kown = (s.r[2] >> 8) & 255, rs = s.r[1];
                 const int units = d >> 1;  // ceil((d - 1) / 2)
                 s.pos = head;
+                const unsigned written = FRESH ? (unsigned)s.r[6] : ~0u;
 #pragma unroll
                 for (int c = 0; c < NDMAX; ++c)
                     if (c < units) {
                         const int t0 = 2 * c, t1 = 2 * c + 1;
-                        const unsigned ea = (unsigned)(rs + t0 + (t0 >= kown ? 1 : 0)) << 9;
-                        const unsigned eb = t1 < d - 1 ? (unsigned)(rs + t1 + (t1 >= kown ? 1 : 0)) << 9 : beyond;
                         int u = head + c;
                         if (u >= U) u -= U;
-                        lds_dma16(At.rsrc, (upper ? eb : ea) + l16, 0u, ring_addr + (unsigned)u * 1024u);
+                        if (FRESH) {  // either array, a 64-bit address per lane (an odd last half fetches the first initial segment: valid memory, never read)
+                            const unsigned long long a0 = (((written >> t0) & 1u) ? tile_base : init_base) + ((unsigned long long)(unsigned)(rs + t0 + (t0 >= kown ? 1 : 0)) << 9);
+                            const unsigned long long a1 = t1 < d - 1 ? (((written >> t1) & 1u) ? tile_base : init_base) + ((unsigned long long)(unsigned)(rs + t1 + (t1 >= kown ? 1 : 0)) << 9)
+                                                                     : init_base;
+                            lds_dma16_flat((upper ? a1 : a0) + l16, ring_addr + (unsigned)u * 1024u);
+                        } else {
+                            const unsigned ea = (unsigned)(rs + t0 + (t0 >= kown ? 1 : 0)) << 9;
+                            const unsigned eb = t1 < d - 1 ? (unsigned)(rs + t1 + (t1 >= kown ? 1 : 0)) << 9 : beyond;
+                            lds_dma16(At.rsrc, (upper ? eb : ea) + l16, 0u, ring_addr + (unsigned)u * 1024u);
+                        }
                     }
                 head += units;
                 if (head >= U) head -= U;
@@ -204,6 +238,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
                 if (ahead > 0) --ahead;
             }
             wait_vmcnt<0>();
+        };
+        const bool fresh = implicit_init && it == 1;
+        for (int l = 0; l < a.n_levels; ++l) {
+            if (fresh) run_level(std::true_type{}, l);
+            else run_level(std::false_type{}, l);
             __syncthreads();  // the next level reads what this one wrote
         }
         // candidate syndrome of this iteration's hard decision vs the syndrome bytes (bp.hpp:537-543)

@@ -206,6 +206,7 @@ struct ldpc_hip_bp {
     DeviceBuf ser_rows[2], ser_synd2;                                // decode_serial_streamed: the rows of a compacted pass (numbers in the caller's arrays), their syndromes
     DeviceBuf ser_pos_tab;                                           // bp_serial_stream_kernel: one record per position of the level-major order
     bool ser_pos_valid = false;                                     // ... describing the current levels
+    DeviceBuf ser_var_init;                                         // ... [nnz][64] initial segments shared by all tiles (SerialArgs::var_init), rewritten by every decode that uses it
     DeviceBuf ser_var_items, ser_var_wq, ser_var_lane_items, ser_var_lane_lvl;  // bp_serial_var_kernel.h: item streams per (level, wavefront); the level-major item list of the lane kernel
     bool ser_var_valid = false;                                     // ... describing the current levels, for ser_var_waves wavefronts per tile
     int ser_var_waves = 0;

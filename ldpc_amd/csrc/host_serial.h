@@ -95,10 +95,30 @@ static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
                 row_of[(size_t)e] = i;
             }
     }
-    auto record = [&](int32_t *r, int j, int k, bool lane_form) {
+    // which entries an earlier position of the schedule has written, per item of every position (first iteration; the positions of one level
+    // share no row, so "earlier" is "in an earlier level" and the dealing below changes nothing): mask over the row's OTHER entries
+    std::vector<int32_t> pos_item0((size_t)n + 1, 0);
+    for (int p = 0; p < n; ++p) { const int j = h->h_lvl_bits[(size_t)p]; pos_item0[(size_t)p + 1] = pos_item0[(size_t)p] + (col_ptr[(size_t)j + 1] - col_ptr[(size_t)j]); }
+    std::vector<int32_t> item_mask((size_t)pos_item0[(size_t)n] + 1, 0);
+    {
+        std::vector<char> written((size_t)(h->nnz ? h->nnz : 1), 0);
+        for (int p = 0; p < n; ++p) {
+            const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
+            for (int k = 0; k < dj; ++k) {
+                const int e = col_edge[(size_t)col_ptr[(size_t)j] + k], i = row_of[(size_t)e], rs = h->h_row_ptr[(size_t)i], d = h->h_row_ptr[(size_t)i + 1] - rs;
+                int32_t mask = 0;
+                for (int t = 0; t < d - 1; ++t) if (written[(size_t)(rs + t + (t >= e - rs ? 1 : 0))]) mask |= 1 << t;
+                item_mask[(size_t)pos_item0[(size_t)p] + k] = mask;
+            }
+            for (int k = 0; k < dj; ++k) written[(size_t)col_edge[(size_t)col_ptr[(size_t)j] + k]] = 1;
+        }
+    }
+    auto record = [&](int32_t *r, int p, int k, bool lane_form) {
+        const int j = h->h_lvl_bits[(size_t)p];
         const int e = col_edge[(size_t)col_ptr[(size_t)j] + k], i = row_of[(size_t)e], rs = h->h_row_ptr[(size_t)i], d = h->h_row_ptr[(size_t)i + 1] - rs;
         const int dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
-        r[0] = e; r[1] = rs; r[2] = d | ((e - rs) << 8) | (k << 16) | (dj << 24); r[3] = j; r[4] = i; r[5] = lane_form ? 1 : 0; r[6] = r[7] = 0;
+        r[0] = e; r[1] = rs; r[2] = d | ((e - rs) << 8) | (k << 16) | (dj << 24); r[3] = j; r[4] = i; r[5] = lane_form ? 1 : 0;
+        r[6] = item_mask[(size_t)pos_item0[(size_t)p] + k]; r[7] = 0;
     };
     std::vector<int32_t> items, wq((size_t)L * (size_t)waves + 1, 0), lane_items, lane_lvl((size_t)L + 1, 0);
     items.reserve((size_t)h->nnz * SERIAL_VAR_REC);
@@ -135,7 +155,7 @@ static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
                     const int j = h->h_lvl_bits[(size_t)p], dj = col_ptr[(size_t)j + 1] - col_ptr[(size_t)j];
                     for (int k = 0; k < dj; ++k) {
                         items.resize(items.size() + SERIAL_VAR_REC);
-                        record(items.data() + items.size() - SERIAL_VAR_REC, j, k, false);
+                        record(items.data() + items.size() - SERIAL_VAR_REC, p, k, false);
                     }
                 }
             }
@@ -147,7 +167,7 @@ static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
             if (at % 64 + (size_t)dj > 64) lane_items.resize((at + 63) / 64 * 64 * SERIAL_VAR_REC, 0);  // padding: the position starts a new wavefront
             for (int k = 0; k < dj; ++k) {
                 lane_items.resize(lane_items.size() + SERIAL_VAR_REC);
-                record(lane_items.data() + lane_items.size() - SERIAL_VAR_REC, j, k, true);
+                record(lane_items.data() + lane_items.size() - SERIAL_VAR_REC, p, k, true);
             }
         }
         lane_items.resize((lane_items.size() / SERIAL_VAR_REC + 63) / 64 * 64 * SERIAL_VAR_REC, 0);  // a level ends on a wavefront boundary
@@ -164,6 +184,22 @@ static int ensure_serial_var_tables(ldpc_hip_bp *h, int waves) {
     HIPCHK(hipMemcpy(h->ser_var_lane_lvl.p, lane_lvl.data(), lane_lvl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     h->ser_var_valid = true;
     h->ser_var_waves = waves;
+    return LDPC_HIP_OK;
+}
+
+// the array of initial segments of the item form (bp_serial_var_kernel.h), from the current priors; nullptr in *out where the first iteration
+// must find its messages written out (an order that skips bits, or EXPLICIT_INIT)
+static int serial_var_init_segments(ldpc_hip_bp *h, const double **out) {
+    *out = nullptr;
+    if (!h->order_visits_all || h->on("EXPLICIT_INIT") || h->nnz <= 0) return LDPC_HIP_OK;
+    int rc;
+    if ((rc = h->ser_var_init.ensure(sizeof(double) * (size_t)h->nnz * LDPC_WAVE))) return rc;
+    const dim3 g((unsigned)((h->nnz + 3) / 4));
+    if (h->bp_method == LDPC_HIP_MINIMUM_SUM) hipLaunchKernelGGL((serial_var_init_kernel<LDPC_HIP_MINIMUM_SUM, 0>), g, dim3(256), 0, h->stream, h->d_llr0, h->d_col_idx, h->nnz, (double *)h->ser_var_init.p);
+    else if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((serial_var_init_kernel<LDPC_HIP_PRODUCT_SUM, 1>), g, dim3(256), 0, h->stream, h->d_llr0, h->d_col_idx, h->nnz, (double *)h->ser_var_init.p);
+    else hipLaunchKernelGGL((serial_var_init_kernel<LDPC_HIP_PRODUCT_SUM, 0>), g, dim3(256), 0, h->stream, h->d_llr0, h->d_col_idx, h->nnz, (double *)h->ser_var_init.p);
+    HIPCHK(hipGetLastError());
+    *out = (const double *)h->ser_var_init.p;
     return LDPC_HIP_OK;
 }
 
@@ -358,6 +394,7 @@ static int decode_serial_pass(ldpc_hip_bp *h, int max_iter, const uint8_t *synd,
         if (sp.var) {
             a.var_items = (const int32_t *)h->ser_var_items.p; a.var_wq = (const int32_t *)h->ser_var_wq.p; a.var_units = var_units;
             a.clk = h->d_clk;
+            if ((rc = serial_var_init_segments(h, &a.var_init))) return rc;
             const size_t dyn = (size_t)ser_waves * (size_t)var_units * 1024u;
             if (dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3((unsigned)(64 * ser_waves)), (unsigned)dyn, st, a);
@@ -878,6 +915,7 @@ static int serial_stream_launch(ldpc_hip_bp *h, const SerialStreamPlan &sp, int 
     a.resume = resume ? 1 : 0;
     if (sp.var) {
         a.var_items = (const int32_t *)h->ser_var_items.p; a.var_wq = (const int32_t *)h->ser_var_wq.p; a.var_units = var_units;
+        if (it_start == 0 && (rc = serial_var_init_segments(h, &a.var_init))) return rc;
     } else if (it_start == 0 && h->order_visits_all && !h->on("EXPLICIT_INIT")) {  // the first iteration reads these tables instead of initial messages
         a.edge0 = (const double *)h->d_edge0.p;
         a.pos_e0 = (const double *)h->ser_pos_e0.p;
