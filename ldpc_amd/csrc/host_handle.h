@@ -59,7 +59,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE", "REPACK2"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -96,6 +96,8 @@ struct ldpc_hip_bp {
     int64_t cont_alive[4] = {-1, -1, -1, -1}, cont_alive_total = 0;  // ... still running after the first pass + 0 .. 3 iterations, of how many
     int64_t cont_late_rows = -1;                  // rows the steering histogram expects to be still running 8 iterations into it (-1: unknown)
     int64_t cont_grid_tiles = 0;                  // grid.y of its tile-looping kernels (an estimate; they loop)
+    const int32_t *cont_src_map = nullptr;        // where its rows sit in the tiles the state is gathered from (nullptr: cont_row_map -- tiles of the caller's rows)
+    bool cont_extend = false;                     // a THIRD pass (second compaction): its kernels extend the second pass's timed interval
     bool keep_state = false;       // this decode_device call is a first pass: its last bit pass must leave the messages behind
     int64_t last_chunk_tiles = 0;  // tiles per chunk of the last streamed decode (== its tile count: the whole batch's state is resident)
     int edge_rounds = 0;     // rounds the uploaded slot tables of bp_edge_kernel were built for (0: none)
@@ -120,6 +122,7 @@ struct ldpc_hip_bp {
     DeviceBuf sched_lvl_bits, sched_lvl_ptr;      // the random schedule's orders once more, level-major, and their level bounds (host_serial.h: random_orders_*)
     DeviceBuf rl_edge, rl_chk, rl_cdeg, rl_last;  // per-column tables and the last row's final order of bp_relative_lds_kernel
     int rl_dc = 0;                                // stride the tables were built for (0: none)
+    DeviceBuf flood_src;                          // decode_stream_repacked's second compaction: positions of the third pass's rows in the second pass's tiles
     DeviceBuf rl_first;                           // the order after the first iteration's sort of the current call (RelLdsArgs::first_order)
     DeviceBuf rl_rec, rl_ext_A;                   // EXT form: the per-entry records [n][dc] u64; the wavefronts' message slots [workgroups][wavefronts][nnz] f64
     bool rl_rec_valid = false;

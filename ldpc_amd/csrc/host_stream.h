@@ -125,10 +125,12 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
     const bool per_pass_first = h->handoff < 0 && h->bp_method == LDPC_HIP_PRODUCT_SUM && kern.ring_depth == 0 && !kern.var_ring &&
                                 h->max_row_deg <= 16 && h->max_col_deg <= 8 && h->max_iter <= 128;
     const int handoff = h->handoff < 0 ? (per_pass_first ? INT32_MAX : 256) : h->handoff;
-    h->accumulated_ms = 0.f;
-    h->accumulated_persistent_ms = 0.f;
-    h->timed = false;
-    h->timed_mid = false;
+    if (!h->cont_extend) {
+        h->accumulated_ms = 0.f;
+        h->accumulated_persistent_ms = 0.f;
+        h->timed = false;
+        h->timed_mid = false;
+    }
     hipStream_t st = h->stream;
     // second pass of a compacted decode: its rows are known to the device only -- `batch` is the most there can be, the kernels read the
     // real count (cont_rows_dev) and reach the caller's rows through cont_row_map; the grids of the tile-looping kernels follow an estimate
@@ -195,7 +197,7 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
         const size_t dyn_lds = lds_per_wave * (size_t)waves;
         if (dyn_lds > 48u * 1024u)
             HIPCHK(hipFuncSetAttribute((const void *)kern.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-        if (h->timed) {  // fold the previous chunk's time before the events are re-recorded
+        if (h->timed && !h->cont_extend) {  // fold the previous chunk's time before the events are re-recorded
             float prev = 0.f;
             HIPCHK(hipEventSynchronize(h->ev1));
             HIPCHK(hipEventElapsedTime(&prev, h->ev0, h->ev1));
@@ -205,13 +207,15 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
                 h->accumulated_persistent_ms += prev;
             }
         }
-        h->timed_mid = false;
-        HIPCHK(hipEventRecord(h->ev0, st));
+        if (!h->cont_extend) {  // (a third pass: the second pass's interval goes on -- its ev0 and ev_mid stay, ev1 is recorded again at the end)
+            h->timed_mid = false;
+            HIPCHK(hipEventRecord(h->ev0, st));
+        }
         if (h->cont_A) {
             // the listed rows' message state after the first pass, lane by lane, into dense tiles (inside this pass's timed region)
             const int epw = 16;
             const dim3 gg((unsigned)((h->nnz + 4 * epw - 1) / (4 * epw)), loop_tiles);
-            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)h->cont_C, row_map, (int64_t)0, h->nnz, epw, h->cont_A, rows_dev);
+            hipLaunchKernelGGL(gather_lane_state_kernel, gg, dim3(256), 0, st, (const double *)h->cont_C, h->cont_src_map ? h->cont_src_map : row_map, (int64_t)0, h->nnz, epw, h->cont_A, rows_dev);
             HIPCHK(hipGetLastError());
         }
         SpreadArgs sa = {};
@@ -250,8 +254,10 @@ int decode_device(ldpc_hip_bp *h, const uint8_t *synd, int64_t batch, uint8_t *d
             }
             hipLaunchKernelGGL(kern.fn, dim3((unsigned)tiles), dim3((unsigned)(waves * LDPC_WAVE)), (unsigned)dyn_lds, st, a);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(h->ev_mid, st));
-            h->timed_mid = true;
+            if (!h->cont_extend) {
+                HIPCHK(hipEventRecord(h->ev_mid, st));
+                h->timed_mid = true;
+            }
             if (handoff > 0 && h->max_iter > 1) {
                 // the persistent kernel parks at most `handoff` tiles (it starts parking when that many are unfinished);
                 // how many it did park stays on the device
@@ -447,6 +453,13 @@ __global__ void __launch_bounds__(256) row_positions_kernel(const int32_t *__res
     if (r < (int64_t)count_dev[0]) pos[list[r]] = (int32_t)r;
 }
 
+// out[i] = pos[list[i]] for the listed rows
+__global__ void __launch_bounds__(256) compose_positions_kernel(const int32_t *__restrict__ list, const unsigned *__restrict__ count_dev, const int32_t *__restrict__ pos,
+                                                                int32_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < (int64_t)count_dev[0]) out[r] = pos[list[r]];
+}
+
 // Nothing here waits for the device: the second pass is queued at once, sized for the most rows there can be (all of them), and
 // finds out on the device how many rows the first pass left -- osd_collect_kernel lists them, repack_rows_kernel turns the count
 // into rows / tiles, every kernel of the second pass reads those (BpArgs::rows_dev) and reaches the caller's arrays through the
@@ -556,6 +569,22 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
         if ((rc = launch_lanes(k1, (const double *)h->msgA.p, nullptr, (const int32_t *)h->osd_list.p, (const unsigned *)h->osd_counters.p, true))) return rc;
         return stream_leave_histogram(h, iters, conv, batch);
     }
+    // A SECOND COMPACTION (round 6).  Where the histogram says that a few iterations into the second pass most of ITS rows are done too -- the
+    // headline code at p = 0.05: 17 % of the batch go on after iteration 7, 1.9 % after iteration 8 -- the rows that are left sit in every one of
+    // the second pass's tiles, which keep moving 64 lanes' messages for them.  So the second pass stops after k2 iterations (keeping its
+    // messages), the rows still decoding are listed again, their lane state is gathered once more -- out of the second pass's tiles, into the
+    // array that was its check_to_bit scratch -- and a third pass finishes them in a tenth of the tiles.  Same machinery, same bits, still
+    // nothing waits for the device.  k2: the smallest number of iterations after which at most a fifth of the second pass's rows, but more
+    // than the late rounds' list compaction is for, are expected to be left; "REPACK2" 0 = never, 1 .. 3 = always after that many.
+    int k2 = 0;
+    if (lane_after < 0 && h->sw("REPACK2") != 0) {
+        if (h->sw("REPACK2") > 0) k2 = h->sw("REPACK2") <= 3 ? h->sw("REPACK2") : 3;
+        else if (h->cont_alive[0] > 0)
+            for (int R = 1; R <= 3 && !k2; ++R)
+                if (h->cont_alive[R] >= 0 && h->cont_alive[R] * 5 <= h->cont_alive[0] && h->cont_alive[R] * (double)batch / (double)(h->cont_alive_total > 0 ? h->cont_alive_total : 1) > 256.0) k2 = R;
+        if (k1 + k2 + 2 > full) k2 = 0;  // (nothing worth a gather is left to do)
+    }
+    const int64_t alive2 = k2 > 0 && h->cont_alive[k2] >= 0 && h->cont_alive_total > 0 ? (int64_t)((double)h->cont_alive[k2] * (double)batch / (double)h->cont_alive_total) : -1;
     h->cont_A = (double *)h->msgC.p;   // compacted bit_to_check state (gathered inside decode_device)
     h->cont_C = (double *)h->msgA.p;   // the gather's source, then the second pass's check_to_bit array
     h->cont_it_start = k1;
@@ -564,6 +593,7 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     // grids of the tile-looping kernels: the rows the histogram expects + a margin (they loop, so any count is handled)
     h->cont_grid_tiles = (int64_t)(live * 1.25 * (double)tiles1) + 8;
     if (lane_after > 0) { h->max_iter = k1 + lane_after; h->keep_state = true; }  // (lanes follow: these rounds leave their messages behind)
+    else if (k2 > 0) { h->max_iter = k1 + k2; h->keep_state = true; }             // (a third pass follows)
     rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
     h->keep_state = false;
     h->max_iter = full;
@@ -572,6 +602,36 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     h->cont_row_map = nullptr;
     h->cont_rows_dev = nullptr;
     if (rc) return rc;
+    if (k2 > 0 && lane_after <= 0) {
+        // what the second pass left: the rows of the whole batch whose flag is still down (only its rows can be), where each sat in its tiles,
+        // {rows, tiles} of the third pass on the device
+        if ((rc = h->flood_list2.ensure(B * sizeof(int32_t))) || (rc = h->flood_pos.ensure(B * sizeof(int32_t))) || (rc = h->flood_src.ensure(B * sizeof(int32_t)))) return rc;
+        unsigned *count2 = (unsigned *)h->osd_counters.p + 4;
+        HIPCHK(hipMemsetAsync(count2, 0, 4 * sizeof(unsigned), h->stream));
+        const dim3 gb((unsigned)((batch + 255) / 256));
+        hipLaunchKernelGGL(osd_collect_kernel, gb, dim3(256), 0, h->stream, conv, batch, (int32_t *)h->flood_list2.p, count2);
+        hipLaunchKernelGGL(row_positions_kernel, gb, dim3(256), 0, h->stream, (const int32_t *)h->osd_list.p, (const unsigned *)h->osd_counters.p, (int32_t *)h->flood_pos.p);
+        hipLaunchKernelGGL(compose_positions_kernel, gb, dim3(256), 0, h->stream, (const int32_t *)h->flood_list2.p, (const unsigned *)count2, (const int32_t *)h->flood_pos.p,
+                           (int32_t *)h->flood_src.p);
+        hipLaunchKernelGGL(repack_rows_kernel, dim3(1), dim3(1), 0, h->stream, (const unsigned *)count2, count2 + 2);
+        HIPCHK(hipGetLastError());
+        h->cont_A = (double *)h->msgA.p;   // gathered out of the second pass's bit_to_check array ...
+        h->cont_C = (double *)h->msgC.p;   // ... which then serves as the third pass's check_to_bit array
+        h->cont_it_start = k1 + k2;
+        h->cont_row_map = (const int32_t *)h->flood_list2.p;
+        h->cont_src_map = (const int32_t *)h->flood_src.p;
+        h->cont_rows_dev = (const unsigned *)count2 + 2;
+        h->cont_grid_tiles = (alive2 >= 0 ? (int64_t)((double)alive2 * 1.5 / LDPC_WAVE) : tiles1 / 8) + 8;
+        h->cont_late_rows = -1;
+        h->cont_extend = true;
+        rc = decode_device(h, synd, batch, decoding, llr, iters, conv, false);
+        h->cont_extend = false;
+        h->cont_A = h->cont_C = nullptr;
+        h->cont_it_start = 0;
+        h->cont_row_map = h->cont_src_map = nullptr;
+        h->cont_rows_dev = nullptr;
+        if (rc) return rc;
+    }
     if (lane_after > 0) {
         // what those rounds left: the rows of the whole batch whose flag is still down (only rows of the second pass can be), where each sat in
         // the second pass's tiles (the inverse of its row list), and the lane kernel on them from the second pass's bit->check array
