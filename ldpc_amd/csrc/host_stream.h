@@ -574,11 +574,14 @@ static int decode_stream_repacked(ldpc_hip_bp *h, const uint8_t *synd, int64_t b
     // the second pass's tiles, which keep moving 64 lanes' messages for them.  So the second pass stops after k2 iterations (keeping its
     // messages), the rows still decoding are listed again, their lane state is gathered once more -- out of the second pass's tiles, into the
     // array that was its check_to_bit scratch -- and a third pass finishes them in a tenth of the tiles.  Same machinery, same bits, still
-    // nothing waits for the device.  k2: the smallest number of iterations after which at most a fifth of the second pass's rows, but more
-    // than the late rounds' list compaction is for, are expected to be left; "REPACK2" 0 = never, 1 .. 3 = always after that many.
+    // nothing waits for the device.  MEASURED (profiles/r6_second_compaction_ab.txt, same box, interleaved): 111.5 - 113.4 ms with it against
+    // 112.0 - 112.5 ms without on the headline code at p = 0.05, 146.5 - 148.0 against 146.1 - 146.7 on the irregular code at p = 0.06 -- the gather
+    // and the extra launches cost what the thinner rounds save -- so it is NOT chosen by default: "REPACK2" 1 .. 3 = always, after that many
+    // iterations of the second pass; 4 = where the histogram expects at most a fifth of the second pass's rows (but more than the late rounds'
+    // list compaction is for) to be left after 1 .. 3 iterations.  The tests keep the path honest: it gives the plain decode's bits.
     int k2 = 0;
-    if (lane_after < 0 && h->sw("REPACK2") != 0) {
-        if (h->sw("REPACK2") > 0) k2 = h->sw("REPACK2") <= 3 ? h->sw("REPACK2") : 3;
+    if (lane_after < 0 && h->sw("REPACK2") > 0) {
+        if (h->sw("REPACK2") <= 3) k2 = h->sw("REPACK2");
         else if (h->cont_alive[0] > 0)
             for (int R = 1; R <= 3 && !k2; ++R)
                 if (h->cont_alive[R] >= 0 && h->cont_alive[R] * 5 <= h->cont_alive[0] && h->cont_alive[R] * (double)batch / (double)(h->cont_alive_total > 0 ? h->cont_alive_total : 1) > 256.0) k2 = R;

@@ -34,7 +34,7 @@ def test_second_compaction_gives_the_plain_decodes_bits(code, method, alpha, p, 
     assert np.array_equal(ref[0][rows], want[0]) and np.array_equal(ref[2][rows], want[2]) and np.array_equal(ref[3][rows].astype(bool), want[3].astype(bool))
     assert bits_equal(ref[1][rows], want[1])
     for k1 in (2, 3, 5):
-        for k2 in (0, 1, 2, 3, -1):
+        for k2 in (0, 1, 2, 3, 4):
             eng.set_repack(k1)
             eng.set_debug_switch("REPACK2", k2)
             for want_llr in (True, False):
@@ -44,7 +44,7 @@ def test_second_compaction_gives_the_plain_decodes_bits(code, method, alpha, p, 
                 assert got[1] is None if not want_llr else bits_equal(got[1], ref[1]), tag
     # steered by the histogram of the previous decode (repack -1): whatever it chooses, the same bits
     eng.set_repack(-1)
-    eng.set_debug_switch("REPACK2", -1)
+    eng.set_debug_switch("REPACK2", 4)
     for _ in range(3):
         got = _decode(eng, s, want_llr=True)
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]) and bits_equal(got[1], ref[1])
