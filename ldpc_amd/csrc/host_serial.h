@@ -646,6 +646,7 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     const size_t per_wave_f = (size_t)Gf * per_syn + scratch;
     int waves = (int)((lds - shared) / per_wave_f);
     if (waves > 16) waves = 16;
+    if (ext && waves > 8) waves = 8;  // (the EXT instantiations are compiled for workgroups of at most 8 wavefronts: 256 VGPRs, no spills)
     // several workgroups per compute unit where the state is small: each pays for its own copy of the shared tables
     int groups_per_cu = 1;
     while (waves * (groups_per_cu + 1) <= 24 && (size_t)(groups_per_cu + 1) * (shared + (size_t)waves * per_wave_f) <= lds) ++groups_per_cu;
