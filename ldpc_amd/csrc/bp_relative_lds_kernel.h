@@ -677,9 +677,12 @@ __device__ __forceinline__ double group_lane(double x, int p, int lane) {  // th
 
 // GS: lanes of a syndrome (64: one per wavefront; 16: four per wavefront).  DRT: bound of the row loop (heaviest row <= DRT).  DCT: bound of
 // the per-lane column arrays of the level-parallel sweep (heaviest column <= DCT; GS = 64 only).
+#ifndef LDPC_REL_LB
+#define LDPC_REL_LB 1024
+#endif
 // (EXT: at most 8 wavefronts per workgroup -- the codes it is for leave room for 3 to 8 -- so the compiler may use 256 VGPRs: no spills)
 template <int METHOD, int MATH, int DRT, int GS, int DCT, int EXT = 0>
-__global__ void __launch_bounds__(EXT ? 512 : 1024) bp_relative_lds_kernel(const RelLdsArgs a) {
+__global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kernel(const RelLdsArgs a) {
     using namespace rel_lds;
     constexpr int G = 64 / GS;
     static_assert(!EXT || GS == 64, "state in global memory: a wavefront per syndrome");
