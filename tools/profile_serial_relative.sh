@@ -12,6 +12,8 @@ from ldpc_amd.engine import HipBpEngine
 which = sys.argv[1]
 if which == "surface":
     h, p, it, meth, alpha = codes.rotated_surface_code_x(21), 0.05, 30, 1, 0.625
+elif which == "hgp":  # state beyond LDS: the EXT form (round 6)
+    h, p, it, meth, alpha = codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)), 0.02, 30, 1, 0.625
 else:
     h, p, it, meth, alpha = codes.bivariate_bicycle_hx(), 0.05, 50, 0, 1.0
 eng = HipBpEngine(h.indptr, h.indices, h.shape[1], np.full(h.shape[1], p), it, meth, alpha)
@@ -22,7 +24,7 @@ out = eng.decode_batch(s)
 out = eng.decode_batch(s)
 print(which, "kernel ms", eng.last_kernel_ms(), "mean it", float(out[2].float().mean()))
 PY
-for which in surface bb; do
+for which in ${REL_WHICH:-surface bb hgp}; do
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -35,7 +37,7 @@ python - "$OUT" > "$OUT/summary.txt" <<'PY'
 import glob, os, sqlite3, sys
 out = sys.argv[1]
 allres = {}
-for which in ("surface", "bb"):
+for which in ("surface", "bb", "hgp"):
     res = {}
     for p in sorted(glob.glob(os.path.join(out, which + "*", "**", "*.db"), recursive=True)):
         cur = sqlite3.connect(p).cursor()
@@ -57,11 +59,11 @@ except Exception:
     tag = None
 its = {}
 for line in open(os.path.join(out, "log.txt")):
-    mm = re.match(r"(surface|bb) kernel ms [0-9.]+ mean it ([0-9.]+)", line)
+    mm = re.match(r"(surface|bb|hgp) kernel ms [0-9.]+ mean it ([0-9.]+)", line)
     if mm:
         its[mm.group(1)] = float(mm.group(2))
-doc = {"source": "tools/profile_serial_relative.sh: rocprofv3 --pmc over bp_relative_lds_kernel, 16 384 syndromes, p = 0.05", "kernel_sources_sha16": tag}
-for which, key in (("surface", "f1_rel_surface"), ("bb", "f1_rel_bb144")):
+doc = {"source": "tools/profile_serial_relative.sh: rocprofv3 --pmc over bp_relative_lds_kernel, 16 384 syndromes, p = 0.05 (hgp1600: 0.02)", "kernel_sources_sha16": tag}
+for which, key in (("surface", "f1_rel_surface"), ("bb", "f1_rel_bb144"), ("hgp", "f1_rel_hgp1600")):
     r = allres.get(which, {})
     if which in its and "SQ_INSTS_VALU" in r and "GRBM_GUI_ACTIVE" in r:
         si = 16384.0 * its[which]
