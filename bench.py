@@ -323,10 +323,10 @@ def schedule_configs(dev, steps):
              h=codes.rotated_surface_code_x(21), p=0.05, max_iter=30, method=1, alpha=0.625),
         dict(key="f1_rel_bb144", name="serial_relative: BB [[144,12,12]] hx (72 x 144), product_sum max_iter=50, batch=65536, BSC p=0.05",
              h=codes.bivariate_bicycle_hx(), p=0.05, max_iter=50, method=0, alpha=1.0),
-        # state beyond LDS (61 KB a syndrome + 93 KB of tables): messages and per-entry records in global memory, three wavefronts per compute
-        # unit (bp_relative_lds_kernel<..., EXT = 1>, round 6; the per-lane kernel that ran before: 7.0 k syndromes/s, profiles/r6_serial_relative_hgp1600.txt)
-        dict(key="f1_rel_hgp1600", name="serial_relative: hypergraph-product [[1600,64]] hx (768 x 1600), minimum_sum alpha=0.625, max_iter=30, batch=16384, BSC p=0.02",
-             h=codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)), p=0.02, max_iter=30, method=1, alpha=0.625, batch=16384),
+        # state beyond LDS (61 KB a syndrome + 93 KB of tables): messages, posteriors, priors and per-entry records in global memory, six wavefronts
+        # per compute unit (bp_relative_lds_kernel<..., EXT = 1>, round 6; the per-lane kernel that ran before: 7.0 k syndromes/s, profiles/r6_serial_relative_hgp1600.txt)
+        dict(key="f1_rel_hgp1600", name="serial_relative: hypergraph-product [[1600,64]] hx (768 x 1600), minimum_sum alpha=0.625, max_iter=30, batch=65536, BSC p=0.02",
+             h=codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5)), p=0.02, max_iter=30, method=1, alpha=0.625),
     ]
     for sp in specs:
         B = sp.get("batch", 65536)

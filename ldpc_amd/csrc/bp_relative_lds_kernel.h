@@ -58,13 +58,14 @@ struct RelLdsArgs {
     int32_t levels;                     // 1: the level-parallel sweep (the starting order is a permutation of the bits); 0: bit by bit
     int32_t scratch_in_l;               // 1: most of the sort's and the levels' scratch lives in the syndrome's posterior array (rel_lds_scratch)
     int32_t lds_shared, lds_per_syn, lds_scratch;  // bytes: shared tables of the workgroup / one syndrome's state / one wavefront's sort scratch
-    // EXT = 1 (state beyond LDS, round 6): a syndrome's messages A[nnz] and the per-entry records live in global memory -- A in a slot of
-    // its wavefront (A_g: [workgroups][wavefronts][nnz], L2 / Infinity Cache resident: written and read by that one wavefront), the records as a
-    // read-only table shared by everybody (rec_g: [n][dc], the words the kernel otherwise builds in LDS) -- and LDS keeps posteriors, order,
-    // decisions, syndrome, priors and the sort's scratch: three wavefronts per compute unit on the [[1600,64]] hypergraph-product code
-    // instead of one (min-sum) or none (product-sum)
-    double *A_g;
+    // EXT = 1 (state beyond LDS, round 6): a syndrome's messages A[nnz] and posteriors L[n] live in global memory -- in a slot of its
+    // wavefront (A_g, L2 / Infinity Cache resident: written and read by that one wavefront) -- and so do the read-only tables that were the
+    // bulk of the shared LDS: the per-entry records (rec_g: [n][dc], the words the kernel otherwise builds in LDS), the priors (llr0) and their
+    // edge forms (pform_g).  LDS keeps order, decisions, syndrome, the CSR copy, the log table and the sort's scratch: 23 KB a wavefront on the
+    // [[1600,64]] hypergraph-product code -- five to six wavefronts per compute unit where everything in LDS left one (min-sum) or none (product-sum)
+    double *A_g;                        // [workgroups][wavefronts][nnz + n]: a wavefront's messages, then its posteriors
     const unsigned long long *rec_g;
+    const double *pform_g;              // [n] edge form of the priors (product-sum: tanh(llr0 / 2)); the priors themselves are llr0
     // [n] the order after the FIRST iteration's sort, or nullptr: every row of a call starts from the same order and the first sort's keys are
     // the priors, so its outcome is the same for every row -- worked out once per call (rel_first_order_kernel) instead of once per syndrome
     // (with uniform priors all its keys are equal: the sort whose re-enactment costs most)
@@ -77,13 +78,13 @@ struct RelLdsArgs {
 
 // shared by the workgroup: [prior n f64][edge form of the priors n f64, log table 256 f64: product-sum][rec n dc u64][rstart m + 1 u16][rcol nnz u16][cdeg n u8]
 __host__ __device__ inline size_t rel_lds_shared(int m, int n, int nnz, int dc, bool product_sum, bool ext = false) {
-    size_t b = (size_t)n * 8 + (product_sum ? (size_t)n * 8 + 256 * 8 : 0) + (ext ? 0 : (size_t)n * dc * 8);
+    size_t b = (ext ? 0 : (size_t)n * 8 + (product_sum ? (size_t)n * 8 : 0) + (size_t)n * dc * 8) + (product_sum ? 256 * 8 : 0);
     b += ((size_t)(m + 1) * 2 + (size_t)nnz * 2 + (size_t)n + 15) & ~(size_t)15;
     return (b + 15) & ~(size_t)15;
 }
 // one syndrome: [A nnz f64][L n f64][ord n u16][dbit n u8][sy m u8]
 __host__ __device__ inline size_t rel_lds_per_syndrome(int m, int n, int nnz, int dc, bool ext = false) {
-    size_t b = (ext ? 0 : (size_t)nnz * 8) + (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
+    size_t b = (ext ? 0 : (size_t)nnz * 8 + (size_t)n * 8) + (((size_t)n * 2 + 7) & ~(size_t)7) + (((size_t)n + 7) & ~(size_t)7) + (((size_t)m + 7) & ~(size_t)7);
     (void)dc;
     return (b + 15) & ~(size_t)15;
 }
@@ -117,14 +118,16 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 }
 
 // the sequential restatement (bp_relative_kernel.h: rel_sort) on wave-private LDS arrays, for ONE lane
-struct SeqCtx {
+template <class KP = const l_f64 *>   // KP: where the keys live -- LDS, or (EXT) global memory
+struct SeqCtxT {
     l_u16 *v;
-    const l_f64 *key;
+    KP key;
     __device__ __forceinline__ int get(long i) const { return v[i]; }
     __device__ __forceinline__ void set(long i, int x) const { v[i] = (uint16_t)x; }
     __device__ __forceinline__ bool gt(int a, int b) const { return key[a] > key[b]; }
     __device__ __forceinline__ void swap(long i, long j) const { const int t = get(i); set(i, get(j)); set(j, t); }
 };
+typedef SeqCtxT<> SeqCtx;
 }  // namespace rel_lds
 
 namespace rel_sort {
@@ -274,8 +277,8 @@ constexpr int bitonic_stages(int places) { int m = 0; while ((1 << m) < places) 
 // the same rank.  Returns true (in every lane) and leaves `rank` alone if a key is NaN.
 // With base0 / sorted: the same for the keys [base0, min(n, base0 + 64 E)) alone -- ranks within that chunk -- and the chunk's keys, descending,
 // written to sorted[0 .. its size) (dense_ranks_chunked below).
-template <int E>
-__device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l_u16 *rank, int base0 = 0, l_f64 *sorted = nullptr) {
+template <int E, class KP = const l_f64 *>
+__device__ __forceinline__ bool dense_ranks(KP key, int n, int lane, l_u16 *rank, int base0 = 0, l_f64 *sorted = nullptr) {
     double kk[E];
     int bb[E];
     bool nan = false;
@@ -348,12 +351,13 @@ __device__ __forceinline__ bool dense_ranks(const l_f64 *key, int n, int lane, l
 // into `sorted` -- n doubles of scratch), then a key's rank is its rank at home plus, for every other chunk, the number of that chunk's keys
 // that are greater: the place a binary search for the key stops in the chunk's descending list.  (Counting against all keys one by one --
 // dense_ranks_counting below, what ran until round 6 -- is n^2 / 64 comparisons per lane: 58 % of a wavefront-iteration at n = 1600.)
-__device__ inline bool dense_ranks_chunked(const l_f64 *key, int n, int lane, l_u16 *rank, l_f64 *sorted) {
+template <class KP>
+__device__ inline bool dense_ranks_chunked(KP key, int n, int lane, l_u16 *rank, l_f64 *sorted) {
     bool nan = false;
     for (int j = lane; j < n; j += 64) nan = nan || key[j] != key[j];
     if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
     const int chunks = (n + 511) / 512;
-    for (int c = 0; c < chunks; ++c) (void)dense_ranks<8>(key, n, lane, rank, c * 512, sorted + c * 512);
+    for (int c = 0; c < chunks; ++c) (void)dense_ranks<8, KP>(key, n, lane, rank, c * 512, sorted + c * 512);
     lds_sync();
     for (int b0 = 0; b0 < n; b0 += 256) {  // four keys per lane at a time: their searches are independent chains
         double x[4];
@@ -395,7 +399,8 @@ __device__ inline bool dense_ranks_chunked(const l_f64 *key, int n, int lane, l_
 }
 
 // the same ranks by counting, any n: 64 keys compared per broadcast read, eight keys per lane in registers and every key read once per pass
-__device__ inline bool dense_ranks_counting(const l_f64 *key, int n, int lane, l_u16 *rank) {
+template <class KP>
+__device__ inline bool dense_ranks_counting(KP key, int n, int lane, l_u16 *rank) {
     bool nan = false;
     for (int j = lane; j < n; j += 64) nan = nan || key[j] != key[j];
     if (__builtin_amdgcn_ballot_w64(nan) != 0) return true;
@@ -433,7 +438,8 @@ struct PackedCtx {  // rel_sort's routines on packed words
 // std::sort(ord, ord + n, [](a, b) { return key[a] > key[b]; }) by one wavefront.  Scratch (wave-private LDS): v / tmp u32 [n],
 // posL / posR / rank u16 [n], list u16 [n + 1], runs u8 [n] (tmp may share the room of posL + posR; list that of rank).  A word
 // of v: (rank of the bit's key << 16) | bit; "x comes before y" (key x > key y) is "rank x < rank y".
-__device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int lane, l_u32 *v, l_u32 *tmp, l_u16 *posL, l_u16 *posR, l_u16 *rank,
+template <class KP>
+__device__ inline void sort_desc_wave(l_u16 *ord, KP key, int n, int lane, l_u32 *v, l_u32 *tmp, l_u16 *posL, l_u16 *posR, l_u16 *rank,
                                       l_u16 *list, l_u8 *runs, unsigned long long *pfs) {
     if (n <= 1) return;
     unsigned long long pfs_t = pfs ? __builtin_readcyclecounter() : 0;
@@ -443,10 +449,10 @@ __device__ inline void sort_desc_wave(l_u16 *ord, const l_f64 *key, int n, int l
     // (n > 512: v and tmp -- 8 n bytes next to each other when the scratch is not housed in the posterior array, which it never is beyond 512
     // bits -- are not yet in use and take the chunks' sorted keys)
     const bool chunked = n > 512 && (l_u8 *)tmp == (l_u8 *)v + (size_t)n * 4 && (n & 1) == 0;
-    const bool nan = n <= 256 ? dense_ranks<4>(key, n, lane, rank) : n <= 512 ? dense_ranks<8>(key, n, lane, rank)
-                     : chunked ? dense_ranks_chunked(key, n, lane, rank, (l_f64 *)v) : dense_ranks_counting(key, n, lane, rank);
+    const bool nan = n <= 256 ? dense_ranks<4, KP>(key, n, lane, rank) : n <= 512 ? dense_ranks<8, KP>(key, n, lane, rank)
+                     : chunked ? dense_ranks_chunked<KP>(key, n, lane, rank, (l_f64 *)v) : dense_ranks_counting<KP>(key, n, lane, rank);
     if (nan) {
-        if (lane == 0) { SeqCtx cx{ord, key}; rel_sort::sort_desc_seq(cx, n, reinterpret_cast<l_u16 *>(v)); }  // (v: 4 n bytes, not yet in use; the stack needs 6 (2 log2 n + 2) for n > 16, 6 below)
+        if (lane == 0) { SeqCtxT<KP> cx{ord, key}; rel_sort::sort_desc_seq(cx, n, reinterpret_cast<l_u16 *>(v)); }  // (v: 4 n bytes, not yet in use; the stack needs 6 (2 log2 n + 2) for n > 16, 6 below)
         lds_sync();
         return;
     }
@@ -686,7 +692,8 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
     using namespace rel_lds;
     constexpr int G = 64 / GS;
     static_assert(!EXT || GS == 64, "state in global memory: a wavefront per syndrome");
-    typedef typename std::conditional<EXT != 0, double, l_f64>::type a_f64;                            // where the messages live
+    typedef typename std::conditional<EXT != 0, double, l_f64>::type a_f64;                            // where the messages and posteriors live
+    typedef typename std::conditional<EXT != 0, const double, l_f64>::type p_f64;                      // ... and the priors / their edge forms
     typedef typename std::conditional<EXT != 0, const unsigned long long, l_u64>::type rec_u64;       // ... and the records
     // (EXT: a wavefront's stores to A must have completed before its next level's loads -- same wavefront, same L1: a wait, no invalidate)
     auto state_sync = [&]() {
@@ -705,17 +712,19 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
     if (tid == 0) clock_probe_begin(clk_stamp);
     // shared (rel_lds_shared)
     l_u8 *base = (l_u8 *)rl_lds;
-    l_f64 *prior = (l_f64 *)base;
-    l_f64 *pform = prior + n;
-    l_f64 *log_tab_l = pform + (PS ? n : 0);
-    const double *log_tab = reinterpret_cast<const double *>(rl_lds) + (size_t)n + (PS ? (size_t)n : 0);
+    l_f64 *prior_l = (l_f64 *)base;
+    l_f64 *pform_l = prior_l + (EXT ? 0 : n);
+    l_f64 *log_tab_l = pform_l + (PS && !EXT ? n : 0);
+    const double *log_tab = reinterpret_cast<const double *>(rl_lds) + (EXT ? (size_t)0 : (size_t)n + (PS ? (size_t)n : 0));
+    p_f64 *prior, *pform;
+    if constexpr (EXT != 0) { prior = a.llr0; pform = a.pform_g; } else { prior = prior_l; pform = pform_l; }
     l_u64 *rec_l = (l_u64 *)(log_tab_l + (PS ? 256 : 0));   // per (bit, entry of its column): CSR edge | row start << 16 | row weight << 32 | check << 48
     rec_u64 *rec;
     if constexpr (EXT != 0) rec = a.rec_g; else rec = rec_l;
     l_u16 *rstart = (l_u16 *)(rec_l + (EXT ? 0 : (size_t)n * dc));
     l_u16 *rcol = rstart + (m + 1);
     l_u8 *cdeg = (l_u8 *)(rcol + nnz);
-    for (int q = tid; q < n; q += T) { prior[q] = a.llr0[q]; cdeg[q] = a.t_cdeg[q]; }
+    for (int q = tid; q < n; q += T) { if constexpr (EXT == 0) prior_l[q] = a.llr0[q]; cdeg[q] = a.t_cdeg[q]; }
     for (int q = tid; q <= m; q += T) rstart[q] = (uint16_t)a.row_ptr[q];
     for (int q = tid; q < nnz; q += T) rcol[q] = (uint16_t)a.col_idx[q];
     if constexpr (EXT == 0)
@@ -727,8 +736,9 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
     if (PS && MATH == 0)
         for (int q = tid; q < 256; q += T) log_tab_l[q] = ldpc_math::k_log_tab[q];
     __syncthreads();
-    if (PS)
-        for (int q = tid; q < n; q += T) pform[q] = edge_form<METHOD, MATH>(prior[q]);
+    if constexpr (EXT == 0)
+        if (PS)
+            for (int q = tid; q < n; q += T) pform_l[q] = edge_form<METHOD, MATH>(prior_l[q]);
     __syncthreads();
 
     // this lane's syndrome (rel_lds_per_syndrome) and this wavefront's sort scratch (rel_lds_scratch)
@@ -736,16 +746,24 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
     l_u8 *wave_base = base + a.lds_shared + (size_t)wave * ((size_t)G * a.lds_per_syn + a.lds_scratch);
     auto syn_base = [&](int gg) { return wave_base + (size_t)gg * a.lds_per_syn; };
     l_u8 *mine = syn_base(g);
-    a_f64 *A;
-    if constexpr (EXT != 0) A = a.A_g + ((size_t)blockIdx.x * (size_t)(T >> 6) + (size_t)wave) * (size_t)nnz; else A = (l_f64 *)mine;
-    l_f64 *L = (l_f64 *)mine + (EXT ? 0 : nnz);
-    l_u16 *ord = (l_u16 *)(L + n);
+    a_f64 *A, *L;
+    l_u16 *ord;
+    if constexpr (EXT != 0) {
+        A = a.A_g + ((size_t)blockIdx.x * (size_t)(T >> 6) + (size_t)wave) * ((size_t)nnz + (size_t)n);
+        L = A + nnz;
+        ord = (l_u16 *)mine;
+    } else {
+        A = (l_f64 *)mine;
+        L = A + nnz;
+        ord = (l_u16 *)(L + n);
+    }
     l_u8 *dbit = (l_u8 *)ord + n2;     // hard decisions (a bit the order never visits keeps its 0)
     l_u8 *sy = dbit + n1;
     l_u8 *scr = wave_base + (size_t)G * a.lds_per_syn;
     const bool in_l = a.scratch_in_l != 0;  // (GS = 64 only: `L` is the wavefront's one syndrome's)
     l_u32 *s_v = (l_u32 *)scr;
-    l_u8 *room = in_l ? (l_u8 *)L : scr + (size_t)n * 4;
+    l_u8 *room = scr + (size_t)n * 4;
+    if constexpr (EXT == 0) { if (in_l) room = (l_u8 *)L; }
     l_u32 *s_tmp = (l_u32 *)room;                 // (the partitions' position lists are dead when the final pass fills tmp)
     l_u16 *s_posL = (l_u16 *)s_tmp;
     l_u16 *s_posR = s_posL + n;
@@ -803,15 +821,16 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
             for (int gg = 0; gg < G; ++gg) {
                 if (!((runm >> (gg * GS)) & 1ull)) continue;
                 l_u8 *sb = syn_base(gg);
-                l_f64 *Lg = (l_f64 *)sb + (EXT ? 0 : nnz);
+                a_f64 *Lg;
+                l_u16 *og;
+                if constexpr (EXT != 0) { Lg = L; og = ord; } else { Lg = (l_f64 *)sb + nnz; og = (l_u16 *)(Lg + n); }
                 const int itg = __builtin_amdgcn_readlane(it, gg * GS);
                 if (itg == 1 && a.first_order) {
-                    l_u16 *og = (l_u16 *)(Lg + n);
                     for (int t = lane; t < n; t += 64) og[t] = (uint16_t)a.first_order[t];
                     lds_sync();
                     continue;
                 }
-                sort_desc_wave((l_u16 *)(Lg + n), itg != 1 ? Lg : prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, a.prof ? pfs : nullptr);
+                sort_desc_wave<const a_f64 *>(og, itg != 1 ? (const a_f64 *)Lg : (const a_f64 *)prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_list, s_runs, a.prof ? pfs : nullptr);
             }
             RL_MARK(1);
             if (GS == 64 && a.levels) {
@@ -821,7 +840,9 @@ __global__ void __launch_bounds__(EXT ? 512 : LDPC_REL_LB) bp_relative_lds_kerne
                 // shares a check with the bit at t (none: 1) -- and a level's bits go through the update side by side.  The levels depend on
                 // the order, i.e. on this syndrome and this iteration: worked out here, in LDS (the sort's scratch is free again).  On the
                 // d = 21 surface code 25 levels stand for 441 bit steps; the arithmetic per bit is the bit-by-bit walk's.
-                l_u16 *pos = in_l ? (l_u16 *)L : (l_u16 *)scr + n, *level = pos + n, *llist = (l_u16 *)scr;
+                l_u16 *pos = (l_u16 *)scr + n;
+                if constexpr (EXT == 0) { if (in_l) pos = (l_u16 *)L; }
+                l_u16 *level = pos + n, *llist = (l_u16 *)scr;
                 l_u16 *lcnt = in_l ? llist + n + (n & 1) : level + n + (n & 1);  // [n + 2], on a 4-byte boundary: counted with 32-bit atomics, two counts to a word
                 l_u32 *lcnt_w = (l_u32 *)lcnt;
                 auto count_up = [&](int lv) {  // ++lcnt[lv], returns the old count (counts stay below 65536: no carry into the neighbour)
@@ -1092,7 +1113,7 @@ __global__ void __launch_bounds__(64) rel_first_order_kernel(const double *__res
     l_u8 *s_runs = (l_u8 *)s_rank + (((n + 1) * 2 + 7) & ~7);
     for (int t = lane; t < n; t += 64) { prior[t] = llr0[t]; ord[t] = (uint16_t)(order0 ? order0[t] : t); }
     lds_sync();
-    sort_desc_wave(ord, prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_rank, s_runs, nullptr);
+    sort_desc_wave<const l_f64 *>(ord, prior, n, lane, s_v, s_tmp, s_posL, s_posR, s_rank, s_rank, s_runs, nullptr);
     lds_sync();
     for (int t = lane; t < n; t += 64) out[t] = (int32_t)ord[t];
 }

@@ -734,9 +734,17 @@ static int decode_serial_relative_lds(ldpc_hip_bp *h, const uint8_t *synd, int64
     int64_t groups = (batch + (int64_t)waves * Gf - 1) / ((int64_t)waves * Gf);
     if (groups > 256 * (int64_t)groups_per_cu) groups = 256 * (int64_t)groups_per_cu;
     if (ext) {
-        if ((rc = h->rl_ext_A.ensure((size_t)groups * (size_t)waves * (size_t)h->nnz * sizeof(double)))) return rc;
+        if ((rc = h->rl_ext_A.ensure((size_t)groups * (size_t)waves * ((size_t)h->nnz + (size_t)h->n) * sizeof(double)))) return rc;
         a.A_g = (double *)h->rl_ext_A.p;
         a.rec_g = (const unsigned long long *)h->rl_rec.p;
+        if (ps) {  // the edge form of the priors (what the messages start from): a table in global memory here
+            if ((rc = h->d_edge0.ensure(sizeof(double) * (size_t)h->n))) return rc;
+            const dim3 ge((unsigned)((h->n + 255) / 256));
+            if (h->math_mode == LDPC_HIP_MATH_FAST) hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 1>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+            else hipLaunchKernelGGL((serial_edge0_kernel<LDPC_HIP_PRODUCT_SUM, 0>), ge, dim3(256), 0, st, h->d_llr0, h->n, (double *)h->d_edge0.p);
+            HIPCHK(hipGetLastError());
+            a.pform_g = (const double *)h->d_edge0.p;
+        }
     }
     h->accumulated_ms = 0.f;
     h->accumulated_persistent_ms = 0.f;
