@@ -43,3 +43,26 @@ def test_clock_probe_reads_a_plausible_shader_clock(kind):
     idle = eng.clock_probe()
     assert idle[:2] == after[:2], "nothing ran: the counters must not move"
     eng.close()
+
+
+def test_copy_probe_reports_a_plausible_rate_and_checks_its_arguments():
+    """ldpc_hip_bp_copy_probe (bench.py's box normaliser): a bare copy of message segments between the handle's two message arrays."""
+    from ldpc_amd import codes
+    from ldpc_amd._lib import LdpcHipError
+    from ldpc_amd.engine import HipBpEngine
+    h = codes.regular_ldpc_code(1200, 3, 6, seed=2)
+    eng = HipBpEngine(h.indptr, h.indices, 1200, np.full(1200, 0.05), 10, 0, 1.0)
+    ms, rate = eng.copy_probe(512, 30000, passes=2)      # 2 x 7.9 GB, as half of the headline's tiles
+    assert ms > 0 and 1500.0 < rate < 8000.0, (ms, rate)  # (GB/s read + written; the spec's 8 TB/s is the ceiling)
+    ms2, rate2 = eng.copy_probe(8)                         # segments per tile default to the handle's nnz; tiny: latency, any positive rate
+    assert ms2 > 0 and rate2 > 0
+    for bad in ((0, 100, 1), (4, -3, 1), (4, 100, 0), (4, 100, 65)):
+        with pytest.raises((LdpcHipError, ValueError)):
+            eng.copy_probe(*bad)
+    # the decode after a probe is unaffected (the message arrays are scratch between decodes)
+    s = eng.gen_bsc_syndromes(3, 0.05, shot0=0, shots=500, device="cuda:0")
+    a = [x.cpu().numpy() for x in eng.decode_batch(s)]
+    eng.copy_probe(16, 3600)
+    b = [x.cpu().numpy() for x in eng.decode_batch(s)]
+    assert all(np.array_equal(x.view(np.int64) if x.dtype == np.float64 else x, y.view(np.int64) if y.dtype == np.float64 else y) for x, y in zip(a, b))
+    eng.close()
