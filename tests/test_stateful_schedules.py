@@ -349,3 +349,40 @@ def test_soft_mirror_decode_sequence_and_batch(name):
     out = d2.decode_batch(c["soft"])
     assert np.array_equal(out, c["fresh"][0]) and np.array_equal(d2.iter_batch, c["fresh"][2])
     assert bits_equal(d2.log_prob_ratios_batch, c["fresh"][1]) and bits_equal(d2.soft_syndrome_batch, c["fresh"][4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code", ["bb144", "hgp1600"])
+def test_serial_relative_with_nan_keys_on_every_kernel_form(code, oracle_built):
+    """Priors of exactly 0 and 1 give posteriors inf - inf = NaN: the comparator of bp.hpp:472-482 is then no strict weak order and the
+    reference's result is whatever its std::sort's loops happen to do -- the sequential restatement (oracle/: pinned to the host's std::sort
+    on ordered keys) that every kernel form falls back to as soon as a key is NaN.  The on-chip forms -- all in LDS (BB144), messages and
+    posteriors in global memory with the ranks in chunks (hgp1600: n > 512) -- against the per-lane kernel and the checker."""
+    from ldpc_amd import codes
+    from ldpc_amd.engine import HipBpEngine
+    h = {"bb144": codes.bivariate_bicycle_hx, "hgp1600": lambda: codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))}[code]()
+    m, n = h.shape
+    probs = np.full(n, 0.03)
+    probs[5] = 0.0
+    probs[n // 2] = 1.0
+    probs[n - 3] = 0.0
+    B = 300
+    outs = {}
+    for form in ("default", "ext_walk", 0):
+        eng = HipBpEngine(h.indptr, h.indices, n, probs, 6, 0, 1.0)
+        eng.set_schedule("serial_relative")
+        if form == "ext_walk":
+            eng.set_debug_switch("REL_EXT", 1)
+            eng.set_debug_switch("REL_LEVELS", 0)
+        elif form == 0:
+            eng.set_debug_switch("REL_LDS", 0)
+        s = eng.gen_bsc_syndromes(23, 0.03, shot0=0, shots=B, device="cuda:0").cpu().numpy()
+        outs[form] = eng.decode_batch(s) + (eng.schedule_order(),)
+        eng.close()
+    assert np.isnan(outs[0][1]).any()  # (the case is what it says)
+    for form in ("default", "ext_walk"):
+        assert same(outs[form][:4], outs[0][:4]) and np.array_equal(outs[form][4], outs[0][4]), form
+    o = oracle_built.BpOracle(h, error_channel=probs, max_iter=6, bp_method=0)
+    rows = np.r_[0:30, B - 1]
+    want = o.decode_serial_relative_batch(s[rows], fresh=True)
+    assert same(tuple(x[rows] for x in outs[0][:4]), want[:4]) and np.array_equal(outs[0][4], want[4])
