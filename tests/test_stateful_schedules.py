@@ -363,8 +363,9 @@ def test_serial_relative_with_nan_keys_on_every_kernel_form(code, oracle_built):
     h = {"bb144": codes.bivariate_bicycle_hx, "hgp1600": lambda: codes.hypergraph_product_hx(codes.regular_ldpc_code(n=32, dv=3, dc=4, seed=5))}[code]()
     m, n = h.shape
     probs = np.full(n, 0.03)
-    probs[5] = 0.0
-    probs[n // 2] = 1.0
+    row0 = h.indices[h.indptr[0]:h.indptr[1]]  # every bit of check 0 certain, the last one the other way: its posterior is -inf + inf wherever
+    probs[row0[:-1]] = 0.0                      # the syndrome bit is 0 (the check's message to it is +inf)
+    probs[row0[-1]] = 1.0
     probs[n - 3] = 0.0
     B = 300
     outs = {}
