@@ -180,10 +180,13 @@ __device__ __forceinline__ double edge_form(double b2c) {
 
 // One check row held in registers: cur[0..d) are the row's A values in ascending column order.
 // Computes the d check->bit messages (bp.hpp:201-219 / 220-273) and stores them to C[rs + k].
+// Returns the number of message stores it issued (the variable-degree ring's counted wait adds exactly that to its count of
+// vector-memory operations: a store skipped here and not there would end a wait early, bp_stream_kernel.h).
 template <int METHOD, int MATH, int DR, class BUF>
-__device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs, bool neg, int parity0,
+__device__ __forceinline__ int check_row(const double (&cur)[DR], int d, int rs, bool neg, int parity0,
                                           double alpha, const BUF &Ct, int l8, const double *log_tab) {
     double pre[DR];
+    int stores = 0;
     if (METHOD == LDPC_HIP_PRODUCT_SUM) {
         double temp = 1.0;
 #pragma unroll
@@ -194,6 +197,7 @@ __device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs
         for (int k = DR - 1; k >= 0; --k)
             if (k < d) {
                 Ct.st(l8, rs + k, ps_message<MATH>(pre[k] * temp, neg, log_tab));
+                ++stores;
                 temp *= cur[k];
                 LDPC_EDGE_FENCE();
             }
@@ -218,10 +222,12 @@ __device__ __forceinline__ void check_row(const double (&cur)[DR], int d, int rs
                 if (temp < mag) mag = temp;
                 const double signed_alpha = sgn ? -alpha : alpha;  // message_sign * alpha
                 Ct.st(l8, rs + k, mag * signed_alpha);
+                ++stores;
                 const double ab = fabs(cur[k]);
                 if (ab < temp) temp = ab;
             }
     }
+    return stores;
 }
 
 // ---- product-sum check row, libm-exact math: the fast path -------------------------------------------------------
@@ -246,15 +252,16 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) {  // number of set bits
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Returns the number of message stores issued, or -1 when the row does not qualify (nothing stored: the caller takes the generic row).
 template <int DR, class BUF>
-__device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR], int d, int rs, bool neg, const BUF &Ct, int l8,
+__device__ __forceinline__ int check_row_ps_exact_fast(const double (&cur)[DR], int d, int rs, bool neg, const BUF &Ct, int l8,
                                                         const double *log_tab, uint64_t live, double *near_buf) {
-    if (d < 2) return false;  // a weight-1 row: x is the empty product 1.0, q = 2 / 0 (generic path: +inf)
+    if (d < 2) return -1;  // a weight-1 row: x is the empty product 1.0, q = 2 / 0 (generic path: +inf)
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < DR; ++k)
         if (k < d) bad = bad || !(__builtin_fabs(cur[k]) < 1.0);
-    if (__builtin_amdgcn_ballot_w64(bad) & live) return false;
+    if (__builtin_amdgcn_ballot_w64(bad) & live) return -1;
     const int lane = (int)(threadIdx.x & (LDPC_WAVE - 1));
     const bool lane_live = (live >> lane) & 1ull;
     const uint64_t sign = neg ? 0x8000000000000000ull : 0ull;  // message_sign (bp.hpp:213) as a sign-bit flip
@@ -305,20 +312,25 @@ __device__ __forceinline__ bool check_row_ps_exact_fast(const double (&cur)[DR],
                 if ((parked[k] >> lane) & 1ull) out[k] = near_buf[first[k] + lane_rank(parked[k])];
             }
     }
+    int stores = 0;
 #pragma unroll
     for (int k = 0; k < DR; ++k)
-        if (k < d) Ct.st(l8, rs + k, ldpc_math::as_f64(ldpc_math::as_u64(out[k]) ^ sign));
-    return true;
+        if (k < d) {
+            Ct.st(l8, rs + k, ldpc_math::as_f64(ldpc_math::as_u64(out[k]) ^ sign));
+            ++stores;
+        }
+    return stores;
 }
 
-// product-sum rows of the streaming kernels: the fast path where it applies, else the generic row
+// product-sum rows of the streaming kernels: the fast path where it applies, else the generic row; returns the message stores issued
 template <int METHOD, int MATH, int DR, class BUF>
-__device__ __forceinline__ void check_row_live(const double (&cur)[DR], int d, int rs, bool neg, int parity0, double alpha,
+__device__ __forceinline__ int check_row_live(const double (&cur)[DR], int d, int rs, bool neg, int parity0, double alpha,
                                                const BUF &Ct, int l8, const double *log_tab, uint64_t live, double *near_buf) {
     if (METHOD == LDPC_HIP_PRODUCT_SUM && MATH == 0) {
-        if (check_row_ps_exact_fast<DR, BUF>(cur, d, rs, neg, Ct, l8, log_tab, live, near_buf)) return;
+        const int fast = check_row_ps_exact_fast<DR, BUF>(cur, d, rs, neg, Ct, l8, log_tab, live, near_buf);
+        if (fast >= 0) return fast;
     }
-    check_row<METHOD, MATH, DR, BUF>(cur, d, rs, neg, parity0, alpha, Ct, l8, log_tab);
+    return check_row<METHOD, MATH, DR, BUF>(cur, d, rs, neg, parity0, alpha, Ct, l8, log_tab);
 }
 
 // A row heavier than the register bound: two streaming sweeps, exactly the reference's loops.
@@ -361,11 +373,13 @@ __device__ __forceinline__ void check_row_streamed(int d, int rs, bool neg, int 
 }
 
 // One bit column held in registers: c[0..d) are its check->bit messages in ascending row order, e[] the
-// CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored.
+// CSR edge ids.  Posterior (bp.hpp:276-287) returned; bit->check messages (bp.hpp:279 + 311-318) stored; *stores (if asked
+// for) = the number of message stores issued (see check_row).
 template <int METHOD, int MATH, int DC, class BUF>
 __device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&e)[DC], int d, double prior,
-                                             const BUF &At, int l8, bool messages = true) {
+                                             const BUF &At, int l8, bool messages = true, int *stores = nullptr) {
     double pre[DC];
+    if (stores) *stores = 0;
     double temp = prior;
 #pragma unroll
     for (int k = 0; k < DC; ++k)
@@ -377,6 +391,7 @@ __device__ __forceinline__ double bit_column(const double (&c)[DC], const int (&
     for (int k = DC - 1; k >= 0; --k)
         if (k < d) {
             At.st(l8, e[k], edge_form<METHOD, MATH>(pre[k] + s));
+            if (stores) ++*stores;
             s += c[k];
             if (METHOD == LDPC_HIP_PRODUCT_SUM) LDPC_EDGE_FENCE();
         }

@@ -181,8 +181,7 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
                 const int i = c0.y;
                 const bool neg = (sload(nzm + i) >> lane) & 1ull;
                 const int parity = (int)((sload(par + i) >> lane) & 1ull);
-                check_row_live<METHOD, MATH, DR>(cur, d, c0.x, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);
-                ops += (unsigned)d;  // one message store per entry, whichever routine ran
+                ops += (unsigned)check_row_live<METHOD, MATH, DR>(cur, d, c0.x, neg, parity, alpha, Ct, l8, log_tab, ~done, near_buf);  // the stores the routine that ran REPORTS (one per entry)
                 c0 = c1; p0 = p1; m0 = m1;
                 c1 = c2; p1 = p2; m1 = m2;
                 if (ahead > 0) --ahead;
@@ -353,11 +352,12 @@ __global__ void __launch_bounds__(64 * stream_max_waves(DR, RING)) __attribute__
 #pragma unroll
                         for (int k = 0; k < DC; ++k)
                             if (k < dj) e[k] = sload(csc_edge + c0.x + (u2 ? d0 : 0) + k);
-                        const double llr = bit_column<METHOD, MATH, DC>(c[u2], e, dj, sload(llr0 + j), At, l8, sends);
+                        int sent;
+                        const double llr = bit_column<METHOD, MATH, DC>(c[u2], e, dj, sload(llr0 + j), At, l8, sends, &sent);
                         const uint64_t hard = __ballot(llr <= 0);  // bp.hpp:290
                         if (lane == 0) dcur[j] = hard;
                         if ((last || llr_each) && want_llr && lane_live) Lt.st(l8, j, llr);
-                        ops += (unsigned)(sends ? dj : 0) + 1u;  // message stores + the decision word
+                        ops += (unsigned)sent + 1u;  // the message stores bit_column reports + the decision word
                     }
                 }
                 c0 = c1; p0 = p1; m0 = m1;
