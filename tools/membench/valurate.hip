@@ -30,6 +30,13 @@ __global__ void __launch_bounds__(256) rate_kernel(double *out, int iters, doubl
 #define CMP(q) asm volatile("v_cmp_lt_f64 vcc, %0, %1" :: "v"(v[q]), "v"(c) : "vcc");
 #define RCP32(q) { float f_ = (float)q + 1.5f; asm volatile("v_rcp_f32 %0, %0" : "+v"(f_)); asm volatile("" :: "v"(f_)); }
 #define LDEXP(q) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(v[q]));
+// DEPENDENT chains (round 6): every instruction reads the result of the one before it -- what a wavefront that has its SIMD to itself pays
+// per instruction of an exact tanh / log evaluation; two / four chains interleaved
+#define DFMA(q) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[0]) : "v"(c), "v"(d));
+#define DFMA2(q) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[(q) & 1]) : "v"(c), "v"(d));
+#define DFMA4(q) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[(q) & 3]) : "v"(c), "v"(d));
+#define DADD(q) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v[0]) : "v"(c));
+#define DCND(q) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(w[0]) : "v"(wc));
         if (KIND == 0) { REP16(FMA) }
         if (KIND == 1) { REP16(MUL) }
         if (KIND == 2) { REP16(ADD) }
@@ -40,6 +47,11 @@ __global__ void __launch_bounds__(256) rate_kernel(double *out, int iters, doubl
         if (KIND == 7) { REP16(CMP) }
         if (KIND == 8) { REP16(RCP32) }
         if (KIND == 9) { REP16(LDEXP) }
+        if (KIND == 10) { REP16(DFMA) }
+        if (KIND == 11) { REP16(DFMA2) }
+        if (KIND == 12) { REP16(DFMA4) }
+        if (KIND == 13) { REP16(DADD) }
+        if (KIND == 14) { REP16(DCND) }
     }
     double s = 0;
 #pragma unroll
@@ -53,11 +65,14 @@ int main() {
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
-    const char *names[10] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_min_f64", "v_cndmask_b32", "v_cvt_i32_f64", "v_cmp_lt_f64", "v_rcp_f32", "v_ldexp_f64"};
-    void (*kerns[10])(double *, int, double) = {rate_kernel<0>, rate_kernel<1>, rate_kernel<2>, rate_kernel<3>, rate_kernel<4>, rate_kernel<5>, rate_kernel<6>, rate_kernel<7>, rate_kernel<8>, rate_kernel<9>};
+    const char *names[15] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_min_f64", "v_cndmask_b32", "v_cvt_i32_f64", "v_cmp_lt_f64", "v_rcp_f32", "v_ldexp_f64",
+                             "v_fma_f64 dependent chain", "v_fma_f64 two dependent chains interleaved", "v_fma_f64 four dependent chains interleaved",
+                             "v_add_f64 dependent chain", "v_cndmask_b32 dependent chain"};
+    void (*kerns[15])(double *, int, double) = {rate_kernel<0>, rate_kernel<1>, rate_kernel<2>, rate_kernel<3>, rate_kernel<4>, rate_kernel<5>, rate_kernel<6>, rate_kernel<7>, rate_kernel<8>, rate_kernel<9>,
+                                                rate_kernel<10>, rate_kernel<11>, rate_kernel<12>, rate_kernel<13>, rate_kernel<14>};
     const int iters = 20000;
     for (int waves_per_simd : {1, 2, 4}) {
-        for (int k = 0; k < 10; ++k) {
+        for (int k = 0; k < 15; ++k) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CHK(hipEventRecord(e0));
