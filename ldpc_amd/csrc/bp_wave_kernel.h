@@ -337,6 +337,13 @@ struct WavePsArgs {
 };
 
 #define LDPC_PS_NEAR_SLOTS 64  // entries whose log argument is near 1, listed per wavefront and iteration (see check B)
+#ifdef LDPC_WPS_PROF  // measurement build (tools/wave_ps_phases.py): shader cycles of wavefront 0 of every workgroup per phase of an iteration, summed
+// {check A, check B, bit A, bit B + syndrome test, the iteration's closing barrier / flags, set-up of a syndrome + results out, pulls}, iterations, syndromes
+__device__ unsigned long long g_wps_prof[12];
+#define WPS_MARK(k) do { if (wave == 0 && lane == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); wps_pf[k] += now_ - wps_t; wps_t = now_; } } while (0)
+#else
+#define WPS_MARK(k) do { } while (0)
+#endif
 
 __host__ __device__ inline size_t wave_ps_lds_shared(int m, int np, int DR, int DC) {
     size_t b = 256 * 8 + (size_t)(np + 2) * 16 + (size_t)m * DR * 2 + (size_t)np * DC * 2 + (size_t)m;
@@ -424,8 +431,12 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
 
     int pool = (int)((blockIdx.x * (T / 64) + wave) & (WORK_POOLS - 1));  // work_pool_next (bp_device_common.h)
     bool first_turn = true;
+#ifdef LDPC_WPS_PROF
+    unsigned long long wps_pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, wps_t = __builtin_readcyclecounter();
+#endif
     for (;;) {
         int64_t b;
+        WPS_MARK(5);
         if (TEAM && a.mail) {  // resident: wait for the next request (see WavePsArgs::mail)
             if (tid == 0) {
                 const unsigned long long t_idle = (unsigned long long)__builtin_readsteadycounter();
@@ -462,7 +473,11 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
             int b0 = 0, b1 = 0;
             b = work_pool_next(a.next, 0, a.pool_per, 1, (int)a.batch, lane, pool, b0, b1) ? (int64_t)b0 : a.batch;
         }
+        WPS_MARK(6);
         if (b >= a.batch) break;
+#ifdef LDPC_WPS_PROF
+        ++wps_pf[8];
+#endif
         for (int i = tl; i < m; i += TS) sy[i] = a.synd[b * m + i];
         for (int q = tl; q < rm; q += TS) A[q] = pform[col[q]];  // initialise_log_domain_bp (bp.hpp:147-157)
         if (TEAM && tid == 0) { team_unsat[0] = 0; team_unsat[1] = 0; }  // (a syndrome that ran out of iterations leaves its last flag raised)
@@ -478,6 +493,10 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
         bool tame = prior_tame;  // wave-uniform: the tanh values of this iteration's check pass all lie inside (-1, 1)
         do {
             ++it;
+            WPS_MARK(5);
+#ifdef LDPC_WPS_PROF
+            ++wps_pf[7];
+#endif
             // ---- check A (bp.hpp:205-209, 211-212, 217): lane = row, both sweeps; x_k = prefix_k * suffix_k parked at entry k ----
             for (int i0 = wt * 64; i0 < m; i0 += 64 * W) {
                 const int i = i0 + lane;
@@ -494,6 +513,7 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
                 }
             }
             team_sync();
+            WPS_MARK(0);
             // ---- check B (bp.hpp:213-216): lane = entry, one log each, in place ----
             if (LISTED && tame) {
                 int total = 0;
@@ -530,6 +550,7 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
                 }
             }
             team_sync();
+            WPS_MARK(1);
             // ---- bit A (bp.hpp:276-298, 311-318): lane = column, both sweeps; the new bit_to_check values parked at their entries ----
             for (int j0 = wt * 64; j0 < n; j0 += 64 * W) {
                 const int j = j0 + lane;
@@ -549,6 +570,7 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
                 }
             }
             team_sync();
+            WPS_MARK(2);
             // ---- bit B: lane = entry, one tanh each, in place (A holds tanh(bit_to_check / 2), bp.hpp:208) ----
             bool wild = false;
             for (int s0 = wt * 64; s0 < rm; s0 += 64 * W) {
@@ -569,12 +591,14 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
                 unsat |= par != (unsigned)sy[i];
             }
             unsat_any = __ballot(unsat) != 0;
+            WPS_MARK(3);
             if (TEAM) {  // (two flags: iteration it + 1 raises the other one, which nobody has read since iteration it - 1)
                 if (unsat_any && lane == 0) team_unsat[it & 1] = 1;
                 if (tid == 0) team_unsat[(it + 1) & 1] = 0;
                 __syncthreads();
                 unsat_any = team_unsat[it & 1] != 0;
             }
+            WPS_MARK(4);
         } while (unsat_any && it < a.max_iter);
 
         for (int j = tl; j < n; j += TS) {
@@ -596,4 +620,8 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
         team_sync();
     }
     if (threadIdx.x == 0) clock_probe_end(a.clk, clk_stamp);
+#ifdef LDPC_WPS_PROF
+    if (tid == 0)
+        for (int k = 0; k < 9; ++k) atomicAdd(&g_wps_prof[k], wps_pf[k]);
+#endif
 }

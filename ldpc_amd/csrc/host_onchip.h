@@ -303,6 +303,17 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     if (timed) HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->timed = timed;
     HIPCHK(hipGetLastError());
+#ifdef LDPC_WPS_PROF  // measurement build: print and clear the kernel's cycle sums (tools/wave_ps_phases.py)
+    {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        unsigned long long v[12] = {};
+        HIPCHK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wps_prof), sizeof v));
+        fprintf(stderr, "[wps_prof] team %d waves %d groups %lld batch %lld : checkA %llu checkB %llu bitA %llu bitB+synd %llu close %llu setup/out %llu pull %llu iterations %llu syndromes %llu\n",
+                (int)p.team, p.waves, (long long)groups, (long long)batch, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]);
+        unsigned long long z[12] = {};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wps_prof), z, sizeof z));
+    }
+#endif
     return LDPC_HIP_OK;
 }
 
