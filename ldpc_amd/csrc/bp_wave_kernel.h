@@ -40,6 +40,9 @@ struct WaveArgs {
     double *llr;                 // [batch][n] or nullptr
     int32_t *iters;              // [batch] or nullptr
     uint8_t *conv;               // [batch] or nullptr
+    // BP + OSD (host_osd.h): the kernel lists the rows it leaves unconverged itself (any order) and clears their status bytes -- the
+    // launches that did so afterwards cost 4 - 5 us each whatever the batch.  All three nullptr in a plain BP decode.
+    int32_t *osd_list; unsigned *osd_count; uint8_t *osd_status;
     unsigned long long *next;    // WORK_POOLS work counters (work_pool_next, bp_device_common.h; zeroed before launch)
     int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;  // bytes
@@ -288,6 +291,8 @@ __global__ void __launch_bounds__(1024) bp_wave_kernel(const WaveArgs a) {
         if (tl == 0) {
             if (a.iters) a.iters[b] = it;
             if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
+            if (a.osd_status) a.osd_status[b] = 0;
+            if (a.osd_list && unsat_any) a.osd_list[atomicAdd(a.osd_count, 1u)] = (int32_t)b;
         }
         team_sync();
     }
@@ -321,6 +326,7 @@ struct WavePsArgs {
     double *llr;
     int32_t *iters;
     uint8_t *conv;
+    int32_t *osd_list; unsigned *osd_count; uint8_t *osd_status;  // (as WaveArgs)
     unsigned long long *next;    // WORK_POOLS work counters (work_pool_next; zeroed before launch)
     int32_t pool_per;            // syndromes per pool
     int32_t lds_shared, lds_per_wave;
@@ -608,6 +614,8 @@ __global__ void __launch_bounds__(DR > 16 ? 256 : 1024) bp_wave_ps_kernel(const 
         if (tl == 0) {
             if (a.iters) a.iters[b] = it;
             if (a.conv) a.conv[b] = unsat_any ? 0 : 1;
+            if (a.osd_status) a.osd_status[b] = 0;
+            if (a.osd_list && unsat_any) a.osd_list[atomicAdd(a.osd_count, 1u)] = (int32_t)b;
         }
         if (TEAM && a.mail) {  // resident: the results are in the host's memory -- then, and only then, the request counts as served
             __threadfence_system();

@@ -277,7 +277,10 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     // (a team per syndrome and no more syndromes than resident teams -- e.g. ONE decode(): static assignment, no work counter to reset)
     const bool static_teams = p.team && batch <= 256 * (int64_t)p.groups_per_cu;
     if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
-    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
+    // (BP + OSD: the OSD counters sit right behind the work pools -- bposd_device saw to the room -- and share the fill)
+    const bool osd_hook = h->osd_hook.armed && h->osd_hook.count == (unsigned *)((char *)h->counter.p + work_pool_bytes());
+    if (osd_hook && static_teams) HIPCHK(hipMemsetAsync((char *)h->counter.p + work_pool_bytes(), 0, 64, h->stream));
+    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes() + (osd_hook ? 64 : 0), h->stream));
     WavePsArgs a = {};
     a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.np = p.np; a.max_iter = h->max_iter;
@@ -285,6 +288,7 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     a.rdeg = (const uint8_t *)h->wp_rdeg.p; a.col = (const uint16_t *)h->wp_col.p; a.epos = (const uint16_t *)h->wp_epos.p;
     a.llr0 = h->d_llr0;
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    if (osd_hook) { a.osd_list = h->osd_hook.list; a.osd_count = h->osd_hook.count; a.osd_status = h->osd_hook.status; h->osd_hook.done = true; }
     a.next = static_teams ? nullptr : (unsigned long long *)h->counter.p;
     a.clk = h->d_clk;
     a.lds_shared = (int32_t)p.shared; a.lds_per_wave = (int32_t)p.per_wave;
@@ -324,7 +328,10 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     if ((rc = ensure_wave_tables(h, p))) return rc;
     const bool static_teams = p.team && batch <= 256 * (int64_t)p.groups_per_cu;  // (as decode_wave_ps: no work counter for a handful of syndromes)
     if ((rc = h->counter.ensure(work_pool_bytes()))) return rc;
-    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes(), h->stream));
+    // (BP + OSD: the OSD counters sit right behind the work pools -- bposd_device saw to the room -- and share the fill)
+    const bool osd_hook = h->osd_hook.armed && h->osd_hook.count == (unsigned *)((char *)h->counter.p + work_pool_bytes());
+    if (osd_hook && static_teams) HIPCHK(hipMemsetAsync((char *)h->counter.p + work_pool_bytes(), 0, 64, h->stream));
+    if (!static_teams) HIPCHK(hipMemsetAsync(h->counter.p, 0, work_pool_bytes() + (osd_hook ? 64 : 0), h->stream));
     WaveArgs a = {};
     a.pool_per = work_pool_share(batch, 0);
     a.m = h->m; a.n = h->n; a.mp = p.mp; a.np = p.np; a.max_iter = h->max_iter;
@@ -339,6 +346,7 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
         a.prior_g = (const double *)h->w_prior.p;
     }
     a.synd = synd; a.decoding = decoding; a.llr = llr; a.iters = iters; a.conv = conv;
+    if (osd_hook) { a.osd_list = h->osd_hook.list; a.osd_count = h->osd_hook.count; a.osd_status = h->osd_hook.status; h->osd_hook.done = true; }
     a.llr_direct = p.llr_direct ? 1 : 0;
     a.next = static_teams ? nullptr : (unsigned long long *)h->counter.p;
     a.clk = h->d_clk;

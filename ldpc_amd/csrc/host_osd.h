@@ -31,10 +31,8 @@ static int osd_k(ldpc_hip_bp *h) {
 }
 
 // After the OSD kernels: did every OSD output solve its syndrome?  (osd_status_kernel; read back with ldpc_hip_bposd_get_status)
+// (the array was cleared on the way -- by the BP kernel or by osd_collect_kernel; osd0_reg_kernel writes its rows' entries itself and needs no pass)
 static int osd_status_pass(ldpc_hip_bp *h, const OsdArgs &a, int64_t batch) {
-    int rc;
-    if ((rc = h->osd_status.ensure((size_t)(batch ? batch : 1)))) return rc;
-    HIPCHK(hipMemsetAsync(h->osd_status.p, 0, (size_t)batch, h->stream));
     int64_t blocks = batch < 4096 ? batch : 4096;
     hipLaunchKernelGGL(osd_status_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, h->stream, a, (uint8_t *)h->osd_status.p);
     HIPCHK(hipGetLastError());
@@ -52,7 +50,18 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
     if (!llr) { if ((rc = h->osd_llr.ensure(B * n * 8 ? B * n * 8 : 1))) return rc; llr = (double *)h->osd_llr.p; }
     if (!conv) { if ((rc = h->osd_conv.ensure(B ? B : 1))) return rc; conv = (uint8_t *)h->osd_conv.p; }
     h->osd_status_rows = 0;
-    if ((rc = decode_device(h, synd, batch, decoding, llr, iters, conv))) return rc;
+    // The counters of the OSD passes -- {listed, next} of the first at [0..1], of the second (rows outside the image) at [8..9] -- sit behind the
+    // BP kernels' work pools, so that ONE fill serves both, and an on-chip BP kernel lists the rows it leaves unconverged and clears the
+    // status array itself (osd_hook; otherwise osd_collect_kernel does both below): every launch costs 4 - 5 us whatever it does, and at
+    // BASELINE config 5's 8 192 rows the eight small ones around BP and OSD-0 were a tenth of the step.
+    if ((rc = h->counter.ensure(work_pool_bytes() + 64))) return rc;
+    if ((rc = h->osd_list.ensure((B ? B : 1) * sizeof(int32_t)))) return rc;
+    if ((rc = h->osd_status.ensure(B ? B : 1))) return rc;
+    unsigned *const osd_ctr = (unsigned *)((char *)h->counter.p + work_pool_bytes());
+    h->osd_hook = {(int32_t *)h->osd_list.p, osd_ctr, (uint8_t *)h->osd_status.p, !h->on("OSD_COLLECT_AFTER"), false};
+    rc = decode_device(h, synd, batch, decoding, llr, iters, conv);
+    h->osd_hook.armed = false;
+    if (rc) return rc;
     if (h->m == 0 || h->n == 0) return LDPC_HIP_OK;
     OsdArgs a = {};
     a.m = h->m; a.n = h->n; a.words = (h->n + 1 + 63) / 64;
@@ -72,6 +81,7 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
     void (*reg0)(const OsdArgs) = nullptr;
     if (!higher && h->osd_reg && !h->osd_big) {
         if (a.m <= 64 && a.words <= 2) reg0 = osd0_reg_kernel<1, 2>;
+        else if (a.m <= 128 && a.words <= 3) reg0 = osd0_reg_kernel<2, 3>;  // (BB [[144,12,12]]: 72 x 145 bits -- a fourth word would be a quarter more sort and XOR work)
         else if (a.m <= 128 && a.words <= 4) reg0 = osd0_reg_kernel<2, 4>;
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
     }
@@ -122,13 +132,15 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
     const void *fn = reg0 ? (const void *)reg0 : regw ? (const void *)regw : higher ? (const void *)osdw_kernel : (const void *)osd0_kernel;
     if (!big0 && dyn > 48u * 1024u) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     // list the unconverged rows, then persistent wavefronts (as many as LDS lets reside) pull rows from the list
-    if ((rc = h->osd_list.ensure(B * sizeof(int32_t)))) return rc;
-    if ((rc = h->osd_counters.ensure(2 * sizeof(unsigned)))) return rc;
-    HIPCHK(hipMemsetAsync(h->osd_counters.p, 0, 2 * sizeof(unsigned), h->stream));
     a.list = (const int32_t *)h->osd_list.p;
-    a.counters = (unsigned *)h->osd_counters.p;
-    hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
-                       (int32_t *)h->osd_list.p, (unsigned *)h->osd_counters.p);
+    a.counters = osd_ctr;
+    a.status = reg0 ? (uint8_t *)h->osd_status.p : nullptr;
+    if (!h->osd_hook.done) {
+        HIPCHK(hipMemsetAsync(osd_ctr, 0, 64, h->stream));
+        hipLaunchKernelGGL(osd_collect_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, h->stream, conv, batch,
+                           (int32_t *)h->osd_list.p, osd_ctr, (uint8_t *)h->osd_status.p);
+    }
+    h->osd_status_rows = batch;
     // the OSD kernels proper, over the rows of a.list: run once on the caller's syndromes and -- for a rank-deficient H -- once more
     // on the corrected syndromes of the rows that turned out to lie outside the image (osd_exact_kernel.h)
     auto run_osd = [&](OsdArgs a) -> int {
@@ -226,7 +238,7 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
     };
     if ((rc = run_osd(a))) return rc;
     if (big0 && h->h_flag) HIPCHK(hipMemcpyAsync(&h->h_flag[8], a.counters, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));  // rows listed: the next call's guide
-    if ((rc = osd_status_pass(h, a, batch))) return rc;
+    if (!reg0 && (rc = osd_status_pass(h, a, batch))) return rc;
     // Rows whose syndrome lies outside the image of H (status 2; only a rank-deficient H has any): the reference's answer depends on
     // which rows its linked-list elimination made pivot rows.  One workgroup per such row re-enacts that choice and writes the syndrome
     // that keeps exactly those rows (osd_exact_kernel.h); the same OSD kernels then run once more over these rows.  No host round trip:
@@ -244,20 +256,19 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
         if (room) {
             if (slots > cap) slots = cap;
             if (h->osd_fix_synd.ensure(B * (size_t)a.m) || h->osd_fix_list.ensure(B * sizeof(int32_t)) ||
-                h->osd_fix_counters.ensure(2 * sizeof(unsigned)) || h->osd_fix_scratch.ensure((size_t)slots * slot_words * 8)) {
+                h->osd_fix_scratch.ensure((size_t)slots * slot_words * 8)) {
                 (void)hipGetLastError();  // out of memory: not an error of this decode
                 g_last_error.clear();
                 room = false;
             }
         }
         if (room) {
-            HIPCHK(hipMemsetAsync(h->osd_fix_counters.p, 0, 2 * sizeof(unsigned), h->stream));
             OsdExactArgs X = {};
             X.o = a;
             X.status = (const uint8_t *)h->osd_status.p;
             X.corrected = (uint8_t *)h->osd_fix_synd.p;
             X.list2 = (int32_t *)h->osd_fix_list.p;
-            X.counters2 = (unsigned *)h->osd_fix_counters.p;
+            X.counters2 = osd_ctr + 8;
             X.scratch = (uint64_t *)h->osd_fix_scratch.p;
             X.slot_words = (int64_t)slot_words;
             X.hw = (a.n + 63) / 64;
@@ -268,7 +279,8 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
             OsdArgs a2 = a;
             a2.synd = (const uint8_t *)h->osd_fix_synd.p;
             a2.list = (const int32_t *)h->osd_fix_list.p;
-            a2.counters = (unsigned *)h->osd_fix_counters.p;
+            a2.counters = osd_ctr + 8;
+            a2.status = nullptr;  // (these rows keep their 2)
             if ((rc = run_osd(a2))) return rc;
         }
     }

@@ -231,9 +231,12 @@ LDPC_IO_KERNEL void __launch_bounds__(256) iteration_histogram_kernel(const int3
 
 // Rows that need OSD are a few percent of a batch and scattered: list them first, then persistent wavefronts pull rows
 // from the list, so every resident wavefront has work (one wavefront per batch row would leave the chip almost empty).
-LDPC_IO_KERNEL void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restrict__ conv, int64_t batch, int32_t *list, unsigned *counters) {
+// `status` (or nullptr): the OSD status array of the batch, cleared here (0 = BP converged, OSD not run) so that BP + OSD needs no fill of its own.
+LDPC_IO_KERNEL void __launch_bounds__(256) osd_collect_kernel(const uint8_t *__restrict__ conv, int64_t batch, int32_t *list, unsigned *counters,
+                                                              uint8_t *status = nullptr) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool need = b < batch && !conv[b];
+    if (status && b < batch) status[b] = 0;
     const uint64_t mask = __ballot(need);
     if (!mask) return;
     const int lane = threadIdx.x & 63;

@@ -50,6 +50,8 @@ struct OsdArgs {
     const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
     const int32_t *list;   // rows BP left unconverged, any order (osd_collect_kernel)
     unsigned *counters;    // [0] number of entries of `list`, [1] next entry to hand out (both zeroed before the collect)
+    uint8_t *status;       // [batch] or nullptr: osd0_reg_kernel says itself what became of a row (1 solved, 2 outside the image: osd_status_kernel's
+                           // answer, read off the eliminated matrix); nullptr in the second pass over corrected syndromes, whose rows keep their 2
 };
 
 // (osd_collect_kernel -- the list of rows BP left unconverged -- lives in io_kernels.h: the streamed and serial hosts use it too)
@@ -193,6 +195,8 @@ template <int R, int W>
 struct OsdRows {
     uint64_t w[R][W];  // H (bit j = column j); bits >= n stay clear
     uint32_t s[R];     // the syndrome column of [H | s], kept apart so that no step has to index a word by n / 64
+    uint64_t sm[R];    // the same column as wave-uniform lane masks -- the form the steps with SS = true keep up to date INSTEAD of s[]: its
+                       // updates and the early-stop test are then scalar instructions that hang on no vector result (osd0_reg_kernel)
     int32_t pcol[R];   // pivot column carried by the row, -1: none
     uint64_t unp[R];   // wave-uniform: lanes whose row r carries no pivot yet
 };
@@ -218,15 +222,16 @@ __device__ __forceinline__ void osd_load_rows(const OsdArgs &a, int64_t b, int l
 #pragma unroll
         for (int w = 0; w < W; ++w) rows.w[r][w] = (i < m && w < a.words) ? a.packed[(size_t)i * a.words + w] : 0ull;
         rows.s[r] = (i < m && a.synd[b * m + i]) ? 1u : 0u;
+        rows.sm[r] = __ballot(rows.s[r] != 0);
     }
 }
 
 // osd_less as one unsigned compare: numbers ascending (-0.0 == +0.0), NaNs after every number
-__device__ __forceinline__ uint64_t osd_sort_key(double x) {
-    if (x != x) return ~0ull;
-    if (x == 0.0) x = 0.0;  // -0.0 ties with +0.0 (neither a < b nor a > b in the comparator)
-    const uint64_t u = __builtin_bit_cast(uint64_t, x);
-    return (u >> 63) ? ~u : u | (1ull << 63);
+__device__ __forceinline__ uint64_t osd_sort_key(double x) {  // (selects, no branches: a lone wavefront pays for every jump)
+    uint64_t u = __builtin_bit_cast(uint64_t, x);
+    u = x == 0.0 ? 0ull : u;  // -0.0 ties with +0.0 (neither a < b nor a > b in the comparator)
+    const uint64_t k = (u >> 63) ? ~u : u | (1ull << 63);
+    return x != x ? ~0ull : k;
 }
 
 // soft_decision_col_sort (sort.hpp:48-62) with the keys in registers: order[rank of column i] = i
@@ -234,24 +239,56 @@ template <int W, class OrderPtr>
 __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, int lane, OrderPtr order) {
     uint64_t key[W];
     int rk[W];
+    double val[W];
 #pragma unroll
-    for (int q = 0; q < W; ++q) {
+    for (int q = 0; q < W; ++q) {  // (all loads in flight at once: places behind the row read its last entry)
         const int j = q * 64 + lane;
-        key[q] = j < n ? osd_sort_key(llr_row[j]) : ~0ull;
-        rk[q] = 0;
+        val[q] = llr_row[j < n ? j : n - 1];
     }
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-        const int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
-        for (int l = 0; l < cnt; ++l) {
-            const uint64_t kj = osd_readlane64(key[q], l);
-            // column jj sorts before column q2 * 64 + lane: smaller key, ties by index -- and which index is smaller is
-            // known at compile time unless both sit in the same group of 64
+        key[q] = q * 64 + lane < n ? osd_sort_key(val[q]) : ~0ull;
+        rk[q] = 0;
+    }
+    // Every key goes round once (two v_readlane) and every lane counts it against its own keys.  Eight keys per trip, unrolled: a lone
+    // wavefront -- the rows that need OSD are a few hundred, one per SIMD -- pays ~15 cycles for every instruction that waits on the one before
+    // (v_readlane -> SGPR -> compare -> carry), so the loop one key at a time took 240 cycles a key: 44 % of an OSD-0 row on the BB [[144,12,12]] code
+    // (tools/osd_phase_clocks.py --bb --osd0).  Places behind column n - 1 hold the largest key and never count before a real column:
+    // a smaller index only helps among EQUAL keys (NaN columns), and theirs is the larger -- so the trip count may round up to eight.
+    // Up to four groups the places are compile-time constants (64 x W keys of straight-line code, W <= 4: 8 - 40 KB): the lane of a v_readlane
+    // and the mask of the lanes above it are literals then -- 12 instructions a key instead of 29 on the BB code (4 compares, 2 carries,
+    // 2 v_readlane, select + add, and + or).
+    auto one_key = [&](int q, int l) __attribute__((always_inline)) {
+        const uint64_t kj = osd_readlane64(key[q], l);
+        // column q * 64 + l sorts before column q2 * 64 + lane: smaller key, ties by index -- and which index is smaller is
+        // known at compile time unless both sit in the same group of 64, where it is a lane mask
 #pragma unroll
-            for (int q2 = 0; q2 < W; ++q2) {
-                if (q < q2) rk[q2] += kj <= key[q2] ? 1 : 0;
-                else if (q > q2) rk[q2] += kj < key[q2] ? 1 : 0;
-                else rk[q2] += (kj < key[q2] || (kj == key[q2] && l < lane)) ? 1 : 0;
+        for (int q2 = 0; q2 < W; ++q2) {
+            if (q < q2) rk[q2] += kj <= key[q2] ? 1 : 0;
+            else if (q > q2) rk[q2] += kj < key[q2] ? 1 : 0;
+            else {
+                const uint64_t above = l >= 63 ? 0ull : ~0ull << (l + 1);  // lanes whose index is larger than l
+                const uint64_t before = __ballot(kj < key[q2]) | (__ballot(kj <= key[q2]) & above);
+                rk[q2] += __builtin_amdgcn_inverse_ballot_w64(before) ? 1 : 0;
+            }
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
+        cnt = (cnt + 7) & ~7;
+        if constexpr (W <= 4) {
+#pragma unroll
+            for (int l0 = 0; l0 < 64; l0 += 8) {
+                if (l0 < cnt) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) one_key(q, l0 + u);
+                }
+            }
+        } else {
+            for (int l0 = 0; l0 < cnt; l0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) one_key(q, l0 + u);
             }
         }
     }
@@ -264,7 +301,7 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
 // Everything that steers the step is scalar: `has` (which lanes' rows carry the bit) comes out of a compare, the set
 // of unpivoted rows is kept as one 64-bit lane mask per register row, the pivot row is fetched with v_readlane from
 // the right register under a scalar branch, and the XOR runs under the execution mask of the rows that have the bit.
-template <int R, int W, int CW>
+template <int R, int W, int CW, bool SS = false>
 __device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, int c, int lane) {
     uint64_t has[R];
     const uint32_t cb = 1u << (c & 31);
@@ -291,17 +328,19 @@ __device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, int c, int l
         if (p_r == r) {
 #pragma unroll
             for (int w = 0; w < W; ++w) prow[w] = osd_readlane64(rows.w[r][w], p_lane);
-            psy = (uint32_t)__builtin_amdgcn_readlane((int)rows.s[r], p_lane);
+            if (SS) psy = (uint32_t)((rows.sm[r] >> p_lane) & 1ull);
+            else psy = (uint32_t)__builtin_amdgcn_readlane((int)rows.s[r], p_lane);
             rows.unp[r] &= ~(1ull << p_lane);
             rows.pcol[r] = lane == p_lane ? c : rows.pcol[r];
             has[r] &= ~(1ull << p_lane);  // the pivot row keeps its own bit
         }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        if (SS && psy) rows.sm[r] ^= has[r];
         if (__builtin_amdgcn_inverse_ballot_w64(has[r])) {
 #pragma unroll
             for (int w = 0; w < W; ++w) rows.w[r][w] ^= prow[w];
-            rows.s[r] ^= psy;
+            if (!SS) rows.s[r] ^= psy;
         }
     }
     return true;
@@ -310,7 +349,7 @@ __device__ __forceinline__ bool osd_pivot_step(OsdRows<R, W> &rows, int c, int l
 // Greedy elimination over the sorted columns (gf2sparse_linalg.hpp:132-226 / 298-401), rows fully reduced.
 // EARLY_STOP: leave as soon as the syndrome lies in the span of the pivots (fast_solve, :373-383).  Returns the rank reached.
 // The column order is read 64 entries at a time (one per lane) and handed out with v_readlane.
-template <int R, int W, bool EARLY_STOP, class OrderPtr>
+template <int R, int W, bool EARLY_STOP, bool SS = false, class OrderPtr>
 __device__ __forceinline__ int osd_eliminate(OsdRows<R, W> &rows, OrderPtr order, int max_rank, int n, int lane) {
     // max_rank = rank H (the host knows it): once that many pivots exist every unpivoted row is zero, and the columns
     // not visited yet are non-pivot columns whatever they hold
@@ -323,21 +362,21 @@ __device__ __forceinline__ int osd_eliminate(OsdRows<R, W> &rows, OrderPtr order
             const int c = __builtin_amdgcn_readlane(mine, tt);
             const int cw = c >> 6;  // scalar: a scalar branch picks the specialisation
             bool found = false;
-            if (cw == 0) found = osd_pivot_step<R, W, 0>(rows, c, lane);
-            if constexpr (W > 1) { if (cw == 1) found = osd_pivot_step<R, W, 1>(rows, c, lane); }
-            if constexpr (W > 2) { if (cw == 2) found = osd_pivot_step<R, W, 2>(rows, c, lane); }
-            if constexpr (W > 3) { if (cw == 3) found = osd_pivot_step<R, W, 3>(rows, c, lane); }
-            if constexpr (W > 4) { if (cw == 4) found = osd_pivot_step<R, W, 4>(rows, c, lane); }
-            if constexpr (W > 5) { if (cw == 5) found = osd_pivot_step<R, W, 5>(rows, c, lane); }
-            if constexpr (W > 6) { if (cw == 6) found = osd_pivot_step<R, W, 6>(rows, c, lane); }
-            if constexpr (W > 7) { if (cw == 7) found = osd_pivot_step<R, W, 7>(rows, c, lane); }
+            if (cw == 0) found = osd_pivot_step<R, W, 0, SS>(rows, c, lane);
+            if constexpr (W > 1) { if (cw == 1) found = osd_pivot_step<R, W, 1, SS>(rows, c, lane); }
+            if constexpr (W > 2) { if (cw == 2) found = osd_pivot_step<R, W, 2, SS>(rows, c, lane); }
+            if constexpr (W > 3) { if (cw == 3) found = osd_pivot_step<R, W, 3, SS>(rows, c, lane); }
+            if constexpr (W > 4) { if (cw == 4) found = osd_pivot_step<R, W, 4, SS>(rows, c, lane); }
+            if constexpr (W > 5) { if (cw == 5) found = osd_pivot_step<R, W, 5, SS>(rows, c, lane); }
+            if constexpr (W > 6) { if (cw == 6) found = osd_pivot_step<R, W, 6, SS>(rows, c, lane); }
+            if constexpr (W > 7) { if (cw == 7) found = osd_pivot_step<R, W, 7, SS>(rows, c, lane); }
             if (!found) continue;
             ++rank;
             if (EARLY_STOP) {
                 bool pending = false;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    pending |= (__ballot(rows.s[r] != 0) & rows.unp[r]) != 0;
+                    pending |= ((SS ? rows.sm[r] : __ballot(rows.s[r] != 0)) & rows.unp[r]) != 0;
                 if (!pending) { done = true; break; }
             }
         }
@@ -356,18 +395,40 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
     const int n = a.n;
     volatile lds_i32 *order = (volatile lds_i32 *)((__attribute__((address_space(3))) unsigned char *)osd_lds + wave * a.lds_per_wave);  // [n]
     for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
+        OSD_CLK_START();
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
+        OSD_CLK(0);
         osd_sort_columns<W>(a.llr + b * n, n, lane, order);
         __builtin_amdgcn_wave_barrier();
-        osd_eliminate<R, W, true>(rows, order, a.rank, n, lane);
-        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
-        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        OSD_CLK(1);
+        const int rank_reached = osd_eliminate<R, W, true, true>(rows, order, a.rank, n, lane);
+        (void)rank_reached;
+        OSD_CLK(2);
+#ifdef LDPC_HIP_OSD_CLOCKS
+        if (lane == 0) { atomicAdd(&osd_phase_clocks[8], (unsigned long long)rank_reached); atomicAdd(&osd_phase_clocks[9], 1ull); }
+#endif
+        if (a.status) {
+            // H x = s for the x written below <=> no row without a pivot keeps a syndrome bit: the pivot rows are reduced against every pivot
+            // column (x satisfies them by construction), the others have lost all their pivot-column bits and x is zero elsewhere.  The
+            // elimination left either because of exactly that (fast_solve's early stop) or with rank H pivots / every column visited.
+            bool pending = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) pending |= (rows.sm[r] & rows.unp[r]) != 0;
+            if (lane == 0) a.status[b] = pending ? 2 : 1;
+        }
+        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288): put together in
+        // LDS, where the column order lay (a wavefront's LDS instructions execute in the order issued; zeros and ones straight to global
+        // memory needed a release fence in between -- a round trip to L2 -- and left as single bytes), then whole rows leave
+        typedef __attribute__((address_space(3))) uint8_t lds_u8;
+        volatile lds_u8 *xl = (volatile lds_u8 *)order;
+        for (int j = lane; j < n; j += 64) xl[j] = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            if (rows.pcol[r] >= 0 && rows.s[r]) a.decoding[b * n + rows.pcol[r]] = 1;
+            if (rows.pcol[r] >= 0 && __builtin_amdgcn_inverse_ballot_w64(rows.sm[r])) xl[rows.pcol[r]] = 1;
+        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = xl[j];
         __builtin_amdgcn_wave_barrier();
+        OSD_CLK(6);
     }
 }
 

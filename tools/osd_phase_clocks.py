@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--bb", action="store_true")
     ap.add_argument("--hgp1600", action="store_true", help="the [[1600,64]] code of bench_configs.py: workgroup kernel, H in HBM")
+    ap.add_argument("--osd0", action="store_true", help="OSD-0 through osd0_reg_kernel (with --bb and --shots 8192: BASELINE config 5's OSD stage)")
     ap.add_argument("--order", type=int, default=10)
     ap.add_argument("--shots", type=int, default=65536, help="batch size (few rows through OSD = the latency regime: little contention between wavefronts)")
     ap.add_argument("--mask", type=lambda v: int(v, 0), default=0xffff,
@@ -35,8 +36,8 @@ def main():
         DBG = DBG[:-3] + "_%x.so" % args.mask
     if args.build:
         os.makedirs(os.path.dirname(DBG), exist_ok=True)
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ldpc_amd", "csrc"), "OUT=" + DBG,
-                               "FLAGS=-O3 -std=c++17 -ffp-contract=off -fPIC -shared --offload-arch=gfx950 -Wall "
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ldpc_amd", "csrc"), "OUT=" + DBG, "OBJDIR=" + os.path.join(ROOT, "build", "csrc_osd_clocks_%x" % args.mask),
+                               "CFLAGS=-O3 -std=c++17 -ffp-contract=off -fPIC --offload-arch=gfx950 -Wall "
                                "-Wno-unused-function -DLDPC_HIP_OSD_CLOCKS -DLDPC_HIP_OSD_CLOCK_MASK=0x%x" % args.mask])
         return
     import ldpc_amd._lib as lib
@@ -57,7 +58,7 @@ def main():
     n = h.shape[1]
     eng = HipBpEngine(h.indptr, h.indices, n, np.full(n, p), it, method, alpha)
     s = eng.gen_bsc_syndromes(7, p, shot0=0, shots=args.shots, device="cuda:0")
-    eng.set_osd(3, args.order)
+    eng.set_osd(1 if args.osd0 else 3, 0 if args.osd0 else args.order)
     out = eng.decode_batch(s, osd=True)
     torch.cuda.synchronize()
     dll = lib.load()
@@ -75,6 +76,8 @@ def main():
                  "weigh candidates", "elimination: block pivots", "elimination: rest of the update", "update: list of the rows", "update: table build",
                  "update: barrier", "update: items", "update: closing barrier"]
         tot = sum(buf[:14]) - buf[2]
+    if args.osd0:
+        print(f"  (osd0_reg_kernel: phases 0, 1, 2 and 'pick + write' = status + decisions out; pivots per row {buf[8] / max(buf[9], 1):.1f} over {buf[9]} rows)")
     for name, c in zip(names, buf[:16]):
         print(f"  {name:52s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
 
