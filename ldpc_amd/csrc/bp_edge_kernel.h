@@ -111,7 +111,12 @@ __device__ __forceinline__ uint64_t spread_nibble(uint64_t low) {  // bit 0 of e
 
 // UNIFORM: all columns have the same prior (a decoder built from `error_rate`): it is a scalar, which frees 2 R registers per
 // lane -- a fifth resident wavefront per SIMD; the phantom lanes' +inf then comes from their partner slot instead of their prior.
-template <int R, bool UNIFORM>
+// NOCLAMP (with UNIFORM): the clamp to DBL_MAX cannot bite and is left out (one vector instruction of ~19 per round, and the kernel is bound
+// by vector issue).  The host grants it (plan_edge) when the prior is finite, |alpha| <= 1 and every row has at least two entries: then a
+// real lane's minimum always covers a real entry, every message is bounded by (iterations + 1) x |prior| -- |check_to_bit| <= the largest
+// |bit_to_check| of the round, |bit_to_check| <= |prior| + |check_to_bit| of its one partner -- and no infinity or NaN ever reaches a real
+// lane; the phantom lanes' own infinities stay among themselves as before (inf - inf = NaN is not <= 0 either).
+template <int R, bool UNIFORM, bool NOCLAMP = false>
 __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const EdgeArgs a) {
     using namespace edge_detail;
     typedef EdgeArgs ARGS_T;  // (cold fields: LDPC_KERNARG, bp_device_common.h)
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
                 const double x1 = quad_perm<0xB1>(cur);               // lane ^ 1
                 const double pairmin = min_abs(cur, x1);
                 const double other = quad_perm<0x4E>(pairmin);        // the other pair's minimum (lane ^ 2)
-                const double mag = fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
+                const double mag = NOCLAMP ? min_abs(x1, other) : fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
                 int shi;  // high word of +-alpha: sign = row parity (syndrome included) + own
                 if (r < EDGE_V1) {
                     // the vector unit spreads the row's parity: lane 0 of the quad picks it up from the (unspread) scalar mask, a DPP

@@ -59,7 +59,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE", "REPACK2", "OSD_COLLECT_AFTER"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE", "REPACK2", "OSD_COLLECT_AFTER", "EDGE_CLAMP"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {

@@ -383,16 +383,20 @@ static EdgePlan plan_edge(const ldpc_hip_bp *h) {
     std::vector<char> seen((size_t)h->n, 0);  // a column without entries has no lane to write its outputs
     for (int32_t j : h->h_col_idx) seen[(size_t)j] = 1;
     for (char c : seen) if (!c) return p;
-#define LDPC_EDGE_ROW(U) {nullptr, bp_edge_kernel<1, U>, bp_edge_kernel<2, U>, bp_edge_kernel<3, U>, bp_edge_kernel<4, U>, bp_edge_kernel<5, U>, \
-        bp_edge_kernel<6, U>, bp_edge_kernel<7, U>, bp_edge_kernel<8, U>, bp_edge_kernel<9, U>, bp_edge_kernel<10, U>, bp_edge_kernel<11, U>, \
-        bp_edge_kernel<12, U>, bp_edge_kernel<13, U>, bp_edge_kernel<14, U>, bp_edge_kernel<15, U>, bp_edge_kernel<16, U>}
-    static void (*const kerns[2][17])(const EdgeArgs) = {LDPC_EDGE_ROW(false), LDPC_EDGE_ROW(true)};
+#define LDPC_EDGE_ROW(...) {nullptr, bp_edge_kernel<1, __VA_ARGS__>, bp_edge_kernel<2, __VA_ARGS__>, bp_edge_kernel<3, __VA_ARGS__>, bp_edge_kernel<4, __VA_ARGS__>, \
+        bp_edge_kernel<5, __VA_ARGS__>, bp_edge_kernel<6, __VA_ARGS__>, bp_edge_kernel<7, __VA_ARGS__>, bp_edge_kernel<8, __VA_ARGS__>, bp_edge_kernel<9, __VA_ARGS__>, \
+        bp_edge_kernel<10, __VA_ARGS__>, bp_edge_kernel<11, __VA_ARGS__>, bp_edge_kernel<12, __VA_ARGS__>, bp_edge_kernel<13, __VA_ARGS__>, bp_edge_kernel<14, __VA_ARGS__>, \
+        bp_edge_kernel<15, __VA_ARGS__>, bp_edge_kernel<16, __VA_ARGS__>}
+    static void (*const kerns[3][17])(const EdgeArgs) = {LDPC_EDGE_ROW(false), LDPC_EDGE_ROW(true), LDPC_EDGE_ROW(true, true)};
 #undef LDPC_EDGE_ROW
     p.uniform = true;
     for (int j = 1; j < h->n && p.uniform; ++j)
         p.uniform = std::memcmp(&h->channel_probs[(size_t)j], &h->channel_probs[0], sizeof(double)) == 0;
     p.rounds = rounds;
-    p.kern = kerns[p.uniform ? 1 : 0][rounds];
+    // the form without the clamp to DBL_MAX (bp_edge_kernel.h, NOCLAMP): finite prior, |alpha| <= 1 (0 = the adaptive 1 - 2^-it), rows of two or more
+    bool noclamp = p.uniform && std::isfinite(std::log((1 - h->channel_probs[0]) / h->channel_probs[0])) && std::fabs(h->ms_scaling_factor) <= 1.0 && !h->on("EDGE_CLAMP");
+    for (int i = 0; i < h->m && noclamp; ++i) noclamp = h->h_row_ptr[(size_t)i + 1] - h->h_row_ptr[(size_t)i] >= 2;
+    p.kern = kerns[p.uniform ? (noclamp ? 2 : 1) : 0][rounds];
     return p;
 }
 
