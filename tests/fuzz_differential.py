@@ -50,18 +50,26 @@ def run(seconds=120.0, seed=1, max_cases=None):
                 assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), tag
                 assert oracle.bits_equal(got[1], want[1]), "llr " + tag
         # OSD through the workgroup kernel and the automatic choice (rows outside the image included: the exact second pass)
-        s2 = np.asarray((h @ e.T % 2).T, dtype=np.uint8)[:min(B, 24)].copy()
+        s2 = np.asarray((h @ e.T % 2).T, dtype=np.uint8)[:min(B, 24 if rng.random() < 0.7 else 600)].copy()  # (beyond the resident teams: the BP kernel's own list of rows for OSD)
         s2[0, int(rng.integers(0, m))] ^= 1  # (outside the image where H is rank-deficient: every (2,4) and (4,8) code)
         meth, order = [(1, 0), (3, int(rng.integers(1, 12))), (2, int(rng.integers(1, 8)))][int(rng.integers(0, 3))]
         wo = o.bposd_decode_batch(s2, meth, order, want_llr=False)
         eng.set_small_code_kernel(-1)
         eng.set_osd(meth, order)
-        for kern, sw in ((2, ()), (2, (("OSD_UNBLOCKED", 1),)), (2, (("OSD_PLANES", 1),)), (-1, ())):
+        hd = h.toarray().astype(np.int64)
+        for kern, sw in ((2, ()), (2, (("OSD_UNBLOCKED", 1),)), (2, (("OSD_PLANES", 1),)), (-1, ()), (-1, (("OSD_COLLECT_AFTER", 1),))):
             eng.set_osd_kernel(kern)
             for k, v in sw: eng.set_debug_switch(k, v)
             g = eng.decode_batch(s2, want_llr=False, osd=True)
+            st = eng.osd_status(len(s2))
             for k, v in sw: eng.set_debug_switch(k, -1)
-            assert np.array_equal(g[0], wo[0]), f"osd n={n} dv={dv} {method} method={meth} order={order} kern={kern} switches={sw}"
+            tag = f"osd n={n} dv={dv} {method} method={meth} order={order} rows={len(s2)} kern={kern} switches={sw}"
+            assert np.array_equal(g[0], wo[0]), tag
+            # the status array (round 6: written by the BP kernel / the register OSD-0 kernel themselves): 0 = BP converged, 1 = the returned x
+            # solves H x = s, 2 = it does not (s outside the image: x solves the reference's pivot rows only)
+            solves = np.all((g[0].astype(np.int64) @ hd.T) % 2 == (s2 != 0), axis=1)
+            want_st = np.where(g[3] != 0, 0, np.where(solves, 1, 2)).astype(np.uint8)
+            assert np.array_equal(st, want_st), "status " + tag
         n_ok += 1
     return n_ok
 
