@@ -90,6 +90,7 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
         a.kwords = (osd_k(h) + 63) / 64;
         if (a.kwords < 1) a.kwords = 1;
         if (a.m <= 64 && a.words <= 2) regw = osdw_reg_kernel<1, 2>;
+        else if (a.m <= 128 && a.words <= 3) regw = osdw_reg_kernel<2, 3>;
         else if (a.m <= 128 && a.words <= 4) regw = osdw_reg_kernel<2, 4>;
         else regw = osdw_reg_kernel<4, 8>;
     }

@@ -235,29 +235,33 @@ __device__ __forceinline__ uint64_t osd_sort_key(double x) {  // (selects, no br
 }
 
 // soft_decision_col_sort (sort.hpp:48-62) with the keys in registers: order[rank of column i] = i
-template <int W, class OrderPtr>
+template <int W, bool FLAT = false, class OrderPtr>
 __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, int lane, OrderPtr order) {
     uint64_t key[W];
     int rk[W];
-    double val[W];
+    if constexpr (FLAT) {  // all loads in flight at once (places behind the row read its last entry), then the keys
+        double val[W];
 #pragma unroll
-    for (int q = 0; q < W; ++q) {  // (all loads in flight at once: places behind the row read its last entry)
-        const int j = q * 64 + lane;
-        val[q] = llr_row[j < n ? j : n - 1];
+        for (int q = 0; q < W; ++q) {
+            const int j = q * 64 + lane;
+            val[q] = llr_row[j < n ? j : n - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) key[q] = q * 64 + lane < n ? osd_sort_key(val[q]) : ~0ull;
+    } else {  // (hoisting the loads costs osdw_reg_kernel<2, 4> eight registers and with them its fifth wavefront per SIMD: 92 -> 100 VGPRs)
+#pragma unroll
+        for (int q = 0; q < W; ++q) key[q] = q * 64 + lane < n ? osd_sort_key(llr_row[q * 64 + lane]) : ~0ull;
     }
 #pragma unroll
-    for (int q = 0; q < W; ++q) {
-        key[q] = q * 64 + lane < n ? osd_sort_key(val[q]) : ~0ull;
-        rk[q] = 0;
-    }
-    // Every key goes round once (two v_readlane) and every lane counts it against its own keys.  Eight keys per trip, unrolled: a lone
-    // wavefront -- the rows that need OSD are a few hundred, one per SIMD -- pays ~15 cycles for every instruction that waits on the one before
-    // (v_readlane -> SGPR -> compare -> carry), so the loop one key at a time took 240 cycles a key: 44 % of an OSD-0 row on the BB [[144,12,12]] code
-    // (tools/osd_phase_clocks.py --bb --osd0).  Places behind column n - 1 hold the largest key and never count before a real column:
-    // a smaller index only helps among EQUAL keys (NaN columns), and theirs is the larger -- so the trip count may round up to eight.
-    // Up to four groups the places are compile-time constants (64 x W keys of straight-line code, W <= 4: 8 - 40 KB): the lane of a v_readlane
-    // and the mask of the lanes above it are literals then -- 12 instructions a key instead of 29 on the BB code (4 compares, 2 carries,
-    // 2 v_readlane, select + add, and + or).
+    for (int q = 0; q < W; ++q) rk[q] = 0;
+    // Every key goes round once (two v_readlane) and every lane counts it against its own keys.  A lone wavefront -- the rows that need OSD in a
+    // batch of 8 192 are a few hundred, one per SIMD -- issues an instruction every ~8 cycles whatever it depends on, so what counts there is the
+    // number of instructions: the loop one key at a time took 29 a key = 240 cycles, 44 % of an OSD-0 row on the BB [[144,12,12]] code
+    // (tools/osd_phase_clocks.py --bb --osd0).  FLAT (osd0_reg_kernel up to four groups): the places are compile-time constants (64 x W keys
+    // of straight-line code: 8 - 40 KB) -- the lane of a v_readlane and the mask of the lanes above it are literals then: 12 instructions a key
+    // (4 compares, 2 carries, 2 v_readlane, select + add, and + or).  Places behind column n - 1 hold the largest key and never count before
+    // a real column: a smaller index only helps among EQUAL keys (NaN columns), and theirs is the larger -- so FLAT visits whole eights.
+    // Elsewhere (osdw_reg_kernel, eight groups) the loop stays: unrolling it costs registers, and those kernels live on occupancy.
     auto one_key = [&](int q, int l) __attribute__((always_inline)) {
         const uint64_t kj = osd_readlane64(key[q], l);
         // column q * 64 + l sorts before column q2 * 64 + lane: smaller key, ties by index -- and which index is smaller is
@@ -275,9 +279,8 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
     };
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-        int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
-        cnt = (cnt + 7) & ~7;
-        if constexpr (W <= 4) {
+        const int cnt = n - q * 64 < 64 ? n - q * 64 : 64;
+        if constexpr (FLAT) {
 #pragma unroll
             for (int l0 = 0; l0 < 64; l0 += 8) {
                 if (l0 < cnt) {
@@ -286,10 +289,7 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
                 }
             }
         } else {
-            for (int l0 = 0; l0 < cnt; l0 += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) one_key(q, l0 + u);
-            }
+            for (int l = 0; l < cnt; ++l) one_key(q, l);
         }
     }
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
         OsdRows<R, W> rows;
         osd_load_rows<R, W>(a, b, lane, rows);
         OSD_CLK(0);
-        osd_sort_columns<W>(a.llr + b * n, n, lane, order);
+        osd_sort_columns<W, (W <= 4)>(a.llr + b * n, n, lane, order);
         __builtin_amdgcn_wave_barrier();
         OSD_CLK(1);
         const int rank_reached = osd_eliminate<R, W, true, true>(rows, order, a.rank, n, lane);
