@@ -62,6 +62,9 @@ __host__ __device__ inline size_t edge_lds_bytes(int rounds) { return ((size_t)r
 #ifndef EDGE_V1
 #define EDGE_V1 2
 #endif
+#ifndef EDGE_V1N  // ... in the form without the clamp (one vector instruction a round fewer: the balance moves; C3, M syndromes/s, x3 on one box:
+#define EDGE_V1N 8  //     2: 65.7;  3: 66.2;  4: 66.2;  6: 66.7;  8: 66.7;  10: 66.3;  14: 66.3 -- flat from 6 up, profiles/r6_c3_noclamp_ab.txt)
+#endif
 #ifndef EDGE_V2
 #define EDGE_V2 16
 #endif
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(64, UNIFORM ? 5 : 4) bp_edge_kernel(const Edge
                 const double other = quad_perm<0x4E>(pairmin);        // the other pair's minimum (lane ^ 2)
                 const double mag = NOCLAMP ? min_abs(x1, other) : fmin_pos(min_abs(x1, other), dbl_max);  // over the three other entries, from DBL_MAX down
                 int shi;  // high word of +-alpha: sign = row parity (syndrome included) + own
-                if (r < EDGE_V1) {
+                if (r < (NOCLAMP ? EDGE_V1N : EDGE_V1)) {
                     // the vector unit spreads the row's parity: lane 0 of the quad picks it up from the (unspread) scalar mask, a DPP
                     // broadcast inside the quad XORs it onto everyone's own sign -- 2 vector instructions more, 5 scalar ones fewer
                     const uint64_t par = nibble_parity_low(neg ^ sy[r]);
