@@ -392,7 +392,7 @@ int ldpc_hip_bp_set_small_code_kernel(ldpc_hip_bp *h, int32_t mode);
  * per-entry records in global memory (default: where the all-in-LDS form leaves fewer than four wavefronts per compute unit); "REL_FIRST_ONCE" 0 = every syndrome re-enacts the first
  * iteration's sort itself instead of taking the call's (rel_first_order_kernel); "REPACK2" 1 .. 3 = the two-pass streamed decode compacts a second time, after that many
  * iterations of its second pass, 4 = where the iteration histogram suggests it (default: never -- measured no gain); "OSD_COLLECT_AFTER" 1 = BP + OSD lists the
- * rows BP left unconverged in a launch of its own after the BP kernel instead of inside the on-chip BP kernels; "EDGE_CLAMP" 1 = the lane = edge min-sum kernel always
+ * rows BP left unconverged in a launch of its own after the BP kernel instead of inside the on-chip BP kernels; "OSD_NO_FLAT" 1 = OSD-0 on small matrices without the column permutation (osd0_reg_kernel instead of osd0_flat_kernel); "EDGE_CLAMP" 1 = the lane = edge min-sum kernel always
  * with its clamp to DBL_MAX (default: left out where it provably never bites)).  A handle reads the environment variables LDPC_HIP_<NAME> ONCE, when it is
  * created; afterwards only this call changes a switch (value < 0: back to "not set").  Unknown names are an error. */
 int ldpc_hip_bp_set_debug_switch(ldpc_hip_bp *h, const char *name, int32_t value);

@@ -59,7 +59,7 @@ struct DeviceBuf {  // grow-only device allocation
 // creation, from the environment variables LDPC_HIP_<NAME>, changed afterwards only through ldpc_hip_bp_set_debug_switch -- no
 // getenv on the decode path, and nothing a test can change under a live handle by accident.
 static const char *const k_switch_names[] = {"TEAM_WAVES", "TEAM_PRIOR_LDS", "PS_TEAM", "EXPLICIT_INIT", "DEBUG_HANDOFF",
-                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE", "REPACK2", "OSD_COLLECT_AFTER", "EDGE_CLAMP"};
+                                             "OSD_UNBLOCKED", "OSD_PLANES", "OSD_PER_CU", "OSD_NO_EXACT", "NO_PINNED_PATH", "KEEP_LAST_MESSAGES", "PS_TEAM_WAVES", "EDGE_STATIC_PCT", "EDGE_CHUNK", "NO_HOST_PIPELINE", "NO_DIRECT_LLR", "HOST_CHUNK_ROWS", "TIME_SMALL_CALLS", "REL_LDS", "HOST_PIPE_TIMING", "REL_LEVELS", "REL_PROF", "REL_SCRATCH_IN_L", "SER_RING", "SER_WAVES", "SER_LANE_MAX", "SER_LANE_THREADS", "SER_WAVES2", "RESIDENT", "RESIDENT_LINGER_US", "NO_SPREAD_COMPACT", "HOST_TAPER", "FLOOD_LANES", "FLOOD_LANE_GROUPS", "SER_NO_REMAINDER", "SER_ROUND_TILES", "VAR_RING", "VAR_RING_UNITS", "SPREAD_NODES", "SPREAD_NODES2", "SER_VAR", "SER_VAR_UNITS", "REL_EXT", "REL_FIRST_ONCE", "REPACK2", "OSD_COLLECT_AFTER", "EDGE_CLAMP", "OSD_NO_FLAT"};
 constexpr int k_n_switches = (int)(sizeof(k_switch_names) / sizeof(k_switch_names[0]));
 
 struct ldpc_hip_bp {
@@ -195,6 +195,7 @@ struct ldpc_hip_bp {
     DeviceBuf osd_llr, osd_conv;                                    // BP outputs OSD-0 needs when the caller does not ask for them
     DeviceBuf osd_scratch;                                          // working copies of H for osd0_big_kernel
     DeviceBuf osd_packed;                                           // [m][words] H bit-packed by rows (register OSD kernels)
+    DeviceBuf osd_ell;                                              // [m][8] a row's entries as 16-bit column numbers (osd0_flat_kernel)
     DeviceBuf osd_list, osd_counters;                               // rows BP left unconverged + {count, next}
     DeviceBuf osd_status;                                           // [batch] of the last BP + OSD decode: 0 BP converged, 1 OSD solved, 2 s outside image(H)
     DeviceBuf osd_fix_synd, osd_fix_list, osd_fix_counters, osd_fix_scratch;  // second OSD pass over the rows outside the image (osd_exact_kernel.h)

@@ -85,6 +85,28 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
         else if (a.m <= 128 && a.words <= 4) reg0 = osd0_reg_kernel<2, 4>;
         else if (a.m <= 256 && a.words <= 8) reg0 = osd0_reg_kernel<4, 8>;
     }
+    // ... and with the columns permuted into their sorted order where the matrix allows (osd0_flat_kernel: m <= 128, n <= 256, rows of up to
+    // eight entries): half the instructions per pivot, and a small batch's OSD stage lasts as long as its slowest row
+    int flat_r = 0, flat_d = 0;
+    if (reg0 && a.m <= 128 && a.n <= 256 && h->max_row_deg <= 8 && !h->on("OSD_NO_FLAT")) {
+        static void (*const flat[2][4])(const OsdArgs) = {{osd0_flat_kernel<1, 2>, osd0_flat_kernel<1, 3>, osd0_flat_kernel<1, 5>, osd0_flat_kernel<1, 8>},
+                                                          {osd0_flat_kernel<2, 2>, osd0_flat_kernel<2, 3>, osd0_flat_kernel<2, 5>, osd0_flat_kernel<2, 8>}};
+        static const int flat_ds[4] = {2, 3, 5, 8};
+        const int need = (a.n + 31) / 32;
+        int q = 0;
+        while (flat_ds[q] < need) ++q;
+        flat_r = a.m <= 64 ? 1 : 2;
+        flat_d = flat_ds[q];
+        reg0 = flat[flat_r - 1][q];
+        if (!h->osd_ell.p) {  // a row's entries as eight 16-bit column numbers, once per handle
+            std::vector<uint16_t> ell((size_t)a.m * 8, (uint16_t)0xffff);
+            for (int i = 0; i < a.m; ++i)
+                for (int e = h->h_row_ptr[(size_t)i], k = 0; e < h->h_row_ptr[(size_t)i + 1]; ++e, ++k) ell[(size_t)i * 8 + (size_t)k] = (uint16_t)h->h_col_idx[(size_t)e];
+            if ((rc = h->osd_ell.ensure(ell.size() * 2))) return rc;
+            HIPCHK(hipMemcpy(h->osd_ell.p, ell.data(), ell.size() * 2, hipMemcpyHostToDevice));
+        }
+        a.ell = (const uint16_t *)h->osd_ell.p;
+    }
     void (*regw)(const OsdArgs) = nullptr;
     if (higher && h->osd_reg && !h->osd_big && a.m <= 256 && a.words <= 8) {
         a.kwords = (osd_k(h) + 63) / 64;
@@ -94,7 +116,8 @@ int bposd_device(ldpc_hip_bp *h, int osd_method, int osd_order, const uint8_t *s
         else if (a.m <= 128 && a.words <= 4) regw = osdw_reg_kernel<2, 4>;
         else regw = osdw_reg_kernel<4, 8>;
     }
-    size_t per_wave = reg0 ? (size_t)a.n * 4
+    size_t per_wave = flat_r ? osd_flat_lds_bytes(a.n, flat_r, flat_d)
+                    : reg0 ? (size_t)a.n * 4
                     : regw ? (size_t)a.n * (8 * ((size_t)a.kwords + 2) + 4 + 4) + 64 * (size_t)a.kwords * 4
                     : higher ? (size_t)a.m * a.words * 8 + (size_t)a.m * 8 + (size_t)a.n * 8 + 3 * (size_t)a.n * 4 + (size_t)a.m * 4
                              : (size_t)a.m * a.words * 8 + (size_t)a.n * 8 + (size_t)a.n * 4 + (size_t)a.m * 4 + (size_t)a.n;

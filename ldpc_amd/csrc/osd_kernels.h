@@ -50,6 +50,7 @@ struct OsdArgs {
     const double *wt;      // [n] log(1 / p_j): the weight of bit j in a candidate (osd.hpp:134, 173)
     const int32_t *list;   // rows BP left unconverged, any order (osd_collect_kernel)
     unsigned *counters;    // [0] number of entries of `list`, [1] next entry to hand out (both zeroed before the collect)
+    const uint16_t *ell;   // osd0_flat_kernel: [m][8] the columns of a row's entries, 0xffff behind them (rows of up to eight entries)
     uint8_t *status;       // [batch] or nullptr: osd0_reg_kernel says itself what became of a row (1 solved, 2 outside the image: osd_status_kernel's
                            // answer, read off the eliminated matrix); nullptr in the second pass over corrected syndromes, whose rows keep their 2
 };
@@ -235,8 +236,9 @@ __device__ __forceinline__ uint64_t osd_sort_key(double x) {  // (selects, no br
 }
 
 // soft_decision_col_sort (sort.hpp:48-62) with the keys in registers: order[rank of column i] = i
-template <int W, bool FLAT = false, class OrderPtr>
-__device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, int lane, OrderPtr order) {
+struct OsdNoRanks {};  // (osd_sort_columns without the inverse of the order)
+template <int W, bool FLAT = false, class OrderPtr, class RankPtr = OsdNoRanks>
+__device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, int lane, OrderPtr order, RankPtr rankv = RankPtr()) {
     uint64_t key[W];
     int rk[W];
     if constexpr (FLAT) {  // all loads in flight at once (places behind the row read its last entry), then the keys
@@ -294,7 +296,10 @@ __device__ __forceinline__ void osd_sort_columns(const double *llr_row, int n, i
     }
 #pragma unroll
     for (int q = 0; q < W; ++q)
-        if (q * 64 + lane < n) order[rk[q]] = q * 64 + lane;
+        if (q * 64 + lane < n) {
+            order[rk[q]] = q * 64 + lane;
+            if constexpr (!__is_same(RankPtr, OsdNoRanks)) rankv[q * 64 + lane] = (uint16_t)rk[q];
+        }
 }
 
 // One pivot step for column c, whose bit lives in word CW (compile-time) of a row; false: no unpivoted row has the bit.
@@ -426,6 +431,151 @@ __global__ void __launch_bounds__(256) osd0_reg_kernel(const OsdArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (rows.pcol[r] >= 0 && __builtin_amdgcn_inverse_ballot_w64(rows.sm[r])) xl[rows.pcol[r]] = 1;
+        for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = xl[j];
+        __builtin_amdgcn_wave_barrier();
+        OSD_CLK(6);
+    }
+}
+
+// ---- OSD-0 for small matrices with the COLUMNS PERMUTED into their sorted order (round 6) -----------------------------------------
+// What osd0_reg_kernel pays per pivot is ~100 instructions and a dozen jumps, most of them because the column it visits sits in a
+// word and a half-word only known at run time (a scalar branch per word, another per half, the pivot row fetched whole) -- and a lone
+// wavefront (a batch of 8 192 leaves a few hundred rows for OSD: one per SIMD) issues an instruction every ~8 cycles whatever it depends
+// on, so the kernel ends with its slowest row: up to rank H pivots.  Here the matrix is BUILT with column t = the t-th column of the
+// order: a row's entries come as eight 16-bit column numbers (OsdArgs::ell, one 16-byte load), each is looked up in the inverse of the
+// order (the ranks the sort produces anyway) and ORed into the row's bits in LDS; the rows then live in registers as D dwords with the
+// visit running over dword d = 0 .. D - 1 (compile-time) and bit b (a scalar shift).  A step is two compares per register row, the
+// scalar pivot search, the pivot row's REMAINING dwords d .. D - 1 (earlier columns are never looked at again), XORs under the mask of
+// the rows that have the bit; the syndrome column and the rows without a pivot are scalar lane masks as in osd0_reg_kernel: ~75
+// instructions, half a dozen jumps.  Same pivots as osd0_reg_kernel (first row without a pivot, ascending, that has the bit), same x,
+// same status.  m <= 64 R (R <= 2), n <= 32 D, rows of at most eight entries.
+__host__ __device__ inline size_t osd_flat_lds_bytes(int n, int R, int D) {
+    const size_t n4 = ((size_t)n + 3) & ~(size_t)3;
+    return ((n4 * 4 + n4 * 2 + n4 + (size_t)64 * R * (D | 1) * 4) + 15) & ~(size_t)15;  // order, ranks, x, the rows (odd stride: no bank conflicts)
+}
+
+template <int R, int D>
+__global__ void __launch_bounds__(256) osd0_flat_kernel(const OsdArgs a) {
+    static_assert(R >= 1 && R <= 2 && D >= 1 && D <= 8, "up to 128 rows, 256 columns");
+    constexpr int W = (D + 1) / 2;  // groups of 64 columns in the sort
+    constexpr int DS = D | 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char osd_lds[];
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = a.n, m = a.m;
+    const int n4 = (n + 3) & ~3;
+    auto base = (__attribute__((address_space(3))) unsigned char *)osd_lds + wave * a.lds_per_wave;
+    volatile lds_i32 *order = (volatile lds_i32 *)base;                    // [n] column with rank t
+    volatile lds_u16 *rankv = (volatile lds_u16 *)(base + n4 * 4);         // [n] rank of column j
+    volatile lds_u8 *xl = (volatile lds_u8 *)(base + n4 * 6);              // [n] the solution, before it leaves
+    volatile lds_u32 *P = (volatile lds_u32 *)(base + n4 * 7);             // [64 R][DS] the rows, columns in sorted order
+    for (int64_t b = osd_first_row(a, OSD_WAVE_WORKER()); b >= 0; b = osd_next_row(a, lane, OSD_WAVE_WORKERS())) {
+        OSD_CLK_START();
+        uint64_t sm[R], unp[R];  // wave-uniform: rows whose (reduced) syndrome bit is set / that carry no pivot yet
+        uint4 ell[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = r * 64 + lane;
+            sm[r] = __ballot(i < m && a.synd[b * m + i] != 0);  // (a non-zero byte is a one, gf2sparse_linalg.hpp:309)
+            unp[r] = ~0ull;                                      // (rows >= m are empty: never candidates)
+            ell[r] = i < m ? reinterpret_cast<const uint4 *>(a.ell)[i] : make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) P[(r * 64 + lane) * DS + dd] = 0;
+        }
+        OSD_CLK(0);
+        osd_sort_columns<W, true>(a.llr + b * n, n, lane, order, rankv);
+        __builtin_amdgcn_wave_barrier();
+        OSD_CLK(1);
+        // the rows with their columns in sorted order: bit t of a row = its entry in the column of rank t
+        // (a wavefront's LDS instructions execute in the order issued: the ranks are there, the zeros are there)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t e4[4] = {ell[r].x, ell[r].y, ell[r].z, ell[r].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t c = (e4[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                if (c != 0xffffu) {
+                    const uint32_t t = rankv[c];
+                    __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)&P[(r * 64 + lane) * DS + (t >> 5)], 1u << (t & 31), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t w[R][D];
+        int pc[R];  // sorted position of the pivot column the row carries, -1: none
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            pc[r] = -1;
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) w[r][dd] = P[(r * 64 + lane) * DS + dd];
+        }
+        OSD_CLK(3);
+        // greedy elimination over the sorted columns (gf2sparse_linalg.hpp:298-401): stops with rank H pivots, or as soon as the syndrome
+        // lies in the span of the pivots (fast_solve, :373-383)
+        int rank = 0;
+        bool done = a.rank <= 0 || ((sm[0] & unp[0]) | (R > 1 ? sm[R - 1] & unp[R - 1] : 0ull)) == 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int nb = n - 32 * d < 32 ? n - 32 * d : 32;
+            for (int bit = 0; bit < nb && !done; ++bit) {
+                const uint32_t mask = 1u << bit;
+                uint64_t has[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) has[r] = __ballot((w[r][d] & mask) != 0);
+                const uint64_t c0 = has[0] & unp[0], c1 = R > 1 ? has[R - 1] & unp[R - 1] : 0ull;
+                if ((c0 | c1) == 0) continue;
+                uint32_t prow[D];
+                uint32_t psy;
+                const int t = 32 * d + bit;
+                // (written out per register row that can carry the pivot with everything behind it, the two cases cost 20 register moves to join
+                // again: the common tail below with its scalar selects is the shorter form -- ~75 instructions a pivot)
+                if (R == 1 || c0 != 0) {
+                    const int p = __builtin_ctzll(c0);
+#pragma unroll
+                    for (int dd = d; dd < D; ++dd) prow[dd] = (uint32_t)__builtin_amdgcn_readlane((int)w[0][dd], p);
+                    psy = (uint32_t)((sm[0] >> p) & 1ull);
+                    unp[0] &= ~(1ull << p);
+                    has[0] &= ~(1ull << p);  // the pivot row keeps its own bit
+                    pc[0] = lane == p ? t : pc[0];
+                } else {
+                    const int p = __builtin_ctzll(c1);
+#pragma unroll
+                    for (int dd = d; dd < D; ++dd) prow[dd] = (uint32_t)__builtin_amdgcn_readlane((int)w[R - 1][dd], p);
+                    psy = (uint32_t)((sm[R - 1] >> p) & 1ull);
+                    unp[R - 1] &= ~(1ull << p);
+                    has[R - 1] &= ~(1ull << p);
+                    pc[R - 1] = lane == p ? t : pc[R - 1];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (psy) sm[r] ^= has[r];
+                    if (__builtin_amdgcn_inverse_ballot_w64(has[r])) {
+#pragma unroll
+                        for (int dd = d; dd < D; ++dd) w[r][dd] ^= prow[dd];
+                    }
+                }
+                ++rank;
+                done = rank >= a.rank || ((sm[0] & unp[0]) | (R > 1 ? sm[R - 1] & unp[R - 1] : 0ull)) == 0;
+            }
+        }
+        OSD_CLK(2);
+#ifdef LDPC_HIP_OSD_CLOCKS
+        if (lane == 0) { atomicAdd(&osd_phase_clocks[8], (unsigned long long)rank); atomicAdd(&osd_phase_clocks[9], 1ull); }
+#endif
+        if (a.status) {  // (as osd0_reg_kernel: H x = s <=> no row without a pivot keeps a syndrome bit)
+            const bool pending = ((sm[0] & unp[0]) | (R > 1 ? sm[R - 1] & unp[R - 1] : 0ull)) != 0;
+            if (lane == 0) a.status[b] = pending ? 2 : 1;
+        }
+        // x = 0 except on the pivot columns, where it is the reduced syndrome bit of the pivot's row (lu_solve, :237-288)
+        for (int j = lane; j < n; j += 64) xl[j] = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (pc[r] >= 0 && __builtin_amdgcn_inverse_ballot_w64(sm[r])) xl[order[pc[r]]] = 1;
         for (int j = lane; j < n; j += 64) a.decoding[b * n + j] = xl[j];
         __builtin_amdgcn_wave_barrier();
         OSD_CLK(6);

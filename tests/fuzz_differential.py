@@ -57,7 +57,7 @@ def run(seconds=120.0, seed=1, max_cases=None):
         eng.set_small_code_kernel(-1)
         eng.set_osd(meth, order)
         hd = h.toarray().astype(np.int64)
-        for kern, sw in ((2, ()), (2, (("OSD_UNBLOCKED", 1),)), (2, (("OSD_PLANES", 1),)), (-1, ()), (-1, (("OSD_COLLECT_AFTER", 1),))):
+        for kern, sw in ((2, ()), (2, (("OSD_UNBLOCKED", 1),)), (2, (("OSD_PLANES", 1),)), (-1, ()), (-1, (("OSD_COLLECT_AFTER", 1),)), (-1, (("OSD_NO_FLAT", 1),))):
             eng.set_osd_kernel(kern)
             for k, v in sw: eng.set_debug_switch(k, v)
             g = eng.decode_batch(s2, want_llr=False, osd=True)

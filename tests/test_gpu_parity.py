@@ -385,8 +385,18 @@ def test_bposd0_golden_fixture(name):
     assert np.array_equal(chk, c["syndromes"])  # cpp_test/TestOsdDecoder.cpp:9-35
     dec2, _, _, _ = eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)  # library-owned LLR buffer
     assert np.array_equal(dec2, dec)
+    status = eng.osd_status(len(dec))
+    assert np.array_equal(status, np.where(cv, 0, 1)), "0 = BP converged, 1 = OSD solved H x = s (every fixture syndrome lies in the image)"
+    # the register kernel without the column permutation (what matrices beyond 128 x 256 or with rows heavier than eight take), and the
+    # rows listed after the BP kernel instead of by it: same decisions, same status
+    for switch in ("OSD_NO_FLAT", "OSD_COLLECT_AFTER"):
+        eng.set_debug_switch(switch, 1)
+        assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)[0], dec), switch
+        assert np.array_equal(eng.osd_status(len(dec)), status), switch
+        eng.set_debug_switch(switch, -1)
     eng.set_osd_kernel(0)  # the LDS-resident elimination (what larger matrices use)
     assert np.array_equal(eng.decode_batch(c["syndromes"], want_llr=False, osd0=True)[0], dec)
+    assert np.array_equal(eng.osd_status(len(dec)), status)
 
 
 def test_bposd0_config5_batch_and_device_pointers(oracle_built):

@@ -77,7 +77,8 @@ def main():
                  "update: barrier", "update: items", "update: closing barrier"]
         tot = sum(buf[:14]) - buf[2]
     if args.osd0:
-        print(f"  (osd0_reg_kernel: phases 0, 1, 2 and 'pick + write' = status + decisions out; pivots per row {buf[8] / max(buf[9], 1):.1f} over {buf[9]} rows)")
+        print(f"  (osd0_reg_kernel / osd0_flat_kernel: load, sort, eliminate, 'number non-pivot columns' = the rows built with their columns in sorted order (flat kernel), "
+              f"'pick + write' = status + decisions out; pivots per row {buf[8] / max(buf[9], 1):.1f} over {buf[9]} rows)")
     for name, c in zip(names, buf[:16]):
         print(f"  {name:52s} {c / max(rows, 1):10.0f}  {100.0 * c / max(tot, 1):5.1f} %")
 
