@@ -302,9 +302,10 @@ static int decode_wave_ps(ldpc_hip_bp *h, const WavePsPlan &p, const uint8_t *sy
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
     const bool timed = !(h->untimed_call && static_teams);
-    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
-    if (timed) HIPCHK(hipEventRecord(h->ev1, h->stream));
+    // (the timing events ride on the dispatch itself -- hipExtLaunchKernelGGL attaches them to the kernel's own start and completion -- instead of
+    // two hipEventRecord around it: those are a barrier packet each on the stream, 5.8 us of a 0.38 ms step, profiles/r6_c5_step_fusion.txt)
+    if (timed) hipExtLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, h->ev0, h->ev1, 0, a);
+    else hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
     h->timed = timed;
     HIPCHK(hipGetLastError());
 #ifdef LDPC_WPS_PROF  // measurement build: print and clear the kernel's cycle sums (tools/wave_ps_phases.py)
@@ -359,9 +360,10 @@ static int decode_wave(ldpc_hip_bp *h, const WavePlan &p, const uint8_t *synd, i
     if (groups > resident) groups = resident;
     h->accumulated_ms = 0.f;
     const bool timed = !(h->untimed_call && static_teams);
-    if (timed) HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
-    if (timed) HIPCHK(hipEventRecord(h->ev1, h->stream));
+    // (the timing events ride on the dispatch itself -- hipExtLaunchKernelGGL attaches them to the kernel's own start and completion -- instead of
+    // two hipEventRecord around it: those are a barrier packet each on the stream, 5.8 us of a 0.38 ms step, profiles/r6_c5_step_fusion.txt)
+    if (timed) hipExtLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, h->ev0, h->ev1, 0, a);
+    else hipLaunchKernelGGL(p.kern, dim3((unsigned)groups), dim3((unsigned)(p.waves * 64)), (unsigned)dyn, h->stream, a);
     h->timed = timed;
     HIPCHK(hipGetLastError());
     return LDPC_HIP_OK;
